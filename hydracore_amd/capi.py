@@ -1,0 +1,378 @@
+"""ctypes bindings: include/hydra_hip.h (the C-ABI boundary) and the host layer's small C surface."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_dir():
+    return os.path.join(_HERE, "lib")
+
+
+class HydraError(RuntimeError):
+    pass
+
+
+class LiteHit(C.Structure):          # HydraLiteHit, include/hydra_layouts.h
+    _fields_ = [("t", C.c_float), ("primId", C.c_int32), ("instId", C.c_int32), ("geomId", C.c_int32)]
+
+
+class RaysStat(C.Structure):         # HydraRaysStat
+    _fields_ = [("raysPerSec", C.c_float), ("traversalTimeMs", C.c_float), ("samLightTimeMs", C.c_float),
+                ("shadowTimeMs", C.c_float), ("shadeTimeMs", C.c_float), ("bounceTimeMs", C.c_float),
+                ("evalHitMs", C.c_float), ("nextBounceMs", C.c_float), ("raygenTimeMs", C.c_float),
+                ("accumTimeMs", C.c_float), ("passTimeMs", C.c_float), ("traceTimePerCent", C.c_int32),
+                ("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("samples", C.c_uint64)]
+
+
+LITE_HIT_DTYPE = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
+
+# every entry point include/hydra_hip.h declares (checked by tests/test_capi_symbols.py against the header text)
+C_ABI_SYMBOLS = [
+    "hydra_hip_create", "hydra_hip_destroy", "hydra_hip_last_error", "hydra_hip_device_name", "hydra_hip_resize",
+    "hydra_hip_available_memory", "hydra_hip_finish", "hydra_hip_upload_globals", "hydra_hip_update_globals_header",
+    "hydra_hip_upload_storage", "hydra_hip_upload_bvh", "hydra_hip_set_bvh_trees_num", "hydra_hip_upload_instances",
+    "hydra_hip_upload_remap_lists", "hydra_hip_set_tile_partition", "hydra_hip_set_external_accumulator",
+    "hydra_hip_init_path_tracing", "hydra_hip_clear_accumulated_color", "hydra_hip_trace_pass", "hydra_hip_set_spp",
+    "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_rays_stat",
+    "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_stage_make_eye_rays",
+    "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
+    "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
+]
+
+_hip = None
+_host = None
+
+
+def load_hip_library():
+    """dlopen libhydra_hip.so; raises (never falls back) when it has not been built."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    path = os.path.join(lib_dir(), "libhydra_hip.so")
+    if not os.path.exists(path):
+        raise HydraError("libhydra_hip.so is missing: run `make` (or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32, f32p, u32p, i32p = C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+    sz = C.c_size_t
+    sig = {
+        "hydra_hip_create": ([i32, i32, i32, i32, C.POINTER(vp)], i32),
+        "hydra_hip_destroy": ([vp], i32),
+        "hydra_hip_last_error": ([vp], C.c_char_p),
+        "hydra_hip_device_name": ([vp, C.c_char_p, i32], i32),
+        "hydra_hip_resize": ([vp, i32, i32], i32),
+        "hydra_hip_available_memory": ([vp, C.POINTER(sz), C.POINTER(sz)], i32),
+        "hydra_hip_finish": ([vp], i32),
+        "hydra_hip_upload_globals": ([vp, vp, sz], i32),
+        "hydra_hip_update_globals_header": ([vp, vp, sz], i32),
+        "hydra_hip_upload_storage": ([vp, i32, vp, sz], i32),
+        "hydra_hip_upload_bvh": ([vp, i32, vp, i32, vp, i32, vp, i32, i32], i32),
+        "hydra_hip_set_bvh_trees_num": ([vp, i32], i32),
+        "hydra_hip_upload_instances": ([vp, vp, vp, i32], i32),
+        "hydra_hip_upload_remap_lists": ([vp, vp, i32, vp, i32, vp, i32], i32),
+        "hydra_hip_set_tile_partition": ([vp, i32, i32, i32], i32),
+        "hydra_hip_set_external_accumulator": ([vp, vp, sz], i32),
+        "hydra_hip_init_path_tracing": ([vp, i32], i32),
+        "hydra_hip_clear_accumulated_color": ([vp], i32),
+        "hydra_hip_trace_pass": ([vp, i32], i32),
+        "hydra_hip_set_spp": ([vp, C.c_float], i32),
+        "hydra_hip_get_spp": ([vp], C.c_float),
+        "hydra_hip_get_hdr_image": ([vp, vp, i32, i32], i32),
+        "hydra_hip_get_ldr_image": ([vp, vp, i32, i32], i32),
+        "hydra_hip_get_rays_stat": ([vp, C.POINTER(RaysStat)], i32),
+        "hydra_hip_reset_perf_counters": ([vp], i32),
+        "hydra_hip_enable_stage_timing": ([vp, i32], i32),
+        "hydra_hip_stage_make_eye_rays": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_trace": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_eval_surface": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_path_trace": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_random": ([vp, i32, vp, i32, vp, vp], i32),
+        "hydra_hip_bench_trace": ([vp, i32, vp, vp, i32, i32, f32p], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _hip = lib
+    return lib
+
+
+def load_host_library():
+    global _host
+    if _host is not None:
+        return _host
+    load_hip_library()   # libhydra_host.so links against it
+    path = os.path.join(lib_dir(), "libhydra_host.so")
+    if not os.path.exists(path):
+        raise HydraError("libhydra_host.so is missing: run `make` (or __graft_entry__.build())")
+    lib = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int
+    lib.hydra_host_open_scene.argtypes = [C.c_char_p, i32, i32, i32, i32, i32, i32, i32, C.c_char_p, i32]
+    lib.hydra_host_open_scene.restype = vp
+    lib.hydra_host_close_scene.argtypes = [vp]
+    lib.hydra_host_close_scene.restype = None
+    for n in ("hydra_host_width", "hydra_host_height", "hydra_host_unsupported", "hydra_host_have_inst"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = i32
+    for n in ("hydra_host_log", "hydra_host_last_error"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_char_p
+    lib.hydra_host_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.hydra_host_get_buffer.restype = i32
+    lib.hydra_host_hip_handle.argtypes = [vp]
+    lib.hydra_host_hip_handle.restype = vp
+    lib.hydra_host_draw.argtypes = [vp, i32, i32]
+    lib.hydra_host_draw.restype = i32
+    lib.hydra_host_get_hdr.argtypes = [vp, vp, i32, i32]
+    lib.hydra_host_get_hdr.restype = i32
+    lib.hydra_host_get_spp.argtypes = [vp]
+    lib.hydra_host_get_spp.restype = C.c_float
+    lib.hydra_host_bvh_stats.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.hydra_host_bvh_stats.restype = i32
+    _host = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f4(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.shape == (n, 4), a.shape
+    return a
+
+
+class HipCore:
+    """Thin object wrapper over a hydra_hip_handle.  Either created directly (then the caller uploads the scene
+    buffers) or borrowed from a HostScene that owns a HipHWLayer."""
+
+    def __init__(self, width=0, height=0, device=0, flags=0, _borrowed=None, _owner=None):
+        self.lib = load_hip_library()
+        self._owner = _owner
+        if _borrowed is not None:
+            self.h, self.owned = C.c_void_p(_borrowed), False
+            return
+        h = C.c_void_p()
+        rc = self.lib.hydra_hip_create(width, height, flags, device, C.byref(h))
+        if rc != 0:
+            raise HydraError("hydra_hip_create: %s" % self.lib.hydra_hip_last_error(None).decode())
+        self.h, self.owned = h, True
+
+    def close(self):
+        if self.owned and self.h:
+            self.lib.hydra_hip_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise HydraError("%s failed (%d): %s" % (what, rc, self.lib.hydra_hip_last_error(self.h).decode()))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._ck(self.lib.hydra_hip_device_name(self.h, buf, 256), "device_name")
+        return buf.value.decode()
+
+    # ---- scene upload from host buffers (dict produced by HostScene.buffers())
+    def upload_scene(self, b):
+        L = self.lib
+        g = np.ascontiguousarray(b["globals"], dtype=np.int32)
+        for kind, key in enumerate(("textures", "textures_aux", "geom", "materials", "pdfs")):
+            a = np.ascontiguousarray(b[key])
+            self._ck(L.hydra_hip_upload_storage(self.h, kind, _ptr(a) if a.size else None, a.nbytes), "upload_storage")
+        self._ck(L.hydra_hip_upload_globals(self.h, _ptr(g), g.size), "upload_globals")
+        nodes, tris = np.ascontiguousarray(b["bvh_nodes"]), np.ascontiguousarray(b["bvh_tris"])
+        self._ck(L.hydra_hip_upload_bvh(self.h, 0, _ptr(nodes), nodes.nbytes // 32, _ptr(tris), tris.nbytes // 16, None, 0,
+                                        int(b["have_inst"])), "upload_bvh")
+        self._ck(L.hydra_hip_set_bvh_trees_num(self.h, 1), "set_bvh_trees_num")
+        im, il = np.ascontiguousarray(b["inst_matrices"], dtype=np.float32), np.ascontiguousarray(b["inst_light_id"], dtype=np.int32)
+        if il.size < im.size // 16:
+            il = np.concatenate([il, -np.ones(im.size // 16 - il.size, np.int32)])
+        self._ck(L.hydra_hip_upload_instances(self.h, _ptr(im), _ptr(il), im.size // 16), "upload_instances")
+
+    # ---- rendering
+    def set_tile_partition(self, rank, world, tile=64):
+        self._ck(self.lib.hydra_hip_set_tile_partition(self.h, rank, world, tile), "set_tile_partition")
+
+    def set_external_accumulator(self, dev_ptr, nbytes):
+        self._ck(self.lib.hydra_hip_set_external_accumulator(self.h, C.c_void_p(dev_ptr), nbytes), "set_external_accumulator")
+
+    def init_path_tracing(self, seed):
+        self._ck(self.lib.hydra_hip_init_path_tracing(self.h, seed), "init_path_tracing")
+
+    def clear(self):
+        self._ck(self.lib.hydra_hip_clear_accumulated_color(self.h), "clear_accumulated_color")
+
+    def trace_pass(self, spp=1):
+        self._ck(self.lib.hydra_hip_trace_pass(self.h, spp), "trace_pass")
+
+    def finish(self):
+        self._ck(self.lib.hydra_hip_finish(self.h), "finish")
+
+    def spp(self):
+        return float(self.lib.hydra_hip_get_spp(self.h))
+
+    def set_spp(self, v):
+        self._ck(self.lib.hydra_hip_set_spp(self.h, float(v)), "set_spp")
+
+    def hdr_image(self, w, h):
+        out = np.empty((h, w, 4), np.float32)
+        self._ck(self.lib.hydra_hip_get_hdr_image(self.h, _ptr(out), w, h), "get_hdr_image")
+        return out
+
+    def ldr_image(self, w, h):
+        out = np.empty((h, w), np.uint32)
+        self._ck(self.lib.hydra_hip_get_ldr_image(self.h, _ptr(out), w, h), "get_ldr_image")
+        return out
+
+    def rays_stat(self):
+        st = RaysStat()
+        self._ck(self.lib.hydra_hip_get_rays_stat(self.h, C.byref(st)), "get_rays_stat")
+        return st
+
+    def reset_perf_counters(self):
+        self._ck(self.lib.hydra_hip_reset_perf_counters(self.h), "reset_perf_counters")
+
+    def enable_stage_timing(self, on=True):
+        self._ck(self.lib.hydra_hip_enable_stage_timing(self.h, 1 if on else 0), "enable_stage_timing")
+
+    # ---- stage entry points
+    def stage_random(self, seeds, draws):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        n = seeds.size
+        out, st = np.empty((n, draws, 4), np.float32), np.empty((n, 2), np.uint32)
+        self._ck(self.lib.hydra_hip_stage_random(self.h, n, _ptr(seeds), draws, _ptr(out), _ptr(st)), "stage_random")
+        return out, st
+
+    def stage_make_eye_rays(self, xy, offs4):
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        n = xy.shape[0]
+        offs4 = _f4(offs4, n)
+        pos, dr = np.empty((n, 4), np.float32), np.empty((n, 4), np.float32)
+        self._ck(self.lib.hydra_hip_stage_make_eye_rays(self.h, n, _ptr(xy), _ptr(offs4), _ptr(pos), _ptr(dr)), "stage_make_eye_rays")
+        return pos, dr
+
+    def stage_trace(self, pos4, dir4, counters=False):
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        hits = np.empty(n, LITE_HIT_DTYPE)
+        cnt = np.empty((n, 3), np.uint32) if counters else None
+        self._ck(self.lib.hydra_hip_stage_trace(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(hits), _ptr(cnt) if counters else None), "stage_trace")
+        return (hits, cnt) if counters else hits
+
+    def stage_shadow_trace(self, pos4, dir4, tfar):
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        tfar = np.ascontiguousarray(tfar, dtype=np.float32)
+        vis = np.empty(n, np.float32)
+        self._ck(self.lib.hydra_hip_stage_shadow_trace(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(tfar), _ptr(vis)), "stage_shadow_trace")
+        return vis
+
+    def stage_eval_surface(self, pos4, dir4, hits):
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        hits = np.ascontiguousarray(hits)
+        out = np.empty((n, 24), np.float32)
+        self._ck(self.lib.hydra_hip_stage_eval_surface(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(hits), _ptr(out)), "stage_eval_surface")
+        return out
+
+    def stage_path_trace(self, pos4, dir4, rng2):
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        rng2 = np.ascontiguousarray(rng2, dtype=np.uint32).copy()
+        col = np.empty((n, 4), np.float32)
+        self._ck(self.lib.hydra_hip_stage_path_trace(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(rng2), _ptr(col)), "stage_path_trace")
+        return col, rng2
+
+    def bench_trace(self, pos4, dir4, iters=20, shadow=False):
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        ms = C.c_float(0)
+        self._ck(self.lib.hydra_hip_bench_trace(self.h, n, _ptr(pos4), _ptr(dir4), iters, 1 if shadow else 0, C.byref(ms)), "bench_trace")
+        return float(ms.value)
+
+
+_BUF_KINDS = [("globals", 0, np.int32), ("textures", 1, np.int32), ("textures_aux", 2, np.int32), ("geom", 3, np.float32),
+              ("materials", 4, np.float32), ("pdfs", 5, np.float32), ("bvh_nodes", 6, np.float32), ("bvh_tris", 7, np.float32),
+              ("inst_matrices", 8, np.float32), ("inst_light_id", 9, np.int32), ("remap_lists", 10, np.int32),
+              ("remap_table", 11, np.int32), ("remap_inst", 12, np.int32)]
+
+
+class HostScene:
+    """A HydraAPI scene library committed through RenderDriverLite into an IHWLayer (host-blob or HIP)."""
+
+    def __init__(self, lib_path, width=0, height=0, trace_depth=-1, enable_dof=-1, use_hip=False, device=0, seed=777):
+        self.lib = load_host_library()
+        err = C.create_string_buffer(1024)
+        self.p = self.lib.hydra_host_open_scene(os.fsencode(lib_path), width, height, trace_depth, enable_dof,
+                                                1 if use_hip else 0, device, seed, err, 1024)
+        if not self.p:
+            raise HydraError("open_scene(%s): %s" % (lib_path, err.value.decode()))
+        self.width, self.height = self.lib.hydra_host_width(self.p), self.lib.hydra_host_height(self.p)
+        self.use_hip = use_hip
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.lib.hydra_host_close_scene(self.p)
+        self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def unsupported(self):
+        return self.lib.hydra_host_unsupported(self.p)
+
+    def log(self):
+        return self.lib.hydra_host_log(self.p).decode()
+
+    def buffers(self):
+        """numpy COPIES of every buffer the kernels read (same bytes the HIP layer gets)."""
+        out = {}
+        for name, kind, dt in _BUF_KINDS:
+            ptr, n = C.c_void_p(), C.c_size_t()
+            if self.lib.hydra_host_get_buffer(self.p, kind, C.byref(ptr), C.byref(n)) != 0:
+                raise HydraError("get_buffer(%s)" % name)
+            if n.value == 0 or not ptr.value:
+                out[name] = np.zeros(0, dt)
+            else:
+                raw = (C.c_char * n.value).from_address(ptr.value)
+                out[name] = np.frombuffer(bytes(raw), dtype=dt).copy()
+        out["have_inst"] = self.lib.hydra_host_have_inst(self.p)
+        out["width"], out["height"] = self.width, self.height
+        return out
+
+    def hip(self):
+        h = self.lib.hydra_host_hip_handle(self.p)
+        if not h:
+            raise HydraError("this scene is not backed by a HipHWLayer")
+        return HipCore(_borrowed=h, _owner=self)
+
+    def draw(self, passes=1, spp=1):
+        if self.lib.hydra_host_draw(self.p, passes, spp) != 0:
+            raise HydraError("draw: %s" % self.lib.hydra_host_last_error(self.p).decode())
+
+    def hdr_image(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        if self.lib.hydra_host_get_hdr(self.p, _ptr(out), self.width, self.height) != 0:
+            raise HydraError("get_hdr: %s" % self.lib.hydra_host_last_error(self.p).decode())
+        return out
+
+    def spp(self):
+        return float(self.lib.hydra_host_get_spp(self.p))
+
+    def bvh_stats(self):
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.lib.hydra_host_bvh_stats(self.p, C.byref(a), C.byref(b), C.byref(c))
+        return {"inner_quads": a.value, "leaves": b.value, "triangles": c.value}

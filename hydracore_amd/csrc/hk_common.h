@@ -1,0 +1,108 @@
+// hk_common.h -- device-side vector helpers and scene view for the gfx950 kernels.
+// Arithmetic is plain IEEE float32 in the order written; the library is built with -ffp-contract=off so that
+// integer/byte-level results (hit ids, flags) match the CPU path bit for bit and floats stay within a few ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "../../include/hydra_layouts.h"
+
+#define HK_DEV __device__ __forceinline__
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct m44 { float4 c[4]; };   // four columns (reference: make_float4x4, hydra_drv/cglobals.h:792-800)
+
+HK_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+HK_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+HK_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HK_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HK_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HK_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+HK_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HK_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HK_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+HK_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+HK_DEV float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+HK_DEV f3 clamp3(f3 v, float a, float b) { return mk3(clampf(v.x, a, b), clampf(v.y, a, b), clampf(v.z, a, b)); }
+HK_DEV f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+HK_DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+HK_DEV int   as_int(float f) { return __float_as_int(f); }
+HK_DEV float as_float(int i) { return __int_as_float(i); }
+HK_DEV bool  finite3(f3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+// reference: mul4x3 / mul3x3, hydra_drv/cglobals.h:288-304; mul4x4x4 :828-836
+HK_DEV f3 mul4x3(const m44& m, f3 v) {
+  return mk3(v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x + m.c[3].x,
+             v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y + m.c[3].y,
+             v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z + m.c[3].z);
+}
+HK_DEV f3 mul3x3(const m44& m, f3 v) {
+  return mk3(v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x,
+             v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y,
+             v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z);
+}
+HK_DEV float4 mul4x4x4(const m44& m, float4 v) {
+  float4 r;
+  r.x = v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x + v.w * m.c[3].x;
+  r.y = v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y + v.w * m.c[3].y;
+  r.z = v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z + v.w * m.c[3].z;
+  r.w = v.x * m.c[0].w + v.y * m.c[1].w + v.z * m.c[2].w + v.w * m.c[3].w;
+  return r;
+}
+HK_DEV m44 load_m44(const float4* p) { m44 m; m.c[0] = p[0]; m.c[1] = p[1]; m.c[2] = p[2]; m.c[3] = p[3]; return m; }
+HK_DEV m44 transpose44(const m44& a) {
+  m44 r;
+  r.c[0] = make_float4(a.c[0].x, a.c[1].x, a.c[2].x, a.c[3].x);
+  r.c[1] = make_float4(a.c[0].y, a.c[1].y, a.c[2].y, a.c[3].y);
+  r.c[2] = make_float4(a.c[0].z, a.c[1].z, a.c[2].z, a.c[3].z);
+  r.c[3] = make_float4(a.c[0].w, a.c[1].w, a.c[2].w, a.c[3].w);
+  return r;
+}
+// object->world matrix back from the stored world->object one (kernel_EvalSurface step 4, PT_Loop.cpp:57):
+// instance matrices are affine, so invert the 3x3 block by cofactors and rotate the translation.
+HK_DEV m44 inverse_affine(const m44& m) {
+  const float a00 = m.c[0].x, a10 = m.c[0].y, a20 = m.c[0].z;
+  const float a01 = m.c[1].x, a11 = m.c[1].y, a21 = m.c[1].z;
+  const float a02 = m.c[2].x, a12 = m.c[2].y, a22 = m.c[2].z;
+  const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const float det = a00 * c00 + a01 * c01 + a02 * c02;
+  const float id = 1.0f / det;
+  m44 r;
+  r.c[0] = make_float4(c00 * id, c01 * id, c02 * id, 0.0f);
+  r.c[1] = make_float4((a02 * a21 - a01 * a22) * id, (a00 * a22 - a02 * a20) * id, (a01 * a20 - a00 * a21) * id, 0.0f);
+  r.c[2] = make_float4((a01 * a12 - a02 * a11) * id, (a02 * a10 - a00 * a12) * id, (a00 * a11 - a01 * a10) * id, 0.0f);
+  const float tx = m.c[3].x, ty = m.c[3].y, tz = m.c[3].z;
+  r.c[3] = make_float4(-(r.c[0].x * tx + r.c[1].x * ty + r.c[2].x * tz),
+                       -(r.c[0].y * tx + r.c[1].y * ty + r.c[2].y * tz),
+                       -(r.c[0].z * tx + r.c[1].z * ty + r.c[2].z * tz), 1.0f);
+  return r;
+}
+
+// ---- device view of the scene: raw pointers into the uploaded blobs (layouts: include/hydra_layouts.h)
+struct SceneDev {
+  const int*    globals;       // [EngineGlobals | tables | lights]
+  const float4* matStorage;
+  const int4*   texStorage;
+  const float4* geomStorage;
+  const float4* pdfStorage;
+  const float4* bvh;           // tree 0: 2 float4 per node, 8 per quad
+  const float4* tris;          // tree 0 triangle lists
+  int           haveInst;
+  const float4* instMatrices;  // 4 float4 per instance (world -> object)
+  const int*    instLightInstId;
+  int           instNum;
+  const int*    remapLists; int remapListsSize;
+  const int*    remapTable; int remapTableSize;
+  const int*    remapInst;  int remapInstSize;
+};
+
+HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.globals + HG_VARS_F); }
+HK_DEV const int*   g_varsI(const SceneDev& s) { return s.globals + HG_VARS_I; }
+
+#define HK_GEPSILON  5e-6f
+#define HK_DEPSILON  1e-20f
+#define HK_DEPSILON2 1e-30f
+#define HK_INV_PI    0.31830988618379067154f
+#define HK_INV_TWOPI 0.15915494309189533577f
+#define HK_MAXFLOAT  FLT_MAX   /* ctrace.h:665-667: MAXFLOAT is glibc's FLT_MAX on the CPU path */

@@ -1,0 +1,690 @@
+// hk_shading.h -- device functions for the non-traversal stages: RNG, camera, surface reconstruction, software
+// textures, BxDFs, area lights.  Each function cites the reference inline kernel it reproduces (hydra_drv/...).
+#pragma once
+#include "hk_common.h"
+#include "hk_trace.h"
+
+// ================================================================================================ R1: RandomGen
+// crandom.h:10-83.  2 x u32 state, integer-exact.
+struct RandomGen { uint32_t x, y; };
+
+HK_DEV uint32_t NextState(RandomGen& g) {
+  const uint32_t x = g.x * 17u + g.y * 13123u;
+  g.x = (x << 13) ^ x;
+  g.y ^= (x << 7);
+  return x;
+}
+HK_DEV RandomGen RandomGenInit(int a_seed) {
+  RandomGen g;
+  const uint32_t s = uint32_t(a_seed);
+  g.x = (s * (s * s * 15731u + 74323u) + 871483u);
+  g.y = (s * (s * s * 13734u + 37828u) + 234234u);
+  for (int i = 0; i < (a_seed % 7); i++) NextState(g);
+  return g;
+}
+HK_DEV float4 rndFloat4_Pseudo(RandomGen& g) {
+  const uint32_t x = NextState(g);
+  const uint32_t x1 = (x * (x * x * 15731u + 74323u) + 871483u);
+  const uint32_t y1 = (x * (x * x * 13734u + 37828u) + 234234u);
+  const uint32_t z1 = (x * (x * x * 11687u + 26461u) + 137589u);
+  const uint32_t w1 = (x * (x * x * 15707u + 789221u) + 1376312589u);
+  const float scale = (1.0f / 4294967296.0f);
+  return make_float4(float(x1) * scale, float(y1) * scale, float(z1) * scale, float(w1) * scale);
+}
+HK_DEV float rndFloat1_Pseudo(RandomGen& g) {
+  const uint32_t x = NextState(g);
+  const uint32_t tmp = (x * (x * x * 15731u + 74323u) + 871483u);
+  return float(tmp) * (1.0f / 4294967296.0f);
+}
+
+// ================================================================================================ small helpers
+HK_DEV float epsilonOfPos(f3 p) { return fmaxf(fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))), 2.0f * HK_GEPSILON) * HK_GEPSILON; }   // cglobals.h:737
+HK_DEV float misHeuristicPower1(float p) { return isfinite(p) ? fabsf(p) : 0.0f; }
+HK_DEV float misWeightHeuristic(float a, float b) {   // cglobals.h:741-745 (power 1 = balance heuristic)
+  const float w = misHeuristicPower1(a) / fmaxf(misHeuristicPower1(a) + misHeuristicPower1(b), HK_DEPSILON2);
+  return isfinite(w) ? w : 0.0f;
+}
+HK_DEV f3 OffsRayPos(f3 hitPos, f3 n, f3 sampleDir) {   // cglobals.h:764-769
+  const float sgn = dot(sampleDir, n) < 0.0f ? -1.0f : 1.0f;
+  return hitPos + n * (sgn * epsilonOfPos(hitPos));
+}
+HK_DEV f3 OffsShadowRayPos(f3 hitPos, f3 n, f3 sampleDir, float aux) {   // cglobals.h:779-784
+  const float sgn = dot(sampleDir, n) < 0.0f ? -1.0f : 1.0f;
+  return hitPos + n * (sgn * (epsilonOfPos(hitPos) + aux));
+}
+HK_DEV f3 reflect3(f3 dir, f3 n) { return normalize(((n * dot(dir, n)) * (-2.0f)) + dir); }   // cglobals.h:686-691
+
+HK_DEV void CoordinateSystem(f3 v1, f3& v2, f3& v3) {   // cglobals.h:1502-1518
+  if (fabsf(v1.x) > fabsf(v1.y)) {
+    const float invLen = 1.0f / sqrtf(v1.x * v1.x + v1.z * v1.z);
+    v2 = mk3((-1.0f) * v1.z * invLen, 0.0f, v1.x * invLen);
+  } else {
+    const float invLen = 1.0f / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    v2 = mk3(0.0f, v1.z * invLen, (-1.0f) * v1.y * invLen);
+  }
+  v3 = cross(v1, v2);
+}
+HK_DEV f3 MapSampleToCosineDistribution(float r1, float r2, f3 direction, f3 hit_norm, float power) {   // cglobals.h:1521-1559
+  if (power >= 1e6f) return direction;
+  const float sin_phi = sinf(2.0f * r1 * 3.141592654f), cos_phi = cosf(2.0f * r1 * 3.141592654f);
+  const float cos_theta = powf(1.0f - r2, 1.0f / (power + 1.0f));
+  const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+  const f3 dev = mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+  f3 nx, nzz;
+  CoordinateSystem(direction, nx, nzz);
+  const f3 ny = nzz, nz = direction;   // the reference swaps ny and nz after building the frame
+  f3 res = ((nx * dev.x) + (ny * dev.y)) + (nz * dev.z);
+  const float invSign = dot(direction, hit_norm) > 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot(res, hit_norm) < 0.0f) res = (((nx * (-1.0f)) * dev.x) + (ny * dev.y)) - (nz * dev.z);
+  return res;
+}
+HK_DEV f3 MapSampleToModifiedCosineDistribution(float r1, float r2, f3 direction, f3 hit_norm, float power, bool& under) {   // :1563-1601
+  if (power >= 1e6f) return direction;
+  const float sin_phi = sinf(2.0f * r1 * 3.141592654f), cos_phi = cosf(2.0f * r1 * 3.141592654f);
+  const float sin_theta = sqrtf(1.0f - powf(r2, 2.0f / (power + 1.0f)));
+  f3 dev;
+  dev.x = sin_theta * cos_phi;
+  dev.y = sin_theta * sin_phi;
+  dev.z = sqrtf(1.0f - dev.x * dev.x - dev.y * dev.y);
+  f3 nx, nzz;
+  CoordinateSystem(direction, nx, nzz);
+  const f3 ny = nzz, nz = direction;
+  f3 res = ((nx * dev.x) + (ny * dev.y)) + (nz * dev.z);
+  under = false;
+  const float invSign = dot(direction, hit_norm) >= 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot(res, hit_norm) < 0.0f) {
+    res = (((nx * (-1.0f)) * dev.x) - (ny * dev.y)) + (nz * dev.z);
+    under = true;
+  }
+  return res;
+}
+HK_DEV f2 MapSamplesToDisc(f2 xy) {   // cglobals.h:1609-1652
+  const float x = xy.x, y = xy.y;
+  float r = 0, phi = 0;
+  if (x > y && x > -y) { r = x; phi = 0.25f * 3.141592654f * (y / x); }
+  if (x < y && x > -y) { r = y; phi = 0.25f * 3.141592654f * (2.0f - x / y); }
+  if (x < y && x < -y) { r = -x; phi = 0.25f * 3.141592654f * (4.0f + y / x); }
+  if (x > y && x < -y) { r = -y; phi = 0.25f * 3.141592654f * (6 - x / y); }
+  return mk2(r * sinf(phi), r * cosf(phi));
+}
+HK_DEV float sRGBToLinear(float s) {   // cglobals.h:3024-3030
+  if (s <= 0.0404482362771082f) return s * 0.077399381f;
+  return powf((s + 0.055f) * 0.947867299f, 2.4f);
+}
+HK_DEV float linearToSRGB(float l) {   // cglobals.h:3032-3038 (double constants on the CPU path)
+  if (l <= 0.00313066844250063f) return l * 12.92f;
+  return float(1.055 * double(powf(l, 1.0f / 2.4f)) - 0.055);
+}
+
+// ================================================================================================ P1: camera
+HK_DEV f3 EyeRayDirNormalized(float x, float y, const m44& projInv) {   // cglobals.h:1069-1078
+  float4 pos = make_float4(2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f, 1.0f);
+  pos = mul4x4x4(projInv, pos);
+  return normalize(mk3(pos.x / pos.w, pos.y / pos.w, pos.z / pos.w));
+}
+HK_DEV f3 tiltCorrection(f3 ray_pos, f3 ray_dir, const SceneDev& s) {   // cfetch.h:832-863
+  const float tiltX = g_varsF(s)[HV_F_TILT_ROT_X], tiltY = g_varsF(s)[HV_F_TILT_ROT_Y];
+  if ((fabsf(tiltX) > 0.0f || fabsf(tiltY) > 0.0f) && fabsf(ray_dir.z) > 0.0f) {
+    const float t = (-1.0f - ray_pos.z) / ray_dir.z;
+    f3 p = ray_pos + ray_dir * t;
+    p.z += 1.0f;
+    if (fabsf(tiltY) > 0.0f) { const float sn = sinf(-tiltY), cs = cosf(-tiltY); p = mk3(p.x * cs + p.z * sn, p.y, p.x * (-sn) + p.z * cs); }
+    if (fabsf(tiltX) > 0.0f) { const float sn = sinf(-tiltX), cs = cosf(-tiltX); p = mk3(p.x, p.y * cs + p.z * (-sn), p.y * sn + p.z * cs); }
+    p.z -= 1.0f;
+    ray_dir = normalize(p - ray_pos);
+  }
+  return ray_dir;
+}
+HK_DEV void MakeRandEyeRay(int x, int y, int w, int h, float4 offsets, const SceneDev& s, f3& outPos, f3& outDir) {   // cfetch.h:877-930
+  const m44 projInv = load_m44(reinterpret_cast<const float4*>(s.globals + HG_MPROJ_INV));
+  const m44 wvInv = load_m44(reinterpret_cast<const float4*>(s.globals + HG_MWORLDVIEW_INV));
+  f3 ray_pos = mk3(0.0f, 0.0f, 0.0f);
+  f3 ray_dir = EyeRayDirNormalized((float(x) + 0.5f) / float(w), (float(y) + 0.5f) / float(h), projInv);
+  {
+    const float sinFov = sinf(0.5f * g_varsF(s)[HV_F_CAM_FOV]);
+    const float pxSizeX = sinFov * (1.0f / float(w)), pxSizeY = sinFov * (1.0f / float(h));
+    ray_dir.x += pxSizeX * offsets.x;
+    ray_dir.y += pxSizeY * offsets.y;
+    ray_dir.z = -sqrtf(1.0f - (ray_dir.x * ray_dir.x + ray_dir.y * ray_dir.y));
+  }
+  ray_dir = tiltCorrection(ray_pos, ray_dir, s);
+  if (g_varsI(s)[HV_I_ENABLE_DOF] == 1) {
+    const float tFocus = g_varsF(s)[HV_F_DOF_FOCAL_PLANE_DIST] / (-ray_dir.z);
+    const f3 focusPosition = ray_pos + ray_dir * tFocus;
+    const f2 d = MapSamplesToDisc(mk2(1.0f * offsets.z, 1.0f * offsets.w));
+    const float R = g_varsF(s)[HV_F_DOF_LENS_RADIUS];
+    ray_pos.x += R * d.x;
+    ray_pos.y += R * d.y;
+    ray_dir = normalize(focusPosition - ray_pos);
+  }
+  const f3 pos = mul4x3(wvInv, ray_pos);   // matrix4x4f_mult_ray3, cglobals.h:1080-1087
+  const f3 pos2 = mul4x3(wvInv, ray_pos + ray_dir * 100.0f);
+  outPos = pos;
+  outDir = normalize(pos2 - pos);
+}
+
+// ================================================================================================ H1: surface
+struct SurfaceHit {   // cglobals.h:2514-2528
+  f3 pos, normal, flatNormal, tangent, biTangent;
+  f2 texCoord;
+  int matId; float t, sRayOff; bool hfi;
+};
+
+HK_DEV int remapMaterialId(int mId, int instId, const SceneDev& s) {   // cglobals.h:2931-2983
+  if (mId < 0 || instId < 0 || instId >= s.remapInstSize || s.remapInst == nullptr || s.remapLists == nullptr || s.remapTable == nullptr) return mId;
+  const int listId = s.remapInst[instId];
+  if (listId < 0 || listId >= s.remapTableSize) return mId;
+  const int offs = s.remapTable[2 * listId], size = s.remapTable[2 * listId + 1];
+  int low = 0, high = size - 1;
+  while (low <= high) {
+    const int mid = low + ((high - low) / 2);
+    if (s.remapLists[offs + mid * 2] >= mId) high = mid - 1; else low = mid + 1;
+  }
+  if (high + 1 < size) {
+    const int from = s.remapLists[offs + (high + 1) * 2], to = s.remapLists[offs + (high + 1) * 2 + 1];
+    return (from == mId) ? to : mId;
+  }
+  return mId;
+}
+
+HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, const float4* __restrict__ mesh) {   // ctrace.h:1988-2109
+  const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(mesh);
+  const float4* vertPos = mesh + hdr->vPosOffset;
+  const float4* vertNorm = mesh + hdr->vNormOffset;
+  const float4* vertTang = mesh + hdr->vTangentOffset;
+  const int* vertIndices = reinterpret_cast<const int*>(mesh + hdr->vIndicesOffset);
+  const int* matIndices = reinterpret_cast<const int*>(mesh + hdr->mIndicesOffset);
+  const float* shadowRayOff = reinterpret_cast<const float*>(mesh + hdr->polyShadowOffset);
+
+  SurfaceHit sh;
+  sh.matId = matIndices[hit.primId];
+  const int o = hit.primId * 3;
+  const int iA = vertIndices[o], iB = vertIndices[o + 1], iC = vertIndices[o + 2];
+  const float4 A1 = vertPos[iA], B1 = vertPos[iB], C1 = vertPos[iC];
+  const float4 A2 = vertNorm[iA], B2 = vertNorm[iB], C2 = vertNorm[iC];
+  const f3 A_pos = xyz(A1), B_pos = xyz(B1), C_pos = xyz(C1);
+  const f3 A_norm = xyz(A2), B_norm = xyz(B2), C_norm = xyz(C2);
+
+  float u, v;   // triBaricentrics
+  {
+    const f3 edge1 = B_pos - A_pos, edge2 = C_pos - A_pos;
+    const f3 pvec = cross(a_rdir, edge2);
+    const float inv_det = 1.0f / dot(edge1, pvec);
+    const f3 tvec = a_rpos - A_pos;
+    v = dot(tvec, pvec) * inv_det;
+    const f3 qvec = cross(tvec, edge1);
+    u = dot(a_rdir, qvec) * inv_det;
+  }
+  const float w0 = (1.0f - u - v);
+  sh.pos = ((A_pos * w0) + (B_pos * v)) + (C_pos * u);
+  sh.texCoord.x = w0 * A1.w + v * B1.w + u * C1.w;
+  sh.texCoord.y = w0 * A2.w + v * B2.w + u * C2.w;
+  sh.normal = ((A_norm * w0) + (B_norm * v)) + (C_norm * u);
+  sh.t = hit.t;
+  sh.sRayOff = shadowRayOff[hit.primId];
+
+  const float4 At = vertTang[iA], Bt = vertTang[iB], Ct = vertTang[iC];
+  sh.flatNormal = normalize(cross(A_pos - B_pos, A_pos - C_pos));
+  if (dot(a_rdir, sh.flatNormal) > 0.025f) sh.flatNormal = sh.flatNormal * (-1.0f);
+  const float maxEdge = fmaxf(fmaxf(length(A_pos - B_pos), length(A_pos - C_pos)), length(B_pos - C_pos));
+  if (sh.sRayOff > 1e-5f * maxEdge) {   // smooth low-poly surfaces
+    if (dot(a_rdir, sh.normal) > 0.120f) { sh.normal = sh.normal * (-1.0f); sh.hfi = true; }
+    else if (dot(a_rdir, sh.normal) > 0.0f) { sh.normal = sh.flatNormal; sh.hfi = false; }
+    else sh.hfi = false;
+  } else {
+    if (dot(a_rdir, sh.normal) > 0.0f) { sh.normal = sh.normal * (-1.0f); sh.hfi = true; }
+    else sh.hfi = false;
+  }
+  const float handed = (At.w < 0.0f || Bt.w < 0.0f || Ct.w < 0.0f) ? -1.0f : 1.0f;
+  sh.tangent = normalize(((xyz(At) * w0) + (xyz(Bt) * v)) + (xyz(Ct) * u));
+  sh.biTangent = normalize(handed > 0.0f ? cross(sh.normal, sh.tangent) : cross(sh.tangent, sh.normal));
+  const bool badTangent = !finite3(sh.biTangent);
+  if (fabsf(fabsf(dot(sh.normal, sh.tangent)) - 1.0f) < 1e-4f || badTangent) CoordinateSystem(sh.normal, sh.tangent, sh.biTangent);
+  return sh;
+}
+
+HK_DEV SurfaceHit evalSurface(const SceneDev& s, f3 ray_pos, f3 ray_dir, const HydraLiteHit& hit) {   // CPUExp_Integrators_PT_Loop.cpp:35-84
+  const m44 instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4);
+  const f3 posLS = mul4x3(instInv, ray_pos), dirLS = mul3x3(instInv, ray_dir);
+  const int meshOffset = s.globals[s.globals[HG_GEOM_TABLE_OFFS] + hit.geomId];
+  const SurfaceHit ls = surfaceEvalLS(posLS, dirLS, hit, s.geomStorage + meshOffset);
+  const m44 inst = inverse_affine(instInv);
+  SurfaceHit ws = ls;
+  const float multInv = 1.0f / sqrtf(3.0f);
+  const f3 shadowStart = mul3x3(inst, mk3(multInv * ls.sRayOff, multInv * ls.sRayOff, multInv * ls.sRayOff));
+  const m44 nm = transpose44(instInv);
+  ws.pos = mul4x3(inst, ls.pos);
+  ws.normal = normalize(mul3x3(nm, ls.normal));
+  ws.flatNormal = normalize(mul3x3(nm, ls.flatNormal));
+  ws.tangent = normalize(mul3x3(nm, ls.tangent));
+  ws.biTangent = normalize(mul3x3(nm, ls.biTangent));
+  ws.t = length(ws.pos - ray_pos);
+  ws.sRayOff = length(shadowStart);
+  ws.matId = remapMaterialId(ws.matId, hit.instId, s);
+  return ws;
+}
+
+// ================================================================================================ textures
+HK_DEV int4 bilinearOffsets(float ffx, float ffy, int flags, int w, int h) {   // cfetch.h:312-362
+  const int sx = (ffx > 0.0f) ? 1 : -1, sy = (ffy > 0.0f) ? 1 : -1;
+  const int px = int(ffx), py = int(ffy);
+  int px_w0, px_w1, py_w0, py_w1;
+  if (flags & HTEX_CLAMP_U) {
+    px_w0 = (px >= w) ? w - 1 : px; px_w1 = (px + 1 >= w) ? w - 1 : px + 1;
+    px_w0 = (px_w0 < 0) ? 0 : px_w0; px_w1 = (px_w1 < 0) ? 0 : px_w1;
+  } else {
+    px_w0 = px % w; px_w1 = (px + sx) % w;
+    px_w0 = (px_w0 < 0) ? px_w0 + w : px_w0; px_w1 = (px_w1 < 0) ? px_w1 + w : px_w1;
+  }
+  if (flags & HTEX_CLAMP_V) {
+    py_w0 = (py >= h) ? h - 1 : py; py_w1 = (py + 1 >= h) ? h - 1 : py + 1;
+    py_w0 = (py_w0 < 0) ? 0 : py_w0; py_w1 = (py_w1 < 0) ? 0 : py_w1;
+  } else {
+    py_w0 = py % h; py_w1 = (py + sy) % h;
+    py_w0 = (py_w0 < 0) ? py_w0 + h : py_w0; py_w1 = (py_w1 < 0) ? py_w1 + h : py_w1;
+  }
+  return make_int4(py_w0 * w + px_w0, py_w0 * w + px_w1, py_w1 * w + px_w0, py_w1 * w + px_w1);
+}
+HK_DEV float4 read_uchar4(const uchar4* data, int offset, bool srgb) {   // cfetch.h:298-303
+  const float mult = 0.003921568f;
+  const uchar4 c = data[offset];
+  float4 r = make_float4(mult * float(c.x), mult * float(c.y), mult * float(c.z), mult * float(c.w));
+  if (srgb) r = make_float4(sRGBToLinear(r.x), sRGBToLinear(r.y), sRGBToLinear(r.z), sRGBToLinear(r.w));
+  return r;
+}
+HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   // cfetch.h:461-584 (4-channel textures)
+  const int4 header = tex[0];
+  const int w = header.x, h = header.y, bpp = header.w;
+  float ffx = tc.x * float(w) - 0.5f, ffy = tc.y * float(h) - 0.5f;
+  if ((flags & HTEX_CLAMP_U) != 0 && ffx < 0) ffx = 0.0f;
+  if ((flags & HTEX_CLAMP_V) != 0 && ffy < 0) ffy = 0.0f;
+  const uchar4* bytes = reinterpret_cast<const uchar4*>(tex + 1);
+  const float4* fdata = reinterpret_cast<const float4*>(tex + 1);
+  if (flags & HTEX_POINT_SAM) {
+    int px = int(ffx + 0.5f), py = int(ffy + 0.5f);
+    if (flags & HTEX_CLAMP_U) { px = (px >= w) ? w - 1 : px; px = (px < 0) ? 0 : px; } else { px = px % w; px = (px < 0) ? px + w : px; }
+    if (flags & HTEX_CLAMP_V) { py = (py >= h) ? h - 1 : py; py = (py < 0) ? 0 : py; } else { py = py % h; py = (py < 0) ? py + h : py; }
+    const int offset = py * w + px;
+    if (bpp == 4) return read_uchar4(bytes, offset, srgb);
+    if (bpp == 16) return fdata[offset];
+    return make_float4(0, 0, 0, 0);
+  }
+  const int px = int(ffx), py = int(ffy);
+  const float fx = fabsf(ffx - float(px)), fy = fabsf(ffy - float(py));
+  const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+  const float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+  const int4 offs = bilinearOffsets(ffx, ffy, flags, w, h);
+  float4 f1, f2_, f3_, f4_;
+  if (bpp == 4) {
+    f1 = read_uchar4(bytes, offs.x, srgb); f2_ = read_uchar4(bytes, offs.y, srgb);
+    f3_ = read_uchar4(bytes, offs.z, srgb); f4_ = read_uchar4(bytes, offs.w, srgb);
+  } else {
+    f1 = fdata[offs.x]; f2_ = fdata[offs.y]; f3_ = fdata[offs.z]; f4_ = fdata[offs.w];
+  }
+  return make_float4(f1.x * w1 + f2_.x * w2 + f3_.x * w3 + f4_.x * w4, f1.y * w1 + f2_.y * w2 + f3_.y * w3 + f4_.y * w4,
+                     f1.z * w1 + f2_.z * w2 + f3_.z * w3 + f4_.z * w4, f1.w * w1 + f2_.w * w2 + f3_.w * w3 + f4_.w * w4);
+}
+// sample2DExt, cfetch.h:677-709, without procedural textures.  blob = owning material/light node, int4-addressed.
+HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
+  if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE || samplerOffset < 0) return mk3(1, 1, 1);
+  const float* sm = blob + size_t(samplerOffset) * 4;
+  const int flags = as_int(sm[HS_FLAGS]);
+  const float gamma = sm[HS_GAMMA];
+  const int texId = as_int(sm[HS_TEXID]);
+  if (texId <= 0) return mk3(1, 1, 1);
+  const f2 tct = mk2(sm[HS_ROW0] * texCoord.x + sm[HS_ROW0 + 1] * texCoord.y + sm[HS_ROW0 + 3],
+                     sm[HS_ROW1] * texCoord.x + sm[HS_ROW1 + 1] * texCoord.y + sm[HS_ROW1 + 3]);
+  const int offset = s.globals[s.globals[HG_TEX_TABLE_OFFS] + texId];
+  float4 c = make_float4(1, 1, 1, 1);
+  if (offset >= 0) c = read_imagef_sw4(s.texStorage + offset, tct, flags, (gamma != 1.0f));
+  if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
+  return mk3(c.x, c.y, c.z);
+}
+
+// ================================================================================================ materials
+struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
+struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
+struct ShadeContext { f3 l, v, n; f2 tc; };                                 // cglobals.h:2282-2301 (fields used without normal maps)
+
+HK_DEV const float* materialAt(const SceneDev& s, int matId) {   // cfetch.h:192-213
+  const int matOffset = s.globals[s.globals[HG_MAT_TABLE_OFFS] + matId];
+  return reinterpret_cast<const float*>(s.matStorage + matOffset);
+}
+HK_DEV int matType(const float* m) { return as_int(m[HM_TYPE]); }
+HK_DEV int matFlags(const float* m) { return as_int(m[HM_FLAGS]); }
+HK_DEV f3 matColor(const float* m) { return mk3(m[HM_COLOR], m[HM_COLOR + 1], m[HM_COLOR + 2]); }
+
+__device__ static const float hk_glosscoeff[10][4] = {   // cmaterial.h:435-450
+    {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
+    {357.142857142857f, -35.7142857142857f, 5.0f, 1.5f},
+    {-2142.85714285714f, 428.571428571429f, 8.57142857142857f, 2.0f},
+    {428.571428571431f, -42.8571428571432f, 30.0f, 5.0f},
+    {2095.23809523810f, -152.380952380952f, 34.2857142857143f, 8.0f},
+    {-4761.90476190476f, 1809.52380952381f, 66.6666666666667f, 12.0f},
+    {9914.71215351811f, 1151.38592750533f, 285.714285714286f, 32.0f},
+    {45037.7068059246f, 9161.90096119855f, 813.432835820895f, 82.0f},
+    {167903.678757035f, 183240.189801913f, 3996.94423223835f, 300.0f},
+    {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
+HK_DEV float cosPowerFromGlosiness(float x) {   // cmaterial.h:453-466
+  const int k = (fabsf(x - 1.0f) < 1e-5f) ? 10 : int(x * 10.0f);
+  const float x1 = (x - float(k) * 0.1f);
+  if (k == 10 || x >= 0.99f) return 1000000.0f;
+  return hk_glosscoeff[k][3] + hk_glosscoeff[k][2] * x1 + hk_glosscoeff[k][1] * x1 * x1 + hk_glosscoeff[k][0] * x1 * x1 * x1;
+}
+
+// ---- lambert, cmaterial.h:219-263
+HK_DEV f3 lambertColor(const float* m, f2 tc, const SceneDev& s) {
+  return clamp3(sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s) * matColor(m), 0.0f, 1.0f);
+}
+HK_DEV void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 color = lambertColor(m, tc, s);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, n, n, 1.0f);
+  const float cosTheta = dot(newDir, n);
+  out.direction = newDir;
+  out.pdf = cosTheta * HK_INV_PI;
+  out.color = color * HK_INV_PI;
+  if (cosTheta <= HK_DEPSILON) out.color = mk3(0, 0, 0);
+  out.flags = HRE_D;
+}
+// ---- phong, cmaterial.h:915-1033
+HK_DEV float phongGlosiness(const float* m, f2 tc, const SceneDev& s) {
+  if (uint32_t(as_int(m[HM_PHONG_GLOSS_TEXID])) != HYDRA_INVALID_TEXTURE) {
+    const f3 g = sample2DExt(as_int(m[HM_PHONG_GLOSS_TEXMATRIXID]), tc, m, s);
+    return clampf(m[HM_PHONG_GLOSINESS] * fmaxf(g.x, fmaxf(g.y, g.z)), 0.0f, 0.99f);
+  }
+  return m[HM_PHONG_GLOSINESS];
+}
+HK_DEV float phongEvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return 1.0f;
+  const float cosPower = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 r = reflect3(v * (-1.0f), n);
+  const float cosTheta = clampf(fabsf(dot(l, r)), 0.0f, 1.0f);
+  return powf(cosTheta, cosPower) * (cosPower + 1.0f) * HK_INV_TWOPI;
+}
+HK_DEV f3 phongEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return mk3(0, 0, 0);
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float cosPower = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 r = reflect3(v * (-1.0f), n);
+  const float cosAlpha = clampf(dot(l, r), 0.0f, 1.0f);
+  const float fix = (matFlags(m) & HMF_ENERGY_FIX) ? (cosAlpha / fmaxf(dot(n, l), 1e-6f)) : 1.0f;
+  return (((color * (cosPower + 2.0f)) * HK_INV_TWOPI) * powf(cosAlpha, cosPower)) * fix;
+}
+HK_DEV void PhongSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float gloss = phongGlosiness(m, tc, s);
+  const float cosPower = cosPowerFromGlosiness(gloss);
+  bool under = false;
+  const f3 r = reflect3(ray_dir, n);
+  const f3 newDir = MapSampleToModifiedCosineDistribution(r1, r2, r, n, cosPower, under);
+  const f3 v = ray_dir * (-1.0f);
+  if (dot(n, v) < 1e-6f || dot(n, newDir) < 1e-6f || under) { out.color = mk3(0, 0, 0); out.pdf = 1.0f; }
+  else {
+    const float cosAlpha = clampf(dot(newDir, r), 0.0f, 1.0f);
+    const float eqTemp = powf(cosAlpha, cosPower) * HK_INV_TWOPI;
+    const float fix = (matFlags(m) & HMF_ENERGY_FIX) ? (cosAlpha / fmaxf(dot(n, newDir), 1e-6f)) : 1.0f;
+    out.pdf = eqTemp * (cosPower + 1.0f);
+    out.color = (color * (eqTemp * (cosPower + 2.0f))) * fix;
+  }
+  out.direction = newDir;
+  out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
+}
+// ---- mirror, cmaterial.h:395-430
+HK_DEV void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
+  f3 newDir = reflect3(ray_dir, n);
+  if (dot(ray_dir, n) > 0.0f) newDir = ray_dir;
+  const float cosOut = dot(newDir, n);
+  out.direction = newDir;
+  out.pdf = 1.0f;
+  out.color = (matColor(m) * tex) * (1.0f / fmaxf(cosOut, 1e-6f));
+  if (cosOut <= 1e-6f) out.color = mk3(0, 0, 0);
+  out.flags = HRE_S;
+}
+// ---- blend mask, cmaterial.h:2008-2137; fresnel cglobals.h:1879-1926
+HK_DEV float fresnelDielectric(float c1, float c2, float etaExt, float etaInt) {
+  const float Rs = (etaExt * c1 - etaInt * c2) / (etaExt * c1 + etaInt * c2);
+  const float Rp = (etaInt * c1 - etaExt * c2) / (etaInt * c1 + etaExt * c2);
+  return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+HK_DEV float fresnelReflectionCoeff(float cosTheta1, float etaExt, float etaInt) {
+  if (cosTheta1 < 0.0f) { const float t = etaInt; etaInt = etaExt; etaExt = t; }
+  const float sinTheta2 = etaExt / etaInt * sqrtf(fmaxf(0.0f, 1.0f - cosTheta1 * cosTheta1));
+  if (sinTheta2 > 1.0f) return 1.0f;
+  const float cosTheta2 = sqrtf(fmaxf(0.0f, 1.0f - sinTheta2 * sinTheta2));
+  return fresnelDielectric(fabsf(cosTheta1), cosTheta2, etaInt, etaExt);
+}
+HK_DEV float hermiteSplineEvalT(float t, const float* points, const float* tangents, int numPoints) {
+  int ps = int(t * float(numPoints - 1));
+  if (ps == numPoints - 1) ps--;
+  const int pe = ps + 1;
+  const float tStart = float(ps) / float(numPoints - 1), tEnd = float(pe) / float(numPoints - 1);
+  const float sx = fabsf(t - tStart) / (tEnd - tStart);
+  const float s2 = sx * sx, s3 = s2 * sx;
+  const float h1 = 2.0f * s3 - 3.0f * s2 + 1.0f, h2 = -2.0f * s3 + 3.0f * s2, h3 = s3 - 2.0f * s2 + sx, h4 = s3 - s2;
+  return 1.0f - clampf(h1 * points[2 * ps + 1] + h2 * points[2 * pe + 1] + h3 * tangents[2 * ps + 1] + h4 * tangents[2 * pe + 1], 0.0f, 1.0f);
+}
+HK_DEV float blendMaskAlpha2(const float* m, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  const f3 lum1 = clamp3(sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s) * matColor(m), 0.0f, 1.0f);
+  const int bflags = as_int(m[HM_BLEND_FLAGS]);
+  float lum = (bflags & HBF_EXTRUSION_LUMINANCE) ? dot(mk3(0.2126f, 0.7152f, 0.0722f), lum1) : fmaxf(lum1.x, fmaxf(lum1.y, lum1.z));
+  const float normAngle = fabsf(dot(v, n));
+  float faloff = 0.0f;
+  if (bflags & HBF_FALOFF) {
+    const int start = as_int(m[HM_BLEND_FALOFF_OFFSET]), size = as_int(m[HM_BLEND_FALOFF_SIZE]);
+    const float* points = reinterpret_cast<const float*>(s.globals + s.globals[HG_FLOAT_ARRAYS_OFFS]) + start;
+    const float param = (as_int(m[HM_BLEND_FLAGS2]) & 1) ? normAngle : 1.0f - normAngle;
+    faloff = hermiteSplineEvalT(param, points, points + size / 2, size / 4);
+  }
+  if (as_int(m[HM_BLEND_TYPE]) == 4) {   // BLEND_SIGMOID; unreachable with converter-made blobs (sampler aliasing)
+    const float x2 = -5.0f + 10.0f * lum;
+    lum = 1.04f / (1.0f + expf(-m[HM_BLEND_SIGMOID_EXP] * x2)) - 0.02f;
+  }
+  if (bflags & HBF_FALOFF) return clampf(faloff, 0.0f, 1.0f);
+  if (bflags & HBF_FRESNEL) return clampf(lum * fresnelReflectionCoeff(fabsf(normAngle), 1.0f, m[HM_BLEND_FRESNEL_IOR]), 0.0f, 1.0f);
+  return clampf(lum, 0.0f, 1.0f);
+}
+struct BRDFSelector { float w; int localOffs; };
+HK_DEV BRDFSelector blendSelectBRDF(const float* m, float r3, f3 rayDir, f3 n, f2 tc, bool reflOnly, const SceneDev& s) {
+  float alpha = blendMaskAlpha2(m, rayDir, n, tc, s);
+  BRDFSelector m1, m2;
+  m1.localOffs = as_int(m[HM_BLEND_MAT1]); m2.localOffs = as_int(m[HM_BLEND_MAT2]);
+  m1.w = 1.0f; m2.w = 1.0f;
+  const int bflags = as_int(m[HM_BLEND_FLAGS]);
+  const bool comp1IsLeaf = matType(m + size_t(m1.localOffs) * HM_NODE_FLOATS) != HMT_BLEND_MASK;
+  if ((bflags & HBF_REFLECTION_WEIGHT_IS_ONE) && comp1IsLeaf) { m1.w = alpha; m2.w = 1.0f; }
+  if ((bflags & HBF_FRESNEL) != 0 && reflOnly) { m1.w = alpha; alpha = 1.0f; }
+  return (r3 <= alpha) ? m1 : m2;
+}
+HK_DEV bool isEyeRay(uint32_t flags) {   // cglobals.h:1366-1376
+  const uint32_t other = flags >> 16;
+  const bool nonSpec = (other & HRE_D) || (other & HRE_G);
+  return (((flags >> 8) & 0xFFu) == 0) || !nonSpec;
+}
+// MaterialSampleAndEvalBxDF, cmaterial.h:2345-2371 (random walk :2180-2207, leaf dispatch :2245-2335)
+HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit& sh, f3 rayDir, uint32_t rayFlags, const SceneDev& s, MatSample& out) {
+  const bool reflOnly = (((rayFlags >> 16) & 64u /*RAY_GRAMMAR_DIRECT_LIGHT*/) != 0) && ((matFlags(m) & HMF_CAN_SAMPLE_REFL_ONLY) != 0);
+  float mixW = 1.0f;
+  const float* node = m;
+  for (int i = 0; matType(node) == HMT_BLEND_MASK && i < 7; i++) {
+    const BRDFSelector sel = blendSelectBRDF(node, rands[3 + i], rayDir, sh.normal, sh.texCoord, reflOnly && (i == 0), s);
+    mixW = mixW * sel.w;
+    node = node + size_t(sel.localOffs) * HM_NODE_FLOATS;
+  }
+  out.color = mk3(0, 0, 0); out.direction = mk3(0, 1, 0); out.pdf = 1.0f; out.flags = 0;
+  switch (matType(node)) {
+    case HMT_PHONG: PhongSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
+    default: break;
+  }
+  if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
+  out.color = out.color * (1.0f / fmaxf(mixW, 0.015625f));
+  if ((matFlags(node) & HMF_SKIP_SKY_PORTAL) && isEyeRay(rayFlags)) { out.color = mk3(1, 1, 1); out.pdf = 1.0f; }
+}
+// materialEval, cmaterial.h:2554-2628 (leaf: :2425-2551)
+HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const SceneDev& s) {
+  BxDFResult val;
+  val.brdf = mk3(0, 0, 0); val.btdf = mk3(0, 0, 0); val.pdfFwd = 0.0f; val.pdfRev = 0.0f; val.diffuse = true;
+  float stackW[7]; int stackO[7];
+  int top = 0, currOffset = 0;
+  float currW = 1.0f;
+  do {
+    if (top > 0) { top--; currOffset = stackO[top]; currW = stackW[top]; }
+    const float* m = a_m + size_t(currOffset) * HM_NODE_FLOATS;
+    if (matType(m) == HMT_BLEND_MASK) {
+      const float alpha = blendMaskAlpha2(m, sc.v, sc.n, sc.tc, s);
+      const int o1 = as_int(m[HM_BLEND_MAT1]), o2 = as_int(m[HM_BLEND_MAT2]);
+      float w1 = alpha;
+      const float w2 = 1.0f - alpha;
+      if ((as_int(m[HM_BLEND_FLAGS]) & HBF_REFLECTION_WEIGHT_IS_ONE) && matType(m + size_t(o1) * HM_NODE_FLOATS) != HMT_BLEND_MASK) w1 = 1.0f;
+      if (top < 7) { stackW[top] = currW * w1; stackO[top] = currOffset + o1; top++; }
+      if (top < 7) { stackW[top] = currW * w2; stackO[top] = currOffset + o2; top++; }
+    } else {
+      f3 brdf = mk3(0, 0, 0);
+      float pf = 0.0f, pr = 0.0f;
+      bool diffuse = false;
+      const int type = matType(m);
+      if (type == HMT_PHONG) {
+        brdf = phongEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
+        pf = phongEvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
+        pr = phongEvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
+      } else if (type == HMT_LAMBERT) {
+        brdf = (lambertColor(m, sc.tc, s) * HK_INV_PI) * 1.0f;
+        pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
+        pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
+        diffuse = true;
+      }
+      val.brdf = val.brdf + (brdf * currW);
+      val.pdfFwd += currW * pf;
+      val.pdfRev += currW * pr;
+      val.diffuse = val.diffuse && diffuse;
+    }
+  } while (top > 0);
+  return val;
+}
+// materialEvalEmission, cmaterial.h:2918-2978
+HK_DEV f3 materialEvalEmission(const float* a_m, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  f3 val = mk3(0, 0, 0);
+  float stackW[7]; int stackO[7];
+  int top = 0, currOffset = 0;
+  float currW = 1.0f;
+  do {
+    if (top > 0) { top--; currOffset = stackO[top]; currW = stackW[top]; }
+    const float* m = a_m + size_t(currOffset) * HM_NODE_FLOATS;
+    if (matType(m) == HMT_BLEND_MASK) {
+      const float alpha = blendMaskAlpha2(m, v, n, tc, s);
+      const int o1 = as_int(m[HM_BLEND_MAT1]), o2 = as_int(m[HM_BLEND_MAT2]);
+      if (top < 7) { stackW[top] = currW * alpha; stackO[top] = currOffset + o1; top++; }
+      if (top < 7) { stackW[top] = currW * (1.0f - alpha); stackO[top] = currOffset + o2; top++; }
+    }
+    const f3 e = mk3(m[HM_EMISSIVE_COLOR], m[HM_EMISSIVE_COLOR + 1], m[HM_EMISSIVE_COLOR + 2]) * sample2DExt(as_int(m[HM_EMISSIVE_TEXMATRIXID]), tc, m, s);
+    val = val + (e * currW);
+  } while (top > 0);
+  return val;
+}
+HK_DEV uint32_t flagsNextBounceLite(uint32_t flags, const MatSample& ms, const SceneDev& s) {   // cmaterial.h:3262-3293
+  const uint32_t bounce = (flags >> 8) & 0xFFu, diff = flags & 0xFFu;
+  uint32_t other = flags >> 16;
+  flags = (flags & 0xFFFF00FFu) | ((bounce + 1) << 8);
+  if (ms.flags & HRE_D) flags = (flags & 0xFFFFFF00u) | (diff + 1);
+  const uint32_t diff2 = flags & 0xFFu;
+  if (((bounce + 1) >= uint32_t(g_varsI(s)[HV_I_TRACE_DEPTH])) || (diff2 >= uint32_t(g_varsI(s)[HV_I_DIFFUSE_TRACE_DEPTH]) + 1)) other |= HRF_IS_DEAD;
+  if (ms.flags & HRE_G) other |= HRE_G;
+  if ((ms.flags & HRE_S) || (ms.flags & HRE_T)) other |= HRE_S;
+  if (ms.flags & HRE_D) other |= HRE_D;
+  if (ms.flags & HRE_T) other |= HRE_T;
+  return (flags & 0x0000FFFFu) | (other << 16);
+}
+
+// ================================================================================================ lights
+HK_DEV const float* lightAt(const SceneDev& s, int id) {   // clight.h:1739-1749
+  if (id < 0) return nullptr;
+  return reinterpret_cast<const float*>(s.globals + s.globals[HG_LIGHTS_OFFS]) + size_t(id) * HL_FLOATS;
+}
+HK_DEV f3 lightPos(const float* L) { return mk3(L[HL_POS], L[HL_POS + 1], L[HL_POS + 2]); }
+HK_DEV f3 lightNorm(const float* L) { return mk3(L[HL_NORM], L[HL_NORM + 1], L[HL_NORM + 2]); }
+HK_DEV f3 lightColor(const float* L) { return mk3(L[HL_COLOR], L[HL_COLOR + 1], L[HL_COLOR + 2]); }
+
+HK_DEV float areaDiffuseLightEvalPDF(const float* L, f3 rayDir, float hitDist) {   // clight.h:524-530, PdfAtoW cglobals.h:1754-1757
+  const float pdfA = 1.0f / fmaxf(L[HL_SURFACE_AREA], HK_DEPSILON);
+  const float d = dot(rayDir, lightNorm(L) * (-1.0f));
+  const float cosVal = (as_int(L[HL_FLAGS]) & HLF_HAS_IES) ? fabsf(d) : fmaxf(d, 0.0f);
+  return (pdfA * hitDist * hitDist) / fmaxf(cosVal, HK_DEPSILON2);
+}
+HK_DEV f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, bool eyeRay) {   // clight.h:542-611 (plain / spot distributions)
+  f3 color = lightColor(L);
+  if (as_int(L[HL_AREA_SPOT_DISTR]) != 0) {
+    const float cos1 = L[HL_AREA_SPOT_COS1], cos2 = L[HL_AREA_SPOT_COS2];
+    const float cos_theta = fmaxf(dot(rayDir * (-1.0f), lightNorm(L)), 0.0f);
+    const float tt = fminf(fmaxf((cos_theta - cos2) / (cos1 - cos2), 0.0f), 1.0f);
+    const float atten = tt * tt * (3.0f - 2.0f * tt);
+    if (!eyeRay) color = color * clampf(atten, 0.0f, 1.0f);
+    else color = color * (1.0f / fmaxf(color.x, fmaxf(color.y, color.z)));
+  }
+  return color;
+}
+struct ShadowSample { f3 pos, color; float pdf, maxDist, cosAtLight; bool isPoint; };   // cglobals.h:2448-2456
+HK_DEV void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:1180-1229
+  const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
+  f3 sp = mk3(offsetX * L[HL_AREA_SIZE_X], 0.0f, offsetY * L[HL_AREA_SIZE_Y]);
+  if (as_int(L[HL_AREA_IS_DISK]) != 0) {
+    const f2 xz = MapSamplesToDisc(mk2(offsetX, offsetY));
+    sp = mk3(xz.x * L[HL_AREA_SIZE_X], 0, xz.y * L[HL_AREA_SIZE_X]);
+  }
+  const float* M = L + HL_AREA_MATRIX;
+  sp = mk3(M[0] * sp.x + M[1] * sp.y + M[2] * sp.z, M[3] * sp.x + M[4] * sp.y + M[5] * sp.z, M[6] * sp.x + M[7] * sp.y + M[8] * sp.z);
+  sp = sp + lightPos(L);
+  const f3 rayDir = normalize(sp - illum);
+  const float hitDist = length(sp - illum);
+  const f3 ln = lightNorm(L);
+  out.isPoint = false;
+  out.pos = sp + ln * epsilonOfPos(sp);
+  out.color = areaDiffuseLightGetIntensity(L, rayDir, false);
+  out.pdf = areaDiffuseLightEvalPDF(L, rayDir, hitDist);
+  out.maxDist = hitDist;
+  out.cosAtLight = -dot(rayDir, ln);
+}
+HK_DEV int SelectIndexPropToOpt(float a_r, const float* a_accum, int N, float& pPDF) {   // cglobals.h:2808-2859
+  int leftBound = 0, rightBound = N - 2, counter = 0, currPos = -1;
+  const float x = a_r * a_accum[N - 1];
+  while (rightBound - leftBound > 1 && counter < 50) {
+    const int currSize = rightBound + leftBound;
+    const int currPos1 = (currSize % 2 == 0) ? (currSize + 1) / 2 : (currSize + 0) / 2;
+    const float a = a_accum[currPos1], b = a_accum[currPos1 + 1];
+    if (a < x && x <= b) { currPos = currPos1; break; }
+    else if (x <= a) rightBound = currPos1;
+    else if (x > b) leftBound = currPos1;
+    counter++;
+  }
+  if (currPos < 0) {
+    if (a_accum[leftBound] < x && x <= a_accum[leftBound + 1]) currPos = leftBound;
+    if (a_accum[rightBound] < x && x <= a_accum[rightBound + 1]) currPos = rightBound;
+  }
+  if (x == 0.0f) currPos = 0;
+  else if (currPos < 0) currPos = (rightBound + leftBound + 1) / 2;
+  pPDF = (a_accum[currPos + 1] - a_accum[currPos]) / a_accum[N - 1];
+  return currPos;
+}
+HK_DEV int SelectRandomLightRev(float r, const SceneDev& s, float& pickProb) {   // clight.h:1774-1793
+  const int tableSize = s.globals[HG_LSEL_REV_SIZE];
+  pickProb = 1.0f;
+  if (tableSize == 0) return -1;
+  if (tableSize <= 2) return 0;
+  return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.globals[HG_LSEL_REV_OFFS]), tableSize, pickProb);
+}
+// emissionEval, cbidir.h:653-678 (+ lightGetIntensity clight.h:1661-1706 for area lights)
+HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_dir, const SurfaceHit& sh, uint32_t flags, const float* pLight, const float* mat) {
+  const f3 normal = sh.hfi ? sh.normal * (-1.0f) : sh.normal;
+  const int lightsNum = s.globals[HG_LIGHTS_NUM];
+  bool hasIES = false;
+  if (lightsNum > 0 && pLight != nullptr) hasIES = (as_int(pLight[HL_FLAGS]) & HLF_HAS_IES) != 0;
+  if (dot(ray_dir, normal) >= 0.0f && !hasIES) return mk3(0, 0, 0);
+  f3 out = materialEvalEmission(mat, ray_dir, normal, sh.texCoord, s);
+  if ((matFlags(mat) & HMF_FORBID_EMISSIVE_GI) && (flags & 0xFFu) > 0) out = mk3(0, 0, 0);
+  if (lightsNum > 0 && pLight != nullptr) {
+    if (as_int(pLight[HL_TYPE]) == HLT_AREA) out = areaDiffuseLightGetIntensity(pLight, ray_dir, (flags & 0xFFu) == 0);
+    else out = lightColor(pLight);
+  }
+  return out;
+}

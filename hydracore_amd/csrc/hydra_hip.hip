@@ -1,0 +1,987 @@
+// hydra_hip.hip -- libhydra_hip.so: wavefront path-tracing core for MI355X (gfx950) behind the C-ABI of
+// include/hydra_hip.h.  Stage split (BASELINE.json north_star): ray generation, BVH4 traversal + Moeller-Trumbore,
+// hit/emission/light-sample with wave-ballot compaction, any-hit shadow traversal, BSDF shade + next bounce,
+// framebuffer accumulate.  Reference behaviour: IntegratorMISPTLoop2 (hydra_drv/CPUExp_Integrators_PT_Loop.cpp:264-321),
+// pass driver IntegratorCommon::DoPass (CPUExp_Integrators_Common.cpp:278-316).
+//
+// HBM layout (SoA, one entry per live path, all float4 so every lane moves 16 B per access):
+//   S.pos4  = ray origin xyz | pixel index         S.dir4 = ray direction xyz | ray flags
+//   S.thr4  = path throughput xyz | prev BSDF pdf  S.acc4 = accumulated radiance xyz | prev-bounce-was-specular
+//   S.rng2  = RandomGen state
+// K_hit writes survivors densely into the M (mid) arrays via a wave-aggregated atomic, so the shadow and shade
+// kernels and the next bounce always read contiguous, fully coalesced arrays; live counts stay on the device
+// (live[bounce]) and every kernel is a grid-stride loop over *count, so a whole pass is enqueued without host syncs.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+#include "../../include/hydra_hip.h"
+#include "hk_common.h"
+#include "hk_trace.h"
+#include "hk_shading.h"
+
+// ================================================================================================ device state
+struct PathState {   // S arrays
+  float4* pos4; float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
+};
+struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
+  float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
+  float4* surfA;      // hit position xyz | matId
+  float4* surfB;      // shading normal xyz | texCoord.x
+  float4* recC;       // direction to the light sample xyz | texCoord.y
+  float4* recD;       // light radiance xyz | light pdf (negative when the sample is a point light)
+  float4* recE;       // light pick prob | lightOffset | pixel | unused
+  float4* shadowOrg;  // shadow ray origin xyz | t_far
+  float*  vis;        // shadow result
+};
+
+#define HK_MAX_DEPTH 64
+
+HK_DEV int wave_compact_index(bool alive, uint32_t* counter) {
+  const unsigned long long mask = __ballot(alive);
+  const int lane = int(__lane_id());
+  int base = 0;
+  if (mask != 0ull) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = int(atomicAdd(counter, uint32_t(__popcll(mask))));
+    base = __shfl(base, leader);
+  }
+  return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ================================================================================================ kernels
+// P1 -- ray generation: IntegratorCommon::makeEyeRay (Common.cpp:347-359) for every owned pixel
+__global__ void k_raygen(SceneDev s, int n, const int* __restrict__ slotPixel, const uint2* __restrict__ gens, int w, int h, PathState S) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int pixel = slotPixel[i];
+    const uint2 g2 = gens[pixel];
+    RandomGen gen; gen.x = g2.x; gen.y = g2.y;
+    const float4 r = rndFloat4_Pseudo(gen);   // rndUniform(gen, -1, 1), crandom.h:617-620
+    const float4 offs = make_float4(-1.0f + 2.0f * r.x, -1.0f + 2.0f * r.y, -1.0f + 2.0f * r.z, -1.0f + 2.0f * r.w);
+    f3 pos, dir;
+    MakeRandEyeRay(pixel % w, pixel / w, w, h, offs, s, pos, dir);
+    S.pos4[i] = mk4(pos, as_float(pixel));
+    S.dir4[i] = mk4(dir, as_float(0));
+    S.thr4[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // kernel_InitAccumData + makeInitialMisData (pdf = 1)
+    S.acc4[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // isSpecular = 1
+    S.rng2[i] = make_uint2(gen.x, gen.y);
+  }
+}
+
+// T1 -- closest hit for every live path (kernel_RayTrace)
+template <bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
+                                                           const float4* __restrict__ pos4, const float4* __restrict__ dir4,
+                                                           HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3) {
+  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+  const int count = countPtr ? int(*countPtr) : countImm;
+  HkStack st;
+  st.lds = ldsStack + threadIdx.x;
+  st.stride = HK_TRACE_BLOCK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
+    TravCounters c = {0, 0, 0};
+    const HydraLiteHit hit = hk_traverse<false, COUNT>(s.bvh, s.tris, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
+    reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
+    if (COUNT) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
+  }
+}
+
+// T2 -- any-hit visibility: origin xyz | t_far, direction xyz (kernel_ShadowTrace)
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
+                                                            const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis) {
+  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+  const int count = countPtr ? int(*countPtr) : countImm;
+  HkStack st;
+  st.lds = ldsStack + threadIdx.x;
+  st.stride = HK_TRACE_BLOCK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float4 o = org4[i];
+    float v = 0.0f;
+    if (o.w >= 0.0f) {   // t_far < 0 marks "no light sample": shadow = 0 (PT_Loop.cpp:175-178)
+      HydraLiteHit h = hk_miss_hit();
+      h.t = o.w;
+      TravCounters c = {0, 0, 0};
+      h = hk_traverse<true, false>(s.bvh, s.tris, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
+      v = (h.primId != -1) ? 0.0f : 1.0f;
+    }
+    vis[i] = v;
+  }
+}
+
+// H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample; survivors are
+// compacted into M (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample)
+__global__ void __launch_bounds__(256) k_hit(SceneDev s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
+                                              uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
+                                              const HydraLiteHit* __restrict__ hits, MidState M,
+                                              float4* __restrict__ contrib, uint2* __restrict__ gens) {
+  const int count = int(*countPtr);
+  for (int base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const int i = base + threadIdx.x;
+    bool alive = false;
+    float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
+    RandomGen gen; gen.x = gen.y = 0;
+    SurfaceHit surf;
+    float4 recC = pos4, recD = pos4, recE = pos4, shadowOrg = make_float4(0, 0, 0, -1.0f);
+    bool wantShadow = false;
+    if (i < count) {
+      pos4 = S.pos4[i]; dir4 = S.dir4[i]; thr4 = S.thr4[i]; acc4 = S.acc4[i];
+      const uint2 g2 = S.rng2[i];
+      gen.x = g2.x; gen.y = g2.y;
+      const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
+      HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
+      const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
+      const uint32_t flags = uint32_t(as_int(dir4.w));
+      const int pixel = as_int(pos4.w);
+      f3 currColor = mk3(0, 0, 0);
+      bool done = false;
+      if (!HitSome(hit)) done = true;   // environmentColor: no sky light in the supported subset => black (cbidir.h:498-499)
+      else {
+        surf = evalSurface(s, ray_pos, ray_dir, hit);
+        const float* mat = materialAt(s, surf.matId);
+        const int lightOffset0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
+        const float* pLightHit = lightAt(s, lightOffset0);
+        const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
+        if (dot(emission, emission) > 1e-3f) {
+          if (pLightHit != nullptr) {
+            const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, length(ray_pos - surf.pos));
+            float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
+            if (acc4.w != 0.0f) misWeight = 1.0f;
+            currColor = emission * misWeight;
+          } else
+            currColor = emission;
+          done = true;
+        } else if (depth >= maxDepth - 1) done = true;
+      }
+      if (done) {
+        const f3 final = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
+        contrib[pixel] = mk4(final, 0.0f);
+        gens[pixel] = make_uint2(gen.x, gen.y);
+      } else {
+        alive = true;
+        const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
+        float lightPickProb = 1.0f;
+        const int lightOffset = SelectRandomLightRev(rl.z, s, lightPickProb);
+        f3 shadowRayDir = mk3(0, 0, 0);
+        ShadowSample sam;
+        sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
+        if (lightOffset >= 0) {
+          AreaLightSampleRev(lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // LightSampleRev, clight.h:1561-1610
+          shadowRayDir = normalize(sam.pos - surf.pos);
+          const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
+          shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
+          wantShadow = true;
+        }
+        recC = mk4(shadowRayDir, surf.texCoord.y);
+        recD = mk4(sam.color, sam.isPoint ? -sam.pdf : sam.pdf);
+        recE = make_float4(lightPickProb, as_float(lightOffset), as_float(pixel), 0.0f);
+      }
+    }
+    const int dst = wave_compact_index(alive, nextCount);
+    (void)wave_compact_index(wantShadow, shadowCount);
+    if (alive) {
+      M.dir4[dst] = dir4; M.thr4[dst] = thr4; M.acc4[dst] = acc4; M.rng2[dst] = make_uint2(gen.x, gen.y);
+      M.surfA[dst] = mk4(surf.pos, as_float(surf.matId));
+      M.surfB[dst] = mk4(surf.normal, surf.texCoord.x);
+      M.recC[dst] = recC; M.recD[dst] = recD; M.recE[dst] = recE; M.shadowOrg[dst] = shadowOrg;
+    }
+  }
+}
+
+// S1 + S2 -- next-event shading and BSDF sampling of the next bounce (kernel_Shade, kernel_NextBounce)
+__global__ void __launch_bounds__(256) k_shade(SceneDev s, const uint32_t* __restrict__ countPtr, MidState M, PathState S) {
+  const int count = int(*countPtr);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float4 dir4 = M.dir4[i], thr4 = M.thr4[i], acc4 = M.acc4[i];
+    const float4 sa = M.surfA[i], sb = M.surfB[i], rc = M.recC[i], rd = M.recD[i], re = M.recE[i];
+    const uint2 g2 = M.rng2[i];
+    RandomGen gen; gen.x = g2.x; gen.y = g2.y;
+    const f3 ray_dir = xyz(dir4);
+    uint32_t flags = uint32_t(as_int(dir4.w));
+    SurfaceHit surf;
+    surf.pos = xyz(sa); surf.matId = as_int(sa.w); surf.normal = xyz(sb); surf.texCoord = mk2(sb.w, rc.w);
+    const float* mat = materialAt(s, surf.matId);
+    const int lightOffset = as_int(re.y);
+    const float lightPickProb = re.x;
+
+    f3 explicitColor = mk3(0, 0, 0);
+    if (lightOffset >= 0) {
+      const f3 shadowRayDir = xyz(rc);
+      ShadeContext sc;
+      sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
+      const BxDFResult ev = materialEval(mat, sc, s);
+      const float cos1 = fmaxf(+dot(shadowRayDir, surf.normal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surf.normal), 0.0f);
+      const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
+      const float samPdf = fabsf(rd.w);
+      float misWeight = misWeightHeuristic(samPdf * lightPickProb, ev.pdfFwd);
+      if (rd.w < 0.0f) misWeight = 1.0f;
+      const f3 lc = xyz(rd) * (1.0f / fmaxf(samPdf, HK_DEPSILON2));
+      explicitColor = (((lc * (1.0f / lightPickProb)) * bxdfVal) * misWeight) * M.vis[i];
+    }
+    float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
+    {
+      const float4 r4 = rndFloat4_Pseudo(gen);
+      rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
+      for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
+    }
+    MatSample ms;
+    MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
+    const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
+    const float cosTheta = fabsf(dot(ms.direction, surf.normal));
+    const f3 newPos = OffsRayPos(surf.pos, surf.normal, ms.direction);
+    const bool isSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
+    flags = flagsNextBounceLite(flags, ms, s);
+    const f3 accum = xyz(acc4) + (xyz(thr4) * explicitColor);
+    const f3 thr = xyz(thr4) * (bxdfVal * cosTheta);
+    S.pos4[i] = mk4(newPos, re.z);
+    S.dir4[i] = mk4(ms.direction, as_float(int(flags)));
+    S.thr4[i] = mk4(thr, ms.pdf);
+    S.acc4[i] = mk4(accum, isSpec ? 1.0f : 0.0f);
+    S.rng2[i] = make_uint2(gen.x, gen.y);
+  }
+}
+
+// F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
+__global__ void k_accumulate(int n, const int* __restrict__ slotPixel, const float4* __restrict__ contrib, float4* __restrict__ accum) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int pixel = slotPixel[i];
+    const float4 c = contrib[pixel];
+    float4 a = accum[pixel];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    accum[pixel] = a;
+  }
+}
+__global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __restrict__ shadowCnt, int maxDepth, unsigned long long* totals) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long e = 0, sh = 0;
+    for (int b = 0; b < maxDepth; b++) { e += live[b]; sh += shadowCnt[b]; }
+    totals[0] += e; totals[1] += sh; totals[2] += live[0];
+  }
+}
+__global__ void k_init_gens(int n, int seed, uint2* gens) {   // InitRandomGen, shaders/trace.cl:6-13 (slot = pixel)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const RandomGen g = RandomGenInit(seed + i);
+    gens[i] = make_uint2(g.x, g.y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- stage kernels (tests)
+__global__ void k_stage_eye(SceneDev s, int n, int w, int h, const int* xy, const float4* offs, float4* pos4, float4* dir4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f3 p, d;
+  MakeRandEyeRay(xy[2 * i], xy[2 * i + 1], w, h, offs[i], s, p, d);
+  pos4[i] = mk4(p, 0.0f);
+  dir4[i] = mk4(d, 0.0f);
+}
+__global__ void k_stage_surface(SceneDev s, int n, const float4* pos4, const float4* dir4, const HydraLiteHit* hits, float* out24) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* r = out24 + size_t(i) * 24;
+  for (int k = 0; k < 24; k++) r[k] = 0.0f;
+  const HydraLiteHit hit = hits[i];
+  if (!HitSome(hit)) { r[17] = as_float(-1); return; }
+  const SurfaceHit sh = evalSurface(s, xyz(pos4[i]), xyz(dir4[i]), hit);
+  r[0] = sh.pos.x; r[1] = sh.pos.y; r[2] = sh.pos.z; r[3] = sh.normal.x; r[4] = sh.normal.y; r[5] = sh.normal.z;
+  r[6] = sh.flatNormal.x; r[7] = sh.flatNormal.y; r[8] = sh.flatNormal.z; r[9] = sh.tangent.x; r[10] = sh.tangent.y; r[11] = sh.tangent.z;
+  r[12] = sh.biTangent.x; r[13] = sh.biTangent.y; r[14] = sh.biTangent.z; r[15] = sh.texCoord.x; r[16] = sh.texCoord.y;
+  r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
+}
+__global__ void k_stage_random(int n, const int* seeds, int draws, float4* out4, uint2* state2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  RandomGen g = RandomGenInit(seeds[i]);
+  for (int d = 0; d < draws; d++) out4[size_t(i) * draws + d] = rndFloat4_Pseudo(g);
+  state2[i] = make_uint2(g.x, g.y);
+}
+// one whole path per lane: the same device functions as the wavefront kernels, strung together the way
+// IntegratorMISPTLoop2::PathTrace does (PT_Loop.cpp:264-321); used for function-level parity of the shading code.
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_stage_path(SceneDev s, int n, const float4* pos4, const float4* dir4, uint2* rng2, float4* color4) {
+  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  HkStack st;
+  st.lds = ldsStack + threadIdx.x;
+  st.stride = HK_TRACE_BLOCK;
+  TravCounters tc = {0, 0, 0};
+  f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
+  RandomGen gen; gen.x = rng2[i].x; gen.y = rng2[i].y;
+  f3 accumColor = mk3(0, 0, 0), thr = mk3(1, 1, 1), currColor = mk3(0, 0, 0);
+  float misPdf = 1.0f; bool misSpec = true;
+  uint32_t flags = 0;
+  float rays = 0.0f;
+  const int maxDepth = g_varsI(s)[HV_I_TRACE_DEPTH];
+  for (int depth = 0; depth < maxDepth; depth++) {
+    const HydraLiteHit hit = hk_traverse<false, false>(s.bvh, s.tris, s.haveInst != 0, ray_pos, ray_dir, 0.0f, hk_miss_hit(), st, tc);
+    rays += 1.0f;
+    if (!HitSome(hit)) { currColor = mk3(0, 0, 0); break; }
+    const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
+    const float* mat = materialAt(s, surf.matId);
+    {
+      const int lo0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
+      const float* pL = lightAt(s, lo0);
+      const f3 emission = emissionEval(s, ray_dir, surf, flags, pL, mat);
+      if (dot(emission, emission) > 1e-3f) {
+        if (pL != nullptr) {
+          const float lgtPdf = pL[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pL, ray_dir, length(ray_pos - surf.pos));
+          float w = misWeightHeuristic(misPdf, lgtPdf);
+          if (misSpec) w = 1.0f;
+          currColor = emission * w;
+        } else currColor = emission;
+        break;
+      } else if (depth >= maxDepth - 1) { currColor = mk3(0, 0, 0); break; }
+    }
+    const float4 rl = rndFloat4_Pseudo(gen);
+    float pick = 1.0f;
+    const int lightOffset = SelectRandomLightRev(rl.z, s, pick);
+    f3 explicitColor = mk3(0, 0, 0);
+    if (lightOffset >= 0) {
+      ShadowSample sam;
+      AreaLightSampleRev(lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);
+      const f3 sdir = normalize(sam.pos - surf.pos);
+      const f3 spos = OffsShadowRayPos(surf.pos, surf.normal, sdir, surf.sRayOff);
+      HydraLiteHit sh = hk_miss_hit();
+      sh.t = length(spos - sam.pos) * 0.995f;
+      sh = hk_traverse<true, false>(s.bvh, s.tris, s.haveInst != 0, spos, sdir, 0.0f, sh, st, tc);
+      rays += 1.0f;
+      const float shadow = (sh.primId != -1) ? 0.0f : 1.0f;
+      ShadeContext sc;
+      sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
+      const BxDFResult ev = materialEval(mat, sc, s);
+      const float cos1 = fmaxf(+dot(sdir, surf.normal), 0.0f), cos2 = fmaxf(-dot(sdir, surf.normal), 0.0f);
+      const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
+      float w = misWeightHeuristic(sam.pdf * pick, ev.pdfFwd);
+      if (sam.isPoint) w = 1.0f;
+      const f3 lc = sam.color * (1.0f / fmaxf(sam.pdf, HK_DEPSILON2));
+      explicitColor = (((lc * (1.0f / pick)) * bxdfVal) * w) * shadow;
+    }
+    float rands[10];
+    {
+      const float4 r4 = rndFloat4_Pseudo(gen);
+      rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
+      for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
+    }
+    MatSample ms;
+    MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
+    const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
+    const float cosTheta = fabsf(dot(ms.direction, surf.normal));
+    ray_dir = ms.direction;
+    ray_pos = OffsRayPos(surf.pos, surf.normal, ms.direction);
+    misSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
+    misPdf = ms.pdf;
+    flags = flagsNextBounceLite(flags, ms, s);
+    accumColor = accumColor + (thr * explicitColor);
+    thr = thr * (bxdfVal * cosTheta);
+  }
+  accumColor = accumColor + (thr * currColor);
+  color4[i] = mk4(accumColor, rays);
+  rng2[i] = make_uint2(gen.x, gen.y);
+}
+
+// ================================================================================================ host side
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct hydra_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int w = 0, h = 0;
+  std::string err;
+  char devName[256] = {0};
+  int numCU = 256;
+
+  DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, remapLists, remapTable, remapInst;
+  size_t globalsWords = 0;
+  int haveInst[4] = {0, 0, 0, 0};
+  int treesNum = 0, instNum = 0;
+  int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
+  std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
+
+  // render state
+  int rank = 0, world = 1, tile = 64;
+  int N = 0;                         // owned pixels = path slots
+  DevBuf slotPixel, gens, accumInternal, contrib, hits, live, shadowCnt, totals;
+  float4* accum = nullptr;           // internal or external
+  bool externalAccum = false;
+  DevBuf sPos, sDir, sThr, sAcc, sRng;
+  DevBuf mDir, mThr, mAcc, mRng, mSurfA, mSurfB, mRecC, mRecD, mRecE, mShadowOrg, mVis;
+  bool stateAllocated = false, gensReady = false;
+  int seed = 777;
+  float spp = 0.0f;
+
+  bool stageTiming = false;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
+  std::vector<hipEvent_t> evPool;
+  struct EvSpan { int a, b, kind; };
+  std::vector<EvSpan> spans;
+};
+
+static std::string g_createError;
+
+#define HCHECK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      c->err = std::string(#call) + ": " + hipGetErrorString(e_);                                      \
+      return HYDRA_HIP_EDEVICE;                                                                        \
+    }                                                                                                  \
+  } while (0)
+
+static int fail(hydra_hip_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_createError = msg;
+  return code;
+}
+
+static int dev_alloc(hydra_hip_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.p != nullptr && b.bytes >= bytes && bytes > 0) return HYDRA_HIP_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  if (bytes == 0) return HYDRA_HIP_OK;
+  if (hipMalloc(&b.p, bytes) != hipSuccess) { c->err = "hipMalloc failed for " + std::to_string(bytes) + " bytes"; return HYDRA_HIP_ENOMEM; }
+  b.bytes = bytes;
+  return HYDRA_HIP_OK;
+}
+static int dev_upload(hydra_hip_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+  const size_t alloc = bytes > 0 ? bytes : 16;   // never hand a null pointer to a kernel
+  int rc = dev_alloc(c, b, alloc);
+  if (rc != HYDRA_HIP_OK) return rc;
+  if (bytes > 0) HCHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HCHECK(hipStreamSynchronize(c->stream));       // the caller may free `src` right after the call
+  return HYDRA_HIP_OK;
+}
+static void dev_free(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+
+static SceneDev make_scene(const hydra_hip_ctx* c) {
+  SceneDev s;
+  s.globals = static_cast<const int*>(c->globals.p);
+  s.texStorage = static_cast<const int4*>(c->storage[HYDRA_STORAGE_TEXTURES].p);
+  s.geomStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_GEOM].p);
+  s.matStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_MATERIALS].p);
+  s.pdfStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_PDFS].p);
+  s.bvh = static_cast<const float4*>(c->bvhNodes[0].p);
+  s.tris = static_cast<const float4*>(c->bvhTris[0].p);
+  s.haveInst = c->haveInst[0];
+  s.instMatrices = static_cast<const float4*>(c->instMat.p);
+  s.instLightInstId = static_cast<const int*>(c->instLight.p);
+  s.instNum = c->instNum;
+  s.remapLists = c->remapListsSize > 0 ? static_cast<const int*>(c->remapLists.p) : nullptr; s.remapListsSize = c->remapListsSize;
+  s.remapTable = c->remapTableSize > 0 ? static_cast<const int*>(c->remapTable.p) : nullptr; s.remapTableSize = c->remapTableSize;
+  s.remapInst = c->remapInstSize > 0 ? static_cast<const int*>(c->remapInst.p) : nullptr;   s.remapInstSize = c->remapInstSize;
+  return s;
+}
+static bool scene_ready(const hydra_hip_ctx* c) {
+  return c->globals.p && c->bvhNodes[0].p && c->bvhTris[0].p && c->instMat.p && c->instLight.p &&
+         c->storage[HYDRA_STORAGE_GEOM].p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->treesNum >= 1;
+}
+static int grid_for(const hydra_hip_ctx* c, int n, int block, int blocksPerCU) {
+  int g = (n + block - 1) / block;
+  const int cap = c->numCU * blocksPerCU;
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : g;
+}
+
+// slot -> pixel map: owned tiles (tile % world == rank), pixels inside a tile in 8x8 blocks so that one wave = one block
+static void build_slot_map(hydra_hip_ctx* c, std::vector<int>& out) {
+  out.clear();
+  const int T = c->tile, w = c->w, h = c->h;
+  const int tilesX = (w + T - 1) / T, tilesY = (h + T - 1) / T;
+  for (int ty = 0; ty < tilesY; ty++)
+    for (int tx = 0; tx < tilesX; tx++) {
+      const int t = ty * tilesX + tx;
+      if (c->world > 1 && (t % c->world) != c->rank) continue;
+      const int x0 = tx * T, y0 = ty * T, x1 = std::min(x0 + T, w), y1 = std::min(y0 + T, h);
+      for (int by = y0; by < y1; by += 8)
+        for (int bx = x0; bx < x1; bx += 8)
+          for (int y = by; y < std::min(by + 8, y1); y++)
+            for (int x = bx; x < std::min(bx + 8, x1); x++) out.push_back(y * w + x);
+    }
+}
+
+static int alloc_render_state(hydra_hip_ctx* c) {
+  std::vector<int> slots;
+  build_slot_map(c, slots);
+  c->N = int(slots.size());
+  const size_t npix = size_t(c->w) * c->h, N = size_t(std::max(c->N, 1));
+  int rc;
+  if ((rc = dev_upload(c, c->slotPixel, slots.data(), slots.size() * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->gens, npix * 8)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->contrib, npix * 16)) != 0) return rc;
+  if (!c->externalAccum) {
+    const bool fresh = (c->accumInternal.bytes < npix * 16);
+    if ((rc = dev_alloc(c, c->accumInternal, npix * 16)) != 0) return rc;
+    if (fresh) HCHECK(hipMemsetAsync(c->accumInternal.p, 0, npix * 16, c->stream));
+    c->accum = static_cast<float4*>(c->accumInternal.p);
+  }
+  DevBuf* f4s[] = {&c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->mDir, &c->mThr, &c->mAcc, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->hits};
+  for (DevBuf* b : f4s) if ((rc = dev_alloc(c, *b, N * 16)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->sRng, N * 8)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->mRng, N * 8)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->mVis, N * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->live, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->shadowCnt, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
+  if (c->totals.p == nullptr) {
+    if ((rc = dev_alloc(c, c->totals, 4 * 8)) != 0) return rc;
+    HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream));
+  }
+  c->stateAllocated = true;
+  return HYDRA_HIP_OK;
+}
+
+extern "C" {
+
+int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_handle* out) {
+  (void)flags;
+  if (out == nullptr || width <= 0 || height <= 0) return fail(nullptr, HYDRA_HIP_EINVAL, "hydra_hip_create: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HYDRA_HIP_ENODEV, "hydra_hip_create: no HIP device available (the HIP layer has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, HYDRA_HIP_ENODEV, "hydra_hip_create: bad device id");
+  if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, HYDRA_HIP_ENODEV, "hydra_hip_create: hipSetDevice failed");
+  hydra_hip_ctx* c = new hydra_hip_ctx();
+  c->device = device_id;
+  c->w = width; c->h = height;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    snprintf(c->devName, sizeof(c->devName), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    c->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  c->stream = nullptr;   // the null stream: ordered with torch's default stream and with plain hipMemcpy
+  *out = c;
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_destroy(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->gens, &c->accumInternal,
+                   &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->mDir, &c->mThr, &c->mAcc,
+                   &c->mRng, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
+  for (DevBuf* b : all) dev_free(*b);
+  for (auto& b : c->storage) dev_free(b);
+  for (auto& b : c->bvhNodes) dev_free(b);
+  for (auto& b : c->bvhTris) dev_free(b);
+  for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
+  delete c;
+  return HYDRA_HIP_OK;
+}
+
+const char* hydra_hip_last_error(hydra_hip_handle c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+int hydra_hip_device_name(hydra_hip_handle c, char* buf, int n) {
+  if (!c || !buf || n <= 0) return HYDRA_HIP_EINVAL;
+  strncpy(buf, c->devName, size_t(n - 1));
+  buf[n - 1] = 0;
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_resize(hydra_hip_handle c, int width, int height) {
+  if (!c || width <= 0 || height <= 0) return HYDRA_HIP_EINVAL;
+  if (width == c->w && height == c->h && c->stateAllocated) return HYDRA_HIP_OK;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipDeviceSynchronize());
+  c->w = width; c->h = height;
+  dev_free(c->accumInternal);
+  c->stateAllocated = false; c->gensReady = false;
+  c->spp = 0.0f;
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_available_memory(hydra_hip_handle c, size_t* free_bytes, size_t* total_bytes) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  size_t f = 0, t = 0;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_finish(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->stream));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t words) {
+  if (!c || !blob || words < HG_HEADER_WORDS) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: blob shorter than the EngineGlobals header");
+  HCHECK(hipSetDevice(c->device));
+  c->globalsWords = words;
+  c->hostHeader.assign(blob, blob + HG_TABLES_READY + 1);
+  return dev_upload(c, c->globals, blob, words * 4);
+}
+int hydra_hip_update_globals_header(hydra_hip_handle c, const int32_t* blob, size_t words) {
+  if (!c || !blob || words == 0 || words > c->globalsWords || c->globals.p == nullptr) return fail(c, HYDRA_HIP_ESTATE, "update_globals_header: upload_globals first");
+  HCHECK(hipSetDevice(c->device));
+  const size_t keep = std::min<size_t>(words, HG_TABLES_READY + 1);
+  c->hostHeader.assign(blob, blob + keep);
+  HCHECK(hipMemcpyAsync(c->globals.p, blob, words * 4, hipMemcpyHostToDevice, c->stream));
+  HCHECK(hipStreamSynchronize(c->stream));
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, size_t bytes) {
+  if (!c || kind < 0 || kind >= HYDRA_STORAGE_KINDS || (bytes > 0 && !data)) return fail(c, HYDRA_HIP_EINVAL, "upload_storage: bad arguments");
+  HCHECK(hipSetDevice(c->device));
+  return dev_upload(c, c->storage[kind], data, bytes);
+}
+int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes, int nodes_num, const float* tri_f4, int tri_f4_num,
+                         const uint32_t* alpha, int alpha_num, int have_inst) {
+  if (!c || tree < 0 || tree >= 4 || !nodes || nodes_num < 8 || !tri_f4 || tri_f4_num <= 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: bad arguments");
+  if (alpha != nullptr && alpha_num > 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: alpha-tested trees are not supported by the HIP layer yet");
+  if (tree != 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: only tree 0 is traversed by the HIP layer yet");
+  HCHECK(hipSetDevice(c->device));
+  int rc = dev_upload(c, c->bvhNodes[tree], nodes, size_t(nodes_num) * sizeof(HydraBVHNode));
+  if (rc) return rc;
+  rc = dev_upload(c, c->bvhTris[tree], tri_f4, size_t(tri_f4_num) * 16);
+  if (rc) return rc;
+  c->haveInst[tree] = have_inst ? 1 : 0;
+  if (c->treesNum < tree + 1) c->treesNum = tree + 1;
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_set_bvh_trees_num(hydra_hip_handle c, int n) {
+  if (!c || n < 1 || n > 4) return HYDRA_HIP_EINVAL;
+  if (n != 1) return fail(c, HYDRA_HIP_EINVAL, "set_bvh_trees_num: only one BVH tree is traversed by the HIP layer yet");
+  c->treesNum = n;
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_upload_instances(hydra_hip_handle c, const float* inv16, const int32_t* lightInstId, int n) {
+  if (!c || !inv16 || !lightInstId || n <= 0) return fail(c, HYDRA_HIP_EINVAL, "upload_instances: bad arguments");
+  HCHECK(hipSetDevice(c->device));
+  int rc = dev_upload(c, c->instMat, inv16, size_t(n) * 64);
+  if (rc) return rc;
+  rc = dev_upload(c, c->instLight, lightInstId, size_t(n) * 4);
+  if (rc) return rc;
+  c->instNum = n;
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_upload_remap_lists(hydra_hip_handle c, const int32_t* all_lists, int all_size, const int32_t* table_int2, int table_size,
+                                 const int32_t* inst_to_remap, int inst_num) {
+  if (!c || all_size < 0 || table_size < 0 || inst_num < 0) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = dev_upload(c, c->remapLists, all_lists, size_t(all_size) * 4))) return rc;
+  if ((rc = dev_upload(c, c->remapTable, table_int2, size_t(table_size) * 8))) return rc;
+  if ((rc = dev_upload(c, c->remapInst, inst_to_remap, size_t(inst_num) * 4))) return rc;
+  c->remapListsSize = all_size; c->remapTableSize = table_size; c->remapInstSize = inst_num;
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_set_tile_partition(hydra_hip_handle c, int rank, int world, int tile) {
+  if (!c || world < 1 || rank < 0 || rank >= world || tile < 8 || (tile % 8) != 0) return fail(c, HYDRA_HIP_EINVAL, "set_tile_partition: need 0 <= rank < world and tile a multiple of 8");
+  c->rank = rank; c->world = world; c->tile = tile;
+  c->stateAllocated = false;
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_set_external_accumulator(hydra_hip_handle c, void* dev, size_t bytes) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (dev == nullptr) { c->externalAccum = false; c->accum = static_cast<float4*>(c->accumInternal.p); c->stateAllocated = false; return HYDRA_HIP_OK; }
+  if (bytes < size_t(c->w) * c->h * 16) return fail(c, HYDRA_HIP_EINVAL, "set_external_accumulator: buffer smaller than width*height float4");
+  c->externalAccum = true;
+  c->accum = static_cast<float4*>(dev);
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_init_path_tracing(hydra_hip_handle c, int seed) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
+  c->seed = seed;
+  const int npix = c->w * c->h;
+  hipLaunchKernelGGL(k_init_gens, dim3(grid_for(c, npix, 256, 8)), dim3(256), 0, c->stream, npix, seed, static_cast<uint2*>(c->gens.p));
+  HCHECK(hipGetLastError());
+  c->gensReady = true;
+  return hydra_hip_clear_accumulated_color(c);
+}
+int hydra_hip_clear_accumulated_color(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
+  HCHECK(hipMemsetAsync(c->accum, 0, size_t(c->w) * c->h * 16, c->stream));
+  c->spp = 0.0f;
+  return HYDRA_HIP_OK;
+}
+
+static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor) {
+  if (cursor >= c->evPool.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->evPool.push_back(e); }
+  return c->evPool[cursor++];
+}
+
+int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
+  if (!c || spp < 1) return HYDRA_HIP_EINVAL;
+  if (!scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: scene is not completely uploaded (globals, storages, BVH, instances)");
+  HCHECK(hipSetDevice(c->device));
+  if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
+  if (!c->gensReady) { int rc = hydra_hip_init_path_tracing(c, c->seed); if (rc) return rc; }
+  if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
+  const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
+  if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: HRT_TRACE_DEPTH out of range");
+  if (c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: sky lights are not supported by the HIP layer yet");
+
+  const SceneDev s = make_scene(c);
+  PathState S = {static_cast<float4*>(c->sPos.p), static_cast<float4*>(c->sDir.p), static_cast<float4*>(c->sThr.p), static_cast<float4*>(c->sAcc.p), static_cast<uint2*>(c->sRng.p)};
+  MidState M = {static_cast<float4*>(c->mDir.p), static_cast<float4*>(c->mThr.p), static_cast<float4*>(c->mAcc.p), static_cast<uint2*>(c->mRng.p),
+                static_cast<float4*>(c->mSurfA.p), static_cast<float4*>(c->mSurfB.p), static_cast<float4*>(c->mRecC.p), static_cast<float4*>(c->mRecD.p),
+                static_cast<float4*>(c->mRecE.p), static_cast<float4*>(c->mShadowOrg.p), static_cast<float*>(c->mVis.p)};
+  uint32_t* live = static_cast<uint32_t*>(c->live.p);
+  uint32_t* shadowCnt = static_cast<uint32_t*>(c->shadowCnt.p);
+  HydraLiteHit* hits = static_cast<HydraLiteHit*>(c->hits.p);
+  const int N = c->N;
+  const int gTrace = grid_for(c, N, HK_TRACE_BLOCK, 16), gWide = grid_for(c, N, 256, 8);
+  size_t evCursor = 0;
+  const bool timing = c->stageTiming;
+  if (timing) c->spans.clear();
+  auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, evCursor); (void)hipEventRecord(e, c->stream); return int(evCursor) - 1; };
+
+  for (int sub = 0; sub < spp; sub++) {
+    HCHECK(hipMemsetAsync(live, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
+    HCHECK(hipMemsetAsync(shadowCnt, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
+    HCHECK(hipMemcpyAsync(live, &c->N, 4, hipMemcpyHostToDevice, c->stream));
+    int e0 = mark();
+    hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, N, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
+    int e1 = mark();
+    if (timing) c->spans.push_back({e0, e1, 0});
+    for (int depth = 0; depth < maxDepth; depth++) {
+      int a = mark();
+      hipLaunchKernelGGL(k_trace<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr));
+      int b = mark();
+      hipLaunchKernelGGL(k_hit, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M,
+                         static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p));
+      int d = mark();
+      if (depth + 1 < maxDepth) {
+        hipLaunchKernelGGL(k_shadow, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis);
+        int e = mark();
+        hipLaunchKernelGGL(k_shade, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S);
+        int f = mark();
+        if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
+      }
+      if (timing) { c->spans.push_back({a, b, 1}); c->spans.push_back({b, d, 2}); }
+    }
+    int g0 = mark();
+    hipLaunchKernelGGL(k_accumulate, dim3(gWide), dim3(256), 0, c->stream, N, static_cast<const int*>(c->slotPixel.p), static_cast<const float4*>(c->contrib.p), c->accum);
+    hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, static_cast<unsigned long long*>(c->totals.p));
+    int g1 = mark();
+    if (timing) { c->spans.push_back({g0, g1, 5}); c->spans.push_back({e0, g1, 6}); }
+    HCHECK(hipGetLastError());
+    if (timing) {   // fold this sub-pass's events into the stage totals (one sync per sub-pass, only in timing mode)
+      HCHECK(hipStreamSynchronize(c->stream));
+      for (const auto& sp : c->spans) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, c->evPool[sp.a], c->evPool[sp.b]);
+        switch (sp.kind) { case 0: c->tRaygen += ms; break; case 1: c->tTrace += ms; break; case 2: c->tHit += ms; break; case 3: c->tShadow += ms; break;
+                           case 4: c->tShade += ms; break; case 5: c->tAccum += ms; break; default: c->tPass += ms; break; }
+      }
+      c->spans.clear();
+      evCursor = 0;
+    }
+  }
+  c->spp += float(spp);
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_set_spp(hydra_hip_handle c, float spp) { if (!c) return HYDRA_HIP_EINVAL; c->spp = spp; return HYDRA_HIP_OK; }
+float hydra_hip_get_spp(hydra_hip_handle c) { return c ? c->spp : 0.0f; }
+
+int hydra_hip_get_hdr_image(hydra_hip_handle c, float* rgba, int width, int height) {
+  if (!c || !rgba) return HYDRA_HIP_EINVAL;
+  if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "get_hdr_image: bad input resolution");
+  if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "get_hdr_image: nothing rendered yet");
+  HCHECK(hipSetDevice(c->device));
+  const size_t n = size_t(width) * height;
+  HCHECK(hipMemcpy(rgba, c->accum, n * 16, hipMemcpyDeviceToHost));
+  const float inv = c->spp > 0.0f ? 1.0f / c->spp : 0.0f;
+  for (size_t i = 0; i < n * 4; i++) rgba[i] *= inv;
+  return HYDRA_HIP_OK;
+}
+// IntegratorCommon::GetImageToLDR (Common.cpp:319-333): clamp to 1, linear -> sRGB, pack RGBA8
+int hydra_hip_get_ldr_image(hydra_hip_handle c, uint32_t* out, int width, int height) {
+  if (!c || !out) return HYDRA_HIP_EINVAL;
+  std::vector<float> hdr(size_t(width) * height * 4);
+  const int rc = hydra_hip_get_hdr_image(c, hdr.data(), width, height);
+  if (rc) return rc;
+  auto toSRGB = [](float l) { return (l <= 0.00313066844250063f) ? l * 12.92f : float(1.055 * double(powf(l, 1.0f / 2.4f)) - 0.055); };
+  for (size_t i = 0; i < size_t(width) * height; i++) {
+    float ch[4];
+    for (int k = 0; k < 4; k++) ch[k] = fminf(hdr[4 * i + k], 1.0f);
+    for (int k = 0; k < 3; k++) ch[k] = toSRGB(ch[k]);
+    const unsigned char r = (unsigned char)(ch[0] * 255.0f), g = (unsigned char)(ch[1] * 255.0f), b = (unsigned char)(ch[2] * 255.0f), a = (unsigned char)(ch[3] * 255.0f);
+    out[i] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | (uint32_t(a) << 24);
+  }
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_get_rays_stat(hydra_hip_handle c, HydraRaysStat* out) {
+  if (!c || !out) return HYDRA_HIP_EINVAL;
+  memset(out, 0, sizeof(*out));
+  HCHECK(hipSetDevice(c->device));
+  if (c->totals.p) {
+    unsigned long long t[4] = {0, 0, 0, 0};
+    HCHECK(hipMemcpy(t, c->totals.p, 32, hipMemcpyDeviceToHost));
+    out->extensionRays = t[0]; out->shadowRays = t[1]; out->samples = t[2];
+  }
+  out->raygenTimeMs = float(c->tRaygen); out->traversalTimeMs = float(c->tTrace); out->evalHitMs = float(c->tHit);
+  out->samLightTimeMs = float(c->tHit); out->shadowTimeMs = float(c->tShadow); out->shadeTimeMs = float(c->tShade); out->nextBounceMs = float(c->tShade);
+  out->accumTimeMs = float(c->tAccum); out->passTimeMs = float(c->tPass); out->bounceTimeMs = float(c->tTrace + c->tHit + c->tShadow + c->tShade);
+  if (c->tPass > 0) {
+    out->traceTimePerCent = int(100.0 * (c->tTrace + c->tShadow) / c->tPass);
+    out->raysPerSec = float(double(out->extensionRays + out->shadowRays) / (c->tPass * 1e-3));
+  }
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_reset_perf_counters(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  c->tTrace = c->tHit = c->tShadow = c->tShade = c->tRaygen = c->tAccum = c->tPass = 0;
+  if (c->totals.p) { HCHECK(hipSetDevice(c->device)); HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream)); }
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_enable_stage_timing(hydra_hip_handle c, int enable) { if (!c) return HYDRA_HIP_EINVAL; c->stageTiming = (enable != 0); return HYDRA_HIP_OK; }
+
+// ------------------------------------------------------------------------------------------------ stage entry points
+struct TmpBufs {
+  std::vector<void*> ptrs;
+  ~TmpBufs() { for (void* p : ptrs) (void)hipFree(p); }
+  void* up(hydra_hip_ctx* c, const void* src, size_t bytes, int& rc) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes > 0 ? bytes : 16) != hipSuccess) { c->err = "hipMalloc failed in stage call"; rc = HYDRA_HIP_ENOMEM; return nullptr; }
+    ptrs.push_back(p);
+    if (src && bytes) { if (hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy H2D failed"; rc = HYDRA_HIP_EDEVICE; } }
+    return p;
+  }
+};
+#define STAGE_PROLOG(needScene)                                                                         \
+  if (!c || n <= 0) return HYDRA_HIP_EINVAL;                                                           \
+  if ((needScene) && !scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "stage call: scene is not uploaded"); \
+  HCHECK(hipSetDevice(c->device));                                                                      \
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+#define STAGE_EPILOG()                                                                                  \
+  HCHECK(hipGetLastError());                                                                            \
+  HCHECK(hipStreamSynchronize(c->stream));
+
+int hydra_hip_stage_make_eye_rays(hydra_hip_handle c, int n, const int32_t* xy, const float* offs4, float* ray_pos4, float* ray_dir4) {
+  if (!c || n <= 0 || !c->globals.p) return fail(c, HYDRA_HIP_ESTATE, "stage_make_eye_rays: globals are not uploaded");
+  HCHECK(hipSetDevice(c->device));
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  int* dxy = (int*)tb.up(c, xy, size_t(n) * 8, rc);
+  float4* doffs = (float4*)tb.up(c, offs4, size_t(n) * 16, rc);
+  float4* dpos = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  hipLaunchKernelGGL(k_stage_eye, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, n, c->w, c->h, dxy, doffs, dpos, ddir);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(ray_pos4, dpos, size_t(n) * 16, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(ray_dir4, ddir, size_t(n) * 16, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, HydraLiteHit* hits, uint32_t* counters3) {
+  STAGE_PROLOG(true);
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  uint32_t* dc = counters3 ? (uint32_t*)tb.up(c, nullptr, size_t(n) * 12, rc) : nullptr;
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  const int g = grid_for(c, n, HK_TRACE_BLOCK, 16);
+  if (counters3) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc);
+  else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(hits, dh, size_t(n) * 16, hipMemcpyDeviceToHost));
+  if (counters3) HCHECK(hipMemcpy(counters3, dc, size_t(n) * 12, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_shadow_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, const float* t_far, float* visibility) {
+  STAGE_PROLOG(true);
+  std::vector<float> org(size_t(n) * 4);
+  for (int i = 0; i < n; i++) { org[4 * i] = ray_pos4[4 * i]; org[4 * i + 1] = ray_pos4[4 * i + 1]; org[4 * i + 2] = ray_pos4[4 * i + 2]; org[4 * i + 3] = t_far[i]; }
+  float4* dorg = (float4*)tb.up(c, org.data(), size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  float* dv = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  hipLaunchKernelGGL(k_shadow, dim3(grid_for(c, n, HK_TRACE_BLOCK, 16)), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dorg, ddir, dv);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(visibility, dv, size_t(n) * 4, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_eval_surface(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, const HydraLiteHit* hits, float* surf24) {
+  STAGE_PROLOG(true);
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, hits, size_t(n) * 16, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 96, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  hipLaunchKernelGGL(k_stage_surface, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, n, dpos, ddir, dh, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(surf24, dout, size_t(n) * 96, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, uint32_t* rng_state2, float* color4) {
+  STAGE_PROLOG(true);
+  if (c->hostHeader.size() > HG_SKY_LIGHT_ID && c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: sky lights are not supported");
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  uint2* drng = (uint2*)tb.up(c, rng_state2, size_t(n) * 8, rc);
+  float4* dcol = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  hipLaunchKernelGGL(k_stage_path, dim3((n + HK_TRACE_BLOCK - 1) / HK_TRACE_BLOCK), dim3(HK_TRACE_BLOCK), 0, c->stream, s, n, dpos, ddir, drng, dcol);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(color4, dcol, size_t(n) * 16, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(rng_state2, drng, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_random(hydra_hip_handle c, int n, const int32_t* seeds, int draws, float* out4, uint32_t* state2) {
+  if (!c || n <= 0 || draws <= 0) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  int* ds = (int*)tb.up(c, seeds, size_t(n) * 4, rc);
+  float4* dout = (float4*)tb.up(c, nullptr, size_t(n) * draws * 16, rc);
+  uint2* dst = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_random, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, ds, draws, dout, dst);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out4, dout, size_t(n) * draws * 16, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(state2, dst, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_bench_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, int iters, int shadow, float* avg_ms) {
+  STAGE_PROLOG(true);
+  if (iters < 1 || !avg_ms) return HYDRA_HIP_EINVAL;
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);   // for shadow: w of pos = t_far
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  const int g = grid_for(c, n, HK_TRACE_BLOCK, 16);
+  hipEvent_t e0, e1;
+  HCHECK(hipEventCreate(&e0));
+  HCHECK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    if (shadow) hipLaunchKernelGGL(k_shadow, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, reinterpret_cast<float*>(dh));
+    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, static_cast<uint32_t*>(nullptr));
+  };
+  launch();   // warm-up
+  HCHECK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; i++) launch();
+  HCHECK(hipEventRecord(e1, c->stream));
+  HCHECK(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  HCHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HCHECK(hipGetLastError());
+  *avg_ms = ms / float(iters);
+  return HYDRA_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// bvh4_builder.cpp -- binned-SAH BVH4 build + emission of the reference's flattened layout.
+// Layout citations: bvh_builder/bvh_access_dll2.cpp:264-386 (triangle lists), :388-545 (quads, instance quads),
+// :604-717 (root quad, mesh subtrees shared between instances).  The build algorithm itself is ours.
+#include "bvh4_builder.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace hydra_host {
+
+const char* BVH4Builder::kTypeObject = "object";
+
+namespace {
+const float kInf = std::numeric_limits<float>::infinity();
+inline void box_reset(float3& mn, float3& mx) { mn = float3(kInf, kInf, kInf); mx = float3(-kInf, -kInf, -kInf); }
+inline float box_area(const float3& mn, const float3& mx) {
+  const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+  if (dx < 0.0f || dy < 0.0f || dz < 0.0f) return 0.0f;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+inline float axis_of(const float3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+inline HydraBVHNode default_node() {
+  HydraBVHNode n;
+  n.boxMin[0] = n.boxMin[1] = n.boxMin[2] = kInf;
+  n.boxMax[0] = n.boxMax[1] = n.boxMax[2] = -kInf;
+  n.leftOffsetAndLeaf = HYDRA_BVH_INVALID;
+  n.escapeIndex = HYDRA_BVH_INVALID;
+  return n;
+}
+inline void set_box(HydraBVHNode& n, const float3& mn, const float3& mx) {
+  n.boxMin[0] = mn.x; n.boxMin[1] = mn.y; n.boxMin[2] = mn.z;
+  n.boxMax[0] = mx.x; n.boxMax[1] = mx.y; n.boxMax[2] = mx.z;
+}
+inline void set_link(HydraBVHNode& n, bool leaf, uint32_t offset) {
+  n.leftOffsetAndLeaf = (leaf ? HYDRA_BVH_LEAF : 0u) | (offset & 0x7fffffffu);
+}
+}  // namespace
+
+void BVH4Builder::ClearScene() {
+  m_meshes.clear(); m_insts.clear(); m_nodes.clear(); m_primIds.clear(); m_conns.clear();
+  m_outNodes.clear(); m_outTris.clear();
+  m_topRoot = -1;
+  statInnerQuads = statLeaves = statTriangles = 0;
+}
+
+int BVH4Builder::InstanceTriangleMeshes(InstanceInputData d, int a_treeId, int a_realInstIdBase) {
+  if (a_treeId != 0) RunTimeError("BVH4Builder: only tree 0 (opaque geometry) is supported in this tier");
+  int slot = -1;
+  for (size_t i = 0; i < m_meshes.size(); i++)
+    if (m_meshes[i].meshId == d.meshId) slot = int(i);
+  if (slot < 0) {
+    MeshRec m;
+    m.meshId = d.meshId;
+    m.vert4f.assign(d.vert4f, d.vert4f + size_t(d.numVert) * 4);
+    m.indices.assign(d.indices, d.indices + d.numIndices);
+    m_meshes.push_back(std::move(m));
+    slot = int(m_meshes.size()) - 1;
+  }
+  for (int i = 0; i < d.numInst; i++) {
+    InstRec r;
+    r.meshSlot = slot;
+    r.realInstId = a_realInstIdBase + i;
+    memcpy(r.matrix.c, d.matrices + size_t(i) * 16, 64);
+    m_insts.push_back(r);
+  }
+  return slot;
+}
+
+// ------------------------------------------------------------------------------------------ build
+int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const {
+  const int NB = 16;
+  float3 cmn, cmx;
+  box_reset(cmn, cmx);
+  for (int i = begin; i < end; i++) { cmn = vmin(cmn, prims[i].centroid); cmx = vmax(cmx, prims[i].centroid); }
+
+  float bestCost = kInf;
+  int bestAxis = -1, bestBin = -1;
+  for (int axis = 0; axis < 3; axis++) {
+    const float lo = axis_of(cmn, axis), hi = axis_of(cmx, axis);
+    if (!(hi > lo)) continue;
+    const float scale = float(NB) / (hi - lo);
+    int cnt[NB]; float3 bmn[NB], bmx[NB];
+    for (int b = 0; b < NB; b++) { cnt[b] = 0; box_reset(bmn[b], bmx[b]); }
+    for (int i = begin; i < end; i++) {
+      int b = int((axis_of(prims[i].centroid, axis) - lo) * scale);
+      b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+      cnt[b]++;
+      bmn[b] = vmin(bmn[b], prims[i].box.mn); bmx[b] = vmax(bmx[b], prims[i].box.mx);
+    }
+    float rightArea[NB]; int rightCnt[NB];
+    float3 amn, amx; box_reset(amn, amx);
+    int c = 0;
+    for (int b = NB - 1; b > 0; b--) {
+      amn = vmin(amn, bmn[b]); amx = vmax(amx, bmx[b]); c += cnt[b];
+      rightArea[b] = box_area(amn, amx); rightCnt[b] = c;
+    }
+    box_reset(amn, amx); c = 0;
+    for (int b = 0; b < NB - 1; b++) {
+      amn = vmin(amn, bmn[b]); amx = vmax(amx, bmx[b]); c += cnt[b];
+      if (c == 0 || rightCnt[b + 1] == 0) continue;
+      const float cost = box_area(amn, amx) * float(c) + rightArea[b + 1] * float(rightCnt[b + 1]);
+      if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+    }
+  }
+  if (bestAxis < 0) return (begin + end) / 2;   // all centroids coincide: split in the middle
+  const float lo = axis_of(cmn, bestAxis), hi = axis_of(cmx, bestAxis);
+  const float scale = float(NB) / (hi - lo);
+  auto mid = std::partition(prims.begin() + begin, prims.begin() + end, [&](const PrimRef& p) {
+    int b = int((axis_of(p.centroid, bestAxis) - lo) * scale);
+    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+    return b <= bestBin;
+  });
+  int m = int(mid - prims.begin());
+  if (m == begin || m == end) m = (begin + end) / 2;
+  return m;
+}
+
+int BVH4Builder::BuildRecursive(std::vector<PrimRef>& prims, int begin, int end, int leafMax) {
+  TmpNode node;
+  box_reset(node.box.mn, node.box.mx);
+  for (int i = begin; i < end; i++) { node.box.mn = vmin(node.box.mn, prims[i].box.mn); node.box.mx = vmax(node.box.mx, prims[i].box.mx); }
+  const int idx = int(m_nodes.size());
+  m_nodes.push_back(node);
+
+  if (end - begin <= leafMax) {
+    m_nodes[idx].first = int(m_primIds.size());
+    m_nodes[idx].count = end - begin;
+    for (int i = begin; i < end; i++) m_primIds.push_back(prims[i].id);
+    return idx;
+  }
+  // open the node into up to four ranges, always splitting the range with the largest area*count
+  struct Range { int b, e; };
+  Range r[4];
+  int nr = 1;
+  r[0] = {begin, end};
+  while (nr < 4) {
+    int pick = -1;
+    float best = -1.0f;
+    for (int i = 0; i < nr; i++) {
+      const int cnt = r[i].e - r[i].b;
+      if (cnt <= leafMax) continue;
+      float3 mn, mx; box_reset(mn, mx);
+      for (int k = r[i].b; k < r[i].e; k++) { mn = vmin(mn, prims[k].box.mn); mx = vmax(mx, prims[k].box.mx); }
+      const float w = box_area(mn, mx) * float(cnt) + 1e-30f * float(cnt);
+      if (w > best) { best = w; pick = i; }
+    }
+    if (pick < 0) break;
+    const int m = SplitSAH(prims, r[pick].b, r[pick].e);
+    const Range left = {r[pick].b, m}, right = {m, r[pick].e};
+    r[pick] = left;
+    r[nr++] = right;
+  }
+  for (int i = 0; i < nr; i++) {
+    const int c = BuildRecursive(prims, r[i].b, r[i].e, leafMax);
+    m_nodes[idx].child[i] = c;
+  }
+  return idx;
+}
+
+int BVH4Builder::BuildTree(std::vector<PrimRef>& prims, int leafMax) {
+  if (prims.empty()) return -1;
+  return BuildRecursive(prims, 0, int(prims.size()), leafMax);
+}
+
+void BVH4Builder::CommitScene() {
+  m_nodes.clear(); m_primIds.clear();
+  // (1) one tree per mesh, over its non-degenerate triangles (zero-area triangles are dropped, bvh_access_dll2.cpp:354-355)
+  for (auto& mesh : m_meshes) {
+    const int triNum = int(mesh.indices.size() / 3);
+    std::vector<PrimRef> prims;
+    prims.reserve(triNum);
+    const float* v = mesh.vert4f.data();
+    for (int t = 0; t < triNum; t++) {
+      const int ia = mesh.indices[t * 3 + 0], ib = mesh.indices[t * 3 + 1], ic = mesh.indices[t * 3 + 2];
+      const float3 A(v[ia * 4], v[ia * 4 + 1], v[ia * 4 + 2]), B(v[ib * 4], v[ib * 4 + 1], v[ib * 4 + 2]), C(v[ic * 4], v[ic * 4 + 1], v[ic * 4 + 2]);
+      const float area = 0.5f * length(cross(B - A, C - A));
+      if (!(area > 0.0f)) continue;
+      PrimRef p;
+      p.box.mn = vmin(A, vmin(B, C));
+      p.box.mx = vmax(A, vmax(B, C));
+      p.centroid = (p.box.mn + p.box.mx) * 0.5f;
+      p.id = t;
+      prims.push_back(p);
+    }
+    if (prims.empty()) RunTimeError("BVH4Builder::CommitScene: mesh without valid triangles");
+    mesh.rootNode = BuildTree(prims, maxLeafSize);
+    mesh.bounds = m_nodes[mesh.rootNode].box;
+  }
+  // (2) top level over instances
+  std::vector<PrimRef> iprims;
+  box_reset(m_sceneBox.mn, m_sceneBox.mx);
+  for (size_t i = 0; i < m_insts.size(); i++) {
+    InstRec& in = m_insts[i];
+    const Box& mb = m_meshes[in.meshSlot].bounds;
+    float3 mn, mx; box_reset(mn, mx);
+    for (int k = 0; k < 8; k++) {
+      const float3 c((k & 1) ? mb.mx.x : mb.mn.x, (k & 2) ? mb.mx.y : mb.mn.y, (k & 4) ? mb.mx.z : mb.mn.z);
+      const float3 w = mul_point(in.matrix, c);
+      mn = vmin(mn, w); mx = vmax(mx, w);
+    }
+    // guard against rounding of the 8-corner bound: pad by a few ulp of the extent
+    const float3 ext = mx - mn;
+    const float pad = 1e-5f * fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, 1e-20f));
+    in.worldBox.mn = mn - float3(pad, pad, pad);
+    in.worldBox.mx = mx + float3(pad, pad, pad);
+    PrimRef p;
+    p.box = in.worldBox;
+    p.centroid = (p.box.mn + p.box.mx) * 0.5f;
+    p.id = int(i);
+    iprims.push_back(p);
+    m_sceneBox.mn = vmin(m_sceneBox.mn, in.worldBox.mn);
+    m_sceneBox.mx = vmax(m_sceneBox.mx, in.worldBox.mx);
+  }
+  if (iprims.empty()) RunTimeError("BVH4Builder::CommitScene: no instances in the scene");
+  m_topRoot = BuildTree(iprims, 1);
+}
+
+void BVH4Builder::GetBounds(float a_bMin[3], float a_bMax[3]) const {
+  a_bMin[0] = m_sceneBox.mn.x; a_bMin[1] = m_sceneBox.mn.y; a_bMin[2] = m_sceneBox.mn.z;
+  a_bMax[0] = m_sceneBox.mx.x; a_bMax[1] = m_sceneBox.mx.y; a_bMax[2] = m_sceneBox.mx.z;
+}
+
+// ------------------------------------------------------------------------------------------ emission
+size_t BVH4Builder::Alloc4Nodes() {
+  const size_t o = m_outNodes.size();
+  for (int i = 0; i < 4; i++) m_outNodes.push_back(default_node());
+  return o;
+}
+
+size_t BVH4Builder::EmitTriangleLeaf(const MeshRec& mesh, const TmpNode& leaf) {
+  const size_t listOffset = m_outTris.size() / 4;
+  m_outTris.resize(m_outTris.size() + 4);
+  const float* v = mesh.vert4f.data();
+  for (int k = 0; k < leaf.count; k++) {
+    const int t = m_primIds[leaf.first + k];
+    const int ia = mesh.indices[t * 3 + 0], ib = mesh.indices[t * 3 + 1], ic = mesh.indices[t * 3 + 2];
+    const int32_t ids[3] = {t, mesh.meshId, -1};
+    const int iv[3] = {ia, ib, ic};
+    for (int c = 0; c < 3; c++) {
+      float w;
+      memcpy(&w, &ids[c], 4);
+      m_outTris.push_back(v[iv[c] * 4 + 0]); m_outTris.push_back(v[iv[c] * 4 + 1]); m_outTris.push_back(v[iv[c] * 4 + 2]);
+      m_outTris.push_back(w);
+    }
+  }
+  const int32_t hdr[4] = {int32_t(listOffset + 1), leaf.count, -1, -1};
+  memcpy(&m_outTris[listOffset * 4], hdr, 16);
+  statLeaves++;
+  statTriangles += leaf.count;
+  return listOffset;
+}
+
+size_t BVH4Builder::EmitMeshSubtree(const MeshRec& mesh, int tmp, size_t curr) {
+  const TmpNode node = m_nodes[tmp];
+  if (node.count > 0) {
+    const size_t list = EmitTriangleLeaf(mesh, node);
+    set_link(m_outNodes[curr], true, uint32_t(list));
+    m_outNodes[curr].escapeIndex = 0;
+    return size_t(-1);
+  }
+  const size_t quad = Alloc4Nodes();
+  statInnerQuads++;
+  for (int i = 0; i < 4; i++)
+    if (node.child[i] >= 0) set_box(m_outNodes[quad + i], m_nodes[node.child[i]].box.mn, m_nodes[node.child[i]].box.mx);
+  set_link(m_outNodes[curr], false, uint32_t(quad / 4));
+  for (int i = 0; i < 4; i++)
+    if (node.child[i] >= 0) EmitMeshSubtree(mesh, node.child[i], quad + i);
+  return quad;
+}
+
+void BVH4Builder::EmitTop(int tmp, size_t curr) {
+  const TmpNode node = m_nodes[tmp];
+  if (node.count > 0) {  // instance leaf
+    const InstRec& in = m_insts[m_primIds[node.first]];
+    if (curr == 0) {     // single-instance scene: synthetic top quad (bvh_access_dll2.cpp:458-484)
+      const size_t q = Alloc4Nodes();
+      set_link(m_outNodes[0], false, uint32_t(q / 4));
+      set_box(m_outNodes[q], in.worldBox.mn, in.worldBox.mx);
+      curr = q;
+    }
+    const size_t q = Alloc4Nodes();
+    set_link(m_outNodes[curr], true, uint32_t(q / 4));
+    m_outNodes[curr].escapeIndex = 1;  // SetInstance(1)
+    const MeshRec& mesh = m_meshes[in.meshSlot];
+    set_box(m_outNodes[q], mesh.bounds.mn, mesh.bounds.mx);
+    const float4x4 inv = inverse4x4(in.matrix);
+    memcpy(&m_outNodes[q + 1], inv.c, 64);
+    const int32_t ids[4] = {in.realInstId, mesh.meshId, 0, 0};
+    memcpy(&m_outNodes[q + 3], ids, 16);
+    m_conns.push_back({q, in.meshSlot});
+    return;
+  }
+  const size_t quad = Alloc4Nodes();
+  statInnerQuads++;
+  for (int i = 0; i < 4; i++)
+    if (node.child[i] >= 0) set_box(m_outNodes[quad + i], m_nodes[node.child[i]].box.mn, m_nodes[node.child[i]].box.mx);
+  set_link(m_outNodes[curr], false, uint32_t(quad / 4));
+  for (int i = 0; i < 4; i++)
+    if (node.child[i] >= 0) EmitTop(node.child[i], quad + i);
+}
+
+ConvertionResult BVH4Builder::ConvertMap() {
+  if (m_topRoot < 0) RunTimeError("BVH4Builder::ConvertMap: CommitScene was not called");
+  m_outNodes.clear(); m_outTris.clear(); m_conns.clear();
+  statInnerQuads = statLeaves = statTriangles = 0;
+
+  const size_t root = Alloc4Nodes();               // quad 0: root box + identity matrix in nodes 1-2
+  set_box(m_outNodes[root], m_sceneBox.mn, m_sceneBox.mx);
+  float4x4 ident;
+  memcpy(&m_outNodes[root + 1], ident.c, 64);
+  EmitTop(m_topRoot, root);
+
+  std::vector<uint32_t> meshLink(m_meshes.size(), 0u);
+  std::vector<char> meshDone(m_meshes.size(), 0);
+  for (const Conn& c : m_conns) {
+    if (!meshDone[c.meshSlot]) {
+      EmitMeshSubtree(m_meshes[c.meshSlot], m_meshes[c.meshSlot].rootNode, c.instNode0);
+      meshLink[c.meshSlot] = m_outNodes[c.instNode0].leftOffsetAndLeaf;
+      meshDone[c.meshSlot] = 1;
+    } else
+      m_outNodes[c.instNode0].leftOffsetAndLeaf = meshLink[c.meshSlot];   // all instances share one mesh subtree
+    m_outNodes[c.instNode0].escapeIndex = HYDRA_BVH_INVALID;
+  }
+
+  ConvertionResult res;
+  res.treesNum = 1;
+  res.bvhType[0] = kTypeObject;
+  res.pBVH[0] = m_outNodes.data();
+  res.pTriangleData[0] = m_outTris.data();
+  res.nodesNum[0] = int(m_outNodes.size());
+  res.trif4Num[0] = int(m_outTris.size() / 4);
+  return res;
+}
+
+void BVH4Builder::ConvertUnmap() {
+  m_outNodes = std::vector<HydraBVHNode>();
+  m_outTris = std::vector<float>();
+  m_conns.clear();
+}
+
+}  // namespace hydra_host

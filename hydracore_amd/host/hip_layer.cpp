@@ -1,0 +1,134 @@
+// hip_layer.cpp -- HipHWLayer: the IHWLayer subclass that forwards to the C-ABI of libhydra_hip.so.
+//
+// Counterpart of GPUOCLLayer (hydra_drv/GPUOCLLayer.h:28 derives from CPUSharedData the same way) for the PT path.
+// C-ABI error codes are turned into RUN_TIME_ERROR exceptions, which is how the reference reports fatal layer errors
+// (hydra_drv/globals_sys.h:56-66, caught in hydra_app/main.cpp:331-338).
+#include "hw_layer.h"
+#include "../../include/hydra_hip.h"
+#include <cstring>
+
+namespace hydra_host {
+
+class HipHWLayer : public SharedDataLayer {
+public:
+  HipHWLayer(int w, int h, int a_flags, int a_deviceId) : SharedDataLayer(w, h, a_flags), m_h(nullptr) {
+    const int rc = hydra_hip_create(w, h, a_flags, a_deviceId, &m_h);
+    if (rc != HYDRA_HIP_OK) RunTimeError(std::string("CreateHipImpl: ") + hydra_hip_last_error(nullptr));
+    hydra_hip_device_name(m_h, m_devName, sizeof(m_devName));
+  }
+  ~HipHWLayer() override { if (m_h) hydra_hip_destroy(m_h); }
+
+  bool HasDevice() const override { return true; }
+  bool StoreCPUData() const override { return false; }
+  const char* GetDeviceName(int* pOCLVer = nullptr) const override { if (pOCLVer) *pOCLVer = 0; return m_devName; }
+
+  void ResizeScreen(int w, int h, int a_flags) override {
+    SharedDataLayer::ResizeScreen(w, h, a_flags);
+    check(hydra_hip_resize(m_h, w, h), "ResizeScreen");
+  }
+
+  void PrepareEngineGlobals() override {
+    SharedDataLayer::PrepareEngineGlobals();
+    if (m_cdataPrepared.empty()) RunTimeError("HipHWLayer: EngineGlobals were not prepared");
+    if (m_tablesUploaded)   // per-Draw refresh: camera matrices, vars, flags, table offsets (first 1268 words)
+      check(hydra_hip_update_globals_header(m_h, m_cdataPrepared.data(), HG_TABLES_READY + 1), "PrepareEngineGlobals");
+  }
+
+  void PrepareEngineTables() override {
+    SharedDataLayer::PrepareEngineTables();
+    static const char* names[HYDRA_STORAGE_KINDS] = {"textures", "textures_aux", "geom", "materials", "pdfs"};
+    for (int k = 0; k < HYDRA_STORAGE_KINDS; k++) {
+      IMemoryStorage* st = FindStorage(names[k]);
+      if (st == nullptr) RunTimeError(std::string("HipHWLayer::PrepareEngineTables: no storage ") + names[k]);
+      check(hydra_hip_upload_storage(m_h, k, st->GetBegin(), st->GetSize()), names[k]);
+    }
+    check(hydra_hip_upload_globals(m_h, m_cdataPrepared.data(), m_cdataPrepared.size()), "upload_globals");
+    m_tablesUploaded = true;
+  }
+
+  void SetAllBVH4(const ConvertionResult& cr, void* a_builder, int a_flags) override {
+    SharedDataLayer::SetAllBVH4(cr, a_builder, a_flags);   // host copy for debugging / CPU cross-checks
+    for (int i = 0; i < cr.treesNum; i++)
+      check(hydra_hip_upload_bvh(m_h, i, cr.pBVH[i], cr.nodesNum[i], cr.pTriangleData[i], cr.trif4Num[i],
+                                 cr.pTriangleAlpha[i], cr.triAfNum[i], m_bvhTrees[i].haveInst ? 1 : 0), "SetAllBVH4");
+    check(hydra_hip_set_bvh_trees_num(m_h, cr.treesNum), "SetAllBVH4");
+  }
+
+  void SetAllInstMatrices(const float4x4* a_matrices, int32_t n) override {
+    SharedDataLayer::SetAllInstMatrices(a_matrices, n);
+    upload_instances();
+  }
+  void SetAllInstLightInstId(const int32_t* ids, int32_t n) override {
+    SharedDataLayer::SetAllInstLightInstId(ids, n);
+    upload_instances();
+  }
+  void SetAllRemapLists(const int* a_allLists, const int* a_tableInt2, int a_allSize, int a_tableSize) override {
+    SharedDataLayer::SetAllRemapLists(a_allLists, a_tableInt2, a_allSize, a_tableSize);
+    upload_remap();
+  }
+  void SetAllInstIdToRemapId(const int* a_allInstId, int a_instNum) override {
+    SharedDataLayer::SetAllInstIdToRemapId(a_allInstId, a_instNum);
+    upload_remap();
+  }
+
+  void InitPathTracing(int seed, std::vector<int32_t>* = nullptr) override { check(hydra_hip_init_path_tracing(m_h, seed), "InitPathTracing"); }
+  void ClearAccumulatedColor() override { check(hydra_hip_clear_accumulated_color(m_h), "ClearAccumulatedColor"); }
+  void BeginTracingPass() override { check(hydra_hip_trace_pass(m_h, GetRaysPerPixel()), "BeginTracingPass"); }
+  void EndTracingPass() override {}
+  void FinishAll() override { check(hydra_hip_finish(m_h), "FinishAll"); }
+  void SetRaysPerPixel(int a_num) override { m_spp = a_num > 0 ? a_num : 1; }
+  int  GetRaysPerPixel() const override { return m_spp; }
+
+  void ResetPerfCounters() override { hydra_hip_reset_perf_counters(m_h); }
+  HydraRaysStat GetRaysStat() override {
+    HydraRaysStat st;
+    memset(&st, 0, sizeof(st));
+    hydra_hip_get_rays_stat(m_h, &st);
+    return st;
+  }
+  // size mismatch: silently return, as CPUExpLayer does (hydra_drv/CPUExpLayer.cpp:133-147)
+  void GetHDRImage(float* data4, int width, int height) const override { hydra_hip_get_hdr_image(m_h, data4, width, height); }
+  void GetLDRImage(uint32_t* data, int width, int height) const override { hydra_hip_get_ldr_image(m_h, data, width, height); }
+  float GetSPP() const override { return hydra_hip_get_spp(m_h); }
+
+  size_t GetAvaliableMemoryAmount(bool allMem = false) override {
+    size_t f = 0, t = 0;
+    hydra_hip_available_memory(m_h, &f, &t);
+    return allMem ? t : f;
+  }
+  void SetExternalImageAccumulator(void* a_pImage, size_t a_bytes) override {
+    SharedDataLayer::SetExternalImageAccumulator(a_pImage, a_bytes);
+    check(hydra_hip_set_external_accumulator(m_h, a_pImage, a_bytes), "SetExternalImageAccumulator");
+  }
+  hydra_hip_handle Handle() const { return m_h; }
+
+private:
+  hydra_hip_handle m_h;
+  char m_devName[256] = {0};
+  bool m_tablesUploaded = false;
+  int m_spp = 1;
+
+  void check(int rc, const char* where) const {
+    if (rc != HYDRA_HIP_OK) RunTimeError(std::string("HipHWLayer::") + where + ": " + hydra_hip_last_error(m_h));
+  }
+  void upload_instances() {
+    const size_t n = m_instMatrices.size() / 16;
+    if (n == 0) return;
+    std::vector<int32_t> lid = m_instLightInstId;
+    lid.resize(n, -1);   // lights may be absent: every instance is "not a light"
+    check(hydra_hip_upload_instances(m_h, m_instMatrices.data(), lid.data(), int(n)), "upload_instances");
+  }
+  void upload_remap() {
+    check(hydra_hip_upload_remap_lists(m_h, m_remapLists.data(), int(m_remapLists.size()), m_remapTable.data(), int(m_remapTable.size() / 2),
+                                       m_remapInst.data(), int(m_remapInst.size())), "upload_remap");
+  }
+};
+
+IHWLayer* CreateHipImpl(int w, int h, int a_flags, int a_deviceId) { return new HipHWLayer(w, h, a_flags, a_deviceId); }
+
+void* HipLayerHandle(IHWLayer* layer) {
+  HipHWLayer* p = dynamic_cast<HipHWLayer*>(layer);
+  return p ? static_cast<void*>(p->Handle()) : nullptr;
+}
+
+}  // namespace hydra_host

@@ -1,0 +1,797 @@
+// render_driver_lite.cpp -- scene-library reader + RenderDriverRTE-compatible packing (see header for citations).
+#include "render_driver_lite.h"
+#include <fstream>
+#include <sstream>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <set>
+
+namespace hydra_host {
+
+namespace {
+
+typedef std::vector<float> PlainMaterialVec;   // n * 192 floats
+
+inline void put_i(float* data, int idx, int32_t v) { memcpy(data + idx, &v, 4); }
+inline int32_t get_i(const float* data, int idx) { int32_t v; memcpy(&v, data + idx, 4); return v; }
+
+struct Sampler {               // SWTexSampler, hydra_drv/cfetch.h:108-131
+  int32_t flags = 0; float gamma = 2.2f; int32_t texId = int32_t(HYDRA_INVALID_TEXTURE); int32_t dummy2 = 0;
+  float row0[4] = {1, 0, 0, 0}, row1[4] = {0, 1, 0, 0};
+};
+inline void put_sampler_raw(float* data, int offset, const Sampler& s) {
+  put_i(data, offset + HS_FLAGS, s.flags);
+  data[offset + HS_GAMMA] = s.gamma;
+  put_i(data, offset + HS_TEXID, s.texId);
+  put_i(data, offset + HS_DUMMY, s.dummy2);
+  memcpy(data + offset + HS_ROW0, s.row0, 16);
+  memcpy(data + offset + HS_ROW1, s.row1, 16);
+}
+// IMaterial::PutSamplerAt, hydra_drv/AbstractMaterial.h:83-92
+inline void put_sampler_at(float* data, int32_t texId, const Sampler& s, int texSlot, int matrixSlot, int offset) {
+  const int32_t samplerOffset = (texId == int32_t(HYDRA_INVALID_TEXTURE)) ? int32_t(HYDRA_INVALID_TEXTURE) : offset / 4;
+  put_i(data, texSlot, texId);
+  put_i(data, matrixSlot, samplerOffset);
+  put_sampler_raw(data, offset, s);
+}
+// IMaterial::IMaterial, AbstractMaterial.h:32-68
+void init_material_node(float* d) {
+  memset(d, 0, sizeof(float) * HM_NODE_FLOATS);
+  const int32_t INV = int32_t(HYDRA_INVALID_TEXTURE);
+  put_i(d, HM_EMISSIVE_LIGHTID, -1);
+  Sampler dummy;
+  put_sampler_at(d, INV, dummy, HM_NORMAL_TEX, HM_NORMAL_TEX_MATRIX, HM_NORMAL_SAMPLER);
+  put_sampler_at(d, INV, dummy, HM_OPACITY_TEX, HM_OPACITY_TEX_MATRIX, HM_OPACITY_SAMPLER);
+  put_sampler_at(d, INV, dummy, HM_EMISSIVE_TEXID, HM_EMISSIVE_TEXMATRIXID, HM_EMISSIVE_SAMPLER);
+  for (int i = 0; i < 16; i++) put_i(d, HM_PROC_TEX_IDS + i, INV);
+  put_i(d, HM_AO_TYPE, 0); put_i(d, HM_AO_TEX_ID, INV); put_i(d, HM_AO_TEXMATRIX_ID, INV); d[HM_AO_LENGTH] = 0.0f;
+  put_i(d, HM_AO_TYPE2, 0); put_i(d, HM_AO_TEX_ID2, INV); put_i(d, HM_AO_TEXMATRIX_ID2, INV); d[HM_AO_LENGTH2] = 0.0f;
+}
+
+bool parse_floats(const std::string& s, float* out, int n) {
+  std::istringstream in(s);
+  for (int i = 0; i < n; i++) {
+    std::string tok;
+    if (!(in >> tok)) return false;
+    out[i] = strtof(tok.c_str(), nullptr);   // tolerates "0.25f"
+  }
+  return true;
+}
+// HydraXMLHelpers::ReadValue3f / ReadValue1f (HydraAPI, absent): value in attribute "val" or in the node text
+float3 read_value3f(const XmlNode* n) {
+  float v[3] = {0, 0, 0};
+  if (n == nullptr) return float3(0, 0, 0);
+  std::string s = n->has_attr("val") ? std::string(n->attr("val")) : n->text;
+  if (!parse_floats(s, v, 3)) {
+    float one = 0.0f;
+    if (parse_floats(s, &one, 1)) v[0] = v[1] = v[2] = one;
+  }
+  return float3(v[0], v[1], v[2]);
+}
+float read_value1f(const XmlNode* n) {
+  if (n == nullptr) return 0.0f;
+  float v = 0.0f;
+  parse_floats(n->has_attr("val") ? std::string(n->attr("val")) : n->text, &v, 1);
+  return v;
+}
+
+// SamplerNode / SamplerFromTexref, hydra_drv/PlainMaterialConverter.cpp:886-951
+const XmlNode* sampler_node(const XmlNode* a) {
+  const XmlNode* inside = xchild(xchild(a, "color"), "texture");
+  return inside ? inside : xchild(a, "texture");
+}
+Sampler sampler_from_texref(const XmlNode* a, bool allowAlphaToRGB = false) {
+  Sampler res;
+  res.texId = a->attr_int("id");
+  res.flags = 0;
+  res.gamma = a->has_attr("input_gamma") ? a->attr_float("input_gamma") : 2.2f;
+  if (a->has_attr("matrix")) {
+    float m[16];
+    if (parse_floats(a->attr("matrix"), m, 16)) { memcpy(res.row0, m, 16); memcpy(res.row1, m + 4, 16); }
+  }
+  const std::string modeU = a->attr("addressing_mode_u"), modeV = a->attr("addressing_mode_v"), modeS = a->attr("filter");
+  const std::string alphaSrc = a->attr("input_alpha"), channel = a->attr("channel");
+  if (modeU == "clamp") res.flags |= HTEX_CLAMP_U;
+  if (modeV == "clamp") res.flags |= HTEX_CLAMP_V;
+  if (modeS == "point" || modeS == "nearest") res.flags |= HTEX_POINT_SAM;
+  if (allowAlphaToRGB && alphaSrc == "alpha") res.flags |= HTEX_ALPHASRC_W;
+  if (channel == "1") res.flags |= HTEX_COORD_SECOND;
+  else if (channel == "camera_mapped") res.flags |= HTEX_COORD_CAM_PROJ;
+  return res;
+}
+
+struct MatTree {                      // RAYTR::IMaterial tree, flattened by flatten()
+  float plain[HM_NODE_FLOATS];
+  std::shared_ptr<MatTree> c1, c2;    // blend children
+  bool isBlend = false;
+};
+typedef std::shared_ptr<MatTree> MatPtr;
+
+MatPtr new_node() { auto p = std::make_shared<MatTree>(); init_material_node(p->plain); return p; }
+
+// LambertMaterial, PlainMaterialConverter.cpp:96-136
+MatPtr make_lambert(float3 color, int32_t texId, const Sampler& s) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  put_sampler_at(d, texId, s, HM_TEXID, HM_TEXMATRIXID, HM_LAMBERT_SAMPLER);
+  put_i(d, HM_TYPE, HMT_LAMBERT);
+  put_i(d, HM_FLAGS, HMF_HAS_DIFFUSE);
+  return p;
+}
+// PhongMaterial, PlainMaterialConverter.cpp:414-460
+MatPtr make_phong(float3 color, int32_t texId, const Sampler& sc, float cosPower, int32_t glossTexId, const Sampler& sg, float gloss) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  d[HM_PHONG_COSPOWER] = cosPower;
+  d[HM_PHONG_GLOSINESS] = gloss;
+  put_sampler_at(d, texId, sc, HM_TEXID, HM_TEXMATRIXID, HM_PHONG_SAMPLER0);
+  put_sampler_at(d, glossTexId, sg, HM_PHONG_GLOSS_TEXID, HM_PHONG_GLOSS_TEXMATRIXID, HM_PHONG_SAMPLER1);
+  put_i(d, HM_TYPE, HMT_PHONG);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
+  return p;
+}
+// MirrorMaterial, PlainMaterialConverter.cpp:219-247
+MatPtr make_mirror(float3 color, int32_t texId, const Sampler& s) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  put_sampler_at(d, texId, s, HM_TEXID, HM_TEXMATRIXID, HM_MIRROR_SAMPLER);
+  put_i(d, HM_TYPE, HMT_MIRROR);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
+  return p;
+}
+// EmissiveMaterial, PlainMaterialConverter.cpp:31-70
+MatPtr make_emissive(float3 color, int32_t texId, const Sampler& s, int32_t lightId) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_EMISSIVE_COLOR] = color.x; d[HM_EMISSIVE_COLOR + 1] = color.y; d[HM_EMISSIVE_COLOR + 2] = color.z;
+  put_sampler_at(d, texId, s, HM_EMISSIVE_TEXID, HM_EMISSIVE_TEXMATRIXID, HM_EMISSIVE_SAMPLER);
+  put_i(d, HM_EMISSIVE_LIGHTID, lightId);
+  put_i(d, HM_TYPE, HMT_EMISSIVE);
+  return p;
+}
+// BlendMaskMaterial, PlainMaterialConverter.cpp:750-791.  Field aliasing reproduced byte for byte:
+// BLEND_TYPE written first, then the 12-word sampler lands on words 20..31, then FALOFF_OFFSET/SIZE overwrite 19/20.
+MatPtr make_blend(MatPtr m1, MatPtr m2, float3 alpha, int32_t alphaTex, const Sampler& s, bool isFresnel, bool vrayLike, int extrusion, float ior) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  p->isBlend = true; p->c1 = m1; p->c2 = m2;
+  d[HM_COLOR] = alpha.x; d[HM_COLOR + 1] = alpha.y; d[HM_COLOR + 2] = alpha.z;
+  d[HM_BLEND_FRESNEL_IOR] = isFresnel ? ior : 1.0f;
+  put_i(d, HM_BLEND_TYPE, isFresnel ? 1 : 3);
+  put_sampler_at(d, alphaTex, s, HM_TEXID, HM_TEXMATRIXID, HM_BLEND_SAMPLER);
+  put_i(d, HM_TYPE, HMT_BLEND_MASK);
+  put_i(d, HM_BLEND_FALOFF_OFFSET, -1);
+  put_i(d, HM_BLEND_FALOFF_SIZE, 0);
+  int32_t flags = isFresnel ? HBF_FRESNEL : 0;
+  if (vrayLike && !isFresnel) flags |= HBF_REFLECTION_WEIGHT_IS_ONE;
+  flags |= extrusion;
+  put_i(d, HM_BLEND_FLAGS, flags);
+  return p;
+}
+// BlendMaskMaterial::ConvertToPlainMaterial, PlainMaterialConverter.cpp:793-811: [blend | subtree1 | subtree2], relative offsets
+PlainMaterialVec flatten(const MatPtr& m) {
+  PlainMaterialVec res(m->plain, m->plain + HM_NODE_FLOATS);
+  if (!m->isBlend) return res;
+  PlainMaterialVec d1 = flatten(m->c1), d2 = flatten(m->c2);
+  put_i(res.data(), HM_BLEND_MAT1, int32_t(res.size() / HM_NODE_FLOATS));
+  res.insert(res.end(), d1.begin(), d1.end());
+  put_i(res.data(), HM_BLEND_MAT2, int32_t(res.size() / HM_NODE_FLOATS));
+  res.insert(res.end(), d2.begin(), d2.end());
+  return res;
+}
+
+int read_extrusion(const XmlNode* n) {   // ReadExtrusionType, PlainMaterialConverter.cpp:1201-1216
+  if (n == nullptr) return HBF_EXTRUSION_STRONG;
+  const std::string e = xattr(xchild(n, "extrusion"), "val");
+  if (e == "luminance") return HBF_EXTRUSION_LUMINANCE;
+  if (e == "colored") return 0;
+  return HBF_EXTRUSION_STRONG;
+}
+float read_fresnel_ior(const XmlNode* n) {  // ReadFresnelIOR, :1218-1226
+  if (n == nullptr) return 1.5f;
+  if (n->child("fresnel_ior")) return n->child("fresnel_ior")->attr_float("val");
+  return n->child("fresnel_IOR") ? n->child("fresnel_IOR")->attr_float("val") : 0.0f;
+}
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  f.seekg(0, std::ios::end);
+  out.resize(size_t(f.tellg()));
+  f.seekg(0);
+  f.read(out.data(), out.size());
+  return true;
+}
+
+}  // namespace
+
+// ================================================================================================
+RenderDriverLite::RenderDriverLite(IHWLayer* a_layer, int w, int h) : m_pHWLayer(a_layer), m_width(w), m_height(h) {}
+
+RenderDriverLite::~RenderDriverLite() {
+  delete m_pHWLayer;
+  delete m_pTexStorage; delete m_pTexStorageAux; delete m_pGeomStorage; delete m_pMaterialStorage; delete m_pPdfStorage;
+}
+
+void RenderDriverLite::Unsupported(const std::string& what) {
+  m_unsupported++;
+  m_log += "[unsupported] " + what + "\n";
+}
+
+void RenderDriverLite::AllocAll(int imgNum, int matNum, int lightNum, int meshNum) {
+  m_pTexStorage = m_pHWLayer->CreateMemStorage(0, "textures");
+  m_pTexStorageAux = m_pHWLayer->CreateMemStorage(0, "textures_aux");
+  m_pGeomStorage = m_pHWLayer->CreateMemStorage(0, "geom");
+  m_pMaterialStorage = m_pHWLayer->CreateMemStorage(0, "materials");
+  m_pPdfStorage = m_pHWLayer->CreateMemStorage(0, "pdfs");
+  m_pHWLayer->ResizeTablesForEngineGlobals(meshNum, imgNum, matNum, lightNum);
+
+  // white diffuse dummy in the last material slot, first in the arena (RenderDriverRTE.cpp:718-727)
+  PlainMaterialVec white = flatten(make_lambert(float3(1, 1, 1), int32_t(HYDRA_INVALID_TEXTURE), Sampler()));
+  const int32_t whiteOffs = m_pMaterialStorage->Update(matNum - 1, white.data(), white.size() * sizeof(float));
+  auto vars = m_pHWLayer->GetAllFlagsAndVars();
+  vars.m_varsI[8 /*HRT_WHITE_DIFFUSE_OFFSET*/] = whiteOffs;
+  m_pHWLayer->SetAllFlagsAndVars(vars);
+}
+
+bool RenderDriverLite::UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_t bpp, int32_t chan, const void* a_data) {
+  if (a_data == nullptr) return false;
+  int32_t header[4] = {w, h, chan, bpp};   // SWTextureHeader, cfetch.h:96-105
+  const size_t inBytes = size_t(w) * size_t(h) * size_t(bpp);
+  const size_t headerSize = 16;
+  const size_t total = ((inBytes + 15) / 16) * 16 + headerSize;
+  if (m_pTexStorage->Update(a_texId, nullptr, total) == -1) return false;
+  m_pTexStorage->UpdatePartial(a_texId, header, 0, 16);
+  m_pTexStorage->UpdatePartial(a_texId, a_data, headerSize, inBytes);
+  return true;
+}
+
+// CreateFromHydraMaterialXmlNode + CreateMaterialFromXmlNode, PlainMaterialConverter.cpp:1502-1738
+bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
+  const std::string mtype = a_node->attr("type");
+  if (mtype != "hydra_material") { Unsupported("material type '" + mtype + "' (id " + std::to_string(a_matId) + ")"); }
+
+  const XmlNode* emission = a_node->child("emission");
+  const XmlNode* diffuse = a_node->child("diffuse");
+  const XmlNode* reflect = a_node->child("reflectivity");
+  const XmlNode* transpar = a_node->child("transparency");
+  const XmlNode* sss = a_node->child("translucency");
+  const float3 colorE = read_value3f(xchild(emission, "color"));
+  float3 colorD = read_value3f(xchild(diffuse, "color"));
+  const float3 colorS = read_value3f(xchild(reflect, "color"));
+  const float3 colorT = read_value3f(xchild(transpar, "color"));
+  const float3 colorSSS = read_value3f(xchild(sss, "color"));
+  if (length(colorT) > 1e-5f) Unsupported("transparency (material " + std::to_string(a_matId) + ")");
+  if (length(colorSSS) > 1e-5f) Unsupported("translucency (material " + std::to_string(a_matId) + ")");
+  if (a_node->child("displacement") || a_node->child("opacity")) Unsupported("displacement/opacity (material " + std::to_string(a_matId) + ")");
+  if (length(colorD) <= 1e-5f) colorD = colorSSS;
+
+  const bool haveFresnelRefl = (xchild(reflect, "fresnel") && xchild(reflect, "fresnel")->attr_int("val") == 1);
+  const float fresnelIOR = read_fresnel_ior(reflect);
+  const int reflExtrusion = read_extrusion(reflect);
+
+  // DiffuseMaterialFromHydraMtl :980-1001
+  MatPtr pMaterialD;
+  {
+    Sampler s; int32_t texId = int32_t(HYDRA_INVALID_TEXTURE);
+    if (sampler_node(diffuse)) { s = sampler_from_texref(sampler_node(diffuse)); texId = s.texId; }
+    if (std::string(xattr(diffuse, "brdf_type")) == "orennayar") Unsupported("oren-nayar diffuse (material " + std::to_string(a_matId) + ")");
+    pMaterialD = make_lambert(read_value3f(xchild(diffuse, "color")), texId, s);
+  }
+  // ReflectiveMaterialFromHydraMtl :1061-1149
+  MatPtr pMaterialS;
+  int32_t texReflId = int32_t(HYDRA_INVALID_TEXTURE);
+  Sampler samplRefl;
+  {
+    const XmlNode* gloss = xchild(reflect, "glossiness");
+    const float glossVal = read_value1f(gloss);
+    Sampler sg; int32_t texGloss = int32_t(HYDRA_INVALID_TEXTURE);
+    if (sampler_node(reflect)) { samplRefl = sampler_from_texref(sampler_node(reflect)); texReflId = samplRefl.texId; }
+    if (sampler_node(gloss)) { sg = sampler_from_texref(sampler_node(gloss)); texGloss = sg.texId; }
+    const std::string brdf = xattr(reflect, "brdf_type");
+    if (texGloss == int32_t(HYDRA_INVALID_TEXTURE) && glossVal >= 0.995f)
+      pMaterialS = make_mirror(colorS, texReflId, samplRefl);
+    else {
+      if (length(colorS) > 1e-5f && brdf != "phong" && brdf != "")
+        Unsupported("reflectivity brdf_type '" + brdf + "' (material " + std::to_string(a_matId) + "), packed as phong");
+      pMaterialS = make_phong(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal);
+    }
+    const XmlNode* efix = xchild(reflect, "energy_fix");
+    if (!efix) efix = xchild(reflect, "multiscatter_fix");
+    if (!efix) efix = xchild(reflect, "multiscatter");
+    if (efix && efix->attr_int("val") == 1) put_i(pMaterialS->plain, HM_FLAGS, get_i(pMaterialS->plain, HM_FLAGS) | HMF_ENERGY_FIX);
+  }
+  // EmissiveMaterialFromHydraMtl :953-978
+  MatPtr pMaterialE;
+  {
+    float mult = 1.0f;
+    if (xhas(xchild(emission, "multiplier"), "val")) mult = xchild(emission, "multiplier")->attr_float("val");
+    Sampler s; int32_t texId = int32_t(HYDRA_INVALID_TEXTURE);
+    if (sampler_node(emission)) { s = sampler_from_texref(sampler_node(emission)); texId = s.texId; }
+    pMaterialE = make_emissive(colorE * mult, texId, s, a_node->attr_int("light_id"));
+    if (xchild(emission, "cast_gi") && xchild(emission, "cast_gi")->attr_int("val") == 0)
+      put_i(pMaterialE->plain, HM_FLAGS, get_i(pMaterialE->plain, HM_FLAGS) | HMF_FORBID_EMISSIVE_GI);
+  }
+
+  MatPtr pResult;
+  if ((length(colorD) > 1e-5f && length(colorS) > 1e-5f) || (length(colorS) > 1e-5f && haveFresnelRefl))
+    pResult = make_blend(pMaterialS, pMaterialD, colorS, texReflId, samplRefl, haveFresnelRefl, true, reflExtrusion, fresnelIOR);
+  else if (length(colorS) > 1e-5f) pResult = pMaterialS;
+  else if (length(colorD) > 1e-5f) pResult = pMaterialD;
+  else if (length(colorE) > 1e-5f) pResult = pMaterialE;
+  else pResult = pMaterialD;
+
+  // emission header copied into the root when the material is not emissive-only (:1716-1728)
+  if (length(colorE) > 1e-5f && pResult != pMaterialE) {
+    const bool visible = (a_node->attr_int("visible") == 1);
+    if (!visible && a_node->has_attr("light_id")) Unsupported("invisible light material " + std::to_string(a_matId));
+    float* dst = pResult->plain;
+    const float* src = pMaterialE->plain;
+    memcpy(dst + HM_EMISSIVE_COLOR, src + HM_EMISSIVE_COLOR, 12);
+    memcpy(dst + HM_EMISSIVE_TEXID, src + HM_EMISSIVE_TEXID, 12);
+    memcpy(dst + HM_EMISSIVE_SAMPLER, src + HM_EMISSIVE_SAMPLER, 48);
+  }
+  // PopUpTransparencyAndCaustics :1284-1304 (one level)
+  if (pResult->isBlend) {
+    const int mask = HMF_CAST_CAUSTICS | HMF_HAS_TRANSPARENCY;
+    const int f = (get_i(pResult->c1->plain, HM_FLAGS) & mask) | (get_i(pResult->c2->plain, HM_FLAGS) & mask);
+    put_i(pResult->plain, HM_FLAGS, get_i(pResult->plain, HM_FLAGS) | f);
+  }
+  // PutAbstractMaterialToStorage :1848-1881
+  PlainMaterialVec mdata = flatten(pResult);
+  m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
+  return true;
+}
+
+// AreaDiffuseLight, hydra_drv/PlainLightConverter.cpp:130-253
+bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
+  const std::string ltype = a_node->attr("type"), lshape = a_node->attr("shape"), distr = a_node->attr("distribution");
+  if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
+  if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
+  if (xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1) Unsupported("sky portal");
+
+  LightProto lp;
+  lp.plain.assign(HL_FLOATS, 0.0f);
+  float* d = lp.plain.data();
+  d[HL_PROB_MULT] = 1.0f;                                   // ILight::ILight, AbstractMaterial.h:130-134
+  const bool isSpot = (distr == "spot"), isDisk = (lshape == "disk");
+  const XmlNode* size = a_node->child("size");
+  float sx = size ? size->attr_float("half_length") : 0.0f;  // ReadRectLightSize (HydraAPI): x = half_length, y = half_width,
+  float sy = size ? size->attr_float("half_width") : 0.0f;   // pinned by the light meshes of test_42/test_224 (x extent = half_length)
+  if (isDisk) sx = size ? size->attr_float("radius") : 0.0f;
+  const XmlNode* inten = a_node->child("intensity");
+  float3 color = read_value3f(xchild(inten, "color"));
+  const float mult = read_value1f(xchild(inten, "multiplier"));
+  color = color * mult;
+  float area = 4.0f * sx * sy;
+  if (isDisk) area = 3.14159265358979323846f * sx * sx;
+  const float angle1 = read_value1f(xchild(a_node, "falloff_angle")), angle2 = read_value1f(xchild(a_node, "falloff_angle2"));
+  const float DEG2RAD = 3.14159265358979323846f / 180.f;
+
+  d[HL_POS + 0] = 0; d[HL_POS + 1] = 0; d[HL_POS + 2] = 0;
+  d[HL_NORM + 0] = 0; d[HL_NORM + 1] = -1; d[HL_NORM + 2] = 0;
+  d[HL_COLOR + 0] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+  put_i(d, HL_COLOR_TEX, int32_t(HYDRA_INVALID_TEXTURE));
+  put_i(d, HL_COLOR_TEX_MATRIX, int32_t(HYDRA_INVALID_TEXTURE));
+  d[HL_SURFACE_AREA] = area;
+  d[HL_AREA_SIZE_X] = sx; d[HL_AREA_SIZE_Y] = sy;
+  const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  memcpy(d + HL_AREA_MATRIX, ident, 36);
+  d[HL_AREA_SPOT_COS1] = cosf(0.5f * DEG2RAD * angle2);
+  d[HL_AREA_SPOT_COS2] = cosf(0.5f * DEG2RAD * angle1);
+  put_i(d, HL_AREA_IS_DISK, int(isDisk));
+  put_i(d, HL_AREA_SPOT_DISTR, int(isSpot));
+  put_i(d, HL_AREA_SKY_SOURCE, 0);
+  put_i(d, HL_TYPE, HLT_AREA);
+  put_i(d, HL_FLAGS, 0);
+  put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
+  put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
+  // IES matrix: identity rotated 90 degrees about Y (ROTATE_IES_90_DEG, PlainLightConverter.cpp:14,170-174); unused without IES
+  const float iesM[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};
+  memcpy(d + HL_IES_LIGHT_MATRIX, iesM, 36);
+  lp.isDisk = isDisk;
+  m_lights[a_lightId] = lp;
+  return true;
+}
+
+// CalcAuxShadowRaysOffsets + UpdateMesh, RenderDriverRTE.cpp:990-1159
+bool RenderDriverLite::UpdateMesh(int32_t a_meshId, int vertNum, int triNum, const float* pos4f, const float* norm4f, const float* tan4f,
+                                  const float* texcoord2f, const int* indices, const int* triMatIndices) {
+  auto rb = [](size_t b) { return ((b + 15) / 16) * 16; };
+  const size_t headerSize = rb(sizeof(HydraPlainMesh));
+  const size_t vertPosOffset = headerSize, vertPosSize = rb(16 * size_t(vertNum));
+  const size_t vertNormOffset = vertPosOffset + vertPosSize, vertNormSize = vertPosSize;
+  const size_t vertTexcOffset = vertNormOffset + vertNormSize, vertTexcSize = 0;
+  const size_t vertTangOffset = vertTexcOffset + vertTexcSize, vertTangSize = vertPosSize;
+  const size_t triIndOffset = vertTangOffset + vertTangSize, triIndSize = rb(size_t(triNum) * 3 * 4);
+  const size_t triMIndOffset = triIndOffset + triIndSize, triMIndSize = rb(size_t(triNum) * 4);
+  const size_t triSOffOffset = triMIndOffset + triMIndSize, triSOffSize = rb(size_t(triNum) * 4);
+  const size_t totalByteSize = triSOffOffset + triSOffSize;
+
+  std::vector<float> posAndTx(pos4f, pos4f + size_t(vertNum) * 4), normAndTy(norm4f, norm4f + size_t(vertNum) * 4);
+  for (int i = 0; i < vertNum; i++) { posAndTx[i * 4 + 3] = texcoord2f[2 * i]; normAndTy[i * 4 + 3] = texcoord2f[2 * i + 1]; }
+
+  // per-polygon auxiliary shadow offsets
+  float3 bmn(1e30f, 1e30f, 1e30f), bmx(-1e30f, -1e30f, -1e30f);
+  auto P = [&](int i) { return float3(pos4f[i * 4], pos4f[i * 4 + 1], pos4f[i * 4 + 2]); };
+  auto N = [&](int i) { return float3(norm4f[i * 4], norm4f[i * 4 + 1], norm4f[i * 4 + 2]); };
+  for (int t = 0; t < triNum; t++)
+    for (int k = 0; k < 3; k++) { const float3 v = P(indices[t * 3 + k]); bmn = vmin(bmn, v); bmx = vmax(bmx, v); }
+  const float3 ext = bmx - bmn;
+  const float meshMaxShadowOffset = 0.00025f * fmaxf(ext.x, fmaxf(ext.y, ext.z));
+  auto normalDiff = [](float3 n1, float3 n2) { if (dot(n1, n2) < 0) n2 = n2 * (-1.0f); return length(n1 - n2); };
+  std::vector<float> shadowOffsets(triNum);
+  for (int t = 0; t < triNum; t++) {
+    const int iA = indices[t * 3], iB = indices[t * 3 + 1], iC = indices[t * 3 + 2];
+    const float3 A = P(iA), B = P(iB), C = P(iC);
+    const float3 crpd = cross(A - B, A - C);
+    const float3 fN = normalize(crpd);
+    const float nd = normalDiff(fN, N(iA)) + normalDiff(fN, N(iB)) + normalDiff(fN, N(iC));
+    shadowOffsets[t] = (nd > 0.001f) ? fminf(0.05f * sqrtf(length(crpd * 0.5f)), meshMaxShadowOffset) : 0.0f;
+  }
+
+  if (m_pGeomStorage->Update(a_meshId, nullptr, totalByteSize) == -1) return false;
+  HydraPlainMesh header;
+  memset(&header, 0, sizeof(header));
+  header.vPosOffset = int(vertPosOffset / 16); header.vNormOffset = int(vertNormOffset / 16);
+  header.vTexCoordOffset = int(vertTexcOffset / 16); header.vTangentOffset = int(vertTangOffset / 16);
+  header.vIndicesOffset = int(triIndOffset / 16); header.mIndicesOffset = int(triMIndOffset / 16);
+  header.polyShadowOffset = int(triSOffOffset / 16);
+  header.vPosNum = header.vNormNum = header.vTexCoordNum = header.vTangentNum = vertNum;
+  header.tIndicesNum = triNum * 3; header.mIndicesNum = triNum;
+  header.totalBytesNum = uint32_t(totalByteSize);
+  m_pGeomStorage->UpdatePartial(a_meshId, &header, 0, sizeof(header));
+  m_pGeomStorage->UpdatePartial(a_meshId, posAndTx.data(), vertPosOffset, size_t(vertNum) * 16);
+  m_pGeomStorage->UpdatePartial(a_meshId, normAndTy.data(), vertNormOffset, size_t(vertNum) * 16);
+  m_pGeomStorage->UpdatePartial(a_meshId, tan4f, vertTangOffset, size_t(vertNum) * 16);
+  m_pGeomStorage->UpdatePartial(a_meshId, indices, triIndOffset, size_t(triNum) * 12);
+  m_pGeomStorage->UpdatePartial(a_meshId, triMatIndices, triMIndOffset, size_t(triNum) * 4);
+  m_pGeomStorage->UpdatePartial(a_meshId, shadowOffsets.data(), triSOffOffset, size_t(triNum) * 4);
+  return true;
+}
+
+bool RenderDriverLite::UpdateCamera(const XmlNode* cam) {
+  if (cam == nullptr) return true;
+  if (std::string(cam->attr("type")) == "two_matrices") Unsupported("two_matrices camera");
+  float v[3];
+  if (cam->child("fov") && !cam->child("fov")->text.empty()) m_camera.fov = strtof(cam->child("fov")->text.c_str(), nullptr);
+  if (cam->child("nearClipPlane")) m_camera.nearPlane = strtof(cam->child("nearClipPlane")->text.c_str(), nullptr);
+  if (cam->child("farClipPlane")) m_camera.farPlane = strtof(cam->child("farClipPlane")->text.c_str(), nullptr);
+  if (cam->child("position") && parse_floats(cam->child("position")->text, v, 3)) m_camera.pos = float3(v[0], v[1], v[2]);
+  if (cam->child("look_at") && parse_floats(cam->child("look_at")->text, v, 3)) m_camera.lookAt = float3(v[0], v[1], v[2]);
+  if (cam->child("up") && parse_floats(cam->child("up")->text, v, 3)) m_camera.up = float3(v[0], v[1], v[2]);
+
+  auto vars = m_pHWLayer->GetAllFlagsAndVars();
+  vars.m_varsF[HV_F_CAM_FOV] = (3.14159265358979323846f / 180.f) * m_camera.fov;
+  if (cam->child("dof_lens_radius") && !cam->child("dof_lens_radius")->text.empty())
+    vars.m_varsF[HV_F_DOF_LENS_RADIUS] = strtof(cam->child("dof_lens_radius")->text.c_str(), nullptr);
+  vars.m_varsF[HV_F_DOF_FOCAL_PLANE_DIST] = length(m_camera.pos - m_camera.lookAt);
+  int hasDof = -1;
+  if (cam->child("enable_dof") && !cam->child("enable_dof")->text.empty()) hasDof = atoi(cam->child("enable_dof")->text.c_str());
+  if (m_forceDof >= 0) hasDof = m_forceDof;
+  if (hasDof >= 0) {
+    if (hasDof > 0) vars.m_varsI[HV_I_ENABLE_DOF] = hasDof;
+    else { vars.m_varsI[HV_I_ENABLE_DOF] = 0; vars.m_varsF[HV_F_DOF_LENS_RADIUS] = 0.0f; }
+  }
+  if (cam->child("tiltRotX") || cam->child("tiltRotY")) {  // swapped on purpose, RenderDriverRTE.cpp:1254-1258
+    vars.m_varsF[HV_F_TILT_ROT_Y] = strtof(xtext(cam->child("tiltRotX")).c_str(), nullptr);
+    vars.m_varsF[HV_F_TILT_ROT_X] = strtof(xtext(cam->child("tiltRotY")).c_str(), nullptr);
+  } else { vars.m_varsF[HV_F_TILT_ROT_Y] = 0.0f; vars.m_varsF[HV_F_TILT_ROT_X] = 0.0f; }
+  vars.m_varsI[21 /*HRT_SAMPLES_PER_PASS*/] = cam->has_attr("integrator_iters") ? cam->attr_int("integrator_iters") : 1;
+  m_pHWLayer->SetAllFlagsAndVars(vars);
+  return true;
+}
+
+bool RenderDriverLite::UpdateSettings(const XmlNode* st) {
+  auto vars = m_pHWLayer->GetAllFlagsAndVars();
+  vars.m_varsI[47 /*HRT_FBUF_CHANNELS*/] = 4;
+  vars.m_flags |= (HF_USE_MIS | HF_COMPUTE_SHADOWS);
+  const std::string mc = xtext(xchild(st, "method_caustic"));
+  if (mc == "none" || mc == "disabled") vars.m_flags &= ~unsigned(HF_ENABLE_PT_CAUSTICS);
+  else vars.m_flags |= HF_ENABLE_PT_CAUSTICS;
+  vars.m_varsI[HV_I_TRACE_DEPTH] = 6;
+  vars.m_varsI[HV_I_DIFFUSE_TRACE_DEPTH] = 3;
+  vars.m_varsI[29 /*HRT_ENABLE_PATH_REGENERATE*/] = 1;
+  vars.m_varsF[HV_F_IMAGE_GAMMA] = 2.2f;
+  vars.m_varsF[HV_F_TEXINPUT_GAMMA] = 2.2f;
+  vars.m_varsF[15 /*HRT_PATH_TRACE_ERROR*/] = 0.025f;
+  vars.m_varsF[3 /*HRT_TRACE_PROCEEDINGS_TRESHOLD*/] = 1e-8f;
+  vars.m_varsF[16 /*HRT_PATH_TRACE_CLAMPING*/] = 1e6f;
+  vars.m_varsI[33 /*HRT_MMLT_BURN_ITERS*/] = 1024;
+  if (xchild(st, "outgamma")) vars.m_varsF[HV_F_IMAGE_GAMMA] = strtof(xtext(xchild(st, "outgamma")).c_str(), nullptr);
+  if (xchild(st, "trace_depth")) vars.m_varsI[HV_I_TRACE_DEPTH] = atoi(xtext(xchild(st, "trace_depth")).c_str()) + 1;
+  if (xchild(st, "diff_trace_depth")) vars.m_varsI[HV_I_DIFFUSE_TRACE_DEPTH] = atoi(xtext(xchild(st, "diff_trace_depth")).c_str()) + 1;
+  m_pHWLayer->SetAllFlagsAndVars(vars);
+  m_pHWLayer->ResizeScreen(m_width, m_height, 0);
+  return true;
+}
+
+void RenderDriverLite::BeginScene() {
+  m_instMatricesInv.clear(); m_instLightInstId.clear(); m_meshIdByInstId.clear(); m_meshRemapListId.clear();
+  m_lightsInstanced.clear();
+  m_bvh.ClearScene();
+  const int32_t dummyList[2] = {0, 0};
+  m_pHWLayer->SetAllRemapLists(dummyList, dummyList, 0, 0);
+}
+
+void RenderDriverLite::InstanceMeshes(int32_t a_mesh_id, const float* a_matrices, int32_t a_instNum, const int* a_lightInstId,
+                                      const int* a_remapId, const int* a_realInstId) {
+  const auto table = m_pGeomStorage->GetTable();
+  if (a_mesh_id >= int(table.size()) || table[a_mesh_id] < 0) { m_log += "InstanceMeshes: bad mesh id\n"; return; }
+  const char* base = static_cast<const char*>(m_pGeomStorage->GetBegin()) + size_t(table[a_mesh_id]) * 16;
+  const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(base);
+  BVH4Builder::InstanceInputData in;
+  in.vert4f = reinterpret_cast<const float*>(base + size_t(hdr->vPosOffset) * 16);
+  in.indices = reinterpret_cast<const int*>(base + size_t(hdr->vIndicesOffset) * 16);
+  in.numVert = hdr->vPosNum;
+  in.numIndices = hdr->tIndicesNum;
+  in.meshId = a_mesh_id;
+  in.matrices = a_matrices;
+  in.numInst = a_instNum;
+  m_bvh.InstanceTriangleMeshes(in, 0, int(m_meshIdByInstId.size()));
+  for (int i = 0; i < a_instNum; i++) {
+    float4x4 m;
+    memcpy(m.c, a_matrices + 16 * i, 64);
+    m_instMatricesInv.push_back(inverse4x4(m));
+    m_instLightInstId.push_back(a_lightInstId[i]);
+    m_meshIdByInstId.push_back(a_mesh_id);
+    m_meshRemapListId.push_back(a_remapId[i]);
+    (void)a_realInstId;
+  }
+}
+
+// AreaDiffuseLight::Transform, PlainLightConverter.cpp:281-352 + RenderDriverRTE::InstanceLights :2012-2080
+void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, const XmlNode** a_lightNodes, int32_t a_instNum, int32_t a_lightGroupId) {
+  auto it = m_lights.find(a_lightId);
+  if (it == m_lights.end()) { m_log += "InstanceLights: bad light id\n"; return; }
+  for (int i = 0; i < a_instNum; i++) {
+    float4x4 M;
+    memcpy(M.c, a_matrix + 16 * i, 64);
+    std::vector<float> copy = it->second.plain;
+    float* d = copy.data();
+    const float3 lpos = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+    d[HL_POS] = lpos.x; d[HL_POS + 1] = lpos.y; d[HL_POS + 2] = lpos.z;
+    const float3 ln = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
+    d[HL_NORM] = ln.x; d[HL_NORM + 1] = ln.y; d[HL_NORM + 2] = ln.z;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) d[HL_AREA_MATRIX + r * 3 + c] = M.at(r, c);
+    if (it->second.isDisk) {
+      const float3 vert = mul_vec(M, normalize(float3(1, 1, 1)));
+      const float radius = d[HL_AREA_SIZE_X] * length(vert);
+      d[HL_SURFACE_AREA] = 3.1415926535f * radius * radius;
+    } else {
+      const float sx = d[HL_AREA_SIZE_X], sy = d[HL_AREA_SIZE_Y];
+      const float3 v0 = mul_point(M, float3(-sx, 0, -sy)), v1 = mul_point(M, float3(-sx, 0, sy)), v2 = mul_point(M, float3(sx, 0, sy));
+      d[HL_SURFACE_AREA] = length(v1 - v0) * length(v1 - v2);
+    }
+    if (a_lightNodes && a_lightNodes[i]) {
+      const XmlNode* n = a_lightNodes[i];
+      if (n->has_attr("color_mult")) {
+        float cm[3] = {1, 1, 1};
+        parse_floats(n->attr("color_mult"), cm, 3);
+        d[HL_COLOR] *= cm[0]; d[HL_COLOR + 1] *= cm[1]; d[HL_COLOR + 2] *= cm[2];
+      }
+      if (n->has_attr("prob_mult")) d[HL_PROB_MULT] = n->attr_float("prob_mult");
+    }
+    put_i(d, HL_GROUP_ID, a_lightGroupId);
+    d[HL_PICK_PROB_REV] = 1.0f;
+    d[HL_PICK_PROB_FWD] = 1.0f;
+    m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
+  }
+}
+
+// RenderDriverRTE_PdfTables.cpp:575-647
+std::vector<float> RenderDriverLite::CalcLightPickProbTable(bool a_fwd) {
+  const size_t n = m_lightsInstanced.size() / HL_FLOATS;
+  std::vector<float> pick(n);
+  std::map<int, int> groups;
+  int noGroups = 0;
+  for (size_t i = 0; i < n; i++) {
+    const int g = get_i(&m_lightsInstanced[i * HL_FLOATS], HL_GROUP_ID);
+    if (g == -1) noGroups++; else groups[g]++;
+  }
+  noGroups += int(groups.size());
+  const float pickGroupProb = 1.0f / float(noGroups);
+  for (size_t i = 0; i < n; i++) {
+    float* d = &m_lightsInstanced[i * HL_FLOATS];
+    const int g = get_i(d, HL_GROUP_ID);
+    float pp = (g == -1) ? pickGroupProb : pickGroupProb / float(groups[g]);
+    if (get_i(d, HL_TYPE) == HLT_SKY_DOME && a_fwd) pp = 0.0f;
+    if (length(float3(d[HL_COLOR], d[HL_COLOR + 1], d[HL_COLOR + 2])) < 0.01f) pp = 0.0f;
+    if (d[HL_PROB_MULT] > 0.0f) pp *= d[HL_PROB_MULT];
+    d[a_fwd ? HL_PICK_PROB_FWD : HL_PICK_PROB_REV] = pp;
+    pick[i] = pp;
+  }
+  return pick;
+}
+
+void RenderDriverLite::EndScene() {
+  m_bvh.CommitScene();
+  {
+    ConvertionResult cr = m_bvh.ConvertMap();
+    m_pHWLayer->SetAllBVH4(cr, nullptr, 0);
+    m_bvh.ConvertUnmap();
+  }
+  float bmin[3], bmax[3];
+  m_bvh.GetBounds(bmin, bmax);
+  const float3 half = 0.5f * (float3(bmax[0], bmax[1], bmax[2]) - float3(bmin[0], bmin[1], bmin[2]));
+  const float3 center = 0.5f * (float3(bmax[0], bmax[1], bmax[2]) + float3(bmin[0], bmin[1], bmin[2]));
+
+  if (m_instMatricesInv.empty()) RunTimeError("RenderDriverRTE::EndScene, no instances in the scene!");
+  m_pHWLayer->SetAllInstMatrices(m_instMatricesInv.data(), int32_t(m_instMatricesInv.size()));
+  m_pHWLayer->SetAllInstIdToRemapId(m_meshRemapListId.data(), int32_t(m_meshRemapListId.size()));
+
+  auto vars = m_pHWLayer->GetAllFlagsAndVars();
+  vars.m_varsF[HV_F_BSPHERE_CENTER_X] = center.x;
+  vars.m_varsF[HV_F_BSPHERE_CENTER_X + 1] = center.y;
+  vars.m_varsF[HV_F_BSPHERE_CENTER_X + 2] = center.z;
+  vars.m_varsF[HV_F_BSPHERE_RADIUS] = length(half);
+  vars.m_varsI[35 /*HRT_SHADOW_MATTE_BACK*/] = int32_t(HYDRA_INVALID_TEXTURE);
+  vars.m_varsF[36 /*HRT_BACK_TEXINPUT_GAMMA*/] = 2.2f;
+  m_pHWLayer->SetAllFlagsAndVars(vars);
+
+  const size_t nl = m_lightsInstanced.size() / HL_FLOATS;
+  if (nl > 0) {
+    m_pHWLayer->SetAllInstLightInstId(m_instLightInstId.data(), int32_t(m_instLightInstId.size()));
+    const std::vector<float> rev = CalcLightPickProbTable(false), fwd = CalcLightPickProbTable(true);
+    auto prefix = [](const std::vector<float>& v) {
+      std::vector<float> acc(v.size() + 1);
+      float a = 0.0f;
+      for (size_t i = 0; i < v.size(); i++) { acc[i] = a; a += v[i]; }
+      acc[v.size()] = a;
+      return acc;
+    };
+    const std::vector<float> tRev = prefix(rev), tFwd = prefix(fwd);
+    const float nRev = 1.0f / tRev.back(), nFwd = 1.0f / tFwd.back();
+    for (size_t i = 0; i < nl; i++) {
+      m_lightsInstanced[i * HL_FLOATS + HL_PICK_PROB_FWD] *= nFwd;
+      m_lightsInstanced[i * HL_FLOATS + HL_PICK_PROB_REV] *= nRev;
+    }
+    m_pHWLayer->SetAllLightsSelectTable(tRev.data(), int32_t(tRev.size()), false);
+    m_pHWLayer->SetAllLightsSelectTable(tFwd.data(), int32_t(tFwd.size()), true);
+    m_pHWLayer->SetAllPODLights(m_lightsInstanced.data(), nl);
+  } else {
+    m_log += "WARNING: RenderDriverRTE::EndScene(), no lights!\n";
+    std::vector<int32_t> none(m_instLightInstId.size(), -1);
+    m_pHWLayer->SetAllInstLightInstId(none.data(), int32_t(none.size()));
+    m_pHWLayer->SetAllLightsSelectTable(nullptr, 0, false);
+    m_pHWLayer->SetAllLightsSelectTable(nullptr, 0, true);
+    m_pHWLayer->SetAllPODLights(nullptr, 0);
+  }
+  m_pHWLayer->PrepareEngineTables();
+}
+
+void RenderDriverLite::Draw() {
+  const float aspect = float(m_width) / float(m_height);
+  float4x4 proj = perspective_matrix(m_camera.fov, aspect, m_camera.nearPlane, m_camera.farPlane);
+  float4x4 worldView = look_at(m_camera.pos, m_camera.lookAt, m_camera.up);
+  float4x4 projInv = inverse4x4(proj), mvInv = inverse4x4(worldView);
+  m_pHWLayer->SetCamMatrices(&projInv.c[0][0], &mvInv.c[0][0], &proj.c[0][0], &worldView.c[0][0], aspect,
+                             (3.14159265358979323846f / 180.f) * m_camera.fov, m_camera.lookAt);
+  m_pHWLayer->PrepareEngineGlobals();
+  SharedDataLayer* shared = dynamic_cast<SharedDataLayer*>(m_pHWLayer);
+  if (shared != nullptr && !shared->HasDevice()) return;   // host-blob layer: buffers only, nothing to trace
+  if (!m_ptInitDone) { m_pHWLayer->InitPathTracing(m_seed); m_ptInitDone = true; }
+  m_pHWLayer->BeginTracingPass();
+  m_pHWLayer->EndTracingPass();
+}
+
+// ------------------------------------------------------------------------------------------------ HydraAPI's part
+void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width, int a_height, int a_traceDepth, int a_enableDof) {
+  std::vector<char> xmlData;
+  std::string xmlPath = libPath + "/statex_00001.xml";
+  if (!read_file(xmlPath, xmlData)) RunTimeError("LoadSceneLibrary: can't open " + xmlPath);
+  const std::string src(xmlData.begin(), xmlData.end());
+  XmlParser parser(src);
+  std::unique_ptr<XmlNode> doc = parser.parse_document();
+  m_forceDof = a_enableDof;
+
+  const XmlNode* texLib = doc->child("textures_lib");
+  const XmlNode* matLib = doc->child("materials_lib");
+  const XmlNode* lgtLib = doc->child("lights_lib");
+  const XmlNode* camLib = doc->child("cam_lib");
+  const XmlNode* geoLib = doc->child("geometry_lib");
+  const XmlNode* rndLib = doc->child("render_lib");
+  const XmlNode* scnLib = doc->child("scenes");
+  if (!matLib || !geoLib || !scnLib) RunTimeError("LoadSceneLibrary: incomplete scene library " + xmlPath);
+
+  auto maxId = [](const XmlNode* lib, const char* name) {
+    int m = -1;
+    if (lib) for (auto* n : lib->children_named(name)) m = std::max(m, n->attr_int("id"));
+    return m;
+  };
+  const int imgNum = maxId(texLib, "texture") + 1, matNum = maxId(matLib, "material") + 2;
+  const int lightNum = std::max(maxId(lgtLib, "light") + 1, 1), meshNum = maxId(geoLib, "mesh") + 1;
+
+  const XmlNode* settings = rndLib ? rndLib->child("render_settings") : nullptr;
+  if (a_width <= 0 && settings && settings->child("width")) a_width = atoi(settings->child("width")->text.c_str());
+  if (a_height <= 0 && settings && settings->child("height")) a_height = atoi(settings->child("height")->text.c_str());
+  if (a_width > 0) m_width = a_width;
+  if (a_height > 0) m_height = a_height;
+
+  const XmlNode* scene = scnLib->child("scene");
+  if (!scene) RunTimeError("LoadSceneLibrary: no <scene>");
+  const auto lightInstNodes = scene->children_named("instance_light");
+  const int lightInstNum = int(lightInstNodes.size());
+
+  AllocAll(imgNum, matNum, std::max(lightNum, lightInstNum), meshNum);
+
+  if (texLib)
+    for (auto* t : texLib->children_named("texture")) {
+      if (!t->has_attr("loc")) continue;                       // delayed-load textures without data (dl="1")
+      std::vector<char> d;
+      if (!read_file(libPath + "/" + t->attr("loc"), d) || d.size() < 8) { m_log += std::string("missing texture chunk ") + t->attr("loc") + "\n"; continue; }
+      int32_t wh[2];
+      memcpy(wh, d.data(), 8);
+      const size_t bytes = d.size() - 8;
+      const int bpp = int(bytes / (size_t(wh[0]) * size_t(wh[1])));
+      if (bpp != 4 && bpp != 16) { Unsupported("texture bpp " + std::to_string(bpp)); continue; }
+      UpdateImage(t->attr_int("id"), wh[0], wh[1], bpp, 4, d.data() + 8);
+    }
+  for (auto* m : matLib->children_named("material")) UpdateMaterial(m->attr_int("id"), m);
+  if (lgtLib)
+    for (auto* l : lgtLib->children_named("light")) UpdateLight(l->attr_int("id"), l);
+
+  std::set<int> loadedMeshes;
+  for (auto* me : geoLib->children_named("mesh")) {
+    std::vector<char> d;
+    if (!me->has_attr("loc") || !read_file(libPath + "/" + me->attr("loc"), d)) { m_log += std::string("missing mesh chunk for mesh ") + me->attr("id") + "\n"; continue; }
+    const int vertNum = me->attr_int("vertNum"), triNum = me->attr_int("triNum");
+    auto arr = [&](const char* name) -> const char* {
+      const XmlNode* a = me->child(name);
+      if (!a) RunTimeError(std::string("mesh without <") + name + ">");
+      const size_t off = size_t(atoll(a->attr("offset"))), sz = size_t(atoll(a->attr("bytesize")));
+      if (off + sz > d.size()) RunTimeError("mesh chunk is shorter than its XML description");
+      return d.data() + off;
+    };
+    UpdateMesh(me->attr_int("id"), vertNum, triNum, (const float*)arr("positions"), (const float*)arr("normals"),
+               (const float*)arr("tangents"), (const float*)arr("texcoords"), (const int*)arr("indices"), (const int*)arr("matindices"));
+    loadedMeshes.insert(me->attr_int("id"));
+  }
+
+  UpdateCamera(camLib ? camLib->child("camera") : nullptr);
+  UpdateSettings(settings);
+  if (a_traceDepth >= 0) {
+    auto vars = m_pHWLayer->GetAllFlagsAndVars();
+    vars.m_varsI[HV_I_TRACE_DEPTH] = a_traceDepth + 1;
+    m_pHWLayer->SetAllFlagsAndVars(vars);
+  }
+
+  BeginScene();
+  // lights first so that linst_id of mesh instances indexes m_lightsInstanced
+  {
+    std::vector<const XmlNode*> sorted(lightInstNodes.begin(), lightInstNodes.end());
+    std::sort(sorted.begin(), sorted.end(), [](const XmlNode* a, const XmlNode* b) { return a->attr_int("id") < b->attr_int("id"); });
+    for (auto* li : sorted) {
+      float m[16];
+      if (!parse_floats(li->attr("matrix"), m, 16)) RunTimeError("instance_light without matrix");
+      const float4x4 M = float4x4::from_row_major(m);
+      const XmlNode* nodes[1] = {li};
+      InstanceLights(li->attr_int("light_id"), M.data(), nodes, 1, li->attr_int("lgroup_id", -1));
+    }
+  }
+  // mesh instances grouped by mesh id (HydraAPI hands the driver one InstanceMeshes call per mesh)
+  std::map<int, std::vector<const XmlNode*>> byMesh;
+  for (auto* in : scene->children_named("instance")) byMesh[in->attr_int("mesh_id")].push_back(in);
+  for (auto& kv : byMesh) {
+    if (!loadedMeshes.count(kv.first)) { m_log += "skipping instances of missing mesh " + std::to_string(kv.first) + "\n"; continue; }
+    std::vector<float> mats; std::vector<int> lid, rid, real;
+    for (auto* in : kv.second) {
+      float m[16];
+      if (!parse_floats(in->attr("matrix"), m, 16)) RunTimeError("instance without matrix");
+      const float4x4 M = float4x4::from_row_major(m);
+      mats.insert(mats.end(), M.data(), M.data() + 16);
+      lid.push_back(in->has_attr("linst_id") ? in->attr_int("linst_id") : -1);
+      rid.push_back(in->attr_int("rmap_id", -1));
+      real.push_back(in->attr_int("id"));
+    }
+    InstanceMeshes(kv.first, mats.data(), int(kv.second.size()), lid.data(), rid.data(), real.data());
+  }
+  EndScene();
+}
+
+}  // namespace hydra_host

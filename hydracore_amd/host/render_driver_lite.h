@@ -1,0 +1,83 @@
+// render_driver_lite.h -- minimal caller of the IHWLayer boundary: reads a HydraAPI scene library
+// (statex_*.xml + data/chunk_*.vsgf|image4ub) and issues the same IHWLayer calls, in the same order and with the
+// same buffer contents, as RenderDriverRTE does when HydraAPI commits a scene (call stack: SURVEY.md 3.1;
+// hydra_drv/RenderDriverRTE.cpp:604-745 AllocAll, :753-836 UpdateImage, :1059-1159 UpdateMesh, :1171-1289 UpdateCamera,
+// :160-396 UpdateSettings, :1953-2080 InstanceMeshes/InstanceLights, :1396-1550 EndScene, :1687-1936 Draw).
+//
+// HydraAPI itself is not in this image, so this class also plays HydraAPI's part of walking the XML (row f1,
+// "scene front end").  Supported subset: hydra_material {lambert diffuse, phong/mirror reflectivity, emission},
+// area lights (rect/disk), uvn camera with optional DOF.  Anything else is counted in UnsupportedFeatures().
+#pragma once
+#include <string>
+#include <vector>
+#include <memory>
+#include <map>
+#include "hw_layer.h"
+#include "bvh4_builder.h"
+#include "xml_mini.h"
+
+namespace hydra_host {
+
+class RenderDriverLite {
+public:
+  // a_layer is owned by the driver (reference: RenderDriverRTE deletes m_pHWLayer, RenderDriverRTE.cpp:406-410)
+  RenderDriverLite(IHWLayer* a_layer, int w, int h);
+  ~RenderDriverLite();
+
+  // plays HydraAPI: open the library and commit scene 0 / camera 0 / render settings 0.
+  // width/height <= 0 keep the values of <render_settings>.  trace_depth < 0 keeps the XML value.
+  void LoadSceneLibrary(const std::string& a_libPath, int a_width, int a_height, int a_traceDepth, int a_enableDof);
+
+  void Draw();                         // one pass: SetCamMatrices, PrepareEngineGlobals, (InitPathTracing), BeginTracingPass
+  void GetFrameBufferHDR(float* rgba, int w, int h) { m_pHWLayer->GetHDRImage(rgba, w, h); }
+
+  IHWLayer* Layer() { return m_pHWLayer; }
+  int Width() const { return m_width; }
+  int Height() const { return m_height; }
+  int UnsupportedFeatures() const { return m_unsupported; }
+  const std::string& Log() const { return m_log; }
+  BVH4Builder& Builder() { return m_bvh; }
+  void SetSeed(int s) { m_seed = s; m_ptInitDone = false; }
+
+  // individual driver entry points (same names as the IHRRenderDriver overrides in RenderDriverRTE.h:60-134)
+  void AllocAll(int imgNum, int matNum, int lightNum, int meshNum);
+  bool UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_t bpp, int32_t chan, const void* a_data);
+  bool UpdateMaterial(int32_t a_matId, const XmlNode* a_materialNode);
+  bool UpdateLight(int32_t a_lightId, const XmlNode* a_lightNode);
+  bool UpdateMesh(int32_t a_meshId, int vertNum, int triNum, const float* pos4f, const float* norm4f, const float* tan4f,
+                  const float* texcoord2f, const int* indices, const int* triMatIndices);
+  bool UpdateCamera(const XmlNode* a_camNode);
+  bool UpdateSettings(const XmlNode* a_settingsNode);
+  void BeginScene();
+  void InstanceMeshes(int32_t a_mesh_id, const float* a_matrices, int32_t a_instNum, const int* a_lightInstId,
+                      const int* a_remapId, const int* a_realInstId);
+  void InstanceLights(int32_t a_lightId, const float* a_matrix, const XmlNode** a_lightNodes, int32_t a_instNum, int32_t a_lightGroupId);
+  void EndScene();
+
+private:
+  IHWLayer* m_pHWLayer;
+  int m_width, m_height;
+  int m_unsupported = 0;
+  std::string m_log;
+  int m_seed = 777;                    // the value the reference test harness forces (hydra_app/main_app_console.cpp:142-143)
+  bool m_ptInitDone = false;
+  int m_forceDof = -1;
+
+  IMemoryStorage *m_pTexStorage = nullptr, *m_pTexStorageAux = nullptr, *m_pGeomStorage = nullptr,
+                 *m_pMaterialStorage = nullptr, *m_pPdfStorage = nullptr;
+  BVH4Builder m_bvh;
+
+  struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0}; } m_camera;
+
+  struct LightProto { std::vector<float> plain; bool isDisk = false; };   // un-instanced PlainLight (128 floats)
+  std::map<int, LightProto> m_lights;
+  std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
+
+  std::vector<float4x4> m_instMatricesInv;
+  std::vector<int32_t> m_instLightInstId, m_meshIdByInstId, m_meshRemapListId;
+
+  void Unsupported(const std::string& what);
+  std::vector<float> CalcLightPickProbTable(bool a_fwd);
+};
+
+}  // namespace hydra_host

@@ -1,0 +1,131 @@
+/* hydra_hip.h -- C-ABI of libhydra_hip.so, the MI355X (gfx950) wavefront path-tracing core.
+ *
+ * This is the drop-in boundary: an IHWLayer subclass in the reference driver
+ * (hydra_drv/IHWLayer.h:97-246, factories :256-257, call site RenderDriverRTE.cpp:85-88) forwards each
+ * virtual call to one of these entry points.  Plain C types only; every function returns 0 on success
+ * or a negative HYDRA_HIP_E* code, with a text in hydra_hip_last_error().  The library never falls
+ * back to a CPU path: without a usable HIP device hydra_hip_create fails.
+ *
+ * Blob/arena/BVH layouts are the reference's own (include/hydra_layouts.h).
+ */
+#ifndef HYDRA_HIP_H
+#define HYDRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "hydra_layouts.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hydra_hip_ctx* hydra_hip_handle;
+
+enum {
+  HYDRA_HIP_OK = 0,
+  HYDRA_HIP_EINVAL = -1,   /* bad argument / size mismatch                  */
+  HYDRA_HIP_ENODEV = -2,   /* no usable HIP device                          */
+  HYDRA_HIP_ENOMEM = -3,   /* device allocation failed                      */
+  HYDRA_HIP_ESTATE = -4,   /* call order violated (e.g. pass before upload) */
+  HYDRA_HIP_EDEVICE = -5   /* a HIP runtime call failed                     */
+};
+
+/* storage arena kinds -- names RenderDriverRTE::AllocAll passes to IHWLayer::CreateMemStorage
+ * (hydra_drv/RenderDriverRTE.cpp:705-709) */
+enum {
+  HYDRA_STORAGE_TEXTURES = 0,
+  HYDRA_STORAGE_TEXTURES_AUX = 1,
+  HYDRA_STORAGE_GEOM = 2,
+  HYDRA_STORAGE_MATERIALS = 3,
+  HYDRA_STORAGE_PDFS = 4,
+  HYDRA_STORAGE_KINDS = 5
+};
+
+/* ---------------------------------------------------------------- life cycle */
+/* replaces CreateOclImpl/CreateCPUExpImpl (IHWLayer.h:256-257) */
+int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_handle* out);
+int hydra_hip_destroy(hydra_hip_handle h);
+const char* hydra_hip_last_error(hydra_hip_handle h);            /* valid for h == NULL too (create errors) */
+int hydra_hip_device_name(hydra_hip_handle h, char* buf, int n); /* IHWLayer::GetDeviceName  :163 */
+int hydra_hip_resize(hydra_hip_handle h, int width, int height); /* IHWLayer::ResizeScreen   :147 */
+int hydra_hip_available_memory(hydra_hip_handle h, size_t* free_bytes, size_t* total_bytes); /* GetAvaliableMemoryAmount :152 */
+int hydra_hip_finish(hydra_hip_handle h);                        /* IHWLayer::FinishAll      :137 */
+
+/* ---------------------------------------------------------------- scene upload */
+/* IHWLayer::PrepareEngineGlobals / PrepareEngineTables (:109-110): the assembled int blob
+ * [EngineGlobals | tables | lights] (IHWLayerDataAssembler.cpp:149-170, 326-388). */
+int hydra_hip_upload_globals(hydra_hip_handle h, const int32_t* blob, size_t words);
+/* only the first `words` words changed (camera matrices, vars, flags); cheaper per-Draw refresh */
+int hydra_hip_update_globals_header(hydra_hip_handle h, const int32_t* blob, size_t words);
+/* contents of one IMemoryStorage arena (IMemoryStorage.h:16-49) */
+int hydra_hip_upload_storage(hydra_hip_handle h, int kind, const void* data, size_t bytes);
+/* IHWLayer::SetAllBVH4 (:116): one converted tree (IBVHBuilderAPI.h:7-33). Pointers are only read inside the call. */
+int hydra_hip_upload_bvh(hydra_hip_handle h, int tree_id, const HydraBVHNode* nodes, int nodes_num,
+                         const float* tri_f4, int tri_f4_num, const uint32_t* alpha_u2, int alpha_num,
+                         int have_inst);
+int hydra_hip_set_bvh_trees_num(hydra_hip_handle h, int trees_num);
+/* IHWLayer::SetAllInstMatrices + SetAllInstLightInstId (:117-118); copied inside the call */
+int hydra_hip_upload_instances(hydra_hip_handle h, const float* inv_matrices16, const int32_t* light_inst_id, int inst_num);
+/* IHWLayer::SetAllRemapLists + SetAllInstIdToRemapId (:122-123) */
+int hydra_hip_upload_remap_lists(hydra_hip_handle h, const int32_t* all_lists, int all_size,
+                                 const int32_t* table_int2, int table_size,
+                                 const int32_t* inst_to_remap_id, int inst_num);
+
+/* ---------------------------------------------------------------- rendering */
+/* image-plane tile partition for multi-GPU: this context renders only tiles t with
+ * t % world == rank, tiles are tile_size x tile_size pixels in row-major tile order. rank 0/world 1 = all. */
+int hydra_hip_set_tile_partition(hydra_hip_handle h, int rank, int world, int tile_size);
+/* IHWLayer::SetExternalImageAccumulator (:199): use caller-owned device memory (float4 sums, w*h*16 B)
+ * instead of the internal accumulator, e.g. a torch tensor that is later reduced over RCCL. NULL restores. */
+int hydra_hip_set_external_accumulator(hydra_hip_handle h, void* dev_float4, size_t bytes);
+int hydra_hip_init_path_tracing(hydra_hip_handle h, int seed);   /* IHWLayer::InitPathTracing :139 */
+int hydra_hip_clear_accumulated_color(hydra_hip_handle h);       /* IHWLayer::ClearAccumulatedColor :140 */
+/* IHWLayer::BeginTracingPass + EndTracingPass (:134-135): adds `spp` samples to every owned pixel.
+ * Asynchronous on the context's stream. */
+int hydra_hip_trace_pass(hydra_hip_handle h, int spp);
+/* overwrite the accumulated sample count (after an external reduce of the accumulator) */
+int hydra_hip_set_spp(hydra_hip_handle h, float spp);
+float hydra_hip_get_spp(hydra_hip_handle h);                     /* IHWLayer::GetSPP :207 */
+/* IHWLayer::GetHDRImage / GetLDRImage (:149-150): mean radiance, row-major, row 0 = bottom as generated;
+ * size mismatch returns HYDRA_HIP_EINVAL and leaves the buffer untouched (CPUExpLayer.cpp:133-147). */
+int hydra_hip_get_hdr_image(hydra_hip_handle h, float* rgba, int width, int height);
+int hydra_hip_get_ldr_image(hydra_hip_handle h, uint32_t* rgba8, int width, int height);
+/* IHWLayer::GetRaysStat / ResetPerfCounters (:145,155): per-stage HIP-event times and exact ray counters */
+int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
+int hydra_hip_reset_perf_counters(hydra_hip_handle h);
+/* enable per-stage hipEvent timing inside trace_pass (adds event records, no syncs) */
+int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
+
+/* ---------------------------------------------------------------- stage entry points
+ * One call = one wavefront kernel over n host-provided items; used by the parity tests and by the
+ * traversal roofline bench.  All pointers are HOST pointers; float4 arrays are n*4 floats.           */
+/* P1  MakeRandEyeRay (cfetch.h:877-930): pixel (x,y) + 4 offsets in [-1,1] -> world ray */
+int hydra_hip_stage_make_eye_rays(hydra_hip_handle h, int n, const int32_t* xy, const float* offs4,
+                                  float* ray_pos4, float* ray_dir4);
+/* T1  IntegratorCommon::rayTrace (CPUExp_Integrators_Common.cpp:122-154) -> Lite_Hit;
+ * counters (optional, 3 uint32 per ray): quads visited, instance quads entered, triangles tested */
+int hydra_hip_stage_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                          HydraLiteHit* hits, uint32_t* counters3);
+/* T2  IntegratorCommon::shadowTrace (Common.cpp:156-180) -> visibility 0/1 */
+int hydra_hip_stage_shadow_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                                 const float* t_far, float* visibility);
+/* H1  kernel_EvalSurface (CPUExp_Integrators_PT_Loop.cpp:35-84) -> 24 floats per hit:
+ * pos3 normal3 flatNormal3 tangent3 biTangent3 texCoord2 matId(as int bits) t sRayOff hfi(0/1) pad3 */
+int hydra_hip_stage_eval_surface(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                                 const HydraLiteHit* hits, float* surf24);
+/* whole path for n given primary rays with given per-path RandomGen state (2 uint32 each):
+ * IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb + rays traced */
+int hydra_hip_stage_path_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                               uint32_t* rng_state2, float* color4);
+/* R1  RandomGenInit + rndFloat4_Pseudo (crandom.h:20-63): for each seed the first `draws` float4 outputs */
+int hydra_hip_stage_random(hydra_hip_handle h, int n, const int32_t* seeds, int draws, float* out4, uint32_t* state2);
+
+/* traversal replay for the roofline number: rays are uploaded once, then the closest-hit kernel is
+ * launched `iters` times between two hipEvents on the context stream; returns average ms per launch. */
+int hydra_hip_bench_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                          int iters, int shadow, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1290 @@
+/* hydra_oracle.c -- see hydra_oracle.h.  TEST INFRASTRUCTURE ONLY (CPU checker / CPU baseline).
+ *
+ * All "ref:" comments cite files under /root/reference/hydra_drv/ unless another directory is named.
+ * Arithmetic is IEEE float32, evaluated in the order the reference writes it; build with -ffp-contract=off
+ * (the reference's x86 build has no FMA contraction either).  vector helpers the reference takes from HydraAPI's
+ * LiteMath (absent here) use the OpenCL-branch definitions in cglobals.h:288-304 / the textbook formulas.
+ */
+#include "hydra_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------ constants */
+/* ref: cglobals.h:16, 61-66, 405-434, 438-538 */
+#define INVALID_TEXTURE 0xFFFFFFFEu
+#define M_PI_F      3.14159265358979323846f
+#define INV_PI      0.31830988618379067154f
+#define INV_TWOPI   0.15915494309189533577f
+#define GEPSILON    5e-6f
+#define DEPSILON    1e-20f
+#define DEPSILON2   1e-30f
+#define MAXFLOAT_T  FLT_MAX      /* ref: ctrace.h:665-667 -- glibc <math.h> defines MAXFLOAT as FLT_MAX */
+
+enum { TEX_POINT_SAM = 1, TEX_ALPHASRC_W = 2, TEX_CLAMP_U = 4, TEX_CLAMP_V = 8, TEX_COORD_CAM_PROJ = 32 };
+enum { HRT_STUPID_PT_MODE = 65536 * 8, HRT_ENABLE_PT_CAUSTICS = 65536 * 2048 };
+enum { HRT_ENABLE_DOF = 0, HRT_TRACE_DEPTH = 9, HRT_DIFFUSE_TRACE_DEPTH = 13 };
+enum { HRT_DOF_LENS_RADIUS = 0, HRT_DOF_FOCAL_PLANE_DIST = 1, HRT_TILT_ROT_X = 2, HRT_TILT_ROT_Y = 4, HRT_CAM_FOV = 14 };
+/* EngineGlobals word offsets, ref: cfetch.h:21-81 */
+enum { G_MPROJ_INV = 32, G_MWORLDVIEW_INV = 48, G_VARS_I = 64, G_VARS_F = 128,
+       G_TEX_TABLE = 218, G_MAT_TABLE = 219, G_GEOM_TABLE = 221, G_FLOAT_ARRAYS = 228,
+       G_LSEL_REV_OFFS = 230, G_LSEL_REV_SIZE = 231, G_FLAGS = 234, G_SKY_LIGHT_ID = 235, G_LIGHTS_OFFS = 236, G_LIGHTS_NUM = 238 };
+/* materials, ref: cglobals.h:2604-2722, cmaterial.h:200-210, 374-382, 887-903, 1965-2006 */
+enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSIVE_TEXMATRIXID = 8,
+       NORMAL_TEX = 83, MAT_COLOR = 10, MAT_TEXMATRIXID = 14,
+       PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
+       BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
+       BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
+enum { MT_PHONG = 0, MT_MIRROR = 2, MT_LAMBERT = 7, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
+enum { MF_CAST_CAUSTICS = 2, MF_FORBID_EMISSIVE_GI = 512, MF_SKIP_SKY_PORTAL = 1024, MF_CAN_SAMPLE_REFL_ONLY = 32768,
+       MF_ENERGY_FIX = 32768 * 256 };
+enum { BMF_FRESNEL = 1, BMF_FALOFF = 2, BMF_REFL_WEIGHT_IS_ONE = 4, BMF_EXTRUSION_LUMINANCE = 16 };
+enum { BLEND_SIGMOID = 4, BLEND_INVERT_FALOFF = 1 };
+enum { MIX_TREE_MAX_DEEP = 7, FLOATS_PER_SAMPLE = 3, FLOATS_PER_MLAYER = 7 };
+/* lights, ref: clight.h:14-62, 493-521; cglobals.h:2236-2252 */
+enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, PL_COLOR = 8, PL_COLOR_TEX = 11,
+       PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
+       AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107 };
+enum { LT_AREA = 4 };
+enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16 };
+/* ray flags, ref: cglobals.h:1330-1376 */
+enum { RAY_EVENT_S = 1, RAY_EVENT_D = 2, RAY_EVENT_G = 4, RAY_EVENT_T = 8 };
+enum { RAY_GRAMMAR_DIRECT_LIGHT = 64, RAY_IS_DEAD = 4096 };
+
+/* ------------------------------------------------------------------------------------------------ small vectors */
+typedef struct { float x, y; } f2;
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y, z, w; } f4;
+typedef struct { f4 c[4]; } m44;      /* columns, ref: cglobals.h:792-800 make_float4x4 */
+
+static inline f3 v3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 add3(f3 a, f3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scale3(f3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline f3 cross3(f3 a, f3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float length3(f3 a) { return sqrtf(dot3(a, a)); }
+static inline f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+static inline float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+static inline f3 clamp3(f3 v, float a, float b) { return v3(clampf(v.x, a, b), clampf(v.y, a, b), clampf(v.z, a, b)); }
+static inline int32_t as_int(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static inline float as_float(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int finite3(f3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+static inline m44 load_m44(const float* p) { m44 m; memcpy(&m, p, 64); return m; }
+/* ref: cglobals.h:288-304 (mul4x3, mul3x3), :828-849 (mul4x4x4, mul) */
+static inline f3 mul4x3(m44 m, f3 v) {
+  return v3(v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x + m.c[3].x,
+            v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y + m.c[3].y,
+            v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z + m.c[3].z);
+}
+static inline f3 mul3x3(m44 m, f3 v) {
+  return v3(v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x,
+            v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y,
+            v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z);
+}
+static inline f4 mul4x4x4(m44 m, f4 v) {
+  f4 r;
+  r.x = v.x * m.c[0].x + v.y * m.c[1].x + v.z * m.c[2].x + v.w * m.c[3].x;
+  r.y = v.x * m.c[0].y + v.y * m.c[1].y + v.z * m.c[2].y + v.w * m.c[3].y;
+  r.z = v.x * m.c[0].z + v.y * m.c[1].z + v.z * m.c[2].z + v.w * m.c[3].z;
+  r.w = v.x * m.c[0].w + v.y * m.c[1].w + v.z * m.c[2].w + v.w * m.c[3].w;
+  return r;
+}
+static inline m44 transpose44(m44 a) {  /* ref: cglobals.h:1038-1047 */
+  m44 r;
+  r.c[0].x = a.c[0].x; r.c[0].y = a.c[1].x; r.c[0].z = a.c[2].x; r.c[0].w = a.c[3].x;
+  r.c[1].x = a.c[0].y; r.c[1].y = a.c[1].y; r.c[1].z = a.c[2].y; r.c[1].w = a.c[3].y;
+  r.c[2].x = a.c[0].z; r.c[2].y = a.c[1].z; r.c[2].z = a.c[2].z; r.c[2].w = a.c[3].z;
+  r.c[3].x = a.c[0].w; r.c[3].y = a.c[1].w; r.c[3].z = a.c[2].w; r.c[3].w = a.c[3].w;
+  return r;
+}
+/* inverse4x4: LiteMath (absent).  Instance matrices are affine, so: inverse of the upper 3x3 by cofactors and the
+ * translation -R^-1 t, all in float32.  The HIP kernels use the same formula. */
+static inline m44 inverse_affine(m44 m) {
+  const float a00 = m.c[0].x, a10 = m.c[0].y, a20 = m.c[0].z;
+  const float a01 = m.c[1].x, a11 = m.c[1].y, a21 = m.c[1].z;
+  const float a02 = m.c[2].x, a12 = m.c[2].y, a22 = m.c[2].z;
+  const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const float det = a00 * c00 + a01 * c01 + a02 * c02;
+  const float id = 1.0f / det;
+  m44 r;
+  r.c[0].x = c00 * id;                          r.c[0].y = c01 * id;                          r.c[0].z = c02 * id;                          r.c[0].w = 0.0f;
+  r.c[1].x = (a02 * a21 - a01 * a22) * id;      r.c[1].y = (a00 * a22 - a02 * a20) * id;      r.c[1].z = (a01 * a20 - a00 * a21) * id;      r.c[1].w = 0.0f;
+  r.c[2].x = (a01 * a12 - a02 * a11) * id;      r.c[2].y = (a02 * a10 - a00 * a12) * id;      r.c[2].z = (a00 * a11 - a01 * a10) * id;      r.c[2].w = 0.0f;
+  const f3 t = v3(m.c[3].x, m.c[3].y, m.c[3].z);
+  r.c[3].x = -(r.c[0].x * t.x + r.c[1].x * t.y + r.c[2].x * t.z);
+  r.c[3].y = -(r.c[0].y * t.x + r.c[1].y * t.y + r.c[2].y * t.z);
+  r.c[3].z = -(r.c[0].z * t.x + r.c[1].z * t.y + r.c[2].z * t.z);
+  r.c[3].w = 1.0f;
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ R1: random numbers */
+/* ref: crandom.h:20-26 NextState */
+uint32_t orc_next_state(uint32_t st[2]) {
+  const uint32_t x = st[0] * 17u + st[1] * 13123u;
+  st[0] = (x << 13) ^ x;
+  st[1] ^= (x << 7);
+  return x;
+}
+/* ref: crandom.h:28-43 RandomGenInit (int arithmetic wraps; evaluated here in uint32) */
+void orc_random_init(int32_t a_seed, uint32_t st[2]) {
+  const uint32_t s = (uint32_t)a_seed;
+  st[0] = (s * (s * s * 15731u + 74323u) + 871483u);
+  st[1] = (s * (s * s * 13734u + 37828u) + 234234u);
+  for (int i = 0; i < (a_seed % 7); i++) orc_next_state(st);
+}
+/* ref: crandom.h:51-63 rndFloat4_Pseudo */
+void orc_rnd_float4(uint32_t st[2], float out[4]) {
+  const uint32_t x = orc_next_state(st);
+  const uint32_t x1 = (x * (x * x * 15731u + 74323u) + 871483u);
+  const uint32_t y1 = (x * (x * x * 13734u + 37828u) + 234234u);
+  const uint32_t z1 = (x * (x * x * 11687u + 26461u) + 137589u);
+  const uint32_t w1 = (x * (x * x * 15707u + 789221u) + 1376312589u);
+  const float scale = (1.0f / 4294967296.0f);
+  out[0] = (float)(x1) * scale; out[1] = (float)(y1) * scale; out[2] = (float)(z1) * scale; out[3] = (float)(w1) * scale;
+}
+/* ref: crandom.h:77-83 rndFloat1_Pseudo */
+float orc_rnd_float1(uint32_t st[2]) {
+  const uint32_t x = orc_next_state(st);
+  const uint32_t tmp = (x * (x * x * 15731u + 74323u) + 871483u);
+  return ((float)(tmp)) * (1.0f / 4294967296.0f);
+}
+
+/* ------------------------------------------------------------------------------------------------ shared helpers */
+static inline const float* g_varsF(const OrcScene* s) { return (const float*)(s->globals + G_VARS_F); }
+static inline const int32_t* g_varsI(const OrcScene* s) { return s->globals + G_VARS_I; }
+
+/* ref: cglobals.h:726-735 SafeInverse */
+static inline f3 SafeInverse(f3 d) {
+  const float ooeps = 1.0e-36f;
+  f3 r;
+  r.x = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+  r.y = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+  r.z = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+  return r;
+}
+/* ref: cglobals.h:737-745 */
+static inline float epsilonOfPos(f3 p) { return fmaxf(fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))), 2.0f * GEPSILON) * GEPSILON; }
+static inline float misHeuristicPower1(float p) { return isfinite(p) ? fabsf(p) : 0.0f; }
+static inline float misWeightHeuristic(float a, float b) {
+  const float w = misHeuristicPower1(a) / fmaxf(misHeuristicPower1(a) + misHeuristicPower1(b), DEPSILON2);
+  return isfinite(w) ? w : 0.0f;
+}
+/* ref: cglobals.h:764-784 */
+static inline f3 OffsRayPos(f3 hitPos, f3 n, f3 sampleDir) {
+  const float sgn = dot3(sampleDir, n) < 0.0f ? -1.0f : 1.0f;
+  const float eps = epsilonOfPos(hitPos);
+  return add3(hitPos, scale3(n, sgn * eps));
+}
+static inline f3 OffsShadowRayPos(f3 hitPos, f3 n, f3 sampleDir, float aux) {
+  const float sgn = dot3(sampleDir, n) < 0.0f ? -1.0f : 1.0f;
+  const float eps = epsilonOfPos(hitPos);
+  return add3(hitPos, scale3(n, sgn * (eps + aux)));
+}
+/* ref: cglobals.h:686-691 reflect */
+static inline f3 reflect3(f3 dir, f3 n) { return normalize3(add3(scale3(scale3(n, dot3(dir, n)), -2.0f), dir)); }
+
+/* ref: cglobals.h:1502-1518 CoordinateSystem */
+static inline void CoordinateSystem(f3 v1, f3* v2, f3* v3o) {
+  float invLen;
+  if (fabsf(v1.x) > fabsf(v1.y)) {
+    invLen = 1.0f / sqrtf(v1.x * v1.x + v1.z * v1.z);
+    *v2 = v3((-1.0f) * v1.z * invLen, 0.0f, v1.x * invLen);
+  } else {
+    invLen = 1.0f / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    *v2 = v3(0.0f, v1.z * invLen, (-1.0f) * v1.y * invLen);
+  }
+  *v3o = cross3(v1, *v2);
+}
+/* ref: cglobals.h:1521-1559 MapSampleToCosineDistribution */
+static f3 MapSampleToCosineDistribution(float r1, float r2, f3 direction, f3 hit_norm, float power) {
+  if (power >= 1e6f) return direction;
+  const float sin_phi = sinf(2.0f * r1 * 3.141592654f);
+  const float cos_phi = cosf(2.0f * r1 * 3.141592654f);
+  const float cos_theta = powf(1.0f - r2, 1.0f / (power + 1.0f));
+  const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+  const f3 dev = v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+  f3 ny = direction, nx, nz;
+  CoordinateSystem(ny, &nx, &nz);
+  { f3 t = ny; ny = nz; nz = t; }
+  f3 res = add3(add3(scale3(nx, dev.x), scale3(ny, dev.y)), scale3(nz, dev.z));
+  const float invSign = dot3(direction, hit_norm) > 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot3(res, hit_norm) < 0.0f)
+    res = sub3(add3(scale3(scale3(nx, -1.0f), dev.x), scale3(ny, dev.y)), scale3(nz, dev.z));
+  return res;
+}
+/* ref: cglobals.h:1563-1601 MapSampleToModifiedCosineDistribution */
+static f3 MapSampleToModifiedCosineDistribution(float r1, float r2, f3 direction, f3 hit_norm, float power, int* under) {
+  if (power >= 1e6f) return direction;   /* note: *under keeps the caller's initial 'false' */
+  const float sin_phi = sinf(2.0f * r1 * 3.141592654f);
+  const float cos_phi = cosf(2.0f * r1 * 3.141592654f);
+  const float sin_theta = sqrtf(1.0f - powf(r2, 2.0f / (power + 1.0f)));
+  f3 dev;
+  dev.x = sin_theta * cos_phi;
+  dev.y = sin_theta * sin_phi;
+  dev.z = sqrtf(1.0f - dev.x * dev.x - dev.y * dev.y);
+  f3 ny = direction, nx, nz;
+  CoordinateSystem(ny, &nx, &nz);
+  { f3 t = ny; ny = nz; nz = t; }
+  f3 res = add3(add3(scale3(nx, dev.x), scale3(ny, dev.y)), scale3(nz, dev.z));
+  *under = 0;
+  const float invSign = dot3(direction, hit_norm) >= 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot3(res, hit_norm) < 0.0f) {
+    res = add3(sub3(scale3(scale3(nx, -1.0f), dev.x), scale3(ny, dev.y)), scale3(nz, dev.z));
+    *under = 1;
+  }
+  return res;
+}
+/* ref: cglobals.h:1609-1652 MapSamplesToDisc */
+static f2 MapSamplesToDisc(f2 xy) {
+  const float x = xy.x, y = xy.y;
+  float r = 0, phi = 0;
+  if (x > y && x > -y) { r = x; phi = 0.25f * 3.141592654f * (y / x); }
+  if (x < y && x > -y) { r = y; phi = 0.25f * 3.141592654f * (2.0f - x / y); }
+  if (x < y && x < -y) { r = -x; phi = 0.25f * 3.141592654f * (4.0f + y / x); }
+  if (x > y && x < -y) { r = -y; phi = 0.25f * 3.141592654f * (6 - x / y); }
+  const float sin_phi = sinf(phi), cos_phi = cosf(phi);
+  f2 res = {r * sin_phi, r * cos_phi};
+  return res;
+}
+/* ref: cglobals.h:3024-3038 */
+static inline float sRGBToLinear(float s) {
+  if (s <= 0.0404482362771082f) return s * 0.077399381f;
+  return powf((s + 0.055f) * 0.947867299f, 2.4f);
+}
+
+/* ------------------------------------------------------------------------------------------------ P1: camera */
+/* ref: cglobals.h:1069-1087 EyeRayDirNormalized, matrix4x4f_mult_ray3 */
+static f3 EyeRayDirNormalized(float x, float y, m44 projInv) {
+  f4 pos = {2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f, 1.0f};
+  pos = mul4x4x4(projInv, pos);
+  pos.x /= pos.w; pos.y /= pos.w; pos.z /= pos.w;
+  return normalize3(v3(pos.x, pos.y, pos.z));
+}
+/* ref: cfetch.h:832-863 tiltCorrection.  Rotation by make_matrix_rotationX/Y cglobals.h:802-826 */
+static f3 tiltCorrection(f3 ray_pos, f3 ray_dir, const OrcScene* s) {
+  const float tiltX = g_varsF(s)[HRT_TILT_ROT_X], tiltY = g_varsF(s)[HRT_TILT_ROT_Y];
+  if ((fabsf(tiltX) > 0.0f || fabsf(tiltY) > 0.0f) && fabsf(ray_dir.z) > 0.0f) {
+    const float t = (-1.0f - ray_pos.z) / ray_dir.z;
+    f3 p = add3(ray_pos, scale3(ray_dir, t));
+    p.z += 1.0f;
+    if (fabsf(tiltY) > 0.0f) {
+      const float sn = sinf(-tiltY), cs = cosf(-tiltY);
+      p = v3(p.x * cs + p.z * sn, p.y, p.x * (-sn) + p.z * cs);
+    }
+    if (fabsf(tiltX) > 0.0f) {
+      const float sn = sinf(-tiltX), cs = cosf(-tiltX);
+      p = v3(p.x, p.y * cs + p.z * (-sn), p.y * sn + p.z * cs);
+    }
+    p.z -= 1.0f;
+    ray_dir = normalize3(sub3(p, ray_pos));
+  }
+  return ray_dir;
+}
+/* ref: cfetch.h:877-930 MakeRandEyeRay */
+static void MakeRandEyeRay(int x, int y, int w, int h, const float offs[4], const OrcScene* s, f3* pRayPos, f3* pRayDir) {
+  const m44 projInv = load_m44((const float*)(s->globals + G_MPROJ_INV));
+  const m44 wvInv = load_m44((const float*)(s->globals + G_MWORLDVIEW_INV));
+  const float sx = (float)x + 0.5f, sy = (float)y + 0.5f;
+  f3 ray_pos = v3(0.0f, 0.0f, 0.0f);
+  f3 ray_dir = EyeRayDirNormalized(sx / (float)w, sy / (float)h, projInv);
+  {
+    const float sinFov = sinf(0.5f * g_varsF(s)[HRT_CAM_FOV]);
+    const float pxSizeX = sinFov * (1.0f / (float)w);
+    const float pxSizeY = sinFov * (1.0f / (float)h);
+    ray_dir.x += pxSizeX * offs[0];
+    ray_dir.y += pxSizeY * offs[1];
+    ray_dir.z = -sqrtf(1.0f - (ray_dir.x * ray_dir.x + ray_dir.y * ray_dir.y));
+  }
+  ray_dir = tiltCorrection(ray_pos, ray_dir, s);
+  if (g_varsI(s)[HRT_ENABLE_DOF] == 1) {
+    const float tFocus = g_varsF(s)[HRT_DOF_FOCAL_PLANE_DIST] / (-ray_dir.z);
+    const f3 focusPosition = add3(ray_pos, scale3(ray_dir, tFocus));
+    f2 in = {1.0f * offs[2], 1.0f * offs[3]};
+    const f2 d = MapSamplesToDisc(in);
+    const float R = g_varsF(s)[HRT_DOF_LENS_RADIUS];
+    ray_pos.x += R * d.x;
+    ray_pos.y += R * d.y;
+    ray_dir = normalize3(sub3(focusPosition, ray_pos));
+  }
+  {
+    const f3 pos = mul4x3(wvInv, ray_pos);
+    const f3 pos2 = mul4x3(wvInv, add3(ray_pos, scale3(ray_dir, 100.0f)));
+    *pRayPos = pos;
+    *pRayDir = normalize3(sub3(pos2, pos));
+  }
+}
+
+void orc_make_eye_rays(const OrcScene* s, int n, int w, int h, const int32_t* xy, const float* offs4, float* pos4, float* dir4) {
+  for (int i = 0; i < n; i++) {
+    f3 p, d;
+    MakeRandEyeRay(xy[2 * i], xy[2 * i + 1], w, h, offs4 + 4 * i, s, &p, &d);
+    pos4[4 * i] = p.x; pos4[4 * i + 1] = p.y; pos4[4 * i + 2] = p.z; pos4[4 * i + 3] = 0.0f;
+    dir4[4 * i] = d.x; dir4[4 * i + 1] = d.y; dir4[4 * i + 2] = d.z; dir4[4 * i + 3] = 0.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ T1/T2: traversal */
+#define STACK_SIZE 80   /* ref: ctrace.h:576 */
+typedef struct { uint32_t quads, insts, tris, leaves; } TravStat;
+
+/* ref: ctrace.h:32-53 RayBoxIntersectionLite2 */
+static inline f2 RayBox(f3 o, f3 inv, const float* node) {
+  const float lo = inv.x * (node[0] - o.x), hi = inv.x * (node[4] - o.x);
+  const float lo1 = inv.y * (node[1] - o.y), hi1 = inv.y * (node[5] - o.y);
+  const float lo2 = inv.z * (node[2] - o.z), hi2 = inv.z * (node[6] - o.z);
+  float tmin = fminf(lo, hi), tmax = fmaxf(lo, hi);
+  tmin = fmaxf(tmin, fminf(lo1, hi1)); tmax = fminf(tmax, fmaxf(lo1, hi1));
+  tmin = fmaxf(tmin, fminf(lo2, hi2)); tmax = fminf(tmax, fmaxf(lo2, hi2));
+  f2 r = {tmin, tmax};
+  return r;
+}
+/* ref: ctrace.h:63-182 IntersectAllPrimitivesInLeaf(1): Moeller-Trumbore, first-found wins ties (t < best) */
+static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, OrcHit res, const float* tris, int instIdOverride, int useOverride, TravStat* st) {
+  const int first = as_int(tris[leaf_offset * 4 + 0]), count = as_int(tris[leaf_offset * 4 + 1]);
+  const int end = first + count * 3;
+  if (st) { st->leaves++; st->tris += (uint32_t)count; }
+  for (int a = first; a < end; a += 3) {
+    const float* d1 = tris + a * 4; const float* d2 = d1 + 4; const float* d3 = d1 + 8;
+    const f3 A = v3(d1[0], d1[1], d1[2]), B = v3(d2[0], d2[1], d2[2]), C = v3(d3[0], d3[1], d3[2]);
+    const f3 edge1 = sub3(B, A), edge2 = sub3(C, A);
+    const f3 pvec = cross3(ray_dir, edge2);
+    const f3 tvec = sub3(ray_pos, A);
+    const f3 qvec = cross3(tvec, edge1);
+    const float invDet = 1.0f / dot3(edge1, pvec);
+    const float v = dot3(tvec, pvec) * invDet;
+    const float u = dot3(qvec, ray_dir) * invDet;
+    const float t = dot3(edge2, qvec) * invDet;
+    if (v > -1e-6f && u > -1e-6f && (u + v < 1.0f + 1e-6f) && t > t_min && t < res.t) {
+      res.t = t; res.primId = as_int(d1[3]); res.geomId = as_int(d2[3]);
+      res.instId = useOverride ? instIdOverride : as_int(d3[3]);
+    }
+  }
+  return res;
+}
+
+/* ref: ctrace.h:841-1062 BVH4InstTraverse (haveInst) and :669-838 BVH4Traverse (!haveInst): one state machine, the
+ * instancing steps are skipped for plain trees exactly as the reference's second function omits them. */
+static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, TravStat* st) {
+  f3 invDir = SafeInverse(ray_dir);
+  int stackData[STACK_SIZE + 2];
+  int* stack = stackData + 2;
+  stackData[0] = stackData[1] = 0;   /* the reference reads stack[-1] uninitialised after the last pop */
+  int top = 0, leftNodeOffset = 1, searchingForLeaf = 1;
+  int instDeep = 0, instTop = 0, instId = -1;
+  f3 old_pos = v3(0, 0, 0), old_dir = v3(0, 0, 0);
+
+  while (top >= 0) {
+    while (searchingForLeaf) {
+      int child[4]; float key[4];
+      if (st) st->quads++;
+      for (int k = 0; k < 4; k++) {
+        const float* node = bvh + (size_t)(4 * leftNodeOffset + k) * 8;
+        const uint32_t loal = (uint32_t)as_int(node[3]), esc = (uint32_t)as_int(node[7]);
+        const int valid = !(loal == 0xffffffffu && esc == 0xffffffffu);
+        const f2 tm = RayBox(ray_pos, invDir, node);
+        const int hitChild = (tm.x <= tm.y) && (tm.y >= t_rayMin) && (tm.x <= hit.t) && valid;
+        child[k] = (int)loal;
+        key[k] = hitChild ? tm.x : MAXFLOAT_T;
+      }
+      /* 5-comparator sorting network, ref: ctrace.h:906-960 */
+#define CSWAP(i, j) if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; int tc = child[i]; child[i] = child[j]; child[j] = tc; }
+      CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+      const int stackHaveSpace = (top < STACK_SIZE);
+      if (key[3] < MAXFLOAT_T && stackHaveSpace) { stack[top] = child[3]; top++; }
+      if (key[2] < MAXFLOAT_T && stackHaveSpace) { stack[top] = child[2]; top++; }
+      if (key[1] < MAXFLOAT_T && stackHaveSpace) { stack[top] = child[1]; top++; }
+      if (key[0] < MAXFLOAT_T) leftNodeOffset = child[0];
+      else if (top >= 0) { top--; leftNodeOffset = stack[top]; }
+      searchingForLeaf = !(leftNodeOffset & 0x80000000) && (top >= 0);
+      leftNodeOffset = leftNodeOffset & 0x7fffffff;
+      if (haveInst && top < instTop && instDeep == 1) {
+        ray_pos = old_pos; ray_dir = old_dir; invDir = SafeInverse(ray_dir); instDeep = 0;
+      }
+    }
+    if (!haveInst) {
+      if (top >= 0) hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, 0, 0, st);
+      top--;
+      leftNodeOffset = stack[top];
+    } else if (top >= 0 && instDeep == 1) {
+      hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, instId, 1, st);
+      top--;
+      leftNodeOffset = stack[top];
+    } else if (top >= 0 && instDeep == 0) {
+      instDeep = 1;
+      old_pos = ray_pos; old_dir = ray_dir;
+      const float* q = bvh + (size_t)leftNodeOffset * 32;
+      const int nextOffset = as_int(q[3]);
+      const m44 matrix = load_m44(q + 8);
+      instId = as_int(q[24]);
+      if (st) st->insts++;
+      ray_pos = mul4x3(matrix, ray_pos);
+      ray_dir = mul3x3(matrix, ray_dir);   /* not normalised: t stays in world units */
+      invDir = SafeInverse(ray_dir);
+      instTop = top;
+      leftNodeOffset = nextOffset;
+    }
+    searchingForLeaf = !(leftNodeOffset & 0x80000000);
+    leftNodeOffset = leftNodeOffset & 0x7fffffff;
+    if (haveInst && top < instTop && instDeep == 1) {
+      ray_pos = old_pos; ray_dir = old_dir; invDir = SafeInverse(ray_dir); instDeep = 0;
+    }
+  }
+  return hit;
+}
+
+/* ref: CPUExp_Integrators_Common.cpp:122-154 IntegratorCommon::rayTrace (tree 0; Make_Lite_Hit cglobals.h:1256-1266) */
+static OrcHit rayTrace(const OrcScene* s, f3 pos, f3 dir, TravStat* st) {
+  OrcHit h; h.t = MAXFLOAT_T; h.primId = -1; h.instId = -1; h.geomId = (int32_t)(((uint32_t)(-1) << 30) & 0xC0000000u);
+  return BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, st);
+}
+static inline int HitSome(OrcHit h) { return (h.primId != -1) && isfinite(h.t); }
+/* ref: Common.cpp:156-180 IntegratorCommon::shadowTrace: full closest hit, then 0 < t < t_far */
+static float shadowTrace(const OrcScene* s, f3 pos, f3 dir, float t_far) {
+  const OrcHit h = rayTrace(s, pos, dir, NULL);
+  return (HitSome(h) && h.t > 0.0f && h.t < t_far) ? 0.0f : 1.0f;
+}
+
+void orc_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, OrcHit* hits, uint32_t* c3, uint32_t* leaves1) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int i = 0; i < n; i++) {
+    TravStat st = {0, 0, 0, 0};
+    hits[i] = rayTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), &st);
+    if (c3) { c3[3 * i] = st.quads; c3[3 * i + 1] = st.insts; c3[3 * i + 2] = st.tris; }
+    if (leaves1) leaves1[i] = st.leaves;
+  }
+}
+void orc_shadow_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int i = 0; i < n; i++)
+    vis[i] = shadowTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), tfar[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------ H1: surface */
+typedef struct {
+  f3 pos, normal, flatNormal, tangent, biTangent;
+  f2 texCoord;
+  int matId; float t, sRayOff; int hfi;
+} SurfaceHit;
+
+/* ref: cglobals.h:2931-2983 remapMaterialId */
+static int remapMaterialId(int mId, int instId, const OrcScene* s) {
+  if (mId < 0 || instId < 0 || instId >= s->remapInstSize || s->remapInst == NULL || s->remapLists == NULL || s->remapTable == NULL) return mId;
+  const int listId = s->remapInst[instId];
+  if (listId < 0 || listId >= s->remapTableSize) return mId;
+  const int offs = s->remapTable[2 * listId], size = s->remapTable[2 * listId + 1];
+  int low = 0, high = size - 1;
+  while (low <= high) {
+    const int mid = low + ((high - low) / 2);
+    if (s->remapLists[offs + mid * 2] >= mId) high = mid - 1; else low = mid + 1;
+  }
+  if (high + 1 < size) {
+    const int from = s->remapLists[offs + (high + 1) * 2], to = s->remapLists[offs + (high + 1) * 2 + 1];
+    return (from == mId) ? to : mId;
+  }
+  return mId;
+}
+
+/* ref: ctrace.h:1988-2109 triBaricentrics + surfaceEvalLS; mesh accessors cfetch.h:1038-1119 */
+static SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, OrcHit hit, const float* mesh) {
+  const int32_t* hdr = (const int32_t*)mesh;
+  const float* vertPos = mesh + (size_t)hdr[0] * 4;
+  const float* vertNorm = mesh + (size_t)hdr[1] * 4;
+  const float* vertTang = mesh + (size_t)hdr[10] * 4;
+  const int32_t* vertIndices = (const int32_t*)(mesh + (size_t)hdr[3] * 4);
+  const int32_t* matIndices = (const int32_t*)(mesh + (size_t)hdr[8] * 4);
+  const float* shadowRayOff = mesh + (size_t)hdr[13] * 4;
+
+  SurfaceHit sh;
+  sh.matId = matIndices[hit.primId];
+  const int o = hit.primId * 3;
+  const int iA = vertIndices[o], iB = vertIndices[o + 1], iC = vertIndices[o + 2];
+  const float* A1 = vertPos + iA * 4; const float* B1 = vertPos + iB * 4; const float* C1 = vertPos + iC * 4;
+  const float* A2 = vertNorm + iA * 4; const float* B2 = vertNorm + iB * 4; const float* C2 = vertNorm + iC * 4;
+  const f3 A_pos = v3(A1[0], A1[1], A1[2]), B_pos = v3(B1[0], B1[1], B1[2]), C_pos = v3(C1[0], C1[1], C1[2]);
+  const f3 A_norm = v3(A2[0], A2[1], A2[2]), B_norm = v3(B2[0], B2[1], B2[2]), C_norm = v3(C2[0], C2[1], C2[2]);
+  const f2 A_tex = {A1[3], A2[3]}, B_tex = {B1[3], B2[3]}, C_tex = {C1[3], C2[3]};
+
+  f2 uv;
+  {
+    const f3 edge1 = sub3(B_pos, A_pos), edge2 = sub3(C_pos, A_pos);
+    const f3 pvec = cross3(a_rdir, edge2);
+    const float det = dot3(edge1, pvec);
+    const float inv_det = 1.0f / det;
+    const f3 tvec = sub3(a_rpos, A_pos);
+    const float v = dot3(tvec, pvec) * inv_det;
+    const f3 qvec = cross3(tvec, edge1);
+    const float u = dot3(a_rdir, qvec) * inv_det;
+    uv.x = u; uv.y = v;
+  }
+  const float w0 = (1.0f - uv.x - uv.y);
+  sh.pos = add3(add3(scale3(A_pos, w0), scale3(B_pos, uv.y)), scale3(C_pos, uv.x));
+  sh.texCoord.x = w0 * A_tex.x + uv.y * B_tex.x + uv.x * C_tex.x;
+  sh.texCoord.y = w0 * A_tex.y + uv.y * B_tex.y + uv.x * C_tex.y;
+  sh.normal = add3(add3(scale3(A_norm, w0), scale3(B_norm, uv.y)), scale3(C_norm, uv.x));
+  sh.t = hit.t;
+  sh.sRayOff = shadowRayOff[hit.primId];
+
+  const float* At = vertTang + iA * 4; const float* Bt = vertTang + iB * 4; const float* Ct = vertTang + iC * 4;
+  sh.flatNormal = normalize3(cross3(sub3(A_pos, B_pos), sub3(A_pos, C_pos)));
+  if (dot3(a_rdir, sh.flatNormal) > 0.025f) sh.flatNormal = scale3(sh.flatNormal, -1.0f);
+  const float maxEdge = fmaxf(fmaxf(length3(sub3(A_pos, B_pos)), length3(sub3(A_pos, C_pos))), length3(sub3(B_pos, C_pos)));
+
+  if (sh.sRayOff > 1e-5f * maxEdge) {
+    if (dot3(a_rdir, sh.normal) > 0.120f) { sh.normal = scale3(sh.normal, -1.0f); sh.hfi = 1; }
+    else if (dot3(a_rdir, sh.normal) > 0.0f) { sh.normal = sh.flatNormal; sh.hfi = 0; }
+    else sh.hfi = 0;
+  } else {
+    if (dot3(a_rdir, sh.normal) > 0.0f) { sh.normal = scale3(sh.normal, -1.0f); sh.hfi = 1; }
+    else sh.hfi = 0;
+  }
+  const float handed = (At[3] < 0.0f || Bt[3] < 0.0f || Ct[3] < 0.0f) ? -1.0f : 1.0f;
+  sh.tangent = normalize3(add3(add3(scale3(v3(At[0], At[1], At[2]), w0), scale3(v3(Bt[0], Bt[1], Bt[2]), uv.y)), scale3(v3(Ct[0], Ct[1], Ct[2]), uv.x)));
+  sh.biTangent = normalize3(handed > 0.0f ? cross3(sh.normal, sh.tangent) : cross3(sh.tangent, sh.normal));
+  const int badTangent = !finite3(sh.biTangent);
+  if (fabsf(fabsf(dot3(sh.normal, sh.tangent)) - 1.0f) < 1e-4f || badTangent) CoordinateSystem(sh.normal, &sh.tangent, &sh.biTangent);
+  return sh;
+}
+
+/* ref: CPUExp_Integrators_PT_Loop.cpp:35-84 kernel_EvalSurface */
+static SurfaceHit evalSurface(const OrcScene* s, f3 ray_pos, f3 ray_dir, OrcHit hit) {
+  const m44 instInv = load_m44(s->instMatrices + (size_t)hit.instId * 16);
+  const f3 posLS = mul4x3(instInv, ray_pos), dirLS = mul3x3(instInv, ray_dir);
+  const int meshOffset = s->globals[s->globals[G_GEOM_TABLE] + hit.geomId];   /* ref: cfetch.h:135-139 */
+  const float* mesh = s->geomStorage + (size_t)meshOffset * 4;
+  const SurfaceHit ls = surfaceEvalLS(posLS, dirLS, hit, mesh);
+  const m44 inst = inverse_affine(instInv);
+  SurfaceHit ws = ls;
+  const float multInv = 1.0f / sqrtf(3.0f);
+  const f3 shadowStart = mul3x3(inst, v3(multInv * ws.sRayOff, multInv * ws.sRayOff, multInv * ws.sRayOff));
+  const m44 nm = transpose44(instInv);
+  ws.pos = mul4x3(inst, ls.pos);
+  ws.normal = normalize3(mul3x3(nm, ls.normal));
+  ws.flatNormal = normalize3(mul3x3(nm, ls.flatNormal));
+  ws.tangent = normalize3(mul3x3(nm, ls.tangent));
+  ws.biTangent = normalize3(mul3x3(nm, ls.biTangent));
+  ws.t = length3(sub3(ws.pos, ray_pos));
+  ws.sRayOff = length3(shadowStart);
+  ws.matId = remapMaterialId(ws.matId, hit.instId, s);
+  return ws;
+}
+
+void orc_eval_surface(const OrcScene* s, int n, const float* pos4, const float* dir4, const OrcHit* hits, float* o) {
+  for (int i = 0; i < n; i++) {
+    float* r = o + 24 * (size_t)i;
+    memset(r, 0, 96);
+    if (!HitSome(hits[i])) { r[17] = as_float(-1); continue; }
+    const SurfaceHit sh = evalSurface(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), hits[i]);
+    r[0] = sh.pos.x; r[1] = sh.pos.y; r[2] = sh.pos.z; r[3] = sh.normal.x; r[4] = sh.normal.y; r[5] = sh.normal.z;
+    r[6] = sh.flatNormal.x; r[7] = sh.flatNormal.y; r[8] = sh.flatNormal.z; r[9] = sh.tangent.x; r[10] = sh.tangent.y; r[11] = sh.tangent.z;
+    r[12] = sh.biTangent.x; r[13] = sh.biTangent.y; r[14] = sh.biTangent.z; r[15] = sh.texCoord.x; r[16] = sh.texCoord.y;
+    r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ textures */
+/* ref: cfetch.h:312-362 bilinearOffsets */
+static void bilinearOffsets(float ffx, float ffy, int flags, int w, int h, int out[4]) {
+  const int sx = (ffx > 0.0f) ? 1 : -1, sy = (ffy > 0.0f) ? 1 : -1;
+  const int px = (int)(ffx), py = (int)(ffy);
+  int px_w0, px_w1, py_w0, py_w1;
+  if (flags & TEX_CLAMP_U) {
+    px_w0 = (px >= w) ? w - 1 : px; px_w1 = (px + 1 >= w) ? w - 1 : px + 1;
+    px_w0 = (px_w0 < 0) ? 0 : px_w0; px_w1 = (px_w1 < 0) ? 0 : px_w1;
+  } else {
+    px_w0 = px % w; px_w1 = (px + sx) % w;
+    px_w0 = (px_w0 < 0) ? px_w0 + w : px_w0; px_w1 = (px_w1 < 0) ? px_w1 + w : px_w1;
+  }
+  if (flags & TEX_CLAMP_V) {
+    py_w0 = (py >= h) ? h - 1 : py; py_w1 = (py + 1 >= h) ? h - 1 : py + 1;
+    py_w0 = (py_w0 < 0) ? 0 : py_w0; py_w1 = (py_w1 < 0) ? 0 : py_w1;
+  } else {
+    py_w0 = py % h; py_w1 = (py + sy) % h;
+    py_w0 = (py_w0 < 0) ? py_w0 + h : py_w0; py_w1 = (py_w1 < 0) ? py_w1 + h : py_w1;
+  }
+  out[0] = py_w0 * w + px_w0; out[1] = py_w0 * w + px_w1; out[2] = py_w1 * w + px_w0; out[3] = py_w1 * w + px_w1;
+}
+static inline f4 read_uchar4(const uint8_t* data, int offset, int srgb) {   /* ref: cfetch.h:298-303 + sRGBToLinear4f */
+  const float mult = 0.003921568f;
+  const uint8_t* c = data + (size_t)offset * 4;
+  f4 r = {mult * (float)c[0], mult * (float)c[1], mult * (float)c[2], mult * (float)c[3]};
+  if (srgb) { r.x = sRGBToLinear(r.x); r.y = sRGBToLinear(r.y); r.z = sRGBToLinear(r.z); r.w = sRGBToLinear(r.w); }
+  return r;
+}
+/* ref: cfetch.h:461-584 read_imagef_sw4 (4-channel textures; depth==1 single-channel variant :364-459 is outside the subset) */
+static f4 read_imagef_sw4(const int32_t* tex, f2 tc, int flags, int srgb) {
+  const int w = tex[0], h = tex[1], bpp = tex[3];
+  const float fw = (float)w, fh = (float)h;
+  float ffx = tc.x * fw - 0.5f, ffy = tc.y * fh - 0.5f;
+  if ((flags & TEX_CLAMP_U) != 0 && ffx < 0) ffx = 0.0f;
+  if ((flags & TEX_CLAMP_V) != 0 && ffy < 0) ffy = 0.0f;
+  const uint8_t* bytes = (const uint8_t*)(tex + 4);
+  const float* fdata = (const float*)(tex + 4);
+  f4 res = {0, 0, 0, 0};
+  if (flags & TEX_POINT_SAM) {
+    int px = (int)(ffx + 0.5f), py = (int)(ffy + 0.5f);
+    if (flags & TEX_CLAMP_U) { px = (px >= w) ? w - 1 : px; px = (px < 0) ? 0 : px; } else { px = px % w; px = (px < 0) ? px + w : px; }
+    if (flags & TEX_CLAMP_V) { py = (py >= h) ? h - 1 : py; py = (py < 0) ? 0 : py; } else { py = py % h; py = (py < 0) ? py + h : py; }
+    const int offset = py * w + px;
+    if (bpp == 4) res = read_uchar4(bytes, offset, srgb);
+    else if (bpp == 16) { const float* p = fdata + (size_t)offset * 4; res.x = p[0]; res.y = p[1]; res.z = p[2]; res.w = p[3]; }
+    return res;
+  }
+  const int px = (int)(ffx), py = (int)(ffy);
+  const float fx = fabsf(ffx - (float)px), fy = fabsf(ffy - (float)py);
+  const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+  const float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+  int offs[4];
+  bilinearOffsets(ffx, ffy, flags, w, h, offs);
+  f4 f[4];
+  for (int k = 0; k < 4; k++) {
+    if (bpp == 4) f[k] = read_uchar4(bytes, offs[k], srgb);
+    else { const float* p = fdata + (size_t)offs[k] * 4; f[k].x = p[0]; f[k].y = p[1]; f[k].z = p[2]; f[k].w = p[3]; }
+  }
+  res.x = f[0].x * w1 + f[1].x * w2 + f[2].x * w3 + f[3].x * w4;
+  res.y = f[0].y * w1 + f[1].y * w2 + f[2].y * w3 + f[3].y * w4;
+  res.z = f[0].z * w1 + f[1].z * w2 + f[2].z * w3 + f[3].z * w4;
+  res.w = f[0].w * w1 + f[1].w * w2 + f[2].w * w3 + f[3].w * w4;
+  return res;
+}
+/* ref: cfetch.h:677-709 sample2DExt (no procedural textures: readProcTex returns w = -1, cglobals.h:2402-2440).
+ * blob = the material / light the sampler is embedded in, addressed in int4 units. */
+static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const OrcScene* s) {
+  if ((uint32_t)samplerOffset == INVALID_TEXTURE || samplerOffset < 0) return v3(1, 1, 1);
+  const float* sm = blob + (size_t)samplerOffset * 4;
+  const int flags = as_int(sm[0]); const float gamma = sm[1]; const int texId = as_int(sm[2]);
+  if (texId <= 0) return v3(1, 1, 1);
+  f2 tct;   /* mul2x4, cfetch.h:642-648 */
+  tct.x = sm[4] * texCoord.x + sm[5] * texCoord.y + sm[7];
+  tct.y = sm[8] * texCoord.x + sm[9] * texCoord.y + sm[11];
+  const int offset = s->globals[s->globals[G_TEX_TABLE] + texId];
+  f4 c;
+  if (offset >= 0) c = read_imagef_sw4(s->texStorage + (size_t)offset * 4, tct, flags, (gamma != 1.0f));
+  else { c.x = c.y = c.z = c.w = 1.0f; }
+  if (flags & TEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
+  return v3(c.x, c.y, c.z);
+}
+/* sampler flags for the TEX_COORD_CAM_PROJ test in lambert (cmaterial.h:224-226, 240-242).  With no texture the
+ * reference reads the sampler at int4 index -2 (out of the node); that word is zero for every material after the
+ * first arena entry, so the flags are taken as 0 here. */
+static inline int samplerFlagsOrZero(int samplerOffset, const float* blob) {
+  if ((uint32_t)samplerOffset == INVALID_TEXTURE || samplerOffset < 0) return 0;
+  return as_int(blob[(size_t)samplerOffset * 4]);
+}
+
+/* ------------------------------------------------------------------------------------------------ materials */
+static inline const float* materialAt(const OrcScene* s, int matId) {   /* ref: cfetch.h:192-213 */
+  if (matId == -1) return NULL;
+  const int matOffset = s->globals[s->globals[G_MAT_TABLE] + matId];
+  return s->matStorage + (size_t)matOffset * 4;
+}
+static inline int matType(const float* m) { return as_int(m[MAT_TYPE]); }
+static inline int matFlags(const float* m) { return as_int(m[MAT_FLAGS]); }
+static inline f3 matColor(const float* m) { return v3(m[MAT_COLOR], m[MAT_COLOR + 1], m[MAT_COLOR + 2]); }
+
+typedef struct { f3 color; f3 direction; float pdf; int flags; } MatSample;
+typedef struct { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; int diffuse; } BxDFResult;
+typedef struct { f3 l, v, n, fn, tg, bn; f2 tc; } ShadeContext;
+
+/* ref: cmaterial.h:435-466 glosscoeff + cosPowerFromGlosiness */
+static const float glosscoeff[10][4] = {
+    {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
+    {357.142857142857f, -35.7142857142857f, 5.0f, 1.5f},
+    {-2142.85714285714f, 428.571428571429f, 8.57142857142857f, 2.0f},
+    {428.571428571431f, -42.8571428571432f, 30.0f, 5.0f},
+    {2095.23809523810f, -152.380952380952f, 34.2857142857143f, 8.0f},
+    {-4761.90476190476f, 1809.52380952381f, 66.6666666666667f, 12.0f},
+    {9914.71215351811f, 1151.38592750533f, 285.714285714286f, 32.0f},
+    {45037.7068059246f, 9161.90096119855f, 813.432835820895f, 82.0f},
+    {167903.678757035f, 183240.189801913f, 3996.94423223835f, 300.0f},
+    {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
+static float cosPowerFromGlosiness(float glosiness) {
+  const float cMax = 1000000.0f;
+  const float x = glosiness;
+  const int k = (fabsf(x - 1.0f) < 1e-5f) ? 10 : (int)(x * 10.0f);
+  const float x1 = (x - (float)(k)*0.1f);
+  if (k == 10 || x >= 0.99f) return cMax;
+  return glosscoeff[k][3] + glosscoeff[k][2] * x1 + glosscoeff[k][1] * x1 * x1 + glosscoeff[k][0] * x1 * x1 * x1;
+}
+
+/* ---- lambert, ref: cmaterial.h:219-263 */
+static inline float lambertEvalPDF(f3 l, f3 n) { return fabsf(dot3(l, n)) * INV_PI; }
+static f3 lambertEvalBxDF(const float* m, f2 tc, const OrcScene* s) {
+  const int so = as_int(m[MAT_TEXMATRIXID]);
+  (void)samplerFlagsOrZero(so, m);   /* TEX_COORD_CAM_PROJ: camera-projected coords are outside the subset */
+  const f3 tex = sample2DExt(so, tc, m, s);
+  return scale3(clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f), INV_PI);
+}
+static void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, n, n, 1.0f);
+  const float cosTheta = dot3(newDir, n);
+  out->direction = newDir;
+  out->pdf = cosTheta * INV_PI;
+  out->color = scale3(color, INV_PI);
+  if (cosTheta <= DEPSILON) out->color = v3(0, 0, 0);
+  out->flags = RAY_EVENT_D;
+}
+/* ---- phong, ref: cmaterial.h:915-1033 */
+static float phongGlosiness(const float* m, f2 tc, const OrcScene* s) {
+  if ((uint32_t)as_int(m[PHONG_GLOSS_TEXID]) != INVALID_TEXTURE) {
+    const f3 g = sample2DExt(as_int(m[PHONG_GLOSS_TEXMATRIXID]), tc, m, s);
+    return clampf(m[PHONG_GLOSINESS] * fmaxf(g.x, fmaxf(g.y, g.z)), 0.0f, 0.99f);
+  }
+  return m[PHONG_GLOSINESS];
+}
+static float phongEvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const float dotNV = dot3(n, v), dotNL = dot3(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 1.0f;
+  const float cosPower = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 r = reflect3(scale3(v, -1.0f), n);
+  const float cosTheta = clampf(fabsf(dot3(l, r)), 0.0f, 1.0f);
+  return powf(cosTheta, cosPower) * (cosPower + 1.0f) * INV_TWOPI;
+}
+static inline float PhongEnergyFix(float dotRL, f3 l, f3 n) { return dotRL / fmaxf(dot3(n, l), 1e-6f); }
+static f3 phongEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const float dotNV = dot3(n, v), dotNL = dot3(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return v3(0, 0, 0);
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(matColor(m), tex), 0.0f, 1.0f);
+  const float cosPower = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 r = reflect3(scale3(v, -1.0f), n);
+  const float cosAlpha = clampf(dot3(l, r), 0.0f, 1.0f);
+  const float fix = (matFlags(m) & MF_ENERGY_FIX) ? PhongEnergyFix(cosAlpha, l, n) : 1.0f;
+  return scale3(scale3(scale3(scale3(color, (cosPower + 2.0f)), INV_TWOPI), powf(cosAlpha, cosPower)), fix);
+}
+static void PhongSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(matColor(m), tex), 0.0f, 1.0f);
+  const float gloss = phongGlosiness(m, tc, s);
+  const float cosPower = cosPowerFromGlosiness(gloss);
+  int under = 0;
+  const f3 r = reflect3(ray_dir, n);
+  const f3 newDir = MapSampleToModifiedCosineDistribution(r1, r2, r, n, cosPower, &under);
+  const f3 v = scale3(ray_dir, -1.0f), l = newDir;
+  const float dotNV = dot3(n, v), dotNL = dot3(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f || under) { out->color = v3(0, 0, 0); out->pdf = 1.0f; }
+  else {
+    const float cosAlpha = clampf(dot3(newDir, r), 0.0f, 1.0f);
+    const float eqTemp = powf(cosAlpha, cosPower) * INV_TWOPI;
+    const float fix = (matFlags(m) & MF_ENERGY_FIX) ? PhongEnergyFix(cosAlpha, newDir, n) : 1.0f;
+    out->pdf = eqTemp * (cosPower + 1.0f);
+    out->color = scale3(scale3(color, eqTemp * (cosPower + 2.0f)), fix);
+  }
+  out->direction = newDir;
+  out->flags = (gloss >= 0.99f) ? RAY_EVENT_S : RAY_EVENT_G;
+}
+/* ---- mirror, ref: cmaterial.h:395-430 */
+static void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  f3 newDir = reflect3(ray_dir, n);
+  if (dot3(ray_dir, n) > 0.0f) newDir = ray_dir;
+  const float cosOut = dot3(newDir, n);
+  out->direction = newDir;
+  out->pdf = 1.0f;
+  out->color = scale3(mul3(matColor(m), tex), (1.0f / fmaxf(cosOut, 1e-6f)));
+  if (cosOut <= 1e-6f) out->color = v3(0, 0, 0);
+  out->flags = RAY_EVENT_S;
+}
+
+/* ---- blend, ref: cglobals.h:1880-1926 fresnel helpers, cmaterial.h:2008-2137 */
+static float fresnelDielectric(float cosTheta1, float cosTheta2, float etaExt, float etaInt) {   /* ref: cglobals.h:1868-1877 */
+  const float Rs = (etaExt * cosTheta1 - etaInt * cosTheta2) / (etaExt * cosTheta1 + etaInt * cosTheta2);
+  const float Rp = (etaInt * cosTheta1 - etaExt * cosTheta2) / (etaInt * cosTheta1 + etaExt * cosTheta2);
+  return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+static float fresnelReflectionCoeff(float cosTheta1, float etaExt, float etaInt) {               /* ref: cglobals.h:1879-1921 */
+  if (cosTheta1 < 0.0f) { const float t = etaInt; etaInt = etaExt; etaExt = t; }
+  const float sinTheta2 = etaExt / etaInt * sqrtf(fmaxf(0.0f, 1.0f - cosTheta1 * cosTheta1));
+  if (sinTheta2 > 1.0f) return 1.0f;
+  const float cosTheta2 = sqrtf(fmaxf(0.0f, 1.0f - sinTheta2 * sinTheta2));
+  return fresnelDielectric(fabsf(cosTheta1), cosTheta2, etaInt, etaExt);
+}
+static float hermiteSplineEvalT(float t, const float* points, const float* tangents, int numPoints) {   /* cmaterial.h:2008-2040 */
+  int ps = (int)(t * (float)(numPoints - 1));
+  if (ps == numPoints - 1) ps--;
+  const int pe = ps + 1;
+  const float tStart = (float)(ps) / (float)(numPoints - 1), tEnd = (float)(pe) / (float)(numPoints - 1);
+  const float sx = fabsf(t - tStart) / (tEnd - tStart);
+  const float s2 = sx * sx, s3 = s2 * sx;
+  const float h1 = 2.0f * s3 - 3.0f * s2 + 1.0f, h2 = -2.0f * s3 + 3.0f * s2, h3 = s3 - 2.0f * s2 + sx, h4 = s3 - s2;
+  return 1.0f - clampf(h1 * points[2 * ps + 1] + h2 * points[2 * pe + 1] + h3 * tangents[2 * ps + 1] + h4 * tangents[2 * pe + 1], 0.0f, 1.0f);
+}
+static float blendMaskAlpha2(const float* m, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 lum1 = clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f);
+  const int bflags = as_int(m[BLEND_FLAGS_OFFSET]);
+  float lum;
+  if (bflags & BMF_EXTRUSION_LUMINANCE) lum = dot3(v3(0.2126f, 0.7152f, 0.0722f), lum1);
+  else lum = fmaxf(lum1.x, fmaxf(lum1.y, lum1.z));
+  const float normAngle = fabsf(dot3(v, n));
+  float faloff = 0.0f;
+  if (bflags & BMF_FALOFF) {
+    const int start = as_int(m[BLEND_FALOFF_OFFSET]), size = as_int(m[BLEND_FALOFF_SIZE]);
+    const float* points = (const float*)(s->globals + s->globals[G_FLOAT_ARRAYS]) + start;
+    const float* tangents = points + size / 2;
+    const float param = (as_int(m[BLEND_FLAGS2]) & BLEND_INVERT_FALOFF) ? normAngle : 1.0f - normAngle;
+    faloff = hermiteSplineEvalT(param, points, tangents, size / 4);
+  }
+  if (as_int(m[BLEND_TYPE]) == BLEND_SIGMOID) {   /* maxSigmoid, cmaterial.h:2042-2046 */
+    const float x2 = -5.0f + 10.0f * lum;
+    lum = 1.04f / (1.0f + expf(-m[BLEND_SIGMOID_EXP] * x2)) - 0.02f;
+  }
+  if (bflags & BMF_FALOFF) return clampf(faloff, 0.0f, 1.0f);
+  if (bflags & BMF_FRESNEL) return clampf(lum * fresnelReflectionCoeff(fabsf(normAngle), 1.0f, m[BLEND_FRESNEL_IOR]), 0.0f, 1.0f);
+  return clampf(lum, 0.0f, 1.0f);
+}
+typedef struct { float w; int localOffs; } BRDFSelector;
+static BRDFSelector blendSelectBRDF(const float* m, float r3, f3 rayDir, f3 n, f2 tc, int reflOnly, const OrcScene* s) {   /* :2091-2137 */
+  float alpha = blendMaskAlpha2(m, rayDir, n, tc, s);
+  BRDFSelector m1, m2;
+  m1.localOffs = as_int(m[BLEND_MAT1]); m2.localOffs = as_int(m[BLEND_MAT2]);
+  const float* comp1 = m + (size_t)m1.localOffs * MAT_FLOATS;
+  m1.w = 1.0f; m2.w = 1.0f;
+  const int bflags = as_int(m[BLEND_FLAGS_OFFSET]);
+  if ((bflags & BMF_REFL_WEIGHT_IS_ONE) && matType(comp1) != MT_BLEND_MASK) { m1.w = alpha; m2.w = 1.0f; }
+  if ((bflags & BMF_FRESNEL) != 0 && reflOnly) { m1.w = alpha; alpha = 1.0f; }
+  return (r3 <= alpha) ? m1 : m2;
+}
+/* ref: cmaterial.h:2180-2207 materialRandomWalkBRDF */
+static BRDFSelector materialRandomWalkBRDF(const float* m, const float* rands, f3 rayDir, f3 n, f2 tc, const OrcScene* s, int reflOnly) {
+  BRDFSelector res = {1.0f, 0}, sel = {1.0f, 0};
+  const float* node = m;
+  int i = 0;
+  while (matType(node) == MT_BLEND_MASK && i < FLOATS_PER_MLAYER) {
+    const float rnd = rands[FLOATS_PER_SAMPLE + i];
+    sel = blendSelectBRDF(node, rnd, rayDir, n, tc, (reflOnly && (i == 0)), s);
+    res.w = res.w * sel.w;
+    res.localOffs = res.localOffs + sel.localOffs;
+    node = node + (size_t)sel.localOffs * MAT_FLOATS;
+    i++;
+  }
+  return res;
+}
+/* ref: cmaterial.h:2245-2335 MaterialLeafSampleAndEvalBRDF (no normal maps in the subset) */
+static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, f3 ray_dir, const float* rands, const OrcScene* s, MatSample* out) {
+  const f3 n = sh->normal;
+  out->color = v3(0, 0, 0); out->direction = v3(0, 1, 0); out->pdf = 1.0f; out->flags = 0;
+  switch (matType(m)) {
+    case MT_PHONG: PhongSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_MIRROR: MirrorSampleAndEvalBRDF(m, ray_dir, n, sh->texCoord, s, out); break;
+    case MT_LAMBERT: LambertSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
+    default: break;
+  }
+  if (out->pdf <= 0.0f) out->color = v3(0, 0, 0);
+}
+/* ref: cglobals.h:1366-1376 isEyeRay */
+static inline int isEyeRay(uint32_t flags) {
+  const uint32_t other = (flags & 0xFFFF0000u) >> 16;
+  const int nonSpec = (other & RAY_EVENT_D) || (other & RAY_EVENT_G);
+  return (((flags & 0x0000FF00u) >> 8) == 0) || !nonSpec;
+}
+/* ref: cmaterial.h:2345-2371 MaterialSampleAndEvalBxDF */
+static void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit* sh, f3 rayDir, uint32_t rayFlags, const OrcScene* s, MatSample* out) {
+  const uint32_t other = (rayFlags & 0xFFFF0000u) >> 16;
+  const int canReflOnly = (matFlags(m) & MF_CAN_SAMPLE_REFL_ONLY) != 0;
+  const int reflOnly = ((other & RAY_GRAMMAR_DIRECT_LIGHT) != 0) && canReflOnly;
+  const BRDFSelector mix = materialRandomWalkBRDF(m, rands, rayDir, sh->normal, sh->texCoord, s, reflOnly);
+  const float* leaf = m + (size_t)mix.localOffs * MAT_FLOATS;
+  MaterialLeafSampleAndEvalBRDF(leaf, sh, rayDir, rands, s, out);
+  out->color = scale3(out->color, 1.0f / fmaxf(mix.w, 0.015625f));
+  if ((matFlags(leaf) & MF_SKIP_SKY_PORTAL) && isEyeRay(rayFlags)) { out->color = v3(1, 1, 1); out->pdf = 1.0f; }
+}
+/* ref: cmaterial.h:2425-2551 materialLeafEval (EVAL_FLAG_DEFAULT: no forward-direction fix, no normal map) */
+static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const OrcScene* s) {
+  BxDFResult r;
+  r.brdf = v3(0, 0, 0); r.btdf = v3(0, 0, 0); r.pdfFwd = 0.0f; r.pdfRev = 0.0f; r.diffuse = 0;
+  const float cosMult = 1.0f;
+  switch (matType(m)) {
+    case MT_PHONG:
+      r.brdf = scale3(phongEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
+      r.pdfFwd = phongEvalPDF(m, sc->l, sc->v, sc->n, sc->tc, s);
+      r.pdfRev = phongEvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
+      break;
+    case MT_MIRROR: break;   /* mirrorEvalBxDF / PDF return 0, cmaterial.h:395-403 */
+    case MT_LAMBERT:
+      r.brdf = scale3(lambertEvalBxDF(m, sc->tc, s), cosMult);
+      r.pdfFwd = lambertEvalPDF(sc->l, sc->n);
+      r.pdfRev = lambertEvalPDF(sc->v, sc->n);
+      r.diffuse = 1;
+      break;
+    default: break;
+  }
+  return r;
+}
+/* ref: cmaterial.h:2554-2628 materialEval: explicit-stack walk over the blend tree */
+static BxDFResult materialEval(const float* a_m, const ShadeContext* sc, const OrcScene* s) {
+  BxDFResult val;
+  val.brdf = v3(0, 0, 0); val.btdf = v3(0, 0, 0); val.pdfFwd = 0.0f; val.pdfRev = 0.0f; val.diffuse = 1;
+  float stackW[MIX_TREE_MAX_DEEP]; int stackO[MIX_TREE_MAX_DEEP];
+  int top = 0, currOffset = 0;
+  float currW = 1.0f;
+  do {
+    if (top > 0) { top--; currOffset = stackO[top]; currW = stackW[top]; }
+    const float* m = a_m + (size_t)currOffset * MAT_FLOATS;
+    if (matType(m) == MT_BLEND_MASK) {
+      const float alpha = blendMaskAlpha2(m, sc->v, sc->n, sc->tc, s);
+      const int o1 = as_int(m[BLEND_MAT1]), o2 = as_int(m[BLEND_MAT2]);
+      float w1 = alpha, w2 = 1.0f - alpha;
+      const float* comp1 = m + (size_t)o1 * MAT_FLOATS;
+      if ((as_int(m[BLEND_FLAGS_OFFSET]) & BMF_REFL_WEIGHT_IS_ONE) && matType(comp1) != MT_BLEND_MASK) w1 = 1.0f;
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w1; stackO[top] = currOffset + o1; top++; }
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w2; stackO[top] = currOffset + o2; top++; }
+    } else {
+      const BxDFResult b = materialLeafEval(m, sc, s);
+      val.brdf = add3(val.brdf, scale3(b.brdf, currW));
+      val.btdf = add3(val.btdf, scale3(b.btdf, currW));
+      val.pdfFwd += currW * b.pdfFwd;
+      val.pdfRev += currW * b.pdfRev;
+      val.diffuse = val.diffuse && b.diffuse;
+    }
+  } while (top > 0);
+  return val;
+}
+/* ref: cmaterial.h:2918-2978 materialEvalEmission; leaf: :20-26 */
+static f3 materialEvalEmission(const float* a_m, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  f3 val = v3(0, 0, 0);
+  float stackW[MIX_TREE_MAX_DEEP]; int stackO[MIX_TREE_MAX_DEEP];
+  int top = 0, currOffset = 0;
+  float currW = 1.0f;
+  do {
+    if (top > 0) { top--; currOffset = stackO[top]; currW = stackW[top]; }
+    const float* m = a_m + (size_t)currOffset * MAT_FLOATS;
+    if (matType(m) == MT_BLEND_MASK) {
+      const float alpha = blendMaskAlpha2(m, v, n, tc, s);
+      const int o1 = as_int(m[BLEND_MAT1]), o2 = as_int(m[BLEND_MAT2]);
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * alpha; stackO[top] = currOffset + o1; top++; }
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * (1.0f - alpha); stackO[top] = currOffset + o2; top++; }
+    }
+    {
+      const f3 tex = sample2DExt(as_int(m[EMISSIVE_TEXMATRIXID]), tc, m, s);
+      const f3 e = mul3(v3(m[EMISSIVE_COLOR], m[EMISSIVE_COLOR + 1], m[EMISSIVE_COLOR + 2]), tex);
+      val = add3(val, scale3(e, currW));
+    }
+  } while (top > 0);
+  return val;
+}
+/* ref: cmaterial.h:3262-3293 flagsNextBounceLite */
+static uint32_t flagsNextBounceLite(uint32_t flags, const MatSample* ms, const OrcScene* s) {
+  const int thisDiffuse = (ms->flags & RAY_EVENT_D) != 0;
+  const uint32_t bounce = (flags & 0x0000FF00u) >> 8, diff = (flags & 0x000000FFu);
+  uint32_t other = (flags & 0xFFFF0000u) >> 16;
+  flags = (flags & 0xFFFF00FFu) | ((bounce + 1) << 8);
+  if (thisDiffuse) flags = (flags & 0xFFFFFF00u) | (diff + 1);
+  const uint32_t bounce2 = bounce + 1, diff2 = flags & 0xFFu;
+  if ((bounce2 >= (uint32_t)g_varsI(s)[HRT_TRACE_DEPTH]) || (diff2 >= (uint32_t)g_varsI(s)[HRT_DIFFUSE_TRACE_DEPTH] + 1)) other |= RAY_IS_DEAD;
+  if (ms->flags & RAY_EVENT_G) other |= RAY_EVENT_G;
+  if ((ms->flags & RAY_EVENT_S) || (ms->flags & RAY_EVENT_T)) other |= RAY_EVENT_S;
+  if (ms->flags & RAY_EVENT_D) other |= RAY_EVENT_D;
+  if (ms->flags & RAY_EVENT_T) other |= RAY_EVENT_T;
+  return (flags & 0x0000FFFFu) | (other << 16);
+}
+
+/* ------------------------------------------------------------------------------------------------ lights */
+static inline const float* lightAt(const OrcScene* s, int id) {   /* ref: clight.h:1739-1749 */
+  if (id < 0) return NULL;
+  return (const float*)(s->globals + s->globals[G_LIGHTS_OFFS]) + (size_t)id * LIGHT_FLOATS;
+}
+static inline f3 lightPos(const float* L) { return v3(L[PL_POS], L[PL_POS + 1], L[PL_POS + 2]); }
+static inline f3 lightNorm(const float* L) { return v3(L[PL_NORM], L[PL_NORM + 1], L[PL_NORM + 2]); }
+static inline f3 lightColor(const float* L) { return v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]); }
+
+/* ref: clight.h:524-530 areaDiffuseLightEvalPDF (+ PdfAtoW cglobals.h:1754-1757) */
+static float areaDiffuseLightEvalPDF(const float* L, f3 rayDir, float hitDist) {
+  const f3 ln = lightNorm(L);
+  const float pdfA = 1.0f / fmaxf(L[PL_SURFACE_AREA], DEPSILON);
+  const float d = dot3(rayDir, scale3(ln, -1.0f));
+  const float cosVal = (as_int(L[PL_FLAGS]) & LF_HAS_IES) ? fabsf(d) : fmaxf(d, 0.0f);
+  return (pdfA * hitDist * hitDist) / fmaxf(cosVal, DEPSILON2);
+}
+/* ref: clight.h:542-611 areaDiffuseLightGetIntensity (no texture, no IES, no sky portal in the subset; spot kept) */
+static f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, int eyeRay) {
+  f3 color = lightColor(L);
+  if (as_int(L[AL_SPOT_DISTR]) != 0) {
+    const float cos1 = L[AL_SPOT_COS1], cos2 = L[AL_SPOT_COS2];
+    const float cos_theta = fmaxf(dot3(scale3(rayDir, -1.0f), lightNorm(L)), 0.0f);
+    const float tVal = (cos_theta - cos2) / (cos1 - cos2);           /* mylocalsmoothstep, clight.h:7-12 */
+    const float tt = fminf(fmaxf(tVal, 0.0f), 1.0f);
+    const float atten = tt * tt * (3.0f - 2.0f * tt);
+    if (!eyeRay) color = scale3(color, clampf(atten, 0.0f, 1.0f));
+    else color = scale3(color, 1.0f / fmaxf(color.x, fmaxf(color.y, color.z)));
+  }
+  return color;
+}
+/* ref: clight.h:1180-1229 AreaLightSampleRev */
+typedef struct { f3 pos, color; float pdf, maxDist, cosAtLight; int isPoint; } ShadowSample;
+static void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
+  f3 sp = v3(offsetX * L[AL_SIZE_X], 0.0f, offsetY * L[AL_SIZE_Y]);
+  if (as_int(L[AL_IS_DISK]) != 0) {
+    f2 in = {offsetX, offsetY};
+    const f2 xz = MapSamplesToDisc(in);
+    sp = v3(xz.x * L[AL_SIZE_X], 0, xz.y * L[AL_SIZE_X]);
+  }
+  const float* M = L + AL_MATRIX;   /* matrix3x3f_mult_float3, cglobals.h:1091-1098 */
+  sp = v3(M[0] * sp.x + M[1] * sp.y + M[2] * sp.z, M[3] * sp.x + M[4] * sp.y + M[5] * sp.z, M[6] * sp.x + M[7] * sp.y + M[8] * sp.z);
+  sp = add3(sp, lightPos(L));
+  const f3 rayDir = normalize3(sub3(sp, illum));
+  const float hitDist = length3(sub3(sp, illum));
+  const f3 color = areaDiffuseLightGetIntensity(L, rayDir, 0);
+  const f3 ln = lightNorm(L);
+  out->isPoint = 0;
+  out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
+  out->color = color;
+  out->pdf = areaDiffuseLightEvalPDF(L, rayDir, hitDist);
+  out->maxDist = hitDist;
+  out->cosAtLight = -dot3(rayDir, ln);
+}
+/* ref: cglobals.h:2808-2859 SelectIndexPropToOpt */
+static int SelectIndexPropToOpt(float a_r, const float* a_accum, int N, float* pPDF) {
+  int leftBound = 0, rightBound = N - 2, counter = 0, currPos = -1;
+  const int maxStep = 50;
+  const float x = a_r * a_accum[N - 1];
+  while (rightBound - leftBound > 1 && counter < maxStep) {
+    const int currSize = rightBound + leftBound;
+    const int currPos1 = (currSize % 2 == 0) ? (currSize + 1) / 2 : (currSize + 0) / 2;
+    const float a = a_accum[currPos1 + 0], b = a_accum[currPos1 + 1];
+    if (a < x && x <= b) { currPos = currPos1; break; }
+    else if (x <= a) rightBound = currPos1;
+    else if (x > b) leftBound = currPos1;
+    counter++;
+  }
+  if (currPos < 0) {
+    const float a1 = a_accum[leftBound + 0], b1 = a_accum[leftBound + 1], a2 = a_accum[rightBound + 0], b2 = a_accum[rightBound + 1];
+    if (a1 < x && x <= b1) currPos = leftBound;
+    if (a2 < x && x <= b2) currPos = rightBound;
+  }
+  if (x == 0.0f) currPos = 0;
+  else if (currPos < 0) currPos = (rightBound + leftBound + 1) / 2;
+  *pPDF = (a_accum[currPos + 1] - a_accum[currPos]) / a_accum[N - 1];
+  return currPos;
+}
+/* ref: clight.h:1774-1793 SelectRandomLightRev */
+static int SelectRandomLightRev(float r, const OrcScene* s, float* pickProb) {
+  const int tableSize = s->globals[G_LSEL_REV_SIZE];
+  if (tableSize == 0) { *pickProb = 1.0f; return -1; }
+  if (tableSize <= 2) { *pickProb = 1.0f; return 0; }
+  return SelectIndexPropToOpt(r, (const float*)(s->globals + s->globals[G_LSEL_REV_OFFS]), tableSize, pickProb);
+}
+
+/* ------------------------------------------------------------------------------------------------ path tracer */
+typedef struct { float matSamplePdf; int isSpecular; } MisData;   /* ref: cglobals.h:1382-1400 (fields the PT path reads) */
+
+/* ref: cbidir.h:653-678 emissionEval + CPUExp_Integrators_Common.cpp:516-527 */
+static f3 emissionEval(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceHit* sh, uint32_t flags, const float* pLight, const float* mat) {
+  const f3 normal = sh->hfi ? scale3(sh->normal, -1.0f) : sh->normal;
+  int hasIES = 0;
+  const int lightsNum = s->globals[G_LIGHTS_NUM];
+  if (lightsNum > 0 && pLight != NULL) hasIES = (as_int(pLight[PL_FLAGS]) & LF_HAS_IES) != 0;
+  if (dot3(ray_dir, normal) >= 0.0f && !hasIES) return v3(0, 0, 0);
+  f3 out = materialEvalEmission(mat, ray_dir, normal, sh->texCoord, s);
+  if ((matFlags(mat) & MF_FORBID_EMISSIVE_GI) && (flags & 0xFFu) > 0) out = v3(0, 0, 0);
+  if (lightsNum > 0 && pLight != NULL) {
+    /* lightGetIntensity, clight.h:1661-1706: area lights only in the subset */
+    const int eyeRay = ((flags & 0xFFu) == 0);
+    if (as_int(pLight[PL_TYPE]) == LT_AREA) out = areaDiffuseLightGetIntensity(pLight, ray_dir, eyeRay);
+    else out = lightColor(pLight);
+  }
+  (void)ray_pos;
+  return out;
+}
+
+typedef struct { uint64_t rays; } PathStat;
+
+/* optional ray recorder used by orc_collect_rays */
+typedef struct { int bounce, shadow; f3 pos, dir; float tfar; int have; } RayProbe;
+
+/* ref: CPUExp_Integrators_PT_Loop.cpp:264-321 IntegratorMISPTLoop2::PathTrace with its kernel_* stages :9-262 */
+static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], PathStat* st, RayProbe* probe) {
+  f3 accumColor = v3(0, 0, 0), thoroughput = v3(1, 1, 1), currColor = v3(0, 0, 0);
+  MisData misPrev = {1.0f, 1};   /* makeInitialMisData */
+  uint32_t flags = 0;
+  const int maxDepth = g_varsI(s)[HRT_TRACE_DEPTH];   /* SetMaxDepth(varsI[HRT_TRACE_DEPTH]), CPUExpLayer.cpp:130 */
+
+  for (int depth = 0; depth < maxDepth; depth++) {
+    /* kernel_RayTrace */
+    if (probe && !probe->shadow && probe->bounce == depth) { probe->pos = ray_pos; probe->dir = ray_dir; probe->have = 1; }
+    const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
+    st->rays++;
+    /* kernel_HitEnvironment: environmentColor, cbidir.h:492-533 -- no sky light in the subset => black */
+    if (!HitSome(hit)) { currColor = v3(0, 0, 0); break; }
+    /* kernel_EvalSurface */
+    const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
+    const float* mat = materialAt(s, surf.matId);
+    /* kernel_EvalEmission :86-139 */
+    {
+      const int lightOffset0 = (s->globals[G_LIGHTS_NUM] != 0) ? s->instLightInstId[hit.instId] : -1;
+      const float* pLightHit = lightAt(s, lightOffset0);
+      const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, pLightHit, mat);
+      if (dot3(emission, emission) > 1e-3f) {
+        if (pLightHit != NULL) {
+          const float hitDist = length3(sub3(ray_pos, surf.pos));   /* lightEvalPDF, clight.h:1613-1633 */
+          const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, hitDist);
+          float misWeight = misWeightHeuristic(misPrev.matSamplePdf, lgtPdf);
+          if (misPrev.isSpecular) misWeight = 1.0f;
+          currColor = scale3(emission, misWeight);
+        } else
+          currColor = emission;
+        break;
+      } else if (depth >= maxDepth - 1) { currColor = v3(0, 0, 0); break; }
+    }
+    /* kernel_LightSelect :141-151 */
+    float rl[4];
+    orc_rnd_float4(gen, rl);   /* rndLight, crandom.h:404-418 (pseudo-random branch) */
+    float lightPickProb = 1.0f;
+    const int lightOffset = SelectRandomLightRev(rl[2], s, &lightPickProb);
+    /* kernel_LightSample :154-168 */
+    f3 shadowRayPos = v3(0, 0, 0), shadowRayDir = v3(0, 0, 0);
+    ShadowSample explicitSam;
+    memset(&explicitSam, 0, sizeof(explicitSam));
+    if (lightOffset >= 0) {
+      AreaLightSampleRev(lightAt(s, lightOffset), v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);   /* LightSampleRev, clight.h:1561-1610 */
+      shadowRayDir = normalize3(sub3(explicitSam.pos, surf.pos));
+      shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
+    }
+    /* kernel_ShadowTrace :170-179 */
+    float shadow = 0.0f;
+    if (lightOffset >= 0) {
+      const float tfar = length3(sub3(shadowRayPos, explicitSam.pos)) * 0.995f;
+      if (probe && probe->shadow && probe->bounce == depth) { probe->pos = shadowRayPos; probe->dir = shadowRayDir; probe->tfar = tfar; probe->have = 1; }
+      shadow = shadowTrace(s, shadowRayPos, shadowRayDir, tfar);
+      st->rays++;
+    }
+    /* kernel_Shade :181-216 */
+    f3 explicitColor = v3(0, 0, 0);
+    if (lightOffset >= 0) {
+      ShadeContext sc;
+      sc.l = shadowRayDir; sc.v = scale3(ray_dir, -1.0f); sc.n = surf.normal; sc.fn = surf.flatNormal;
+      sc.tg = surf.tangent; sc.bn = surf.biTangent; sc.tc = surf.texCoord;
+      const BxDFResult ev = materialEval(mat, &sc, s);
+      const float cos1 = fmaxf(+dot3(shadowRayDir, surf.normal), 0.0f), cos2 = fmaxf(-dot3(shadowRayDir, surf.normal), 0.0f);
+      const f3 bxdfVal = add3(scale3(ev.brdf, cos1), scale3(ev.btdf, cos2));
+      const float lgtPdf = explicitSam.pdf * lightPickProb;
+      float misWeight = misWeightHeuristic(lgtPdf, ev.pdfFwd);
+      if (explicitSam.isPoint) misWeight = 1.0f;
+      const f3 lc = scale3(explicitSam.color, (1.0f / fmaxf(explicitSam.pdf, DEPSILON2)));
+      explicitColor = scale3(scale3(mul3(scale3(lc, (1.0f / lightPickProb)), bxdfVal), misWeight), shadow);
+    }
+    /* kernel_NextBounce :218-256; RndMatAll crandom.h:478-494 */
+    float allRands[FLOATS_PER_SAMPLE + FLOATS_PER_MLAYER];
+    {
+      float r4[4];
+      orc_rnd_float4(gen, r4);
+      allRands[0] = r4[0]; allRands[1] = r4[1]; allRands[2] = r4[2];
+      for (int k = 0; k < FLOATS_PER_MLAYER; k++) allRands[FLOATS_PER_SAMPLE + k] = orc_rnd_float1(gen);
+    }
+    MatSample ms;
+    MaterialSampleAndEvalBxDF(mat, allRands, &surf, ray_dir, flags, s, &ms);
+    const f3 bxdfVal = scale3(ms.color, (1.0f / fmaxf(ms.pdf, 1e-20f)));
+    const float cosTheta = fabsf(dot3(ms.direction, surf.normal));
+    ray_dir = ms.direction;
+    ray_pos = OffsRayPos(surf.pos, surf.normal, ms.direction);
+    misPrev.isSpecular = ((ms.flags & RAY_EVENT_S) != 0 || (ms.flags & RAY_EVENT_T) != 0);
+    misPrev.matSamplePdf = ms.pdf;
+    flags = flagsNextBounceLite(flags, &ms, s);
+    accumColor = add3(accumColor, mul3(thoroughput, explicitColor));
+    thoroughput = mul3(thoroughput, scale3(bxdfVal, cosTheta));
+  }
+  accumColor = add3(accumColor, mul3(thoroughput, currColor));   /* kernel_AddLastBouceContrib */
+  return accumColor;
+}
+
+void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n; i++) {
+    PathStat st = {0};
+    const f3 c = PathTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), rng2 + 2 * (size_t)i, &st, NULL);
+    color4[4 * i] = c.x; color4[4 * i + 1] = c.y; color4[4 * i + 2] = c.z; color4[4 * i + 3] = (float)st.rays;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ P0: passes */
+/* generator of pixel i = RandomGenInit(seed + i): the per-slot seeding of the reference's wavefront layer
+ * (shaders/trace.cl:6-13 InitRandomGen) with slot = pixel, instead of the CPU layer's per-OpenMP-thread generators
+ * (CPUExp_Integrators_Common.cpp:43-44), which make the reference image thread-count dependent. */
+void orc_init_generators(int w, int h, int seed, uint32_t* gens) {
+  for (int i = 0; i < w * h; i++) orc_random_init(seed + i, gens + 2 * (size_t)i);
+}
+static inline int pixel_owned(int x, int y, int w, int rank, int world, int tile) {
+  if (world <= 1) return 1;
+  const int tilesX = (w + tile - 1) / tile;
+  const int t = (y / tile) * tilesX + (x / tile);
+  return (t % world) == rank;
+}
+/* ref: CPUExp_Integrators_Common.cpp:278-316 IntegratorCommon::DoPass + :347-359 makeEyeRay */
+uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float* image4, int spp_done, int sum_mode,
+                         int rank, int world, int tile, int threads) {
+  const float alpha = 1.0f / (float)(spp_done + 1);
+  uint64_t totalRays = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for collapse(2) schedule(dynamic, 64) reduction(+ : totalRays)
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      if (!pixel_owned(x, y, w, rank, world, tile)) continue;
+      uint32_t* gen = gens + 2 * ((size_t)y * w + x);
+      float r4[4], offs[4];
+      orc_rnd_float4(gen, r4);   /* rndUniform(gen, -1, 1), crandom.h:617-620 */
+      for (int k = 0; k < 4; k++) offs[k] = -1.0f + (1.0f - (-1.0f)) * r4[k];
+      f3 ray_pos, ray_dir;
+      MakeRandEyeRay(x, y, w, h, offs, s, &ray_pos, &ray_dir);
+      PathStat st = {0};
+      const f3 color = PathTrace(s, ray_pos, ray_dir, gen, &st, NULL);
+      totalRays += st.rays;
+      float* px = image4 + 4 * ((size_t)y * w + x);
+      if (sum_mode) { px[0] += color.x; px[1] += color.y; px[2] += color.z; px[3] += 0.0f; }
+      else {   /* the debug red pixel of Common.cpp:295-301 is deliberately not reproduced */
+        px[0] = px[0] * (1.0f - alpha) + color.x * alpha;
+        px[1] = px[1] * (1.0f - alpha) + color.y * alpha;
+        px[2] = px[2] * (1.0f - alpha) + color.z * alpha;
+        px[3] = px[3] * (1.0f - alpha) + 0.0f * alpha;
+      }
+    }
+  }
+  return totalRays;
+}
+
+int64_t orc_collect_rays(const OrcScene* s, int w, int h, int seed, int bounce, int shadow, float* pos4, float* dir4, float* tfar, int64_t cap) {
+  int64_t count = 0;
+  for (int y = 0; y < h && count < cap; y++) {
+    for (int x = 0; x < w && count < cap; x++) {
+      uint32_t gen[2];
+      orc_random_init(seed + y * w + x, gen);
+      float r4[4], offs[4];
+      orc_rnd_float4(gen, r4);
+      for (int k = 0; k < 4; k++) offs[k] = -1.0f + 2.0f * r4[k];
+      f3 ray_pos, ray_dir;
+      MakeRandEyeRay(x, y, w, h, offs, s, &ray_pos, &ray_dir);
+      PathStat st = {0};
+      RayProbe pr;
+      memset(&pr, 0, sizeof(pr));
+      pr.bounce = bounce; pr.shadow = shadow;
+      (void)PathTrace(s, ray_pos, ray_dir, gen, &st, &pr);
+      if (pr.have) {
+        pos4[4 * count] = pr.pos.x; pos4[4 * count + 1] = pr.pos.y; pos4[4 * count + 2] = pr.pos.z; pos4[4 * count + 3] = 0.0f;
+        dir4[4 * count] = pr.dir.x; dir4[4 * count + 1] = pr.dir.y; dir4[4 * count + 2] = pr.dir.z; dir4[4 * count + 3] = 0.0f;
+        if (tfar) tfar[count] = pr.tfar;
+        count++;
+      }
+    }
+  }
+  return count;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,75 @@
+/* hydra_oracle.h -- CPU oracle: plain-C restatement of the reference's unidirectional MIS path tracer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked into, imported by or executed from the product
+ * (hydracore_amd/, include/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the reported CPU baseline.
+ *
+ * Follows, function by function, hydra_drv/CPUExp_Integrators_PT_Loop.cpp (IntegratorMISPTLoop2),
+ * CPUExp_Integrators_Common.cpp (DoPass, rayTrace, shadowTrace) and the inline kernels in hydra_drv/c*.h; each
+ * function in hydra_oracle.c cites the file:line it restates.
+ *
+ * PINNING: the reference's C++ path cannot be compiled in this image (hydra_drv/cglobals.h:324-327 includes
+ * HydraAPI's LiteMath.h / HR_HDRImage.h, which are absent, and stand-ins are not allowed), and the reference ships no
+ * golden vectors for this path.  The restatement is therefore pinned against the reference's own OpenCL build of the
+ * same inline functions (oracle/_ref/<kernel>.hsaco, built by oracle/build_ref.sh from hydra_drv/shaders/<kernel>.cl and run on
+ * the GPU box; vectors committed under tests/golden/).  Anything not covered by those vectors is "parity unpinned".
+ */
+#ifndef HYDRA_ORACLE_H
+#define HYDRA_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcScene {
+  const int32_t* globals;        /* [EngineGlobals | tables | lights] blob            */
+  const float*   matStorage;     /* materials arena (float4 units addressable)        */
+  const int32_t* texStorage;     /* textures arena                                    */
+  const float*   geomStorage;    /* geometry arena                                    */
+  const float*   pdfStorage;     /* pdf tables arena (unused by the supported subset) */
+  const float*   bvh;            /* tree 0 nodes, 8 floats per node                   */
+  const float*   tris;           /* tree 0 triangle float4 list                       */
+  int32_t        haveInst;
+  const float*   instMatrices;   /* 16 floats per instance, world -> object, columns  */
+  const int32_t* instLightInstId;
+  int32_t        instNum;
+  const int32_t* remapLists;  int32_t remapListsSize;
+  const int32_t* remapTable;  int32_t remapTableSize;   /* int2 entries */
+  const int32_t* remapInst;   int32_t remapInstSize;
+} OrcScene;
+
+typedef struct OrcHit { float t; int32_t primId, instId, geomId; } OrcHit;
+
+/* R1 */
+void orc_random_init(int32_t seed, uint32_t state[2]);
+uint32_t orc_next_state(uint32_t state[2]);
+void orc_rnd_float4(uint32_t state[2], float out[4]);
+float orc_rnd_float1(uint32_t state[2]);
+
+/* P1: xy = 2 ints per ray, offs4 = 4 floats in [-1,1] */
+void orc_make_eye_rays(const OrcScene* s, int n, int w, int h, const int32_t* xy, const float* offs4, float* pos4, float* dir4);
+/* T1 (counters3 optional: quads visited, instance quads entered, triangles tested; leaves = optional 4th array NULL) */
+void orc_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, OrcHit* hits, uint32_t* counters3, uint32_t* leaves1);
+/* T2 */
+void orc_shadow_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis);
+/* H1: 24 floats per hit (layout in include/hydra_hip.h, hydra_hip_stage_eval_surface) */
+void orc_eval_surface(const OrcScene* s, int n, const float* pos4, const float* dir4, const OrcHit* hits, float* surf24);
+/* whole paths, per-path RandomGen state (updated in place); color4.w = number of rays traced (extension + shadow) */
+void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4);
+
+/* P0: one sample for every pixel owned by (rank, world, tile) -- IntegratorCommon::DoPass with per-pixel generators.
+ * gens: 2 uint32 per pixel, image: float4 running mean (reference semantics) OR sums when sum_mode != 0.
+ * Returns the number of rays traced (extension + shadow). threads <= 0: OpenMP default. */
+uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float* image4, int spp_done, int sum_mode,
+                         int rank, int world, int tile, int threads);
+void orc_init_generators(int w, int h, int seed, uint32_t* gens);
+/* dump the live rays of a given bounce (0 = primary) for the first sample of every pixel: returns count */
+int64_t orc_collect_rays(const OrcScene* s, int w, int h, int seed, int bounce, int shadow, float* pos4, float* dir4, float* tfar, int64_t cap);
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

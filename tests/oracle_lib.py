@@ -1,0 +1,158 @@
+"""ctypes wrapper of oracle/liboracle.so -- the CPU checker.  Imported only by tests, smoke() and bench.py's
+cpu_baseline leg; never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LITE_HIT_DTYPE = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("globals", C.c_void_p), ("matStorage", C.c_void_p), ("texStorage", C.c_void_p), ("geomStorage", C.c_void_p),
+                ("pdfStorage", C.c_void_p), ("bvh", C.c_void_p), ("tris", C.c_void_p), ("haveInst", C.c_int32),
+                ("instMatrices", C.c_void_p), ("instLightInstId", C.c_void_p), ("instNum", C.c_int32),
+                ("remapLists", C.c_void_p), ("remapListsSize", C.c_int32), ("remapTable", C.c_void_p),
+                ("remapTableSize", C.c_int32), ("remapInst", C.c_void_p), ("remapInstSize", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ROOT, "oracle/liboracle.so"])
+    lib = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int
+    sp = C.POINTER(OrcScene)
+    lib.orc_random_init.argtypes = [C.c_int32, vp]
+    lib.orc_next_state.argtypes = [vp]
+    lib.orc_next_state.restype = C.c_uint32
+    lib.orc_rnd_float4.argtypes = [vp, vp]
+    lib.orc_rnd_float1.argtypes = [vp]
+    lib.orc_rnd_float1.restype = C.c_float
+    lib.orc_make_eye_rays.argtypes = [sp, i32, i32, i32, vp, vp, vp, vp]
+    lib.orc_trace.argtypes = [sp, i32, vp, vp, vp, vp, vp]
+    lib.orc_shadow_trace.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_eval_surface.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_path_trace.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
+    lib.orc_render_pass.restype = C.c_uint64
+    lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
+    lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
+    lib.orc_collect_rays.restype = C.c_int64
+    lib.orc_max_threads.restype = i32
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Oracle:
+    """Oracle bound to one set of scene buffers (the dict from HostScene.buffers()); keeps the arrays alive."""
+
+    def __init__(self, buffers):
+        self.lib = load()
+        self.b = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in buffers.items()}
+        b = self.b
+        s = OrcScene()
+        s.globals, s.matStorage, s.texStorage = _p(b["globals"]), _p(b["materials"]), _p(b["textures"])
+        s.geomStorage, s.pdfStorage, s.bvh, s.tris = _p(b["geom"]), _p(b["pdfs"]), _p(b["bvh_nodes"]), _p(b["bvh_tris"])
+        s.haveInst = int(b["have_inst"])
+        s.instMatrices, s.instLightInstId = _p(b["inst_matrices"]), _p(b["inst_light_id"])
+        s.instNum = b["inst_matrices"].size // 16
+        s.remapLists, s.remapListsSize = _p(b["remap_lists"]), b["remap_lists"].size
+        s.remapTable, s.remapTableSize = _p(b["remap_table"]), b["remap_table"].size // 2
+        s.remapInst, s.remapInstSize = _p(b["remap_inst"]), b["remap_inst"].size
+        self.s = s
+        self.w, self.h = b["width"], b["height"]
+
+    # R1
+    def random(self, seeds, draws):
+        seeds = np.asarray(seeds, np.int32)
+        out = np.empty((seeds.size, draws, 4), np.float32)
+        st = np.empty((seeds.size, 2), np.uint32)
+        tmp = np.empty(4, np.float32)
+        for i, sd in enumerate(seeds):
+            g = np.zeros(2, np.uint32)
+            self.lib.orc_random_init(int(sd), _p(g))
+            for d in range(draws):
+                self.lib.orc_rnd_float4(_p(g), _p(tmp))
+                out[i, d] = tmp
+            st[i] = g
+        return out, st
+
+    def make_eye_rays(self, xy, offs4):
+        xy = np.ascontiguousarray(xy, np.int32)
+        offs4 = np.ascontiguousarray(offs4, np.float32)
+        n = xy.shape[0]
+        pos, dr = np.empty((n, 4), np.float32), np.empty((n, 4), np.float32)
+        self.lib.orc_make_eye_rays(C.byref(self.s), n, self.w, self.h, _p(xy), _p(offs4), _p(pos), _p(dr))
+        return pos, dr
+
+    def trace(self, pos4, dir4, counters=False):
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        n = pos4.shape[0]
+        hits = np.empty(n, LITE_HIT_DTYPE)
+        cnt = np.empty((n, 3), np.uint32) if counters else None
+        leaves = np.empty(n, np.uint32) if counters else None
+        self.lib.orc_trace(C.byref(self.s), n, _p(pos4), _p(dir4), _p(hits), _p(cnt), _p(leaves))
+        return (hits, cnt, leaves) if counters else hits
+
+    def shadow_trace(self, pos4, dir4, tfar):
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        tfar = np.ascontiguousarray(tfar, np.float32)
+        n = pos4.shape[0]
+        vis = np.empty(n, np.float32)
+        self.lib.orc_shadow_trace(C.byref(self.s), n, _p(pos4), _p(dir4), _p(tfar), _p(vis))
+        return vis
+
+    def eval_surface(self, pos4, dir4, hits):
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        hits = np.ascontiguousarray(hits)
+        n = pos4.shape[0]
+        out = np.empty((n, 24), np.float32)
+        self.lib.orc_eval_surface(C.byref(self.s), n, _p(pos4), _p(dir4), _p(hits), _p(out))
+        return out
+
+    def path_trace(self, pos4, dir4, rng2):
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        rng2 = np.ascontiguousarray(rng2, np.uint32).copy()
+        n = pos4.shape[0]
+        col = np.empty((n, 4), np.float32)
+        self.lib.orc_path_trace(C.byref(self.s), n, _p(pos4), _p(dir4), _p(rng2), _p(col))
+        return col, rng2
+
+    def init_generators(self, seed):
+        g = np.empty((self.h * self.w, 2), np.uint32)
+        self.lib.orc_init_generators(self.w, self.h, seed, _p(g))
+        return g
+
+    def render(self, spp, seed=777, sum_mode=False, rank=0, world=1, tile=64, threads=0, gens=None, image=None, spp_done=0):
+        """spp passes of DoPass; returns (image float4 [h,w,4], rays traced, gens)."""
+        if gens is None:
+            gens = self.init_generators(seed)
+        if image is None:
+            image = np.zeros((self.h, self.w, 4), np.float32)
+        rays = 0
+        for k in range(spp):
+            rays += self.lib.orc_render_pass(C.byref(self.s), self.w, self.h, _p(gens), _p(image), spp_done + k, 1 if sum_mode else 0,
+                                             rank, world, tile, threads)
+        return image, int(rays), gens
+
+    def collect_rays(self, seed, bounce, shadow=False, cap=None):
+        cap = cap or self.w * self.h
+        pos, dr, tf = np.empty((cap, 4), np.float32), np.empty((cap, 4), np.float32), np.empty(cap, np.float32)
+        n = self.lib.orc_collect_rays(C.byref(self.s), self.w, self.h, seed, bounce, 1 if shadow else 0, _p(pos), _p(dr), _p(tf), cap)
+        return pos[:n].copy(), dr[:n].copy(), tf[:n].copy()
+
+    def max_threads(self):
+        return self.lib.orc_max_threads()
