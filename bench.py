@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the MI355X wavefront path tracer on BASELINE.json configs[1]:
+Cornell-box-style test scene (tests/golden/scenes/test_224 = the reference's hydra_app/tests/test_224), 1920x1080,
+8 bounces, PT integrator; 256 spp = 16 steps x 16 spp by default.
+
+A "step" = one pass of the hot path: `--spp-per-step` samples for every pixel this rank owns (ray generation, up to 9
+closest-hit traversals, emission/light sampling with compaction, shadow traversals, shading, accumulate).  With N > 1
+GPUs the image plane is tile-partitioned (weak work per step is fixed per pixel, the frame is split => "strong"
+scaling of one frame) and the float4 accumulator is reduced once over RCCL at the end of the timed region.
+
+Prints ONE JSON line (rank 0).  Rays are counted exactly on the device (every extension and shadow ray traced).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def traversal_bytes(counters):
+    """Algorithmic bytes of the traversal kernels: per ray 36 B in (pos, dir, flags/count) + 16 B out,
+    128 B per quad visited, 128 B per instance quad entered, 16 B per leaf header, 48 B per triangle tested.
+    counters: uint64 [depth, 2 (closest|shadow), 5 (rays, quads, insts, leaves, tris)] -> bytes [depth, 2]"""
+    c = counters.astype("float64")
+    return c[..., 0] * (36 + 16) + c[..., 1] * 128 + c[..., 2] * 128 + c[..., 3] * 16 + c[..., 4] * 48
+
+
+def cpu_baseline(scene, depth, budget_s=15.0):
+    """the CPU oracle (kind "port") on a bounded sample of the same workload: a 320x180 frame of the same scene and
+    depth, as many spp as fit the budget, OpenMP over all host cores"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hydracore_amd import HostScene
+    from oracle_lib import Oracle
+    w, h = 320, 180
+    sc = HostScene(scene, w, h, trace_depth=depth, enable_dof=0, use_hip=False)
+    orc = Oracle(sc.buffers())
+    gens = orc.init_generators(777)
+    t0 = time.time()
+    img, rays, gens = orc.render(1, gens=gens)
+    one = time.time() - t0
+    spp = max(1, min(64, int(budget_s / max(one, 1e-3)) - 1))
+    t0 = time.time()
+    img, rays, gens = orc.render(spp, gens=gens, image=img, spp_done=1)
+    dt = time.time() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": orc.max_threads(), "kind": "port",
+            "sample": "%dx%d, %d bounces, %d spp of the same scene (%d rays, %.1f s); CPU oracle, own BVH4 walk (the stock "
+                      "reference CPU layer traces through Embree 2.17, absent here)" % (w, h, depth, spp, rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--trace-depth", type=int, default=8)
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "test_224"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from hydracore_amd import HostScene
+    from hydracore_amd.multi_gpu import all_reduce_max, all_reduce_scalar, reduce_accumulator
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h, depth = args.width, args.height, args.trace_depth
+    sc = HostScene(args.scene, w, h, trace_depth=depth, enable_dof=0, use_hip=True, device=local_rank, seed=777)
+    if sc.unsupported():
+        raise SystemExit("bench.py: scene uses features outside the HIP layer's subset:\n" + sc.log())
+    core = sc.hip()
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)       # SetExternalImageAccumulator: reduced over RCCL
+    core.set_external_accumulator(accum.data_ptr(), accum.numel() * 4)
+    core.set_tile_partition(rank, world, args.tile)
+    sc.draw(passes=1, spp=1)          # first Draw: camera matrices, globals, InitPathTracing(seed), one pass
+    max_depth = depth + 1
+
+    # algorithmic work per spp (counting kernels, outside the timed region)
+    core.enable_traversal_counters(True)
+    core.trace_pass(1)
+    core.finish()
+    counters = core.traversal_counters(max_depth)
+    core.enable_traversal_counters(False)
+    bytes_per_spp = traversal_bytes(counters)                     # [depth, 2]
+
+    for _ in range(args.warmup):
+        core.trace_pass(args.spp_per_step)
+    core.clear()
+    core.enable_stage_timing(True)
+    core.reset_perf_counters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        core.trace_pass(args.spp_per_step)
+    reduce_accumulator(accum, dst=0)                              # the one RCCL exchange of the frame
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = core.rays_stat()
+    rays_local = int(st.extensionRays + st.shadowRays)
+    rays_total = all_reduce_scalar(rays_local, dev)
+    t_max = all_reduce_max(elapsed, dev)
+    spp_total = args.steps * args.spp_per_step
+    trace_bytes = float(bytes_per_spp[:, 0].sum()) * spp_total    # closest-hit launches of this rank in the timed region
+    trace_s = st.traversalTimeMs * 1e-3
+    achieved = trace_bytes / trace_s / 1e9 if trace_s > 0 else 0.0
+
+    if rank == 0:
+        img = accum.cpu().numpy() / float(spp_total)
+        assert np.isfinite(img).all()
+        result = {
+            "metric": "Mrays/s at 1080p, 8 bounces, 256 spp; 1/2/4/8 GPUs + % HBM roofline",
+            "value": rays_total / t_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: Cornell-box-style test scene (reference hydra_app/tests/test_224, 25.6k-tri teapot), "
+                                   "%dx%d, %d bounces, %d spp, PT (MIS) integrator" % (w, h, depth, spp_total),
+                       "spp_per_step": args.spp_per_step, "tile": args.tile, "partition": "image tiles, t %% %d" % world,
+                       "rays": int(rays_total), "mean_radiance": float(img[..., :3].mean())},
+            "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit BVH4 traversal)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(st.traceLaunches), "avg_launch_ms": st.traversalTimeMs / max(int(st.traceLaunches), 1),
+                         "algorithmic_bytes_per_launch": trace_bytes / max(int(st.traceLaunches), 1)},
+            "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "hit_light_sample": st.evalHitMs, "shadow": st.shadowTimeMs,
+                         "shade_next_bounce": st.shadeTimeMs, "accumulate": st.accumTimeMs, "pass_total": st.passTimeMs},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.scene, depth)
+        print(json.dumps(result))
+    sc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

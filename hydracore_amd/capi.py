@@ -24,7 +24,8 @@ class RaysStat(C.Structure):         # HydraRaysStat
                 ("shadowTimeMs", C.c_float), ("shadeTimeMs", C.c_float), ("bounceTimeMs", C.c_float),
                 ("evalHitMs", C.c_float), ("nextBounceMs", C.c_float), ("raygenTimeMs", C.c_float),
                 ("accumTimeMs", C.c_float), ("passTimeMs", C.c_float), ("traceTimePerCent", C.c_int32),
-                ("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("samples", C.c_uint64)]
+                ("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("samples", C.c_uint64),
+                ("traceLaunches", C.c_uint64), ("shadowLaunches", C.c_uint64)]
 
 
 LITE_HIT_DTYPE = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
@@ -37,7 +38,8 @@ C_ABI_SYMBOLS = [
     "hydra_hip_upload_remap_lists", "hydra_hip_set_tile_partition", "hydra_hip_set_external_accumulator",
     "hydra_hip_init_path_tracing", "hydra_hip_clear_accumulated_color", "hydra_hip_trace_pass", "hydra_hip_set_spp",
     "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_rays_stat",
-    "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_stage_make_eye_rays",
+    "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_enable_traversal_counters",
+    "hydra_hip_get_traversal_counters", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
     "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
 ]
@@ -84,6 +86,8 @@ def load_hip_library():
         "hydra_hip_get_rays_stat": ([vp, C.POINTER(RaysStat)], i32),
         "hydra_hip_reset_perf_counters": ([vp], i32),
         "hydra_hip_enable_stage_timing": ([vp, i32], i32),
+        "hydra_hip_enable_traversal_counters": ([vp, i32], i32),
+        "hydra_hip_get_traversal_counters": ([vp, vp, i32], i32),
         "hydra_hip_stage_make_eye_rays": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
@@ -244,6 +248,15 @@ class HipCore:
 
     def enable_stage_timing(self, on=True):
         self._ck(self.lib.hydra_hip_enable_stage_timing(self.h, 1 if on else 0), "enable_stage_timing")
+
+    def enable_traversal_counters(self, on=True):
+        self._ck(self.lib.hydra_hip_enable_traversal_counters(self.h, 1 if on else 0), "enable_traversal_counters")
+
+    def traversal_counters(self, max_depth):
+        """uint64 [max_depth, 2 (closest|shadow), 5 (rays, quads, insts, leaves, tris)]"""
+        out = np.zeros((max_depth, 2, 5), np.uint64)
+        self._ck(self.lib.hydra_hip_get_traversal_counters(self.h, _ptr(out), max_depth), "get_traversal_counters")
+        return out
 
     # ---- stage entry points
     def stage_random(self, seeds, draws):

@@ -18,7 +18,7 @@
 #define HK_LDS_DEPTH 24
 #define HK_TRACE_BLOCK 128
 
-struct TravCounters { uint32_t quads, insts, tris; };
+struct TravCounters { uint32_t quads, insts, tris, leaves; };
 
 HK_DEV f3 SafeInverse(f3 d) {   // hydra_drv/cglobals.h:726-735
   const float ooeps = 1.0e-36f;
@@ -58,7 +58,7 @@ HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float
   const float4 hdr = tris[leaf_offset];
   const int first = as_int(hdr.x), count = as_int(hdr.y);
   const int end = first + count * 3;
-  if (COUNT) cnt.tris += uint32_t(count);
+  if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; }
   for (int a = first; a < end; a += 3) {
     const float4 d1 = tris[a], d2 = tris[a + 1], d3 = tris[a + 2];
     const f3 A = xyz(d1), B = xyz(d2), C = xyz(d3);

@@ -75,7 +75,8 @@ __global__ void k_raygen(SceneDev s, int n, const int* __restrict__ slotPixel, c
 template <bool COUNT>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
                                                            const float4* __restrict__ pos4, const float4* __restrict__ dir4,
-                                                           HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3) {
+                                                           HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3,
+                                                           unsigned long long* __restrict__ totals5) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
   const int count = countPtr ? int(*countPtr) : countImm;
   HkStack st;
@@ -83,16 +84,22 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint
   st.stride = HK_TRACE_BLOCK;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
-    TravCounters c = {0, 0, 0};
+    TravCounters c = {0, 0, 0, 0};
     const HydraLiteHit hit = hk_traverse<false, COUNT>(s.bvh, s.tris, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
     reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
-    if (COUNT) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
+    if (COUNT && counters3) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
+    if (COUNT && totals5) {   // algorithmic-work counters for the roofline byte model
+      atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
+      atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+    }
   }
 }
 
 // T2 -- any-hit visibility: origin xyz | t_far, direction xyz (kernel_ShadowTrace)
+template <bool COUNT>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
-                                                            const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis) {
+                                                            const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis,
+                                                            unsigned long long* __restrict__ totals5) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
   const int count = countPtr ? int(*countPtr) : countImm;
   HkStack st;
@@ -104,9 +111,13 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uin
     if (o.w >= 0.0f) {   // t_far < 0 marks "no light sample": shadow = 0 (PT_Loop.cpp:175-178)
       HydraLiteHit h = hk_miss_hit();
       h.t = o.w;
-      TravCounters c = {0, 0, 0};
-      h = hk_traverse<true, false>(s.bvh, s.tris, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
+      TravCounters c = {0, 0, 0, 0};
+      h = hk_traverse<true, COUNT>(s.bvh, s.tris, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
       v = (h.primId != -1) ? 0.0f : 1.0f;
+      if (COUNT && totals5) {
+        atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
+        atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+      }
     }
     vis[i] = v;
   }
@@ -306,7 +317,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_stage_path(SceneDev s, int n
   HkStack st;
   st.lds = ldsStack + threadIdx.x;
   st.stride = HK_TRACE_BLOCK;
-  TravCounters tc = {0, 0, 0};
+  TravCounters tc = {0, 0, 0, 0};
   f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
   RandomGen gen; gen.x = rng2[i].x; gen.y = rng2[i].y;
   f3 accumColor = mk3(0, 0, 0), thr = mk3(1, 1, 1), currColor = mk3(0, 0, 0);
@@ -415,11 +426,15 @@ struct hydra_hip_ctx {
   float spp = 0.0f;
 
   bool stageTiming = false;
+  bool travCounters = false;
+  DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris]
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
+  uint64_t nTrace = 0, nShadow = 0;   // launches folded into tTrace / tShadow
   std::vector<hipEvent_t> evPool;
   struct EvSpan { int a, b, kind; };
   std::vector<EvSpan> spans;
+  size_t evCursor = 0;
 };
 
 static std::string g_createError;
@@ -560,7 +575,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   (void)hipDeviceSynchronize();
   DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->mDir, &c->mThr, &c->mAcc,
-                   &c->mRng, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
+                   &c->mRng, &c->travTotals, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
   for (auto& b : c->bvhNodes) dev_free(b);
@@ -705,6 +720,21 @@ int hydra_hip_clear_accumulated_color(hydra_hip_handle c) {
   return HYDRA_HIP_OK;
 }
 
+// resolve the recorded stage events into per-stage totals (needs the stream to be idle => one sync)
+static int fold_stage_events(hydra_hip_ctx* c) {
+  if (c->spans.empty()) { c->evCursor = 0; return HYDRA_HIP_OK; }
+  HCHECK(hipStreamSynchronize(c->stream));
+  for (const auto& sp : c->spans) {
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, c->evPool[sp.a], c->evPool[sp.b]);
+    switch (sp.kind) { case 0: c->tRaygen += ms; break; case 1: c->tTrace += ms; c->nTrace++; break; case 2: c->tHit += ms; break; case 3: c->tShadow += ms; c->nShadow++; break;
+                       case 4: c->tShade += ms; break; case 5: c->tAccum += ms; break; default: c->tPass += ms; break; }
+  }
+  c->spans.clear();
+  c->evCursor = 0;
+  return HYDRA_HIP_OK;
+}
+
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor) {
   if (cursor >= c->evPool.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->evPool.push_back(e); }
   return c->evPool[cursor++];
@@ -731,10 +761,8 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   HydraLiteHit* hits = static_cast<HydraLiteHit*>(c->hits.p);
   const int N = c->N;
   const int gTrace = grid_for(c, N, HK_TRACE_BLOCK, 16), gWide = grid_for(c, N, 256, 8);
-  size_t evCursor = 0;
   const bool timing = c->stageTiming;
-  if (timing) c->spans.clear();
-  auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, evCursor); (void)hipEventRecord(e, c->stream); return int(evCursor) - 1; };
+  auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
 
   for (int sub = 0; sub < spp; sub++) {
     HCHECK(hipMemsetAsync(live, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
@@ -746,13 +774,16 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     if (timing) c->spans.push_back({e0, e1, 0});
     for (int depth = 0; depth < maxDepth; depth++) {
       int a = mark();
-      hipLaunchKernelGGL(k_trace<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr));
+      unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
+      if (tt) hipLaunchKernelGGL(k_trace<true>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr), tt);
+      else hipLaunchKernelGGL(k_trace<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr), tt);
       int b = mark();
       hipLaunchKernelGGL(k_hit, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M,
                          static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p));
       int d = mark();
       if (depth + 1 < maxDepth) {
-        hipLaunchKernelGGL(k_shadow, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis);
+        if (tt) hipLaunchKernelGGL(k_shadow<true>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis, tt + 5);
+        else hipLaunchKernelGGL(k_shadow<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis, tt);
         int e = mark();
         hipLaunchKernelGGL(k_shade, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S);
         int f = mark();
@@ -766,17 +797,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     int g1 = mark();
     if (timing) { c->spans.push_back({g0, g1, 5}); c->spans.push_back({e0, g1, 6}); }
     HCHECK(hipGetLastError());
-    if (timing) {   // fold this sub-pass's events into the stage totals (one sync per sub-pass, only in timing mode)
-      HCHECK(hipStreamSynchronize(c->stream));
-      for (const auto& sp : c->spans) {
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, c->evPool[sp.a], c->evPool[sp.b]);
-        switch (sp.kind) { case 0: c->tRaygen += ms; break; case 1: c->tTrace += ms; break; case 2: c->tHit += ms; break; case 3: c->tShadow += ms; break;
-                           case 4: c->tShade += ms; break; case 5: c->tAccum += ms; break; default: c->tPass += ms; break; }
-      }
-      c->spans.clear();
-      evCursor = 0;
-    }
+    if (timing && c->evCursor > 200000) { int rc = fold_stage_events(c); if (rc) return rc; }   // bound the event pool
   }
   c->spp += float(spp);
   return HYDRA_HIP_OK;
@@ -817,6 +838,7 @@ int hydra_hip_get_rays_stat(hydra_hip_handle c, HydraRaysStat* out) {
   if (!c || !out) return HYDRA_HIP_EINVAL;
   memset(out, 0, sizeof(*out));
   HCHECK(hipSetDevice(c->device));
+  { int rc = fold_stage_events(c); if (rc) return rc; }
   if (c->totals.p) {
     unsigned long long t[4] = {0, 0, 0, 0};
     HCHECK(hipMemcpy(t, c->totals.p, 32, hipMemcpyDeviceToHost));
@@ -824,7 +846,8 @@ int hydra_hip_get_rays_stat(hydra_hip_handle c, HydraRaysStat* out) {
   }
   out->raygenTimeMs = float(c->tRaygen); out->traversalTimeMs = float(c->tTrace); out->evalHitMs = float(c->tHit);
   out->samLightTimeMs = float(c->tHit); out->shadowTimeMs = float(c->tShadow); out->shadeTimeMs = float(c->tShade); out->nextBounceMs = float(c->tShade);
-  out->accumTimeMs = float(c->tAccum); out->passTimeMs = float(c->tPass); out->bounceTimeMs = float(c->tTrace + c->tHit + c->tShadow + c->tShade);
+  out->accumTimeMs = float(c->tAccum); out->passTimeMs = float(c->tPass);
+  out->traceLaunches = c->nTrace; out->shadowLaunches = c->nShadow; out->bounceTimeMs = float(c->tTrace + c->tHit + c->tShadow + c->tShade);
   if (c->tPass > 0) {
     out->traceTimePerCent = int(100.0 * (c->tTrace + c->tShadow) / c->tPass);
     out->raysPerSec = float(double(out->extensionRays + out->shadowRays) / (c->tPass * 1e-3));
@@ -833,8 +856,28 @@ int hydra_hip_get_rays_stat(hydra_hip_handle c, HydraRaysStat* out) {
 }
 int hydra_hip_reset_perf_counters(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
+  { int rc = fold_stage_events(c); if (rc) return rc; }
   c->tTrace = c->tHit = c->tShadow = c->tShade = c->tRaygen = c->tAccum = c->tPass = 0;
+  c->nTrace = c->nShadow = 0;
   if (c->totals.p) { HCHECK(hipSetDevice(c->device)); HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream)); }
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_enable_traversal_counters(hydra_hip_handle c, int enable) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  if (enable) {
+    int rc = dev_alloc(c, c->travTotals, size_t(HK_MAX_DEPTH) * 10 * 8);
+    if (rc) return rc;
+    HCHECK(hipMemsetAsync(c->travTotals.p, 0, size_t(HK_MAX_DEPTH) * 10 * 8, c->stream));
+  }
+  c->travCounters = (enable != 0);
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_get_traversal_counters(hydra_hip_handle c, uint64_t* out, int max_depth) {
+  if (!c || !out || max_depth < 1 || max_depth > HK_MAX_DEPTH) return HYDRA_HIP_EINVAL;
+  if (!c->travTotals.p) return fail(c, HYDRA_HIP_ESTATE, "get_traversal_counters: enable_traversal_counters first");
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipMemcpy(out, c->travTotals.p, size_t(max_depth) * 10 * 8, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 int hydra_hip_enable_stage_timing(hydra_hip_handle c, int enable) { if (!c) return HYDRA_HIP_EINVAL; c->stageTiming = (enable != 0); return HYDRA_HIP_OK; }
@@ -886,8 +929,9 @@ int hydra_hip_stage_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   if (rc) return rc;
   SceneDev s = make_scene(c);
   const int g = grid_for(c, n, HK_TRACE_BLOCK, 16);
-  if (counters3) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc);
-  else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc);
+  unsigned long long* noTotals = nullptr;
+  if (counters3) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc, noTotals);
+  else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc, noTotals);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(hits, dh, size_t(n) * 16, hipMemcpyDeviceToHost));
   if (counters3) HCHECK(hipMemcpy(counters3, dc, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -903,7 +947,8 @@ int hydra_hip_stage_shadow_trace(hydra_hip_handle c, int n, const float* ray_pos
   float* dv = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
   if (rc) return rc;
   SceneDev s = make_scene(c);
-  hipLaunchKernelGGL(k_shadow, dim3(grid_for(c, n, HK_TRACE_BLOCK, 16)), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dorg, ddir, dv);
+  hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(c, n, HK_TRACE_BLOCK, 16)), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dorg, ddir, dv,
+                     static_cast<unsigned long long*>(nullptr));
   STAGE_EPILOG();
   HCHECK(hipMemcpy(visibility, dv, size_t(n) * 4, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
@@ -967,8 +1012,10 @@ int hydra_hip_bench_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   HCHECK(hipEventCreate(&e0));
   HCHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (shadow) hipLaunchKernelGGL(k_shadow, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, reinterpret_cast<float*>(dh));
-    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, static_cast<uint32_t*>(nullptr));
+    if (shadow) hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, reinterpret_cast<float*>(dh),
+                                   static_cast<unsigned long long*>(nullptr));
+    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, static_cast<uint32_t*>(nullptr),
+                            static_cast<unsigned long long*>(nullptr));
   };
   launch();   // warm-up
   HCHECK(hipEventRecord(e0, c->stream));

@@ -93,8 +93,13 @@ int hydra_hip_get_ldr_image(hydra_hip_handle h, uint32_t* rgba8, int width, int 
 /* IHWLayer::GetRaysStat / ResetPerfCounters (:145,155): per-stage HIP-event times and exact ray counters */
 int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
 int hydra_hip_reset_perf_counters(hydra_hip_handle h);
-/* enable per-stage hipEvent timing inside trace_pass (adds event records, no syncs) */
+/* enable per-stage hipEvent timing inside trace_pass (event records only; they are resolved by get_rays_stat) */
 int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
+/* algorithmic-work counters of the traversal kernels (roofline byte model).  While enabled, trace_pass
+ * uses the counting kernel variants (slower).  out = max_depth x 2 x 5 uint64:
+ * [bounce][0 = closest-hit | 1 = shadow][rays, quads visited, instance quads entered, leaves visited, triangles tested] */
+int hydra_hip_enable_traversal_counters(hydra_hip_handle h, int enable);
+int hydra_hip_get_traversal_counters(hydra_hip_handle h, uint64_t* out, int max_depth);
 
 /* ---------------------------------------------------------------- stage entry points
  * One call = one wavefront kernel over n host-provided items; used by the parity tests and by the

@@ -183,6 +183,7 @@ typedef struct HydraRaysStat {
   float raygenTimeMs, accumTimeMs, passTimeMs;
   int32_t traceTimePerCent;
   uint64_t extensionRays, shadowRays, samples;
+  uint64_t traceLaunches, shadowLaunches;   /* kernel launches behind traversalTimeMs / shadowTimeMs */
 } HydraRaysStat;
 
 #ifdef __cplusplus

@@ -1,0 +1,265 @@
+/* ref_driver.cl -- kernel entry points (ours) around the REFERENCE's own inline functions.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file contains no reference code: it #includes the reference headers where they lie
+ * (/root/reference/hydra_drv/c*.h, their OpenCL branch, -D OCL_COMPILER) and calls their functions, the same way the
+ * reference's shaders/*.cl do.  oracle/build_ref.sh compiles it with the image's clang for gfx950 into
+ * oracle/_ref/ref_driver.hsaco (git-ignored; travels to the GPU box as a built binary, the sources do not).
+ * tests/golden/make_golden.py launches these kernels through the HIP module API and stores the outputs as golden
+ * vectors that pin the CPU oracle.
+ *
+ * The per-path loop below mirrors IntegratorMISPTLoop2::PathTrace (hydra_drv/CPUExp_Integrators_PT_Loop.cpp:264-321,
+ * C++ class code that cannot be compiled as OpenCL) stage by stage; every stage body is a call into reference code.
+ */
+#include "cglobals.h"
+#include "cfetch.h"
+#include "crandom.h"
+#include "ctrace.h"
+#include "cmaterial.h"
+#include "clight.h"
+#include "cbidir.h"
+
+__kernel void ref_random(__global const int* seeds, int draws, __global float4* out4, __global uint2* state2, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  RandomGen gen = RandomGenInit(seeds[i]);
+  for (int d = 0; d < draws; d++)
+    out4[i * draws + d] = rndFloat4_Pseudo(&gen);
+  state2[i] = gen.state;
+}
+
+__kernel void ref_make_eye_rays(__global const int2* xy, __global const float4* offs, __global const EngineGlobals* a_globals,
+                                int w, int h, __global float4* pos4, __global float4* dir4, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  float3 p, d;
+  MakeRandEyeRay(xy[i].x, xy[i].y, w, h, offs[i], a_globals, &p, &d);
+  pos4[i] = to_float4(p, 0.0f);
+  dir4[i] = to_float4(d, 0.0f);
+}
+
+/* IntegratorCommon::rayTrace, CPUExp_Integrators_Common.cpp:122-154 (tree 0) */
+static inline Lite_Hit ref_rayTrace(float3 pos, float3 dir, __global const float4* bvh, __global const float4* tris, int haveInst)
+{
+  Lite_Hit hit = Make_Lite_Hit(MAXFLOAT, -1);
+  if (haveInst)
+    hit = BVH4InstTraverse(pos, dir, 0.0f, hit, bvh, tris);
+  else
+    hit = BVH4Traverse(pos, dir, 0.0f, hit, bvh, tris);
+  return hit;
+}
+
+__kernel void ref_trace(__global const float4* pos4, __global const float4* dir4, __global const float4* bvh, __global const float4* tris,
+                        __global Lite_Hit* hits, int haveInst, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  hits[i] = ref_rayTrace(to_float3(pos4[i]), to_float3(dir4[i]), bvh, tris, haveInst);
+}
+
+/* kernel_EvalSurface, CPUExp_Integrators_PT_Loop.cpp:35-84 */
+static inline SurfaceHit ref_evalSurface(float3 ray_pos, float3 ray_dir, Lite_Hit hit, __global const float4* in_matrices,
+                                         __global const float4* in_geomStorage, __global const EngineGlobals* a_globals)
+{
+  const float4x4 instanceMatrixInv = fetchMatrix(hit, in_matrices);
+  const float3 rayPosLS = mul4x3(instanceMatrixInv, ray_pos);
+  const float3 rayDirLS = mul3x3(instanceMatrixInv, ray_dir);
+  __global const PlainMesh* mesh = fetchMeshHeader(hit, in_geomStorage, a_globals);
+  const SurfaceHit surfHit = surfaceEvalLS(rayPosLS, rayDirLS, hit, mesh);
+  const float4x4 instanceMatrix = inverse4x4(instanceMatrixInv);
+  SurfaceHit surfHitWS = surfHit;
+  const float multInv = 1.0f / sqrt(3.0f);
+  const float3 shadowStartPos = mul3x3(instanceMatrix, make_float3(multInv*surfHitWS.sRayOff, multInv*surfHitWS.sRayOff, multInv*surfHitWS.sRayOff));
+  const float4x4 normalMatrix = transpose(instanceMatrixInv);
+  surfHitWS.pos        = mul4x3(instanceMatrix, surfHit.pos);
+  surfHitWS.normal     = normalize(mul3x3(normalMatrix, surfHit.normal));
+  surfHitWS.flatNormal = normalize(mul3x3(normalMatrix, surfHit.flatNormal));
+  surfHitWS.tangent    = normalize(mul3x3(normalMatrix, surfHit.tangent));
+  surfHitWS.biTangent  = normalize(mul3x3(normalMatrix, surfHit.biTangent));
+  surfHitWS.t          = length(surfHitWS.pos - ray_pos);
+  surfHitWS.sRayOff    = length(shadowStartPos);
+  surfHitWS.texCoordCamProj = make_float2(0.0f, 0.0f);
+  return surfHitWS;   /* no remap lists in the fixtures: remapMaterialId returns the id unchanged for a null table */
+}
+
+__kernel void ref_eval_surface(__global const float4* pos4, __global const float4* dir4, __global const Lite_Hit* hits,
+                               __global const float4* in_matrices, __global const float4* in_geomStorage,
+                               __global const EngineGlobals* a_globals, __global float* out24, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global float* r = out24 + i * 24;
+  for (int k = 0; k < 24; k++) r[k] = 0.0f;
+  const Lite_Hit hit = hits[i];
+  if (HitNone(hit)) { r[17] = as_float(-1); return; }
+  const SurfaceHit sh = ref_evalSurface(to_float3(pos4[i]), to_float3(dir4[i]), hit, in_matrices, in_geomStorage, a_globals);
+  r[0] = sh.pos.x; r[1] = sh.pos.y; r[2] = sh.pos.z; r[3] = sh.normal.x; r[4] = sh.normal.y; r[5] = sh.normal.z;
+  r[6] = sh.flatNormal.x; r[7] = sh.flatNormal.y; r[8] = sh.flatNormal.z; r[9] = sh.tangent.x; r[10] = sh.tangent.y; r[11] = sh.tangent.z;
+  r[12] = sh.biTangent.x; r[13] = sh.biTangent.y; r[14] = sh.biTangent.z; r[15] = sh.texCoord.x; r[16] = sh.texCoord.y;
+  r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
+}
+
+/* IntegratorMISPTLoop2::PathTrace: the stage order of PT_Loop.cpp:264-321 with the reference's functions as bodies */
+__kernel void ref_path_trace(__global const float4* pos4, __global const float4* dir4, __global uint2* rng2,
+                             __global const float4* bvh, __global const float4* tris, int haveInst,
+                             __global const float4* in_matrices, __global const int* instLightInstId,
+                             __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
+                             __global const int4* in_texStorage, __global const float4* in_pdfStorage,
+                             __global const EngineGlobals* a_globals, __global float4* color4, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+
+  float3 ray_pos = to_float3(pos4[i]);
+  float3 ray_dir = to_float3(dir4[i]);
+  RandomGen gen;
+  gen.state = rng2[i];
+
+  float3 accumColor        = make_float3(0, 0, 0);
+  float3 accumuThoroughput = make_float3(1, 1, 1);
+  float3 currColor         = make_float3(0, 0, 0);
+  MisData misPrev          = makeInitialMisData();
+  uint flags               = 0;
+  float rays               = 0.0f;
+  const int maxDepth       = a_globals->varsI[HRT_TRACE_DEPTH];
+
+  for (int depth = 0; depth < maxDepth; depth++)
+  {
+    /* kernel_RayTrace */
+    const Lite_Hit hit = ref_rayTrace(ray_pos, ray_dir, bvh, tris, haveInst);
+    rays += 1.0f;
+
+    /* kernel_HitEnvironment */
+    if (HitNone(hit))
+    {
+      currColor = environmentColor(ray_dir, misPrev, flags, a_globals, in_mtlStorage, in_pdfStorage, in_texStorage);
+      break;
+    }
+
+    /* kernel_EvalSurface */
+    const SurfaceHit surfElem = ref_evalSurface(ray_pos, ray_dir, hit, in_matrices, in_geomStorage, a_globals);
+    __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, surfElem.matId);
+
+    /* kernel_EvalEmission */
+    {
+      const int lightOffset0 = instLightInstId[hit.instId];
+      __global const PlainLight* pLightHit = lightAt(a_globals, lightOffset0);
+      ProcTextureList ptl;
+      InitProcTextureList(&ptl);
+      const float3 emission = emissionEval(ray_pos, ray_dir, &surfElem, flags, (misPrev.isSpecular == 1), pLightHit, pHitMaterial,
+                                           in_texStorage, in_pdfStorage, a_globals, &ptl);
+      if (dot(emission, emission) > 1e-3f)
+      {
+        __global const PlainLight* pLight = 0;
+        if (a_globals->lightsNum != 0 && lightOffset0 >= 0)
+          pLight = lightAt(a_globals, lightOffset0);
+        if (pLight != 0)
+        {
+          const float lgtPdf  = lightPdfSelectRev(pLight)*lightEvalPDF(pLight, ray_pos, ray_dir, surfElem.pos, surfElem.normal, surfElem.texCoord, in_pdfStorage, a_globals);
+          const float bsdfPdf = misPrev.matSamplePdf;
+          float misWeight     = misWeightHeuristic(bsdfPdf, lgtPdf);
+          if (misPrev.isSpecular)
+            misWeight = 1.0f;
+          currColor = emission*misWeight;
+        }
+        else
+          currColor = emission;
+        break;
+      }
+      else if (depth >= maxDepth - 1)
+      {
+        currColor = make_float3(0, 0, 0);
+        break;
+      }
+    }
+
+    /* kernel_LightSelect */
+    const float4 rndLightData = rndLight(&gen, depth, a_globals->rmQMC, 0, 0);
+    float lightPickProb = 1.0f;
+    const int lightOffset = SelectRandomLightRev(rndLightData.z, surfElem.pos, a_globals, &lightPickProb);
+
+    /* kernel_LightSample */
+    float3 shadowRayPos = make_float3(0, 0, 0), shadowRayDir = make_float3(0, 0, 0);
+    ShadowSample explicitSam;
+    explicitSam.pos = make_float3(0, 0, 0); explicitSam.color = make_float3(0, 0, 0); explicitSam.pdf = 0.0f;
+    explicitSam.maxDist = 0.0f; explicitSam.cosAtLight = 0.0f; explicitSam.isPoint = false;
+    if (lightOffset >= 0)
+    {
+      __global const PlainLight* pLight = lightAt(a_globals, lightOffset);
+      LightSampleRev(pLight, to_float3(rndLightData), surfElem.pos, a_globals, in_pdfStorage, in_texStorage, &explicitSam);
+      shadowRayDir = normalize(explicitSam.pos - surfElem.pos);
+      shadowRayPos = OffsShadowRayPos(surfElem.pos, surfElem.normal, shadowRayDir, surfElem.sRayOff);
+    }
+
+    /* kernel_ShadowTrace: IntegratorCommon::shadowTrace, Common.cpp:156-180 */
+    float3 shadow = make_float3(0, 0, 0);
+    if (lightOffset >= 0)
+    {
+      const float t_far = length(shadowRayPos - explicitSam.pos)*0.995f;
+      const Lite_Hit sh = ref_rayTrace(shadowRayPos, shadowRayDir, bvh, tris, haveInst);
+      rays += 1.0f;
+      shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
+    }
+
+    /* kernel_Shade */
+    float3 explicitColor = make_float3(0, 0, 0);
+    if (lightOffset >= 0)
+    {
+      ShadeContext sc;
+      sc.wp = surfElem.pos;
+      sc.l  = shadowRayDir;
+      sc.v  = (-1.0f)*ray_dir;
+      sc.n  = surfElem.normal;
+      sc.fn = surfElem.flatNormal;
+      sc.tg = surfElem.tangent;
+      sc.bn = surfElem.biTangent;
+      sc.tc = surfElem.texCoord;
+      sc.tccp = surfElem.texCoordCamProj;
+      sc.hfi = surfElem.hfi;
+      ProcTextureList ptlCopy;
+      InitProcTextureList(&ptlCopy);
+      GetProcTexturesIdListFromMaterialHead(pHitMaterial, &ptlCopy);
+      const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlCopy);
+
+      const float cosThetaOut1 = fmax(+dot(shadowRayDir, surfElem.normal), 0.0f);
+      const float cosThetaOut2 = fmax(-dot(shadowRayDir, surfElem.normal), 0.0f);
+      const float3 bxdfVal     = (evalData.brdf*cosThetaOut1 + evalData.btdf*cosThetaOut2);
+      const float lgtPdf       = explicitSam.pdf*lightPickProb;
+      float misWeight = misWeightHeuristic(lgtPdf, evalData.pdfFwd);
+      if (explicitSam.isPoint)
+        misWeight = 1.0f;
+      explicitColor = (1.0f / lightPickProb)*(explicitSam.color * (1.0f / fmax(explicitSam.pdf, DEPSILON2)))*bxdfVal*misWeight*shadow;
+    }
+
+    /* kernel_NextBounce */
+    {
+      const int rayBounceNum = unpackBounceNum(flags);
+      float allRands[MMLT_FLOATS_PER_BOUNCE];
+      RndMatAll(&gen, 0, rayBounceNum, a_globals->rmQMC, 0, 0, allRands);
+
+      ProcTextureList ptlDummy;
+      InitProcTextureList(&ptlDummy);
+      MatSample matSam; int matOffset;
+      MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), flags, false,
+                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+
+      const float3 bxdfVal = matSam.color * (1.0f / fmax(matSam.pdf, 1e-20f));
+      const float cosTheta = fabs(dot(matSam.direction, surfElem.normal));
+
+      ray_dir              = matSam.direction;
+      ray_pos              = OffsRayPos(surfElem.pos, surfElem.normal, matSam.direction);
+      misPrev              = makeInitialMisData();
+      misPrev.isSpecular   = isPureSpecular(matSam);
+      misPrev.matSamplePdf = matSam.pdf;
+      flags                = flagsNextBounceLite(flags, matSam, a_globals);
+
+      accumColor        += accumuThoroughput*explicitColor;
+      accumuThoroughput *= cosTheta*bxdfVal;
+    }
+  }
+
+  accumColor += accumuThoroughput*currColor;   /* kernel_AddLastBouceContrib */
+  color4[i] = to_float4(accumColor, rays);
+  rng2[i]   = gen.state;
+}

@@ -1,0 +1,190 @@
+"""CPU: the scene front end packs buffers with the reference's layouts, and the BVH4 builder emits a valid tree."""
+import numpy as np
+
+from conftest import make_oracle, random_rays
+
+G_LIGHTS_OFFS, G_LIGHTS_NUM, G_MAT_TABLE, G_GEOM_TABLE, G_TEX_TABLE, G_LSEL_REV_SIZE = 236, 238, 219, 221, 218, 231
+G_VARS_I, G_VARS_F, G_FLAGS, G_SKY = 64, 128, 234, 235
+
+
+def test_globals_blob_layout(t224_small):
+    _, b = t224_small
+    g = b["globals"]
+    gf = g.view(np.float32)
+    assert g.size >= 134400 and g[G_MAT_TABLE] == 134400            # header rounded up to 16 words
+    assert g[G_LIGHTS_NUM] == 2 and g[G_SKY] == -1
+    assert g[G_VARS_I + 9] == 5                                      # HRT_TRACE_DEPTH = trace_depth + 1
+    assert g[G_FLAGS] & 32 and g[G_FLAGS] & 1                        # HRT_USE_MIS | HRT_COMPUTE_SHADOWS
+    assert g[G_LSEL_REV_SIZE] == 3                                   # prefix sums of 2 lights
+    assert abs(gf[G_VARS_F + 14] - np.deg2rad(45.0)) < 1e-6          # HRT_CAM_FOV
+    assert (g[192:208] == -1).all()                                  # rmQMC
+    lights = gf[g[G_LIGHTS_OFFS]:g[G_LIGHTS_OFFS] + 256].reshape(2, 128)
+    assert (lights[:, 0].view(np.int32) == 4).all()                  # PLAIN_LIGHT_TYPE_AREA
+    np.testing.assert_allclose(lights[:, 8:11], 160.0)               # colour x multiplier
+    np.testing.assert_allclose(lights[:, 14:16], [[0.25, 0.5]] * 2)  # half sizes
+    np.testing.assert_allclose(lights[:, 13], 0.5, rtol=1e-5)        # area of a 0.5 x 1 rectangle
+    np.testing.assert_allclose(lights[:, 107], 0.5)                  # normalised pick probability
+    np.testing.assert_allclose(lights[1, 2:5], [3.75, 3.95, -3.5])   # instance translation
+    np.testing.assert_allclose(lights[1, 5:8], [0, -1, 0])
+
+
+def test_material_arena(t224_small):
+    _, b = t224_small
+    g, m = b["globals"], b["materials"].reshape(-1, 192)
+    table = g[g[G_MAT_TABLE]:g[G_MAT_TABLE] + 12]
+    mi = m.view(np.int32)
+    assert table[11] == 0 and mi[0, 0] == 7                          # white diffuse dummy first in the arena
+    blend = table[1] * 4 // 192                                      # material 1: blend(phong, lambert)
+    assert mi[blend, 0] == 9 and mi[blend, 16] == 1 and mi[blend, 17] == 2
+    assert mi[blend + 1, 0] == 0 and mi[blend + 2, 0] == 7
+    assert mi[blend, 15] == (4 | 8)                                  # REFLECTION_WEIGHT_IS_ONE | EXTRUSION_STRONG
+    assert mi[blend, 1] & 2                                          # caustics flag popped up from the phong child
+    np.testing.assert_allclose(m[blend, 10:13], [0.367059, 0.345882, 0.0], rtol=1e-6)
+    assert mi[blend, 20] == 0 and mi[blend, 19] == -1                # sampler.flags clobbered by FALOFF_SIZE, FALOFF_OFFSET = -1
+    assert abs(m[blend, 21] - 2.2) < 1e-6                            # BLEND_TYPE clobbered by sampler.gamma
+    em = table[10] * 4 // 192
+    assert mi[em, 0] == 10 and mi[em, 9] == 0
+    np.testing.assert_allclose(m[em, 4:7], 160.0)
+    tex = table[0] * 4 // 192                                        # textured lambert: sampler at float 20
+    assert mi[tex, 13] == 2 and mi[tex, 14] == 5 and mi[tex, 22] == 2
+    plain = table[6] * 4 // 192
+    assert mi[plain, 14] == -2 and mi[plain, 13] == -2               # INVALID_TEXTURE
+
+
+def test_geometry_arena(t224_small):
+    _, b = t224_small
+    g, geom = b["globals"], b["geom"]
+    offs = g[g[G_GEOM_TABLE]:g[G_GEOM_TABLE] + 6]
+    hdr = geom.view(np.int32)[offs[1] * 4: offs[1] * 4 + 16]         # box
+    assert hdr[4] == 20 and hdr[7] == 30 and hdr[9] == 10
+    assert hdr[0] == 4 and hdr[1] == 4 + 20 and hdr[10] == 4 + 40    # header is 64 B = 4 float4
+    idx = geom.view(np.int32)[(offs[1] + hdr[3]) * 4:(offs[1] + hdr[3]) * 4 + 30]
+    assert idx.max() == 19
+    mats = geom.view(np.int32)[(offs[1] + hdr[8]) * 4:(offs[1] + hdr[8]) * 4 + 10]
+    assert list(mats) == [6, 6, 7, 7, 8, 8, 8, 9, 9, 9]
+    so = geom[(offs[1] + hdr[13]) * 4:(offs[1] + hdr[13]) * 4 + 10]
+    assert (so == 0).all()                                           # flat polygons: no auxiliary shadow offset
+    thdr = geom.view(np.int32)[offs[0] * 4: offs[0] * 4 + 16]        # teapot: smooth normals => positive offsets
+    tso = geom[(offs[0] + thdr[13]) * 4:(offs[0] + thdr[13]) * 4 + thdr[9]]
+    assert (tso > 0).mean() > 0.9 and tso.max() <= 0.00025 * 2.1
+
+
+def walk_bvh(nodes, tris):
+    """python walk of the flattened layout; returns per mesh the primitive ids found, and checks box nesting"""
+    n = nodes.reshape(-1, 8)
+    ni = n.view(np.int32)
+    found = {}
+    seen_sub = set()
+
+    def leaf(list_off, mesh_check=None):
+        h = tris.view(np.int32)[list_off * 4: list_off * 4 + 4]
+        first, cnt = h[0], h[1]
+        assert first == list_off + 1 and h[2] == -1 and h[3] == -1
+        t = tris[first * 4:(first + cnt * 3) * 4].reshape(cnt, 3, 4)
+        return t
+
+    def sub(node_idx, box_lo, box_hi, mesh):
+        link = int(ni[node_idx, 3]) & 0xFFFFFFFF
+        off = link & 0x7fffffff
+        if link & 0x80000000:
+            t = leaf(off)
+            assert (t[:, :, :3] >= box_lo - 1e-5).all() and (t[:, :, :3] <= box_hi + 1e-5).all()
+            ids = t[:, 0, 3].view(np.int32)
+            assert (t[:, 1, 3].view(np.int32) == mesh).all() and (t[:, 2, 3].view(np.int32) == -1).all()
+            found.setdefault(mesh, []).extend(ids.tolist())
+            return
+        for k in range(4):
+            c = off * 4 + k
+            if ni[c, 3] == -1 and ni[c, 7] == -1:
+                continue
+            lo, hi = n[c, 0:3], n[c, 4:7]
+            assert (lo >= box_lo - 1e-5).all() and (hi <= box_hi + 1e-5).all()
+            sub(c, lo, hi, mesh)
+
+    insts = []
+
+    def top(node_idx):
+        link = int(ni[node_idx, 3]) & 0xFFFFFFFF
+        off = link & 0x7fffffff
+        if link & 0x80000000:                     # instance leaf
+            assert ni[node_idx, 7] == 1
+            q = off * 4
+            inst_id, mesh = int(ni[q + 3, 0]), int(ni[q + 3, 1])
+            insts.append(inst_id)
+            if (int(mesh), int(ni[q, 3])) not in seen_sub:
+                seen_sub.add((int(mesh), int(ni[q, 3])))
+                sub(q, n[q, 0:3], n[q, 4:7], mesh)
+            return
+        for k in range(4):
+            c = off * 4 + k
+            if ni[c, 3] == -1 and ni[c, 7] == -1:
+                continue
+            top(c)
+
+    assert (int(ni[0, 3]) & 0x7fffffff) == 1          # traversal starts at quad 1
+    top(0)
+    return found, insts
+
+
+def test_bvh_layout_and_coverage(t224_small):
+    sc, b = t224_small
+    found, insts = walk_bvh(b["bvh_nodes"], b["bvh_tris"])
+    assert sorted(insts) == [0, 1, 2, 3]
+    assert sorted(found[1]) == list(range(10))                       # box: all 10 triangles, once
+    assert sorted(found[5]) == [0, 1]                                # light quad mesh shared by two instances
+    teapot = found[0]
+    assert len(teapot) == len(set(teapot)) and 25000 < len(teapot) <= 25600
+    st = sc.bvh_stats()
+    assert st["triangles"] == len(teapot) + 12
+
+
+def test_oracle_traversal_matches_brute_force(t42_small):
+    """box-only test_42: closest hit over the BVH == brute force over all instanced triangles (float64 reference)"""
+    _, b = t42_small
+    orc = make_oracle(b)
+    pos4, dir4 = random_rays(2000, 7)
+    hits = orc.trace(pos4, dir4)
+    # world-space triangles from the packed arena + instance matrices
+    g, geom = b["globals"], b["geom"]
+    offs = g[g[G_GEOM_TABLE]:g[G_GEOM_TABLE] + 9]
+    tri_lists = []
+    inv = b["inst_matrices"].reshape(-1, 4, 4)                       # [inst][col][row]
+    found, insts = walk_bvh(b["bvh_nodes"], b["bvh_tris"])
+    n = b["bvh_nodes"].reshape(-1, 8)
+    ni = n.view(np.int32)
+    # instance -> mesh map from the instance quads
+    inst_mesh = {}
+    for q in range(ni.shape[0] // 4):
+        if ni[q * 4 + 3, 2] == 0 and ni[q * 4 + 3, 3] == 0 and 0 <= ni[q * 4 + 3, 0] < inv.shape[0] and ni[q * 4 + 3, 1] in found:
+            pass
+    for node in range(ni.shape[0]):
+        if ni[node, 7] == 1 and (int(ni[node, 3]) & 0x80000000):
+            q = (int(ni[node, 3]) & 0x7fffffff) * 4
+            inst_mesh[int(ni[q + 3, 0])] = int(ni[q + 3, 1])
+    best_t = np.full(len(pos4), np.inf)
+    for inst, mesh in inst_mesh.items():
+        hdr = geom.view(np.int32)[offs[mesh] * 4: offs[mesh] * 4 + 16]
+        v = geom[(offs[mesh] + hdr[0]) * 4:(offs[mesh] + hdr[0]) * 4 + hdr[4] * 4].reshape(-1, 4)[:, :3].astype(np.float64)
+        idx = geom.view(np.int32)[(offs[mesh] + hdr[3]) * 4:(offs[mesh] + hdr[3]) * 4 + hdr[7]].reshape(-1, 3)
+        M = np.linalg.inv(inv[inst].T.astype(np.float64))            # object -> world
+        vw = (np.c_[v, np.ones(len(v))] @ M.T)[:, :3]
+        A, B, Cc = vw[idx[:, 0]], vw[idx[:, 1]], vw[idx[:, 2]]
+        o, d = pos4[:, None, :3].astype(np.float64), dir4[:, None, :3].astype(np.float64)
+        e1, e2 = (B - A)[None], (Cc - A)[None]
+        p = np.cross(d, e2)
+        det = (e1 * p).sum(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            invd = 1.0 / det
+            tv = o - A[None]
+            vv = (tv * p).sum(-1) * invd
+            qv = np.cross(tv, e1)
+            uu = (qv * d).sum(-1) * invd
+            tt = (e2 * qv).sum(-1) * invd
+        ok = (vv > -1e-6) & (uu > -1e-6) & (uu + vv < 1 + 1e-6) & (tt > 0)
+        tt = np.where(ok, tt, np.inf)
+        best_t = np.minimum(best_t, tt.min(axis=1))
+    hit_mask = hits["primId"] != -1
+    bf_mask = np.isfinite(best_t)
+    assert (hit_mask == bf_mask).mean() > 0.999
+    both = hit_mask & bf_mask
+    np.testing.assert_allclose(hits["t"][both], best_t[both], rtol=2e-4)
