@@ -40,12 +40,14 @@ def cpu_baseline(scene, depth, budget_s=15.0):
     sc = HostScene(scene, w, h, trace_depth=depth, enable_dof=0, use_hip=False)
     orc = Oracle(sc.buffers())
     gens = orc.init_generators(777)
+    img, _, gens = orc.render(1, gens=gens)          # warm-up pass (page-in, thread pool)
+    spp, rays, done = 0, 0, 1
     t0 = time.time()
-    img, rays, gens = orc.render(1, gens=gens)
-    one = time.time() - t0
-    spp = max(1, min(64, int(budget_s / max(one, 1e-3)) - 1))
-    t0 = time.time()
-    img, rays, gens = orc.render(spp, gens=gens, image=img, spp_done=1)
+    while time.time() - t0 < budget_s and spp < 4096:
+        img, r, gens = orc.render(8, gens=gens, image=img, spp_done=done)
+        spp += 8
+        done += 8
+        rays += r
     dt = time.time() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": orc.max_threads(), "kind": "port",
             "sample": "%dx%d, %d bounces, %d spp of the same scene (%d rays, %.1f s); CPU oracle, own BVH4 walk (the stock "

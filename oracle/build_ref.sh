@@ -17,8 +17,11 @@ OUT="$HERE/_ref"
 CLANG=${CLANG:-/opt/rocm/lib/llvm/bin/clang}
 if [ ! -d "$REF/shaders" ]; then echo "build_ref.sh: $REF not present (GPU box): using prebuilt $OUT" ; exit 0; fi
 mkdir -p "$OUT"
+# -force-attribute ... optnone: ROCm 7.2's clang crashes (InstCombine, visitPHINode) while optimising the reference's
+# MapSamplesToDisc (cglobals.h:1609-1652); the function is compiled unoptimised instead, its source is untouched.
 FLAGS="-x cl -Xclang -finclude-default-header -cl-std=CL1.2 -target amdgcn-amd-amdhsa -mcpu=gfx950 -O2 \
- -cl-single-precision-constant -ffp-contract=off -D OCL_COMPILER -D SHADOW_TRACE_COLORED_SHADOWS -D ENABLE_OPACITY_TEX -D ENABLE_BLINN \
+ -mllvm -force-attribute=MapSamplesToDisc:noinline -mllvm -force-attribute=MapSamplesToDisc:optnone \
+ -cl-single-precision-constant -cl-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -D OCL_COMPILER -D SHADOW_TRACE_COLORED_SHADOWS -D ENABLE_OPACITY_TEX -D ENABLE_BLINN \
  -I $REF -I $REF/shaders -w"
 $CLANG $FLAGS "$HERE/ref_driver.cl" -o "$OUT/ref_driver.hsaco"
 $CLANG $FLAGS "$REF/shaders/trace.cl" -o "$OUT/trace.hsaco"

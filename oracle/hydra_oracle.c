@@ -1255,29 +1255,44 @@ uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float*
 }
 
 int64_t orc_collect_rays(const OrcScene* s, int w, int h, int seed, int bounce, int shadow, float* pos4, float* dir4, float* tfar, int64_t cap) {
-  int64_t count = 0;
-  for (int y = 0; y < h && count < cap; y++) {
-    for (int x = 0; x < w && count < cap; x++) {
-      uint32_t gen[2];
-      orc_random_init(seed + y * w + x, gen);
-      float r4[4], offs[4];
-      orc_rnd_float4(gen, r4);
-      for (int k = 0; k < 4; k++) offs[k] = -1.0f + 2.0f * r4[k];
-      f3 ray_pos, ray_dir;
-      MakeRandEyeRay(x, y, w, h, offs, s, &ray_pos, &ray_dir);
-      PathStat st = {0};
-      RayProbe pr;
-      memset(&pr, 0, sizeof(pr));
-      pr.bounce = bounce; pr.shadow = shadow;
-      (void)PathTrace(s, ray_pos, ray_dir, gen, &st, &pr);
-      if (pr.have) {
-        pos4[4 * count] = pr.pos.x; pos4[4 * count + 1] = pr.pos.y; pos4[4 * count + 2] = pr.pos.z; pos4[4 * count + 3] = 0.0f;
-        dir4[4 * count] = pr.dir.x; dir4[4 * count + 1] = pr.dir.y; dir4[4 * count + 2] = pr.dir.z; dir4[4 * count + 3] = 0.0f;
-        if (tfar) tfar[count] = pr.tfar;
-        count++;
-      }
+  /* every pixel records into its own slot in parallel, then the recorded slots are packed in pixel order */
+  const int64_t npix = (int64_t)w * h;
+  float* tp = (float*)malloc((size_t)npix * 4 * sizeof(float));
+  float* td = (float*)malloc((size_t)npix * 4 * sizeof(float));
+  float* tt = (float*)malloc((size_t)npix * sizeof(float));
+  unsigned char* have = (unsigned char*)calloc((size_t)npix, 1);
+  if (!tp || !td || !tt || !have) { free(tp); free(td); free(tt); free(have); return -1; }
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t p = 0; p < npix; p++) {
+    const int x = (int)(p % w), y = (int)(p / w);
+    uint32_t gen[2];
+    orc_random_init(seed + (int)p, gen);
+    float r4[4], offs[4];
+    orc_rnd_float4(gen, r4);
+    for (int k = 0; k < 4; k++) offs[k] = -1.0f + 2.0f * r4[k];
+    f3 ray_pos, ray_dir;
+    MakeRandEyeRay(x, y, w, h, offs, s, &ray_pos, &ray_dir);
+    PathStat st = {0};
+    RayProbe pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.bounce = bounce; pr.shadow = shadow;
+    (void)PathTrace(s, ray_pos, ray_dir, gen, &st, &pr);
+    if (pr.have) {
+      have[p] = 1;
+      tp[4 * p] = pr.pos.x; tp[4 * p + 1] = pr.pos.y; tp[4 * p + 2] = pr.pos.z; tp[4 * p + 3] = 0.0f;
+      td[4 * p] = pr.dir.x; td[4 * p + 1] = pr.dir.y; td[4 * p + 2] = pr.dir.z; td[4 * p + 3] = 0.0f;
+      tt[p] = pr.tfar;
     }
   }
+  int64_t count = 0;
+  for (int64_t p = 0; p < npix && count < cap; p++) {
+    if (!have[p]) continue;
+    memcpy(pos4 + 4 * count, tp + 4 * p, 16);
+    memcpy(dir4 + 4 * count, td + 4 * p, 16);
+    if (tfar) tfar[count] = tt[p];
+    count++;
+  }
+  free(tp); free(td); free(tt); free(have);
   return count;
 }
 

@@ -1,0 +1,125 @@
+"""Launch kernels of oracle/_ref/*.hsaco (the reference's own code compiled for gfx950 by oracle/build_ref.sh) through
+the HIP module API.  TEST INFRASTRUCTURE: used by tests/golden/make_golden.py and by GPU tests, never by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class RefModule:
+    def __init__(self, name="ref_driver.hsaco", device=0):
+        path = os.path.join(REF_DIR, name)
+        if not os.path.exists(path):
+            raise HipError("%s is missing: run oracle/build_ref.sh in the container that has /root/reference" % path)
+        self.hip = C.CDLL("libamdhip64.so")
+        self._ck(self.hip.hipSetDevice(device), "hipSetDevice")
+        self.mod = C.c_void_p()
+        self._ck(self.hip.hipModuleLoad(C.byref(self.mod), path.encode()), "hipModuleLoad")
+        self.bufs = []
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise HipError("%s failed with hip error %d" % (what, rc))
+
+    def up(self, arr):
+        """upload a numpy array, returns device pointer (int)"""
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._ck(self.hip.hipMalloc(C.byref(p), max(arr.nbytes, 16)), "hipMalloc")
+        if arr.nbytes:
+            self._ck(self.hip.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
+        self.bufs.append(p)
+        return p.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(self.hip.hipMalloc(C.byref(p), max(nbytes, 16)), "hipMalloc")
+        self._ck(self.hip.hipMemset(p, 0, max(nbytes, 16)), "hipMemset")
+        self.bufs.append(p)
+        return p.value
+
+    def down(self, ptr, dtype, shape):
+        out = np.empty(shape, dtype)
+        self._ck(self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2), "hipMemcpy D2H")
+        return out
+
+    def launch(self, kernel, n, args, block=64):
+        """args: list of ('p', devptr) | ('i', int).  One work-item per element, 1-D."""
+        fn = C.c_void_p()
+        self._ck(self.hip.hipModuleGetFunction(C.byref(fn), self.mod, kernel.encode()), "hipModuleGetFunction(%s)" % kernel)
+        holders = []
+        for kind, v in args:
+            holders.append(C.c_void_p(v) if kind == "p" else C.c_int(v))
+        params = (C.c_void_p * len(holders))(*[C.cast(C.byref(h), C.c_void_p) for h in holders])
+        grid = (n + block - 1) // block
+        self._ck(self.hip.hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, None, params, None), "hipModuleLaunchKernel(%s)" % kernel)
+        self._ck(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize after %s" % kernel)
+
+    def close(self):
+        for p in self.bufs:
+            self.hip.hipFree(p)
+        self.bufs = []
+        if self.mod:
+            self.hip.hipModuleUnload(self.mod)
+            self.mod = None
+
+
+class RefScene:
+    """scene buffers (dict from HostScene.buffers()) resident on the device for the reference kernels"""
+
+    def __init__(self, mod, b):
+        self.m, self.b = mod, b
+        up = mod.up
+        self.globals = up(b["globals"])
+        self.mat, self.tex, self.geom = up(b["materials"]), up(b["textures"]), up(b["geom"])
+        self.pdf = up(b["pdfs"] if b["pdfs"].size else np.zeros(4, np.float32))
+        self.bvh, self.tris = up(b["bvh_nodes"]), up(b["bvh_tris"])
+        self.matrices, self.light_id = up(b["inst_matrices"]), up(b["inst_light_id"])
+        self.have_inst = int(b["have_inst"])
+        self.w, self.h = b["width"], b["height"]
+
+    def random(self, seeds, draws):
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        n = seeds.size
+        out, st = self.m.alloc(n * draws * 16), self.m.alloc(n * 8)
+        self.m.launch("ref_random", n, [("p", self.m.up(seeds)), ("i", draws), ("p", out), ("p", st), ("i", n)])
+        return self.m.down(out, np.float32, (n, draws, 4)), self.m.down(st, np.uint32, (n, 2))
+
+    def make_eye_rays(self, xy, offs4):
+        n = len(xy)
+        pos, dr = self.m.alloc(n * 16), self.m.alloc(n * 16)
+        self.m.launch("ref_make_eye_rays", n, [("p", self.m.up(np.ascontiguousarray(xy, np.int32))), ("p", self.m.up(np.ascontiguousarray(offs4, np.float32))),
+                                               ("p", self.globals), ("i", self.w), ("i", self.h), ("p", pos), ("p", dr), ("i", n)])
+        return self.m.down(pos, np.float32, (n, 4)), self.m.down(dr, np.float32, (n, 4))
+
+    def trace(self, pos4, dir4):
+        n = len(pos4)
+        hits = self.m.alloc(n * 16)
+        self.m.launch("ref_trace", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
+                                       ("p", self.bvh), ("p", self.tris), ("p", hits), ("i", self.have_inst), ("i", n)])
+        dt = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
+        return self.m.down(hits, dt, (n,))
+
+    def eval_surface(self, pos4, dir4, hits):
+        n = len(pos4)
+        out = self.m.alloc(n * 96)
+        self.m.launch("ref_eval_surface", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
+                                              ("p", self.m.up(np.ascontiguousarray(hits))), ("p", self.matrices), ("p", self.geom), ("p", self.globals),
+                                              ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 24))
+
+    def path_trace(self, pos4, dir4, rng2):
+        n = len(pos4)
+        rng = self.m.up(np.ascontiguousarray(rng2, np.uint32))
+        col = self.m.alloc(n * 16)
+        self.m.launch("ref_path_trace", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
+                                            ("p", rng), ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
+                                            ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", col), ("i", n)])
+        return self.m.down(col, np.float32, (n, 4)), self.m.down(rng, np.uint32, (n, 2))
