@@ -5,9 +5,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <string.h>
 #include "../../include/hydra_layouts.h"
 
+// HK_HOST_EMU: the same device functions compiled for the host (tests/emu/, AddressSanitizer/UBSan runs on CPU only;
+// GPU sanitizers are not available on the pool).  Never defined in the product build.
+#ifdef HK_HOST_EMU
+#include <math.h>
+#define HK_DEV static inline
+#define HK_DEV_MEMBER inline
+#define HK_WAVE_ACTIVE_LANES() 64
+#else
 #define HK_DEV __device__ __forceinline__
+#define HK_DEV_MEMBER __device__ __forceinline__
+#define HK_WAVE_ACTIVE_LANES() __popcll(__ballot(1))
+#endif
 
 struct f2 { float x, y; };
 struct f3 { float x, y, z; };
@@ -27,8 +39,13 @@ HK_DEV float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
 HK_DEV f3 clamp3(f3 v, float a, float b) { return mk3(clampf(v.x, a, b), clampf(v.y, a, b), clampf(v.z, a, b)); }
 HK_DEV f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 HK_DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+#ifdef HK_HOST_EMU
+HK_DEV int   as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+HK_DEV float as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+#else
 HK_DEV int   as_int(float f) { return __float_as_int(f); }
 HK_DEV float as_float(int i) { return __int_as_float(i); }
+#endif
 HK_DEV bool  finite3(f3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
 
 // reference: mul4x3 / mul3x3, hydra_drv/cglobals.h:288-304; mul4x4x4 :828-836

@@ -39,16 +39,24 @@ HK_DEV float2 RayBox(f3 o, f3 inv, float4 lo4, float4 hi4) {
   return make_float2(tmin, tmax);
 }
 
+// LDS pointers are typed with address space 3 so that pushes/pops compile to ds_write_b32/ds_read_b32 with an
+// immediate stride (a generic int* makes the compiler emit flat_* accesses plus 64-bit address arithmetic).
+#ifdef HK_HOST_EMU
+typedef int hk_lds_int;
+#else
+typedef __attribute__((address_space(3))) int hk_lds_int;
+#endif
+
 struct HkStack {
-  int* lds;       // this lane's column in the block's LDS stack
-  int  stride;    // = blockDim.x
-  int  spill[HK_STACK_SIZE - HK_LDS_DEPTH];
-  HK_DEV void put(int top, int v) {
-    if (top < HK_LDS_DEPTH) lds[top * stride] = v; else spill[top - HK_LDS_DEPTH] = v;
+  hk_lds_int* lds;   // this lane's column in the block's LDS stack, stride = HK_TRACE_BLOCK entries
+  int spill[HK_STACK_SIZE - HK_LDS_DEPTH];
+  HK_DEV_MEMBER void init(int* sharedBase, int lane) { lds = (hk_lds_int*)sharedBase + lane; }
+  HK_DEV_MEMBER void put(int top, int v) {
+    if (top < HK_LDS_DEPTH) lds[top * HK_TRACE_BLOCK] = v; else spill[top - HK_LDS_DEPTH] = v;
   }
-  HK_DEV int get(int top) const {
+  HK_DEV_MEMBER int get(int top) const {
     if (top < 0) return 0;   // the reference reads an unused slot here; the value is never acted on
-    return (top < HK_LDS_DEPTH) ? lds[top * stride] : spill[top - HK_LDS_DEPTH];
+    return (top < HK_LDS_DEPTH) ? lds[top * HK_TRACE_BLOCK] : spill[top - HK_LDS_DEPTH];
   }
 };
 
@@ -81,18 +89,31 @@ HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float
   return res;
 }
 
-template <bool ANYHIT, bool COUNT>
-HK_DEV HydraLiteHit hk_traverse(const float4* __restrict__ bvh, const float4* __restrict__ tris, const bool haveInst,
-                                f3 ray_pos, f3 ray_dir, const float t_rayMin, HydraLiteHit hit, HkStack& stack, TravCounters& cnt) {
-  f3 invDir = SafeInverse(ray_dir);
-  int top = 0, leftNodeOffset = 1;
-  bool searchingForLeaf = true;
-  int instDeep = 0, instTop = 0, instId = -1;
-  f3 old_pos = mk3(0, 0, 0), old_dir = mk3(0, 0, 0);
+// Resumable traversal state: everything BVH4InstTraverse keeps in locals.  trav_run() can be left early (when too few
+// lanes of the wave are still walking) and re-entered after the idle lanes fetched new rays; the sequence of node
+// visits, pushes and triangle tests of each ray is the same as in the uninterrupted loop.
+struct TravState {
+  f3 pos, dir, inv, opos, odir;
+  HydraLiteHit hit;
+  int top, left, instDeep, instTop, instId;
+  bool searching;
+};
+HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit) {
+  t.pos = pos; t.dir = dir; t.inv = SafeInverse(dir);
+  t.opos = mk3(0, 0, 0); t.odir = mk3(0, 0, 0);
+  t.hit = hit;
+  t.top = 0; t.left = 1; t.instDeep = 0; t.instTop = 0; t.instId = -1;
+  t.searching = true;
+}
 
-  while (top >= 0) {
-    while (searchingForLeaf) {
-      const float4* q = bvh + size_t(leftNodeOffset) * 8;
+// returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
+// traversing (minActive <= 0: never suspend).
+template <bool ANYHIT, bool COUNT>
+HK_DEV bool trav_run(TravState& t, const float4* __restrict__ bvh, const float4* __restrict__ tris, const bool haveInst,
+                     const float t_rayMin, HkStack& stack, TravCounters& cnt, const int minActive) {
+  while (t.top >= 0) {
+    while (t.searching) {
+      const float4* q = bvh + size_t(t.left) * 8;
       const float4 n0a = q[0], n0b = q[1], n1a = q[2], n1b = q[3], n2a = q[4], n2b = q[5], n3a = q[6], n3b = q[7];
       if (COUNT) cnt.quads++;
       int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
@@ -100,60 +121,70 @@ HK_DEV HydraLiteHit hk_traverse(const float4* __restrict__ bvh, const float4* __
       const bool v1 = !((uint32_t(c1) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n1b.w)) == HYDRA_BVH_INVALID));
       const bool v2 = !((uint32_t(c2) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n2b.w)) == HYDRA_BVH_INVALID));
       const bool v3 = !((uint32_t(c3) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n3b.w)) == HYDRA_BVH_INVALID));
-      const float2 t0 = RayBox(ray_pos, invDir, n0a, n0b), t1 = RayBox(ray_pos, invDir, n1a, n1b);
-      const float2 t2 = RayBox(ray_pos, invDir, n2a, n2b), t3 = RayBox(ray_pos, invDir, n3a, n3b);
-      float k0 = ((t0.x <= t0.y) && (t0.y >= t_rayMin) && (t0.x <= hit.t) && v0) ? t0.x : HK_MAXFLOAT;
-      float k1 = ((t1.x <= t1.y) && (t1.y >= t_rayMin) && (t1.x <= hit.t) && v1) ? t1.x : HK_MAXFLOAT;
-      float k2 = ((t2.x <= t2.y) && (t2.y >= t_rayMin) && (t2.x <= hit.t) && v2) ? t2.x : HK_MAXFLOAT;
-      float k3 = ((t3.x <= t3.y) && (t3.y >= t_rayMin) && (t3.x <= hit.t) && v3) ? t3.x : HK_MAXFLOAT;
+      const float2 t0 = RayBox(t.pos, t.inv, n0a, n0b), t1 = RayBox(t.pos, t.inv, n1a, n1b);
+      const float2 t2 = RayBox(t.pos, t.inv, n2a, n2b), t3 = RayBox(t.pos, t.inv, n3a, n3b);
+      float k0 = ((t0.x <= t0.y) && (t0.y >= t_rayMin) && (t0.x <= t.hit.t) && v0) ? t0.x : HK_MAXFLOAT;
+      float k1 = ((t1.x <= t1.y) && (t1.y >= t_rayMin) && (t1.x <= t.hit.t) && v1) ? t1.x : HK_MAXFLOAT;
+      float k2 = ((t2.x <= t2.y) && (t2.y >= t_rayMin) && (t2.x <= t.hit.t) && v2) ? t2.x : HK_MAXFLOAT;
+      float k3 = ((t3.x <= t3.y) && (t3.y >= t_rayMin) && (t3.x <= t.hit.t) && v3) ? t3.x : HK_MAXFLOAT;
 #define HK_CSWAP(ka, kb, ca, cb) { const bool sw = (kb < ka); const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; const int tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
       HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
 #undef HK_CSWAP
-      const bool stackHaveSpace = (top < HK_STACK_SIZE);
-      if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(top, c3); top++; }
-      if (k2 < HK_MAXFLOAT && stackHaveSpace) { stack.put(top, c2); top++; }
-      if (k1 < HK_MAXFLOAT && stackHaveSpace) { stack.put(top, c1); top++; }
-      if (k0 < HK_MAXFLOAT) leftNodeOffset = c0;
-      else if (top >= 0) { top--; leftNodeOffset = stack.get(top); }
-      searchingForLeaf = !(leftNodeOffset & int(HYDRA_BVH_LEAF)) && (top >= 0);
-      leftNodeOffset = leftNodeOffset & 0x7fffffff;
-      if (haveInst && top < instTop && instDeep == 1) {
-        ray_pos = old_pos; ray_dir = old_dir; invDir = SafeInverse(ray_dir); instDeep = 0;
+      const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
+      if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
+      if (k2 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c2); t.top++; }
+      if (k1 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c1); t.top++; }
+      if (k0 < HK_MAXFLOAT) t.left = c0;
+      else if (t.top >= 0) { t.top--; t.left = stack.get(t.top); }
+      t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);
+      t.left = t.left & 0x7fffffff;
+      if (haveInst && t.top < t.instTop && t.instDeep == 1) {
+        t.pos = t.opos; t.dir = t.odir; t.inv = SafeInverse(t.dir); t.instDeep = 0;
       }
     }
     if (!haveInst) {
-      if (top >= 0) {
-        hit = IntersectLeaf<ANYHIT, COUNT>(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, 0, false, cnt);
-        if (ANYHIT && hit.primId != -1) return hit;
+      if (t.top >= 0) {
+        t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, tris, 0, false, cnt);
+        if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       }
-      top--;
-      leftNodeOffset = stack.get(top);
-    } else if (top >= 0 && instDeep == 1) {
-      hit = IntersectLeaf<ANYHIT, COUNT>(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, instId, true, cnt);
-      if (ANYHIT && hit.primId != -1) return hit;
-      top--;
-      leftNodeOffset = stack.get(top);
-    } else if (top >= 0 && instDeep == 0) {
-      instDeep = 1;
-      old_pos = ray_pos; old_dir = ray_dir;
-      const float4* q = bvh + size_t(leftNodeOffset) * 8;
+      t.top--;
+      t.left = stack.get(t.top);
+    } else if (t.top >= 0 && t.instDeep == 1) {
+      t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, tris, t.instId, true, cnt);
+      if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
+      t.top--;
+      t.left = stack.get(t.top);
+    } else if (t.top >= 0 && t.instDeep == 0) {
+      t.instDeep = 1;
+      t.opos = t.pos; t.odir = t.dir;
+      const float4* q = bvh + size_t(t.left) * 8;
       const int nextOffset = as_int(q[0].w);
       const m44 matrix = load_m44(q + 2);
-      instId = as_int(q[6].x);
+      t.instId = as_int(q[6].x);
       if (COUNT) cnt.insts++;
-      ray_pos = mul4x3(matrix, ray_pos);
-      ray_dir = mul3x3(matrix, ray_dir);   // stays un-normalised so t keeps world units
-      invDir = SafeInverse(ray_dir);
-      instTop = top;
-      leftNodeOffset = nextOffset;
+      t.pos = mul4x3(matrix, t.pos);
+      t.dir = mul3x3(matrix, t.dir);   // stays un-normalised so t keeps world units
+      t.inv = SafeInverse(t.dir);
+      t.instTop = t.top;
+      t.left = nextOffset;
     }
-    searchingForLeaf = !(leftNodeOffset & int(HYDRA_BVH_LEAF));
-    leftNodeOffset = leftNodeOffset & 0x7fffffff;
-    if (haveInst && top < instTop && instDeep == 1) {
-      ray_pos = old_pos; ray_dir = old_dir; invDir = SafeInverse(ray_dir); instDeep = 0;
+    t.searching = !(t.left & int(HYDRA_BVH_LEAF));
+    t.left = t.left & 0x7fffffff;
+    if (haveInst && t.top < t.instTop && t.instDeep == 1) {
+      t.pos = t.opos; t.dir = t.odir; t.inv = SafeInverse(t.dir); t.instDeep = 0;
     }
+    if (minActive > 0 && t.top >= 0 && HK_WAVE_ACTIVE_LANES() < minActive) return false;   // let the wave refill
   }
-  return hit;
+  return true;
+}
+
+template <bool ANYHIT, bool COUNT>
+HK_DEV HydraLiteHit hk_traverse(const float4* __restrict__ bvh, const float4* __restrict__ tris, const bool haveInst,
+                                f3 ray_pos, f3 ray_dir, const float t_rayMin, HydraLiteHit hit, HkStack& stack, TravCounters& cnt) {
+  TravState t;
+  trav_init(t, ray_pos, ray_dir, hit);
+  (void)trav_run<ANYHIT, COUNT>(t, bvh, tris, haveInst, t_rayMin, stack, cnt, 0);
+  return t.hit;
 }
 
 HK_DEV HydraLiteHit hk_miss_hit() {   // Make_Lite_Hit(MAXFLOAT, -1), hydra_drv/cglobals.h:1256-1266

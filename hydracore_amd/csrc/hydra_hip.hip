@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include "../../include/hydra_hip.h"
 #include "hk_common.h"
 #include "hk_trace.h"
@@ -80,8 +81,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
   const int count = countPtr ? int(*countPtr) : countImm;
   HkStack st;
-  st.lds = ldsStack + threadIdx.x;
-  st.stride = HK_TRACE_BLOCK;
+  st.init(ldsStack, threadIdx.x);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
     TravCounters c = {0, 0, 0, 0};
@@ -103,8 +103,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uin
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
   const int count = countPtr ? int(*countPtr) : countImm;
   HkStack st;
-  st.lds = ldsStack + threadIdx.x;
-  st.stride = HK_TRACE_BLOCK;
+  st.init(ldsStack, threadIdx.x);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float4 o = org4[i];
     float v = 0.0f;
@@ -120,6 +119,68 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uin
       }
     }
     vis[i] = v;
+  }
+}
+
+// T1/T2, persistent form: every lane that finishes its ray immediately fetches the next one from a device-side counter
+// (one atomic per wave per refill), and a wave whose active-lane count drops below `minActive` suspends traversal to
+// refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
+// written by ray index, so they are identical to the one-ray-per-lane kernels above.
+template <bool ANYHIT, bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm, uint32_t* __restrict__ fetchCounter,
+                                                               const float4* __restrict__ a4, const float4* __restrict__ b4,
+                                                               float4* __restrict__ outHits, float* __restrict__ outVis,
+                                                               unsigned long long* __restrict__ totals5, int minActive) {
+  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+  const int count = countPtr ? int(*countPtr) : countImm;
+  HkStack st;
+  st.init(ldsStack, threadIdx.x);
+  TravState t;
+  TravCounters c = {0, 0, 0, 0};
+  int rayIdx = -1;
+  bool busy = false, queueEmpty = false;
+  const int lane = int(__lane_id());
+  const bool haveInst = s.haveInst != 0;
+  while (true) {
+    if (!queueEmpty) {
+      const unsigned long long mask = __ballot(!busy);
+      if (mask != 0ull) {
+        const int n = __popcll(mask), leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = int(atomicAdd(fetchCounter, uint32_t(n)));
+        base = __shfl(base, leader);
+        if (!busy) {
+          const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+          if (idx < count) {
+            const float4 a = a4[idx];
+            HydraLiteHit h = hk_miss_hit();
+            bool skip = false;
+            if (ANYHIT) { h.t = a.w; skip = (a.w < 0.0f); }   // t_far < 0: no light sample => shadow = 0
+            if (skip) outVis[idx] = 0.0f;
+            else {
+              trav_init(t, xyz(a), xyz(b4[idx]), h);
+              if (COUNT) { c.quads = c.insts = c.tris = c.leaves = 0; }
+              rayIdx = idx;
+              busy = true;
+            }
+          }
+        }
+        if (base + n >= count) queueEmpty = true;   // wave-uniform
+      }
+    }
+    if (__ballot(busy) == 0ull) break;
+    if (busy) {
+      const bool done = trav_run<ANYHIT, COUNT>(t, s.bvh, s.tris, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+      if (done) {
+        if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
+        else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
+        if (COUNT && totals5) {
+          atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
+          atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+        }
+        busy = false;
+      }
+    }
   }
 }
 
@@ -308,88 +369,15 @@ __global__ void k_stage_random(int n, const int* seeds, int draws, float4* out4,
   for (int d = 0; d < draws; d++) out4[size_t(i) * draws + d] = rndFloat4_Pseudo(g);
   state2[i] = make_uint2(g.x, g.y);
 }
-// one whole path per lane: the same device functions as the wavefront kernels, strung together the way
-// IntegratorMISPTLoop2::PathTrace does (PT_Loop.cpp:264-321); used for function-level parity of the shading code.
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_stage_path(SceneDev s, int n, const float4* pos4, const float4* dir4, uint2* rng2, float4* color4) {
-  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+// seed the path state from caller-provided primary rays and RandomGen states (stage_path_trace): path i plays pixel i
+__global__ void k_stage_seed_paths(int n, const float4* __restrict__ pos4, const float4* __restrict__ dir4, const uint2* __restrict__ rng2, PathState S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  HkStack st;
-  st.lds = ldsStack + threadIdx.x;
-  st.stride = HK_TRACE_BLOCK;
-  TravCounters tc = {0, 0, 0, 0};
-  f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
-  RandomGen gen; gen.x = rng2[i].x; gen.y = rng2[i].y;
-  f3 accumColor = mk3(0, 0, 0), thr = mk3(1, 1, 1), currColor = mk3(0, 0, 0);
-  float misPdf = 1.0f; bool misSpec = true;
-  uint32_t flags = 0;
-  float rays = 0.0f;
-  const int maxDepth = g_varsI(s)[HV_I_TRACE_DEPTH];
-  for (int depth = 0; depth < maxDepth; depth++) {
-    const HydraLiteHit hit = hk_traverse<false, false>(s.bvh, s.tris, s.haveInst != 0, ray_pos, ray_dir, 0.0f, hk_miss_hit(), st, tc);
-    rays += 1.0f;
-    if (!HitSome(hit)) { currColor = mk3(0, 0, 0); break; }
-    const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
-    const float* mat = materialAt(s, surf.matId);
-    {
-      const int lo0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
-      const float* pL = lightAt(s, lo0);
-      const f3 emission = emissionEval(s, ray_dir, surf, flags, pL, mat);
-      if (dot(emission, emission) > 1e-3f) {
-        if (pL != nullptr) {
-          const float lgtPdf = pL[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pL, ray_dir, length(ray_pos - surf.pos));
-          float w = misWeightHeuristic(misPdf, lgtPdf);
-          if (misSpec) w = 1.0f;
-          currColor = emission * w;
-        } else currColor = emission;
-        break;
-      } else if (depth >= maxDepth - 1) { currColor = mk3(0, 0, 0); break; }
-    }
-    const float4 rl = rndFloat4_Pseudo(gen);
-    float pick = 1.0f;
-    const int lightOffset = SelectRandomLightRev(rl.z, s, pick);
-    f3 explicitColor = mk3(0, 0, 0);
-    if (lightOffset >= 0) {
-      ShadowSample sam;
-      AreaLightSampleRev(lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);
-      const f3 sdir = normalize(sam.pos - surf.pos);
-      const f3 spos = OffsShadowRayPos(surf.pos, surf.normal, sdir, surf.sRayOff);
-      HydraLiteHit sh = hk_miss_hit();
-      sh.t = length(spos - sam.pos) * 0.995f;
-      sh = hk_traverse<true, false>(s.bvh, s.tris, s.haveInst != 0, spos, sdir, 0.0f, sh, st, tc);
-      rays += 1.0f;
-      const float shadow = (sh.primId != -1) ? 0.0f : 1.0f;
-      ShadeContext sc;
-      sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
-      const BxDFResult ev = materialEval(mat, sc, s);
-      const float cos1 = fmaxf(+dot(sdir, surf.normal), 0.0f), cos2 = fmaxf(-dot(sdir, surf.normal), 0.0f);
-      const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
-      float w = misWeightHeuristic(sam.pdf * pick, ev.pdfFwd);
-      if (sam.isPoint) w = 1.0f;
-      const f3 lc = sam.color * (1.0f / fmaxf(sam.pdf, HK_DEPSILON2));
-      explicitColor = (((lc * (1.0f / pick)) * bxdfVal) * w) * shadow;
-    }
-    float rands[10];
-    {
-      const float4 r4 = rndFloat4_Pseudo(gen);
-      rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
-      for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
-    }
-    MatSample ms;
-    MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
-    const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
-    const float cosTheta = fabsf(dot(ms.direction, surf.normal));
-    ray_dir = ms.direction;
-    ray_pos = OffsRayPos(surf.pos, surf.normal, ms.direction);
-    misSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
-    misPdf = ms.pdf;
-    flags = flagsNextBounceLite(flags, ms, s);
-    accumColor = accumColor + (thr * explicitColor);
-    thr = thr * (bxdfVal * cosTheta);
-  }
-  accumColor = accumColor + (thr * currColor);
-  color4[i] = mk4(accumColor, rays);
-  rng2[i] = make_uint2(gen.x, gen.y);
+  S.pos4[i] = make_float4(pos4[i].x, pos4[i].y, pos4[i].z, as_float(i));
+  S.dir4[i] = make_float4(dir4[i].x, dir4[i].y, dir4[i].z, as_float(0));
+  S.thr4[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  S.acc4[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+  S.rng2[i] = rng2[i];
 }
 
 // ================================================================================================ host side
@@ -427,6 +415,10 @@ struct hydra_hip_ctx {
 
   bool stageTiming = false;
   bool travCounters = false;
+  int traceMode = 0;          // 0 = one ray per lane (k_trace/k_shadow, default: measured faster), 1 = persistent dynamic fetch (k_trace_dyn)
+  int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
+  int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
+  DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
   DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris]
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
@@ -539,11 +531,68 @@ static int alloc_render_state(hydra_hip_ctx* c) {
   if ((rc = dev_alloc(c, c->mVis, N * 4)) != 0) return rc;
   if ((rc = dev_alloc(c, c->live, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
   if ((rc = dev_alloc(c, c->shadowCnt, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->fetchCnt, (2 * HK_MAX_DEPTH + 4) * 4)) != 0) return rc;
   if (c->totals.p == nullptr) {
     if ((rc = dev_alloc(c, c->totals, 4 * 8)) != 0) return rc;
     HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream));
   }
   c->stateAllocated = true;
+  return HYDRA_HIP_OK;
+}
+
+// ---- traversal launchers: one place decides between the one-ray-per-lane kernels and the persistent dynamic-fetch form
+static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetchCnt, (2 * HK_MAX_DEPTH + 4) * 4); }
+
+static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* pos4, const float4* dir4,
+                           HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounter) {
+  if (c->traceMode == 0 || perRay3 != nullptr || fetchCounter == nullptr) {
+    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, 16);
+    if (perRay3 || totals5) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
+    return;
+  }
+  const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+  float4* out = reinterpret_cast<float4*>(hits);
+  if (totals5) hipLaunchKernelGGL((k_trace_dyn<false, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive);
+  else hipLaunchKernelGGL((k_trace_dyn<false, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive);
+}
+static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* org4, const float4* dir4,
+                          float* vis, unsigned long long* totals5, uint32_t* fetchCounter) {
+  if (c->traceMode == 0 || fetchCounter == nullptr) {
+    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, 16);
+    if (totals5) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
+    return;
+  }
+  const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+  if (totals5) hipLaunchKernelGGL((k_trace_dyn<true, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive);
+  else hipLaunchKernelGGL((k_trace_dyn<true, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive);
+}
+
+static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
+
+// the per-bounce kernel sequence of one sub-pass: trace -> hit/emission/light-sample (+compaction) -> shadow -> shade
+static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int N, int maxDepth, PathState S, MidState M, HydraLiteHit* hits, uint32_t* live, uint32_t* shadowCnt,
+                       float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
+  const int gWide = grid_for(c, N, 256, 8);
+  auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
+  for (int depth = 0; depth < maxDepth; depth++) {
+    int a = mark();
+    unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
+    launch_closest(c, s, live + depth, 0, N, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + 2 * depth : nullptr);
+    int b = mark();
+    hipLaunchKernelGGL(k_hit, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens);
+    int d = mark();
+    if (depth + 1 < maxDepth) {
+      launch_shadow(c, s, live + depth + 1, 0, N, M.shadowOrg, M.recC, M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + 2 * depth + 1 : nullptr);
+      int e = mark();
+      hipLaunchKernelGGL(k_shade, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S);
+      int f = mark();
+      if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
+    }
+    if (timing) { c->spans.push_back({a, b, 1}); c->spans.push_back({b, d, 2}); }
+  }
+  HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
 }
 
@@ -564,6 +613,9 @@ int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_
     snprintf(c->devName, sizeof(c->devName), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     c->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (const char* e = getenv("HYDRA_HIP_TRACE_MODE")) c->traceMode = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("HYDRA_HIP_TRACE_MIN_ACTIVE")) c->traceMinActive = std::max(0, std::min(64, atoi(e)));
+  if (const char* e = getenv("HYDRA_HIP_TRACE_BLOCKS_PER_CU")) c->traceBlocksPerCU = std::max(1, std::min(64, atoi(e)));
   c->stream = nullptr;   // the null stream: ordered with torch's default stream and with plain hipMemcpy
   *out = c;
   return HYDRA_HIP_OK;
@@ -575,7 +627,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   (void)hipDeviceSynchronize();
   DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->mDir, &c->mThr, &c->mAcc,
-                   &c->mRng, &c->travTotals, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
+                   &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
   for (auto& b : c->bvhNodes) dev_free(b);
@@ -760,37 +812,21 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   uint32_t* shadowCnt = static_cast<uint32_t*>(c->shadowCnt.p);
   HydraLiteHit* hits = static_cast<HydraLiteHit*>(c->hits.p);
   const int N = c->N;
-  const int gTrace = grid_for(c, N, HK_TRACE_BLOCK, 16), gWide = grid_for(c, N, 256, 8);
+  const int gWide = grid_for(c, N, 256, 8);
   const bool timing = c->stageTiming;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
 
   for (int sub = 0; sub < spp; sub++) {
     HCHECK(hipMemsetAsync(live, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
     HCHECK(hipMemsetAsync(shadowCnt, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
+    HCHECK(hipMemsetAsync(c->fetchCnt.p, 0, (2 * HK_MAX_DEPTH + 4) * 4, c->stream));
     HCHECK(hipMemcpyAsync(live, &c->N, 4, hipMemcpyHostToDevice, c->stream));
     int e0 = mark();
     hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, N, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
     int e1 = mark();
     if (timing) c->spans.push_back({e0, e1, 0});
-    for (int depth = 0; depth < maxDepth; depth++) {
-      int a = mark();
-      unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
-      if (tt) hipLaunchKernelGGL(k_trace<true>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr), tt);
-      else hipLaunchKernelGGL(k_trace<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth, 0, S.pos4, S.dir4, hits, static_cast<uint32_t*>(nullptr), tt);
-      int b = mark();
-      hipLaunchKernelGGL(k_hit, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M,
-                         static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p));
-      int d = mark();
-      if (depth + 1 < maxDepth) {
-        if (tt) hipLaunchKernelGGL(k_shadow<true>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis, tt + 5);
-        else hipLaunchKernelGGL(k_shadow<false>, dim3(gTrace), dim3(HK_TRACE_BLOCK), 0, c->stream, s, live + depth + 1, 0, M.shadowOrg, M.recC, M.vis, tt);
-        int e = mark();
-        hipLaunchKernelGGL(k_shade, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S);
-        int f = mark();
-        if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
-      }
-      if (timing) { c->spans.push_back({a, b, 1}); c->spans.push_back({b, d, 2}); }
-    }
+    { int rc = run_bounces(c, s, N, maxDepth, S, M, hits, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
+                           static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
     int g0 = mark();
     hipLaunchKernelGGL(k_accumulate, dim3(gWide), dim3(256), 0, c->stream, N, static_cast<const int*>(c->slotPixel.p), static_cast<const float4*>(c->contrib.p), c->accum);
     hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, static_cast<unsigned long long*>(c->totals.p));
@@ -862,6 +898,15 @@ int hydra_hip_reset_perf_counters(hydra_hip_handle c) {
   if (c->totals.p) { HCHECK(hipSetDevice(c->device)); HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream)); }
   return HYDRA_HIP_OK;
 }
+int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
+  if (!c || !name) return HYDRA_HIP_EINVAL;
+  const std::string n(name);
+  if (n == "trace_mode") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "trace_mode: 0 or 1"); c->traceMode = value; }
+  else if (n == "trace_min_active") { if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_min_active: 0..64"); c->traceMinActive = value; }
+  else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
+  else return fail(c, HYDRA_HIP_EINVAL, "set_option: unknown option " + n);
+  return HYDRA_HIP_OK;
+}
 int hydra_hip_enable_traversal_counters(hydra_hip_handle c, int enable) {
   if (!c) return HYDRA_HIP_EINVAL;
   HCHECK(hipSetDevice(c->device));
@@ -928,10 +973,10 @@ int hydra_hip_stage_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   uint32_t* dc = counters3 ? (uint32_t*)tb.up(c, nullptr, size_t(n) * 12, rc) : nullptr;
   if (rc) return rc;
   SceneDev s = make_scene(c);
-  const int g = grid_for(c, n, HK_TRACE_BLOCK, 16);
-  unsigned long long* noTotals = nullptr;
-  if (counters3) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc, noTotals);
-  else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, dc, noTotals);
+  if ((rc = ensure_fetch_counters(c))) return rc;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
+  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+  launch_closest(c, s, nullptr, n, n, dpos, ddir, dh, dc, nullptr, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(hits, dh, size_t(n) * 16, hipMemcpyDeviceToHost));
   if (counters3) HCHECK(hipMemcpy(counters3, dc, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -947,8 +992,10 @@ int hydra_hip_stage_shadow_trace(hydra_hip_handle c, int n, const float* ray_pos
   float* dv = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
   if (rc) return rc;
   SceneDev s = make_scene(c);
-  hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(c, n, HK_TRACE_BLOCK, 16)), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dorg, ddir, dv,
-                     static_cast<unsigned long long*>(nullptr));
+  if ((rc = ensure_fetch_counters(c))) return rc;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
+  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+  launch_shadow(c, s, nullptr, n, n, dorg, ddir, dv, nullptr, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(visibility, dv, size_t(n) * 4, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
@@ -969,18 +1016,37 @@ int hydra_hip_stage_eval_surface(hydra_hip_handle c, int n, const float* ray_pos
 }
 
 int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, uint32_t* rng_state2, float* color4) {
+  // n caller-provided primary rays + RandomGen states run through the PRODUCTION wavefront kernels (path i plays pixel i)
   STAGE_PROLOG(true);
   if (c->hostHeader.size() > HG_SKY_LIGHT_ID && c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: sky lights are not supported");
+  const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
+  if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: HRT_TRACE_DEPTH out of range");
   float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
   float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
   uint2* drng = (uint2*)tb.up(c, rng_state2, size_t(n) * 8, rc);
-  float4* dcol = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  float4* bufs[15];
+  for (auto& b : bufs) b = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  uint2* sRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
+  uint2* mRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
+  uint2* gensOut = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
+  float* vis = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
+  uint32_t* counters = (uint32_t*)tb.up(c, nullptr, size_t(4 * HK_MAX_DEPTH + 16) * 4, rc);
   if (rc) return rc;
+  PathState S = {bufs[0], bufs[1], bufs[2], bufs[3], sRng};
+  MidState M = {bufs[4], bufs[5], bufs[6], mRng, bufs[7], bufs[8], bufs[9], bufs[10], bufs[11], bufs[12], vis};
+  HydraLiteHit* hits = reinterpret_cast<HydraLiteHit*>(bufs[13]);
+  float4* contrib = bufs[14];
+  uint32_t* live = counters, *shadowCnt = counters + HK_MAX_DEPTH + 2, *fetch = counters + 2 * HK_MAX_DEPTH + 4;
+  HCHECK(hipMemsetAsync(counters, 0, size_t(4 * HK_MAX_DEPTH + 16) * 4, c->stream));
+  HCHECK(hipMemcpyAsync(live, &n, 4, hipMemcpyHostToDevice, c->stream));
+  HCHECK(hipMemsetAsync(contrib, 0, size_t(n) * 16, c->stream));
   SceneDev s = make_scene(c);
-  hipLaunchKernelGGL(k_stage_path, dim3((n + HK_TRACE_BLOCK - 1) / HK_TRACE_BLOCK), dim3(HK_TRACE_BLOCK), 0, c->stream, s, n, dpos, ddir, drng, dcol);
+  hipLaunchKernelGGL(k_stage_seed_paths, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dpos, ddir, drng, S);
+  rc = run_bounces(c, s, n, maxDepth, S, M, hits, live, shadowCnt, contrib, gensOut, fetch, false);
+  if (rc) return rc;
   STAGE_EPILOG();
-  HCHECK(hipMemcpy(color4, dcol, size_t(n) * 16, hipMemcpyDeviceToHost));
-  HCHECK(hipMemcpy(rng_state2, drng, size_t(n) * 8, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(rng_state2, gensOut, size_t(n) * 8, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 
@@ -1007,15 +1073,15 @@ int hydra_hip_bench_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
   if (rc) return rc;
   SceneDev s = make_scene(c);
-  const int g = grid_for(c, n, HK_TRACE_BLOCK, 16);
+  if ((rc = ensure_fetch_counters(c))) return rc;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
   hipEvent_t e0, e1;
   HCHECK(hipEventCreate(&e0));
   HCHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (shadow) hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, reinterpret_cast<float*>(dh),
-                                   static_cast<unsigned long long*>(nullptr));
-    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, static_cast<const uint32_t*>(nullptr), n, dpos, ddir, dh, static_cast<uint32_t*>(nullptr),
-                            static_cast<unsigned long long*>(nullptr));
+    (void)hipMemsetAsync(fetch, 0, 4, c->stream);
+    if (shadow) launch_shadow(c, s, nullptr, n, n, dpos, ddir, reinterpret_cast<float*>(dh), nullptr, fetch);
+    else launch_closest(c, s, nullptr, n, n, dpos, ddir, dh, nullptr, nullptr, fetch);
   };
   launch();   // warm-up
   HCHECK(hipEventRecord(e0, c->stream));

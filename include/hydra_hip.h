@@ -95,6 +95,10 @@ int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
 int hydra_hip_reset_perf_counters(hydra_hip_handle h);
 /* enable per-stage hipEvent timing inside trace_pass (event records only; they are resolved by get_rays_stat) */
 int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
+/* tuning knobs (do not change results): "trace_mode" 0 = one ray per lane (default), 1 = persistent kernels with dynamic
+ * ray fetch; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12).
+ * The same knobs can be preset with HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment. */
+int hydra_hip_set_option(hydra_hip_handle h, const char* name, int value);
 /* algorithmic-work counters of the traversal kernels (roofline byte model).  While enabled, trace_pass
  * uses the counting kernel variants (slower).  out = max_depth x 2 x 5 uint64:
  * [bounce][0 = closest-hit | 1 = shadow][rays, quads visited, instance quads entered, leaves visited, triangles tested] */
@@ -118,8 +122,8 @@ int hydra_hip_stage_shadow_trace(hydra_hip_handle h, int n, const float* ray_pos
  * pos3 normal3 flatNormal3 tangent3 biTangent3 texCoord2 matId(as int bits) t sRayOff hfi(0/1) pad3 */
 int hydra_hip_stage_eval_surface(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                                  const HydraLiteHit* hits, float* surf24);
-/* whole path for n given primary rays with given per-path RandomGen state (2 uint32 each):
- * IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb + rays traced */
+/* whole paths for n given primary rays with given per-path RandomGen state (2 uint32 each, updated in place), run
+ * through the production wavefront kernels: IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb, w = 0 */
 int hydra_hip_stage_path_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                                uint32_t* rng_state2, float* color4);
 /* R1  RandomGenInit + rndFloat4_Pseudo (crandom.h:20-63): for each seed the first `draws` float4 outputs */

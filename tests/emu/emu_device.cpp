@@ -1,0 +1,84 @@
+// emu_device.cpp -- the HIP device functions (hydracore_amd/csrc/hk_*.h) compiled for the HOST with
+// -DHK_HOST_EMU -fsanitize=address,undefined.  TEST INFRASTRUCTURE: GPU sanitizers are not available on the pool, so
+// out-of-bounds reads, uninitialised values and UB in the device code are hunted here, on CPU, with the same scene
+// buffers; the results are also compared with the oracle (tests/test_emu_device.py).  Not part of the product.
+#define HK_HOST_EMU 1
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "../../hydracore_amd/csrc/hk_common.h"
+#include "../../hydracore_amd/csrc/hk_trace.h"
+#include "../../hydracore_amd/csrc/hk_shading.h"
+#include "emu_integrator.h"
+
+struct EmuScene {   // mirrors tests/oracle_lib.OrcScene field for field
+  const int* globals; const float* matStorage; const int* texStorage; const float* geomStorage; const float* pdfStorage;
+  const float* bvh; const float* tris; int haveInst; const float* instMatrices; const int* instLightInstId; int instNum;
+  const int* remapLists; int remapListsSize; const int* remapTable; int remapTableSize; const int* remapInst; int remapInstSize;
+};
+
+static SceneDev to_dev(const EmuScene* e) {
+  SceneDev s;
+  s.globals = e->globals;
+  s.matStorage = reinterpret_cast<const float4*>(e->matStorage);
+  s.texStorage = reinterpret_cast<const int4*>(e->texStorage);
+  s.geomStorage = reinterpret_cast<const float4*>(e->geomStorage);
+  s.pdfStorage = reinterpret_cast<const float4*>(e->pdfStorage);
+  s.bvh = reinterpret_cast<const float4*>(e->bvh);
+  s.tris = reinterpret_cast<const float4*>(e->tris);
+  s.haveInst = e->haveInst;
+  s.instMatrices = reinterpret_cast<const float4*>(e->instMatrices);
+  s.instLightInstId = e->instLightInstId;
+  s.instNum = e->instNum;
+  s.remapLists = e->remapListsSize > 0 ? e->remapLists : nullptr; s.remapListsSize = e->remapListsSize;
+  s.remapTable = e->remapTableSize > 0 ? e->remapTable : nullptr; s.remapTableSize = e->remapTableSize;
+  s.remapInst = e->remapInstSize > 0 ? e->remapInst : nullptr;    s.remapInstSize = e->remapInstSize;
+  return s;
+}
+
+extern "C" {
+
+void emu_trace(const EmuScene* e, int n, const float* pos4, const float* dir4, HydraLiteHit* hits, unsigned* counters4, int anyhit, const float* tfar, float* vis) {
+  const SceneDev s = to_dev(e);
+  std::vector<int> lds(HK_LDS_DEPTH * HK_TRACE_BLOCK, 0);
+  for (int i = 0; i < n; i++) {
+    HkStack st;
+    st.init(lds.data(), i % HK_TRACE_BLOCK);
+    TravCounters c = {0, 0, 0, 0};
+    const f3 p = mk3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), d = mk3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
+    if (anyhit) {
+      HydraLiteHit h = hk_miss_hit();
+      h.t = tfar[i];
+      h = hk_traverse<true, true>(s.bvh, s.tris, s.haveInst != 0, p, d, 0.0f, h, st, c);
+      vis[i] = (h.primId != -1) ? 0.0f : 1.0f;
+    } else
+      hits[i] = hk_traverse<false, true>(s.bvh, s.tris, s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c);
+    if (counters4) { counters4[4 * i] = c.quads; counters4[4 * i + 1] = c.insts; counters4[4 * i + 2] = c.tris; counters4[4 * i + 3] = c.leaves; }
+  }
+}
+
+void emu_path_trace(const EmuScene* e, int n, const float* pos4, const float* dir4, unsigned* rng2, float* color4) {
+  const SceneDev s = to_dev(e);
+  std::vector<int> lds(HK_LDS_DEPTH * HK_TRACE_BLOCK, 0);
+  for (int i = 0; i < n; i++) {
+    HkStack st;
+    st.init(lds.data(), i % HK_TRACE_BLOCK);
+    RandomGen gen; gen.x = rng2[2 * i]; gen.y = rng2[2 * i + 1];
+    float rays = 0.0f;
+    const f3 c = hk_path_trace_one(s, st, mk3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), mk3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), gen, rays);
+    color4[4 * i] = c.x; color4[4 * i + 1] = c.y; color4[4 * i + 2] = c.z; color4[4 * i + 3] = rays;
+    rng2[2 * i] = gen.x; rng2[2 * i + 1] = gen.y;
+  }
+}
+
+void emu_eye_rays(const EmuScene* e, int n, int w, int h, const int* xy, const float* offs4, float* pos4, float* dir4) {
+  const SceneDev s = to_dev(e);
+  for (int i = 0; i < n; i++) {
+    f3 p, d;
+    MakeRandEyeRay(xy[2 * i], xy[2 * i + 1], w, h, make_float4(offs4[4 * i], offs4[4 * i + 1], offs4[4 * i + 2], offs4[4 * i + 3]), s, p, d);
+    pos4[4 * i] = p.x; pos4[4 * i + 1] = p.y; pos4[4 * i + 2] = p.z; pos4[4 * i + 3] = 0;
+    dir4[4 * i] = d.x; dir4[4 * i + 1] = d.y; dir4[4 * i + 2] = d.z; dir4[4 * i + 3] = 0;
+  }
+}
+
+}  // extern "C"
