@@ -19,6 +19,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def pmc_traffic(workload_key):
+    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc passes (profiles/*/pmc_traffic.json), or None"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload_key") == workload_key:
+            best = d.get("k_trace_hbm_bytes_per_launch")
+    return best
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -66,6 +80,8 @@ def main():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "test_224"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of N ranks on one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,14 +97,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_id = args.device if args.device >= 0 else local_rank
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     w, h, depth = args.width, args.height, args.trace_depth
-    sc = HostScene(args.scene, w, h, trace_depth=depth, enable_dof=0, use_hip=True, device=local_rank, seed=777)
+    sc = HostScene(args.scene, w, h, trace_depth=depth, enable_dof=0, use_hip=True, device=dev_id, seed=777)
     if sc.unsupported():
         raise SystemExit("bench.py: scene uses features outside the HIP layer's subset:\n" + sc.log())
     core = sc.hip()
@@ -117,7 +137,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         core.trace_pass(args.spp_per_step)
-    reduce_accumulator(accum, dst=0)                              # the one RCCL exchange of the frame
+    if world > 1 and args.backend != "nccl":                       # rehearsal: gloo reduces host memory
+        host = accum.cpu()
+        reduce_accumulator(host, dst=0)
+        accum.copy_(host)
+    else:
+        reduce_accumulator(accum, dst=0)                          # the one RCCL exchange of the frame
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -125,8 +150,9 @@ def main():
 
     st = core.rays_stat()
     rays_local = int(st.extensionRays + st.shadowRays)
-    rays_total = all_reduce_scalar(rays_local, dev)
-    t_max = all_reduce_max(elapsed, dev)
+    cdev = dev if (world == 1 or args.backend == "nccl") else "cpu"
+    rays_total = all_reduce_scalar(rays_local, cdev)
+    t_max = all_reduce_max(elapsed, cdev)
     spp_total = args.steps * args.spp_per_step
     trace_bytes = float(bytes_per_spp[:, 0].sum()) * spp_total    # closest-hit launches of this rank in the timed region
     trace_s = st.traversalTimeMs * 1e-3
@@ -151,7 +177,8 @@ def main():
                        "spp_per_step": args.spp_per_step, "tile": args.tile, "partition": "image tiles, t %% %d" % world,
                        "rays": int(rays_total), "mean_radiance": float(img[..., :3].mean())},
             "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit BVH4 traversal)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("%s|%dx%d|d%d" % (os.path.basename(args.scene), w, h, depth)),
                          "launches": int(st.traceLaunches), "avg_launch_ms": st.traversalTimeMs / max(int(st.traceLaunches), 1),
                          "algorithmic_bytes_per_launch": trace_bytes / max(int(st.traceLaunches), 1)},
             "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "hit_light_sample": st.evalHitMs, "shadow": st.shadowTimeMs,
