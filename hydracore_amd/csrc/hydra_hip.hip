@@ -186,10 +186,10 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, const 
 
 // H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample; survivors are
 // compacted into M (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample)
-__global__ void __launch_bounds__(256) k_hit(SceneDev s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
-                                              uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
-                                              const HydraLiteHit* __restrict__ hits, MidState M,
-                                              float4* __restrict__ contrib, uint2* __restrict__ gens) {
+HK_DEV void k_hit_body(const SceneDev& s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
+                       uint32_t* __restrict__ shadowCount, int depth, int maxDepth, const PathState& S,
+                       const HydraLiteHit* __restrict__ hits, const MidState& M,
+                       float4* __restrict__ contrib, uint2* __restrict__ gens) {
   const int count = int(*countPtr);
   for (int base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const int i = base + threadIdx.x;
@@ -263,8 +263,18 @@ __global__ void __launch_bounds__(256) k_hit(SceneDev s, const uint32_t* __restr
   }
 }
 
+// W = minimum waves per SIMD the register allocator must leave room for (256-thread blocks): 3 => 152 VGPRs, no spills;
+// 4 => 128 VGPRs with a dozen spilled dwords but a third more waves to hide the dependent gathers (measured in DESIGN.md 6)
+template <int W>
+__global__ void __launch_bounds__(256, W) k_hit(SceneDev s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
+                                                 uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
+                                                 const HydraLiteHit* __restrict__ hits, MidState M,
+                                                 float4* __restrict__ contrib, uint2* __restrict__ gens) {
+  k_hit_body(s, countPtr, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
+}
+
 // S1 + S2 -- next-event shading and BSDF sampling of the next bounce (kernel_Shade, kernel_NextBounce)
-__global__ void __launch_bounds__(256) k_shade(SceneDev s, const uint32_t* __restrict__ countPtr, MidState M, PathState S) {
+HK_DEV void k_shade_body(const SceneDev& s, const uint32_t* __restrict__ countPtr, const MidState& M, const PathState& S) {
   const int count = int(*countPtr);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float4 dir4 = M.dir4[i], thr4 = M.thr4[i], acc4 = M.acc4[i];
@@ -314,6 +324,11 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev s, const uint32_t* __res
     S.acc4[i] = mk4(accum, isSpec ? 1.0f : 0.0f);
     S.rng2[i] = make_uint2(gen.x, gen.y);
   }
+}
+
+template <int W>
+__global__ void __launch_bounds__(256, W) k_shade(SceneDev s, const uint32_t* __restrict__ countPtr, MidState M, PathState S) {
+  k_shade_body(s, countPtr, M, S);
 }
 
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
@@ -417,6 +432,9 @@ struct hydra_hip_ctx {
   bool travCounters = false;
   int traceMode = 0;          // 0 = one ray per lane (k_trace/k_shadow, default: measured faster), 1 = persistent dynamic fetch (k_trace_dyn)
   int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
+  int shadeWaves = 4;         // launch-bounds variant of k_hit / k_shade (3, 4 or 5 waves per SIMD)
+  int shadeBlocksPerCU = 8;
+  int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
   DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris]
@@ -546,7 +564,7 @@ static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetc
 static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* pos4, const float4* dir4,
                            HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounter) {
   if (c->traceMode == 0 || perRay3 != nullptr || fetchCounter == nullptr) {
-    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, 16);
+    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->staticBlocksPerCU);
     if (perRay3 || totals5) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
     else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
     return;
@@ -559,7 +577,7 @@ static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* 
 static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* org4, const float4* dir4,
                           float* vis, unsigned long long* totals5, uint32_t* fetchCounter) {
   if (c->traceMode == 0 || fetchCounter == nullptr) {
-    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, 16);
+    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->staticBlocksPerCU);
     if (totals5) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
     else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
     return;
@@ -574,19 +592,27 @@ static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 // the per-bounce kernel sequence of one sub-pass: trace -> hit/emission/light-sample (+compaction) -> shadow -> shade
 static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int N, int maxDepth, PathState S, MidState M, HydraLiteHit* hits, uint32_t* live, uint32_t* shadowCnt,
                        float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
-  const int gWide = grid_for(c, N, 256, 8);
+  const int gWide = grid_for(c, N, 256, c->shadeBlocksPerCU);
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
     int a = mark();
     unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
     launch_closest(c, s, live + depth, 0, N, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + 2 * depth : nullptr);
     int b = mark();
-    hipLaunchKernelGGL(k_hit, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens);
+    switch (c->shadeWaves) {
+      case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
+      case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
+      default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
+    }
     int d = mark();
     if (depth + 1 < maxDepth) {
       launch_shadow(c, s, live + depth + 1, 0, N, M.shadowOrg, M.recC, M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + 2 * depth + 1 : nullptr);
       int e = mark();
-      hipLaunchKernelGGL(k_shade, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S);
+      switch (c->shadeWaves) {
+        case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
+        case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
+        default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
+      }
       int f = mark();
       if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
     }
@@ -903,6 +929,9 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   const std::string n(name);
   if (n == "trace_mode") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "trace_mode: 0 or 1"); c->traceMode = value; }
   else if (n == "trace_min_active") { if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_min_active: 0..64"); c->traceMinActive = value; }
+  else if (n == "shade_waves") { if (value < 3 || value > 5) return fail(c, HYDRA_HIP_EINVAL, "shade_waves: 3, 4 or 5"); c->shadeWaves = value; }
+  else if (n == "shade_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "shade_blocks_per_cu: 1..64"); c->shadeBlocksPerCU = value; }
+  else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
   else return fail(c, HYDRA_HIP_EINVAL, "set_option: unknown option " + n);
   return HYDRA_HIP_OK;

@@ -96,7 +96,8 @@ int hydra_hip_reset_perf_counters(hydra_hip_handle h);
 /* enable per-stage hipEvent timing inside trace_pass (event records only; they are resolved by get_rays_stat) */
 int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
 /* tuning knobs (do not change results): "trace_mode" 0 = one ray per lane (default), 1 = persistent kernels with dynamic
- * ray fetch; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12).
+ * ray fetch; "shade_waves" 3|4|5 = register budget variant of the hit/shade kernels (default 4); "shade_blocks_per_cu",
+ * "static_blocks_per_cu" = grid caps; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12).
  * The same knobs can be preset with HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment. */
 int hydra_hip_set_option(hydra_hip_handle h, const char* name, int value);
 /* algorithmic-work counters of the traversal kernels (roofline byte model).  While enabled, trace_pass

@@ -188,3 +188,21 @@ def test_oracle_traversal_matches_brute_force(t42_small):
     assert (hit_mask == bf_mask).mean() > 0.999
     both = hit_mask & bf_mask
     np.testing.assert_allclose(hits["t"][both], best_t[both], rtol=2e-4)
+
+
+def test_generated_atrium_scene_packs_textures_and_instances(atrium_small):
+    sc, b = atrium_small
+    assert sc.unsupported() == 0, sc.log()
+    g = b["globals"]
+    assert b["inst_matrices"].size // 16 == 173 and g[G_LIGHTS_NUM] == 1
+    tex_table = g[g[G_TEX_TABLE]:g[G_TEX_TABLE] + 3]
+    assert (tex_table >= 0).all()
+    hdr = b["textures"][tex_table[1] * 4: tex_table[1] * 4 + 4]
+    assert list(hdr) == [256, 256, 4, 4]                             # SWTextureHeader {w, h, channels, bpp}
+    found, insts = walk_bvh(b["bvh_nodes"], b["bvh_tris"])
+    assert sorted(insts) == list(range(173))
+    st = sc.bvh_stats()
+    assert st["triangles"] == sum(len(v) for v in found.values())
+    orc = make_oracle(b)
+    img, rays, _ = orc.render(2, seed=5)
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01 and rays > 2 * 96 * 54

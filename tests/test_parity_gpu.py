@@ -31,6 +31,16 @@ def gpu42(built):
     return core, b, make_oracle(b)
 
 
+@pytest.fixture(scope="module")
+def gpu_atrium(built):
+    """generated Sponza-class scene at reduced tessellation: textured materials, 173 instances, 3-level instancing depth"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
 def test_native_library_is_the_one_running(gpu224):
     core, _, _ = gpu224
     name = core.device_name()
@@ -62,10 +72,10 @@ def test_eye_rays(fix, request):
     np.testing.assert_allclose(dr[:, :3], rdr[:, :3], atol=2e-6)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium"])
 def test_closest_hit_bit_exact(fix, request):
     core, b, orc = request.getfixturevalue(fix)
-    pos4, dir4 = random_rays(65536, 21)
+    pos4, dir4 = random_rays(65536, 21) if fix != "gpu_atrium" else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
     hits, cnt = core.stage_trace(pos4, dir4, counters=True)
     ref, rcnt, _ = orc.trace(pos4, dir4, counters=True)
     assert (hits["primId"] == ref["primId"]).all()
@@ -127,7 +137,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -148,7 +158,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Procedural "atrium250k" scene (BASELINE.json configs[2]: Sponza-class, ~250 k triangles, deep BVH).
+
+Writes a HydraAPI scene library (statex_00001.xml + data/chunk_*.vsgf / .image4ub) -- the same on-disk format as the
+reference's hydra_app/tests/* fixtures -- so it goes through the same front end as the reference scenes.
+Everything is generated from one seed (20250213) with numpy; nothing is downloaded.
+
+    python tools/make_atrium.py /tmp/atrium250k            # full size (~249 k triangles incl. instances)
+    python tools/make_atrium.py /tmp/atrium_small --scale 0.25
+"""
+import argparse
+import os
+import struct
+
+import numpy as np
+
+SEED = 20250213
+
+
+def grid_indices(nu, nv):
+    """triangles of a (nu+1) x (nv+1) vertex grid, row-major in v"""
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (i * (nv + 1) + j).ravel()
+    b = a + (nv + 1)
+    tri = np.stack([a, b, a + 1, a + 1, b, b + 1], 1).reshape(-1, 3)
+    return tri.astype(np.int32)
+
+
+def finish_mesh(pos, uv, tri, mat):
+    """per-vertex smooth normals and tangents from the triangles"""
+    pos = pos.astype(np.float64)
+    fn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
+    nrm = np.zeros_like(pos)
+    for k in range(3):
+        np.add.at(nrm, tri[:, k], fn)
+    ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.where(ln > 1e-20, nrm / np.maximum(ln, 1e-20), np.array([[0.0, 1.0, 0.0]]))
+    ref = np.where(np.abs(nrm[:, 1:2]) < 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    tan = np.cross(ref, nrm)
+    tan /= np.maximum(np.linalg.norm(tan, axis=1, keepdims=True), 1e-20)
+    n = len(pos)
+    p4 = np.ones((n, 4), np.float32); p4[:, :3] = pos
+    n4 = np.zeros((n, 4), np.float32); n4[:, :3] = nrm
+    t4 = np.ones((n, 4), np.float32); t4[:, :3] = tan
+    return dict(pos=p4, norm=n4, tan=t4, uv=uv.astype(np.float32), idx=tri.astype(np.int32).ravel(), mat=np.asarray(mat, np.int32))
+
+
+def column(sides, rings, height=8.0, radius=0.45, flutes=16):
+    th = np.linspace(0, 2 * np.pi, sides + 1)
+    y = np.linspace(0, height, rings + 1)
+    T, Y = np.meshgrid(th, y, indexing="ij")
+    entasis = 1.0 - 0.12 * (Y / height) ** 2
+    R = radius * (1.0 + 0.05 * np.cos(flutes * T)) * entasis
+    pos = np.stack([R * np.cos(T), Y, R * np.sin(T)], -1).reshape(-1, 3)
+    uv = np.stack([T / (2 * np.pi) * 4.0, Y / height * 4.0], -1).reshape(-1, 2)
+    tri = grid_indices(sides, rings)[:, ::-1].copy()      # outward facing
+    ring_of_tri = (np.arange(len(tri)) // 2) % rings
+    mat = np.where((ring_of_tri < 2) | (ring_of_tri >= rings - 2), 1, 0)   # base / capital band in a second material
+    return finish_mesh(pos, uv, tri, mat)
+
+
+def arch(seg_u, seg_v, span=3.2, tube=0.22):
+    u = np.linspace(0, np.pi, seg_u + 1)
+    v = np.linspace(0, 2 * np.pi, seg_v + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    R = span * 0.5
+    cx, cy = R * np.cos(U), R * np.sin(U)
+    pos = np.stack([cx + tube * np.cos(V) * np.cos(U), cy + tube * np.cos(V) * np.sin(U), tube * np.sin(V)], -1).reshape(-1, 3)
+    uv = np.stack([U / np.pi * 3.0, V / (2 * np.pi)], -1).reshape(-1, 2)
+    tri = grid_indices(seg_u, seg_v)
+    return finish_mesh(pos, uv, tri, np.full(len(tri), 2))
+
+
+def pot(seg_t, seg_p):
+    t = np.linspace(0, 1, seg_p + 1)
+    prof_r = 0.18 + 0.22 * np.sin(np.pi * np.clip(t * 1.15, 0, 1)) ** 1.5
+    prof_y = 0.7 * t
+    th = np.linspace(0, 2 * np.pi, seg_t + 1)
+    T, P = np.meshgrid(th, np.arange(seg_p + 1), indexing="ij")
+    pos = np.stack([prof_r[P] * np.cos(T), prof_y[P], prof_r[P] * np.sin(T)], -1).reshape(-1, 3)
+    uv = np.stack([T / (2 * np.pi) * 2, t[P]], -1).reshape(-1, 2)
+    tri = grid_indices(seg_t, seg_p)[:, ::-1].copy()
+    return finish_mesh(pos, uv, tri, np.full(len(tri), 3))
+
+
+def floor(nx, nz, lx=40.0, lz=20.0, rng=None):
+    x = np.linspace(-lx / 2, lx / 2, nx + 1)
+    z = np.linspace(-lz / 2, lz / 2, nz + 1)
+    X, Z = np.meshgrid(x, z, indexing="ij")
+    Y = 0.03 * np.sin(1.7 * X) * np.cos(2.3 * Z) + 0.01 * np.sin(9.0 * X + 4.0 * Z)
+    pos = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    uv = np.stack([X / 2.0, Z / 2.0], -1).reshape(-1, 2)
+    tri = grid_indices(nx, nz)[:, ::-1].copy()            # +y up
+    cell = ((np.arange(len(tri)) // 2) // nz // max(nx // 20, 1) + (np.arange(len(tri)) // 2) % nz // max(nz // 10, 1)) % 2
+    return finish_mesh(pos, uv, tri, np.where(cell == 0, 4, 5))
+
+
+def curtain(nu, nv, width=4.0, height=6.0):
+    u = np.linspace(0, 1, nu + 1)
+    v = np.linspace(0, 1, nv + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    pos = np.stack([width * (U - 0.5), height * V, 0.25 * np.sin(14.0 * U) * (0.3 + 0.7 * (1 - V))], -1).reshape(-1, 3)
+    uv = np.stack([U * 2, V * 2], -1).reshape(-1, 2)
+    return finish_mesh(pos, uv, grid_indices(nu, nv), np.full(2 * nu * nv, 6))
+
+
+def room(lx=40.0, ly=10.0, lz=20.0):
+    hx, hz = lx / 2, lz / 2
+    quads = [  # inward-facing walls and ceiling (the floor is its own mesh)
+        ([-hx, 0, -hz], [-hx, 0, hz], [-hx, ly, hz], [-hx, ly, -hz]),
+        ([hx, 0, hz], [hx, 0, -hz], [hx, ly, -hz], [hx, ly, hz]),
+        ([-hx, 0, -hz], [-hx, ly, -hz], [hx, ly, -hz], [hx, 0, -hz]),
+        ([hx, 0, hz], [hx, ly, hz], [-hx, ly, hz], [-hx, 0, hz]),
+        ([-hx, ly, -hz], [-hx, ly, hz], [hx, ly, hz], [hx, ly, -hz]),
+    ]
+    pos, uv, tri = [], [], []
+    for q in quads:
+        b = len(pos)
+        pos += q
+        uv += [[0, 0], [4, 0], [4, 4], [0, 4]]
+        tri += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
+    m = finish_mesh(np.array(pos, float), np.array(uv, float), np.array(tri, np.int32), [7, 7, 7, 7, 8, 8, 8, 8, 9, 9])
+    return m
+
+
+def light_quad(hl, hw):
+    pos = np.array([[-hl, 0, -hw], [-hl, 0, hw], [hl, 0, hw], [hl, 0, -hw]], float)
+    m = finish_mesh(pos, np.array([[0, 0], [0, 1], [1, 1], [1, 0]], float), np.array([[0, 1, 2], [2, 3, 0]], np.int32), [10, 10])
+    m["norm"][:, :3] = [0, -1, 0]
+    return m
+
+
+def write_vsgf(path, m):
+    vn, tn = len(m["pos"]), len(m["idx"]) // 3
+    blobs = [m["pos"].tobytes(), m["norm"].tobytes(), m["tan"].tobytes(), m["uv"].tobytes(), m["idx"].tobytes(), m["mat"].tobytes()]
+    total = 24 + sum(len(b) for b in blobs)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<QIIII", total, vn, tn * 3, 0, 1))
+        for b in blobs:
+            f.write(b)
+    offs, o = [], 24
+    for b in blobs:
+        offs.append((o, len(b)))
+        o += len(b)
+    return vn, tn, total, offs
+
+
+def checker(n, c0, c1, cells=8):
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    m = ((i * cells // n) + (j * cells // n)) % 2
+    img = np.where(m[..., None] == 0, np.array(c0, np.uint8), np.array(c1, np.uint8)).astype(np.uint8)
+    noise = np.random.default_rng(SEED + n).integers(0, 24, (n, n, 1), dtype=np.uint8)
+    img = np.clip(img.astype(np.int32) - noise, 0, 255).astype(np.uint8)
+    return np.concatenate([img, np.full((n, n, 1), 255, np.uint8)], -1)
+
+
+def mat4(scale=1.0, yaw=0.0, t=(0, 0, 0), rot_x=0.0):
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    cx, sx = np.cos(rot_x), np.sin(rot_x)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    m = np.eye(4)
+    m[:3, :3] = ry @ rx * scale
+    m[:3, 3] = t
+    return " ".join("%.7g" % v for v in m.ravel()) + " "
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--scale", type=float, default=1.0, help="tessellation scale (1.0 ~ 249 k triangles)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    args = ap.parse_args()
+    s = np.sqrt(args.scale)
+    rng = np.random.default_rng(SEED)
+    out = args.out
+    os.makedirs(os.path.join(out, "data"), exist_ok=True)
+
+    def r(n, lo=2):
+        return max(lo, int(round(n * s)))
+    meshes = [("column", column(r(64, 8), r(32, 4))), ("arch", arch(r(32, 4), r(32, 4))), ("pot", pot(r(20, 4), r(10, 2))),
+              ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room()), ("light", light_quad(2.0, 0.5))]
+
+    # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
+    texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
+    xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
+    chunk = 0
+    for tid, (n, img) in enumerate(texs):
+        name = "data/chunk_%05d.image4ub" % chunk
+        with open(os.path.join(out, name), "wb") as f:
+            f.write(struct.pack("<II", n, n))
+            f.write(img.tobytes())
+        xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, n * n * 4, n, n))
+        chunk += 1
+    xml.append("</textures_lib>")
+
+    cols = rng.uniform(0.2, 0.8, (10, 3))
+    xml.append("<materials_lib>")
+    for mid in range(10):
+        c = "%.4f %.4f %.4f" % tuple(cols[mid])
+        if mid in (1, 8):      # lambert + phong blend
+            gloss = 0.5 if mid == 1 else 0.85
+            xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
+                       '<reflectivity brdf_type="phong"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" /></reflectivity></material>' % (mid, mid, c, gloss))
+        elif mid in (0, 4, 6):  # textured lambert
+            tex = {0: 1, 4: 1, 6: 2}[mid]
+            xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" />'
+                       '<texture id="%d" type="texref" /></diffuse></material>' % (mid, mid, c, tex))
+        else:
+            xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
+    xml.append("</materials_lib>")
+    xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
+               '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>\n</lights_lib>')
+    xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
+               '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
+
+    xml.append('<geometry_lib total_chunks="%d">' % (len(texs) + len(meshes)))
+    tri_counts = {}
+    for gid, (name, m) in enumerate(meshes):
+        loc = "data/chunk_%05d.vsgf" % chunk
+        vn, tn, total, offs = write_vsgf(os.path.join(out, loc), m)
+        tri_counts[gid] = tn
+        p = m["pos"][:, :3]
+        bbox = " ".join("%.6g" % v for v in (p[:, 0].min(), p[:, 0].max(), p[:, 1].min(), p[:, 1].max(), p[:, 2].min(), p[:, 2].max()))
+        xml.append('  <mesh id="%d" name="%s" type="vsgf" bytesize="%d" loc="%s" offset="0" vertNum="%d" triNum="%d" dl="0" path="" bbox="%s">' % (gid, name, total, loc, vn, tn, bbox))
+        for tag, typ, (o, sz), app in zip(("positions", "normals", "tangents", "texcoords", "indices", "matindices"),
+                                          ("array4f", "array4f", "array4f", "array2f", "array1i", "array1i"), offs,
+                                          ("vertex", "vertex", "vertex", "vertex", "tlist", "primitive")):
+            xml.append('    <%s type="%s" bytesize="%d" offset="%d" apply="%s" />' % (tag, typ, sz, o, app))
+        xml.append("  </mesh>")
+        chunk += 1
+    xml.append("</geometry_lib>")
+    xml.append('<render_lib>\n  <render_settings type="HydraModern" id="0"><width>%d</width><height>%d</height><method_primary>pathtracing</method_primary>'
+               '<trace_depth>8</trace_depth><diff_trace_depth>8</diff_trace_depth><maxRaysPerPixel>1024</maxRaysPerPixel></render_settings>\n</render_lib>' % (args.width, args.height))
+
+    inst, total_tris = [], 0
+
+    def add(mesh_id, matrix, extra=""):
+        nonlocal total_tris
+        inst.append('    <instance id="%d" mesh_id="%d" rmap_id="-1" scn_id="0" scn_sid="0" matrix="%s"%s />' % (len(inst), mesh_id, matrix, extra))
+        total_tris += tri_counts[mesh_id]
+    xs = np.linspace(-16.5, 16.5, 12)
+    for row_z in (-4.0, 4.0):
+        for x in xs:
+            add(0, mat4(t=(x, 0, row_z)))
+        for x0, x1 in zip(xs[:-1], xs[1:]):
+            add(1, mat4(t=((x0 + x1) / 2, 7.6, row_z), scale=(x1 - x0) / 3.2 * 0.98))
+    for _ in range(120):
+        add(2, mat4(scale=rng.uniform(0.8, 1.2), yaw=rng.uniform(0, 2 * np.pi), t=(rng.uniform(-18.5, 18.5), 0.02, rng.uniform(-9, 9))))
+    add(3, mat4())
+    for k, x in enumerate((-12.0, -4.0, 4.0, 12.0)):
+        add(4, mat4(t=(x, 1.8, -9.2 if k % 2 == 0 else 9.2), yaw=0.0 if k % 2 == 0 else np.pi))
+    add(5, mat4())
+    light_m = mat4(t=(2.0, 9.6, 0.0))
+    add(6, light_m, ' light_id="0" linst_id="0"')
+    xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
+    xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
+    xml += inst
+    xml.append("  </scene>\n</scenes>")
+    with open(os.path.join(out, "statex_00001.xml"), "w") as f:
+        f.write("\n".join(xml) + "\n")
+    print("atrium: %d instances, %d triangles (unique + instanced), %d unique" % (len(inst), total_tris, sum(tri_counts.values())))
+
+
+if __name__ == "__main__":
+    main()
