@@ -5,7 +5,7 @@
 // pass driver IntegratorCommon::DoPass (CPUExp_Integrators_Common.cpp:278-316).
 //
 // HBM layout (SoA, one entry per live path, all float4 so every lane moves 16 B per access):
-//   S.pos4  = ray origin xyz | pixel index         S.dir4 = ray direction xyz | ray flags
+//   S.pos4  = ray origin xyz | gid (see below)        S.dir4 = ray direction xyz | ray flags
 //   S.thr4  = path throughput xyz | prev BSDF pdf  S.acc4 = accumulated radiance xyz | prev-bounce-was-specular
 //   S.rng2  = RandomGen state
 // K_hit writes survivors densely into the M (mid) arrays via a wave-aggregated atomic, so the shadow and shade
@@ -53,18 +53,49 @@ HK_DEV int wave_compact_index(bool alive, uint32_t* counter) {
   return base + __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Segmented path queues.  One global "next free slot" word saturates at ~88 returning atomics per microsecond on MI355X
+// (MI355X_MICROARCH.md, dequeue row); with one atomic per wave that alone cost k_hit ~1 ms per sample at 1080p.  The
+// path arrays are therefore split into `nseg` segments of `cap` slots, every thread block works on exactly one segment
+// (block b -> segment b % nseg) and appends survivors to the SAME segment of the next queue through that segment's own
+// counter (counters sit HK_CSTRIDE words = 128 B apart).  A segment can never grow, so cap = its initial share is a hard
+// bound and memory use does not change; results are independent of the segmentation because accumulation is keyed by pixel.
+#define HK_CSTRIDE 32
+#define HK_MAX_SEG 64
+#define HK_CROW (HK_MAX_SEG * HK_CSTRIDE)   // words per counter row: one row per bounce, [segment] inside
+struct SegQ {
+  const uint32_t* counts;   // counts[seg * HK_CSTRIDE]; nullptr => countImm items in one segment
+  int countImm, nseg, cap;
+};
+struct SegIter { int seg, base, count, first, step; };
+HK_DEV SegIter segq_iter(const SegQ& q) {
+  SegIter it;
+  const int bps = int(gridDim.x) / q.nseg;            // blocks per segment (grid is a multiple of nseg)
+  it.seg = int(blockIdx.x) % q.nseg;
+  const int bis = int(blockIdx.x) / q.nseg;
+  it.count = (bis < bps) ? (q.counts ? int(q.counts[it.seg * HK_CSTRIDE]) : q.countImm) : 0;
+  it.base = it.seg * q.cap;
+  it.first = bis * int(blockDim.x) + int(threadIdx.x);
+  it.step = (bps > 0 ? bps : 1) * int(blockDim.x);
+  return it;
+}
+
 // ================================================================================================ kernels
 // P1 -- ray generation: IntegratorCommon::makeEyeRay (Common.cpp:347-359) for every owned pixel
-__global__ void k_raygen(SceneDev s, int n, const int* __restrict__ slotPixel, const uint2* __restrict__ gens, int w, int h, PathState S) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int pixel = slotPixel[i];
-    const uint2 g2 = gens[pixel];
+// slotGid[i] = stream * (w*h) + pixel: the index of the path's RandomGen state and of its contribution record
+__global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ slotGid, const uint2* __restrict__ gens, int w, int h, PathState S) {
+  const SegIter it = segq_iter(q);
+  const int npix = w * h;
+  for (int idx = it.first; idx < it.count; idx += it.step) {
+    const int i = it.base + idx;
+    const int gid = slotGid[i];
+    const int pixel = gid % npix;
+    const uint2 g2 = gens[gid];
     RandomGen gen; gen.x = g2.x; gen.y = g2.y;
     const float4 r = rndFloat4_Pseudo(gen);   // rndUniform(gen, -1, 1), crandom.h:617-620
     const float4 offs = make_float4(-1.0f + 2.0f * r.x, -1.0f + 2.0f * r.y, -1.0f + 2.0f * r.z, -1.0f + 2.0f * r.w);
     f3 pos, dir;
     MakeRandEyeRay(pixel % w, pixel / w, w, h, offs, s, pos, dir);
-    S.pos4[i] = mk4(pos, as_float(pixel));
+    S.pos4[i] = mk4(pos, as_float(gid));
     S.dir4[i] = mk4(dir, as_float(0));
     S.thr4[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // kernel_InitAccumData + makeInitialMisData (pdf = 1)
     S.acc4[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // isSpecular = 1
@@ -74,15 +105,16 @@ __global__ void k_raygen(SceneDev s, int n, const int* __restrict__ slotPixel, c
 
 // T1 -- closest hit for every live path (kernel_RayTrace)
 template <bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, SegQ q,
                                                            const float4* __restrict__ pos4, const float4* __restrict__ dir4,
                                                            HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3,
                                                            unsigned long long* __restrict__ totals5) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
-  const int count = countPtr ? int(*countPtr) : countImm;
+  const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+  for (int idx = it.first; idx < it.count; idx += it.step) {
+    const int i = it.base + idx;
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
     TravCounters c = {0, 0, 0, 0};
     const HydraLiteHit hit = hk_traverse<false, COUNT>(s.bvh, s.tris, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
@@ -97,14 +129,15 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, const uint
 
 // T2 -- any-hit visibility: origin xyz | t_far, direction xyz (kernel_ShadowTrace)
 template <bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, SegQ q,
                                                             const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis,
                                                             unsigned long long* __restrict__ totals5) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
-  const int count = countPtr ? int(*countPtr) : countImm;
+  const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+  for (int idx = it.first; idx < it.count; idx += it.step) {
+    const int i = it.base + idx;
     const float4 o = org4[i];
     float v = 0.0f;
     if (o.w >= 0.0f) {   // t_far < 0 marks "no light sample": shadow = 0 (PT_Loop.cpp:175-178)
@@ -127,12 +160,17 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, const uin
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
 template <bool ANYHIT, bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, const uint32_t* __restrict__ countPtr, int countImm, uint32_t* __restrict__ fetchCounter,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
-                                                               unsigned long long* __restrict__ totals5, int minActive) {
+                                                               unsigned long long* __restrict__ totals5, int minActive, int raysPerLane) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
-  const int count = countPtr ? int(*countPtr) : countImm;
+  const SegIter it = segq_iter(q);
+  const int count = it.count, segBase = it.base;
+  // the live count is only known on the device: when it is small, let only the first blocks of the segment take part so
+  // that every lane still gets ~raysPerLane rays to refill from (a thinly spread queue degenerates to one ray per lane)
+  if ((int(blockIdx.x) / q.nseg) * (HK_TRACE_BLOCK * raysPerLane) >= count) return;
+  uint32_t* fetchCounter = fetchCounters + it.seg * HK_CSTRIDE;
   HkStack st;
   st.init(ldsStack, threadIdx.x);
   TravState t;
@@ -152,15 +190,15 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, const 
         if (!busy) {
           const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
           if (idx < count) {
-            const float4 a = a4[idx];
+            const float4 a = a4[segBase + idx];
             HydraLiteHit h = hk_miss_hit();
             bool skip = false;
             if (ANYHIT) { h.t = a.w; skip = (a.w < 0.0f); }   // t_far < 0: no light sample => shadow = 0
-            if (skip) outVis[idx] = 0.0f;
+            if (skip) outVis[segBase + idx] = 0.0f;
             else {
-              trav_init(t, xyz(a), xyz(b4[idx]), h);
+              trav_init(t, xyz(a), xyz(b4[segBase + idx]), h);
               if (COUNT) { c.quads = c.insts = c.tris = c.leaves = 0; }
-              rayIdx = idx;
+              rayIdx = segBase + idx;
               busy = true;
             }
           }
@@ -186,20 +224,24 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, const 
 
 // H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample; survivors are
 // compacted into M (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample)
-HK_DEV void k_hit_body(const SceneDev& s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
-                       uint32_t* __restrict__ shadowCount, int depth, int maxDepth, const PathState& S,
+HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ nextCounts,
+                       uint32_t* __restrict__ shadowCounts, int depth, int maxDepth, const PathState& S,
                        const HydraLiteHit* __restrict__ hits, const MidState& M,
                        float4* __restrict__ contrib, uint2* __restrict__ gens) {
-  const int count = int(*countPtr);
-  for (int base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-    const int i = base + threadIdx.x;
+  const SegIter it = segq_iter(q);
+  const int count = it.count;
+  uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
+  int shadowRaysOfWave = 0;   // statistic only: one atomic per wave at the end instead of one per iteration
+  for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {   // idx0 is block-uniform: every wave runs the ballots
+    const int idx = idx0 + int(threadIdx.x);
+    const int i = it.base + idx;
     bool alive = false;
     float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
     RandomGen gen; gen.x = gen.y = 0;
     SurfaceHit surf;
     float4 recC = pos4, recD = pos4, recE = pos4, shadowOrg = make_float4(0, 0, 0, -1.0f);
     bool wantShadow = false;
-    if (i < count) {
+    if (idx < count) {
       pos4 = S.pos4[i]; dir4 = S.dir4[i]; thr4 = S.thr4[i]; acc4 = S.acc4[i];
       const uint2 g2 = S.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
@@ -252,8 +294,8 @@ HK_DEV void k_hit_body(const SceneDev& s, const uint32_t* __restrict__ countPtr,
         recE = make_float4(lightPickProb, as_float(lightOffset), as_float(pixel), 0.0f);
       }
     }
-    const int dst = wave_compact_index(alive, nextCount);
-    (void)wave_compact_index(wantShadow, shadowCount);
+    const int dst = it.base + wave_compact_index(alive, nextCount);
+    shadowRaysOfWave += __popcll(__ballot(wantShadow));
     if (alive) {
       M.dir4[dst] = dir4; M.thr4[dst] = thr4; M.acc4[dst] = acc4; M.rng2[dst] = make_uint2(gen.x, gen.y);
       M.surfA[dst] = mk4(surf.pos, as_float(surf.matId));
@@ -261,22 +303,24 @@ HK_DEV void k_hit_body(const SceneDev& s, const uint32_t* __restrict__ countPtr,
       M.recC[dst] = recC; M.recD[dst] = recD; M.recE[dst] = recE; M.shadowOrg[dst] = shadowOrg;
     }
   }
+  if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
 }
 
 // W = minimum waves per SIMD the register allocator must leave room for (256-thread blocks): 3 => 152 VGPRs, no spills;
 // 4 => 128 VGPRs with a dozen spilled dwords but a third more waves to hide the dependent gathers (measured in DESIGN.md 6)
 template <int W>
-__global__ void __launch_bounds__(256, W) k_hit(SceneDev s, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ nextCount,
+__global__ void __launch_bounds__(256, W) k_hit(SceneDev s, SegQ q, uint32_t* __restrict__ nextCount,
                                                  uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
                                                  const HydraLiteHit* __restrict__ hits, MidState M,
                                                  float4* __restrict__ contrib, uint2* __restrict__ gens) {
-  k_hit_body(s, countPtr, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
+  k_hit_body(s, q, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
 }
 
 // S1 + S2 -- next-event shading and BSDF sampling of the next bounce (kernel_Shade, kernel_NextBounce)
-HK_DEV void k_shade_body(const SceneDev& s, const uint32_t* __restrict__ countPtr, const MidState& M, const PathState& S) {
-  const int count = int(*countPtr);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, const PathState& S) {
+  const SegIter it = segq_iter(q);
+  for (int idx = it.first; idx < it.count; idx += it.step) {
+    const int i = it.base + idx;
     const float4 dir4 = M.dir4[i], thr4 = M.thr4[i], acc4 = M.acc4[i];
     const float4 sa = M.surfA[i], sb = M.surfB[i], rc = M.recC[i], rd = M.recD[i], re = M.recE[i];
     const uint2 g2 = M.rng2[i];
@@ -327,28 +371,36 @@ HK_DEV void k_shade_body(const SceneDev& s, const uint32_t* __restrict__ countPt
 }
 
 template <int W>
-__global__ void __launch_bounds__(256, W) k_shade(SceneDev s, const uint32_t* __restrict__ countPtr, MidState M, PathState S) {
-  k_shade_body(s, countPtr, M, S);
+__global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M, PathState S) {
+  k_shade_body(s, q, M, S);
 }
 
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
-__global__ void k_accumulate(int n, const int* __restrict__ slotPixel, const float4* __restrict__ contrib, float4* __restrict__ accum) {
+// one thread per owned pixel adds the `streams` samples of this sub-pass in stream order, so the sum does not depend on
+// where the paths lived in the queues
+__global__ void k_accumulate(int n, const int* __restrict__ ownedPixels, const float4* __restrict__ contrib, float4* __restrict__ accum, int npix, int streams) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int pixel = slotPixel[i];
-    const float4 c = contrib[pixel];
+    const int pixel = ownedPixels[i];
     float4 a = accum[pixel];
-    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    for (int k = 0; k < streams; k++) {
+      const float4 c = contrib[size_t(k) * npix + pixel];
+      a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    }
     accum[pixel] = a;
   }
 }
-__global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __restrict__ shadowCnt, int maxDepth, unsigned long long* totals) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned long long e = 0, sh = 0;
-    for (int b = 0; b < maxDepth; b++) { e += live[b]; sh += shadowCnt[b]; }
-    totals[0] += e; totals[1] += sh; totals[2] += live[0];
+// counters are laid out [bounce][segment] with HK_CSTRIDE words between neighbours; one wave, lane = segment
+__global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __restrict__ shadowCnt, int maxDepth, int nseg, unsigned long long* totals) {
+  const int sg = int(threadIdx.x);
+  if (blockIdx.x != 0 || sg >= nseg) return;
+  unsigned long long e = 0, sh = 0;
+  for (int b = 0; b < maxDepth; b++) {
+    e += live[size_t(b) * HK_CROW + sg * HK_CSTRIDE];
+    sh += shadowCnt[size_t(b) * HK_CROW + sg * HK_CSTRIDE];
   }
+  atomicAdd(&totals[0], e); atomicAdd(&totals[1], sh); atomicAdd(&totals[2], (unsigned long long)live[sg * HK_CSTRIDE]);
 }
-__global__ void k_init_gens(int n, int seed, uint2* gens) {   // InitRandomGen, shaders/trace.cl:6-13 (slot = pixel)
+__global__ void k_init_gens(int n, int seed, uint2* gens) {   // InitRandomGen, shaders/trace.cl:6-13 (slot = stream * pixels + pixel)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const RandomGen g = RandomGenInit(seed + i);
     gens[i] = make_uint2(g.x, g.y);
@@ -418,7 +470,13 @@ struct hydra_hip_ctx {
 
   // render state
   int rank = 0, world = 1, tile = 64;
-  int N = 0;                         // owned pixels = path slots
+  int N = 0;                         // owned pixels = live paths at bounce 0
+  int streamsWanted = 0;             // option "samples_in_flight": samples per pixel traced concurrently, 0 = by resolution
+  int streams = 1;
+  DevBuf ownedPixels;                // the N owned pixels in slot order (k_accumulate)
+  int nsegWanted = 32;               // option "queue_segments"
+  int nseg = 1, segCap = 0;          // segmented path queues (see SegQ): nseg * segCap slots
+  DevBuf liveInit;                   // one counter row holding the initial per-segment path counts
   DevBuf slotPixel, gens, accumInternal, contrib, hits, live, shadowCnt, totals;
   float4* accum = nullptr;           // internal or external
   bool externalAccum = false;
@@ -430,7 +488,8 @@ struct hydra_hip_ctx {
 
   bool stageTiming = false;
   bool travCounters = false;
-  int traceMode = 0;          // 0 = one ray per lane (k_trace/k_shadow, default: measured faster), 1 = persistent dynamic fetch (k_trace_dyn)
+  int traceMode = 1;          // 1 = persistent dynamic fetch (k_trace_dyn, default: 8-35 % faster once the refill counters are per segment), 0 = one ray per lane
+  int traceRaysPerLane = 1;   // persistent kernels: blocks beyond count / (128 * this) leave at once
   int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
   int shadeWaves = 4;         // launch-bounds variant of k_hit / k_shade (3, 4 or 5 waves per SIMD)
   int shadeBlocksPerCU = 8;
@@ -509,6 +568,15 @@ static int grid_for(const hydra_hip_ctx* c, int n, int block, int blocksPerCU) {
   if (g > cap) g = cap;
   return g < 1 ? 1 : g;
 }
+// grid of a segmented-queue kernel: blocks-per-segment from the busiest possible segment, times nseg
+static int seg_grid(const hydra_hip_ctx* c, const SegQ& q, int block, int blocksPerCU) {
+  const int perSeg = q.counts ? q.cap : q.countImm;
+  int bps = (perSeg + block - 1) / block;
+  const int cap = std::max(1, c->numCU * blocksPerCU / q.nseg);
+  if (bps > cap) bps = cap;
+  return std::max(1, bps) * q.nseg;
+}
+static SegQ seg_q(const uint32_t* counts, int countImm, int nseg, int cap) { SegQ q; q.counts = counts; q.countImm = countImm; q.nseg = nseg; q.cap = cap; return q; }
 
 // slot -> pixel map: owned tiles (tile % world == rank), pixels inside a tile in 8x8 blocks so that one wave = one block
 static void build_slot_map(hydra_hip_ctx* c, std::vector<int>& out) {
@@ -527,15 +595,57 @@ static void build_slot_map(hydra_hip_ctx* c, std::vector<int>& out) {
     }
 }
 
+// samples per pixel in flight when the caller does not say: enough paths to keep late bounces (a few percent of the
+// paths survive to bounce 8) above the size where kernels stop scaling down, within ~10 GB of path state at 1080p.
+// Depends on the resolution only -- never on the rank count -- so every rank draws the same streams.
+static int auto_streams(size_t npix) {
+  int k = 1;
+  while (k < 16 && size_t(2 * k) * npix <= size_t(40) << 20) k *= 2;
+  return k;
+}
+
 static int alloc_render_state(hydra_hip_ctx* c) {
-  std::vector<int> slots;
-  build_slot_map(c, slots);
-  c->N = int(slots.size());
-  const size_t npix = size_t(c->w) * c->h, N = size_t(std::max(c->N, 1));
+  std::vector<int> order;
+  build_slot_map(c, order);
+  c->N = int(order.size());
+  const size_t npix = size_t(c->w) * c->h;
+  const int K = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(npix);
+  if (K != c->streams) c->gensReady = false;
+  c->streams = K;
+  if (size_t(K) * npix > size_t(0x7fffffff)) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight * width * height must stay below 2^31");
+  // Deal 256-slot chunks (four 8x8 pixel blocks) round-robin to the segments: every segment sees the whole image, so
+  // path-length differences between image regions do not unbalance them.  Inside a segment the slots of stream 0 come
+  // first, then stream 1, ...: a sub-pass that traces only `ns` streams starts from a dense prefix of every segment.
+  const int chunks = (c->N + 255) / 256;
+  c->nseg = std::max(1, std::min(std::min(c->nsegWanted, HK_MAX_SEG), chunks));
+  std::vector<std::vector<int>> segPixels(c->nseg);
+  for (int k = 0; k < chunks; k++) {
+    const int n = std::min(256, c->N - k * 256);
+    std::vector<int>& v = segPixels[k % c->nseg];
+    v.insert(v.end(), order.begin() + size_t(k) * 256, order.begin() + size_t(k) * 256 + n);
+  }
+  size_t perStream = 1;
+  for (const auto& v : segPixels) perStream = std::max(perStream, v.size());
+  const size_t cap = (perStream * K + 255) / 256 * 256;
+  if (cap * c->nseg > size_t(0x7fffffff)) return fail(c, HYDRA_HIP_EINVAL, "too many path slots");
+  c->segCap = int(cap);
+  std::vector<int> slots(size_t(c->nseg) * cap, -1);
+  std::vector<uint32_t> init(size_t(K) * HK_CROW, 0u);
+  for (int sg = 0; sg < c->nseg; sg++) {
+    const std::vector<int>& v = segPixels[sg];
+    for (int k = 0; k < K; k++) {
+      int* dst = slots.data() + size_t(sg) * cap + size_t(k) * v.size();
+      for (size_t j = 0; j < v.size(); j++) dst[j] = int(size_t(k) * npix + size_t(v[j]));
+      init[size_t(k) * HK_CROW + sg * HK_CSTRIDE] = uint32_t((k + 1) * v.size());   // row k: k + 1 streams live
+    }
+  }
+  const size_t N = slots.size();
   int rc;
   if ((rc = dev_upload(c, c->slotPixel, slots.data(), slots.size() * 4)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->gens, npix * 8)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->contrib, npix * 16)) != 0) return rc;
+  if ((rc = dev_upload(c, c->ownedPixels, order.data(), order.size() * 4)) != 0) return rc;
+  if ((rc = dev_upload(c, c->liveInit, init.data(), init.size() * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->gens, npix * K * 8)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->contrib, npix * K * 16)) != 0) return rc;
   if (!c->externalAccum) {
     const bool fresh = (c->accumInternal.bytes < npix * 16);
     if ((rc = dev_alloc(c, c->accumInternal, npix * 16)) != 0) return rc;
@@ -547,9 +657,9 @@ static int alloc_render_state(hydra_hip_ctx* c) {
   if ((rc = dev_alloc(c, c->sRng, N * 8)) != 0) return rc;
   if ((rc = dev_alloc(c, c->mRng, N * 8)) != 0) return rc;
   if ((rc = dev_alloc(c, c->mVis, N * 4)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->live, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->shadowCnt, (HK_MAX_DEPTH + 2) * 4)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->fetchCnt, (2 * HK_MAX_DEPTH + 4) * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->live, size_t(HK_MAX_DEPTH + 2) * HK_CROW * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->shadowCnt, size_t(HK_MAX_DEPTH + 2) * HK_CROW * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->fetchCnt, size_t(2 * HK_MAX_DEPTH + 4) * HK_CROW * 4)) != 0) return rc;
   if (c->totals.p == nullptr) {
     if ((rc = dev_alloc(c, c->totals, 4 * 8)) != 0) return rc;
     HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream));
@@ -559,59 +669,63 @@ static int alloc_render_state(hydra_hip_ctx* c) {
 }
 
 // ---- traversal launchers: one place decides between the one-ray-per-lane kernels and the persistent dynamic-fetch form
-static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetchCnt, (2 * HK_MAX_DEPTH + 4) * 4); }
+static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetchCnt, size_t(2 * HK_MAX_DEPTH + 4) * HK_CROW * 4); }
 
-static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* pos4, const float4* dir4,
-                           HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounter) {
-  if (c->traceMode == 0 || perRay3 != nullptr || fetchCounter == nullptr) {
-    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-    if (perRay3 || totals5) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, pos4, dir4, hits, perRay3, totals5);
+// `fetchCounters` is one zeroed counter row (HK_CROW words) for the persistent form, or nullptr to force the static form
+static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* pos4, const float4* dir4,
+                           HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounters) {
+  if (c->traceMode == 0 || perRay3 != nullptr || fetchCounters == nullptr) {
+    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    if (perRay3 || totals5) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, pos4, dir4, hits, perRay3, totals5);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, pos4, dir4, hits, perRay3, totals5);
     return;
   }
-  const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+  const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
   float4* out = reinterpret_cast<float4*>(hits);
-  if (totals5) hipLaunchKernelGGL((k_trace_dyn<false, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive);
-  else hipLaunchKernelGGL((k_trace_dyn<false, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive);
+  if (totals5) hipLaunchKernelGGL((k_trace_dyn<false, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive, c->traceRaysPerLane);
+  else hipLaunchKernelGGL((k_trace_dyn<false, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive, c->traceRaysPerLane);
 }
-static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const uint32_t* countPtr, int countImm, int nUpper, const float4* org4, const float4* dir4,
-                          float* vis, unsigned long long* totals5, uint32_t* fetchCounter) {
-  if (c->traceMode == 0 || fetchCounter == nullptr) {
-    const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-    if (totals5) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, org4, dir4, vis, totals5);
+static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* org4, const float4* dir4,
+                          float* vis, unsigned long long* totals5, uint32_t* fetchCounters) {
+  if (c->traceMode == 0 || fetchCounters == nullptr) {
+    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    if (totals5) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, org4, dir4, vis, totals5);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, org4, dir4, vis, totals5);
     return;
   }
-  const int g = grid_for(c, nUpper, HK_TRACE_BLOCK, c->traceBlocksPerCU);
-  if (totals5) hipLaunchKernelGGL((k_trace_dyn<true, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive);
-  else hipLaunchKernelGGL((k_trace_dyn<true, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, countPtr, countImm, fetchCounter, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive);
+  const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+  if (totals5) hipLaunchKernelGGL((k_trace_dyn<true, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive, c->traceRaysPerLane);
+  else hipLaunchKernelGGL((k_trace_dyn<true, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive, c->traceRaysPerLane);
 }
 
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 
 // the per-bounce kernel sequence of one sub-pass: trace -> hit/emission/light-sample (+compaction) -> shadow -> shade
-static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int N, int maxDepth, PathState S, MidState M, HydraLiteHit* hits, uint32_t* live, uint32_t* shadowCnt,
+// counters: live / shadowCnt / fetch are arrays of counter rows (HK_CROW words), row = bounce (fetch: 2*bounce + shadow)
+static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap, int maxDepth, PathState S, MidState M, HydraLiteHit* hits, uint32_t* live, uint32_t* shadowCnt,
                        float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
-  const int gWide = grid_for(c, N, 256, c->shadeBlocksPerCU);
+  const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
     int a = mark();
     unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
-    launch_closest(c, s, live + depth, 0, N, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + 2 * depth : nullptr);
+    const SegQ qIn = seg_q(live + size_t(depth) * HK_CROW, 0, nseg, segCap), qOut = seg_q(live + size_t(depth + 1) * HK_CROW, 0, nseg, segCap);
+    uint32_t* nextCnt = live + size_t(depth + 1) * HK_CROW, *shCnt = shadowCnt + size_t(depth) * HK_CROW;
+    launch_closest(c, s, qIn, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + size_t(2 * depth) * HK_CROW : nullptr);
     int b = mark();
     switch (c->shadeWaves) {
-      case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
-      case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
-      default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth, live + depth + 1, shadowCnt + depth, depth, maxDepth, S, hits, M, contrib, gens); break;
+      case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
+      case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
+      default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
     }
     int d = mark();
     if (depth + 1 < maxDepth) {
-      launch_shadow(c, s, live + depth + 1, 0, N, M.shadowOrg, M.recC, M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + 2 * depth + 1 : nullptr);
+      launch_shadow(c, s, qOut, M.shadowOrg, M.recC, M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
       int e = mark();
       switch (c->shadeWaves) {
-        case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
-        case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
-        default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, live + depth + 1, M, S); break;
+        case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
+        case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
+        default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
       }
       int f = mark();
       if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
@@ -651,7 +765,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->gens, &c->accumInternal,
+  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
@@ -783,8 +897,8 @@ int hydra_hip_init_path_tracing(hydra_hip_handle c, int seed) {
   HCHECK(hipSetDevice(c->device));
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   c->seed = seed;
-  const int npix = c->w * c->h;
-  hipLaunchKernelGGL(k_init_gens, dim3(grid_for(c, npix, 256, 8)), dim3(256), 0, c->stream, npix, seed, static_cast<uint2*>(c->gens.p));
+  const int ngen = c->w * c->h * c->streams;
+  hipLaunchKernelGGL(k_init_gens, dim3(grid_for(c, ngen, 256, 8)), dim3(256), 0, c->stream, ngen, seed, static_cast<uint2*>(c->gens.p));
   HCHECK(hipGetLastError());
   c->gensReady = true;
   return hydra_hip_clear_accumulated_color(c);
@@ -837,25 +951,27 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   uint32_t* live = static_cast<uint32_t*>(c->live.p);
   uint32_t* shadowCnt = static_cast<uint32_t*>(c->shadowCnt.p);
   HydraLiteHit* hits = static_cast<HydraLiteHit*>(c->hits.p);
-  const int N = c->N;
-  const int gWide = grid_for(c, N, 256, 8);
+  const SegQ q0 = seg_q(live, 0, c->nseg, c->segCap);
+  const int gWide = seg_grid(c, q0, 256, 8);
   const bool timing = c->stageTiming;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
 
-  for (int sub = 0; sub < spp; sub++) {
-    HCHECK(hipMemsetAsync(live, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
-    HCHECK(hipMemsetAsync(shadowCnt, 0, (HK_MAX_DEPTH + 2) * 4, c->stream));
-    HCHECK(hipMemsetAsync(c->fetchCnt.p, 0, (2 * HK_MAX_DEPTH + 4) * 4, c->stream));
-    HCHECK(hipMemcpyAsync(live, &c->N, 4, hipMemcpyHostToDevice, c->stream));
+  for (int done = 0; done < spp;) {
+    const int ns = std::min(c->streams, spp - done);   // samples per pixel traced concurrently in this sub-pass: streams 0..ns-1
+    done += ns;
+    HCHECK(hipMemsetAsync(live + HK_CROW, 0, size_t(maxDepth + 1) * HK_CROW * 4, c->stream));
+    HCHECK(hipMemsetAsync(shadowCnt, 0, size_t(maxDepth + 1) * HK_CROW * 4, c->stream));
+    if (c->traceMode != 0) HCHECK(hipMemsetAsync(c->fetchCnt.p, 0, size_t(2 * maxDepth + 2) * HK_CROW * 4, c->stream));
+    HCHECK(hipMemcpyAsync(live, static_cast<const uint32_t*>(c->liveInit.p) + size_t(ns - 1) * HK_CROW, size_t(HK_CROW) * 4, hipMemcpyDeviceToDevice, c->stream));
     int e0 = mark();
-    hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, N, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
+    hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, q0, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
     int e1 = mark();
     if (timing) c->spans.push_back({e0, e1, 0});
-    { int rc = run_bounces(c, s, N, maxDepth, S, M, hits, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
+    { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, S, M, hits, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
                            static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
     int g0 = mark();
-    hipLaunchKernelGGL(k_accumulate, dim3(gWide), dim3(256), 0, c->stream, N, static_cast<const int*>(c->slotPixel.p), static_cast<const float4*>(c->contrib.p), c->accum);
-    hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, static_cast<unsigned long long*>(c->totals.p));
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, c->w * c->h, ns);
+    hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, c->nseg, static_cast<unsigned long long*>(c->totals.p));
     int g1 = mark();
     if (timing) { c->spans.push_back({g0, g1, 5}); c->spans.push_back({e0, g1, 6}); }
     HCHECK(hipGetLastError());
@@ -933,7 +1049,31 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "shade_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "shade_blocks_per_cu: 1..64"); c->shadeBlocksPerCU = value; }
   else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
+  else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
+  else if (n == "samples_in_flight") {
+    if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight: 0 (by resolution) or 1..64");
+    if (value != c->streamsWanted) { c->streamsWanted = value; c->stateAllocated = false; }   // generators are re-seeded by the next init_path_tracing
+  }
+  else if (n == "queue_segments") {
+    if (value < 1 || value > HK_MAX_SEG) return fail(c, HYDRA_HIP_EINVAL, "queue_segments: 1..64");
+    if (value != c->nsegWanted) { c->nsegWanted = value; c->stateAllocated = false; }   // slot map is rebuilt by the next pass; accumulated image stays
+  }
   else return fail(c, HYDRA_HIP_EINVAL, "set_option: unknown option " + n);
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
+  if (!c || !name || !value) return HYDRA_HIP_EINVAL;
+  const std::string n(name);
+  if (n == "trace_mode") *value = c->traceMode;
+  else if (n == "trace_min_active") *value = c->traceMinActive;
+  else if (n == "trace_rays_per_lane") *value = c->traceRaysPerLane;
+  else if (n == "shade_waves") *value = c->shadeWaves;
+  else if (n == "shade_blocks_per_cu") *value = c->shadeBlocksPerCU;
+  else if (n == "static_blocks_per_cu") *value = c->staticBlocksPerCU;
+  else if (n == "trace_blocks_per_cu") *value = c->traceBlocksPerCU;
+  else if (n == "queue_segments") *value = c->nsegWanted;
+  else if (n == "samples_in_flight") *value = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(size_t(c->w) * c->h);
+  else return fail(c, HYDRA_HIP_EINVAL, "get_option: unknown option " + n);
   return HYDRA_HIP_OK;
 }
 int hydra_hip_enable_traversal_counters(hydra_hip_handle c, int enable) {
@@ -1003,9 +1143,9 @@ int hydra_hip_stage_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   if (rc) return rc;
   SceneDev s = make_scene(c);
   if ((rc = ensure_fetch_counters(c))) return rc;
-  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
   HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-  launch_closest(c, s, nullptr, n, n, dpos, ddir, dh, dc, nullptr, fetch);
+  launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, dc, nullptr, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(hits, dh, size_t(n) * 16, hipMemcpyDeviceToHost));
   if (counters3) HCHECK(hipMemcpy(counters3, dc, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -1022,9 +1162,9 @@ int hydra_hip_stage_shadow_trace(hydra_hip_handle c, int n, const float* ray_pos
   if (rc) return rc;
   SceneDev s = make_scene(c);
   if ((rc = ensure_fetch_counters(c))) return rc;
-  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
   HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-  launch_shadow(c, s, nullptr, n, n, dorg, ddir, dv, nullptr, fetch);
+  launch_shadow(c, s, seg_q(nullptr, n, 1, n), dorg, ddir, dv, nullptr, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(visibility, dv, size_t(n) * 4, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
@@ -1059,19 +1199,19 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   uint2* mRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
   uint2* gensOut = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
   float* vis = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
-  uint32_t* counters = (uint32_t*)tb.up(c, nullptr, size_t(4 * HK_MAX_DEPTH + 16) * 4, rc);
+  uint32_t* counters = (uint32_t*)tb.up(c, nullptr, size_t(4 * maxDepth + 8) * HK_CROW * 4, rc);
   if (rc) return rc;
   PathState S = {bufs[0], bufs[1], bufs[2], bufs[3], sRng};
   MidState M = {bufs[4], bufs[5], bufs[6], mRng, bufs[7], bufs[8], bufs[9], bufs[10], bufs[11], bufs[12], vis};
   HydraLiteHit* hits = reinterpret_cast<HydraLiteHit*>(bufs[13]);
   float4* contrib = bufs[14];
-  uint32_t* live = counters, *shadowCnt = counters + HK_MAX_DEPTH + 2, *fetch = counters + 2 * HK_MAX_DEPTH + 4;
-  HCHECK(hipMemsetAsync(counters, 0, size_t(4 * HK_MAX_DEPTH + 16) * 4, c->stream));
+  uint32_t* live = counters, *shadowCnt = counters + size_t(maxDepth + 2) * HK_CROW, *fetch = counters + size_t(2 * maxDepth + 4) * HK_CROW;
+  HCHECK(hipMemsetAsync(counters, 0, size_t(4 * maxDepth + 8) * HK_CROW * 4, c->stream));
   HCHECK(hipMemcpyAsync(live, &n, 4, hipMemcpyHostToDevice, c->stream));
   HCHECK(hipMemsetAsync(contrib, 0, size_t(n) * 16, c->stream));
   SceneDev s = make_scene(c);
   hipLaunchKernelGGL(k_stage_seed_paths, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dpos, ddir, drng, S);
-  rc = run_bounces(c, s, n, maxDepth, S, M, hits, live, shadowCnt, contrib, gensOut, fetch, false);
+  rc = run_bounces(c, s, 1, n, maxDepth, S, M, hits, live, shadowCnt, contrib, gensOut, fetch, false);
   if (rc) return rc;
   STAGE_EPILOG();
   HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));
@@ -1103,14 +1243,14 @@ int hydra_hip_bench_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   if (rc) return rc;
   SceneDev s = make_scene(c);
   if ((rc = ensure_fetch_counters(c))) return rc;
-  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + 2 * HK_MAX_DEPTH + 2;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
   hipEvent_t e0, e1;
   HCHECK(hipEventCreate(&e0));
   HCHECK(hipEventCreate(&e1));
   auto launch = [&]() {
     (void)hipMemsetAsync(fetch, 0, 4, c->stream);
-    if (shadow) launch_shadow(c, s, nullptr, n, n, dpos, ddir, reinterpret_cast<float*>(dh), nullptr, fetch);
-    else launch_closest(c, s, nullptr, n, n, dpos, ddir, dh, nullptr, nullptr, fetch);
+    if (shadow) launch_shadow(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, reinterpret_cast<float*>(dh), nullptr, fetch);
+    else launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, nullptr, nullptr, fetch);
   };
   launch();   // warm-up
   HCHECK(hipEventRecord(e0, c->stream));

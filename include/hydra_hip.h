@@ -95,11 +95,20 @@ int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
 int hydra_hip_reset_perf_counters(hydra_hip_handle h);
 /* enable per-stage hipEvent timing inside trace_pass (event records only; they are resolved by get_rays_stat) */
 int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
-/* tuning knobs (do not change results): "trace_mode" 0 = one ray per lane (default), 1 = persistent kernels with dynamic
- * ray fetch; "shade_waves" 3|4|5 = register budget variant of the hit/shade kernels (default 4); "shade_blocks_per_cu",
- * "static_blocks_per_cu" = grid caps; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12).
- * The same knobs can be preset with HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment. */
+/* Options.
+ * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
+ * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12);
+ * "trace_rays_per_lane"; "shade_waves" 3|4|5 = register budget variant of the hit/shade kernels (default 4);
+ * "shade_blocks_per_cu", "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
+ * (default 32).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
+ * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..64, 0 = chosen from the resolution:
+ * 16 at 1080p).  Sample j of a trace_pass(spp) call draws from generator stream j % K of its pixel, stream k of pixel p
+ * being RandomGenInit(seed + k * width * height + p) -- the per-slot seeding of the reference's wavefront layer
+ * (shaders/trace.cl:6-13) with K * width * height slots.  K = 1 gives one persistent generator per pixel.  Changing K
+ * restarts the image (generators are re-seeded).  K does not depend on the tile partition, so N ranks still sum to the
+ * 1-rank frame. */
 int hydra_hip_set_option(hydra_hip_handle h, const char* name, int value);
+int hydra_hip_get_option(hydra_hip_handle h, const char* name, int* value);   /* "samples_in_flight" returns the K in effect */
 /* algorithmic-work counters of the traversal kernels (roofline byte model).  While enabled, trace_pass
  * uses the counting kernel variants (slower).  out = max_depth x 2 x 5 uint64:
  * [bounce][0 = closest-hit | 1 = shadow][rays, quads visited, instance quads entered, leaves visited, triangles tested] */

@@ -136,15 +136,20 @@ class Oracle:
         self.lib.orc_init_generators(self.w, self.h, seed, _p(g))
         return g
 
-    def render(self, spp, seed=777, sum_mode=False, rank=0, world=1, tile=64, threads=0, gens=None, image=None, spp_done=0):
-        """spp passes of DoPass; returns (image float4 [h,w,4], rays traced, gens)."""
+    def render(self, spp, seed=777, sum_mode=False, rank=0, world=1, tile=64, threads=0, gens=None, image=None, spp_done=0, streams=1):
+        """spp passes of DoPass; returns (image float4 [h,w,4], rays traced, gens).
+        streams = K > 1 follows hydra_hip.h "samples_in_flight": sample j draws from generator stream j % K of its pixel,
+        stream k of pixel p being RandomGenInit(seed + k * w * h + p); gens is then a list of K state arrays."""
         if gens is None:
-            gens = self.init_generators(seed)
+            gens = [self.init_generators(seed + k * self.w * self.h) for k in range(streams)]
+            if streams == 1:
+                gens = gens[0]
+        glist = gens if isinstance(gens, list) else [gens]
         if image is None:
             image = np.zeros((self.h, self.w, 4), np.float32)
         rays = 0
         for k in range(spp):
-            rays += self.lib.orc_render_pass(C.byref(self.s), self.w, self.h, _p(gens), _p(image), spp_done + k, 1 if sum_mode else 0,
+            rays += self.lib.orc_render_pass(C.byref(self.s), self.w, self.h, _p(glist[k % len(glist)]), _p(image), spp_done + k, 1 if sum_mode else 0,
                                              rank, world, tile, threads)
         return image, int(rays), gens
 

@@ -107,20 +107,20 @@ def test_shadow_any_hit_equals_closest_hit_rule(gpu224):
 
 
 def test_persistent_traversal_kernels_give_identical_results(gpu224):
-    """trace_mode 1 (dynamic ray fetch, suspend/refill) must not change a single bit"""
+    """trace_mode 1 (dynamic ray fetch, suspend/refill, the default) and 0 (one ray per lane) must agree to the bit"""
     core, b, orc = gpu224
     pos4, dir4 = random_rays(50000, 77)
     tfar = np.random.default_rng(3).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
     ref, refvis = orc.trace(pos4, dir4), orc.shadow_trace(pos4, dir4, tfar)
     try:
-        for min_active in (0, 40, 64):
-            core.set_option("trace_mode", 1)
+        for mode, min_active in ((0, 40), (1, 0), (1, 40), (1, 64)):
+            core.set_option("trace_mode", mode)
             core.set_option("trace_min_active", min_active)
             hits = core.stage_trace(pos4, dir4)
-            assert (hits == ref).all(), min_active
-            assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), min_active
+            assert (hits == ref).all(), (mode, min_active)
+            assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active)
     finally:
-        core.set_option("trace_mode", 0)
+        core.set_option("trace_mode", 1)
         core.set_option("trace_min_active", 40)
 
 
@@ -168,7 +168,7 @@ def test_wavefront_pass_matches_oracle_image(fix, request):
     core.trace_pass(3)
     img = core.hdr_image(w, h)
     st = core.rays_stat()
-    ref, rays, _ = orc.render(3, seed=777, sum_mode=False)
+    ref, rays, _ = orc.render(3, seed=777, sum_mode=False, streams=core.samples_in_flight())
     assert st.samples == 3 * w * h
     assert abs(int(st.extensionRays + st.shadowRays) - rays) <= 0.002 * rays      # decisions may flip on a handful of paths
     err = np.abs(img[..., :3] - ref[..., :3])
@@ -179,6 +179,42 @@ def test_wavefront_pass_matches_oracle_image(fix, request):
     assert core.spp() == 3.0
     ldr = core.ldr_image(w, h)
     assert ldr.shape == (h, w) and (ldr >> 24 == 0).all()
+
+
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium"])
+def test_samples_in_flight_streams_follow_the_oracle(fix, request):
+    """K samples per pixel in flight: sample j of a call draws from generator stream j % K of its pixel.  Two calls
+    (2 then 5 samples, K = 4: sub-passes of 2 | 4 + 1 streams) against the oracle doing the same draws one by one."""
+    core, b, orc = request.getfixturevalue(fix)
+    w, h = b["width"], b["height"]
+    try:
+        core.set_option("samples_in_flight", 4)
+        assert core.samples_in_flight() == 4
+        core.set_tile_partition(0, 1, 64)
+        core.init_path_tracing(31)
+        core.reset_perf_counters()
+        core.trace_pass(2)
+        core.trace_pass(5)
+        img = core.hdr_image(w, h)
+        st = core.rays_stat()
+        ref, r1, gens = orc.render(2, seed=31, streams=4)
+        ref, r2, gens = orc.render(5, seed=31, streams=4, gens=gens, image=ref, spp_done=2)
+        assert st.samples == 7 * w * h and core.spp() == 7.0
+        assert abs(int(st.extensionRays + st.shadowRays) - (r1 + r2)) <= 0.002 * (r1 + r2)
+        err = np.abs(img[..., :3] - ref[..., :3])
+        bad = (err > 2e-4 * np.maximum(np.abs(ref[..., :3]), 1.0)).any(axis=2)
+        assert bad.mean() < 0.01, bad.mean()
+        # K = 1 is the one-generator-per-pixel sequence: a different (equally valid) set of samples
+        core.set_option("samples_in_flight", 1)
+        core.init_path_tracing(31)
+        core.trace_pass(7)
+        one = core.hdr_image(w, h)
+        ref1, _, _ = orc.render(7, seed=31, streams=1)
+        bad1 = (np.abs(one[..., :3] - ref1[..., :3]) > 2e-4 * np.maximum(np.abs(ref1[..., :3]), 1.0)).any(axis=2)
+        assert bad1.mean() < 0.01, bad1.mean()
+        assert (one != img).any()
+    finally:
+        core.set_option("samples_in_flight", 0)
 
 
 def test_tile_partition_is_exact_on_device(gpu224):
@@ -201,6 +237,29 @@ def test_tile_partition_is_exact_on_device(gpu224):
         acc += part
     assert (acc == full).all()
     core.set_tile_partition(0, 1, 64)
+
+
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium"])
+def test_queue_segmentation_does_not_change_the_image(fix, request):
+    """the segmented path queues only change where a path's record lives: images and ray counts are bit-identical for
+    1, 5 and 32 segments (1 = the single-queue layout the oracle-parity tests above also cover at this size)"""
+    core, b, _ = request.getfixturevalue(fix)
+    w, h = b["width"], b["height"]
+    outs = []
+    for nseg in (1, 5, 32):
+        core.set_option("queue_segments", nseg)
+        core.set_tile_partition(0, 1, 64)
+        core.init_path_tracing(4242)
+        core.reset_perf_counters()
+        core.trace_pass(2)
+        st = core.rays_stat()
+        outs.append((core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays), int(st.samples)))
+    core.set_option("queue_segments", 32)
+    for img, ext, sh, smp in outs[1:]:
+        assert (img.view(np.uint32) == outs[0][0].view(np.uint32)).all()
+        assert (ext, sh, smp) == outs[0][1:]
+    with pytest.raises(Exception):
+        core.set_option("queue_segments", 65)
 
 
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):

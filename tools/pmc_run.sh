@@ -1,0 +1,16 @@
+#!/bin/bash
+# Counter passes for the traversal kernels (GPU box).  Each --pmc set is its own rocprofv3 run (no trace domains mixed in).
+# The TA_*/TCP_* sets are left out on purpose: `--pmc TA_BUSY_avr TA_TA_BUSY_sum ...` made the HIP runtime abort inside
+# hipMemcpy under rocprofv3 on this pool and the run hung until the silence guard killed it.
+# usage: tools/pmc_run.sh <outdir under gpurun_out> [pass_bench args...]
+set -e
+OUT=$1; shift
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD" \
+           "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --output-format csv -d "$OUT/pass$i" -- python3 tools/pass_bench.py --spp 1 "$@" > "$OUT/pass$i.log" 2>&1
+done
+python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.csv"

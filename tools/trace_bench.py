@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--reorder", action="store_true", help="also time each ray set shuffled / sorted by origin cell / by direction octant + origin cell")
     ap.add_argument("--configs", default="0:0:16,1:0:12,1:24:12,1:32:12,1:40:12,1:48:12,1:56:12,1:40:8,1:40:16,1:40:24")
     args = ap.parse_args()
     from hydracore_amd import HipCore, HostScene
@@ -36,6 +37,31 @@ def main():
     for bounce in (0, 2):
         sets["shadow  b%d" % bounce] = orc.collect_rays(777, bounce, shadow=True) + (True,)
     print("ray sets collected in %.1f s: %s" % (time.time() - t0, {k: len(v[0]) for k, v in sets.items()}), flush=True)
+    if args.reorder:
+        def morton(p, bits):
+            lo, hi = p.min(axis=0), p.max(axis=0)
+            q = np.clip(((p - lo) / np.maximum(hi - lo, 1e-20) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+            key = np.zeros(len(p), np.int64)
+            for bit in range(bits):
+                for ax in range(3):
+                    key |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+            return key
+        rng = np.random.default_rng(1)
+        more = {}
+        for name, (pos, dr, tf, shadow) in sets.items():
+            if name.endswith("b0"):
+                continue
+            octant = (dr[:, 0] < 0).astype(np.int64) | ((dr[:, 1] < 0).astype(np.int64) << 1) | ((dr[:, 2] < 0).astype(np.int64) << 2)
+            orders = {"shuf": rng.permutation(len(pos)), "mort10": np.argsort(morton(pos[:, :3], 10), kind="stable"),
+                      "mort4": np.argsort(morton(pos[:, :3], 4), kind="stable"),
+                      "oct+m4": np.argsort((octant << 12) | morton(pos[:, :3], 4), kind="stable"),
+                      "m3+oct": np.argsort((morton(pos[:, :3], 3) << 3) | octant, kind="stable")}
+            # block-local variant: sort inside consecutive groups of 256 rays only (what a k_hit block could do in LDS)
+            g = np.arange(len(pos)) // 256
+            orders["blk256 oct"] = np.lexsort((octant, g))
+            for oname, o in orders.items():
+                more[name[:7] + name[-2:] + " " + oname] = (pos[o], dr[o], tf[o] if hasattr(tf, "__len__") else tf, shadow)
+        sets.update(more)
     core = HipCore(args.width, args.height)
     core.upload_scene(b)
     # algorithmic bytes per set from the per-ray counters (closest only)
@@ -60,7 +86,11 @@ def main():
             if name in byts:
                 cell += " %4.0fGB/s" % (byts[name] / ms / 1e6)
             cells.append(cell)
-        print("%-12s %8s | %s" % (cfg, "", " | ".join(cells)), flush=True)
+        if args.reorder:
+            for name, cell in zip(sets, cells):
+                print("%-12s %-24s %s" % (cfg, name, cell), flush=True)
+        else:
+            print("%-12s %8s | %s" % (cfg, "", " | ".join(cells)), flush=True)
 
 
 if __name__ == "__main__":
