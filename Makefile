@@ -6,8 +6,10 @@ HIPCC    ?= hipcc
 CXX      ?= g++
 CC       ?= gcc
 ARCH     ?= gfx950
-LIBDIR   := hydracore_amd/lib
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -shared
+LIBDIR   ?= hydracore_amd/lib
+# EXTRA_DEFS: compile-time tuning (-DHK_LDS_DEPTH=.. -DHK_TRACE_MIN_BLOCKS=..); LIBDIR can point at a variant directory
+EXTRA_DEFS ?=
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -shared $(EXTRA_DEFS)
 CXXFLAGS := -std=c++17 -O2 -Wall -Wextra -Wno-unused-parameter -fPIC
 HOSTSRC  := $(wildcard hydracore_amd/host/*.cpp)
 HOSTHDR  := $(wildcard hydracore_amd/host/*.h) $(wildcard include/*.h)

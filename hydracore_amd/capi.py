@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_dir():
-    return os.path.join(_HERE, "lib")
+    """in-tree build directory; HYDRA_AMD_LIB_DIR selects another build of the same two libraries (tuning A/B runs)"""
+    return os.environ.get("HYDRA_AMD_LIB_DIR") or os.path.join(_HERE, "lib")
 
 
 class HydraError(RuntimeError):

@@ -15,7 +15,9 @@
 #include "hk_common.h"
 
 #define HK_STACK_SIZE 80
+#ifndef HK_LDS_DEPTH
 #define HK_LDS_DEPTH 24
+#endif
 #define HK_TRACE_BLOCK 128
 
 struct TravCounters { uint32_t quads, insts, tris, leaves; };

@@ -27,6 +27,7 @@
 // ================================================================================================ device state
 struct PathState {   // S arrays
   float4* pos4; float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
+  float4* pend4;      // fused form only: throughput * unoccluded next-event estimate of the previous bounce xyz | unused
 };
 struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
   float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
@@ -40,6 +41,9 @@ struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
 };
 
 #define HK_MAX_DEPTH 64
+#ifndef HK_TRACE_MIN_BLOCKS
+#define HK_TRACE_MIN_BLOCKS 1   // resident 128-thread blocks per CU the traversal kernels are register-budgeted for
+#endif
 
 HK_DEV int wave_compact_index(bool alive, uint32_t* counter) {
   const unsigned long long mask = __ballot(alive);
@@ -105,7 +109,7 @@ __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ slotGid, co
 
 // T1 -- closest hit for every live path (kernel_RayTrace)
 template <bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, SegQ q,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(SceneDev s, SegQ q,
                                                            const float4* __restrict__ pos4, const float4* __restrict__ dir4,
                                                            HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3,
                                                            unsigned long long* __restrict__ totals5) {
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(SceneDev s, SegQ q,
 
 // T2 -- any-hit visibility: origin xyz | t_far, direction xyz (kernel_ShadowTrace)
 template <bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, SegQ q,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(SceneDev s, SegQ q,
                                                             const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis,
                                                             unsigned long long* __restrict__ totals5) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(SceneDev s, SegQ q,
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
 template <bool ANYHIT, bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
                                                                unsigned long long* __restrict__ totals5, int minActive, int raysPerLane) {
@@ -222,8 +226,103 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_dyn(SceneDev s, SegQ q
   }
 }
 
-// H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample; survivors are
-// compacted into M (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample)
+// ---- per-path phases shared by the split (k_hit + k_shade) and the fused (k_bounce) kernels
+struct LightPick {
+  f3 shadowRayDir, color;
+  float pdfSigned;       // light pdf, negative when the sample is a point light
+  float pickProb;
+  int lightOffset;       // < 0: no light sampled
+  float4 shadowOrg;      // shadow ray origin xyz | t_far (t_far < 0: no shadow ray)
+};
+
+// H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample
+// (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample).
+// Returns true when the path goes on (surf, lp, gen valid); false when it ended with radiance `finalColor`.
+HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
+                      const HydraLiteHit& hit, RandomGen& gen, SurfaceHit& surf, LightPick& lp, f3& finalColor) {
+  const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
+  const uint32_t flags = uint32_t(as_int(dir4.w));
+  f3 currColor = mk3(0, 0, 0);
+  bool done = false;
+  if (!HitSome(hit)) done = true;   // environmentColor: no sky light in the supported subset => black (cbidir.h:498-499)
+  else {
+    surf = evalSurface(s, ray_pos, ray_dir, hit);
+    const float* mat = materialAt(s, surf.matId);
+    const int lightOffset0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
+    const float* pLightHit = lightAt(s, lightOffset0);
+    const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
+    if (dot(emission, emission) > 1e-3f) {
+      if (pLightHit != nullptr) {
+        const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, length(ray_pos - surf.pos));
+        float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
+        if (acc4.w != 0.0f) misWeight = 1.0f;
+        currColor = emission * misWeight;
+      } else
+        currColor = emission;
+      done = true;
+    } else if (depth >= maxDepth - 1) done = true;
+  }
+  if (done) {
+    finalColor = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
+    return false;
+  }
+  const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
+  lp.pickProb = 1.0f;
+  lp.lightOffset = SelectRandomLightRev(rl.z, s, lp.pickProb);
+  lp.shadowRayDir = mk3(0, 0, 0);
+  lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
+  ShadowSample sam;
+  sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
+  if (lp.lightOffset >= 0) {
+    AreaLightSampleRev(lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // LightSampleRev, clight.h:1561-1610
+    lp.shadowRayDir = normalize(sam.pos - surf.pos);
+    const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, lp.shadowRayDir, surf.sRayOff);
+    lp.shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
+  }
+  lp.color = sam.color;
+  lp.pdfSigned = sam.isPoint ? -sam.pdf : sam.pdf;
+  return true;
+}
+
+// S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
+HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const f3 surfNormal, const f2 texCoord, const f3 ray_dir,
+                                  const f3 shadowRayDir, const f3 lightColor, const float pdfSigned, const float lightPickProb) {
+  ShadeContext sc;
+  sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = texCoord;
+  const BxDFResult ev = materialEval(mat, sc, s);
+  const float cos1 = fmaxf(+dot(shadowRayDir, surfNormal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surfNormal), 0.0f);
+  const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
+  const float samPdf = fabsf(pdfSigned);
+  float misWeight = misWeightHeuristic(samPdf * lightPickProb, ev.pdfFwd);
+  if (pdfSigned < 0.0f) misWeight = 1.0f;
+  const f3 lc = lightColor * (1.0f / fmaxf(samPdf, HK_DEPSILON2));
+  return ((lc * (1.0f / lightPickProb)) * bxdfVal) * misWeight;
+}
+
+// S2 -- BSDF sampling of the next bounce (kernel_NextBounce); `accum` is the radiance carried on
+HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
+                              const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
+  float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
+  {
+    const float4 r4 = rndFloat4_Pseudo(gen);
+    rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
+    for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
+  }
+  MatSample ms;
+  MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
+  const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
+  const float cosTheta = fabsf(dot(ms.direction, surf.normal));
+  const f3 newPos = OffsRayPos(surf.pos, surf.normal, ms.direction);
+  const bool isSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
+  flags = flagsNextBounceLite(flags, ms, s);
+  const f3 thr = xyz(thr4) * (bxdfVal * cosTheta);
+  oPos = mk4(newPos, gidBits);
+  oDir = mk4(ms.direction, as_float(int(flags)));
+  oThr = mk4(thr, ms.pdf);
+  oAcc = mk4(accum, isSpec ? 1.0f : 0.0f);
+}
+
+// Split form, kernel 1 of 2: hit phase, survivors compacted into M
 HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ nextCounts,
                        uint32_t* __restrict__ shadowCounts, int depth, int maxDepth, const PathState& S,
                        const HydraLiteHit* __restrict__ hits, const MidState& M,
@@ -239,68 +338,32 @@ HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ 
     float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
     RandomGen gen; gen.x = gen.y = 0;
     SurfaceHit surf;
-    float4 recC = pos4, recD = pos4, recE = pos4, shadowOrg = make_float4(0, 0, 0, -1.0f);
-    bool wantShadow = false;
+    LightPick lp;
+    lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
     if (idx < count) {
       pos4 = S.pos4[i]; dir4 = S.dir4[i]; thr4 = S.thr4[i]; acc4 = S.acc4[i];
       const uint2 g2 = S.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
       const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
-      const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
-      const uint32_t flags = uint32_t(as_int(dir4.w));
-      const int pixel = as_int(pos4.w);
-      f3 currColor = mk3(0, 0, 0);
-      bool done = false;
-      if (!HitSome(hit)) done = true;   // environmentColor: no sky light in the supported subset => black (cbidir.h:498-499)
-      else {
-        surf = evalSurface(s, ray_pos, ray_dir, hit);
-        const float* mat = materialAt(s, surf.matId);
-        const int lightOffset0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
-        const float* pLightHit = lightAt(s, lightOffset0);
-        const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
-        if (dot(emission, emission) > 1e-3f) {
-          if (pLightHit != nullptr) {
-            const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, length(ray_pos - surf.pos));
-            float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
-            if (acc4.w != 0.0f) misWeight = 1.0f;
-            currColor = emission * misWeight;
-          } else
-            currColor = emission;
-          done = true;
-        } else if (depth >= maxDepth - 1) done = true;
-      }
-      if (done) {
-        const f3 final = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
-        contrib[pixel] = mk4(final, 0.0f);
-        gens[pixel] = make_uint2(gen.x, gen.y);
-      } else {
-        alive = true;
-        const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
-        float lightPickProb = 1.0f;
-        const int lightOffset = SelectRandomLightRev(rl.z, s, lightPickProb);
-        f3 shadowRayDir = mk3(0, 0, 0);
-        ShadowSample sam;
-        sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
-        if (lightOffset >= 0) {
-          AreaLightSampleRev(lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // LightSampleRev, clight.h:1561-1610
-          shadowRayDir = normalize(sam.pos - surf.pos);
-          const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
-          shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
-          wantShadow = true;
-        }
-        recC = mk4(shadowRayDir, surf.texCoord.y);
-        recD = mk4(sam.color, sam.isPoint ? -sam.pdf : sam.pdf);
-        recE = make_float4(lightPickProb, as_float(lightOffset), as_float(pixel), 0.0f);
+      f3 finalColor;
+      alive = hit_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, gen, surf, lp, finalColor);
+      if (!alive) {
+        const int gid = as_int(pos4.w);
+        contrib[gid] = mk4(finalColor, 0.0f);
+        gens[gid] = make_uint2(gen.x, gen.y);
       }
     }
     const int dst = it.base + wave_compact_index(alive, nextCount);
-    shadowRaysOfWave += __popcll(__ballot(wantShadow));
+    shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
     if (alive) {
       M.dir4[dst] = dir4; M.thr4[dst] = thr4; M.acc4[dst] = acc4; M.rng2[dst] = make_uint2(gen.x, gen.y);
       M.surfA[dst] = mk4(surf.pos, as_float(surf.matId));
       M.surfB[dst] = mk4(surf.normal, surf.texCoord.x);
-      M.recC[dst] = recC; M.recD[dst] = recD; M.recE[dst] = recE; M.shadowOrg[dst] = shadowOrg;
+      M.recC[dst] = mk4(lp.shadowRayDir, surf.texCoord.y);
+      M.recD[dst] = mk4(lp.color, lp.pdfSigned);
+      M.recE[dst] = make_float4(lp.pickProb, as_float(lp.lightOffset), pos4.w, 0.0f);
+      M.shadowOrg[dst] = lp.shadowOrg;
     }
   }
   if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
@@ -316,7 +379,7 @@ __global__ void __launch_bounds__(256, W) k_hit(SceneDev s, SegQ q, uint32_t* __
   k_hit_body(s, q, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
 }
 
-// S1 + S2 -- next-event shading and BSDF sampling of the next bounce (kernel_Shade, kernel_NextBounce)
+// Split form, kernel 2 of 2 (after the shadow rays): next-event shading and BSDF sampling of the next bounce
 HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, const PathState& S) {
   const SegIter it = segq_iter(q);
   for (int idx = it.first; idx < it.count; idx += it.step) {
@@ -326,46 +389,15 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
     const uint2 g2 = M.rng2[i];
     RandomGen gen; gen.x = g2.x; gen.y = g2.y;
     const f3 ray_dir = xyz(dir4);
-    uint32_t flags = uint32_t(as_int(dir4.w));
     SurfaceHit surf;
     surf.pos = xyz(sa); surf.matId = as_int(sa.w); surf.normal = xyz(sb); surf.texCoord = mk2(sb.w, rc.w);
     const float* mat = materialAt(s, surf.matId);
-    const int lightOffset = as_int(re.y);
-    const float lightPickProb = re.x;
-
     f3 explicitColor = mk3(0, 0, 0);
-    if (lightOffset >= 0) {
-      const f3 shadowRayDir = xyz(rc);
-      ShadeContext sc;
-      sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
-      const BxDFResult ev = materialEval(mat, sc, s);
-      const float cos1 = fmaxf(+dot(shadowRayDir, surf.normal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surf.normal), 0.0f);
-      const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
-      const float samPdf = fabsf(rd.w);
-      float misWeight = misWeightHeuristic(samPdf * lightPickProb, ev.pdfFwd);
-      if (rd.w < 0.0f) misWeight = 1.0f;
-      const f3 lc = xyz(rd) * (1.0f / fmaxf(samPdf, HK_DEPSILON2));
-      explicitColor = (((lc * (1.0f / lightPickProb)) * bxdfVal) * misWeight) * M.vis[i];
-    }
-    float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
-    {
-      const float4 r4 = rndFloat4_Pseudo(gen);
-      rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
-      for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
-    }
-    MatSample ms;
-    MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
-    const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
-    const float cosTheta = fabsf(dot(ms.direction, surf.normal));
-    const f3 newPos = OffsRayPos(surf.pos, surf.normal, ms.direction);
-    const bool isSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
-    flags = flagsNextBounceLite(flags, ms, s);
+    if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];
     const f3 accum = xyz(acc4) + (xyz(thr4) * explicitColor);
-    const f3 thr = xyz(thr4) * (bxdfVal * cosTheta);
-    S.pos4[i] = mk4(newPos, re.z);
-    S.dir4[i] = mk4(ms.direction, as_float(int(flags)));
-    S.thr4[i] = mk4(thr, ms.pdf);
-    S.acc4[i] = mk4(accum, isSpec ? 1.0f : 0.0f);
+    float4 oPos, oDir, oThr, oAcc;
+    next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, accum, re.z, oPos, oDir, oThr, oAcc);
+    S.pos4[i] = oPos; S.dir4[i] = oDir; S.thr4[i] = oThr; S.acc4[i] = oAcc;
     S.rng2[i] = make_uint2(gen.x, gen.y);
   }
 }
@@ -373,6 +405,71 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
 template <int W>
 __global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M, PathState S) {
   k_shade_body(s, q, M, S);
+}
+
+// Fused form: one kernel per bounce does hit + light sample + unoccluded next-event estimate + BSDF sampling and writes
+// the next path state straight into the other S buffer.  The light term waits as `pend` = throughput * estimate until
+// the shadow kernel has produced vis; the NEXT k_bounce (which every survivor passes through) adds pend * vis first.
+// vis is 0 or 1, so acc + (thr * X) * vis has the bits of the split form's acc + thr * (X * vis).  Per path-bounce
+// this moves 228 B through HBM instead of 504 B and drops one launch (no M record).
+struct ShadowQ { float4* org4; float4* dir4; float* vis; };
+
+template <int W>
+__global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
+                                                    int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
+                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens) {
+  const SegIter it = segq_iter(q);
+  const int count = it.count;
+  uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
+  int shadowRaysOfWave = 0;
+  for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {
+    const int idx = idx0 + int(threadIdx.x);
+    const int i = it.base + idx;
+    bool alive = false;
+    float4 oPos = make_float4(0, 0, 0, 0), oDir = oPos, oThr = oPos, oAcc = oPos, oPend = oPos, oShDir = oPos;
+    RandomGen gen; gen.x = gen.y = 0;
+    LightPick lp;
+    lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
+    if (idx < count) {
+      const float4 pos4 = Sin.pos4[i], dir4 = Sin.dir4[i], thr4 = Sin.thr4[i];
+      float4 acc4 = Sin.acc4[i];
+      if (depth > 0) {   // settle the previous bounce's next-event estimate
+        const float4 pend = Sin.pend4[i];
+        const float vis = sh.vis[i];
+        acc4.x = acc4.x + pend.x * vis; acc4.y = acc4.y + pend.y * vis; acc4.z = acc4.z + pend.z * vis;
+      }
+      const uint2 g2 = Sin.rng2[i];
+      gen.x = g2.x; gen.y = g2.y;
+      const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
+      HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
+      SurfaceHit surf;
+      f3 finalColor;
+      alive = hit_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, gen, surf, lp, finalColor);
+      if (!alive) {
+        const int gid = as_int(pos4.w);
+        contrib[gid] = mk4(finalColor, 0.0f);
+        gens[gid] = make_uint2(gen.x, gen.y);
+      } else {
+        const float* mat = materialAt(s, surf.matId);
+        const f3 ray_dir = xyz(dir4);
+        f3 pend = mk3(0, 0, 0);
+        if (lp.lightOffset >= 0)
+          pend = xyz(thr4) * direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
+        oPend = mk4(pend, 0.0f);
+        oShDir = mk4(lp.shadowRayDir, 0.0f);
+        next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
+      }
+    }
+    const int dst = it.base + wave_compact_index(alive, nextCount);
+    shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
+    if (alive) {
+      Sout.pos4[dst] = oPos; Sout.dir4[dst] = oDir; Sout.thr4[dst] = oThr; Sout.acc4[dst] = oAcc;
+      Sout.rng2[dst] = make_uint2(gen.x, gen.y);
+      Sout.pend4[dst] = oPend;
+      sh.org4[dst] = lp.shadowOrg; sh.dir4[dst] = oShDir;
+    }
+  }
+  if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
 }
 
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
@@ -474,13 +571,15 @@ struct hydra_hip_ctx {
   int streamsWanted = 0;             // option "samples_in_flight": samples per pixel traced concurrently, 0 = by resolution
   int streams = 1;
   DevBuf ownedPixels;                // the N owned pixels in slot order (k_accumulate)
-  int nsegWanted = 32;               // option "queue_segments"
+  int nsegWanted = 8;                // option "queue_segments"
   int nseg = 1, segCap = 0;          // segmented path queues (see SegQ): nseg * segCap slots
   DevBuf liveInit;                   // one counter row holding the initial per-segment path counts
   DevBuf slotPixel, gens, accumInternal, contrib, hits, live, shadowCnt, totals;
   float4* accum = nullptr;           // internal or external
   bool externalAccum = false;
   DevBuf sPos, sDir, sThr, sAcc, sRng;
+  DevBuf tPos, tDir, tThr, tAcc, tRng, sPend, tPend, shDir;   // fused form: second S set (ping-pong), pending estimates, shadow directions
+  int fusedBounce = 1;               // option "fused_bounce": 1 = k_bounce, 0 = k_hit + k_shade with the M record
   DevBuf mDir, mThr, mAcc, mRng, mSurfA, mSurfB, mRecC, mRecD, mRecE, mShadowOrg, mVis;
   bool stateAllocated = false, gensReady = false;
   int seed = 777;
@@ -491,8 +590,8 @@ struct hydra_hip_ctx {
   int traceMode = 1;          // 1 = persistent dynamic fetch (k_trace_dyn, default: 8-35 % faster once the refill counters are per segment), 0 = one ray per lane
   int traceRaysPerLane = 1;   // persistent kernels: blocks beyond count / (128 * this) leave at once
   int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
-  int shadeWaves = 4;         // launch-bounds variant of k_hit / k_shade (3, 4 or 5 waves per SIMD)
-  int shadeBlocksPerCU = 8;
+  int shadeWaves = 3;         // launch-bounds variant of k_bounce / k_hit / k_shade (3, 4 or 5 waves per SIMD); 3 = no spills, measured fastest for the fused kernel
+  int shadeBlocksPerCU = 16;
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
@@ -652,10 +751,16 @@ static int alloc_render_state(hydra_hip_ctx* c) {
     if (fresh) HCHECK(hipMemsetAsync(c->accumInternal.p, 0, npix * 16, c->stream));
     c->accum = static_cast<float4*>(c->accumInternal.p);
   }
-  DevBuf* f4s[] = {&c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->mDir, &c->mThr, &c->mAcc, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->hits};
-  for (DevBuf* b : f4s) if ((rc = dev_alloc(c, *b, N * 16)) != 0) return rc;
+  // path state: only the arrays of the form in use are held (fused: 228 B per slot, split: 264 B)
+  DevBuf* common[] = {&c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->mShadowOrg, &c->hits};
+  DevBuf* fusedOnly[] = {&c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->sPend, &c->tPend, &c->shDir};
+  DevBuf* splitOnly[] = {&c->mDir, &c->mThr, &c->mAcc, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE};
+  for (DevBuf* b : common) if ((rc = dev_alloc(c, *b, N * 16)) != 0) return rc;
+  for (DevBuf* b : fusedOnly) { if (c->fusedBounce) { if ((rc = dev_alloc(c, *b, N * 16)) != 0) return rc; } else dev_free(*b); }
+  for (DevBuf* b : splitOnly) { if (!c->fusedBounce) { if ((rc = dev_alloc(c, *b, N * 16)) != 0) return rc; } else dev_free(*b); }
   if ((rc = dev_alloc(c, c->sRng, N * 8)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->mRng, N * 8)) != 0) return rc;
+  if (c->fusedBounce) { dev_free(c->mRng); if ((rc = dev_alloc(c, c->tRng, N * 8)) != 0) return rc; }
+  else { dev_free(c->tRng); if ((rc = dev_alloc(c, c->mRng, N * 8)) != 0) return rc; }
   if ((rc = dev_alloc(c, c->mVis, N * 4)) != 0) return rc;
   if ((rc = dev_alloc(c, c->live, size_t(HK_MAX_DEPTH + 2) * HK_CROW * 4)) != 0) return rc;
   if ((rc = dev_alloc(c, c->shadowCnt, size_t(HK_MAX_DEPTH + 2) * HK_CROW * 4)) != 0) return rc;
@@ -700,35 +805,60 @@ static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, co
 
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 
-// the per-bounce kernel sequence of one sub-pass: trace -> hit/emission/light-sample (+compaction) -> shadow -> shade
+// everything one sub-pass reads and writes besides the scene
+struct BounceBufs {
+  PathState A, B;      // A = current path state; B = the other S set (fused form only)
+  MidState M;          // split form only
+  ShadowQ sh;
+  HydraLiteHit* hits;
+};
+
+// the per-bounce kernel sequence of one sub-pass.  fused: trace -> k_bounce (+compaction) -> shadow;
+// split: trace -> k_hit (+compaction) -> shadow -> k_shade.
 // counters: live / shadowCnt / fetch are arrays of counter rows (HK_CROW words), row = bounce (fetch: 2*bounce + shadow)
-static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap, int maxDepth, PathState S, MidState M, HydraLiteHit* hits, uint32_t* live, uint32_t* shadowCnt,
+static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap, int maxDepth, BounceBufs bb, uint32_t* live, uint32_t* shadowCnt,
                        float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
+  const bool fused = c->fusedBounce != 0;
+  HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
     int a = mark();
     unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
     const SegQ qIn = seg_q(live + size_t(depth) * HK_CROW, 0, nseg, segCap), qOut = seg_q(live + size_t(depth + 1) * HK_CROW, 0, nseg, segCap);
     uint32_t* nextCnt = live + size_t(depth + 1) * HK_CROW, *shCnt = shadowCnt + size_t(depth) * HK_CROW;
+    const PathState S = bb.A;
     launch_closest(c, s, qIn, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + size_t(2 * depth) * HK_CROW : nullptr);
     int b = mark();
-    switch (c->shadeWaves) {
-      case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
-      case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
-      default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, M, contrib, gens); break;
+    if (fused) {
+      switch (c->shadeWaves) {
+        case 3: hipLaunchKernelGGL(k_bounce<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 5: hipLaunchKernelGGL(k_bounce<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        default: hipLaunchKernelGGL(k_bounce<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+      }
+      std::swap(bb.A, bb.B);
+    } else {
+      switch (c->shadeWaves) {
+        case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
+        case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
+        default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
+      }
     }
     int d = mark();
     if (depth + 1 < maxDepth) {
-      launch_shadow(c, s, qOut, M.shadowOrg, M.recC, M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
+      if (fused) launch_shadow(c, s, qOut, bb.sh.org4, bb.sh.dir4, bb.sh.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
+      else launch_shadow(c, s, qOut, bb.M.shadowOrg, bb.M.recC, bb.M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
       int e = mark();
-      switch (c->shadeWaves) {
-        case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
-        case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
-        default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, M, S); break;
+      if (timing) c->spans.push_back({d, e, 3});
+      if (!fused) {
+        switch (c->shadeWaves) {
+          case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
+          case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
+          default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
+        }
+        int f = mark();
+        if (timing) c->spans.push_back({e, f, 4});
       }
-      int f = mark();
-      if (timing) { c->spans.push_back({d, e, 3}); c->spans.push_back({e, f, 4}); }
     }
     if (timing) { c->spans.push_back({a, b, 1}); c->spans.push_back({b, d, 2}); }
   }
@@ -766,7 +896,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
-                   &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->mDir, &c->mThr, &c->mAcc,
+                   &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
@@ -944,13 +1074,17 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   if (c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: sky lights are not supported by the HIP layer yet");
 
   const SceneDev s = make_scene(c);
-  PathState S = {static_cast<float4*>(c->sPos.p), static_cast<float4*>(c->sDir.p), static_cast<float4*>(c->sThr.p), static_cast<float4*>(c->sAcc.p), static_cast<uint2*>(c->sRng.p)};
-  MidState M = {static_cast<float4*>(c->mDir.p), static_cast<float4*>(c->mThr.p), static_cast<float4*>(c->mAcc.p), static_cast<uint2*>(c->mRng.p),
-                static_cast<float4*>(c->mSurfA.p), static_cast<float4*>(c->mSurfB.p), static_cast<float4*>(c->mRecC.p), static_cast<float4*>(c->mRecD.p),
-                static_cast<float4*>(c->mRecE.p), static_cast<float4*>(c->mShadowOrg.p), static_cast<float*>(c->mVis.p)};
+  auto f4 = [](const DevBuf& b) { return static_cast<float4*>(b.p); };
+  const PathState S = {f4(c->sPos), f4(c->sDir), f4(c->sThr), f4(c->sAcc), static_cast<uint2*>(c->sRng.p), f4(c->sPend)};
+  BounceBufs bb;
+  bb.A = S;
+  bb.B = {f4(c->tPos), f4(c->tDir), f4(c->tThr), f4(c->tAcc), static_cast<uint2*>(c->tRng.p), f4(c->tPend)};
+  bb.M = {f4(c->mDir), f4(c->mThr), f4(c->mAcc), static_cast<uint2*>(c->mRng.p), f4(c->mSurfA), f4(c->mSurfB), f4(c->mRecC), f4(c->mRecD), f4(c->mRecE),
+          f4(c->mShadowOrg), static_cast<float*>(c->mVis.p)};
+  bb.sh = {f4(c->mShadowOrg), f4(c->shDir), static_cast<float*>(c->mVis.p)};
+  bb.hits = static_cast<HydraLiteHit*>(c->hits.p);
   uint32_t* live = static_cast<uint32_t*>(c->live.p);
   uint32_t* shadowCnt = static_cast<uint32_t*>(c->shadowCnt.p);
-  HydraLiteHit* hits = static_cast<HydraLiteHit*>(c->hits.p);
   const SegQ q0 = seg_q(live, 0, c->nseg, c->segCap);
   const int gWide = seg_grid(c, q0, 256, 8);
   const bool timing = c->stageTiming;
@@ -967,7 +1101,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, q0, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
     int e1 = mark();
     if (timing) c->spans.push_back({e0, e1, 0});
-    { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, S, M, hits, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
+    { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, bb, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
                            static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
     int g0 = mark();
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, c->w * c->h, ns);
@@ -1050,6 +1184,10 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
   else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
+  else if (n == "fused_bounce") {
+    if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "fused_bounce: 0 or 1");
+    if (value != c->fusedBounce) { (void)hipStreamSynchronize(c->stream); c->fusedBounce = value; c->stateAllocated = false; }
+  }
   else if (n == "samples_in_flight") {
     if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight: 0 (by resolution) or 1..64");
     if (value != c->streamsWanted) { c->streamsWanted = value; c->stateAllocated = false; }   // generators are re-seeded by the next init_path_tracing
@@ -1072,6 +1210,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "static_blocks_per_cu") *value = c->staticBlocksPerCU;
   else if (n == "trace_blocks_per_cu") *value = c->traceBlocksPerCU;
   else if (n == "queue_segments") *value = c->nsegWanted;
+  else if (n == "fused_bounce") *value = c->fusedBounce;
   else if (n == "samples_in_flight") *value = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(size_t(c->w) * c->h);
   else return fail(c, HYDRA_HIP_EINVAL, "get_option: unknown option " + n);
   return HYDRA_HIP_OK;
@@ -1193,7 +1332,7 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
   float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
   uint2* drng = (uint2*)tb.up(c, rng_state2, size_t(n) * 8, rc);
-  float4* bufs[15];
+  float4* bufs[22];
   for (auto& b : bufs) b = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
   uint2* sRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
   uint2* mRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
@@ -1201,9 +1340,15 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   float* vis = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
   uint32_t* counters = (uint32_t*)tb.up(c, nullptr, size_t(4 * maxDepth + 8) * HK_CROW * 4, rc);
   if (rc) return rc;
-  PathState S = {bufs[0], bufs[1], bufs[2], bufs[3], sRng};
-  MidState M = {bufs[4], bufs[5], bufs[6], mRng, bufs[7], bufs[8], bufs[9], bufs[10], bufs[11], bufs[12], vis};
-  HydraLiteHit* hits = reinterpret_cast<HydraLiteHit*>(bufs[13]);
+  uint2* tRng = (uint2*)tb.up(c, nullptr, size_t(n) * 8, rc);
+  if (rc) return rc;
+  const PathState S = {bufs[0], bufs[1], bufs[2], bufs[3], sRng, bufs[15]};
+  BounceBufs bb;
+  bb.A = S;
+  bb.B = {bufs[16], bufs[17], bufs[18], bufs[19], tRng, bufs[20]};
+  bb.M = {bufs[4], bufs[5], bufs[6], mRng, bufs[7], bufs[8], bufs[9], bufs[10], bufs[11], bufs[12], vis};
+  bb.sh = {bufs[12], bufs[21], vis};
+  bb.hits = reinterpret_cast<HydraLiteHit*>(bufs[13]);
   float4* contrib = bufs[14];
   uint32_t* live = counters, *shadowCnt = counters + size_t(maxDepth + 2) * HK_CROW, *fetch = counters + size_t(2 * maxDepth + 4) * HK_CROW;
   HCHECK(hipMemsetAsync(counters, 0, size_t(4 * maxDepth + 8) * HK_CROW * 4, c->stream));
@@ -1211,7 +1356,7 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   HCHECK(hipMemsetAsync(contrib, 0, size_t(n) * 16, c->stream));
   SceneDev s = make_scene(c);
   hipLaunchKernelGGL(k_stage_seed_paths, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dpos, ddir, drng, S);
-  rc = run_bounces(c, s, 1, n, maxDepth, S, M, hits, live, shadowCnt, contrib, gensOut, fetch, false);
+  rc = run_bounces(c, s, 1, n, maxDepth, bb, live, shadowCnt, contrib, gensOut, fetch, false);
   if (rc) return rc;
   STAGE_EPILOG();
   HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));
