@@ -104,7 +104,9 @@ struct SceneDev {
   const float4* geomStorage;
   const float4* pdfStorage;
   const float4* bvh;           // tree 0: 2 float4 per node, 8 per quad
+  unsigned      bvhBytes;      // size of the node array (< 4 GiB: the traversal kernels address it as a raw buffer)
   const float4* tris;          // tree 0 triangle lists
+  unsigned      trisBytes;
   int           haveInst;
   const float4* instMatrices;  // 4 float4 per instance (world -> object)
   const int*    instLightInstId;

@@ -62,15 +62,49 @@ struct HkStack {
   }
 };
 
+// How the traversal reads the node and triangle arrays.  Measured on MI355X (tools/micro/ta_bench.hip,
+// profiles/r01/ta_microbench_divergent_loads.log): when every lane reads its own 128-byte line, a 16-byte global_load
+// (64-bit address per lane) costs the CU's address path ~2.0 clk per lane even for the 2nd..8th piece of the same line,
+// while raw buffer loads (one 32-bit offset per lane + immediate piece offset) cost ~1.0 clk per lane.  The traversal
+// kernels are bound by exactly that path, so on the device both arrays are raw buffers.
+#ifdef HK_HOST_EMU
+struct BvhView {
+  const float4* nodes; const float4* tris;
+  HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
+  HK_DEV_MEMBER float4 tri(int index) const { return tris[index]; }
+};
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned) { BvhView v; v.nodes = nodes; v.tris = tris; return v; }
+#else
+typedef float hk_v4f __attribute__((ext_vector_type(4)));
+struct BvhView {
+  __amdgpu_buffer_rsrc_t nodes, tris;
+  HK_DEV_MEMBER float4 node(int quad, int piece) const {
+    const hk_v4f v = __builtin_bit_cast(hk_v4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, uint32_t(quad) * 128u + uint32_t(piece) * 16u, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  HK_DEV_MEMBER float4 tri(int index) const {
+    const hk_v4f v = __builtin_bit_cast(hk_v4f, __builtin_amdgcn_raw_buffer_load_b128(tris, uint32_t(index) * 16u, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+};
+// both sizes come from kernel arguments (wave-uniform), < 4 GiB each (checked by upload_bvh)
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes) {
+  BvhView v;
+  v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
+  v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
+  return v;
+}
+#endif
+
 template <bool ANYHIT, bool COUNT>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,
-                                  const float4* __restrict__ tris, int instId, bool useInstId, TravCounters& cnt) {
-  const float4 hdr = tris[leaf_offset];
+                                  const BvhView& bv, int instId, bool useInstId, TravCounters& cnt) {
+  const float4 hdr = bv.tri(leaf_offset);
   const int first = as_int(hdr.x), count = as_int(hdr.y);
   const int end = first + count * 3;
   if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; }
   for (int a = first; a < end; a += 3) {
-    const float4 d1 = tris[a], d2 = tris[a + 1], d3 = tris[a + 2];
+    const float4 d1 = bv.tri(a), d2 = bv.tri(a + 1), d3 = bv.tri(a + 2);
     const f3 A = xyz(d1), B = xyz(d2), C = xyz(d3);
     const f3 edge1 = B - A, edge2 = C - A;
     const f3 pvec = cross(ray_dir, edge2);
@@ -111,12 +145,12 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit) {
 // returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
 // traversing (minActive <= 0: never suspend).
 template <bool ANYHIT, bool COUNT>
-HK_DEV bool trav_run(TravState& t, const float4* __restrict__ bvh, const float4* __restrict__ tris, const bool haveInst,
+HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
                      const float t_rayMin, HkStack& stack, TravCounters& cnt, const int minActive) {
   while (t.top >= 0) {
     while (t.searching) {
-      const float4* q = bvh + size_t(t.left) * 8;
-      const float4 n0a = q[0], n0b = q[1], n1a = q[2], n1b = q[3], n2a = q[4], n2b = q[5], n3a = q[6], n3b = q[7];
+      const float4 n0a = bv.node(t.left, 0), n0b = bv.node(t.left, 1), n1a = bv.node(t.left, 2), n1b = bv.node(t.left, 3);
+      const float4 n2a = bv.node(t.left, 4), n2b = bv.node(t.left, 5), n3a = bv.node(t.left, 6), n3b = bv.node(t.left, 7);
       if (COUNT) cnt.quads++;
       int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
       const bool v0 = !((uint32_t(c0) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n0b.w)) == HYDRA_BVH_INVALID));
@@ -131,6 +165,12 @@ HK_DEV bool trav_run(TravState& t, const float4* __restrict__ bvh, const float4*
       float k3 = ((t3.x <= t3.y) && (t3.y >= t_rayMin) && (t3.x <= t.hit.t) && v3) ? t3.x : HK_MAXFLOAT;
 #define HK_CSWAP(ka, kb, ca, cb) { const bool sw = (kb < ka); const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; const int tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
       HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
+#ifdef HK_EXP_EXTRA_SORT   /* timing experiment: the network again on sorted keys changes nothing but costs its ~25 VALU instructions */
+      for (int rep = 0; rep < HK_EXP_EXTRA_SORT; rep++) {
+        asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
+        HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
+      }
+#endif
 #undef HK_CSWAP
       const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
       if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
@@ -146,23 +186,23 @@ HK_DEV bool trav_run(TravState& t, const float4* __restrict__ bvh, const float4*
     }
     if (!haveInst) {
       if (t.top >= 0) {
-        t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, tris, 0, false, cnt);
+        t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
         if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       }
       t.top--;
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 1) {
-      t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, tris, t.instId, true, cnt);
+      t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
       if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       t.top--;
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 0) {
       t.instDeep = 1;
       t.opos = t.pos; t.odir = t.dir;
-      const float4* q = bvh + size_t(t.left) * 8;
-      const int nextOffset = as_int(q[0].w);
-      const m44 matrix = load_m44(q + 2);
-      t.instId = as_int(q[6].x);
+      const int nextOffset = as_int(bv.node(t.left, 0).w);
+      m44 matrix;
+      matrix.c[0] = bv.node(t.left, 2); matrix.c[1] = bv.node(t.left, 3); matrix.c[2] = bv.node(t.left, 4); matrix.c[3] = bv.node(t.left, 5);
+      t.instId = as_int(bv.node(t.left, 6).x);
       if (COUNT) cnt.insts++;
       t.pos = mul4x3(matrix, t.pos);
       t.dir = mul3x3(matrix, t.dir);   // stays un-normalised so t keeps world units
@@ -181,11 +221,11 @@ HK_DEV bool trav_run(TravState& t, const float4* __restrict__ bvh, const float4*
 }
 
 template <bool ANYHIT, bool COUNT>
-HK_DEV HydraLiteHit hk_traverse(const float4* __restrict__ bvh, const float4* __restrict__ tris, const bool haveInst,
+HK_DEV HydraLiteHit hk_traverse(const BvhView& bv, const bool haveInst,
                                 f3 ray_pos, f3 ray_dir, const float t_rayMin, HydraLiteHit hit, HkStack& stack, TravCounters& cnt) {
   TravState t;
   trav_init(t, ray_pos, ray_dir, hit);
-  (void)trav_run<ANYHIT, COUNT>(t, bvh, tris, haveInst, t_rayMin, stack, cnt, 0);
+  (void)trav_run<ANYHIT, COUNT>(t, bv, haveInst, t_rayMin, stack, cnt, 0);
   return t.hit;
 }
 

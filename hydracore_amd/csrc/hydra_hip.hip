@@ -117,11 +117,12 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(S
   const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
     TravCounters c = {0, 0, 0, 0};
-    const HydraLiteHit hit = hk_traverse<false, COUNT>(s.bvh, s.tris, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
+    const HydraLiteHit hit = hk_traverse<false, COUNT>(bv, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
     reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
     if (COUNT && counters3) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
     if (COUNT && totals5) {   // algorithmic-work counters for the roofline byte model
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
   const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const float4 o = org4[i];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
       HydraLiteHit h = hk_miss_hit();
       h.t = o.w;
       TravCounters c = {0, 0, 0, 0};
-      h = hk_traverse<true, COUNT>(s.bvh, s.tris, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
+      h = hk_traverse<true, COUNT>(bv, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
       v = (h.primId != -1) ? 0.0f : 1.0f;
       if (COUNT && totals5) {
         atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
@@ -177,6 +179,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_d
   uint32_t* fetchCounter = fetchCounters + it.seg * HK_CSTRIDE;
   HkStack st;
   st.init(ldsStack, threadIdx.x);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
   TravState t;
   TravCounters c = {0, 0, 0, 0};
   int rayIdx = -1;
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_d
     }
     if (__ballot(busy) == 0ull) break;
     if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT>(t, s.bvh, s.tris, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+      const bool done = trav_run<ANYHIT, COUNT>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
       if (done) {
         if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
         else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
@@ -561,6 +564,7 @@ struct hydra_hip_ctx {
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, remapLists, remapTable, remapInst;
   size_t globalsWords = 0;
   int haveInst[4] = {0, 0, 0, 0};
+  size_t bvhNodeBytes[4] = {0, 0, 0, 0}, bvhTriBytes[4] = {0, 0, 0, 0};
   int treesNum = 0, instNum = 0;
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
@@ -647,6 +651,8 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.matStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_MATERIALS].p);
   s.pdfStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_PDFS].p);
   s.bvh = static_cast<const float4*>(c->bvhNodes[0].p);
+  s.bvhBytes = unsigned(c->bvhNodeBytes[0]);
+  s.trisBytes = unsigned(c->bvhTriBytes[0]);
   s.tris = static_cast<const float4*>(c->bvhTris[0].p);
   s.haveInst = c->haveInst[0];
   s.instMatrices = static_cast<const float4*>(c->instMat.p);
@@ -972,10 +978,15 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   if (alpha != nullptr && alpha_num > 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: alpha-tested trees are not supported by the HIP layer yet");
   if (tree != 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: only tree 0 is traversed by the HIP layer yet");
   HCHECK(hipSetDevice(c->device));
+  // the traversal kernels address both arrays as raw buffers with 32-bit byte offsets
+  if (size_t(nodes_num) * sizeof(HydraBVHNode) >= (size_t(1) << 32) || size_t(tri_f4_num) * 16 >= (size_t(1) << 32))
+    return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: node or triangle arrays of 4 GiB and more are not supported");
   int rc = dev_upload(c, c->bvhNodes[tree], nodes, size_t(nodes_num) * sizeof(HydraBVHNode));
   if (rc) return rc;
   rc = dev_upload(c, c->bvhTris[tree], tri_f4, size_t(tri_f4_num) * 16);
   if (rc) return rc;
+  c->bvhNodeBytes[tree] = size_t(nodes_num) * sizeof(HydraBVHNode);
+  c->bvhTriBytes[tree] = size_t(tri_f4_num) * 16;
   c->haveInst[tree] = have_inst ? 1 : 0;
   if (c->treesNum < tree + 1) c->treesNum = tree + 1;
   return HYDRA_HIP_OK;

@@ -49,10 +49,10 @@ void emu_trace(const EmuScene* e, int n, const float* pos4, const float* dir4, H
     if (anyhit) {
       HydraLiteHit h = hk_miss_hit();
       h.t = tfar[i];
-      h = hk_traverse<true, true>(s.bvh, s.tris, s.haveInst != 0, p, d, 0.0f, h, st, c);
+      h = hk_traverse<true, true>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, p, d, 0.0f, h, st, c);
       vis[i] = (h.primId != -1) ? 0.0f : 1.0f;
     } else
-      hits[i] = hk_traverse<false, true>(s.bvh, s.tris, s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c);
+      hits[i] = hk_traverse<false, true>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c);
     if (counters4) { counters4[4 * i] = c.quads; counters4[4 * i + 1] = c.insts; counters4[4 * i + 2] = c.tris; counters4[4 * i + 3] = c.leaves; }
   }
 }

@@ -11,7 +11,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
   uint32_t flags = 0;
   const int maxDepth = g_varsI(s)[HV_I_TRACE_DEPTH];
   for (int depth = 0; depth < maxDepth; depth++) {
-    const HydraLiteHit hit = hk_traverse<false, false>(s.bvh, s.tris, s.haveInst != 0, ray_pos, ray_dir, 0.0f, hk_miss_hit(), st, tc);
+    const HydraLiteHit hit = hk_traverse<false, false>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, ray_pos, ray_dir, 0.0f, hk_miss_hit(), st, tc);
     rays += 1.0f;
     if (!HitSome(hit)) { currColor = mk3(0, 0, 0); break; }
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
@@ -41,7 +41,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
       const f3 spos = OffsShadowRayPos(surf.pos, surf.normal, sdir, surf.sRayOff);
       HydraLiteHit sh = hk_miss_hit();
       sh.t = length(spos - sam.pos) * 0.995f;
-      sh = hk_traverse<true, false>(s.bvh, s.tris, s.haveInst != 0, spos, sdir, 0.0f, sh, st, tc);
+      sh = hk_traverse<true, false>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, spos, sdir, 0.0f, sh, st, tc);
       rays += 1.0f;
       const float shadow = (sh.primId != -1) ? 0.0f : 1.0f;
       ShadeContext sc;
