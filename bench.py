@@ -115,16 +115,17 @@ def main():
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)       # SetExternalImageAccumulator: reduced over RCCL
     core.set_external_accumulator(accum.data_ptr(), accum.numel() * 4)
     core.set_tile_partition(rank, world, args.tile)
-    sc.draw(passes=1, spp=1)          # first Draw: camera matrices, globals, InitPathTracing(seed), one pass
+    sc.draw(passes=1, spp=args.spp_per_step)   # first Draw: camera matrices, globals, InitPathTracing(seed), one pass of the step size
     max_depth = depth + 1
 
-    # algorithmic work per spp (counting kernels, outside the timed region)
+    # algorithmic work of one step (counting kernel variants, outside the timed region): the same number of samples per
+    # pixel through the same generator streams as a timed step, so rays/quads/triangles per step agree to ~0.1 %
     core.enable_traversal_counters(True)
-    core.trace_pass(1)
+    core.trace_pass(args.spp_per_step)
     core.finish()
     counters = core.traversal_counters(max_depth)
     core.enable_traversal_counters(False)
-    bytes_per_spp = traversal_bytes(counters)                     # [depth, 2]
+    bytes_per_step = traversal_bytes(counters)                    # [depth, 2]
 
     for _ in range(args.warmup):
         core.trace_pass(args.spp_per_step)
@@ -154,7 +155,7 @@ def main():
     rays_total = all_reduce_scalar(rays_local, cdev)
     t_max = all_reduce_max(elapsed, cdev)
     spp_total = args.steps * args.spp_per_step
-    trace_bytes = float(bytes_per_spp[:, 0].sum()) * spp_total    # closest-hit launches of this rank in the timed region
+    trace_bytes = float(bytes_per_step[:, 0].sum()) * args.steps  # closest-hit launches of this rank in the timed region
     trace_s = st.traversalTimeMs * 1e-3
     achieved = trace_bytes / trace_s / 1e9 if trace_s > 0 else 0.0
 
@@ -174,15 +175,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: Cornell-box-style test scene (reference hydra_app/tests/test_224, 25.6k-tri teapot), "
                                    "%dx%d, %d bounces, %d spp, PT (MIS) integrator" % (w, h, depth, spp_total),
-                       "spp_per_step": args.spp_per_step, "tile": args.tile, "partition": "image tiles, t %% %d" % world,
+                       "spp_per_step": args.spp_per_step, "samples_in_flight": core.samples_in_flight(), "tile": args.tile, "partition": "image tiles, t %% %d" % world,
                        "rays": int(rays_total), "mean_radiance": float(img[..., :3].mean())},
-            "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit BVH4 traversal)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_trace_dyn<false,false> (closest-hit BVH4 traversal, persistent form)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("%s|%dx%d|d%d" % (os.path.basename(args.scene), w, h, depth)),
+                         "traffic": pmc_traffic("%s|%dx%d|d%d|spp%d" % (os.path.basename(args.scene), w, h, depth, args.spp_per_step)),
                          "launches": int(st.traceLaunches), "avg_launch_ms": st.traversalTimeMs / max(int(st.traceLaunches), 1),
                          "algorithmic_bytes_per_launch": trace_bytes / max(int(st.traceLaunches), 1)},
-            "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "hit_light_sample": st.evalHitMs, "shadow": st.shadowTimeMs,
-                         "shade_next_bounce": st.shadeTimeMs, "accumulate": st.accumTimeMs, "pass_total": st.passTimeMs},
+            "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "bounce_hit_light_bsdf": st.evalHitMs, "shadow": st.shadowTimeMs,
+                         "shade_split_form_only": st.shadeTimeMs, "accumulate": st.accumTimeMs, "pass_total": st.passTimeMs},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.scene, depth)

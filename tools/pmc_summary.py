@@ -24,9 +24,10 @@ def main():
                     k = (short(row["Kernel_Name"]), row["Counter_Name"])
                     acc[k][0] += 1
                     acc[k][1] += float(row["Counter_Value"])
-    print("kernel,counter,launches,avg_per_launch,total")
+    w = csv.writer(sys.stdout, lineterminator="\n")
+    w.writerow(["kernel", "counter", "launches", "avg_per_launch", "total"])
     for (k, c), (n, tot) in sorted(acc.items()):
-        print("%s,%s,%d,%.3f,%.3f" % (k, c, n, tot / n, tot))
+        w.writerow([k, c, n, "%.3f" % (tot / n), "%.3f" % tot])
 
 
 if __name__ == "__main__":
