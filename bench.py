@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the MI355X wavefront path tracer on BASELINE.json configs[1]:
 Cornell-box-style test scene (tests/golden/scenes/test_224 = the reference's hydra_app/tests/test_224), 1920x1080,
-8 bounces, PT integrator; 256 spp = 16 steps x 16 spp by default.
+8 bounces, PT integrator; 256 spp = 4 steps x 64 spp by default.
 
-A "step" = one pass of the hot path: `--spp-per-step` samples for every pixel this rank owns (ray generation, up to 9
-closest-hit traversals, emission/light sampling with compaction, shadow traversals, shading, accumulate).  With N > 1
+A "step" = one pass of the hot path: `--spp-per-step` samples for every pixel this rank owns, all in flight at once
+(ray generation, then per bounce: closest-hit traversal, the fused hit/emission/light-sample/BSDF kernel with
+compaction, shadow traversal; finally accumulate).  With N > 1
 GPUs the image plane is tile-partitioned (weak work per step is fixed per pixel, the frame is split => "strong"
 scaling of one frame) and the float4 accumulator is reduced once over RCCL at the end of the timed region.
 
@@ -71,9 +72,9 @@ def cpu_baseline(scene, depth, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64, help="samples per pixel per step, all in flight at once (64 x 1080p = 133 M paths, 30 GB of path state)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--trace-depth", type=int, default=8)
@@ -115,6 +116,7 @@ def main():
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)       # SetExternalImageAccumulator: reduced over RCCL
     core.set_external_accumulator(accum.data_ptr(), accum.numel() * 4)
     core.set_tile_partition(rank, world, args.tile)
+    core.set_option("samples_in_flight", min(args.spp_per_step, 64))   # one sub-pass per step; same K on every rank
     sc.draw(passes=1, spp=args.spp_per_step)   # first Draw: camera matrices, globals, InitPathTracing(seed), one pass of the step size
     max_depth = depth + 1
 

@@ -23,7 +23,7 @@ fetch_kb, write_kb = rows[(k, "FETCH_SIZE")][1], rows[(k, "WRITE_SIZE")][1]
 hit, miss = rows[(k, "TCC_HIT_sum")][1], rows[(k, "TCC_MISS_sum")][1]
 acc_fetch = rows.get(("k_accumulate", "FETCH_SIZE"), (0, 0.0))[1]
 json.dump({
-    "workload_key": "test_224|1920x1080|d8|spp16",
+    "workload_key": "test_224|1920x1080|d8|spp64",
     "kernel": k,
     "source": "tools/pmc_traffic.sh: rocprofv3 --pmc, one counter group per run (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), "
               "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline; %d launches averaged (all bounces)" % rows[(k, "FETCH_SIZE")][0],
