@@ -153,10 +153,17 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       const float4 n2a = bv.node(t.left, 4), n2b = bv.node(t.left, 5), n3a = bv.node(t.left, 6), n3b = bv.node(t.left, 7);
       if (COUNT) cnt.quads++;
       int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
+#ifdef HK_HOST_EMU
       const bool v0 = !((uint32_t(c0) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n0b.w)) == HYDRA_BVH_INVALID));
       const bool v1 = !((uint32_t(c1) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n1b.w)) == HYDRA_BVH_INVALID));
       const bool v2 = !((uint32_t(c2) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n2b.w)) == HYDRA_BVH_INVALID));
       const bool v3 = !((uint32_t(c3) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n3b.w)) == HYDRA_BVH_INVALID));
+#else
+      // the device copy of the node array has the boxes of invalid children (both link words 0xFFFFFFFF, ctrace.h:889-892)
+      // overwritten with NaN by k_prepare_bvh at upload: every comparison below is then false for them, which is what the
+      // reference's IsValidNode term achieves -- 12 VALU instructions less per quad in a loop that is VALU-issue bound
+      const bool v0 = true, v1 = true, v2 = true, v3 = true;
+#endif
       const float2 t0 = RayBox(t.pos, t.inv, n0a, n0b), t1 = RayBox(t.pos, t.inv, n1a, n1b);
       const float2 t2 = RayBox(t.pos, t.inv, n2a, n2b), t3 = RayBox(t.pos, t.inv, n3a, n3b);
       float k0 = ((t0.x <= t0.y) && (t0.y >= t_rayMin) && (t0.x <= t.hit.t) && v0) ? t0.x : HK_MAXFLOAT;
@@ -172,10 +179,14 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       }
 #endif
 #undef HK_CSWAP
-      const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
-      if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
-      if (k2 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c2); t.top++; }
-      if (k1 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c1); t.top++; }
+      // keys are sorted and misses carry MAXFLOAT, so the children hit are a prefix: nothing is pushed unless k1 is a hit
+      // (same pushes, in the same order, as the three separate tests of ctrace.h:962-975)
+      if (k1 < HK_MAXFLOAT) {
+        const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
+        if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
+        if (k2 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c2); t.top++; }
+        if (stackHaveSpace) { stack.put(t.top, c1); t.top++; }
+      }
       if (k0 < HK_MAXFLOAT) t.left = c0;
       else if (t.top >= 0) { t.top--; t.left = stack.get(t.top); }
       t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);

@@ -500,6 +500,17 @@ __global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __res
   }
   atomicAdd(&totals[0], e); atomicAdd(&totals[1], sh); atomicAdd(&totals[2], (unsigned long long)live[sg * HK_CSTRIDE]);
 }
+// upload-time pass over the device copy of the node array: boxes of invalid children become NaN (see trav_run)
+__global__ void k_prepare_bvh(int nodes, float4* __restrict__ bvh) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nodes; i += gridDim.x * blockDim.x) {
+    float4 a = bvh[2 * size_t(i)], b = bvh[2 * size_t(i) + 1];
+    if (uint32_t(as_int(a.w)) == HYDRA_BVH_INVALID && uint32_t(as_int(b.w)) == HYDRA_BVH_INVALID) {
+      const float qnan = as_float(0x7fc00000);
+      a.x = a.y = a.z = qnan; b.x = b.y = b.z = qnan;
+      bvh[2 * size_t(i)] = a; bvh[2 * size_t(i) + 1] = b;
+    }
+  }
+}
 __global__ void k_init_gens(int n, int seed, uint2* gens) {   // InitRandomGen, shaders/trace.cl:6-13 (slot = stream * pixels + pixel)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const RandomGen g = RandomGenInit(seed + i);
@@ -986,6 +997,8 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   rc = dev_upload(c, c->bvhTris[tree], tri_f4, size_t(tri_f4_num) * 16);
   if (rc) return rc;
   c->bvhNodeBytes[tree] = size_t(nodes_num) * sizeof(HydraBVHNode);
+  hipLaunchKernelGGL(k_prepare_bvh, dim3(grid_for(c, nodes_num, 256, 8)), dim3(256), 0, c->stream, nodes_num, static_cast<float4*>(c->bvhNodes[tree].p));
+  HCHECK(hipGetLastError());
   c->bvhTriBytes[tree] = size_t(tri_f4_num) * 16;
   c->haveInst[tree] = have_inst ? 1 : 0;
   if (c->treesNum < tree + 1) c->treesNum = tree + 1;
