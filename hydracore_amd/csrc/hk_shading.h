@@ -673,6 +673,103 @@ HK_DEV int SelectRandomLightRev(float r, const SceneDev& s, float& pickProb) {  
   if (tableSize <= 2) return 0;
   return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.globals[HG_LSEL_REV_OFFS]), tableSize, pickProb);
 }
+// ---- sky dome light: constant colour or lat-long texture (clight.h:285-306, 308-364, 384-462; cfetch.h:259-296) ----
+#define HK_PI 3.14159265358979323846f   /* the pinned build of the reference compiles with -cl-single-precision-constant */
+HK_DEV f2 sphereMapTo2DTexCoord(f3 ray_dir, float& sinTheta) {   // cfetch.h:259-281
+  const float x = ray_dir.z, y = ray_dir.x, z = -ray_dir.y;
+  const float theta = acosf(z);
+  float phi = atan2f(y, x);
+  if (phi < 0.0f) phi += 2.0f * HK_PI;
+  const float texX = clampf(phi * 0.5f * HK_INV_PI, 0.0f, 1.0f);
+  const float texY = clampf(theta * HK_INV_PI, 0.0f, 1.0f);
+  sinTheta = sqrtf(1.0f - ray_dir.y * ray_dir.y);
+  return mk2(texX, texY);
+}
+HK_DEV f3 texCoord2DToSphereMap(f2 tc, float& sinThetaOut) {   // cfetch.h:283-296
+  const float phi = tc.x * 2.f * HK_PI, theta = tc.y * HK_PI;
+  const float sinTheta = sinf(theta);
+  const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosf(theta);
+  sinThetaOut = sinTheta;
+  return mk3(y, -z, x);
+}
+HK_DEV const float* pdfTableHeader(const SceneDev& s, int tableId) {   // cfetch.h:153-163
+  const int offset = s.globals[s.globals[HG_PDF_TABLE_OFFS] + tableId];
+  return reinterpret_cast<const float*>(s.pdfStorage + offset);
+}
+HK_DEV float evalMap2DPdf(f2 tc, const float* intervals, const int sizeX, const int sizeY) {   // clight.h:308-337
+  const float fw = float(sizeX), fh = float(sizeY);
+  if (tc.x < 0.0f || tc.x > 1.0f) tc.x -= float(int(tc.x));
+  if (tc.y < 0.0f || tc.x > 1.0f) tc.y -= float(int(tc.y));   // sic: the reference tests x twice
+  int pixelX = int(fw * tc.x - 0.5f), pixelY = int(fh * tc.y - 0.5f);
+  if (pixelX >= sizeX) pixelX = sizeX - 1;
+  if (pixelY >= sizeY) pixelY = sizeY - 1;
+  if (pixelX < 0) pixelX += sizeX;
+  if (pixelY < 0) pixelY += sizeY;
+  const int pixelOffset = pixelY * sizeX + pixelX, maxSize = sizeX * sizeY;
+  const int offset0 = (pixelOffset + 0 < maxSize + 0) ? pixelOffset + 0 : maxSize - 1;
+  const int offset1 = (pixelOffset + 1 < maxSize + 1) ? pixelOffset + 1 : maxSize;
+  return (intervals[offset1] - intervals[offset0]) * (fw * fh) / intervals[sizeX * sizeY];
+}
+HK_DEV float skyLightEvalPDF(const SceneDev& s, const float* L, f3 rayDir) {   // clight.h:339-364
+  const float* hdr = pdfTableHeader(s, as_int(L[HL_SKY_PDF_TABLE0]));
+  const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(rayDir, sintheta);
+  if (sintheta == 0.f) return 0.f;
+  const float* r0 = L + HL_SKY_MATRIX0;
+  const f2 tcT = mk2(r0[0] * tc.x + r0[1] * tc.y + r0[3], r0[4] * tc.x + r0[5] * tc.y + r0[7]);   // mul2x4, cfetch.h:642-648
+  const float mapPdf = evalMap2DPdf(tcT, hdr + 4, sizeX, sizeY);
+  return (mapPdf * 1.0f) / (2.f * HK_PI * HK_PI * fmaxf(fabsf(sintheta), HK_DEPSILON));
+}
+// skyLightGetIntensityTexturedENV without the Perez model (rejected at upload), clight.h:285-306
+HK_DEV f3 skyLightIntensity(const SceneDev& s, const float* L, f3 dir) {
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(dir, sintheta);
+  return lightColor(L) * sample2DExt(as_int(L[HL_COLOR_TEX_MATRIX]), tc, L + HL_SKY_SAMPLER0, s);
+}
+HK_DEV void SkyLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:427-462
+  const float* hdr = pdfTableHeader(s, as_int(L[HL_SKY_PDF_TABLE0]));
+  const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+  const float fw = float(sizeX), fh = float(sizeY);
+  float pdf = 1.0f;   // sampleMap2D, clight.h:378-403
+  int pixelOffset = SelectIndexPropToOpt(rands.z, hdr + 4, sizeX * sizeY + 1, pdf);
+  if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+  const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+  const float texX = (1.0f / fw) * ((float(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+  const float texY = (1.0f / fh) * ((float(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+  const float mapPdf = pdf * (fw * fh);
+  const m44 inv = load_m44(reinterpret_cast<const float4*>(L + HL_SKY_INV_MATRIX0));
+  const f3 tcT = mul4x3(inv, mk3(texX, texY, 0.0f));
+  float sintheta = 0.0f;
+  const f3 sampleDir = texCoord2DToSphereMap(mk2(tcT.x, tcT.y), sintheta);
+  const f3 samplePos = illum + sampleDir * g_varsF(s)[HV_F_BSPHERE_RADIUS];
+  const f3 txClr = sample2DExt(as_int(L[HL_COLOR_TEX_MATRIX]), mk2(tcT.x, tcT.y), L + HL_SKY_SAMPLER0, s);
+  out.isPoint = false;
+  out.pos = samplePos;
+  out.color = lightColor(L) * txClr;
+  out.pdf = (mapPdf * 1.0f) / (2.f * HK_PI * HK_PI * fmaxf(fabsf(sintheta), HK_DEPSILON));
+  out.maxDist = length(illum - samplePos);
+  out.cosAtLight = 1.0f;
+}
+// LightSampleRev, clight.h:1561-1610: the light types this layer accepts
+HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
+  if (as_int(L[HL_TYPE]) == HLT_SKY_DOME) SkyLightSampleRev(s, L, rands, illum, out);
+  else AreaLightSampleRev(L, rands, illum, out);
+}
+// environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)
+HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool prevSpecular, uint32_t flags) {
+  const int skyId = s.globals[HG_SKY_LIGHT_ID];
+  if (skyId == -1) return mk3(0, 0, 0);
+  const float* L = lightAt(s, skyId);
+  f3 envColor = skyLightIntensity(s, L, rayDir);
+  const uint32_t rayBounceNum = (flags >> 8) & 0xFFu;   // unpackBounceNum, cglobals.h:1330-1340
+  if (rayBounceNum > 0 && !(uint32_t(s.globals[HG_FLAGS]) & HF_STUPID_PT_MODE) && !prevSpecular) {
+    const float lgtPdf = L[HL_PICK_PROB_REV] * skyLightEvalPDF(s, L, rayDir);
+    envColor = envColor * misWeightHeuristic(prevPdf, lgtPdf);
+  }
+  return envColor;
+}
+
 // emissionEval, cbidir.h:653-678 (+ lightGetIntensity clight.h:1661-1706 for area lights)
 HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_dir, const SurfaceHit& sh, uint32_t flags, const float* pLight, const float* mat) {
   const f3 normal = sh.hfi ? sh.normal * (-1.0f) : sh.normal;

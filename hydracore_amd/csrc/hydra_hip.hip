@@ -247,7 +247,10 @@ HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& 
   const uint32_t flags = uint32_t(as_int(dir4.w));
   f3 currColor = mk3(0, 0, 0);
   bool done = false;
-  if (!HitSome(hit)) done = true;   // environmentColor: no sky light in the supported subset => black (cbidir.h:498-499)
+  if (!HitSome(hit)) {              // kernel_HitEnvironment, PT_Loop.cpp:23-33
+    currColor = environmentColor(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
+    done = true;
+  }
   else {
     surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
@@ -277,7 +280,7 @@ HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& 
   ShadowSample sam;
   sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
   if (lp.lightOffset >= 0) {
-    AreaLightSampleRev(lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // LightSampleRev, clight.h:1561-1610
+    LightSampleRev(s, lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // clight.h:1561-1610
     lp.shadowRayDir = normalize(sam.pos - surf.pos);
     const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, lp.shadowRayDir, surf.sRayOff);
     lp.shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
@@ -579,6 +582,7 @@ struct hydra_hip_ctx {
   int treesNum = 0, instNum = 0;
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
+  bool skyLightOk = true;            // false when the uploaded sky light needs a model this layer lacks
 
   // render state
   int rank = 0, world = 1, tile = 64;
@@ -967,6 +971,22 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
   HCHECK(hipSetDevice(c->device));
   c->globalsWords = words;
   c->hostHeader.assign(blob, blob + HG_TABLES_READY + 1);
+  // the sky light (if any) must be one this layer implements: constant colour or lat-long texture, no Perez model
+  c->skyLightOk = true;
+  const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
+  if (skyId != -1 && lightsNum > 0) {   // (before SetAllPODLights the header is still zero-initialised: nothing to check yet)
+    const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(skyId) * HL_FLOATS;
+    if (skyId < 0 || skyId >= lightsNum || at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId points outside the lights table");
+    if (blob[at + HL_TYPE] != HLT_SKY_DOME) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId does not name a sky light");
+    if (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ) c->skyLightOk = false;
+  }
+  for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone) and sky-dome lights only
+    const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
+    if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
+    const int type = blob[at + HL_TYPE];
+    if (type != HLT_AREA && type != HLT_SKY_DOME)
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area and sky-dome lights only");
+  }
   return dev_upload(c, c->globals, blob, words * 4);
 }
 int hydra_hip_update_globals_header(hydra_hip_handle c, const int32_t* blob, size_t words) {
@@ -1095,7 +1115,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
   const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
   if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: HRT_TRACE_DEPTH out of range");
-  if (c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: sky lights are not supported by the HIP layer yet");
+  if (!c->skyLightOk) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: the scene's sky light uses the Perez model, which the HIP layer does not implement");
 
   const SceneDev s = make_scene(c);
   auto f4 = [](const DevBuf& b) { return static_cast<float4*>(b.p); };
@@ -1350,7 +1370,7 @@ int hydra_hip_stage_eval_surface(hydra_hip_handle c, int n, const float* ray_pos
 int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, uint32_t* rng_state2, float* color4) {
   // n caller-provided primary rays + RandomGen states run through the PRODUCTION wavefront kernels (path i plays pixel i)
   STAGE_PROLOG(true);
-  if (c->hostHeader.size() > HG_SKY_LIGHT_ID && c->hostHeader[HG_SKY_LIGHT_ID] != -1) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: sky lights are not supported");
+  if (!c->skyLightOk) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: the scene's sky light uses the Perez model, which the HIP layer does not implement");
   const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
   if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: HRT_TRACE_DEPTH out of range");
   float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);

@@ -347,9 +347,64 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   return true;
 }
 
+// SkyDomeLight, hydra_drv/PlainLightConverter.cpp:909-1051 + RenderDriverRTE::UpdatePdfTablesForLight
+// (RenderDriverRTE_PdfTables.cpp:479-570).  Constant-colour sky only: a sky without texture gets the reference's 2x2
+// uniform luminance image as its sampling table; textured and Perez skies are counted as unsupported.
+bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) {
+  if (a_node->child("perez")) Unsupported("Perez sky model");
+  const XmlNode* inten = a_node->child("intensity");
+  const XmlNode* colorNode = xchild(inten, "color");
+  if (colorNode && colorNode->child("texture")) Unsupported("textured sky light (environment map)");
+  float3 color = read_value3f(colorNode);
+  color = color * read_value1f(xchild(inten, "multiplier"));   // HydraXMLHelpers::ReadLightIntensity
+
+  LightProto lp;
+  lp.plain.assign(HL_FLOATS, 0.0f);
+  float* d = lp.plain.data();
+  d[HL_PROB_MULT] = 1.0f;
+  d[HL_COLOR] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+  float* sam0 = d + HL_SKY_SAMPLER0;                       // SWTexSampler: flags, gamma, texId, dummy, row0, row1
+  put_i(sam0, HS_FLAGS, 0); sam0[HS_GAMMA] = 1.0f; put_i(sam0, HS_TEXID, int32_t(HYDRA_INVALID_TEXTURE)); put_i(sam0, HS_DUMMY, 0);
+  sam0[HS_ROW0] = 1.0f; sam0[HS_ROW1 + 1] = 1.0f;          // identity sampler matrix rows
+  memcpy(d + HL_SKY_SAMPLER1, sam0, 12 * sizeof(float));
+  put_i(d, HL_COLOR_TEX, int32_t(HYDRA_INVALID_TEXTURE));         // no texture ...
+  put_i(d, HL_COLOR_TEX_MATRIX, int32_t(HYDRA_INVALID_TEXTURE));  // ... and no sampler
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memcpy(d + HL_SKY_INV_MATRIX0, ident, 64);               // the reference writes both inverses to slot 0 (:947-948, 999-1000)
+  d[HL_SKY_COLOR_AUX] = color.x; d[HL_SKY_COLOR_AUX + 1] = color.y; d[HL_SKY_COLOR_AUX + 2] = color.z;
+  put_i(d, HL_SKY_COLOR_TEX_AUX, int32_t(HYDRA_INVALID_TEXTURE));
+  put_i(d, HL_SKY_COLOR_TEX_MATRIX_AUX, int32_t(HYDRA_INVALID_TEXTURE));
+  put_i(d, HL_SKY_AUX_TEX_MATRIX_INV, int32_t(HYDRA_INVALID_TEXTURE));
+  d[HL_SKY_SUN_DIR] = 0.0f; d[HL_SKY_SUN_DIR + 1] = -1.0f; d[HL_SKY_SUN_DIR + 2] = 0.0f;
+  d[HL_SKY_TURBIDITY] = 0.0f;
+  d[HL_SKY_SUN_COLOR] = 1.0f; d[HL_SKY_SUN_COLOR + 1] = 1.0f; d[HL_SKY_SUN_COLOR + 2] = 1.0f;
+  put_i(d, HL_SKY_SUN_DIR_ID, -1);
+  put_i(d, HL_TYPE, HLT_SKY_DOME);
+  put_i(d, HL_FLAGS, 0);
+
+  // pdf tables 0 and 1: header {w, h, 1, n + 1} + prefix sums of the 2x2 luminance image + a trailing 1.0
+  for (int t = 0; t < 2; t++) {
+    const int32_t tabId = m_pPdfStorage->GetMaxObjectId() + 1;
+    const float lum[4] = {0.25f, 0.25f, 0.25f, 0.25f};
+    std::vector<float> data(4 + 5 + 1);
+    put_i(data.data(), 0, 2); put_i(data.data(), 1, 2); put_i(data.data(), 2, 1); put_i(data.data(), 3, 5 + 1);
+    float acc = 0.0f;
+    for (int i = 0; i < 4; i++) { data[4 + i] = acc; acc += lum[i]; }
+    data[4 + 4] = acc;
+    data[9] = 1.0f;
+    m_pPdfStorage->Update(tabId, data.data(), data.size() * sizeof(float));
+    put_i(d, HL_SKY_PDF_TABLE0 + t, tabId);
+  }
+  lp.isDisk = false;
+  lp.isSky = true;
+  m_lights[a_lightId] = lp;
+  return true;
+}
+
 // AreaDiffuseLight, hydra_drv/PlainLightConverter.cpp:130-253
 bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   const std::string ltype = a_node->attr("type"), lshape = a_node->attr("shape"), distr = a_node->attr("distribution");
+  if (ltype == "sky") return UpdateSkyLight(a_lightId, a_node);
   if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
   if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
   if (xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1) Unsupported("sky portal");
@@ -553,6 +608,13 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
     memcpy(M.c, a_matrix + 16 * i, 64);
     std::vector<float> copy = it->second.plain;
     float* d = copy.data();
+    if (it->second.isSky) {                       // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
+      put_i(d, HL_GROUP_ID, a_lightGroupId);
+      d[HL_PICK_PROB_REV] = 1.0f;
+      d[HL_PICK_PROB_FWD] = 1.0f;
+      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
+      continue;
+    }
     const float3 lpos = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
     d[HL_POS] = lpos.x; d[HL_POS + 1] = lpos.y; d[HL_POS + 2] = lpos.z;
     const float3 ln = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
@@ -646,7 +708,7 @@ void RenderDriverLite::EndScene() {
       return acc;
     };
     const std::vector<float> tRev = prefix(rev), tFwd = prefix(fwd);
-    const float nRev = 1.0f / tRev.back(), nFwd = 1.0f / tFwd.back();
+    const float nRev = 1.0f / tRev.back(), nFwd = tFwd.back() > 0.0f ? 1.0f / tFwd.back() : 0.0f;   // a lone sky light has no forward sampler
     for (size_t i = 0; i < nl; i++) {
       m_lightsInstanced[i * HL_FLOATS + HL_PICK_PROB_FWD] *= nFwd;
       m_lightsInstanced[i * HL_FLOATS + HL_PICK_PROB_REV] *= nRev;
@@ -718,7 +780,7 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
   const auto lightInstNodes = scene->children_named("instance_light");
   const int lightInstNum = int(lightInstNodes.size());
 
-  AllocAll(imgNum, matNum, std::max(lightNum, lightInstNum), meshNum);
+  AllocAll(imgNum, matNum, std::max(lightNum, lightInstNum) + 4, meshNum);   // + room in the pdf-table table for the two tables of a sky light
 
   if (texLib)
     for (auto* t : texLib->children_named("texture")) {

@@ -165,12 +165,18 @@ enum {
   HL_AREA_SPOT_DISTR = 26, HL_AREA_SPOT_COS1 = 27, HL_AREA_SPOT_COS2 = 28, HL_AREA_SKY_OFFSET = 29,
   HL_AREA_SKY_SOURCE = 30, HL_AREA_SKYPORTAL_BTEX = 31, HL_AREA_SKYPORTAL_BTEX_MATRIX = 32,
   HL_AREA_SAMPLER0 = 40, HL_AREA_SAMPLER1 = 52,
+  /* sky dome (clight.h:131-165): pdf table ids, sampler (float4 + 2 matrix rows), inverse sampler matrix (float4x4) */
+  HL_SKY_COLOR_AUX = 17, HL_SKY_COLOR_TEX_AUX = 20, HL_SKY_COLOR_TEX_MATRIX_AUX = 21, HL_SKY_AUX_TEX_MATRIX_INV = 22,
+  HL_SKY_SUN_DIR = 23, HL_SKY_TURBIDITY = 26, HL_SKY_SUN_COLOR = 27, HL_SKY_PDF_TABLE0 = 30, HL_SKY_PDF_TABLE1 = 31,
+  HL_SKY_SAMPLER0 = 32, HL_SKY_MATRIX0 = 36, HL_SKY_SAMPLER1 = 44, HL_SKY_MATRIX1 = 48, HL_SKY_INV_MATRIX0 = 56,
+  HL_SKY_INV_MATRIX1 = 72, HL_SKY_SUN_DIR_ID = 88,
   HL_PROB_MULT = 104, HL_GROUP_ID = 105, HL_PICK_PROB_FWD = 106, HL_PICK_PROB_REV = 107,
   HL_IES_INV_MATRIX = 108, HL_IES_LIGHT_MATRIX = 117, HL_IES_SPHERE_PDF_ID = 126, HL_IES_SPHERE_TEX_ID = 127
 };
 enum { HLT_POINT_OMNI = 0, HLT_POINT_SPOT = 1, HLT_DIRECT = 2, HLT_SKY_DOME = 3, HLT_AREA = 4,
        HLT_SPHERE = 5, HLT_CYLINDER = 6, HLT_MESH = 7 };
-enum { HLF_DISABLE_SAMPLING = 1, HLF_SKY_PORTAL = 8, HLF_HAS_IES = 16, HLF_IES_POINT_AREA = 32 };
+enum { HLF_DISABLE_SAMPLING = 1, HLF_SKY_USE_PEREZ = 4, HLF_SKY_PORTAL = 8, HLF_HAS_IES = 16, HLF_IES_POINT_AREA = 32,
+       HLF_DO_NOT_SAMPLE_ME = 64 };   /* cglobals.h:2245-2254 */
 
 /* ---- ray flags word (cglobals.h:1330-1376): diffuse bounces | bounces<<8 | events<<16 ---- */
 enum { HRE_S = 1, HRE_D = 2, HRE_G = 4, HRE_T = 8 };

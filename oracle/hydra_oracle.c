@@ -31,7 +31,7 @@ enum { HRT_ENABLE_DOF = 0, HRT_TRACE_DEPTH = 9, HRT_DIFFUSE_TRACE_DEPTH = 13 };
 enum { HRT_DOF_LENS_RADIUS = 0, HRT_DOF_FOCAL_PLANE_DIST = 1, HRT_TILT_ROT_X = 2, HRT_TILT_ROT_Y = 4, HRT_CAM_FOV = 14 };
 /* EngineGlobals word offsets, ref: cfetch.h:21-81 */
 enum { G_MPROJ_INV = 32, G_MWORLDVIEW_INV = 48, G_VARS_I = 64, G_VARS_F = 128,
-       G_TEX_TABLE = 218, G_MAT_TABLE = 219, G_GEOM_TABLE = 221, G_FLOAT_ARRAYS = 228,
+       G_TEX_TABLE = 218, G_MAT_TABLE = 219, G_PDF_TABLE = 220, G_GEOM_TABLE = 221, G_FLOAT_ARRAYS = 228,
        G_LSEL_REV_OFFS = 230, G_LSEL_REV_SIZE = 231, G_FLAGS = 234, G_SKY_LIGHT_ID = 235, G_LIGHTS_OFFS = 236, G_LIGHTS_NUM = 238 };
 /* materials, ref: cglobals.h:2604-2722, cmaterial.h:200-210, 374-382, 887-903, 1965-2006 */
 enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSIVE_TEXMATRIXID = 8,
@@ -48,8 +48,10 @@ enum { MIX_TREE_MAX_DEEP = 7, FLOATS_PER_SAMPLE = 3, FLOATS_PER_MLAYER = 7 };
 /* lights, ref: clight.h:14-62, 493-521; cglobals.h:2236-2252 */
 enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, PL_COLOR = 8, PL_COLOR_TEX = 11,
        PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
-       AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107 };
-enum { LT_AREA = 4 };
+       AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107,
+       PL_COLOR_TEX_MATRIX = 12, SKY_DOME_PDF_TABLE0 = 30, SKY_DOME_SAMPLER0 = 32, SKY_DOME_MATRIX0 = 36, SKY_DOME_INV_MATRIX0 = 56 };   /* clight.h:131-165 */
+enum { LT_SKY_DOME = 3, LT_AREA = 4 };
+enum { HRT_BSPHERE_RADIUS = 21 };
 enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16 };
 /* ray flags, ref: cglobals.h:1330-1376 */
 enum { RAY_EVENT_S = 1, RAY_EVENT_D = 2, RAY_EVENT_G = 4, RAY_EVENT_T = 8 };
@@ -1076,6 +1078,105 @@ static int SelectRandomLightRev(float r, const OrcScene* s, float* pickProb) {
   return SelectIndexPropToOpt(r, (const float*)(s->globals + s->globals[G_LSEL_REV_OFFS]), tableSize, pickProb);
 }
 
+/* ---- sky dome light (constant colour or lat-long texture; no Perez model) ---- */
+#define ORC_PI 3.14159265358979323846f   /* float: the pinned build of the reference uses -cl-single-precision-constant */
+/* ref: cfetch.h:259-281 sphereMapToPhiTheta + sphereMapTo2DTexCoord */
+static f2 sphereMapTo2DTexCoord(f3 ray_dir, float* pSinTheta) {
+  const float x = ray_dir.z, y = ray_dir.x, z = -ray_dir.y;
+  const float theta = acosf(z);
+  float phi = atan2f(y, x);
+  if (phi < 0.0f) phi += 2.0f * ORC_PI;
+  f2 r;
+  r.x = clampf(phi * 0.5f * INV_PI, 0.0f, 1.0f);
+  r.y = clampf(theta * INV_PI, 0.0f, 1.0f);
+  *pSinTheta = sqrtf(1.0f - ray_dir.y * ray_dir.y);
+  return r;
+}
+/* ref: cfetch.h:283-296 texCoord2DToSphereMap */
+static f3 texCoord2DToSphereMap(f2 tc, float* pSinTheta) {
+  const float phi = tc.x * 2.f * ORC_PI, theta = tc.y * ORC_PI;
+  const float sinTheta = sinf(theta);
+  const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosf(theta);
+  *pSinTheta = sinTheta;
+  return v3(y, -z, x);
+}
+/* ref: cfetch.h:153-163 pdfTableHeader (table offsets are in float4 units) */
+static const float* pdfTableHeader(const OrcScene* s, int tableId) {
+  const int offset = s->globals[s->globals[G_PDF_TABLE] + tableId];
+  return s->pdfStorage + (size_t)offset * 4;
+}
+/* ref: clight.h:308-337 evalMap2DPdf (including its second test of texCoordT.x) */
+static float evalMap2DPdf(f2 tc, const float* intervals, const int sizeX, const int sizeY) {
+  const float fw = (float)sizeX, fh = (float)sizeY;
+  if (tc.x < 0.0f || tc.x > 1.0f) tc.x -= (float)((int)(tc.x));
+  if (tc.y < 0.0f || tc.x > 1.0f) tc.y -= (float)((int)(tc.y));
+  int pixelX = (int)(fw * tc.x - 0.5f), pixelY = (int)(fh * tc.y - 0.5f);
+  if (pixelX >= sizeX) pixelX = sizeX - 1;
+  if (pixelY >= sizeY) pixelY = sizeY - 1;
+  if (pixelX < 0) pixelX += sizeX;
+  if (pixelY < 0) pixelY += sizeY;
+  const int pixelOffset = pixelY * sizeX + pixelX, maxSize = sizeX * sizeY;
+  const int offset0 = (pixelOffset + 0 < maxSize + 0) ? pixelOffset + 0 : maxSize - 1;
+  const int offset1 = (pixelOffset + 1 < maxSize + 1) ? pixelOffset + 1 : maxSize;
+  return (intervals[offset1] - intervals[offset0]) * (fw * fh) / intervals[sizeX * sizeY];
+}
+/* ref: clight.h:339-364 skyLightEvalPDF */
+static float skyLightEvalPDF(const OrcScene* s, const float* L, f3 rayDir) {
+  const float* hdr = pdfTableHeader(s, as_int(L[SKY_DOME_PDF_TABLE0]));
+  const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(rayDir, &sintheta);
+  if (sintheta == 0.f) return 0.f;
+  const float* r0 = L + SKY_DOME_MATRIX0;   /* mul2x4, cfetch.h:642-648 */
+  f2 tcT;
+  tcT.x = r0[0] * tc.x + r0[1] * tc.y + r0[3];
+  tcT.y = r0[4] * tc.x + r0[5] * tc.y + r0[7];
+  const float mapPdf = evalMap2DPdf(tcT, hdr + 4, sizeX, sizeY);
+  return (mapPdf * 1.0f) / (2.f * ORC_PI * ORC_PI * fmaxf(fabsf(sintheta), DEPSILON));
+}
+/* ref: clight.h:427-462 SkyLightSampleRev, :378-403 sampleMap2D */
+static void SkyLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  const float* hdr = pdfTableHeader(s, as_int(L[SKY_DOME_PDF_TABLE0]));
+  const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+  const float fw = (float)sizeX, fh = (float)sizeY;
+  float pdf = 1.0f;
+  int pixelOffset = SelectIndexPropToOpt(rands.z, hdr + 4, sizeX * sizeY + 1, &pdf);
+  if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+  const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+  const float texX = (1.0f / fw) * (((float)(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+  const float texY = (1.0f / fh) * (((float)(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+  const float mapPdf = pdf * (fw * fh);
+  const float* m = L + SKY_DOME_INV_MATRIX0;   /* mul(float4x4, float3) with four float4 columns, cglobals.h:839-846; z = 0 */
+  f2 tcT;
+  tcT.x = texX * m[0] + texY * m[4] + 0.0f * m[8] + m[12];
+  tcT.y = texX * m[1] + texY * m[5] + 0.0f * m[9] + m[13];
+  float sintheta = 0.0f;
+  const f3 sampleDir = texCoord2DToSphereMap(tcT, &sintheta);
+  const f3 samplePos = add3(illum, scale3(sampleDir, g_varsF(s)[HRT_BSPHERE_RADIUS]));
+  const f3 txClr = sample2DExt(as_int(L[PL_COLOR_TEX_MATRIX]), tcT, L + SKY_DOME_SAMPLER0, s);   /* sample2D, cfetch.h:650-675 */
+  out->isPoint = 0;
+  out->pos = samplePos;
+  out->color = mul3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), txClr);
+  out->pdf = (mapPdf * 1.0f) / (2.f * ORC_PI * ORC_PI * fmaxf(fabsf(sintheta), DEPSILON));
+  out->maxDist = length3(sub3(illum, samplePos));
+  out->cosAtLight = 1.0f;
+}
+/* ref: cbidir.h:492-533 environmentColor; misPrev.prevMaterialOffset is -1 on this path (PT_Loop.cpp:247-249) */
+static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prevSpecular, uint32_t flags) {
+  const int skyId = s->globals[G_SKY_LIGHT_ID];
+  if (skyId == -1) return v3(0, 0, 0);
+  const float* L = (const float*)(s->globals + s->globals[G_LIGHTS_OFFS]) + (size_t)skyId * LIGHT_FLOATS;
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(rayDir, &sintheta);   /* skyLightGetIntensityTexturedENV, clight.h:285-306 */
+  f3 envColor = mul3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), sample2DExt(as_int(L[PL_COLOR_TEX_MATRIX]), tc, L + SKY_DOME_SAMPLER0, s));
+  const uint32_t rayBounceNum = (flags >> 8) & 0xFFu;
+  if (rayBounceNum > 0 && !((uint32_t)s->globals[G_FLAGS] & HRT_STUPID_PT_MODE) && !prevSpecular) {
+    const float lgtPdf = L[PL_PICK_PROB_REV] * skyLightEvalPDF(s, L, rayDir);
+    envColor = scale3(envColor, misWeightHeuristic(prevPdf, lgtPdf));
+  }
+  return envColor;
+}
+
 /* ------------------------------------------------------------------------------------------------ path tracer */
 typedef struct { float matSamplePdf; int isSpecular; } MisData;   /* ref: cglobals.h:1382-1400 (fields the PT path reads) */
 
@@ -1115,8 +1216,8 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     if (probe && !probe->shadow && probe->bounce == depth) { probe->pos = ray_pos; probe->dir = ray_dir; probe->have = 1; }
     const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
     st->rays++;
-    /* kernel_HitEnvironment: environmentColor, cbidir.h:492-533 -- no sky light in the subset => black */
-    if (!HitSome(hit)) { currColor = v3(0, 0, 0); break; }
+    /* kernel_HitEnvironment :23-33 */
+    if (!HitSome(hit)) { currColor = environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags); break; }
     /* kernel_EvalSurface */
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
@@ -1147,7 +1248,9 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     ShadowSample explicitSam;
     memset(&explicitSam, 0, sizeof(explicitSam));
     if (lightOffset >= 0) {
-      AreaLightSampleRev(lightAt(s, lightOffset), v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);   /* LightSampleRev, clight.h:1561-1610 */
+      const float* pl = lightAt(s, lightOffset);   /* LightSampleRev, clight.h:1561-1610 */
+      if (as_int(pl[PL_TYPE]) == LT_SKY_DOME) SkyLightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
+      else AreaLightSampleRev(pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
       shadowRayDir = normalize3(sub3(explicitSam.pos, surf.pos));
       shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
     }

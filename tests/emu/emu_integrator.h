@@ -1,7 +1,7 @@
 // emu_integrator.h -- TEST INFRASTRUCTURE.  One whole path per call: the stage order of IntegratorMISPTLoop2::PathTrace
 // (hydra_drv/CPUExp_Integrators_PT_Loop.cpp:264-321) strung together from the product's device functions
 // (hydracore_amd/csrc/hk_*.h) so that the host-emulation build can run them under ASan/UBSan.  The product itself only
-// has the wavefront split of this loop (hydra_hip.hip: k_trace / k_hit / k_shadow / k_shade).
+// has the wavefront split of this loop (hydra_hip.hip: k_trace_dyn / k_bounce).
 #pragma once
 
 HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_dir, RandomGen& gen, float& rays) {
@@ -13,7 +13,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
   for (int depth = 0; depth < maxDepth; depth++) {
     const HydraLiteHit hit = hk_traverse<false, false>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, ray_pos, ray_dir, 0.0f, hk_miss_hit(), st, tc);
     rays += 1.0f;
-    if (!HitSome(hit)) { currColor = mk3(0, 0, 0); break; }
+    if (!HitSome(hit)) { currColor = environmentColor(s, ray_dir, misPdf, misSpec, flags); break; }
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
     {
@@ -36,7 +36,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
     f3 explicitColor = mk3(0, 0, 0);
     if (lightOffset >= 0) {
       ShadowSample sam;
-      AreaLightSampleRev(lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);
+      LightSampleRev(s, lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);
       const f3 sdir = normalize(sam.pos - surf.pos);
       const f3 spos = OffsShadowRayPos(surf.pos, surf.normal, sdir, surf.sRayOff);
       HydraLiteHit sh = hk_miss_hit();

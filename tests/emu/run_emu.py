@@ -25,12 +25,13 @@ def main():
     def p(a):
         return a.ctypes.data_as(C.c_void_p)
     worst = 0.0
-    for name, dof in (("test_224", 0), ("test_42", 1)):
-        _, b = host_scene(name, 96, 96, 4, dof)
+    hall = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
+    for name, ww, hh, depth, dof, rk in (("test_224", 96, 96, 4, 0, {}), ("test_42", 96, 96, 4, 1, {}), ("atrium_sky_small", 96, 54, 5, 0, hall)):
+        _, b = host_scene(name, ww, hh, depth, dof)
         orc = make_oracle(b)
         w, h = b["width"], b["height"]
         # closest hit + counters + shadow
-        pos4, dir4 = random_rays(20000, 21)
+        pos4, dir4 = random_rays(20000, 21, **rk)
         hits = np.empty(len(pos4), np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)]))
         cnt = np.empty((len(pos4), 4), np.uint32)
         lib.emu_trace(C.byref(orc.s), len(pos4), p(pos4), p(dir4), p(hits), p(cnt), 0, None, None)

@@ -29,7 +29,7 @@ def test_rng_matches_reference_bit_for_bit(t42_small):
     assert (st == g["state"]).all()
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))

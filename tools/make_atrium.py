@@ -104,22 +104,24 @@ def curtain(nu, nv, width=4.0, height=6.0):
     return finish_mesh(pos, uv, grid_indices(nu, nv), np.full(2 * nu * nv, 6))
 
 
-def room(lx=40.0, ly=10.0, lz=20.0):
+def room(lx=40.0, ly=10.0, lz=20.0, open_roof=False):
     hx, hz = lx / 2, lz / 2
-    quads = [  # inward-facing walls and ceiling (the floor is its own mesh)
+    quads = [  # inward-facing walls and ceiling (the floor is its own mesh); open_roof leaves the ceiling out (sky variant)
         ([-hx, 0, -hz], [-hx, 0, hz], [-hx, ly, hz], [-hx, ly, -hz]),
         ([hx, 0, hz], [hx, 0, -hz], [hx, ly, -hz], [hx, ly, hz]),
         ([-hx, 0, -hz], [-hx, ly, -hz], [hx, ly, -hz], [hx, 0, -hz]),
         ([hx, 0, hz], [hx, ly, hz], [-hx, ly, hz], [-hx, 0, hz]),
         ([-hx, ly, -hz], [-hx, ly, hz], [hx, ly, hz], [hx, ly, -hz]),
     ]
+    if open_roof:
+        quads = quads[:4]
     pos, uv, tri = [], [], []
     for q in quads:
         b = len(pos)
         pos += q
         uv += [[0, 0], [4, 0], [4, 4], [0, 4]]
         tri += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
-    m = finish_mesh(np.array(pos, float), np.array(uv, float), np.array(tri, np.int32), [7, 7, 7, 7, 8, 8, 8, 8, 9, 9])
+    m = finish_mesh(np.array(pos, float), np.array(uv, float), np.array(tri, np.int32), [7, 7, 7, 7, 8, 8, 8, 8, 9, 9][:len(tri)])
     return m
 
 
@@ -171,6 +173,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="tessellation scale (1.0 ~ 249 k triangles)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
     args = ap.parse_args()
     s = np.sqrt(args.scale)
     rng = np.random.default_rng(SEED)
@@ -180,7 +183,7 @@ def main():
     def r(n, lo=2):
         return max(lo, int(round(n * s)))
     meshes = [("column", column(r(64, 8), r(32, 4))), ("arch", arch(r(32, 4), r(32, 4))), ("pot", pot(r(20, 4), r(10, 2))),
-              ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room()), ("light", light_quad(2.0, 0.5))]
+              ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky)), ("light", light_quad(2.0, 0.5))]
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -212,7 +215,9 @@ def main():
     xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
-               '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>\n</lights_lib>')
+               '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
+               + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
+                  '<multiplier val="0.5" /></intensity></light>' if args.sky else '') + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
 
@@ -257,6 +262,8 @@ def main():
     add(6, light_m, ' light_id="0" linst_id="0"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
+    if args.sky:
+        xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4())
     xml += inst
     xml.append("  </scene>\n</scenes>")
     with open(os.path.join(out, "statex_00001.xml"), "w") as f:
