@@ -42,7 +42,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
     "hydra_hip_get_traversal_counters", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
-    "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
+    "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
 ]
 
 _hip = None
@@ -95,6 +95,7 @@ def load_hip_library():
         "hydra_hip_stage_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_eval_surface": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_shade_point": ([vp, i32, vp, vp, vp, vp, vp, vp], i32),
         "hydra_hip_stage_path_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_random": ([vp, i32, vp, i32, vp, vp], i32),
         "hydra_hip_bench_trace": ([vp, i32, vp, vp, i32, i32, f32p], i32),
@@ -310,6 +311,17 @@ class HipCore:
         hits = np.ascontiguousarray(hits)
         out = np.empty((n, 24), np.float32)
         self._ck(self.lib.hydra_hip_stage_eval_surface(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(hits), _ptr(out)), "stage_eval_surface")
+        return out
+
+    def stage_shade_point(self, surf24, dir4, flags, rnd_light4, rands10):
+        """light pick + sample, materialEval, BxDF sampling at given surface points with given random numbers -> float32 [n, 28]"""
+        n = len(surf24)
+        surf24, dir4 = np.ascontiguousarray(surf24, np.float32), np.ascontiguousarray(dir4, np.float32)
+        flags, rnd_light4 = np.ascontiguousarray(flags, np.int32), np.ascontiguousarray(rnd_light4, np.float32)
+        rands10 = np.ascontiguousarray(rands10, np.float32)
+        out = np.zeros((n, 28), np.float32)
+        self._ck(self.lib.hydra_hip_stage_shade_point(self.h, n, _ptr(surf24), _ptr(dir4), _ptr(flags), _ptr(rnd_light4), _ptr(rands10), _ptr(out)),
+                 "stage_shade_point")
         return out
 
     def stage_path_trace(self, pos4, dir4, rng2):

@@ -543,6 +543,48 @@ __global__ void k_stage_surface(SceneDev s, int n, const float4* pos4, const flo
   r[12] = sh.biTangent.x; r[13] = sh.biTangent.y; r[14] = sh.biTangent.z; r[15] = sh.texCoord.x; r[16] = sh.texCoord.y;
   r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
 }
+// one shading point with the random numbers handed in: the product's light pick / light sample / materialEval / BxDF sampling
+// device functions exactly as k_bounce calls them (hit_phase's second half, direct_light_unoccluded's inputs, next_bounce_phase)
+__global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__ surf24, const float4* __restrict__ dir4, const int* __restrict__ flagsIn,
+                                    const float4* __restrict__ rndLight4, const float* __restrict__ rands10, float* __restrict__ out28) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = surf24 + size_t(i) * 24;
+  float* o = out28 + size_t(i) * 28;
+  for (int k = 0; k < 28; k++) o[k] = 0.0f;
+  SurfaceHit surf;
+  surf.pos = mk3(r[0], r[1], r[2]); surf.normal = mk3(r[3], r[4], r[5]); surf.flatNormal = mk3(r[6], r[7], r[8]);
+  surf.tangent = mk3(r[9], r[10], r[11]); surf.biTangent = mk3(r[12], r[13], r[14]); surf.texCoord = mk2(r[15], r[16]);
+  surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
+  if (surf.matId < 0) { o[8] = as_float(-2); return; }
+  const f3 ray_dir = xyz(dir4[i]);
+  const uint32_t flags = uint32_t(flagsIn[i]);
+  const float* mat = materialAt(s, surf.matId);
+  const float4 rl = rndLight4[i];
+  float pick = 1.0f;
+  const int lightOffset = SelectRandomLightRev(rl.z, s, pick);
+  o[7] = pick; o[8] = as_float(lightOffset);
+  if (lightOffset >= 0) {
+    ShadowSample sam;
+    sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
+    LightSampleRev(s, lightAt(s, lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);
+    const f3 sdir = normalize(sam.pos - surf.pos);
+    o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.pdf;
+    o[4] = sam.color.x; o[5] = sam.color.y; o[6] = sam.color.z; o[9] = sam.isPoint ? 1.0f : 0.0f;
+    ShadeContext sc;
+    sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
+    const BxDFResult ev = materialEval(mat, sc, s);
+    o[10] = ev.brdf.x; o[11] = ev.brdf.y; o[12] = ev.brdf.z; o[13] = ev.pdfFwd;
+    o[14] = ev.btdf.x; o[15] = ev.btdf.y; o[16] = ev.btdf.z;
+  }
+  float rands[10];
+  for (int k = 0; k < 10; k++) rands[k] = rands10[size_t(i) * 10 + k];
+  MatSample ms;
+  MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
+  o[17] = ms.color.x; o[18] = ms.color.y; o[19] = ms.color.z; o[20] = ms.pdf;
+  o[21] = ms.direction.x; o[22] = ms.direction.y; o[23] = ms.direction.z;
+  o[24] = as_float(ms.flags); o[25] = as_float(int(flagsNextBounceLite(flags, ms, s)));
+}
 __global__ void k_stage_random(int n, const int* seeds, int draws, float4* out4, uint2* state2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1364,6 +1406,24 @@ int hydra_hip_stage_eval_surface(hydra_hip_handle c, int n, const float* ray_pos
   hipLaunchKernelGGL(k_stage_surface, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, n, dpos, ddir, dh, dout);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(surf24, dout, size_t(n) * 96, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+int hydra_hip_stage_shade_point(hydra_hip_handle c, int n, const float* surf24, const float* ray_dir4, const int32_t* flags, const float* rnd_light4,
+                                const float* rands10, float* out28) {
+  STAGE_PROLOG(true);
+  if (!surf24 || !ray_dir4 || !flags || !rnd_light4 || !rands10 || !out28) return fail(c, HYDRA_HIP_EINVAL, "stage_shade_point: null argument");
+  float* dsurf = (float*)tb.up(c, surf24, size_t(n) * 96, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  int* dfl = (int*)tb.up(c, flags, size_t(n) * 4, rc);
+  float4* drl = (float4*)tb.up(c, rnd_light4, size_t(n) * 16, rc);
+  float* drn = (float*)tb.up(c, rands10, size_t(n) * 40, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 112, rc);
+  if (rc) return rc;
+  SceneDev s = make_scene(c);
+  hipLaunchKernelGGL(k_stage_shade_point, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, n, dsurf, ddir, dfl, drl, drn, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out28, dout, size_t(n) * 112, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 

@@ -132,6 +132,13 @@ int hydra_hip_stage_shadow_trace(hydra_hip_handle h, int n, const float* ray_pos
  * pos3 normal3 flatNormal3 tangent3 biTangent3 texCoord2 matId(as int bits) t sRayOff hfi(0/1) pad3 */
 int hydra_hip_stage_eval_surface(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                                  const HydraLiteHit* hits, float* surf24);
+/* one shading point with the random numbers handed in (parity fixtures for rows a/L1,L2,S1,S2): kernel_LightSelect +
+ * kernel_LightSample (PT_Loop.cpp:141-168), materialEval towards the sample (cmaterial.h:2554-2628) and the BxDF sampling
+ * of kernel_NextBounce (:218-256).  surf24 as written by stage_eval_surface; out28 = sample pos xyz, pdf, colour xyz,
+ * pick prob, light offset (int), isPoint, brdf xyz, pdfFwd, btdf xyz, MatSample colour xyz, pdf, direction xyz, flags (int),
+ * flagsNextBounceLite (int), 2 spare */
+int hydra_hip_stage_shade_point(hydra_hip_handle h, int n, const float* surf24, const float* ray_dir4, const int32_t* flags,
+                                const float* rnd_light4, const float* rands10, float* out28);
 /* whole paths for n given primary rays with given per-path RandomGen state (2 uint32 each, updated in place), run
  * through the production wavefront kernels: IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb, w = 0 */
 int hydra_hip_stage_path_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,

@@ -1301,6 +1301,55 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
   return accumColor;
 }
 
+/* One shading point: kernel_LightSelect + kernel_LightSample + materialEval towards the sample + the BxDF sampling of
+   kernel_NextBounce, with the random numbers handed in (fixtures 5 and 6 of SURVEY.md 8c).  surf24 as written by
+   orc_eval_surface; out28: [0..2] sample pos, [3] sample pdf, [4..6] sample colour, [7] pick prob, [8] light offset (int;
+   -2 = no surface), [9] isPoint, [10..12] brdf, [13] pdfFwd, [14..16] btdf, [17..19] MatSample.color, [20] pdf,
+   [21..23] direction, [24] MatSample.flags (int), [25] flagsNextBounceLite (int). */
+void orc_shade_point(const OrcScene* s, int n, const float* surf24, const float* dir4, const int32_t* flagsIn, const float* rndLight4,
+                     const float* rands10, float* out28) {
+  for (int i = 0; i < n; i++) {
+    const float* r = surf24 + 24 * (size_t)i;
+    float* o = out28 + 28 * (size_t)i;
+    memset(o, 0, 28 * sizeof(float));
+    SurfaceHit surf;
+    memset(&surf, 0, sizeof(surf));
+    surf.pos = v3(r[0], r[1], r[2]); surf.normal = v3(r[3], r[4], r[5]); surf.flatNormal = v3(r[6], r[7], r[8]);
+    surf.tangent = v3(r[9], r[10], r[11]); surf.biTangent = v3(r[12], r[13], r[14]);
+    surf.texCoord.x = r[15]; surf.texCoord.y = r[16];
+    surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
+    if (surf.matId < 0) { o[8] = as_float(-2); continue; }
+    const f3 ray_dir = v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
+    const uint32_t flags = (uint32_t)flagsIn[i];
+    const float* mat = materialAt(s, surf.matId);
+    const float* rl = rndLight4 + 4 * (size_t)i;
+    float lightPickProb = 1.0f;
+    const int lightOffset = SelectRandomLightRev(rl[2], s, &lightPickProb);
+    o[7] = lightPickProb; o[8] = as_float(lightOffset);
+    if (lightOffset >= 0) {
+      ShadowSample sam;
+      memset(&sam, 0, sizeof(sam));
+      const float* pl = lightAt(s, lightOffset);
+      if (as_int(pl[PL_TYPE]) == LT_SKY_DOME) SkyLightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &sam);
+      else AreaLightSampleRev(pl, v3(rl[0], rl[1], rl[2]), surf.pos, &sam);
+      const f3 shadowRayDir = normalize3(sub3(sam.pos, surf.pos));
+      o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.pdf;
+      o[4] = sam.color.x; o[5] = sam.color.y; o[6] = sam.color.z; o[9] = sam.isPoint ? 1.0f : 0.0f;
+      ShadeContext sc;
+      sc.l = shadowRayDir; sc.v = scale3(ray_dir, -1.0f); sc.n = surf.normal; sc.fn = surf.flatNormal;
+      sc.tg = surf.tangent; sc.bn = surf.biTangent; sc.tc = surf.texCoord;
+      const BxDFResult ev = materialEval(mat, &sc, s);
+      o[10] = ev.brdf.x; o[11] = ev.brdf.y; o[12] = ev.brdf.z; o[13] = ev.pdfFwd;
+      o[14] = ev.btdf.x; o[15] = ev.btdf.y; o[16] = ev.btdf.z;
+    }
+    MatSample ms;
+    MaterialSampleAndEvalBxDF(mat, rands10 + 10 * (size_t)i, &surf, ray_dir, flags, s, &ms);
+    o[17] = ms.color.x; o[18] = ms.color.y; o[19] = ms.color.z; o[20] = ms.pdf;
+    o[21] = ms.direction.x; o[22] = ms.direction.y; o[23] = ms.direction.z;
+    o[24] = as_float(ms.flags); o[25] = as_float((int)flagsNextBounceLite(flags, &ms, s));
+  }
+}
+
 void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4) {
 #pragma omp parallel for schedule(dynamic, 64)
   for (int i = 0; i < n; i++) {

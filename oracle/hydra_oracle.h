@@ -57,6 +57,10 @@ void orc_shadow_trace(const OrcScene* s, int n, const float* pos4, const float* 
 /* H1: 24 floats per hit (layout in include/hydra_hip.h, hydra_hip_stage_eval_surface) */
 void orc_eval_surface(const OrcScene* s, int n, const float* pos4, const float* dir4, const OrcHit* hits, float* surf24);
 /* whole paths, per-path RandomGen state (updated in place); color4.w = number of rays traced (extension + shadow) */
+/* one shading point with the random numbers handed in: light pick + light sample + materialEval + BxDF sampling
+   (layout of surf24 = orc_eval_surface output; out28 documented in hydra_oracle.c) */
+void orc_shade_point(const OrcScene* s, int n, const float* surf24, const float* dir4, const int32_t* flags, const float* rndLight4,
+                     const float* rands10, float* out28);
 void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4);
 
 /* P0: one sample for every pixel owned by (rank, world, tile) -- IntegratorCommon::DoPass with per-pixel generators.

@@ -263,3 +263,64 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
   color4[i] = to_float4(accumColor, rays);
   rng2[i]   = gen.state;
 }
+
+/* One shading point through the reference's light and material functions (fixtures 5 and 6 of SURVEY.md 8c):
+   kernel_LightSelect + kernel_LightSample + materialEval towards the sample + kernel_NextBounce's BxDF sampling, with the
+   random numbers handed in instead of drawn.  out = 28 floats per point, layout documented in tests/oracle_lib.py. */
+__kernel void ref_shade_point(__global const float* surf24, __global const float4* dir4, __global const int* flagsIn,
+                              __global const float4* rndLight4, __global const float* rands10,
+                              __global const float4* in_mtlStorage, __global const int4* in_texStorage, __global const float4* in_pdfStorage,
+                              __global const EngineGlobals* a_globals, __global float* out28, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global const float* r = surf24 + i * 24;
+  __global float* o = out28 + i * 28;
+  for (int k = 0; k < 28; k++) o[k] = 0.0f;
+  SurfaceHit surfElem;
+  surfElem.pos = make_float3(r[0], r[1], r[2]); surfElem.normal = make_float3(r[3], r[4], r[5]);
+  surfElem.flatNormal = make_float3(r[6], r[7], r[8]); surfElem.tangent = make_float3(r[9], r[10], r[11]);
+  surfElem.biTangent = make_float3(r[12], r[13], r[14]); surfElem.texCoord = make_float2(r[15], r[16]);
+  surfElem.texCoordCamProj = make_float2(0, 0);
+  surfElem.matId = as_int(r[17]); surfElem.t = r[18]; surfElem.sRayOff = r[19]; surfElem.hfi = (r[20] != 0.0f);
+  if (surfElem.matId < 0) { o[8] = as_float(-2); return; }
+  const float3 ray_dir = to_float3(dir4[i]);
+  const uint flags = (uint)flagsIn[i];
+  __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, surfElem.matId);
+
+  const float4 rndLightData = rndLight4[i];
+  float lightPickProb = 1.0f;
+  const int lightOffset = SelectRandomLightRev(rndLightData.z, surfElem.pos, a_globals, &lightPickProb);
+  ShadowSample explicitSam;
+  explicitSam.pos = make_float3(0, 0, 0); explicitSam.color = make_float3(0, 0, 0); explicitSam.pdf = 0.0f;
+  explicitSam.maxDist = 0.0f; explicitSam.cosAtLight = 0.0f; explicitSam.isPoint = false;
+  o[7] = lightPickProb; o[8] = as_float(lightOffset);
+  if (lightOffset >= 0)
+  {
+    __global const PlainLight* pLight = lightAt(a_globals, lightOffset);
+    LightSampleRev(pLight, to_float3(rndLightData), surfElem.pos, a_globals, in_pdfStorage, in_texStorage, &explicitSam);
+    const float3 shadowRayDir = normalize(explicitSam.pos - surfElem.pos);
+    o[0] = explicitSam.pos.x; o[1] = explicitSam.pos.y; o[2] = explicitSam.pos.z; o[3] = explicitSam.pdf;
+    o[4] = explicitSam.color.x; o[5] = explicitSam.color.y; o[6] = explicitSam.color.z; o[9] = explicitSam.isPoint ? 1.0f : 0.0f;
+    ShadeContext sc;
+    sc.wp = surfElem.pos; sc.l = shadowRayDir; sc.v = (-1.0f)*ray_dir; sc.n = surfElem.normal; sc.fn = surfElem.flatNormal;
+    sc.tg = surfElem.tangent; sc.bn = surfElem.biTangent; sc.tc = surfElem.texCoord; sc.tccp = surfElem.texCoordCamProj; sc.hfi = surfElem.hfi;
+    ProcTextureList ptlCopy;
+    InitProcTextureList(&ptlCopy);
+    GetProcTexturesIdListFromMaterialHead(pHitMaterial, &ptlCopy);
+    const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlCopy);
+    o[10] = evalData.brdf.x; o[11] = evalData.brdf.y; o[12] = evalData.brdf.z; o[13] = evalData.pdfFwd;
+    o[14] = evalData.btdf.x; o[15] = evalData.btdf.y; o[16] = evalData.btdf.z;
+  }
+  float allRands[MMLT_FLOATS_PER_BOUNCE];
+  for (int k = 0; k < MMLT_FLOATS_PER_BOUNCE; k++) allRands[k] = 0.0f;
+  for (int k = 0; k < 10; k++) allRands[k] = rands10[i * 10 + k];
+  ProcTextureList ptlDummy;
+  InitProcTextureList(&ptlDummy);
+  MatSample matSam; int matOffset;
+  MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), flags, false,
+                            a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+  o[17] = matSam.color.x; o[18] = matSam.color.y; o[19] = matSam.color.z; o[20] = matSam.pdf;
+  o[21] = matSam.direction.x; o[22] = matSam.direction.y; o[23] = matSam.direction.z;
+  o[24] = as_float(matSam.flags); o[25] = as_float((int)flagsNextBounceLite(flags, matSam, a_globals));
+}

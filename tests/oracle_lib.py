@@ -42,6 +42,7 @@ def load():
     lib.orc_shadow_trace.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_eval_surface.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_path_trace.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.orc_render_pass.restype = C.c_uint64
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
@@ -121,6 +122,17 @@ class Oracle:
         n = pos4.shape[0]
         out = np.empty((n, 24), np.float32)
         self.lib.orc_eval_surface(C.byref(self.s), n, _p(pos4), _p(dir4), _p(hits), _p(out))
+        return out
+
+    def shade_point(self, surf24, dir4, flags, rnd_light4, rands10):
+        """orc_shade_point: float32 [n, 28] = sample pos xyz, pdf, colour xyz, pick prob, light offset (int bits), isPoint,
+        brdf xyz, pdfFwd, btdf xyz, MatSample colour xyz, pdf, direction xyz, flags (int bits), next ray flags (int bits), 2 spare"""
+        n = len(surf24)
+        surf24, dir4 = np.ascontiguousarray(surf24, np.float32), np.ascontiguousarray(dir4, np.float32)
+        flags, rnd_light4 = np.ascontiguousarray(flags, np.int32), np.ascontiguousarray(rnd_light4, np.float32)
+        rands10 = np.ascontiguousarray(rands10, np.float32)
+        out = np.zeros((n, 28), np.float32)
+        self.lib.orc_shade_point(C.byref(self.s), n, _p(surf24), _p(dir4), _p(flags), _p(rnd_light4), _p(rands10), _p(out))
         return out
 
     def path_trace(self, pos4, dir4, rng2):

@@ -115,6 +115,15 @@ class RefScene:
                                               ("p", out), ("i", n)])
         return self.m.down(out, np.float32, (n, 24))
 
+    def shade_point(self, surf24, dir4, flags, rnd_light4, rands10):
+        n = len(surf24)
+        out = self.m.alloc(n * 112)
+        self.m.launch("ref_shade_point", n, [("p", self.m.up(np.ascontiguousarray(surf24, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
+                                             ("p", self.m.up(np.ascontiguousarray(flags, np.int32))), ("p", self.m.up(np.ascontiguousarray(rnd_light4, np.float32))),
+                                             ("p", self.m.up(np.ascontiguousarray(rands10, np.float32))), ("p", self.mat), ("p", self.tex), ("p", self.pdf),
+                                             ("p", self.globals), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 28))
+
     def path_trace(self, pos4, dir4, rng2):
         n = len(pos4)
         rng = self.m.up(np.ascontiguousarray(rng2, np.uint32))

@@ -148,6 +148,22 @@ def test_surface_reconstruction(gpu224):
 
 
 @pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky"])
+def test_light_and_material_functions_at_shading_points(fix, request):
+    """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
+    flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
+    from test_golden_ref import check_shade_point
+    core, b, orc = request.getfixturevalue(fix)
+    hall = fix.startswith("gpu_atrium")
+    pos4, dir4 = random_rays(32768, 61, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0) if hall else random_rays(32768, 61)
+    surf = orc.eval_surface(pos4, dir4, orc.trace(pos4, dir4))
+    rng = np.random.default_rng(62)
+    flags = (rng.integers(0, 3, len(pos4)) | (rng.integers(0, 4, len(pos4)) << 8)).astype(np.int32)
+    rl = rng.uniform(0, 1, (len(pos4), 4)).astype(np.float32)
+    rands = rng.uniform(0, 1, (len(pos4), 10)).astype(np.float32)
+    check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
+
+
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
