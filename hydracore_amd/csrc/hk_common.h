@@ -102,6 +102,10 @@ struct SceneDev {
   const float4* matStorage;
   const int4*   texStorage;
   const float4* geomStorage;
+  // private re-layout of the geometry arena, built once per scene on the device (k_geom_fill): one 128-byte, line-aligned
+  // record per triangle = A.pos|u, B.pos|u, C.pos|u, A.norm|v, B.norm|v, C.norm|v, (matId, shadow offset, -, -), pad;
+  // tangents in a second array (3 float4 per triangle).  triBase[geomId] = first record of that mesh.  Same bits as the arena.
+  const float4* triRec; const float4* triTan; const int* triBase;
   const float4* pdfStorage;
   const float4* bvh;           // tree 0: 2 float4 per node, 8 per quad
   unsigned      bvhBytes;      // size of the node array (< 4 GiB: the traversal kernels address it as a raw buffer)

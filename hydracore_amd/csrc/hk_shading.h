@@ -187,7 +187,9 @@ HK_DEV int remapMaterialId(int mId, int instId, const SceneDev& s) {   // cgloba
   return mId;
 }
 
-HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, const float4* __restrict__ mesh) {   // ctrace.h:1988-2109
+// The vertex data of one triangle, however it is stored
+struct TriData { float4 A1, B1, C1, A2, B2, C2, At, Bt, Ct; int matId; float sRayOff; };
+HK_DEV TriData fetchTriFromMesh(const HydraLiteHit& hit, const float4* __restrict__ mesh) {   // the reference's arena layout, cfetch.h:1038-1119
   const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(mesh);
   const float4* vertPos = mesh + hdr->vPosOffset;
   const float4* vertNorm = mesh + hdr->vNormOffset;
@@ -195,13 +197,35 @@ HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, c
   const int* vertIndices = reinterpret_cast<const int*>(mesh + hdr->vIndicesOffset);
   const int* matIndices = reinterpret_cast<const int*>(mesh + hdr->mIndicesOffset);
   const float* shadowRayOff = reinterpret_cast<const float*>(mesh + hdr->polyShadowOffset);
-
-  SurfaceHit sh;
-  sh.matId = matIndices[hit.primId];
+  TriData d;
+  d.matId = matIndices[hit.primId];
   const int o = hit.primId * 3;
   const int iA = vertIndices[o], iB = vertIndices[o + 1], iC = vertIndices[o + 2];
-  const float4 A1 = vertPos[iA], B1 = vertPos[iB], C1 = vertPos[iC];
-  const float4 A2 = vertNorm[iA], B2 = vertNorm[iB], C2 = vertNorm[iC];
+  d.A1 = vertPos[iA]; d.B1 = vertPos[iB]; d.C1 = vertPos[iC];
+  d.A2 = vertNorm[iA]; d.B2 = vertNorm[iB]; d.C2 = vertNorm[iC];
+  d.At = vertTang[iA]; d.Bt = vertTang[iB]; d.Ct = vertTang[iC];
+  d.sRayOff = shadowRayOff[hit.primId];
+  return d;
+}
+// Per-triangle records (SceneDev::triRec): 7 loads from ONE aligned 128-byte line instead of ~25 loads from ~15 lines.
+// k_bounce is bound by the CU's address path, where the first touch of a line costs ~2.3 clk per lane and every further
+// load from it ~1 (tools/micro/ta_bench.hip), and this fetch was two thirds of its divergent loads.
+HK_DEV TriData fetchTriFromRecords(const HydraLiteHit& hit, const SceneDev& s) {
+  const size_t t = size_t(s.triBase[hit.geomId]) + size_t(hit.primId);
+  const float4* r = s.triRec + t * 8;
+  const float4* tg = s.triTan + t * 3;
+  TriData d;
+  d.A1 = r[0]; d.B1 = r[1]; d.C1 = r[2]; d.A2 = r[3]; d.B2 = r[4]; d.C2 = r[5];
+  const float4 misc = r[6];
+  d.matId = as_int(misc.x); d.sRayOff = misc.y;
+  d.At = tg[0]; d.Bt = tg[1]; d.Ct = tg[2];
+  return d;
+}
+
+HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, const TriData& td) {   // ctrace.h:1988-2109
+  const float4 A1 = td.A1, B1 = td.B1, C1 = td.C1, A2 = td.A2, B2 = td.B2, C2 = td.C2;
+  SurfaceHit sh;
+  sh.matId = td.matId;
   const f3 A_pos = xyz(A1), B_pos = xyz(B1), C_pos = xyz(C1);
   const f3 A_norm = xyz(A2), B_norm = xyz(B2), C_norm = xyz(C2);
 
@@ -221,9 +245,9 @@ HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, c
   sh.texCoord.y = w0 * A2.w + v * B2.w + u * C2.w;
   sh.normal = ((A_norm * w0) + (B_norm * v)) + (C_norm * u);
   sh.t = hit.t;
-  sh.sRayOff = shadowRayOff[hit.primId];
+  sh.sRayOff = td.sRayOff;
 
-  const float4 At = vertTang[iA], Bt = vertTang[iB], Ct = vertTang[iC];
+  const float4 At = td.At, Bt = td.Bt, Ct = td.Ct;
   sh.flatNormal = normalize(cross(A_pos - B_pos, A_pos - C_pos));
   if (dot(a_rdir, sh.flatNormal) > 0.025f) sh.flatNormal = sh.flatNormal * (-1.0f);
   const float maxEdge = fmaxf(fmaxf(length(A_pos - B_pos), length(A_pos - C_pos)), length(B_pos - C_pos));
@@ -246,8 +270,12 @@ HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, c
 HK_DEV SurfaceHit evalSurface(const SceneDev& s, f3 ray_pos, f3 ray_dir, const HydraLiteHit& hit) {   // CPUExp_Integrators_PT_Loop.cpp:35-84
   const m44 instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4);
   const f3 posLS = mul4x3(instInv, ray_pos), dirLS = mul3x3(instInv, ray_dir);
-  const int meshOffset = s.globals[s.globals[HG_GEOM_TABLE_OFFS] + hit.geomId];
-  const SurfaceHit ls = surfaceEvalLS(posLS, dirLS, hit, s.geomStorage + meshOffset);
+#ifdef HK_HOST_EMU
+  const TriData td = fetchTriFromMesh(hit, s.geomStorage + s.globals[s.globals[HG_GEOM_TABLE_OFFS] + hit.geomId]);
+#else
+  const TriData td = fetchTriFromRecords(hit, s);
+#endif
+  const SurfaceHit ls = surfaceEvalLS(posLS, dirLS, hit, td);
   const m44 inst = inverse_affine(instInv);
   SurfaceHit ws = ls;
   const float multInv = 1.0f / sqrtf(3.0f);

@@ -503,6 +503,31 @@ __global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __res
   }
   atomicAdd(&totals[0], e); atomicAdd(&totals[1], sh); atomicAdd(&totals[2], (unsigned long long)live[sg * HK_CSTRIDE]);
 }
+// ---- geometry re-layout (SceneDev::triRec): count the triangles of every mesh in the geometry table, then copy each
+// triangle's vertex data into its record (bit copies of the arena: positions|u, normals|v, tangents, material id, shadow offset)
+__global__ void k_geom_count(const int* __restrict__ globals, const float4* __restrict__ geom, int tableSize, int* __restrict__ triCount) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= tableSize) return;
+  const int offset = globals[globals[HG_GEOM_TABLE_OFFS] + id];
+  int n = 0;
+  if (offset >= 0) n = reinterpret_cast<const HydraPlainMesh*>(geom + offset)->tIndicesNum / 3;
+  triCount[id] = n;
+}
+__global__ void k_geom_fill(const int* __restrict__ globals, const float4* __restrict__ geom, int tableSize, const int* __restrict__ triBase, int total,
+                            float4* __restrict__ rec, float4* __restrict__ tan) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    int lo = 0, hi = tableSize - 1;                 // last mesh whose base is <= t (empty meshes share a base with their successor)
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (triBase[mid] <= t) lo = mid; else hi = mid - 1; }
+    HydraLiteHit h;
+    h.t = 0.0f; h.geomId = lo; h.instId = 0; h.primId = t - triBase[lo];
+    const TriData d = fetchTriFromMesh(h, geom + globals[globals[HG_GEOM_TABLE_OFFS] + lo]);
+    float4* r = rec + size_t(t) * 8;
+    r[0] = d.A1; r[1] = d.B1; r[2] = d.C1; r[3] = d.A2; r[4] = d.B2; r[5] = d.C2;
+    r[6] = make_float4(as_float(d.matId), d.sRayOff, 0.0f, 0.0f);
+    r[7] = make_float4(0, 0, 0, 0);
+    tan[size_t(t) * 3] = d.At; tan[size_t(t) * 3 + 1] = d.Bt; tan[size_t(t) * 3 + 2] = d.Ct;
+  }
+}
 // upload-time pass over the device copy of the node array: boxes of invalid children become NaN (see trav_run)
 __global__ void k_prepare_bvh(int nodes, float4* __restrict__ bvh) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nodes; i += gridDim.x * blockDim.x) {
@@ -617,13 +642,14 @@ struct hydra_hip_ctx {
   char devName[256] = {0};
   int numCU = 256;
 
-  DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, remapLists, remapTable, remapInst;
+  DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
   size_t globalsWords = 0;
   int haveInst[4] = {0, 0, 0, 0};
   size_t bvhNodeBytes[4] = {0, 0, 0, 0}, bvhTriBytes[4] = {0, 0, 0, 0};
   int treesNum = 0, instNum = 0;
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
+  bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
   bool skyLightOk = true;            // false when the uploaded sky light needs a model this layer lacks
 
   // render state
@@ -705,6 +731,9 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.globals = static_cast<const int*>(c->globals.p);
   s.texStorage = static_cast<const int4*>(c->storage[HYDRA_STORAGE_TEXTURES].p);
   s.geomStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_GEOM].p);
+  s.triRec = static_cast<const float4*>(c->triRec.p);
+  s.triTan = static_cast<const float4*>(c->triTan.p);
+  s.triBase = static_cast<const int*>(c->triBase.p);
   s.matStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_MATERIALS].p);
   s.pdfStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_PDFS].p);
   s.bvh = static_cast<const float4*>(c->bvhNodes[0].p);
@@ -739,6 +768,40 @@ static int seg_grid(const hydra_hip_ctx* c, const SegQ& q, int block, int blocks
   return std::max(1, bps) * q.nseg;
 }
 static SegQ seg_q(const uint32_t* counts, int countImm, int nseg, int cap) { SegQ q; q.counts = counts; q.countImm = countImm; q.nseg = nseg; q.cap = cap; return q; }
+
+// (re)build the per-triangle records when the geometry arena or the geometry table changed; called by every entry point
+// that shades.  Two small kernels and one read-back of the per-mesh triangle counts.
+static int prepare_geometry(hydra_hip_ctx* c) {
+  if (!c->geomDirty) return HYDRA_HIP_OK;
+  const int tableSize = c->hostHeader[HG_GEOM_TABLE_SIZE];
+  if (tableSize <= 0 || tableSize > (1 << 24)) return fail(c, HYDRA_HIP_EINVAL, "geometry table size out of range");
+  int rc;
+  if ((rc = dev_alloc(c, c->triBase, size_t(tableSize + 1) * 4)) != 0) return rc;
+  const int* globals = static_cast<const int*>(c->globals.p);
+  const float4* geom = static_cast<const float4*>(c->storage[HYDRA_STORAGE_GEOM].p);
+  hipLaunchKernelGGL(k_geom_count, dim3((tableSize + 255) / 256), dim3(256), 0, c->stream, globals, geom, tableSize, static_cast<int*>(c->triBase.p));
+  std::vector<int> counts(size_t(tableSize) + 1, 0);
+  HCHECK(hipMemcpyAsync(counts.data(), c->triBase.p, size_t(tableSize) * 4, hipMemcpyDeviceToHost, c->stream));
+  HCHECK(hipStreamSynchronize(c->stream));
+  long long total = 0;
+  for (int i = 0; i < tableSize; i++) {
+    if (counts[i] < 0) return fail(c, HYDRA_HIP_EINVAL, "geometry table: negative triangle count in mesh " + std::to_string(i));
+    const int n = counts[i];
+    counts[i] = int(total);
+    total += n;
+  }
+  counts[tableSize] = int(total);
+  if (total <= 0 || total >= (1ll << 31)) return fail(c, HYDRA_HIP_EINVAL, "geometry table: no triangles (or 2^31 and more)");
+  HCHECK(hipMemcpyAsync(c->triBase.p, counts.data(), size_t(tableSize + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = dev_alloc(c, c->triRec, size_t(total) * 128)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->triTan, size_t(total) * 48)) != 0) return rc;
+  hipLaunchKernelGGL(k_geom_fill, dim3(grid_for(c, int(total), 256, 8)), dim3(256), 0, c->stream, globals, geom, tableSize,
+                     static_cast<const int*>(c->triBase.p), int(total), static_cast<float4*>(c->triRec.p), static_cast<float4*>(c->triTan.p));
+  HCHECK(hipGetLastError());
+  HCHECK(hipStreamSynchronize(c->stream));     // `counts` must outlive the copy
+  c->geomDirty = false;
+  return HYDRA_HIP_OK;
+}
 
 // slot -> pixel map: owned tiles (tile % world == rank), pixels inside a tile in 8x8 blocks so that one wave = one block
 static void build_slot_map(hydra_hip_ctx* c, std::vector<int>& out) {
@@ -958,7 +1021,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
+  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
@@ -1013,6 +1076,7 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
   HCHECK(hipSetDevice(c->device));
   c->globalsWords = words;
   c->hostHeader.assign(blob, blob + HG_TABLES_READY + 1);
+  c->geomDirty = true;
   // the sky light (if any) must be one this layer implements: constant colour or lat-long texture, no Perez model
   c->skyLightOk = true;
   const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
@@ -1043,6 +1107,7 @@ int hydra_hip_update_globals_header(hydra_hip_handle c, const int32_t* blob, siz
 int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, size_t bytes) {
   if (!c || kind < 0 || kind >= HYDRA_STORAGE_KINDS || (bytes > 0 && !data)) return fail(c, HYDRA_HIP_EINVAL, "upload_storage: bad arguments");
   HCHECK(hipSetDevice(c->device));
+  if (kind == HYDRA_STORAGE_GEOM) c->geomDirty = true;
   return dev_upload(c, c->storage[kind], data, bytes);
 }
 int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes, int nodes_num, const float* tri_f4, int tri_f4_num,
@@ -1152,6 +1217,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   if (!c || spp < 1) return HYDRA_HIP_EINVAL;
   if (!scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: scene is not completely uploaded (globals, storages, BVH, instances)");
   HCHECK(hipSetDevice(c->device));
+  { int rc = prepare_geometry(c); if (rc) return rc; }
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   if (!c->gensReady) { int rc = hydra_hip_init_path_tracing(c, c->seed); if (rc) return rc; }
   if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
@@ -1337,6 +1403,7 @@ struct TmpBufs {
   if (!c || n <= 0) return HYDRA_HIP_EINVAL;                                                           \
   if ((needScene) && !scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "stage call: scene is not uploaded"); \
   HCHECK(hipSetDevice(c->device));                                                                      \
+  if (needScene) { const int prc_ = prepare_geometry(c); if (prc_) return prc_; }                       \
   TmpBufs tb; int rc = HYDRA_HIP_OK;
 #define STAGE_EPILOG()                                                                                  \
   HCHECK(hipGetLastError());                                                                            \

@@ -107,6 +107,45 @@ static void run_octets(const float4* table, int lines, unsigned* out, int blocks
   hipEventDestroy(a); hipEventDestroy(b);
 }
 
+// same as chase<> with group 1, but the LOADS pieces are addressed as base + immediate offset (global_load ... offset:N)
+template <int LOADS>
+__global__ void __launch_bounds__(128) chase_imm(const float4* __restrict__ table, int lines, int steps, int active, unsigned* out) {
+  const int lane = threadIdx.x & 63;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= active) return;
+  unsigned key = (unsigned)gtid * 2654435761u + 12345u;
+  float acc = 0.0f;
+  for (int s = 0; s < steps; s++) {
+    const unsigned line = (key >> 8) % (unsigned)lines;
+    const float4* p = table + (size_t)line * 8;
+    float4 v[LOADS];
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) v[k] = p[k];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) sum += v[k].x + v[k].w;
+    acc += sum;
+    key = key * 1664525u + 1013904223u + (unsigned)(int)(sum * 0.0f);
+  }
+  out[gtid] = __float_as_uint(acc) + key;
+}
+template <int LOADS>
+static void run_imm(const float4* table, int lines, unsigned* out, int blocks, int active, int steps) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(chase_imm<LOADS>, dim3(blocks), dim3(128), 0, 0, table, lines, steps, active, out);
+  hipEventRecord(a);
+  hipLaunchKernelGGL(chase_imm<LOADS>, dim3(blocks), dim3(128), 0, 0, table, lines, steps, active, out);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  const double waveInstr = double(blocks) * 2 * steps * LOADS;
+  printf("global loads/step %d active %2d divergent, base + immediate: %7.3f ms  %6.1f clk/wave-instr/CU  %6.2f clk/lane-load/CU\n", LOADS, active, ms,
+         ms * 1e-3 * 2.4e9 / (waveInstr / 256.0), ms * 1e-3 * 2.4e9 / (waveInstr * active / 256.0));
+  hipEventDestroy(a); hipEventDestroy(b);
+}
+
 template <int LOADS>
 static void run(const float4* table, int lines, unsigned* out, int blocks, int active, int group, int steps) {
   hipEvent_t a, b;
@@ -140,6 +179,7 @@ int main(int argc, char** argv) {
   for (int active : {64, 32, 16}) run<8>(table, lines, out, blocks, active, 1, steps);
   for (int group : {2, 4, 8}) run<2>(table, lines, out, blocks, 64, group, steps);
   run<8>(table, lines, out, blocks, 64, 64, steps);      // whole wave reads the same line (broadcast)
+  for (int active : {64, 16}) { run_imm<8>(table, lines, out, blocks, active, steps); run_imm<2>(table, lines, out, blocks, active, steps); }
   for (int active : {64, 16}) { run_buf<1>(table, lines, out, blocks, active, steps); run_buf<8>(table, lines, out, blocks, active, steps); }
   for (int oob : {0, 1}) for (int live : {8, 4, 2, 1}) run_octets(table, lines, out, blocks, live, oob, steps);
   return 0;
