@@ -85,14 +85,23 @@ HK_DEV SegIter segq_iter(const SegQ& q) {
 
 // ================================================================================================ kernels
 // P1 -- ray generation: IntegratorCommon::makeEyeRay (Common.cpp:347-359) for every owned pixel
-// slotGid[i] = stream * (w*h) + pixel: the index of the path's RandomGen state and of its contribution record
-__global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ slotGid, const uint2* __restrict__ gens, int w, int h, PathState S) {
+// Path p of a sub-pass that traces `ns` samples of each of the N owned pixels: stream-major (p = stream * N + pixelIndex, the
+// default) or pixel-major (p = pixelIndex * ns + stream: the 64 lanes of a wave are 64 / ns neighbouring pixels x ns samples;
+// measured within noise of the default, profiles/r01/pass_path_order.log).  Paths are dealt to the queue segments in
+// chunks of 256: chunk c -> segment c % nseg, so slot idx of segment seg holds path ((idx / 256) * nseg + seg) * 256 + idx % 256.
+// gid = stream * (w*h) + pixel is the index of the path's RandomGen state and of its contribution record.
+__global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels, int nOwned, int ns, int streamMajor,
+                         const uint2* __restrict__ gens, int w, int h, PathState S) {
   const SegIter it = segq_iter(q);
   const int npix = w * h;
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
-    const int gid = slotGid[i];
-    const int pixel = gid % npix;
+    const long long p = ((long long)(idx >> 8) * q.nseg + it.seg) * 256 + (idx & 255);
+    int pixIdx, stream;
+    if (streamMajor) { stream = int(p / nOwned); pixIdx = int(p - (long long)stream * nOwned); }
+    else { pixIdx = int(p / ns); stream = int(p - (long long)pixIdx * ns); }
+    const int pixel = ownedPixels[pixIdx];
+    const int gid = stream * npix + pixel;
     const uint2 g2 = gens[gid];
     RandomGen gen; gen.x = g2.x; gen.y = g2.y;
     const float4 r = rndFloat4_Pseudo(gen);   // rndUniform(gen, -1, 1), crandom.h:617-620
@@ -657,11 +666,12 @@ struct hydra_hip_ctx {
   int N = 0;                         // owned pixels = live paths at bounce 0
   int streamsWanted = 0;             // option "samples_in_flight": samples per pixel traced concurrently, 0 = by resolution
   int streams = 1;
+  int streamMajor = 1;               // option "path_order": 1 = stream-major (default), 0 = pixel-major (samples of a pixel share a wave); measured equal
   DevBuf ownedPixels;                // the N owned pixels in slot order (k_accumulate)
   int nsegWanted = 8;                // option "queue_segments"
   int nseg = 1, segCap = 0;          // segmented path queues (see SegQ): nseg * segCap slots
   DevBuf liveInit;                   // one counter row holding the initial per-segment path counts
-  DevBuf slotPixel, gens, accumInternal, contrib, hits, live, shadowCnt, totals;
+  DevBuf gens, accumInternal, contrib, hits, live, shadowCnt, totals;
   float4* accum = nullptr;           // internal or external
   bool externalAccum = false;
   DevBuf sPos, sDir, sThr, sAcc, sRng;
@@ -838,35 +848,28 @@ static int alloc_render_state(hydra_hip_ctx* c) {
   if (K != c->streams) c->gensReady = false;
   c->streams = K;
   if (size_t(K) * npix > size_t(0x7fffffff)) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight * width * height must stay below 2^31");
-  // Deal 256-slot chunks (four 8x8 pixel blocks) round-robin to the segments: every segment sees the whole image, so
-  // path-length differences between image regions do not unbalance them.  Inside a segment the slots of stream 0 come
-  // first, then stream 1, ...: a sub-pass that traces only `ns` streams starts from a dense prefix of every segment.
-  const int chunks = (c->N + 255) / 256;
-  c->nseg = std::max(1, std::min(std::min(c->nsegWanted, HK_MAX_SEG), chunks));
-  std::vector<std::vector<int>> segPixels(c->nseg);
-  for (int k = 0; k < chunks; k++) {
-    const int n = std::min(256, c->N - k * 256);
-    std::vector<int>& v = segPixels[k % c->nseg];
-    v.insert(v.end(), order.begin() + size_t(k) * 256, order.begin() + size_t(k) * 256 + n);
-  }
-  size_t perStream = 1;
-  for (const auto& v : segPixels) perStream = std::max(perStream, v.size());
-  const size_t cap = (perStream * K + 255) / 256 * 256;
-  if (cap * c->nseg > size_t(0x7fffffff)) return fail(c, HYDRA_HIP_EINVAL, "too many path slots");
+  // Paths are dealt to the queue segments in 256-path chunks round-robin (see k_raygen), so every segment sees the whole
+  // image and path-length differences between image regions do not unbalance them.  Row ns-1 of liveInit holds the
+  // per-segment path counts of a sub-pass that traces ns samples per pixel.
+  const long long maxPaths = (long long)c->N * K;
+  const long long maxChunks = (maxPaths + 255) / 256;
+  c->nseg = int(std::max<long long>(1, std::min<long long>(std::min(c->nsegWanted, HK_MAX_SEG), maxChunks)));
+  const long long cap = std::max<long long>(1, (maxChunks + c->nseg - 1) / c->nseg) * 256;
+  if (cap * c->nseg > 0x7fffffffll) return fail(c, HYDRA_HIP_EINVAL, "too many path slots");
   c->segCap = int(cap);
-  std::vector<int> slots(size_t(c->nseg) * cap, -1);
   std::vector<uint32_t> init(size_t(K) * HK_CROW, 0u);
-  for (int sg = 0; sg < c->nseg; sg++) {
-    const std::vector<int>& v = segPixels[sg];
-    for (int k = 0; k < K; k++) {
-      int* dst = slots.data() + size_t(sg) * cap + size_t(k) * v.size();
-      for (size_t j = 0; j < v.size(); j++) dst[j] = int(size_t(k) * npix + size_t(v[j]));
-      init[size_t(k) * HK_CROW + sg * HK_CSTRIDE] = uint32_t((k + 1) * v.size());   // row k: k + 1 streams live
+  for (int ns = 1; ns <= K; ns++) {
+    const long long paths = (long long)c->N * ns, chunks = (paths + 255) / 256;
+    for (int sg = 0; sg < c->nseg; sg++) {
+      if (sg >= chunks) continue;
+      const long long mine = (chunks - sg + c->nseg - 1) / c->nseg;            // chunks sg, sg + nseg, ...
+      long long count = mine * 256;
+      if ((chunks - 1) % c->nseg == sg) count -= chunks * 256 - paths;           // the last chunk may be partial
+      init[size_t(ns - 1) * HK_CROW + sg * HK_CSTRIDE] = uint32_t(count);
     }
   }
-  const size_t N = slots.size();
+  const size_t N = size_t(c->nseg) * size_t(cap);
   int rc;
-  if ((rc = dev_upload(c, c->slotPixel, slots.data(), slots.size() * 4)) != 0) return rc;
   if ((rc = dev_upload(c, c->ownedPixels, order.data(), order.size() * 4)) != 0) return rc;
   if ((rc = dev_upload(c, c->liveInit, init.data(), init.size() * 4)) != 0) return rc;
   if ((rc = dev_alloc(c, c->gens, npix * K * 8)) != 0) return rc;
@@ -1021,7 +1024,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->slotPixel, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
+  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
@@ -1250,7 +1253,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     if (c->traceMode != 0) HCHECK(hipMemsetAsync(c->fetchCnt.p, 0, size_t(2 * maxDepth + 2) * HK_CROW * 4, c->stream));
     HCHECK(hipMemcpyAsync(live, static_cast<const uint32_t*>(c->liveInit.p) + size_t(ns - 1) * HK_CROW, size_t(HK_CROW) * 4, hipMemcpyDeviceToDevice, c->stream));
     int e0 = mark();
-    hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, q0, static_cast<const int*>(c->slotPixel.p), static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
+    hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, q0, static_cast<const int*>(c->ownedPixels.p), c->N, ns, c->streamMajor, static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
     int e1 = mark();
     if (timing) c->spans.push_back({e0, e1, 0});
     { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, bb, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
@@ -1336,6 +1339,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
   else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
+  else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
   else if (n == "fused_bounce") {
     if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "fused_bounce: 0 or 1");
     if (value != c->fusedBounce) { (void)hipStreamSynchronize(c->stream); c->fusedBounce = value; c->stateAllocated = false; }
@@ -1363,6 +1367,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "trace_blocks_per_cu") *value = c->traceBlocksPerCU;
   else if (n == "queue_segments") *value = c->nsegWanted;
   else if (n == "fused_bounce") *value = c->fusedBounce;
+  else if (n == "path_order") *value = c->streamMajor;
   else if (n == "samples_in_flight") *value = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(size_t(c->w) * c->h);
   else return fail(c, HYDRA_HIP_EINVAL, "get_option: unknown option " + n);
   return HYDRA_HIP_OK;
