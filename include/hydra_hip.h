@@ -98,9 +98,10 @@ int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
 /* Options.
  * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
  * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12);
- * "trace_rays_per_lane"; "shade_waves" 3|4|5 = register budget variant of the hit/shade kernels (default 4);
+ * "shade_waves" 3|4|5 = register budget variant of the bounce kernels (default 3);
  * "shade_blocks_per_cu", "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
- * (default 32).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
+ * (default 8); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
+ * "path_order" 1 = stream-major slots (default), 0 = pixel-major.  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
  * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..64, 0 = chosen from the resolution:
  * 16 at 1080p).  Sample j of a trace_pass(spp) call draws from generator stream j % K of its pixel, stream k of pixel p
  * being RandomGenInit(seed + k * width * height + p) -- the per-slot seeding of the reference's wavefront layer

@@ -288,6 +288,34 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky"])
+def test_tuning_options_do_not_change_the_image(fix, request):
+    """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
+    fusion, slot order, register budget, refill threshold"""
+    core, b, _ = request.getfixturevalue(fix)
+    w, h = b["width"], b["height"]
+    defaults = {k: core.get_option(k) for k in ("trace_mode", "fused_bounce", "path_order", "shade_waves", "trace_min_active")}
+
+    def render():
+        core.set_tile_partition(0, 1, 64)
+        core.init_path_tracing(99)
+        core.reset_perf_counters()
+        core.trace_pass(3)
+        st = core.rays_stat()
+        return core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays)
+    try:
+        base = render()
+        for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8)):
+            core.set_option(name, value)
+            img, ext, sh = render()
+            core.set_option(name, defaults[name])
+            assert (img.view(np.uint32) == base[0].view(np.uint32)).all(), name
+            assert (ext, sh) == base[1:], name
+    finally:
+        for k, v in defaults.items():
+            core.set_option(k, v)
+
+
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     from hydracore_amd import HipCore, HydraError
     core, b, _ = gpu224
