@@ -475,6 +475,13 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
         next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
       }
     }
+#ifdef HK_EXP_BOUNCE_EXTRA_VALU   /* timing experiment: N dependent multiply-adds per path, result parked in the unused pend4.w */
+    {
+      float x = oThr.x;
+      for (int rep = 0; rep < HK_EXP_BOUNCE_EXTRA_VALU; rep++) { asm volatile("" : "+v"(x)); x = x * 1.0001f + 0.5f; }
+      oPend.w = x;
+    }
+#endif
     const int dst = it.base + wave_compact_index(alive, nextCount);
     shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
     if (alive) {
