@@ -247,11 +247,10 @@ struct LightPick {
   float4 shadowOrg;      // shadow ray origin xyz | t_far (t_far < 0: no shadow ray)
 };
 
-// H1 + E1 + E2 + L1 + L2 -- surface, environment/emission with MIS, termination, light pick + sample
-// (kernel_HitEnvironment, kernel_EvalSurface, kernel_EvalEmission, kernel_LightSelect, kernel_LightSample).
-// Returns true when the path goes on (surf, lp, gen valid); false when it ended with radiance `finalColor`.
-HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                      const HydraLiteHit& hit, RandomGen& gen, SurfaceHit& surf, LightPick& lp, f3& finalColor) {
+// H1 + E1 + E2 -- surface, environment/emission with MIS, termination (kernel_HitEnvironment, kernel_EvalSurface,
+// kernel_EvalEmission).  Returns true when the path goes on (surf valid); false when it ended with radiance `finalColor`.
+HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
+                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
   const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
   const uint32_t flags = uint32_t(as_int(dir4.w));
   f3 currColor = mk3(0, 0, 0);
@@ -281,6 +280,11 @@ HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& 
     finalColor = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
     return false;
   }
+  return true;
+}
+
+// L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample)
+HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& gen, LightPick& lp) {
   const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
   lp.pickProb = 1.0f;
   lp.lightOffset = SelectRandomLightRev(rl.z, s, lp.pickProb);
@@ -296,7 +300,6 @@ HK_DEV bool hit_phase(const SceneDev& s, int depth, int maxDepth, const float4& 
   }
   lp.color = sam.color;
   lp.pdfSigned = sam.isPoint ? -sam.pdf : sam.pdf;
-  return true;
 }
 
 // S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
@@ -362,12 +365,13 @@ HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ 
       const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
       f3 finalColor;
-      alive = hit_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, gen, surf, lp, finalColor);
+      alive = surface_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
       if (!alive) {
         const int gid = as_int(pos4.w);
         contrib[gid] = mk4(finalColor, 0.0f);
         gens[gid] = make_uint2(gen.x, gen.y);
-      }
+      } else
+        light_phase(s, surf, gen, lp);
     }
     const int dst = it.base + wave_compact_index(alive, nextCount);
     shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
@@ -445,9 +449,11 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
     RandomGen gen; gen.x = gen.y = 0;
     LightPick lp;
     lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
+    float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
+    SurfaceHit surf;
+    f3 finalColor = mk3(0, 0, 0);
     if (idx < count) {
-      const float4 pos4 = Sin.pos4[i], dir4 = Sin.dir4[i], thr4 = Sin.thr4[i];
-      float4 acc4 = Sin.acc4[i];
+      pos4 = Sin.pos4[i]; dir4 = Sin.dir4[i]; thr4 = Sin.thr4[i]; acc4 = Sin.acc4[i];
       if (depth > 0) {   // settle the previous bounce's next-event estimate
         const float4 pend = Sin.pend4[i];
         const float vis = sh.vis[i];
@@ -457,14 +463,18 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
       gen.x = g2.x; gen.y = g2.y;
       const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
-      SurfaceHit surf;
-      f3 finalColor;
-      alive = hit_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, gen, surf, lp, finalColor);
+      alive = surface_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
+    }
+    // the slot of the survivor is reserved as soon as survival is known: the returning atomic then overlaps the light and
+    // material fetches below instead of standing alone at the end of the iteration
+    const int dst = it.base + wave_compact_index(alive, nextCount);
+    if (idx < count) {
       if (!alive) {
         const int gid = as_int(pos4.w);
         contrib[gid] = mk4(finalColor, 0.0f);
         gens[gid] = make_uint2(gen.x, gen.y);
       } else {
+        light_phase(s, surf, gen, lp);
         const float* mat = materialAt(s, surf.matId);
         const f3 ray_dir = xyz(dir4);
         f3 pend = mk3(0, 0, 0);
@@ -482,7 +492,6 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
       oPend.w = x;
     }
 #endif
-    const int dst = it.base + wave_compact_index(alive, nextCount);
     shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
     if (alive) {
       Sout.pos4[dst] = oPos; Sout.dir4[dst] = oDir; Sout.thr4[dst] = oThr; Sout.acc4[dst] = oAcc;
@@ -585,7 +594,7 @@ __global__ void k_stage_surface(SceneDev s, int n, const float4* pos4, const flo
   r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
 }
 // one shading point with the random numbers handed in: the product's light pick / light sample / materialEval / BxDF sampling
-// device functions exactly as k_bounce calls them (hit_phase's second half, direct_light_unoccluded's inputs, next_bounce_phase)
+// device functions exactly as k_bounce calls them (light_phase, direct_light_unoccluded's inputs, next_bounce_phase)
 __global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__ surf24, const float4* __restrict__ dir4, const int* __restrict__ flagsIn,
                                     const float4* __restrict__ rndLight4, const float* __restrict__ rands10, float* __restrict__ out28) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
