@@ -129,14 +129,14 @@ HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float
 // lanes of the wave are still walking) and re-entered after the idle lanes fetched new rays; the sequence of node
 // visits, pushes and triangle tests of each ray is the same as in the uninterrupted loop.
 struct TravState {
-  f3 pos, dir, inv, opos, odir;
+  f3 pos, dir, inv, opos, odir, oinv;   // oinv = SafeInverse(odir), kept instead of recomputed when the ray leaves an instance
   HydraLiteHit hit;
   int top, left, instDeep, instTop, instId;
   bool searching;
 };
 HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit) {
   t.pos = pos; t.dir = dir; t.inv = SafeInverse(dir);
-  t.opos = mk3(0, 0, 0); t.odir = mk3(0, 0, 0);
+  t.opos = mk3(0, 0, 0); t.odir = mk3(0, 0, 0); t.oinv = mk3(0, 0, 0);
   t.hit = hit;
   t.top = 0; t.left = 1; t.instDeep = 0; t.instTop = 0; t.instId = -1;
   t.searching = true;
@@ -192,7 +192,7 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);
       t.left = t.left & 0x7fffffff;
       if (haveInst && t.top < t.instTop && t.instDeep == 1) {
-        t.pos = t.opos; t.dir = t.odir; t.inv = SafeInverse(t.dir); t.instDeep = 0;
+        t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;   // = SafeInverse(t.odir), same bits (ctrace.h:1000-1006)
       }
     }
     if (!haveInst) {
@@ -209,7 +209,7 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 0) {
       t.instDeep = 1;
-      t.opos = t.pos; t.odir = t.dir;
+      t.opos = t.pos; t.odir = t.dir; t.oinv = t.inv;
       const int nextOffset = as_int(bv.node(t.left, 0).w);
       m44 matrix;
       matrix.c[0] = bv.node(t.left, 2); matrix.c[1] = bv.node(t.left, 3); matrix.c[2] = bv.node(t.left, 4); matrix.c[3] = bv.node(t.left, 5);
@@ -224,7 +224,7 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
     t.searching = !(t.left & int(HYDRA_BVH_LEAF));
     t.left = t.left & 0x7fffffff;
     if (haveInst && t.top < t.instTop && t.instDeep == 1) {
-      t.pos = t.opos; t.dir = t.odir; t.inv = SafeInverse(t.dir); t.instDeep = 0;
+      t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;
     }
     if (minActive > 0 && t.top >= 0 && HK_WAVE_ACTIVE_LANES() < minActive) return false;   // let the wave refill
   }
