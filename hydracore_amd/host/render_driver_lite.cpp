@@ -348,13 +348,26 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
 }
 
 // SkyDomeLight, hydra_drv/PlainLightConverter.cpp:909-1051 + RenderDriverRTE::UpdatePdfTablesForLight
-// (RenderDriverRTE_PdfTables.cpp:479-570).  Constant-colour sky only: a sky without texture gets the reference's 2x2
-// uniform luminance image as its sampling table; textured and Perez skies are counted as unsupported.
+// (RenderDriverRTE_PdfTables.cpp:479-570).  A sky without texture gets the reference's 2x2 uniform luminance image as its
+// sampling table; an 8-bit lat-long texture gets the table of LuminanceFromUchar4Image (:312-356: halve until <= 256,
+// max(r,g,b)/255, + 0.1 * max(mean, 1)).  Skies with a sampler matrix other than identity, float textures (their table is
+// Gauss-blurred by HydraAPI's HDRImageLite, absent here) and the Perez model are counted as unsupported.
 bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) {
   if (a_node->child("perez")) Unsupported("Perez sky model");
   const XmlNode* inten = a_node->child("intensity");
   const XmlNode* colorNode = xchild(inten, "color");
-  if (colorNode && colorNode->child("texture")) Unsupported("textured sky light (environment map)");
+  const XmlNode* texNode = colorNode ? colorNode->child("texture") : nullptr;
+  int32_t skyTexId = int32_t(HYDRA_INVALID_TEXTURE);
+  float skyGamma = 1.0f;
+  if (texNode) {
+    if (texNode->has_attr("matrix")) {
+      float m[16];
+      const float ident16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      if (!parse_floats(texNode->attr("matrix"), m, 16) || memcmp(m, ident16, 64) != 0) Unsupported("sky light texture matrix other than identity");
+    }
+    if (texNode->has_attr("input_gamma")) skyGamma = texNode->attr_float("input_gamma");
+    if (texNode->has_attr("id")) skyTexId = texNode->attr_int("id");
+  }
   float3 color = read_value3f(colorNode);
   color = color * read_value1f(xchild(inten, "multiplier"));   // HydraXMLHelpers::ReadLightIntensity
 
@@ -364,16 +377,16 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   d[HL_PROB_MULT] = 1.0f;
   d[HL_COLOR] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
   float* sam0 = d + HL_SKY_SAMPLER0;                       // SWTexSampler: flags, gamma, texId, dummy, row0, row1
-  put_i(sam0, HS_FLAGS, 0); sam0[HS_GAMMA] = 1.0f; put_i(sam0, HS_TEXID, int32_t(HYDRA_INVALID_TEXTURE)); put_i(sam0, HS_DUMMY, 0);
+  put_i(sam0, HS_FLAGS, 0); sam0[HS_GAMMA] = skyGamma; put_i(sam0, HS_TEXID, skyTexId); put_i(sam0, HS_DUMMY, 0);
   sam0[HS_ROW0] = 1.0f; sam0[HS_ROW1 + 1] = 1.0f;          // identity sampler matrix rows
   memcpy(d + HL_SKY_SAMPLER1, sam0, 12 * sizeof(float));
-  put_i(d, HL_COLOR_TEX, int32_t(HYDRA_INVALID_TEXTURE));         // no texture ...
-  put_i(d, HL_COLOR_TEX_MATRIX, int32_t(HYDRA_INVALID_TEXTURE));  // ... and no sampler
+  put_i(d, HL_COLOR_TEX, skyTexId);                                                 // used to build the pdf table
+  put_i(d, HL_COLOR_TEX_MATRIX, texNode ? 0 : int32_t(HYDRA_INVALID_TEXTURE));     // 0 = "have sampler and texture" (:976-977)
   const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(d + HL_SKY_INV_MATRIX0, ident, 64);               // the reference writes both inverses to slot 0 (:947-948, 999-1000)
   d[HL_SKY_COLOR_AUX] = color.x; d[HL_SKY_COLOR_AUX + 1] = color.y; d[HL_SKY_COLOR_AUX + 2] = color.z;
-  put_i(d, HL_SKY_COLOR_TEX_AUX, int32_t(HYDRA_INVALID_TEXTURE));
-  put_i(d, HL_SKY_COLOR_TEX_MATRIX_AUX, int32_t(HYDRA_INVALID_TEXTURE));
+  put_i(d, HL_SKY_COLOR_TEX_AUX, skyTexId);
+  put_i(d, HL_SKY_COLOR_TEX_MATRIX_AUX, texNode ? 0 : int32_t(HYDRA_INVALID_TEXTURE));
   put_i(d, HL_SKY_AUX_TEX_MATRIX_INV, int32_t(HYDRA_INVALID_TEXTURE));
   d[HL_SKY_SUN_DIR] = 0.0f; d[HL_SKY_SUN_DIR + 1] = -1.0f; d[HL_SKY_SUN_DIR + 2] = 0.0f;
   d[HL_SKY_TURBIDITY] = 0.0f;
@@ -382,16 +395,54 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   put_i(d, HL_TYPE, HLT_SKY_DOME);
   put_i(d, HL_FLAGS, 0);
 
-  // pdf tables 0 and 1: header {w, h, 1, n + 1} + prefix sums of the 2x2 luminance image + a trailing 1.0
+  // luminance image the directions are importance-sampled from
+  int lw = 2, lh = 2;
+  std::vector<float> lum(4, 0.25f);
+  if (skyTexId != int32_t(HYDRA_INVALID_TEXTURE)) {
+    const std::vector<int32_t> table = m_pTexStorage->GetTable();
+    if (skyTexId < 0 || skyTexId >= int32_t(table.size()) || table[skyTexId] < 0) RunTimeError("UpdateLight: sky light texture " + std::to_string(skyTexId) + " is not loaded");
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(static_cast<const char*>(m_pTexStorage->GetBegin()) + size_t(table[skyTexId]) * 16);
+    int w = hdr[0], h = hdr[1];
+    const int bpp = hdr[3];
+    if (bpp != 4) { Unsupported("float sky light texture (its pdf table needs HydraAPI's Gauss blur)"); }
+    else {
+      std::vector<uint8_t> px(reinterpret_cast<const uint8_t*>(hdr + 4), reinterpret_cast<const uint8_t*>(hdr + 4) + size_t(w) * h * 4);
+      for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizeUB4, :268-310
+        if (w <= 256 && h <= 256) continue;
+        const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
+        std::vector<uint8_t> half(size_t(nw) * nh * 4);
+        for (int y = 0; y < nh; y++)
+          for (int x = 0; x < nw; x++)
+            for (int ch = 0; ch < 4; ch++) {
+              const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
+              const int sum = px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch] + px[size_t(o2 + 2 * x) * 4 + ch] + px[size_t(o2 + 2 * x + 1) * 4 + ch];
+              half[(size_t(y) * nw + x) * 4 + ch] = uint8_t(std::min(sum >> 2, 255));
+            }
+        px.swap(half); w = nw; h = nh;
+      }
+      lum.assign(size_t(w) * h, 0.0f);
+      float avg = 0.0f;
+      for (size_t i = 0; i < lum.size(); i++) {
+        const float r = px[i * 4] * (1.0f / 255.0f), g = px[i * 4 + 1] * (1.0f / 255.0f), b = px[i * 4 + 2] * (1.0f / 255.0f);
+        lum[i] = std::max(r, std::max(g, b));
+        avg += lum[i];
+      }
+      avg /= float(lum.size());
+      avg = std::max(avg, 1.0f);
+      for (float& v : lum) v += 0.1f * avg;                         // no pixel with zero pdf
+      lw = w; lh = h;
+    }
+  }
+  // pdf tables 0 and 1: header {w, h, 1, n + 1} + prefix sums of the luminance image + a trailing 1.0 (:546-566)
   for (int t = 0; t < 2; t++) {
     const int32_t tabId = m_pPdfStorage->GetMaxObjectId() + 1;
-    const float lum[4] = {0.25f, 0.25f, 0.25f, 0.25f};
-    std::vector<float> data(4 + 5 + 1);
-    put_i(data.data(), 0, 2); put_i(data.data(), 1, 2); put_i(data.data(), 2, 1); put_i(data.data(), 3, 5 + 1);
+    const size_t n = lum.size() + 1;                                // PrefixSumm: n + 1 entries
+    std::vector<float> data(4 + n + 1);
+    put_i(data.data(), 0, lw); put_i(data.data(), 1, lh); put_i(data.data(), 2, 1); put_i(data.data(), 3, int32_t(n + 1));
     float acc = 0.0f;
-    for (int i = 0; i < 4; i++) { data[4 + i] = acc; acc += lum[i]; }
-    data[4 + 4] = acc;
-    data[9] = 1.0f;
+    for (size_t i = 0; i < lum.size(); i++) { data[4 + i] = acc; acc += lum[i]; }
+    data[4 + lum.size()] = acc;
+    data[4 + n] = 1.0f;
     m_pPdfStorage->Update(tabId, data.data(), data.size() * sizeof(float));
     put_i(d, HL_SKY_PDF_TABLE0 + t, tabId);
   }

@@ -51,6 +51,16 @@ def gpu_atrium_sky(built):
     return core, b, make_oracle(b)
 
 
+@pytest.fixture(scope="module")
+def gpu_atrium_skytex(built):
+    """open roof and a lat-long environment texture as the sky light (512x256, importance table 256x128)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_skytex_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
 def test_native_library_is_the_one_running(gpu224):
     core, _, _ = gpu224
     name = core.device_name()
@@ -147,7 +157,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -163,7 +173,7 @@ def test_light_and_material_functions_at_shading_points(fix, request):
     check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -184,7 +194,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]

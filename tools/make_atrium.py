@@ -174,7 +174,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
+    ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     args = ap.parse_args()
+    args.sky = args.sky or args.sky_tex
     s = np.sqrt(args.scale)
     rng = np.random.default_rng(SEED)
     out = args.out
@@ -187,14 +189,26 @@ def main():
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
+    if args.sky_tex:   # id 3: environment map, y = 0 is straight down (texCoord2DToSphereMap: theta = v * pi measured from -y)
+        hh, ww = 256, 512
+        v, u = np.meshgrid((np.arange(hh) + 0.5) / hh, (np.arange(ww) + 0.5) / ww, indexing="ij")
+        up = np.clip((v - 0.5) * 2.0, 0.0, 1.0)                       # 0 at the horizon, 1 at the zenith
+        env = np.zeros((hh, ww, 4), np.float64)
+        env[..., 0] = 0.35 + 0.25 * (1 - up); env[..., 1] = 0.45 + 0.25 * (1 - up); env[..., 2] = 0.75 - 0.15 * (1 - up)
+        env[v < 0.5] = [0.12, 0.11, 0.10, 0]                          # ground half
+        sun = np.exp(-(((u - 0.62) * 2.0) ** 2 + (v - 0.80) ** 2) / (2 * 0.02 ** 2))
+        env[..., :3] = np.clip(env[..., :3] + sun[..., None] * np.array([1.0, 0.95, 0.8]), 0, 1)
+        env[..., 3] = 1.0
+        texs.append((None, (env * 255.0 + 0.5).astype(np.uint8)))
     xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
     chunk = 0
     for tid, (n, img) in enumerate(texs):
         name = "data/chunk_%05d.image4ub" % chunk
+        th, tw = img.shape[0], img.shape[1]
         with open(os.path.join(out, name), "wb") as f:
-            f.write(struct.pack("<II", n, n))
+            f.write(struct.pack("<II", tw, th))
             f.write(img.tobytes())
-        xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, n * n * 4, n, n))
+        xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, tw * th * 4, tw, th))
         chunk += 1
     xml.append("</textures_lib>")
 
@@ -216,7 +230,9 @@ def main():
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
-               + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
+               + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1">'
+                  '<texture id="3" type="texref" input_gamma="2.2" /></color><multiplier val="0.8" /></intensity></light>' if args.sky_tex else
+                  '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
                   '<multiplier val="0.5" /></intensity></light>' if args.sky else '') + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
