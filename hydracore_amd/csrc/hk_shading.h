@@ -779,10 +779,80 @@ HK_DEV void SkyLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 il
   out.maxDist = length(illum - samplePos);
   out.cosAtLight = 1.0f;
 }
-// LightSampleRev, clight.h:1561-1610: the light types this layer accepts
+// ---- delta lights: point (omni, no IES), spot, directional (clight.h:1394-1506) ----
+HK_DEV float mylocalsmoothstep(float edge0, float edge1, float x) {   // clight.h:7-12
+  const float tVal = (x - edge0) / (edge1 - edge0);
+  const float t = fminf(fmaxf(tVal, 0.0f), 1.0f);
+  return t * t * (3.0f - 2.0f * t);
+}
+HK_DEV float PdfAtoW(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / fmaxf(aCosThere, HK_DEPSILON2); }   // cglobals.h:1754-1757
+HK_DEV void PointLightSampleRev(const float* L, f3 illum, ShadowSample& out) {   // clight.h:1394-1407; lightDistributionMask = 1 without IES (:465-484)
+  const f3 samplePos = lightPos(L);
+  const float hitDist = length(samplePos - illum);
+  out.isPoint = true;
+  out.pos = samplePos;
+  out.color = mk3(1.0f, 1.0f, 1.0f) * lightColor(L);
+  out.pdf = PdfAtoW(1.0f, hitDist, 1.0f);
+  out.maxDist = hitDist;
+  out.cosAtLight = 1.0f;
+}
+HK_DEV void SpotLightSampleRev(const float* L, f3 illum, ShadowSample& out) {   // clight.h:1416-1450
+  const f3 samplePos = lightPos(L), norm = lightNorm(L);
+  const float hitDist = length(samplePos - illum);
+  const f3 rayDir = normalize(samplePos - illum);
+  const float cos_theta = fmaxf(dot(rayDir * (-1.0f), norm), 0.0f);
+  const float atten = mylocalsmoothstep(L[HL_POINT_SPOT_COS2], L[HL_POINT_SPOT_COS1], cos_theta);
+  out.isPoint = true;
+  out.pos = samplePos;
+  out.color = lightColor(L) * atten;
+  out.pdf = PdfAtoW(1.0f, hitDist, 1.0f);
+  out.maxDist = hitDist;
+  out.cosAtLight = fmaxf(-dot(rayDir, norm), 0.0f);
+}
+HK_DEV f3 MapSamplesToCone(float cosCutoff, f2 sample, f3 direction) {   // cglobals.h:1655-1681
+  const float cosTheta = (1.0f - sample.x) + sample.x * cosCutoff;
+  const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+  const float sinPhi = sinf(2.0f * HK_PI * sample.y), cosPhi = cosf(2.0f * HK_PI * sample.y);
+  const f3 deviation = mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+  f3 nx, nz;
+  CoordinateSystem(direction, nx, nz);
+  const f3 ny = nz, nz2 = direction;   // the reference swaps ny and nz
+  return ((nx * deviation.x) + (ny * deviation.y)) + (nz2 * deviation.z);
+}
+HK_DEV void DirectLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:1478-1506, attenuation :892-912
+  const f3 lpos = lightPos(L);
+  f3 norm = lightNorm(L);
+  const float pdfW = 1.0f;
+  if (L[HL_DIRECT_SSOFTNESS] > 1e-5f) norm = MapSamplesToCone(L[HL_DIRECT_ALPHA_COS], mk2(rands.x, rands.y), norm);
+  const f3 AC = illum - lpos;
+  const float CBLen = dot(normalize(AC), norm) * length(AC);
+  float atten = 0.0f;
+  {
+    const f3 n0 = lightNorm(L);
+    const float cos_alpha = dot(normalize(illum - lpos), n0);
+    if (cos_alpha > 0.0f) {
+      const float sinAlpha = sqrtf(1.0f - cos_alpha * cos_alpha);
+      const float d = length(illum - lpos) * sinAlpha;
+      const float r1 = L[HL_DIRECT_RADIUS1], r2 = L[HL_DIRECT_RADIUS2];
+      atten = mylocalsmoothstep(fmaxf(r2, r1), fminf(r2, r1), d);
+    }
+  }
+  out.isPoint = true;
+  out.pos = illum - norm * CBLen;
+  out.color = (lightColor(L) * atten) * pdfW;
+  out.pdf = pdfW;
+  out.maxDist = CBLen;
+  out.cosAtLight = 1.0f;
+}
+// LightSampleRev, clight.h:1561-1610: the light types this layer accepts (upload_globals rejects the others)
 HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
-  if (as_int(L[HL_TYPE]) == HLT_SKY_DOME) SkyLightSampleRev(s, L, rands, illum, out);
-  else AreaLightSampleRev(L, rands, illum, out);
+  switch (as_int(L[HL_TYPE])) {
+    case HLT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
+    case HLT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
+    case HLT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
+    case HLT_POINT_OMNI: PointLightSampleRev(L, illum, out); break;
+    default: AreaLightSampleRev(L, rands, illum, out); break;
+  }
 }
 // environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)
 HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool prevSpecular, uint32_t flags) {

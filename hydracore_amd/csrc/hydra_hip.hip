@@ -1105,12 +1105,15 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (blob[at + HL_TYPE] != HLT_SKY_DOME) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId does not name a sky light");
     if (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ) c->skyLightOk = false;
   }
-  for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone) and sky-dome lights only
+  for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sky-dome, point, spot and directional lights
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
     const int type = blob[at + HL_TYPE];
-    if (type != HLT_AREA && type != HLT_SKY_DOME)
-      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area and sky-dome lights only");
+    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT);
+    if (!known)
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sky-dome, point, spot and directional lights only");
+    if (blob[at + HL_FLAGS] & HLF_HAS_IES)
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
   }
   return dev_upload(c, c->globals, blob, words * 4);
 }

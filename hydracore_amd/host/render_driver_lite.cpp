@@ -347,6 +347,55 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   return true;
 }
 
+// DirectLight (:500-566, CreateDirectLightFromXmlNode :840-855), SpotLight (:568-626, CreatePointSpotLightFromXmlNode :894-906)
+// and PointLight without IES (:628-700); OLD_PHOTOMETRIC_SCALE is 1 (:15)
+bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node) {
+  const std::string ltype = a_node->attr("type"), distr = a_node->attr("distribution");
+  if (distr == "ies" || a_node->child("ies") || a_node->child("honio")) Unsupported("IES / honio light distribution");
+  const XmlNode* inten = a_node->child("intensity");
+  const float3 color = read_value3f(xchild(inten, "color")) * read_value1f(xchild(inten, "multiplier"));
+  const float DEG2RAD = 3.14159265358979323846f / 180.f;
+  LightProto lp;
+  lp.plain.assign(HL_FLOATS, 0.0f);
+  float* d = lp.plain.data();
+  d[HL_PROB_MULT] = 1.0f;
+  d[HL_COLOR] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+  put_i(d, HL_FLAGS, 0);
+  if (ltype == "directional" || distr == "directional") {
+    const XmlNode* size = a_node->child("size");
+    const float r1 = size ? size->attr_float("inner_radius") : 0.0f, r2 = size ? size->attr_float("outer_radius") : 0.0f;
+    const float soft = read_value1f(xchild(a_node, "shadow_softness"));
+    float angle = read_value1f(xchild(a_node, "angle_radius"));
+    if (!a_node->child("angle_radius")) angle = 0.25f * soft;
+    d[HL_NORM + 1] = -1.0f;
+    d[HL_DIRECT_RADIUS1] = r1; d[HL_DIRECT_RADIUS2] = r2;
+    const float alpha = DEG2RAD * angle;
+    d[HL_DIRECT_SSOFTNESS] = angle / 0.25f;
+    d[HL_DIRECT_ALPHA_TAN] = tanf(alpha);
+    d[HL_DIRECT_ALPHA_COS] = cosf(alpha);
+    d[HL_SURFACE_AREA] = 3.14159265358979323846f * r2 * r2;
+    put_i(d, HL_TYPE, HLT_DIRECT);
+    lp.kind = 2;
+  } else if (distr == "spot") {
+    const float angle2 = read_value1f(xchild(a_node, "falloff_angle")), angle1 = read_value1f(xchild(a_node, "falloff_angle2"));
+    d[HL_NORM + 1] = -1.0f;
+    d[HL_POINT_SPOT_COS1] = cosf(0.5f * DEG2RAD * angle1);
+    d[HL_POINT_SPOT_COS2] = cosf(0.5f * DEG2RAD * angle2);
+    d[HL_SURFACE_AREA] = 1e-10f;
+    put_i(d, HL_TYPE, HLT_POINT_SPOT);
+    lp.kind = 1;
+  } else {
+    d[HL_SURFACE_AREA] = 1e-10f;
+    put_i(d, HL_TYPE, HLT_POINT_OMNI);
+    put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
+    put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
+    lp.kind = 0;
+  }
+  lp.isDelta = true;
+  m_lights[a_lightId] = lp;
+  return true;
+}
+
 // SkyDomeLight, hydra_drv/PlainLightConverter.cpp:909-1051 + RenderDriverRTE::UpdatePdfTablesForLight
 // (RenderDriverRTE_PdfTables.cpp:479-570).  A sky without texture gets the reference's 2x2 uniform luminance image as its
 // sampling table; an 8-bit lat-long texture gets the table of LuminanceFromUchar4Image (:312-356: halve until <= 256,
@@ -456,6 +505,7 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
 bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   const std::string ltype = a_node->attr("type"), lshape = a_node->attr("shape"), distr = a_node->attr("distribution");
   if (ltype == "sky") return UpdateSkyLight(a_lightId, a_node);
+  if (ltype == "directional" || distr == "directional" || lshape == "point") return UpdateDeltaLight(a_lightId, a_node);   // factory order of PlainLightConverter.cpp:1070-1105
   if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
   if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
   if (xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1) Unsupported("sky portal");
@@ -659,6 +709,19 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
     memcpy(M.c, a_matrix + 16 * i, 64);
     std::vector<float> copy = it->second.plain;
     float* d = copy.data();
+    if (it->second.isDelta) {                     // position by the matrix; spot/direct also rotate their normal (:534-566, 594-626, 700-715)
+      const float3 lp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+      d[HL_POS] = lp0.x; d[HL_POS + 1] = lp0.y; d[HL_POS + 2] = lp0.z;
+      if (it->second.kind != 0) {
+        const float3 ln0 = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
+        d[HL_NORM] = ln0.x; d[HL_NORM + 1] = ln0.y; d[HL_NORM + 2] = ln0.z;
+      }
+      put_i(d, HL_GROUP_ID, a_lightGroupId);
+      d[HL_PICK_PROB_REV] = 1.0f;
+      d[HL_PICK_PROB_FWD] = 1.0f;
+      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
+      continue;
+    }
     if (it->second.isSky) {                       // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
       put_i(d, HL_GROUP_ID, a_lightGroupId);
       d[HL_PICK_PROB_REV] = 1.0f;

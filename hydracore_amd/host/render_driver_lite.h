@@ -45,6 +45,7 @@ public:
   bool UpdateMaterial(int32_t a_matId, const XmlNode* a_materialNode);
   bool UpdateLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateSkyLight(int32_t a_lightId, const XmlNode* a_lightNode);
+  bool UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateMesh(int32_t a_meshId, int vertNum, int triNum, const float* pos4f, const float* norm4f, const float* tan4f,
                   const float* texcoord2f, const int* indices, const int* triMatIndices);
   bool UpdateCamera(const XmlNode* a_camNode);
@@ -70,7 +71,7 @@ private:
 
   struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0}; } m_camera;
 
-  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false; };   // un-instanced PlainLight (128 floats)
+  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false; int kind = 0; };   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
   std::map<int, LightProto> m_lights;
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
 

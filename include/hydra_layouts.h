@@ -165,6 +165,9 @@ enum {
   HL_AREA_SPOT_DISTR = 26, HL_AREA_SPOT_COS1 = 27, HL_AREA_SPOT_COS2 = 28, HL_AREA_SKY_OFFSET = 29,
   HL_AREA_SKY_SOURCE = 30, HL_AREA_SKYPORTAL_BTEX = 31, HL_AREA_SKYPORTAL_BTEX_MATRIX = 32,
   HL_AREA_SAMPLER0 = 40, HL_AREA_SAMPLER1 = 52,
+  /* point/spot (clight.h:118-119) and directional lights (:123-127) */
+  HL_POINT_SPOT_COS1 = 14, HL_POINT_SPOT_COS2 = 15,
+  HL_DIRECT_RADIUS1 = 14, HL_DIRECT_RADIUS2 = 15, HL_DIRECT_SSOFTNESS = 16, HL_DIRECT_ALPHA_TAN = 17, HL_DIRECT_ALPHA_COS = 18,
   /* sky dome (clight.h:131-165): pdf table ids, sampler (float4 + 2 matrix rows), inverse sampler matrix (float4x4) */
   HL_SKY_COLOR_AUX = 17, HL_SKY_COLOR_TEX_AUX = 20, HL_SKY_COLOR_TEX_MATRIX_AUX = 21, HL_SKY_AUX_TEX_MATRIX_INV = 22,
   HL_SKY_SUN_DIR = 23, HL_SKY_TURBIDITY = 26, HL_SKY_SUN_COLOR = 27, HL_SKY_PDF_TABLE0 = 30, HL_SKY_PDF_TABLE1 = 31,

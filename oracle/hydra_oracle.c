@@ -50,7 +50,9 @@ enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, P
        PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
        AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107,
        PL_COLOR_TEX_MATRIX = 12, SKY_DOME_PDF_TABLE0 = 30, SKY_DOME_SAMPLER0 = 32, SKY_DOME_MATRIX0 = 36, SKY_DOME_INV_MATRIX0 = 56 };   /* clight.h:131-165 */
-enum { LT_SKY_DOME = 3, LT_AREA = 4 };
+enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4 };
+enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADIUS1 = 14, DIRECT_LIGHT_RADIUS2 = 15,
+       DIRECT_LIGHT_SSOFTNESS = 16, DIRECT_LIGHT_ALPHA_TAN = 17, DIRECT_LIGHT_ALPHA_COS = 18 };   /* clight.h:118-127 */
 enum { HRT_BSPHERE_RADIUS = 21 };
 enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16 };
 /* ray flags, ref: cglobals.h:1330-1376 */
@@ -1161,6 +1163,86 @@ static void SkyLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 il
   out->maxDist = length3(sub3(illum, samplePos));
   out->cosAtLight = 1.0f;
 }
+/* ---- delta lights ---- */
+/* ref: clight.h:7-12 mylocalsmoothstep */
+static float mylocalsmoothstep(float edge0, float edge1, float x) {
+  const float tVal = (x - edge0) / (edge1 - edge0);
+  const float t = fminf(fmaxf(tVal, 0.0f), 1.0f);
+  return t * t * (3.0f - 2.0f * t);
+}
+/* ref: cglobals.h:1754-1757 PdfAtoW */
+static float PdfAtoW_full(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / fmaxf(aCosThere, DEPSILON2); }
+/* ref: clight.h:1394-1407 PointLightSampleRev; lightDistributionMask (:465-484) is (1,1,1) without IES */
+static void PointLightSampleRev(const float* L, f3 illum, ShadowSample* out) {
+  const f3 samplePos = v3(L[PL_POS], L[PL_POS + 1], L[PL_POS + 2]);
+  const float hitDist = length3(sub3(samplePos, illum));
+  out->isPoint = 1;
+  out->pos = samplePos;
+  out->color = mul3(v3(1.0f, 1.0f, 1.0f), v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]));
+  out->pdf = PdfAtoW_full(1.0f, hitDist, 1.0f);
+  out->maxDist = hitDist;
+  out->cosAtLight = 1.0f;
+}
+/* ref: clight.h:1416-1450 pointSpotLightAttenuation + SpotLightSampleRev */
+static void SpotLightSampleRev(const float* L, f3 illum, ShadowSample* out) {
+  const f3 samplePos = v3(L[PL_POS], L[PL_POS + 1], L[PL_POS + 2]), norm = v3(L[PL_NORM], L[PL_NORM + 1], L[PL_NORM + 2]);
+  const float hitDist = length3(sub3(samplePos, illum));
+  const f3 rayDir = normalize3(sub3(samplePos, illum));
+  const float cos_theta = fmaxf(dot3(scale3(rayDir, -1.0f), norm), 0.0f);
+  const float atten = mylocalsmoothstep(L[POINT_LIGHT_SPOT_COS2], L[POINT_LIGHT_SPOT_COS1], cos_theta);
+  out->isPoint = 1;
+  out->pos = samplePos;
+  out->color = scale3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), atten);
+  out->pdf = PdfAtoW_full(1.0f, hitDist, 1.0f);
+  out->maxDist = hitDist;
+  out->cosAtLight = fmaxf(-dot3(rayDir, norm), 0.0f);
+}
+/* ref: cglobals.h:1655-1681 MapSamplesToCone */
+static f3 MapSamplesToCone(float cosCutoff, f2 sample, f3 direction) {
+  const float cosTheta = (1.0f - sample.x) + sample.x * cosCutoff;
+  const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+  const float sinPhi = sinf(2.0f * ORC_PI * sample.y), cosPhi = cosf(2.0f * ORC_PI * sample.y);
+  const f3 deviation = v3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+  f3 nx, nz;
+  CoordinateSystem(direction, &nx, &nz);
+  const f3 ny = nz, nz2 = direction;   /* the reference swaps ny and nz */
+  return add3(add3(scale3(nx, deviation.x), scale3(ny, deviation.y)), scale3(nz2, deviation.z));
+}
+/* ref: clight.h:1478-1506 DirectLightSampleRev, :892-912 directLightAttenuation */
+static void DirectLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  const f3 lpos = v3(L[PL_POS], L[PL_POS + 1], L[PL_POS + 2]);
+  const f3 n0 = v3(L[PL_NORM], L[PL_NORM + 1], L[PL_NORM + 2]);
+  f3 norm = n0;
+  const float pdfW = 1.0f;
+  if (L[DIRECT_LIGHT_SSOFTNESS] > 1e-5f) { f2 sm; sm.x = rands.x; sm.y = rands.y; norm = MapSamplesToCone(L[DIRECT_LIGHT_ALPHA_COS], sm, norm); }
+  const f3 AC = sub3(illum, lpos);
+  const float CBLen = dot3(normalize3(AC), norm) * length3(AC);
+  float atten = 0.0f;
+  const float cos_alpha = dot3(normalize3(sub3(illum, lpos)), n0);
+  if (cos_alpha > 0.0f) {
+    const float sinAlpha = sqrtf(1.0f - cos_alpha * cos_alpha);
+    const float d = length3(sub3(illum, lpos)) * sinAlpha;
+    const float r1 = L[DIRECT_LIGHT_RADIUS1], r2 = L[DIRECT_LIGHT_RADIUS2];
+    atten = mylocalsmoothstep(fmaxf(r2, r1), fminf(r2, r1), d);
+  }
+  out->isPoint = 1;
+  out->pos = sub3(illum, scale3(norm, CBLen));
+  out->color = scale3(scale3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), atten), pdfW);
+  out->pdf = pdfW;
+  out->maxDist = CBLen;
+  out->cosAtLight = 1.0f;
+}
+/* ref: clight.h:1561-1610 LightSampleRev, the types the layer accepts */
+static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  switch (as_int(L[PL_TYPE])) {
+    case LT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
+    case LT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
+    case LT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
+    case LT_POINT_OMNI: PointLightSampleRev(L, illum, out); break;
+    default: AreaLightSampleRev(L, rands, illum, out); break;
+  }
+}
+
 /* ref: cbidir.h:492-533 environmentColor; misPrev.prevMaterialOffset is -1 on this path (PT_Loop.cpp:247-249) */
 static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prevSpecular, uint32_t flags) {
   const int skyId = s->globals[G_SKY_LIGHT_ID];
@@ -1249,8 +1331,7 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     memset(&explicitSam, 0, sizeof(explicitSam));
     if (lightOffset >= 0) {
       const float* pl = lightAt(s, lightOffset);   /* LightSampleRev, clight.h:1561-1610 */
-      if (as_int(pl[PL_TYPE]) == LT_SKY_DOME) SkyLightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
-      else AreaLightSampleRev(pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
+      LightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
       shadowRayDir = normalize3(sub3(explicitSam.pos, surf.pos));
       shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
     }
@@ -1330,8 +1411,7 @@ void orc_shade_point(const OrcScene* s, int n, const float* surf24, const float*
       ShadowSample sam;
       memset(&sam, 0, sizeof(sam));
       const float* pl = lightAt(s, lightOffset);
-      if (as_int(pl[PL_TYPE]) == LT_SKY_DOME) SkyLightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &sam);
-      else AreaLightSampleRev(pl, v3(rl[0], rl[1], rl[2]), surf.pos, &sam);
+      LightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &sam);
       const f3 shadowRayDir = normalize3(sub3(sam.pos, surf.pos));
       o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.pdf;
       o[4] = sam.color.x; o[5] = sam.color.y; o[6] = sam.color.z; o[9] = sam.isPoint ? 1.0f : 0.0f;

@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
+    ap.add_argument("--delta-lights", action="store_true", help="open roof, no sky: adds a point, a spot and a directional (soft sun) light to the roof light")
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
@@ -185,7 +186,7 @@ def main():
     def r(n, lo=2):
         return max(lo, int(round(n * s)))
     meshes = [("column", column(r(64, 8), r(32, 4))), ("arch", arch(r(32, 4), r(32, 4))), ("pot", pot(r(20, 4), r(10, 2))),
-              ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky)), ("light", light_quad(2.0, 0.5))]
+              ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky or args.delta_lights)), ("light", light_quad(2.0, 0.5))]
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -233,7 +234,13 @@ def main():
                + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1">'
                   '<texture id="3" type="texref" input_gamma="2.2" /></color><multiplier val="0.8" /></intensity></light>' if args.sky_tex else
                   '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
-                  '<multiplier val="0.5" /></intensity></light>' if args.sky else '') + '\n</lights_lib>')
+                  '<multiplier val="0.5" /></intensity></light>' if args.sky else
+                  '\n  <light id="1" name="bulb" type="point" shape="point" distribution="uniform" visible="1"><intensity><color val="1 0.8 0.6" /><multiplier val="40.0" /></intensity></light>'
+                  '\n  <light id="2" name="spot" type="point" shape="point" distribution="spot" visible="1"><falloff_angle val="70" /><falloff_angle2 val="40" />'
+                  '<intensity><color val="0.7 0.8 1" /><multiplier val="90.0" /></intensity></light>'
+                  '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
+                  '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>' if args.delta_lights else '')
+               + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
 
@@ -280,6 +287,10 @@ def main():
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
     if args.sky:
         xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4())
+    if args.delta_lights:
+        xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4(t=(-10.0, 5.0, 1.0)))
+        xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % mat4(t=(6.0, 7.5, -2.0), rot_x=0.3))
+        xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
     xml += inst
     xml.append("  </scene>\n</scenes>")
     with open(os.path.join(out, "statex_00001.xml"), "w") as f:
