@@ -1,6 +1,7 @@
 // bvh4_builder.cpp -- binned-SAH BVH4 build + emission of the reference's flattened layout.
 // Layout citations: bvh_builder/bvh_access_dll2.cpp:264-386 (triangle lists), :388-545 (quads, instance quads),
 // :604-717 (root quad, mesh subtrees shared between instances).  The build algorithm itself is ours.
+#include <cstdlib>
 #include "bvh4_builder.h"
 #include <algorithm>
 #include <cmath>
@@ -185,7 +186,9 @@ void BVH4Builder::CommitScene() {
       prims.push_back(p);
     }
     if (prims.empty()) RunTimeError("BVH4Builder::CommitScene: mesh without valid triangles");
-    mesh.rootNode = BuildTree(prims, maxLeafSize);
+    int leafMax = maxLeafSize;
+    if (const char* e = getenv("HYDRA_BVH_MAX_LEAF")) leafMax = std::max(1, std::min(16, atoi(e)));   // tuning sweeps only
+    mesh.rootNode = BuildTree(prims, leafMax);
     mesh.bounds = m_nodes[mesh.rootNode].box;
   }
   // (2) top level over instances

@@ -39,7 +39,7 @@ public:
   void ConvertUnmap();
 
   // build statistics (for DESIGN.md / tests)
-  int maxLeafSize = 4;
+  int maxLeafSize = 2;   // measured on MI355X (profiles/r01/pass_bvh_leaf_size.log): closest-hit traversal 11 % faster than with 4, shadow rays equal
   size_t statInnerQuads = 0, statLeaves = 0, statTriangles = 0;
 
 private:
