@@ -71,7 +71,8 @@ int BVH4Builder::InstanceTriangleMeshes(InstanceInputData d, int a_treeId, int a
 
 // ------------------------------------------------------------------------------------------ build
 int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const {
-  const int NB = 16;
+  static constexpr int NBMAX = 64;
+  static const int NB = [] { const char* e = getenv("HYDRA_BVH_BINS"); const int v = e ? atoi(e) : 32; return std::max(4, std::min(NBMAX, v)); }();   // tuning sweeps only
   float3 cmn, cmx;
   box_reset(cmn, cmx);
   for (int i = begin; i < end; i++) { cmn = vmin(cmn, prims[i].centroid); cmx = vmax(cmx, prims[i].centroid); }
@@ -82,7 +83,7 @@ int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const
     const float lo = axis_of(cmn, axis), hi = axis_of(cmx, axis);
     if (!(hi > lo)) continue;
     const float scale = float(NB) / (hi - lo);
-    int cnt[NB]; float3 bmn[NB], bmx[NB];
+    int cnt[NBMAX]; float3 bmn[NBMAX], bmx[NBMAX];
     for (int b = 0; b < NB; b++) { cnt[b] = 0; box_reset(bmn[b], bmx[b]); }
     for (int i = begin; i < end; i++) {
       int b = int((axis_of(prims[i].centroid, axis) - lo) * scale);
@@ -90,7 +91,7 @@ int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const
       cnt[b]++;
       bmn[b] = vmin(bmn[b], prims[i].box.mn); bmx[b] = vmax(bmx[b], prims[i].box.mx);
     }
-    float rightArea[NB]; int rightCnt[NB];
+    float rightArea[NBMAX]; int rightCnt[NBMAX];
     float3 amn, amx; box_reset(amn, amx);
     int c = 0;
     for (int b = NB - 1; b > 0; b--) {
