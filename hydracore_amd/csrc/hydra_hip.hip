@@ -1032,6 +1032,9 @@ int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_
   if (const char* e = getenv("HYDRA_HIP_TRACE_MIN_ACTIVE")) c->traceMinActive = std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("HYDRA_HIP_TRACE_BLOCKS_PER_CU")) c->traceBlocksPerCU = std::max(1, std::min(64, atoi(e)));
   c->stream = nullptr;   // the null stream: ordered with torch's default stream and with plain hipMemcpy
+  if (const char* e = getenv("HYDRA_HIP_PRIVATE_STREAM")) {   // experiment only (tools/overlap_bench.py): two layers sharing one GPU on their own streams
+    if (atoi(e) != 0 && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) c->stream = nullptr;
+  }
   *out = c;
   return HYDRA_HIP_OK;
 }
