@@ -414,6 +414,40 @@ HK_DEV void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f
   if (cosTheta <= HK_DEPSILON) out.color = mk3(0, 0, 0);
   out.flags = HRE_D;
 }
+// ---- oren-nayar, cmaterial.h:264-371 (CosPhiPBRT1 / SinPhiPBRT1: cmatpbrt.h:17-31)
+HK_DEV float orennayarFunc(f3 l, f3 v, f3 n, float A, float B) {
+  const float cosTheta_wi = dot(l, n), cosTheta_wo = dot(v, n);
+  const float sinTheta_wi = sqrtf(fmaxf(0.0f, 1.0f - cosTheta_wi * cosTheta_wi));
+  const float sinTheta_wo = sqrtf(fmaxf(0.0f, 1.0f - cosTheta_wo * cosTheta_wo));
+  f3 nx, ny;
+  CoordinateSystem(n, nx, ny);
+  const f3 wo = mk3(-dot(v, nx), -dot(v, ny), -dot(v, n));
+  const f3 wi = mk3(-dot(l, nx), -dot(l, ny), -dot(l, n));
+  float maxcos = 0.f;
+  if (sinTheta_wi > 1e-4f && sinTheta_wo > 1e-4f) {
+    const float sinphii = clampf(wi.y / sinTheta_wi, -1.f, 1.f), cosphii = clampf(wi.x / sinTheta_wi, -1.f, 1.f);
+    const float sinphio = clampf(wo.y / sinTheta_wo, -1.f, 1.f), cosphio = clampf(wo.x / sinTheta_wo, -1.f, 1.f);
+    const float dcos = cosphii * cosphio + sinphii * sinphio;
+    maxcos = fmaxf(0.f, dcos);
+  }
+  float sinalpha, tanbeta;
+  if (fabsf(cosTheta_wi) > fabsf(cosTheta_wo)) { sinalpha = sinTheta_wo; tanbeta = sinTheta_wi / fmaxf(fabsf(cosTheta_wi), HK_DEPSILON); }
+  else { sinalpha = sinTheta_wi; tanbeta = sinTheta_wo / fmaxf(fabsf(cosTheta_wo), HK_DEPSILON); }
+  return (A + B * maxcos * sinalpha * tanbeta);
+}
+HK_DEV f3 orennayarEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  return (lambertColor(m, tc, s) * HK_INV_PI) * orennayarFunc(l, v, n, m[HM_ORENNAYAR_A], m[HM_ORENNAYAR_B]);   // same colour/sampler offsets as lambert
+}
+HK_DEV void OrennayarSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 color = lambertColor(m, tc, s);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, n, n, 1.0f);
+  const float cosTheta = dot(newDir, n);
+  out.direction = newDir;
+  out.pdf = cosTheta * HK_INV_PI;
+  out.color = (color * HK_INV_PI) * orennayarFunc(newDir, ray_dir * (-1.0f), n, m[HM_ORENNAYAR_A], m[HM_ORENNAYAR_B]);
+  if (cosTheta <= HK_DEPSILON) out.color = mk3(0, 0, 0);
+  out.flags = HRE_D;
+}
 // ---- phong, cmaterial.h:915-1033
 HK_DEV float phongGlosiness(const float* m, f2 tc, const SceneDev& s) {
   if (uint32_t(as_int(m[HM_PHONG_GLOSS_TEXID])) != HYDRA_INVALID_TEXTURE) {
@@ -544,6 +578,7 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_PHONG: PhongSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
+    case HMT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     default: break;
   }
   if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
@@ -579,6 +614,11 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         pr = phongEvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
       } else if (type == HMT_LAMBERT) {
         brdf = (lambertColor(m, sc.tc, s) * HK_INV_PI) * 1.0f;
+        pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
+        pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
+        diffuse = true;
+      } else if (type == HMT_OREN_NAYAR) {
+        brdf = orennayarEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
         pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
         pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
         diffuse = true;

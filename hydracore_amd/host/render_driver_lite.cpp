@@ -120,6 +120,20 @@ MatPtr make_lambert(float3 color, int32_t texId, const Sampler& s) {
   put_i(d, HM_FLAGS, HMF_HAS_DIFFUSE);
   return p;
 }
+// OrenNayarMaterial, PlainMaterialConverter.cpp:137-170
+MatPtr make_orennayar(float3 color, float roughness, int32_t texId, const Sampler& s) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  const float sigma = roughness * (3.14159265358979323846f / 2.0f), sigma2 = sigma * sigma;
+  d[HM_ORENNAYAR_ROUGHNESS] = roughness;
+  d[HM_ORENNAYAR_A] = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+  d[HM_ORENNAYAR_B] = 0.45f * sigma2 / (sigma2 + 0.09f);
+  put_sampler_at(d, texId, s, HM_TEXID, HM_TEXMATRIXID, HM_ORENNAYAR_SAMPLER);
+  put_i(d, HM_TYPE, HMT_OREN_NAYAR);
+  put_i(d, HM_FLAGS, HMF_HAS_DIFFUSE);
+  return p;
+}
 // PhongMaterial, PlainMaterialConverter.cpp:414-460
 MatPtr make_phong(float3 color, int32_t texId, const Sampler& sc, float cosPower, int32_t glossTexId, const Sampler& sg, float gloss) {
   MatPtr p = new_node();
@@ -279,8 +293,10 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   {
     Sampler s; int32_t texId = int32_t(HYDRA_INVALID_TEXTURE);
     if (sampler_node(diffuse)) { s = sampler_from_texref(sampler_node(diffuse)); texId = s.texId; }
-    if (std::string(xattr(diffuse, "brdf_type")) == "orennayar") Unsupported("oren-nayar diffuse (material " + std::to_string(a_matId) + ")");
-    pMaterialD = make_lambert(read_value3f(xchild(diffuse, "color")), texId, s);
+    if (std::string(xattr(diffuse, "brdf_type")) == "orennayar")
+      pMaterialD = make_orennayar(read_value3f(xchild(diffuse, "color")), read_value1f(xchild(diffuse, "roughness")), texId, s);
+    else
+      pMaterialD = make_lambert(read_value3f(xchild(diffuse, "color")), texId, s);
   }
   // ReflectiveMaterialFromHydraMtl :1061-1149
   MatPtr pMaterialS;

@@ -128,6 +128,7 @@ enum {
   /* leaf BxDF fields (lambert cmaterial.h:200-210, phong :887-903, mirror :374-382) */
   HM_COLOR = 10, HM_TEXID = 13, HM_TEXMATRIXID = 14,
   HM_LAMBERT_SAMPLER = 20,
+  HM_ORENNAYAR_ROUGHNESS = 15, HM_ORENNAYAR_A = 16, HM_ORENNAYAR_B = 17, HM_ORENNAYAR_SAMPLER = 20,   /* cmaterial.h:264-276 */
   HM_PHONG_COSPOWER = 15, HM_PHONG_GLOSINESS = 16, HM_PHONG_GLOSS_TEXID = 17, HM_PHONG_GLOSS_TEXMATRIXID = 18,
   HM_PHONG_SAMPLER0 = 20, HM_PHONG_SAMPLER1 = 32,
   HM_MIRROR_SAMPLER = 16,

@@ -39,7 +39,8 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_MIRROR = 2, MT_LAMBERT = 7, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
+enum { MT_PHONG = 0, MT_MIRROR = 2, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
+enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
 enum { MF_CAST_CAUSTICS = 2, MF_FORBID_EMISSIVE_GI = 512, MF_SKIP_SKY_PORTAL = 1024, MF_CAN_SAMPLE_REFL_ONLY = 32768,
        MF_ENERGY_FIX = 32768 * 256 };
 enum { BMF_FRESNEL = 1, BMF_FALOFF = 2, BMF_REFL_WEIGHT_IS_ONE = 4, BMF_EXTRUSION_LUMINANCE = 16 };
@@ -738,6 +739,41 @@ static void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f
   if (cosTheta <= DEPSILON) out->color = v3(0, 0, 0);
   out->flags = RAY_EVENT_D;
 }
+/* ---- oren-nayar, ref: cmaterial.h:288-371; CosPhiPBRT1 / SinPhiPBRT1 cmatpbrt.h:17-31 */
+static float orennayarFunc(f3 l, f3 v, f3 n, float A, float B) {
+  const float cosTheta_wi = dot3(l, n), cosTheta_wo = dot3(v, n);
+  const float sinTheta_wi = sqrtf(fmaxf(0.0f, 1.0f - cosTheta_wi * cosTheta_wi));
+  const float sinTheta_wo = sqrtf(fmaxf(0.0f, 1.0f - cosTheta_wo * cosTheta_wo));
+  f3 nx, ny;
+  CoordinateSystem(n, &nx, &ny);
+  const f3 wo = v3(-dot3(v, nx), -dot3(v, ny), -dot3(v, n));
+  const f3 wi = v3(-dot3(l, nx), -dot3(l, ny), -dot3(l, n));
+  float maxcos = 0.f;
+  if (sinTheta_wi > 1e-4f && sinTheta_wo > 1e-4f) {
+    const float sinphii = clampf(wi.y / sinTheta_wi, -1.f, 1.f), cosphii = clampf(wi.x / sinTheta_wi, -1.f, 1.f);
+    const float sinphio = clampf(wo.y / sinTheta_wo, -1.f, 1.f), cosphio = clampf(wo.x / sinTheta_wo, -1.f, 1.f);
+    const float dcos = cosphii * cosphio + sinphii * sinphio;
+    maxcos = fmaxf(0.f, dcos);
+  }
+  float sinalpha, tanbeta;
+  if (fabsf(cosTheta_wi) > fabsf(cosTheta_wo)) { sinalpha = sinTheta_wo; tanbeta = sinTheta_wi / fmaxf(fabsf(cosTheta_wi), DEPSILON); }
+  else { sinalpha = sinTheta_wi; tanbeta = sinTheta_wo / fmaxf(fabsf(cosTheta_wo), DEPSILON); }
+  return (A + B * maxcos * sinalpha * tanbeta);
+}
+static f3 orennayarEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  return scale3(lambertEvalBxDF(m, tc, s), orennayarFunc(l, v, n, m[ORENNAYAR_A], m[ORENNAYAR_B]));
+}
+static void OrennayarSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, n, n, 1.0f);
+  const float cosTheta = dot3(newDir, n);
+  out->direction = newDir;
+  out->pdf = cosTheta * INV_PI;
+  out->color = scale3(scale3(color, INV_PI), orennayarFunc(newDir, scale3(ray_dir, -1.0f), n, m[ORENNAYAR_A], m[ORENNAYAR_B]));
+  if (cosTheta <= DEPSILON) out->color = v3(0, 0, 0);
+  out->flags = RAY_EVENT_D;
+}
 /* ---- phong, ref: cmaterial.h:915-1033 */
 static float phongGlosiness(const float* m, f2 tc, const OrcScene* s) {
   if ((uint32_t)as_int(m[PHONG_GLOSS_TEXID]) != INVALID_TEXTURE) {
@@ -882,6 +918,7 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_PHONG: PhongSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_MIRROR: MirrorSampleAndEvalBRDF(m, ray_dir, n, sh->texCoord, s, out); break;
     case MT_LAMBERT: LambertSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
+    case MT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     default: break;
   }
   if (out->pdf <= 0.0f) out->color = v3(0, 0, 0);
@@ -917,6 +954,12 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const
     case MT_MIRROR: break;   /* mirrorEvalBxDF / PDF return 0, cmaterial.h:395-403 */
     case MT_LAMBERT:
       r.brdf = scale3(lambertEvalBxDF(m, sc->tc, s), cosMult);
+      r.pdfFwd = lambertEvalPDF(sc->l, sc->n);
+      r.pdfRev = lambertEvalPDF(sc->v, sc->n);
+      r.diffuse = 1;
+      break;
+    case MT_OREN_NAYAR:
+      r.brdf = scale3(orennayarEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
       r.pdfFwd = lambertEvalPDF(sc->l, sc->n);
       r.pdfRev = lambertEvalPDF(sc->v, sc->n);
       r.diffuse = 1;

@@ -225,6 +225,8 @@ def main():
             tex = {0: 1, 4: 1, 6: 2}[mid]
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" />'
                        '<texture id="%d" type="texref" /></diffuse></material>' % (mid, mid, c, tex))
+        elif args.delta_lights and mid in (2, 7):   # rough plaster: Oren-Nayar
+            xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
     xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
