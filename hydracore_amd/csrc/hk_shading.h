@@ -503,6 +503,118 @@ HK_DEV void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, con
   if (cosOut <= 1e-6f) out.color = mk3(0, 0, 0);
   out.flags = HRE_S;
 }
+// ---- thin glass, cmaterial.h:472-556.  Eval is zero (:512-520): shadow rays never sample it.
+HK_DEV float transpGloss(const float* m, int glossMult, int glossTexMatrixId, f2 tc, const SceneDev& s) {   // thinglassCosPower :496-505, glassGloss :610-618
+  const f3 g = sample2DExt(as_int(m[glossTexMatrixId]), tc, m, s);
+  return clampf(m[glossMult] * fmaxf(g.x, fmaxf(g.y, g.z)), 0.0f, 1.0f);
+}
+HK_DEV void ThinglassSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {   // :522-556
+  const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
+  const float cosPower = cosPowerFromGlosiness(transpGloss(m, HM_THINGLASS_GLOSINESS, HM_THINGLASS_GLOSS_TEXMATRIXID, tc, s));
+  float pdf = 1.0f, fVal = 1.0f;
+  if (cosPower < 1e6f) {
+    bool under = false;
+    const f3 oldDir = ray_dir;
+    ray_dir = MapSampleToModifiedCosineDistribution(r1, r2, ray_dir, n * (-1.0f), cosPower, under);
+    const float cosTheta = clampf(dot(oldDir, ray_dir), 0.0f, (HK_PI * 0.499995f));
+    fVal = (cosPower + 2.0f) * HK_INV_TWOPI * powf(cosTheta, cosPower);
+    if (under) fVal = 0.0f;
+    pdf = powf(cosTheta, cosPower) * (cosPower + 1.0f) * (0.5f * HK_INV_PI);
+  }
+  const float cosOut = dot(ray_dir, n);
+  const float cosMult = 1.0f / fmaxf(fabsf(cosOut), 1e-6f);
+  out.direction = ray_dir;
+  out.pdf = pdf;
+  out.color = ((matColor(m) * fVal) * tex) * cosMult;
+  if (cosOut >= -1e-6f) out.color = mk3(0, 0, 0);   // transparency must leave on the far side
+  out.flags = (HRE_S | HRE_T | HRE_THINGLASS);
+}
+// ---- glass, cmaterial.h:566-867: the GGX form the reference dispatches to (:2298-2301)
+struct RefractResult { f3 ray_dir; bool success; float eta; };   // :634-641
+HK_DEV RefractResult myRefractGgx(f3 ray_dir, f3 n, float matIOR, float outsideIOR) {   // :684-714
+  RefractResult res;
+  res.eta = outsideIOR / matIOR;
+  float cosTheta = dot(n, ray_dir) * (-1.0f);
+  if (cosTheta < 0.0f) { cosTheta = cosTheta * (-1.0f); n = n * (-1.0f); res.eta = 1.0f / res.eta; }
+  const float dotVN = cosTheta * (-1.0f);
+  const float k = 1.0f - res.eta * res.eta * (1.0f - cosTheta * cosTheta);
+  if (k > 0.0f) {
+    res.ray_dir = normalize((ray_dir * res.eta) + (n * (res.eta * cosTheta - sqrtf(k))));
+    res.success = true;
+  } else {
+    res.ray_dir = normalize((n * (dotVN * (-2.0f))) + ray_dir);
+    res.success = false;
+    res.eta = 1.0f;
+  }
+  return res;
+}
+HK_DEV float SmithGGXMasking(float dotNV, float roughSqr) {   // :1214-1218
+  const float denomC = sqrtf(roughSqr + (1.0f - roughSqr) * dotNV * dotNV) + dotNV;
+  return 2.0f * dotNV / fmaxf(denomC, 1e-6f);
+}
+HK_DEV float SmithGGXMaskingShadowing(float dotNL, float dotNV, float roughSqr) {   // :1247-1252
+  const float denomA = dotNV * sqrtf(roughSqr + (1.0f - roughSqr) * dotNL * dotNL);
+  const float denomB = dotNL * sqrtf(roughSqr + (1.0f - roughSqr) * dotNV * dotNV);
+  return 2.0f * dotNL * dotNV / fmaxf(denomA + denomB, 1e-6f);
+}
+HK_DEV f3 GgxVndf(f3 wo, float roughness, float u1, float u2) {   // :1220-1245 (Heitz 2017, as the reference wrote it)
+  const f3 v = normalize(mk3(wo.x * roughness, wo.y * roughness, wo.z));
+  const f3 t1 = (v.z < 0.999f) ? normalize(cross(v, mk3(0, 0, 1))) : mk3(1, 0, 0);
+  const f3 t2 = cross(t1, v);
+  const float a = 1.0f / (1.0f + v.z);
+  const float r = sqrtf(u1);
+  const float phi = (u2 < a) ? (u2 / a) * HK_PI : HK_PI + (u2 - a) / (1.0f - a) * HK_PI;
+  const float p1 = r * cosf(phi);
+  const float p2 = r * sinf(phi) * ((u2 < a) ? 1.0f : v.z);
+  const f3 n = ((t1 * p1) + (t2 * p2)) + (v * sqrtf(fmaxf(0.0f, 1.0f - p1 * p1 - p2 * p2)));
+  return normalize(mk3(roughness * n.x, roughness * n.y, fmaxf(0.0f, n.z)));
+}
+// The multi-scattering table (:858-860, PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER on a glass node) is not part of this path:
+// no front end here sets that flag on glass (TransparentMaterialFromHydraMtl, PlainMaterialConverter.cpp:1151-1199, never does).
+HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray_dir, f3 n, f2 tc, bool hitFromInside, const SceneDev& s, MatSample& out) {   // :775-882, a_isFwdDir = false
+  const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(matColor(m) * tex, 0.0f, 1.0f);
+  const float gloss = transpGloss(m, HM_GLASS_GLOSINESS, HM_GLASS_GLOSS_TEXMATRIXID, tc, s);
+  const float roughness = clampf(1.0f - gloss, 0.0f, 1.0f);
+  const float roughSqr = roughness * roughness;
+  const float IOR = m[HM_GLASS_IOR];
+  const f3 normal2 = hitFromInside ? n * (-1.0f) : n;
+  bool spec = true;
+  float Pss = 1.0f;
+  out.pdf = 1.0f;
+  RefractResult refr = myRefractGgx(ray_dir, normal2, IOR, 1.0f);
+  if (gloss < 0.999f) {
+    spec = false;
+    float eta = 1.0f / IOR;
+    const float cosTheta = dot(normal2, ray_dir) * (-1.0f);
+    if (cosTheta < 0.0f) eta = 1.0f / eta;
+    f3 nx, ny;
+    const f3 nz = n;
+    CoordinateSystem(nz, nx, ny);
+    const f3 wo = mk3(-dot(ray_dir, nx), -dot(ray_dir, ny), -dot(ray_dir, nz));
+    const f3 wh = GgxVndf(wo, roughSqr, rands[0], rands[1]);
+    const float dotWoWh = dot(wo, wh);
+    f3 newDir;
+    const float radicand = 1.0f + eta * eta * (dotWoWh * dotWoWh - 1.0f);
+    if (radicand > 0.0f) { newDir = (wh * (eta * dotWoWh - sqrtf(radicand))) - (wo * eta); refr.success = true; refr.eta = eta; }
+    else { newDir = (wh * (2.0f * dotWoWh)) - wo; refr.success = false; refr.eta = 1.0f; }
+    refr.ray_dir = normalize(((nx * newDir.x) + (ny * newDir.y)) + (nz * newDir.z));
+    const f3 v = ray_dir * (-1.0f);
+    const float dotNV = fabsf(dot(n, v)), dotNL = fabsf(dot(n, refr.ray_dir));
+    const float G1 = SmithGGXMasking(dotNV, roughSqr);
+    const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+    Pss = G2 / fmaxf(G1, 1e-6f);
+  }
+  const float cosOut = dot(refr.ray_dir, n);
+  const float cosMult = 1.0f / fmaxf(fabsf(cosOut), 1e-6f);
+  out.direction = refr.ray_dir;
+  const float adjointBtdfMult = refr.eta * refr.eta;   // camera paths: radiance flows against the walk (:867-869)
+  if (refr.success) out.color = ((color * adjointBtdfMult) * Pss) * cosMult;
+  else out.color = (mk3(1, 1, 1) * Pss) * cosMult;
+  out.flags = spec ? (HRE_S | HRE_T) : (HRE_G | HRE_T);
+  if (refr.success && cosOut >= -1e-6f) out.color = mk3(0, 0, 0);
+  else if (!refr.success && cosOut < 1e-6f) out.color = mk3(0, 0, 0);
+}
 // ---- blend mask, cmaterial.h:2008-2137; fresnel cglobals.h:1879-1926
 HK_DEV float fresnelDielectric(float c1, float c2, float etaExt, float etaInt) {
   const float Rs = (etaExt * c1 - etaInt * c2) / (etaExt * c1 + etaInt * c2);
@@ -579,6 +691,8 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
     case HMT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_THIN_GLASS: ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_GLASS: GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out); break;
     default: break;
   }
   if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
@@ -742,7 +856,6 @@ HK_DEV int SelectRandomLightRev(float r, const SceneDev& s, float& pickProb) {  
   return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.globals[HG_LSEL_REV_OFFS]), tableSize, pickProb);
 }
 // ---- sky dome light: constant colour or lat-long texture (clight.h:285-306, 308-364, 384-462; cfetch.h:259-296) ----
-#define HK_PI 3.14159265358979323846f   /* the pinned build of the reference compiles with -cl-single-precision-constant */
 HK_DEV f2 sphereMapTo2DTexCoord(f3 ray_dir, float& sinTheta) {   // cfetch.h:259-281
   const float x = ray_dir.z, y = ray_dir.x, z = -ray_dir.y;
   const float theta = acosf(z);

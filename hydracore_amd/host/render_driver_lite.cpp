@@ -157,6 +157,36 @@ MatPtr make_mirror(float3 color, int32_t texId, const Sampler& s) {
   put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
   return p;
 }
+// ThinGlassMaterial, PlainMaterialConverter.cpp:254-300
+MatPtr make_thinglass(float3 color, int32_t texId, const Sampler& sc, float cosPower, float gloss, int32_t glossTexId, const Sampler& sg) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  d[HM_THINGLASS_COS_POWER] = cosPower;
+  d[HM_THINGLASS_GLOSINESS] = gloss;
+  put_sampler_at(d, texId, sc, HM_TEXID, HM_TEXMATRIXID, HM_THINGLASS_SAMPLER0);
+  put_sampler_at(d, glossTexId, sg, HM_THINGLASS_GLOSS_TEXID, HM_THINGLASS_GLOSS_TEXMATRIXID, HM_THINGLASS_SAMPLER1);
+  put_i(d, HM_TYPE, HMT_THIN_GLASS);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS | HMF_HAS_TRANSPARENCY);
+  return p;
+}
+// GlassMaterial, PlainMaterialConverter.cpp:363-410
+MatPtr make_glass(float3 color, int32_t texId, const Sampler& sc, float ior, float3 fogColor, float fogMult, float cosPower, float gloss,
+                  int32_t glossTexId, const Sampler& sg) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  d[HM_GLASS_FOG_COLOR] = fogColor.x; d[HM_GLASS_FOG_COLOR + 1] = fogColor.y; d[HM_GLASS_FOG_COLOR + 2] = fogColor.z;
+  d[HM_GLASS_FOG_MULT] = fogMult;
+  d[HM_GLASS_IOR] = ior;
+  d[HM_GLASS_COS_POWER] = cosPower;
+  d[HM_GLASS_GLOSINESS] = gloss;
+  put_sampler_at(d, texId, sc, HM_TEXID, HM_TEXMATRIXID, HM_GLASS_SAMPLER0);
+  put_sampler_at(d, glossTexId, sg, HM_GLASS_GLOSS_TEXID, HM_GLASS_GLOSS_TEXMATRIXID, HM_GLASS_SAMPLER1);
+  put_i(d, HM_TYPE, HMT_GLASS);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS | HMF_HAS_TRANSPARENCY);
+  return p;
+}
 // EmissiveMaterial, PlainMaterialConverter.cpp:31-70
 MatPtr make_emissive(float3 color, int32_t texId, const Sampler& s, int32_t lightId) {
   MatPtr p = new_node();
@@ -279,7 +309,6 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const float3 colorS = read_value3f(xchild(reflect, "color"));
   const float3 colorT = read_value3f(xchild(transpar, "color"));
   const float3 colorSSS = read_value3f(xchild(sss, "color"));
-  if (length(colorT) > 1e-5f) Unsupported("transparency (material " + std::to_string(a_matId) + ")");
   if (length(colorSSS) > 1e-5f) Unsupported("translucency (material " + std::to_string(a_matId) + ")");
   if (a_node->child("displacement") || a_node->child("opacity")) Unsupported("displacement/opacity (material " + std::to_string(a_matId) + ")");
   if (length(colorD) <= 1e-5f) colorD = colorSSS;
@@ -321,6 +350,23 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     if (!efix) efix = xchild(reflect, "multiscatter");
     if (efix && efix->attr_int("val") == 1) put_i(pMaterialS->plain, HM_FLAGS, get_i(pMaterialS->plain, HM_FLAGS) | HMF_ENERGY_FIX);
   }
+  // TransparentMaterialFromHydraMtl :1151-1199.  The fog (Beer) term the glass node carries is stored as the reference
+  // stores it; IntegratorMISPTLoop2 never reads it (no materialLeafGetFog call on that path).
+  MatPtr pMaterialT;
+  int32_t texTranspId = int32_t(HYDRA_INVALID_TEXTURE);
+  Sampler samplTransp;
+  {
+    const XmlNode* gloss = xchild(transpar, "glossiness");
+    const float3 fogColor = read_value3f(xchild(transpar, "fog_color"));
+    const float fogMult = read_value1f(xchild(transpar, "fog_multiplier"));
+    const float glossVal = read_value1f(gloss), iorVal = read_value1f(xchild(transpar, "ior"));
+    const bool thinWall = (xchild(transpar, "thin_walled") && xchild(transpar, "thin_walled")->attr_int("val") == 1);
+    Sampler sg; int32_t texGloss = int32_t(HYDRA_INVALID_TEXTURE);
+    if (sampler_node(transpar)) { samplTransp = sampler_from_texref(sampler_node(transpar)); texTranspId = samplTransp.texId; }
+    if (sampler_node(gloss)) { sg = sampler_from_texref(sampler_node(gloss)); texGloss = sg.texId; }
+    if (fabsf(iorVal) < 1e-4f || thinWall) pMaterialT = make_thinglass(colorT, texTranspId, samplTransp, 0.0f, glossVal, texGloss, sg);
+    else pMaterialT = make_glass(colorT, texTranspId, samplTransp, iorVal, fogColor, fogMult, 0.0f, glossVal, texGloss, sg);
+  }
   // EmissiveMaterialFromHydraMtl :953-978
   MatPtr pMaterialE;
   {
@@ -334,8 +380,22 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   }
 
   MatPtr pResult;
-  if ((length(colorD) > 1e-5f && length(colorS) > 1e-5f) || (length(colorS) > 1e-5f && haveFresnelRefl))
+  const bool haveT = length(colorT) > 1e-5f, haveS = length(colorS) > 1e-5f, haveD = length(colorD) > 1e-5f;
+  auto add_flags = [](const MatPtr& m, int f) { put_i(m->plain, HM_FLAGS, get_i(m->plain, HM_FLAGS) | f); };
+  if (haveT && haveS && haveD) {          // :1541-1553
+    MatPtr pST = make_blend(pMaterialS, pMaterialT, colorS, texReflId, samplRefl, haveFresnelRefl, true, reflExtrusion, fresnelIOR);
+    pResult = make_blend(pST, pMaterialD, colorT, texTranspId, samplTransp, false, true, reflExtrusion, fresnelIOR);
+    add_flags(pST, HMF_HAS_TRANSPARENCY | HMF_CAN_SAMPLE_REFL_ONLY);
+    add_flags(pResult, HMF_HAS_TRANSPARENCY);
+  } else if (haveT && haveS) {            // :1554-1563
+    pResult = make_blend(pMaterialS, pMaterialT, colorS, texReflId, samplRefl, haveFresnelRefl, true, reflExtrusion, fresnelIOR);
+    add_flags(pResult, HMF_HAS_TRANSPARENCY | HMF_CAN_SAMPLE_REFL_ONLY);
+  } else if ((haveD && haveS) || (haveS && haveFresnelRefl))
     pResult = make_blend(pMaterialS, pMaterialD, colorS, texReflId, samplRefl, haveFresnelRefl, true, reflExtrusion, fresnelIOR);
+  else if (haveD && haveT) {              // :1570-1582: plain mask, strong extrusion, the glass IOR in the (unused) fresnel slot
+    pResult = make_blend(pMaterialT, pMaterialD, colorT, texTranspId, samplTransp, false, true, HBF_EXTRUSION_STRONG, read_value1f(xchild(transpar, "ior")));
+    add_flags(pResult, HMF_HAS_TRANSPARENCY);
+  } else if (haveT) pResult = pMaterialT;
   else if (length(colorS) > 1e-5f) pResult = pMaterialS;
   else if (length(colorD) > 1e-5f) pResult = pMaterialD;
   else if (length(colorE) > 1e-5f) pResult = pMaterialE;

@@ -132,6 +132,10 @@ enum {
   HM_PHONG_COSPOWER = 15, HM_PHONG_GLOSINESS = 16, HM_PHONG_GLOSS_TEXID = 17, HM_PHONG_GLOSS_TEXMATRIXID = 18,
   HM_PHONG_SAMPLER0 = 20, HM_PHONG_SAMPLER1 = 32,
   HM_MIRROR_SAMPLER = 16,
+  HM_THINGLASS_COS_POWER = 15, HM_THINGLASS_GLOSINESS = 16, HM_THINGLASS_GLOSS_TEXID = 17, HM_THINGLASS_GLOSS_TEXMATRIXID = 18,   /* cmaterial.h:472-491 */
+  HM_THINGLASS_SAMPLER0 = 20, HM_THINGLASS_SAMPLER1 = 32,
+  HM_GLASS_IOR = 15, HM_GLASS_FOG_COLOR = 16, HM_GLASS_FOG_MULT = 19, HM_GLASS_COS_POWER = 20, HM_GLASS_GLOSINESS = 21,          /* cmaterial.h:566-590 */
+  HM_GLASS_GLOSS_TEXID = 22, HM_GLASS_GLOSS_TEXMATRIXID = 23, HM_GLASS_SAMPLER0 = 24, HM_GLASS_SAMPLER1 = 36,
   /* blend node (cmaterial.h:1965-2006) */
   HM_BLEND_FLAGS = 15, HM_BLEND_MAT1 = 16, HM_BLEND_MAT2 = 17, HM_BLEND_FRESNEL_IOR = 18,
   HM_BLEND_FALOFF_OFFSET = 19, HM_BLEND_FALOFF_SIZE = 20, HM_BLEND_TYPE = 21, HM_BLEND_SIGMOID_EXP = 22,
@@ -183,7 +187,7 @@ enum { HLF_DISABLE_SAMPLING = 1, HLF_SKY_USE_PEREZ = 4, HLF_SKY_PORTAL = 8, HLF_
        HLF_DO_NOT_SAMPLE_ME = 64 };   /* cglobals.h:2245-2254 */
 
 /* ---- ray flags word (cglobals.h:1330-1376): diffuse bounces | bounces<<8 | events<<16 ---- */
-enum { HRE_S = 1, HRE_D = 2, HRE_G = 4, HRE_T = 8 };
+enum { HRE_S = 1, HRE_D = 2, HRE_G = 4, HRE_T = 8, HRE_THINGLASS = 64 };   /* cglobals.h:1331-1340 */
 enum { HRF_OUT_OF_SCENE = 128, HRF_IS_DEAD = 4096 };
 
 /* ---- per-kernel timing record returned by hydra_hip_get_stats (MRaysStat, cglobals.h:1764-1787) ---- */

@@ -39,8 +39,10 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_MIRROR = 2, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
-enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
+enum { MT_PHONG = 0, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
+enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };
+enum { THINGLASS_GLOSINESS = 16, THINGLASS_GLOSINESS_TEXMATRIXID = 18,                  /* cmaterial.h:472-491 */
+       GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23 };       /* cmaterial.h:566-590 */   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
 enum { MF_CAST_CAUSTICS = 2, MF_FORBID_EMISSIVE_GI = 512, MF_SKIP_SKY_PORTAL = 1024, MF_CAN_SAMPLE_REFL_ONLY = 32768,
        MF_ENERGY_FIX = 32768 * 256 };
 enum { BMF_FRESNEL = 1, BMF_FALOFF = 2, BMF_REFL_WEIGHT_IS_ONE = 4, BMF_EXTRUSION_LUMINANCE = 16 };
@@ -57,7 +59,7 @@ enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADI
 enum { HRT_BSPHERE_RADIUS = 21 };
 enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16 };
 /* ray flags, ref: cglobals.h:1330-1376 */
-enum { RAY_EVENT_S = 1, RAY_EVENT_D = 2, RAY_EVENT_G = 4, RAY_EVENT_T = 8 };
+enum { RAY_EVENT_S = 1, RAY_EVENT_D = 2, RAY_EVENT_G = 4, RAY_EVENT_T = 8, RAY_EVENT_TNINGLASS = 64 };
 enum { RAY_GRAMMAR_DIRECT_LIGHT = 64, RAY_IS_DEAD = 4096 };
 
 /* ------------------------------------------------------------------------------------------------ small vectors */
@@ -836,6 +838,129 @@ static void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, con
   out->flags = RAY_EVENT_S;
 }
 
+/* ---- thin glass, ref: cmaterial.h:496-556.  thinglassEvalBxDF / EvalPDF return 0 (:510-520). */
+static float transparencyGloss(const float* m, int multOffs, int texMatrixOffs, f2 tc, const OrcScene* s) {   /* :496-505, :610-618 */
+  const f3 glossColor = sample2DExt(as_int(m[texMatrixOffs]), tc, m, s);
+  return clampf(m[multOffs] * fmaxf(glossColor.x, fmaxf(glossColor.y, glossColor.z)), 0.0f, 1.0f);
+}
+static void ThinglassSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 texColor = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const float cosPower = cosPowerFromGlosiness(transparencyGloss(m, THINGLASS_GLOSINESS, THINGLASS_GLOSINESS_TEXMATRIXID, tc, s));
+  float pdf = 1.0f, fVal = 1.0f;
+  if (cosPower < 1e6f) {
+    int underSurface = 0;
+    const f3 oldDir = ray_dir;
+    ray_dir = MapSampleToModifiedCosineDistribution(r1, r2, ray_dir, scale3(n, -1.0f), cosPower, &underSurface);
+    const float cosTheta = clampf(dot3(oldDir, ray_dir), 0.0f, M_PI_F * 0.499995f);
+    fVal = (cosPower + 2.0f) * INV_TWOPI * powf(cosTheta, cosPower);
+    if (underSurface) fVal = 0.0f;
+    pdf = powf(cosTheta, cosPower) * (cosPower + 1.0f) * (0.5f * INV_PI);
+  }
+  const float cosThetaOut = dot3(ray_dir, n);
+  const float cosMult = 1.0f / fmaxf(fabsf(cosThetaOut), 1e-6f);
+  out->direction = ray_dir;
+  out->pdf = pdf;
+  out->color = scale3(mul3(scale3(matColor(m), fVal), texColor), cosMult);
+  if (cosThetaOut >= -1e-6f) out->color = v3(0, 0, 0);
+  out->flags = (RAY_EVENT_S | RAY_EVENT_T | RAY_EVENT_TNINGLASS);
+}
+/* ---- glass, ref: cmaterial.h:684-714 myRefractGgx, :775-882 GlassGGXSampleAndEvalBRDF (the one :2298-2301 dispatches to),
+ *      :1214-1252 SmithGGXMasking / GgxVndf / SmithGGXMaskingShadowing.  glassEvalBxDF / EvalPDF return 0 (:622-630).
+ *      The multi-scattering table lookup (:858-860) needs PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER on the glass node, which
+ *      TransparentMaterialFromHydraMtl (PlainMaterialConverter.cpp:1151-1199) never sets: not restated. */
+typedef struct { f3 ray_dir; int success; float eta; } RefractResult;
+static RefractResult myRefractGgx(f3 ray_dir, f3 a_normal, float a_matIOR, float a_outsideIOR) {
+  RefractResult res;
+  res.eta = a_outsideIOR / a_matIOR;
+  float cosTheta = dot3(a_normal, ray_dir) * (-1.0f);
+  if (cosTheta < 0.0f) { cosTheta = cosTheta * (-1.0f); a_normal = scale3(a_normal, -1.0f); res.eta = 1.0f / res.eta; }
+  const float dotVN = cosTheta * (-1.0f);
+  const float k = 1.0f - res.eta * res.eta * (1.0f - cosTheta * cosTheta);
+  if (k > 0.0f) {
+    res.ray_dir = normalize3(add3(scale3(ray_dir, res.eta), scale3(a_normal, res.eta * cosTheta - sqrtf(k))));
+    res.success = 1;
+  } else {
+    res.ray_dir = normalize3(add3(scale3(a_normal, dotVN * (-2.0f)), ray_dir));
+    res.success = 0;
+    res.eta = 1.0f;
+  }
+  return res;
+}
+static float SmithGGXMasking(float dotNV, float roughSqr) {
+  const float denomC = sqrtf(roughSqr + (1.0f - roughSqr) * dotNV * dotNV) + dotNV;
+  return 2.0f * dotNV / fmaxf(denomC, 1e-6f);
+}
+static float SmithGGXMaskingShadowing(float dotNL, float dotNV, float roughSqr) {
+  const float denomA = dotNV * sqrtf(roughSqr + (1.0f - roughSqr) * dotNL * dotNL);
+  const float denomB = dotNL * sqrtf(roughSqr + (1.0f - roughSqr) * dotNV * dotNV);
+  return 2.0f * dotNL * dotNV / fmaxf(denomA + denomB, 1e-6f);
+}
+static f3 GgxVndf(f3 wo, float roughness, float u1, float u2) {
+  const f3 v = normalize3(v3(wo.x * roughness, wo.y * roughness, wo.z));
+  const f3 XAxis = v3(1.0f, 0.0f, 0.0f), ZAxis = v3(0.0f, 0.0f, 1.0f);
+  const f3 t1 = (v.z < 0.999f) ? normalize3(cross3(v, ZAxis)) : XAxis;
+  const f3 t2 = cross3(t1, v);
+  const float a = 1.0f / (1.0f + v.z);
+  const float r = sqrtf(u1);
+  const float phi = (u2 < a) ? (u2 / a) * M_PI_F : M_PI_F + (u2 - a) / (1.0f - a) * M_PI_F;
+  const float p1 = r * cosf(phi);
+  const float p2 = r * sinf(phi) * ((u2 < a) ? 1.0f : v.z);
+  const f3 n = add3(add3(scale3(t1, p1), scale3(t2, p2)), scale3(v, sqrtf(fmaxf(0.0f, 1.0f - p1 * p1 - p2 * p2))));
+  return normalize3(v3(roughness * n.x, roughness * n.y, fmaxf(0.0f, n.z)));
+}
+static void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray_dir, f3 a_normal, f2 tc, int a_hitFromInside, int a_isFwdDir,
+                                      const OrcScene* s, MatSample* out) {
+  const f3 texColor = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(matColor(m), texColor), 0.0f, 1.0f);
+  const float gloss = transparencyGloss(m, GLASS_GLOSINESS, GLASS_GLOSINESS_TEXMATRIXID, tc, s);
+  const float roughness = clampf(1.0f - gloss, 0.0f, 1.0f);
+  const float roughSqr = roughness * roughness;
+  const float IOR = m[GLASS_IOR];
+  const f3 normal2 = a_hitFromInside ? scale3(a_normal, -1.0f) : a_normal;
+  int spec = 1;
+  float Pss = 1.0f;
+  out->pdf = 1.0f;
+  RefractResult refrData = myRefractGgx(ray_dir, normal2, IOR, 1.0f);
+  if (gloss < 0.999f) {
+    spec = 0;
+    float eta = 1.0f / IOR;
+    const float cosTheta = dot3(normal2, ray_dir) * (-1.0f);
+    if (cosTheta < 0.0f) eta = 1.0f / eta;
+    f3 nx, ny;
+    const f3 nz = a_normal;
+    CoordinateSystem(nz, &nx, &ny);
+    const f3 wo = v3(-dot3(ray_dir, nx), -dot3(ray_dir, ny), -dot3(ray_dir, nz));
+    const f3 wh = GgxVndf(wo, roughSqr, rands[0], rands[1]);
+    const float dotWoWh = dot3(wo, wh);
+    f3 newDir;
+    const float radicand = 1.0f + eta * eta * (dotWoWh * dotWoWh - 1.0f);
+    if (radicand > 0.0f) {
+      newDir = sub3(scale3(wh, eta * dotWoWh - sqrtf(radicand)), scale3(wo, eta));
+      refrData.success = 1;
+      refrData.eta = eta;
+    } else {
+      newDir = sub3(scale3(wh, 2.0f * dotWoWh), wo);
+      refrData.success = 0;
+      refrData.eta = 1.0f;
+    }
+    refrData.ray_dir = normalize3(add3(add3(scale3(nx, newDir.x), scale3(ny, newDir.y)), scale3(nz, newDir.z)));
+    const f3 v = scale3(ray_dir, -1.0f), l = refrData.ray_dir;
+    const float dotNV = fabsf(dot3(a_normal, v)), dotNL = fabsf(dot3(a_normal, l));
+    const float G1 = SmithGGXMasking(dotNV, roughSqr);
+    const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+    Pss = G2 / fmaxf(G1, 1e-6f);
+  }
+  const float cosThetaOut = dot3(refrData.ray_dir, a_normal);
+  const float cosMult = 1.0f / fmaxf(fabsf(cosThetaOut), 1e-6f);
+  out->direction = refrData.ray_dir;
+  const float adjointBtdfMult = a_isFwdDir ? 1.0f : (refrData.eta * refrData.eta);
+  if (refrData.success) out->color = scale3(scale3(scale3(color, adjointBtdfMult), Pss), cosMult);
+  else out->color = scale3(scale3(v3(1.0f, 1.0f, 1.0f), Pss), cosMult);
+  out->flags = spec ? (RAY_EVENT_S | RAY_EVENT_T) : (RAY_EVENT_G | RAY_EVENT_T);
+  if (refrData.success && cosThetaOut >= -1e-6f) out->color = v3(0, 0, 0);
+  else if (!refrData.success && cosThetaOut < 1e-6f) out->color = v3(0, 0, 0);
+}
+
 /* ---- blend, ref: cglobals.h:1880-1926 fresnel helpers, cmaterial.h:2008-2137 */
 static float fresnelDielectric(float cosTheta1, float cosTheta2, float etaExt, float etaInt) {   /* ref: cglobals.h:1868-1877 */
   const float Rs = (etaExt * cosTheta1 - etaInt * cosTheta2) / (etaExt * cosTheta1 + etaInt * cosTheta2);
@@ -919,6 +1044,8 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_MIRROR: MirrorSampleAndEvalBRDF(m, ray_dir, n, sh->texCoord, s, out); break;
     case MT_LAMBERT: LambertSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
     case MT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, /*a_isFwdDir*/ 0, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false */
     default: break;
   }
   if (out->pdf <= 0.0f) out->color = v3(0, 0, 0);
@@ -952,6 +1079,7 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const
       r.pdfRev = phongEvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
       break;
     case MT_MIRROR: break;   /* mirrorEvalBxDF / PDF return 0, cmaterial.h:395-403 */
+    case MT_THIN_GLASS: case MT_GLASS: break;   /* thinglass / glass EvalBxDF and EvalPDF return 0, cmaterial.h:510-520, 622-630 */
     case MT_LAMBERT:
       r.brdf = scale3(lambertEvalBxDF(m, sc->tc, s), cosMult);
       r.pdfFwd = lambertEvalPDF(sc->l, sc->n);

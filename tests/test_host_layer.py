@@ -1,7 +1,7 @@
 """CPU: the scene front end packs buffers with the reference's layouts, and the BVH4 builder emits a valid tree."""
 import numpy as np
 
-from conftest import make_oracle, random_rays
+from conftest import host_scene, make_oracle, random_rays
 
 G_LIGHTS_OFFS, G_LIGHTS_NUM, G_MAT_TABLE, G_GEOM_TABLE, G_TEX_TABLE, G_LSEL_REV_SIZE = 236, 238, 219, 221, 218, 231
 G_VARS_I, G_VARS_F, G_FLAGS, G_SKY = 64, 128, 234, 235
@@ -206,3 +206,38 @@ def test_generated_atrium_scene_packs_textures_and_instances(atrium_small):
     orc = make_oracle(b)
     img, rays, _ = orc.render(2, seed=5)
     assert np.isfinite(img).all() and img[..., :3].mean() > 0.01 and rays > 2 * 96 * 54
+
+
+def test_transparency_layers_pack_like_the_reference_converter():
+    """CreateFromHydraMaterialXmlNode, PlainMaterialConverter.cpp:1541-1591: the four transparency shapes of the glass hall"""
+    sc, b = host_scene("atrium_glass_small", 96, 54, 8)
+    assert sc.unsupported() == 0, sc.log()
+    g, m = b["globals"], b["materials"].reshape(-1, 192)
+    mi = m.view(np.int32)
+    table = g[g[G_MAT_TABLE]:g[G_MAT_TABLE] + 12]
+    HAS_T, CAUSTICS, REFL_ONLY = 8, 2, 32768
+    # material 3: reflection + transparency -> fresnel blend(mirror, glass), CAN_SAMPLE_REFL_ONLY
+    n = table[3] * 4 // 192
+    assert mi[n, 0] == 9 and mi[n + mi[n, 16], 0] == 2 and mi[n + mi[n, 17], 0] == 4
+    assert mi[n, 15] & 1 and abs(m[n, 18] - 1.5) < 1e-6              # BLEND_MASK_FRESNEL, fresnel IOR
+    assert (mi[n, 1] & (HAS_T | REFL_ONLY | CAUSTICS)) == (HAS_T | REFL_ONLY | CAUSTICS)
+    gl = n + mi[n, 17]
+    assert abs(m[gl, 15] - 1.5) < 1e-6 and abs(m[gl, 21] - 1.0) < 1e-6 and mi[gl, 13] == -2 and mi[gl, 22] == -2   # IOR, gloss, no textures
+    assert mi[gl, 1] == (HAS_T | CAUSTICS)
+    # material 2: transparency only -> a bare glass node (rough: gloss 0.7, ior 1.33)
+    n = table[2] * 4 // 192
+    assert mi[n, 0] == 4 and abs(m[n, 21] - 0.7) < 1e-6 and abs(m[n, 15] - 1.33) < 1e-6
+    # material 1: reflection + transparency + diffuse -> blend(blend(S, T), D), alpha of the outer mask = transparency colour
+    n = table[1] * 4 // 192
+    st, d = n + mi[n, 16], n + mi[n, 17]
+    assert mi[n, 0] == 9 and mi[st, 0] == 9 and mi[d, 0] == 7
+    assert mi[st + mi[st, 16], 0] == 0 and mi[st + mi[st, 17], 0] == 4
+    np.testing.assert_allclose(m[n, 10:13], 0.5)
+    assert (mi[n, 15] & 1) == 0 and (mi[st, 15] & 1) == 1 and (mi[st, 1] & REFL_ONLY) and (mi[n, 1] & REFL_ONLY) == 0
+    # material 6: thin-walled + diffuse -> plain blend(thin glass, lambert) with strong extrusion; the transparency texture
+    # drives both the mask and the thin-glass colour sampler (float 20)
+    n = table[6] * 4 // 192
+    tg = n + mi[n, 16]
+    assert mi[n, 0] == 9 and mi[tg, 0] == 3 and mi[n + mi[n, 17], 0] == 7 and (mi[n, 15] & 8)
+    assert mi[tg, 13] == 2 and mi[tg, 14] == 5 and abs(m[tg, 16] - 0.85) < 1e-6 and m[tg, 15] == 0.0
+    assert mi[n, 13] == 2

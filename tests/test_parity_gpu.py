@@ -71,6 +71,17 @@ def gpu_atrium_lights(built):
     return core, b, make_oracle(b)
 
 
+@pytest.fixture(scope="module")
+def gpu_atrium_glass(built):
+    """closed hall with clear glass + Fresnel mirror (pots), rough GGX glass (arches), reflection + glass + diffuse (column bands)
+    and textured glossy thin glass over diffuse (curtains); 8 bounces so that paths get through both faces of a pot"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_glass_small", 96, 54, 8)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
 def test_native_library_is_the_one_running(gpu224):
     core, _, _ = gpu224
     name = core.device_name()
@@ -167,7 +178,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -183,7 +194,7 @@ def test_light_and_material_functions_at_shading_points(fix, request):
     check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -204,7 +215,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]

@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
     ap.add_argument("--delta-lights", action="store_true", help="open roof, no sky: adds a point, a spot and a directional (soft sun) light to the roof light")
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
+    ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
+                    "reflection + glass + diffuse, curtains = textured glossy thin glass over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
     s = np.sqrt(args.scale)
@@ -217,7 +219,19 @@ def main():
     xml.append("<materials_lib>")
     for mid in range(10):
         c = "%.4f %.4f %.4f" % tuple(cols[mid])
-        if mid in (1, 8):      # lambert + phong blend
+        if args.glass and mid in (1, 2, 3, 6):
+            body = {
+                3: '<reflectivity brdf_type="phong"><color val="0.9 0.9 0.9" /><glossiness val="1" /><fresnel val="1" /><fresnel_ior val="1.5" /></reflectivity>'
+                   '<transparency><color val="0.9 0.97 0.92" /><glossiness val="1" /><thin_walled val="0" /><fog_color val="1 1 1" /><fog_multiplier val="0" /><ior val="1.5" /></transparency>',
+                2: '<transparency><color val="0.85 0.9 0.95" /><glossiness val="0.7" /><thin_walled val="0" /><ior val="1.33" /></transparency>',
+                1: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
+                   '<reflectivity brdf_type="phong"><color val="0.3 0.3 0.3" /><glossiness val="0.8" /><fresnel val="1" /><fresnel_ior val="1.6" /></reflectivity>'
+                   '<transparency><color val="0.5 0.5 0.5" /><glossiness val="1" /><thin_walled val="0" /><ior val="1.6" /></transparency>' % c,
+                6: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
+                   '<transparency><color val="0.6 0.6 0.6"><texture id="2" type="texref" /></color><glossiness val="0.85" /><thin_walled val="1" /><ior val="1.5" /></transparency>' % c,
+            }[mid]
+            xml.append('  <material id="%d" name="m%d" type="hydra_material">%s</material>' % (mid, mid, body))
+        elif mid in (1, 8):      # lambert + phong blend
             gloss = 0.5 if mid == 1 else 0.85
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
                        '<reflectivity brdf_type="phong"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" /></reflectivity></material>' % (mid, mid, c, gloss))
