@@ -674,6 +674,9 @@ struct hydra_hip_ctx {
   int treesNum = 0, instNum = 0;
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
+  bool matDirty = true;              // material arena or material table changed since validate_materials last passed
+  std::vector<float> hostMaterials;  // host copy of the material arena and table, for validate_materials only
+  std::vector<int32_t> hostMatTable;
   bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
   bool skyLightOk = true;            // false when the uploaded sky light needs a model this layer lacks
 
@@ -794,6 +797,46 @@ static int seg_grid(const hydra_hip_ctx* c, const SegQ& q, int block, int blocks
   return std::max(1, bps) * q.nseg;
 }
 static SegQ seg_q(const uint32_t* counts, int countImm, int nseg, int cap) { SegQ q; q.counts = counts; q.countImm = countImm; q.nseg = nseg; q.cap = cap; return q; }
+
+// Every material a table entry reaches must be one this layer shades: the device's leaf dispatch would otherwise return
+// black for it without a word.  Walks the blend trees (cmaterial.h:2180-2207 addressing) on a host copy of the arena.
+static int validate_materials(hydra_hip_ctx* c) {
+  if (!c->matDirty) return HYDRA_HIP_OK;
+  const size_t floats = c->hostMaterials.size();
+  auto word = [](const float* m, int i) { int32_t v; memcpy(&v, m + i, 4); return v; };
+  for (size_t id = 0; id < c->hostMatTable.size(); id++) {
+    const int32_t offs = c->hostMatTable[id];
+    if (offs < 0) continue;
+    size_t stack[2 * 8];
+    int top = 0, visited = 0;
+    stack[top++] = size_t(offs) * 4;
+    while (top > 0) {
+      const size_t at = stack[--top];
+      const std::string who = "material " + std::to_string(id) + " (node at float " + std::to_string(at) + ")";
+      if (at + HM_NODE_FLOATS > floats) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " lies outside the material arena");
+      if (++visited > 64) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": blend tree with more than 64 nodes (cycle?)");
+      const float* m = c->hostMaterials.data() + at;
+      const int type = word(m, HM_TYPE), flags = word(m, HM_FLAGS);
+      if (uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has a normal map, which the HIP layer does not implement");
+      if (type == HMT_BLEND_MASK) {
+        const int o1 = word(m, HM_BLEND_MAT1), o2 = word(m, HM_BLEND_MAT2);
+        if (o1 <= 0 || o2 <= 0 || top + 2 > 16) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": bad blend children");
+        stack[top++] = at + size_t(o1) * HM_NODE_FLOATS;
+        stack[top++] = at + size_t(o2) * HM_NODE_FLOATS;
+        continue;
+      }
+      const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
+                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE);
+      if (!known)
+        return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has BxDF class " + std::to_string(type) +
+                                             "; the HIP layer implements phong, mirror, thin glass, glass, lambert, oren-nayar, blend mask and emissive only");
+      if (type == HMT_GLASS && (flags & HMF_ENERGY_FIX))
+        return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " asks for the glass multi-scattering table, which the HIP layer does not implement");
+    }
+  }
+  c->matDirty = false;
+  return HYDRA_HIP_OK;
+}
 
 // (re)build the per-triangle records when the geometry arena or the geometry table changed; called by every entry point
 // that shades.  Two small kernels and one read-back of the per-mesh triangle counts.
@@ -1099,6 +1142,12 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
   c->globalsWords = words;
   c->hostHeader.assign(blob, blob + HG_TABLES_READY + 1);
   c->geomDirty = true;
+  {
+    const int64_t to = blob[HG_MAT_TABLE_OFFS], ts = blob[HG_MAT_TABLE_SIZE];
+    if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: material table runs past the blob");
+    c->hostMatTable.assign(blob + to, blob + to + ts);
+    c->matDirty = true;
+  }
   // the sky light (if any) must be one this layer implements: constant colour or lat-long texture, no Perez model
   c->skyLightOk = true;
   const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
@@ -1133,6 +1182,10 @@ int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, siz
   if (!c || kind < 0 || kind >= HYDRA_STORAGE_KINDS || (bytes > 0 && !data)) return fail(c, HYDRA_HIP_EINVAL, "upload_storage: bad arguments");
   HCHECK(hipSetDevice(c->device));
   if (kind == HYDRA_STORAGE_GEOM) c->geomDirty = true;
+  if (kind == HYDRA_STORAGE_MATERIALS) {
+    c->hostMaterials.assign(static_cast<const float*>(data), static_cast<const float*>(data) + bytes / 4);
+    c->matDirty = true;
+  }
   return dev_upload(c, c->storage[kind], data, bytes);
 }
 int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes, int nodes_num, const float* tri_f4, int tri_f4_num,
@@ -1243,6 +1296,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   if (!scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: scene is not completely uploaded (globals, storages, BVH, instances)");
   HCHECK(hipSetDevice(c->device));
   { int rc = prepare_geometry(c); if (rc) return rc; }
+  { int rc = validate_materials(c); if (rc) return rc; }
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   if (!c->gensReady) { int rc = hydra_hip_init_path_tracing(c, c->seed); if (rc) return rc; }
   if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
@@ -1431,6 +1485,7 @@ struct TmpBufs {
   if ((needScene) && !scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "stage call: scene is not uploaded"); \
   HCHECK(hipSetDevice(c->device));                                                                      \
   if (needScene) { const int prc_ = prepare_geometry(c); if (prc_) return prc_; }                       \
+  if (needScene) { const int vrc_ = validate_materials(c); if (vrc_) return vrc_; }                      \
   TmpBufs tb; int rc = HYDRA_HIP_OK;
 #define STAGE_EPILOG()                                                                                  \
   HCHECK(hipGetLastError());                                                                            \

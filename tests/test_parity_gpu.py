@@ -358,6 +358,28 @@ def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     fresh.close()
 
 
+def test_materials_the_layer_does_not_shade_are_refused(gpu224):
+    """a GGX reflection node (class 15), a normal-mapped node or a glass node asking for the multi-scattering table would
+    come out black from the device's leaf dispatch: the layer refuses to render instead"""
+    from hydracore_amd import HipCore, HydraError
+    _, b, _ = gpu224
+    g = b["globals"]
+    root = g[g[219] + 1] * 4                                          # material 1 = blend(phong, lambert): its phong child
+    for word, value, what in ((0, 15, "BxDF class 15"), (83, 1, "normal map")):
+        bad = dict(b)
+        m = b["materials"].copy().view(np.int32)
+        m[root + 192 + word] = value
+        bad["materials"] = m.view(b["materials"].dtype)
+        core = HipCore(32, 32, device=0)
+        core.upload_scene(bad)
+        core.init_path_tracing(1)
+        with pytest.raises(HydraError, match=what):
+            core.trace_pass(1)
+        core.upload_scene(b)                                          # a good arena clears the refusal
+        core.trace_pass(1)
+        core.close()
+
+
 @pytest.mark.parametrize("scene,light_max", [("test_224", 160.0), ("atrium250k_sky", 60.0)])
 def test_full_size_properties_1080p(built, scene, light_max):
     """BASELINE configs[1] and configs[2] sizes: 1920x1080, 8 bounces.  Size-independent properties only (the oracle is too
