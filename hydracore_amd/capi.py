@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_upload_remap_lists", "hydra_hip_set_tile_partition", "hydra_hip_set_external_accumulator",
     "hydra_hip_init_path_tracing", "hydra_hip_clear_accumulated_color", "hydra_hip_trace_pass", "hydra_hip_set_spp",
     "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_rays_stat",
-    "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
+    "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_get_stage_times_per_bounce", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
     "hydra_hip_get_traversal_counters", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
@@ -87,6 +87,7 @@ def load_hip_library():
         "hydra_hip_get_rays_stat": ([vp, C.POINTER(RaysStat)], i32),
         "hydra_hip_reset_perf_counters": ([vp], i32),
         "hydra_hip_enable_stage_timing": ([vp, i32], i32),
+        "hydra_hip_get_stage_times_per_bounce": ([vp, vp, i32], i32),
         "hydra_hip_set_option": ([vp, C.c_char_p, i32], i32),
         "hydra_hip_get_option": ([vp, C.c_char_p, C.POINTER(i32)], i32),
         "hydra_hip_enable_traversal_counters": ([vp, i32], i32),
@@ -252,6 +253,12 @@ class HipCore:
 
     def enable_stage_timing(self, on=True):
         self._ck(self.lib.hydra_hip_enable_stage_timing(self.h, 1 if on else 0), "enable_stage_timing")
+
+    def stage_times_per_bounce(self, max_depth):
+        """float32 [max_depth, 3 (closest-hit traversal | bounce kernels | shadow traversal)] in ms since the last reset"""
+        out = np.zeros((max_depth, 3), np.float32)
+        self._ck(self.lib.hydra_hip_get_stage_times_per_bounce(self.h, _ptr(out), max_depth), "get_stage_times_per_bounce")
+        return out
 
     def set_option(self, name, value):
         self._ck(self.lib.hydra_hip_set_option(self.h, name.encode(), int(value)), "set_option(%s)" % name)

@@ -503,6 +503,49 @@ HK_DEV void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, con
   if (cosOut <= 1e-6f) out.color = mk3(0, 0, 0);
   out.flags = HRE_S;
 }
+// ---- multi-scattering energy tables of the globals header (cfetch.h:78-79), cmaterial.h:61-196.  Read only when a node carries
+// PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER; whoever assembles the blob fills them (IHWLayerDataAssembler.cpp via cfetch.h:84-93).
+HK_DEV float BilinearFrom2dTable(const uint16_t* t, float x, float y, int w, int h) {   // :61-90
+  x = clampf(x, 0.0f, float(w) - 1.0001f);
+  y = clampf(y, 0.0f, float(h) - 1.0001f);
+  const int fy = int(floorf(y)), fx = int(floorf(x));
+  const int d1 = fy * w + fx, d2 = d1 + 1, d3 = (fy + 1) * w + fx, d4 = d3 + 1;
+  const float dx = x - float(fx), dy = y - float(fy);
+  const float m1 = (1.0f - dx) * (1.0f - dy), m2 = dx * (1.0f - dy), m3 = dy * (1.0f - dx), m4 = dx * dy;
+  if (fy >= 0 && fx >= 0 && fy <= h - 2 && fx <= w - 2) return float(t[d1]) * m1 + float(t[d2]) * m2 + float(t[d3]) * m3 + float(t[d4]) * m4;
+  return 1.0f;
+}
+HK_DEV float BilinearFrom3dTable(const uint16_t* t, float x, float y, float z, int w, int h, int d, int size2d) {   // :93-150
+  x = clampf(x, 0.0f, float(w) - 1.0001f);
+  y = clampf(y, 0.0f, float(h) - 1.0001f);
+  z = clampf(z, 0.0f, float(d) - 1.0001f);
+  const int fx = int(floorf(x)), fy = int(floorf(y)), fz = int(floorf(z));
+  const int zo = fz * size2d, zo2 = (fz + 1) * size2d;
+  const int d1 = zo + fy * w + fx, d3 = zo + (fy + 1) * w + fx, d2 = d1 + 1, d4 = d3 + 1;
+  const int d5 = zo2 + fy * w + fx, d7 = zo2 + (fy + 1) * w + fx, d6 = d5 + 1, d8 = d7 + 1;
+  const float dx = x - float(fx), dy = y - float(fy), dz = z - float(fz);
+  const float m1 = (1.0f - dx) * (1.0f - dy), m2 = dx * (1.0f - dy), m3 = dy * (1.0f - dx), m4 = dx * dy;
+  if (fy >= 0 && fx >= 0 && fy <= h - 2 && fx <= w - 2) {
+    const float p1 = float(t[d1]) * m1 + float(t[d2]) * m2 + float(t[d3]) * m3 + float(t[d4]) * m4;
+    const float p2 = float(t[d5]) * m1 + float(t[d6]) * m2 + float(t[d7]) * m3 + float(t[d8]) * m4;
+    return p1 + dz * (p2 - p1);
+  }
+  return 1.0f;
+}
+HK_DEV f3 multiscatterFromEss(float Ess, f3 color) {
+  const float a = 1.0f - Ess, b = fmaxf(Ess, 1e-6f);
+  return mk3(1.0f + (color.x * a) / b, 1.0f + (color.y * a) / b, 1.0f + (color.z * a) / b);
+}
+HK_DEV f3 GetMultiscatteringFrom2dTable(const SceneDev& s, float roughness, float dotNV, f3 color) {   // :152-159, 64 x 64
+  const uint16_t* t = reinterpret_cast<const uint16_t*>(s.globals + HG_ESS_GGX_TABLE);
+  return multiscatterFromEss(BilinearFrom2dTable(t, dotNV * 64.0f, roughness * 64.0f, 64, 64) * (1.0f / 65535.0f), color);
+}
+HK_DEV f3 GetMultiscatteringFrom3dTable(const SceneDev& s, float roughness, float dotNV, float ior, f3 color) {   // :161-196, 64^3
+  if (!(ior >= 0.4166f && ior <= 2.4f)) return mk3(1, 1, 1);
+  const uint16_t* t = reinterpret_cast<const uint16_t*>(s.globals + HG_ESS_TRANSP_TABLE);
+  const float iorNormal = (ior - 0.4166f) / (2.4f - 0.4166f);
+  return multiscatterFromEss(BilinearFrom3dTable(t, dotNV * 64.0f, roughness * 64.0f, iorNormal * 64.0f, 64, 64, 64, 64 * 64) * (1.0f / 65536.0f), color);
+}
 // ---- thin glass, cmaterial.h:472-556.  Eval is zero (:512-520): shadow rays never sample it.
 HK_DEV float transpGloss(const float* m, int glossMult, int glossTexMatrixId, f2 tc, const SceneDev& s) {   // thinglassCosPower :496-505, glassGloss :610-618
   const f3 g = sample2DExt(as_int(m[glossTexMatrixId]), tc, m, s);
@@ -569,8 +612,6 @@ HK_DEV f3 GgxVndf(f3 wo, float roughness, float u1, float u2) {   // :1220-1245 
   const f3 n = ((t1 * p1) + (t2 * p2)) + (v * sqrtf(fmaxf(0.0f, 1.0f - p1 * p1 - p2 * p2)));
   return normalize(mk3(roughness * n.x, roughness * n.y, fmaxf(0.0f, n.z)));
 }
-// The multi-scattering table (:858-860, PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER on a glass node) is not part of this path:
-// no front end here sets that flag on glass (TransparentMaterialFromHydraMtl, PlainMaterialConverter.cpp:1151-1199, never does).
 HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray_dir, f3 n, f2 tc, bool hitFromInside, const SceneDev& s, MatSample& out) {   // :775-882, a_isFwdDir = false
   const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
   const f3 color = clamp3(matColor(m) * tex, 0.0f, 1.0f);
@@ -581,6 +622,7 @@ HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray
   const f3 normal2 = hitFromInside ? n * (-1.0f) : n;
   bool spec = true;
   float Pss = 1.0f;
+  f3 Pms = mk3(1, 1, 1);
   out.pdf = 1.0f;
   RefractResult refr = myRefractGgx(ray_dir, normal2, IOR, 1.0f);
   if (gloss < 0.999f) {
@@ -604,16 +646,94 @@ HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray
     const float G1 = SmithGGXMasking(dotNV, roughSqr);
     const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
     Pss = G2 / fmaxf(G1, 1e-6f);
+    if (matFlags(m) & HMF_ENERGY_FIX) Pms = GetMultiscatteringFrom3dTable(s, roughness, dotNV, 1.0f / eta, color);   // :858-860
   }
   const float cosOut = dot(refr.ray_dir, n);
   const float cosMult = 1.0f / fmaxf(fabsf(cosOut), 1e-6f);
   out.direction = refr.ray_dir;
   const float adjointBtdfMult = refr.eta * refr.eta;   // camera paths: radiance flows against the walk (:867-869)
-  if (refr.success) out.color = ((color * adjointBtdfMult) * Pss) * cosMult;
-  else out.color = (mk3(1, 1, 1) * Pss) * cosMult;
+  if (refr.success) out.color = (((color * adjointBtdfMult) * Pss) * Pms) * cosMult;
+  else out.color = ((mk3(1, 1, 1) * Pss) * Pms) * cosMult;
   out.flags = spec ? (HRE_S | HRE_T) : (HRE_G | HRE_T);
   if (refr.success && cosOut >= -1e-6f) out.color = mk3(0, 0, 0);
   else if (!refr.success && cosOut < 1e-6f) out.color = mk3(0, 0, 0);
+}
+// ---- GGX reflection, cmaterial.h:1165-1212, 1285-1291, 1317-1381, 1454-1520 (the 2017 VNDF form the reference dispatches to)
+HK_DEV float ggxGlosiness(const float* m, f2 tc, const SceneDev& s) {
+  if (uint32_t(as_int(m[HM_GGX_GLOSS_TEXID])) != HYDRA_INVALID_TEXTURE) {
+    const f3 g = sample2DExt(as_int(m[HM_GGX_GLOSS_TEXMATRIXID]), tc, m, s);
+    return clampf(m[HM_GGX_GLOSINESS] * fmaxf(g.x, fmaxf(g.y, g.z)), 0.0f, 0.99f);
+  }
+  return m[HM_GGX_GLOSINESS];
+}
+HK_DEV float GGX_Distribution(float cosThetaNH, float alpha) {
+  const float alpha2 = alpha * alpha;
+  const float NH_sqr = clampf(cosThetaNH * cosThetaNH, 0.0f, 1.0f);
+  const float den = NH_sqr * alpha2 + (1.0f - NH_sqr);
+  return alpha2 / fmaxf(HK_PI * den * den, 1e-6f);
+}
+HK_DEV float ggx2EvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 1.0f;
+  const float roughness = 1.0f - ggxGlosiness(m, tc, s);
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize(v + l);
+  const float dotNH = dot(n, h), dotHV = dot(h, v);
+  const float G1 = SmithGGXMasking(dotNV, roughSqr);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  const float Dv = D * G1 * dotHV / fmaxf(dotNV, 1e-6f);
+  const float jacob = 1.0f / fmaxf(4.0f * dotHV, 1e-6f);
+  return Dv * jacob;
+}
+HK_DEV f3 ggxEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return mk3(0, 0, 0);
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float roughness = 1.0f - ggxGlosiness(m, tc, s);
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize(v + l);
+  const float dotNH = dot(n, h);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  const float G = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+  const float Pss = D * G / fmaxf(4.0f * dotNV * dotNL, 1e-6f);
+  f3 Pms = mk3(1, 1, 1);
+  if (matFlags(m) & HMF_ENERGY_FIX) Pms = GetMultiscatteringFrom2dTable(s, roughness, dotNV, color);
+  return (color * Pss) * Pms;
+}
+HK_DEV void GGXSample2AndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float gloss = ggxGlosiness(m, tc, s);
+  const float roughness = 1.0f - gloss;
+  const float roughSqr = roughness * roughness;
+  f3 nx, ny;
+  const f3 nz = n;
+  CoordinateSystem(nz, nx, ny);
+  float Pss = 1.0f;
+  f3 Pms = mk3(1, 1, 1);
+  const f3 wo = mk3(-dot(ray_dir, nx), -dot(ray_dir, ny), -dot(ray_dir, nz));
+  const f3 wh = GgxVndf(wo, roughSqr, r1, r2);
+  const f3 wi = (wh * (2.0f * dot(wo, wh))) - wo;
+  const f3 newDir = normalize(((nx * wi.x) + (ny * wi.y)) + (nz * wi.z));
+  const f3 v = ray_dir * (-1.0f), l = newDir;
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) { Pss = 0.0f; out.pdf = 1.0f; }
+  else {
+    const f3 h = normalize(v + l);
+    const float dotNH = dot(n, h), dotHV = dot(h, v);
+    const float D = GGX_Distribution(dotNH, roughSqr);
+    const float G1 = SmithGGXMasking(dotNV, roughSqr);
+    const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+    Pss = D * G2 / fmaxf(4.0f * dotNV, 1e-6f);
+    const float Dv = D * G1 * dotHV / fmaxf(dotNV, 1e-6f);
+    const float jacob = 1.0f / fmaxf(4.0f * dotHV, 1e-6f);
+    out.pdf = Dv * jacob;
+    if (matFlags(m) & HMF_ENERGY_FIX) Pms = GetMultiscatteringFrom2dTable(s, roughness, dotNV, color);
+  }
+  out.direction = newDir;
+  const f3 c = (color * Pss) * Pms;
+  const float d = fmaxf(dotNL, 1e-6f);
+  out.color = mk3(c.x / d, c.y / d, c.z / d);
+  out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
 }
 // ---- blend mask, cmaterial.h:2008-2137; fresnel cglobals.h:1879-1926
 HK_DEV float fresnelDielectric(float c1, float c2, float etaExt, float etaInt) {
@@ -691,6 +811,7 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
     case HMT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_GGX: GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_THIN_GLASS: ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_GLASS: GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out); break;
     default: break;
@@ -726,6 +847,10 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         brdf = phongEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
         pf = phongEvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
         pr = phongEvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
+      } else if (type == HMT_GGX) {
+        brdf = ggxEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
+        pf = ggx2EvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
+        pr = ggx2EvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
       } else if (type == HMT_LAMBERT) {
         brdf = (lambertColor(m, sc.tc, s) * HK_INV_PI) * 1.0f;
         pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;

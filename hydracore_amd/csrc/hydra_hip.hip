@@ -716,7 +716,8 @@ struct hydra_hip_ctx {
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
   uint64_t nTrace = 0, nShadow = 0;   // launches folded into tTrace / tShadow
   std::vector<hipEvent_t> evPool;
-  struct EvSpan { int a, b, kind; };
+  struct EvSpan { int a, b, kind, depth; };
+  double tDepth[HK_MAX_DEPTH][3] = {};   // per bounce: closest-hit traversal, bounce kernel(s), shadow traversal (ms)
   std::vector<EvSpan> spans;
   size_t evCursor = 0;
 };
@@ -816,7 +817,7 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (at + HM_NODE_FLOATS > floats) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " lies outside the material arena");
       if (++visited > 64) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": blend tree with more than 64 nodes (cycle?)");
       const float* m = c->hostMaterials.data() + at;
-      const int type = word(m, HM_TYPE), flags = word(m, HM_FLAGS);
+      const int type = word(m, HM_TYPE);
       if (uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has a normal map, which the HIP layer does not implement");
       if (type == HMT_BLEND_MASK) {
         const int o1 = word(m, HM_BLEND_MAT1), o2 = word(m, HM_BLEND_MAT2);
@@ -826,12 +827,10 @@ static int validate_materials(hydra_hip_ctx* c) {
         continue;
       }
       const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
-                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE);
+                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX);
       if (!known)
         return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has BxDF class " + std::to_string(type) +
-                                             "; the HIP layer implements phong, mirror, thin glass, glass, lambert, oren-nayar, blend mask and emissive only");
-      if (type == HMT_GLASS && (flags & HMF_ENERGY_FIX))
-        return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " asks for the glass multi-scattering table, which the HIP layer does not implement");
+                                             "; the HIP layer implements phong, GGX, mirror, thin glass, glass, lambert, oren-nayar, blend mask and emissive only");
     }
   }
   c->matDirty = false;
@@ -1037,7 +1036,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       if (fused) launch_shadow(c, s, qOut, bb.sh.org4, bb.sh.dir4, bb.sh.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
       else launch_shadow(c, s, qOut, bb.M.shadowOrg, bb.M.recC, bb.M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
       int e = mark();
-      if (timing) c->spans.push_back({d, e, 3});
+      if (timing) c->spans.push_back({d, e, 3, depth});
       if (!fused) {
         switch (c->shadeWaves) {
           case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
@@ -1045,10 +1044,10 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
         }
         int f = mark();
-        if (timing) c->spans.push_back({e, f, 4});
+        if (timing) c->spans.push_back({e, f, 4, depth});
       }
     }
-    if (timing) { c->spans.push_back({a, b, 1}); c->spans.push_back({b, d, 2}); }
+    if (timing) { c->spans.push_back({a, b, 1, depth}); c->spans.push_back({b, d, 2, depth}); }
   }
   HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
@@ -1280,6 +1279,7 @@ static int fold_stage_events(hydra_hip_ctx* c) {
     (void)hipEventElapsedTime(&ms, c->evPool[sp.a], c->evPool[sp.b]);
     switch (sp.kind) { case 0: c->tRaygen += ms; break; case 1: c->tTrace += ms; c->nTrace++; break; case 2: c->tHit += ms; break; case 3: c->tShadow += ms; c->nShadow++; break;
                        case 4: c->tShade += ms; break; case 5: c->tAccum += ms; break; default: c->tPass += ms; break; }
+    if (sp.depth >= 0 && sp.depth < HK_MAX_DEPTH && sp.kind >= 1 && sp.kind <= 4) c->tDepth[sp.depth][sp.kind == 4 ? 1 : sp.kind - 1] += ms;
   }
   c->spans.clear();
   c->evCursor = 0;
@@ -1331,14 +1331,14 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     int e0 = mark();
     hipLaunchKernelGGL(k_raygen, dim3(gWide), dim3(256), 0, c->stream, s, q0, static_cast<const int*>(c->ownedPixels.p), c->N, ns, c->streamMajor, static_cast<const uint2*>(c->gens.p), c->w, c->h, S);
     int e1 = mark();
-    if (timing) c->spans.push_back({e0, e1, 0});
+    if (timing) c->spans.push_back({e0, e1, 0, -1});
     { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, bb, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
                            static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
     int g0 = mark();
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, c->w * c->h, ns);
     hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, c->nseg, static_cast<unsigned long long*>(c->totals.p));
     int g1 = mark();
-    if (timing) { c->spans.push_back({g0, g1, 5}); c->spans.push_back({e0, g1, 6}); }
+    if (timing) { c->spans.push_back({g0, g1, 5, -1}); c->spans.push_back({e0, g1, 6, -1}); }
     HCHECK(hipGetLastError());
     if (timing && c->evCursor > 200000) { int rc = fold_stage_events(c); if (rc) return rc; }   // bound the event pool
   }
@@ -1397,10 +1397,18 @@ int hydra_hip_get_rays_stat(hydra_hip_handle c, HydraRaysStat* out) {
   }
   return HYDRA_HIP_OK;
 }
+int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle c, float* out, int max_depth) {
+  if (!c || !out || max_depth < 1 || max_depth > HK_MAX_DEPTH) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  { int rc = fold_stage_events(c); if (rc) return rc; }
+  for (int d = 0; d < max_depth; d++) for (int k = 0; k < 3; k++) out[d * 3 + k] = float(c->tDepth[d][k]);
+  return HYDRA_HIP_OK;
+}
 int hydra_hip_reset_perf_counters(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   { int rc = fold_stage_events(c); if (rc) return rc; }
   c->tTrace = c->tHit = c->tShadow = c->tShade = c->tRaygen = c->tAccum = c->tPass = 0;
+  memset(c->tDepth, 0, sizeof(c->tDepth));
   c->nTrace = c->nShadow = 0;
   if (c->totals.p) { HCHECK(hipSetDevice(c->device)); HCHECK(hipMemsetAsync(c->totals.p, 0, 32, c->stream)); }
   return HYDRA_HIP_OK;

@@ -147,6 +147,20 @@ MatPtr make_phong(float3 color, int32_t texId, const Sampler& sc, float cosPower
   put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
   return p;
 }
+// GGXMaterial, PlainMaterialConverter.cpp:635-680 (the anisotropy arguments of the constructor are never stored)
+MatPtr make_ggx(float3 color, int32_t texId, const Sampler& sc, float cosPower, int32_t glossTexId, const Sampler& sg, float gloss, float ior) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  d[HM_GGX_COSPOWER] = cosPower;
+  d[HM_GGX_GLOSINESS] = gloss;
+  d[HM_GGX_FRESNEL_IOR] = ior;
+  put_sampler_at(d, texId, sc, HM_TEXID, HM_TEXMATRIXID, HM_GGX_SAMPLER0);
+  put_sampler_at(d, glossTexId, sg, HM_GGX_GLOSS_TEXID, HM_GGX_GLOSS_TEXMATRIXID, HM_GGX_SAMPLER1);
+  put_i(d, HM_TYPE, HMT_GGX);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
+  return p;
+}
 // MirrorMaterial, PlainMaterialConverter.cpp:219-247
 MatPtr make_mirror(float3 color, int32_t texId, const Sampler& s) {
   MatPtr p = new_node();
@@ -340,6 +354,8 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     const std::string brdf = xattr(reflect, "brdf_type");
     if (texGloss == int32_t(HYDRA_INVALID_TEXTURE) && glossVal >= 0.995f)
       pMaterialS = make_mirror(colorS, texReflId, samplRefl);
+    else if (brdf == "ggx" || brdf == "GGX")
+      pMaterialS = make_ggx(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal, fresnelIOR);
     else {
       if (length(colorS) > 1e-5f && brdf != "phong" && brdf != "")
         Unsupported("reflectivity brdf_type '" + brdf + "' (material " + std::to_string(a_matId) + "), packed as phong");
@@ -348,7 +364,13 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     const XmlNode* efix = xchild(reflect, "energy_fix");
     if (!efix) efix = xchild(reflect, "multiscatter_fix");
     if (!efix) efix = xchild(reflect, "multiscatter");
-    if (efix && efix->attr_int("val") == 1) put_i(pMaterialS->plain, HM_FLAGS, get_i(pMaterialS->plain, HM_FLAGS) | HMF_ENERGY_FIX);
+    if (efix && efix->attr_int("val") == 1) {
+      put_i(pMaterialS->plain, HM_FLAGS, get_i(pMaterialS->plain, HM_FLAGS) | HMF_ENERGY_FIX);
+      // on a GGX node the flag makes the shading read EngineGlobals::m_essGgx2017Table; the table data lives in the reference's
+      // bakeBrdfEnergy/MSTables*.cpp, which this front end does not have: the header it assembles carries zeros there
+      if (get_i(pMaterialS->plain, HM_TYPE) == HMT_GGX && length(colorS) > 1e-5f)
+        Unsupported("GGX multi-scattering (material " + std::to_string(a_matId) + "): the energy table is not available to this front end");
+    }
   }
   // TransparentMaterialFromHydraMtl :1151-1199.  The fog (Beer) term the glass node carries is stored as the reference
   // stores it; IntegratorMISPTLoop2 never reads it (no materialLeafGetFog call on that path).

@@ -95,6 +95,9 @@ int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
 int hydra_hip_reset_perf_counters(hydra_hip_handle h);
 /* enable per-stage hipEvent timing inside trace_pass (event records only; they are resolved by get_rays_stat) */
 int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
+/* per-bounce split of the same stage timers since the last reset: out = max_depth x 3 floats (ms):
+ * [bounce][0 = closest-hit traversal | 1 = bounce kernel(s) | 2 = shadow traversal]  (traversal rate per bounce class) */
+int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max_depth);
 /* Options.
  * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
  * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12);

@@ -132,6 +132,8 @@ enum {
   HM_PHONG_COSPOWER = 15, HM_PHONG_GLOSINESS = 16, HM_PHONG_GLOSS_TEXID = 17, HM_PHONG_GLOSS_TEXMATRIXID = 18,
   HM_PHONG_SAMPLER0 = 20, HM_PHONG_SAMPLER1 = 32,
   HM_MIRROR_SAMPLER = 16,
+  HM_GGX_COSPOWER = 15, HM_GGX_GLOSINESS = 16, HM_GGX_GLOSS_TEXID = 17, HM_GGX_GLOSS_TEXMATRIXID = 18, HM_GGX_FRESNEL_IOR = 19,   /* cmaterial.h:1165-1185 */
+  HM_GGX_SAMPLER0 = 20, HM_GGX_SAMPLER1 = 32,
   HM_THINGLASS_COS_POWER = 15, HM_THINGLASS_GLOSINESS = 16, HM_THINGLASS_GLOSS_TEXID = 17, HM_THINGLASS_GLOSS_TEXMATRIXID = 18,   /* cmaterial.h:472-491 */
   HM_THINGLASS_SAMPLER0 = 20, HM_THINGLASS_SAMPLER1 = 32,
   HM_GLASS_IOR = 15, HM_GLASS_FOG_COLOR = 16, HM_GLASS_FOG_MULT = 19, HM_GLASS_COS_POWER = 20, HM_GLASS_GLOSINESS = 21,          /* cmaterial.h:566-590 */

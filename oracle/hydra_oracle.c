@@ -39,10 +39,12 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10 };
+enum { MT_PHONG = 0, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_GGX = 15 };
 enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };
 enum { THINGLASS_GLOSINESS = 16, THINGLASS_GLOSINESS_TEXMATRIXID = 18,                  /* cmaterial.h:472-491 */
-       GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23 };       /* cmaterial.h:566-590 */   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
+       GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23,         /* cmaterial.h:566-590 */
+       GGX_GLOSINESS = 16, GGX_GLOSINESS_TEXID = 17, GGX_GLOSINESS_TEXMATRIXID = 18 };  /* cmaterial.h:1165-1185 */
+enum { G_ESS_GGX_TABLE = 1268, G_ESS_TRANSP_TABLE = 3316 };   /* EngineGlobals::m_essGgx2017Table / m_essTranspTable in int32 words, cfetch.h:21-81 */   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
 enum { MF_CAST_CAUSTICS = 2, MF_FORBID_EMISSIVE_GI = 512, MF_SKIP_SKY_PORTAL = 1024, MF_CAN_SAMPLE_REFL_ONLY = 32768,
        MF_ENERGY_FIX = 32768 * 256 };
 enum { BMF_FRESNEL = 1, BMF_FALOFF = 2, BMF_REFL_WEIGHT_IS_ONE = 4, BMF_EXTRUSION_LUMINANCE = 16 };
@@ -838,6 +840,53 @@ static void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, con
   out->flags = RAY_EVENT_S;
 }
 
+/* ---- multi-scattering tables, ref: cmaterial.h:61-196 (BilinearFrom2dTable, BilinearFrom3dTable, GetMultiscatteringFrom2dTable / 3dTable) */
+static float BilinearFrom2dTable(const uint16_t* a_inData, float a_newPosX, float a_newPosY, int a_width, int a_height) {
+  a_newPosX = clampf(a_newPosX, 0.0f, (float)a_width - 1.0001f);
+  a_newPosY = clampf(a_newPosY, 0.0f, (float)a_height - 1.0001f);
+  const int floorY = (int)floorf(a_newPosY), floorX = (int)floorf(a_newPosX);
+  const int dxy1 = floorY * a_width + floorX, dxy2 = dxy1 + 1, dxy3 = (floorY + 1) * a_width + floorX, dxy4 = dxy3 + 1;
+  const float dx = a_newPosX - (float)floorX, dy = a_newPosY - (float)floorY;
+  const float mult1 = (1.0f - dx) * (1.0f - dy), mult2 = dx * (1.0f - dy), mult3 = dy * (1.0f - dx), mult4 = dx * dy;
+  if (floorY >= 0 && floorX >= 0 && floorY <= a_height - 2 && floorX <= a_width - 2)
+    return (float)a_inData[dxy1] * mult1 + (float)a_inData[dxy2] * mult2 + (float)a_inData[dxy3] * mult3 + (float)a_inData[dxy4] * mult4;
+  return 1.0f;
+}
+static float BilinearFrom3dTable(const uint16_t* a_inData, float x, float y, float z, int a_width, int a_height, int a_depth, int a_size2dTable) {
+  x = clampf(x, 0.0f, (float)a_width - 1.0001f);
+  y = clampf(y, 0.0f, (float)a_height - 1.0001f);
+  z = clampf(z, 0.0f, (float)a_depth - 1.0001f);
+  const int floorX = (int)floorf(x), floorY = (int)floorf(y), floorZ = (int)floorf(z);
+  const int zOffset = floorZ * a_size2dTable, zOffset2 = (floorZ + 1) * a_size2dTable;
+  const int dxy1 = zOffset + floorY * a_width + floorX, dxy3 = zOffset + (floorY + 1) * a_width + floorX, dxy2 = dxy1 + 1, dxy4 = dxy3 + 1;
+  const int dxy5 = zOffset2 + floorY * a_width + floorX, dxy7 = zOffset2 + (floorY + 1) * a_width + floorX, dxy6 = dxy5 + 1, dxy8 = dxy7 + 1;
+  const float dx = x - (float)floorX, dy = y - (float)floorY, dz = z - (float)floorZ;
+  const float mult1 = (1.0f - dx) * (1.0f - dy), mult2 = dx * (1.0f - dy), mult3 = dy * (1.0f - dx), mult4 = dx * dy;
+  if (floorY >= 0 && floorX >= 0 && floorY <= a_height - 2 && floorX <= a_width - 2) {
+    const float plane1 = (float)a_inData[dxy1] * mult1 + (float)a_inData[dxy2] * mult2 + (float)a_inData[dxy3] * mult3 + (float)a_inData[dxy4] * mult4;
+    const float plane2 = (float)a_inData[dxy5] * mult1 + (float)a_inData[dxy6] * mult2 + (float)a_inData[dxy7] * mult3 + (float)a_inData[dxy8] * mult4;
+    return plane1 + dz * (plane2 - plane1);
+  }
+  return 1.0f;
+}
+static f3 multiscatter(float Ess, f3 color) {   /* 1.0f + color * (1.0f - Ess) / fmax(Ess, 1e-6f), component-wise */
+  const float k = 1.0f - Ess, d = fmaxf(Ess, 1e-6f);
+  return v3(1.0f + (color.x * k) / d, 1.0f + (color.y * k) / d, 1.0f + (color.z * k) / d);
+}
+static f3 GetMultiscatteringFrom2dTable(const OrcScene* s, float roughness, float dotNV, f3 color) {
+  const uint16_t* msTable = (const uint16_t*)(s->globals + G_ESS_GGX_TABLE);
+  const float Ess = BilinearFrom2dTable(msTable, dotNV * 64.0f, roughness * 64.0f, 64, 64) * (1.0f / 65535.0f);
+  return multiscatter(Ess, color);
+}
+static f3 GetMultiscatteringFrom3dTable(const OrcScene* s, float a_roughness, float a_dotNV, float a_ior, f3 a_color) {
+  if (a_ior >= 0.4166f && a_ior <= 2.4f) {
+    const uint16_t* msTable = (const uint16_t*)(s->globals + G_ESS_TRANSP_TABLE);
+    const float iorNormal = (a_ior - 0.4166f) / (2.4f - 0.4166f);
+    const float Ess = BilinearFrom3dTable(msTable, a_dotNV * 64.0f, a_roughness * 64.0f, iorNormal * 64.0f, 64, 64, 64, 64 * 64) * (1.0f / 65536.0f);
+    return multiscatter(Ess, a_color);
+  }
+  return v3(1.0f, 1.0f, 1.0f);
+}
 /* ---- thin glass, ref: cmaterial.h:496-556.  thinglassEvalBxDF / EvalPDF return 0 (:510-520). */
 static float transparencyGloss(const float* m, int multOffs, int texMatrixOffs, f2 tc, const OrcScene* s) {   /* :496-505, :610-618 */
   const f3 glossColor = sample2DExt(as_int(m[texMatrixOffs]), tc, m, s);
@@ -866,8 +915,7 @@ static void ThinglassSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ra
 }
 /* ---- glass, ref: cmaterial.h:684-714 myRefractGgx, :775-882 GlassGGXSampleAndEvalBRDF (the one :2298-2301 dispatches to),
  *      :1214-1252 SmithGGXMasking / GgxVndf / SmithGGXMaskingShadowing.  glassEvalBxDF / EvalPDF return 0 (:622-630).
- *      The multi-scattering table lookup (:858-860) needs PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER on the glass node, which
- *      TransparentMaterialFromHydraMtl (PlainMaterialConverter.cpp:1151-1199) never sets: not restated. */
+ */
 typedef struct { f3 ray_dir; int success; float eta; } RefractResult;
 static RefractResult myRefractGgx(f3 ray_dir, f3 a_normal, float a_matIOR, float a_outsideIOR) {
   RefractResult res;
@@ -919,6 +967,7 @@ static void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray
   const f3 normal2 = a_hitFromInside ? scale3(a_normal, -1.0f) : a_normal;
   int spec = 1;
   float Pss = 1.0f;
+  f3 Pms = v3(1.0f, 1.0f, 1.0f);
   out->pdf = 1.0f;
   RefractResult refrData = myRefractGgx(ray_dir, normal2, IOR, 1.0f);
   if (gloss < 0.999f) {
@@ -949,16 +998,102 @@ static void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray
     const float G1 = SmithGGXMasking(dotNV, roughSqr);
     const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
     Pss = G2 / fmaxf(G1, 1e-6f);
+    if (matFlags(m) & MF_ENERGY_FIX) Pms = GetMultiscatteringFrom3dTable(s, roughness, dotNV, 1.0f / eta, color);
   }
   const float cosThetaOut = dot3(refrData.ray_dir, a_normal);
   const float cosMult = 1.0f / fmaxf(fabsf(cosThetaOut), 1e-6f);
   out->direction = refrData.ray_dir;
   const float adjointBtdfMult = a_isFwdDir ? 1.0f : (refrData.eta * refrData.eta);
-  if (refrData.success) out->color = scale3(scale3(scale3(color, adjointBtdfMult), Pss), cosMult);
-  else out->color = scale3(scale3(v3(1.0f, 1.0f, 1.0f), Pss), cosMult);
+  if (refrData.success) out->color = scale3(mul3(scale3(scale3(color, adjointBtdfMult), Pss), Pms), cosMult);
+  else out->color = scale3(mul3(scale3(v3(1.0f, 1.0f, 1.0f), Pss), Pms), cosMult);
   out->flags = spec ? (RAY_EVENT_S | RAY_EVENT_T) : (RAY_EVENT_G | RAY_EVENT_T);
   if (refrData.success && cosThetaOut >= -1e-6f) out->color = v3(0, 0, 0);
   else if (!refrData.success && cosThetaOut < 1e-6f) out->color = v3(0, 0, 0);
+}
+
+/* ---- GGX reflection, ref: cmaterial.h:1197-1210 ggxGlosiness, :1285-1291 GGX_Distribution, :1317-1344 ggx2EvalPDF,
+ *      :1346-1381 ggxEvalBxDF, :1454-1520 GGXSample2AndEvalBRDF (the forms :2288-2291 and :2491-2497 dispatch to) */
+static float ggxGlosiness(const float* m, f2 tc, const OrcScene* s) {
+  if ((uint32_t)as_int(m[GGX_GLOSINESS_TEXID]) != INVALID_TEXTURE) {
+    const f3 glossColor = sample2DExt(as_int(m[GGX_GLOSINESS_TEXMATRIXID]), tc, m, s);
+    return clampf(m[GGX_GLOSINESS] * fmaxf(glossColor.x, fmaxf(glossColor.y, glossColor.z)), 0.0f, 0.99f);
+  }
+  return m[GGX_GLOSINESS];
+}
+static float GGX_Distribution(float cosThetaNH, float alpha) {
+  const float alpha2 = alpha * alpha;
+  const float NH_sqr = clampf(cosThetaNH * cosThetaNH, 0.0f, 1.0f);
+  const float den = NH_sqr * alpha2 + (1.0f - NH_sqr);
+  return alpha2 / fmaxf(M_PI_F * den * den, 1e-6f);
+}
+static float ggx2EvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const float dotNV = dot3(n, v), dotNL = dot3(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 1.0f;
+  const float gloss = ggxGlosiness(m, tc, s);
+  const float roughness = 1.0f - gloss;
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize3(add3(v, l));
+  const float dotNH = dot3(n, h), dotHV = dot3(h, v);
+  const float G1 = SmithGGXMasking(dotNV, roughSqr);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  const float Dv = D * G1 * dotHV / fmaxf(dotNV, 1e-6f);
+  const float jacob = 1.0f / fmaxf(4.0f * dotHV, 1e-6f);
+  return Dv * jacob;
+}
+static f3 ggxEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const float dotNV = dot3(n, v), dotNL = dot3(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return v3(0.0f, 0.0f, 0.0f);
+  const f3 texColor = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(matColor(m), texColor), 0.0f, 1.0f);
+  const float gloss = ggxGlosiness(m, tc, s);
+  const float roughness = 1.0f - gloss;
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize3(add3(v, l));
+  const float dotNH = dot3(n, h);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  const float G = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+  const float Pss = D * G / fmaxf(4.0f * dotNV * dotNL, 1e-6f);
+  f3 Pms = v3(1, 1, 1);
+  if (matFlags(m) & MF_ENERGY_FIX) Pms = GetMultiscatteringFrom2dTable(s, roughness, dotNV, color);
+  return mul3(scale3(color, Pss), Pms);
+}
+static void GGXSample2AndEvalBRDF(const float* m, float a_r1, float a_r2, f3 ray_dir, f3 a_normal, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 texColor = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 color = clamp3(mul3(matColor(m), texColor), 0.0f, 1.0f);
+  const float gloss = ggxGlosiness(m, tc, s);
+  const float roughness = 1.0f - gloss;
+  const float roughSqr = roughness * roughness;
+  f3 nx, ny;
+  const f3 nz = a_normal;
+  CoordinateSystem(nz, &nx, &ny);
+  float Pss = 1.0f;
+  f3 Pms = v3(1.0f, 1.0f, 1.0f);
+  const f3 wo = v3(-dot3(ray_dir, nx), -dot3(ray_dir, ny), -dot3(ray_dir, nz));
+  const f3 wh = GgxVndf(wo, roughSqr, a_r1, a_r2);
+  const f3 wi = sub3(scale3(wh, 2.0f * dot3(wo, wh)), wo);
+  const f3 newDir = normalize3(add3(add3(scale3(nx, wi.x), scale3(ny, wi.y)), scale3(nz, wi.z)));
+  const f3 v = scale3(ray_dir, -1.0f), l = newDir;
+  const float dotNV = dot3(a_normal, v), dotNL = dot3(a_normal, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) {
+    Pss = 0.0f;
+    out->pdf = 1.0f;
+  } else {
+    const f3 h = normalize3(add3(v, l));
+    const float dotNH = dot3(a_normal, h), dotHV = dot3(h, v);
+    const float D = GGX_Distribution(dotNH, roughSqr);
+    const float G1 = SmithGGXMasking(dotNV, roughSqr);
+    const float G2 = SmithGGXMaskingShadowing(dotNL, dotNV, roughSqr);
+    Pss = D * G2 / fmaxf(4.0f * dotNV, 1e-6f);
+    const float Dv = D * G1 * dotHV / fmaxf(dotNV, 1e-6f);
+    const float jacob = 1.0f / fmaxf(4.0f * dotHV, 1e-6f);
+    out->pdf = Dv * jacob;
+    if (matFlags(m) & MF_ENERGY_FIX) Pms = GetMultiscatteringFrom2dTable(s, roughness, dotNV, color);
+  }
+  out->direction = newDir;
+  const f3 c = mul3(scale3(color, Pss), Pms);
+  const float d = fmaxf(dotNL, 1e-6f);
+  out->color = v3(c.x / d, c.y / d, c.z / d);
+  out->flags = (gloss >= 0.99f) ? RAY_EVENT_S : RAY_EVENT_G;
 }
 
 /* ---- blend, ref: cglobals.h:1880-1926 fresnel helpers, cmaterial.h:2008-2137 */
@@ -1044,6 +1179,7 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_MIRROR: MirrorSampleAndEvalBRDF(m, ray_dir, n, sh->texCoord, s, out); break;
     case MT_LAMBERT: LambertSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
     case MT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_GGX: GGXSample2AndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, /*a_isFwdDir*/ 0, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false */
     default: break;
@@ -1077,6 +1213,11 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const
       r.brdf = scale3(phongEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
       r.pdfFwd = phongEvalPDF(m, sc->l, sc->v, sc->n, sc->tc, s);
       r.pdfRev = phongEvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
+      break;
+    case MT_GGX:
+      r.brdf = scale3(ggxEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
+      r.pdfFwd = ggx2EvalPDF(m, sc->l, sc->v, sc->n, sc->tc, s);
+      r.pdfRev = ggx2EvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
       break;
     case MT_MIRROR: break;   /* mirrorEvalBxDF / PDF return 0, cmaterial.h:395-403 */
     case MT_THIN_GLASS: case MT_GLASS: break;   /* thinglass / glass EvalBxDF and EvalPDF return 0, cmaterial.h:510-520, 622-630 */

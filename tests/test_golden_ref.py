@@ -55,7 +55,7 @@ def check_shade_point(out, ref, frac=0.002):
     assert valid.mean() > 0.3
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
@@ -96,6 +96,10 @@ def test_oracle_matches_reference_functions(name, built):
     # the directional light's falloff (clight.h:892-912) computes sin = sqrt(1 - cos^2) with cos close to 1: a last-bit
     # difference in the normalised vector moves the attenuation by ~1e-3 inside the 30..40 m penumbra ring, which crosses
     # the corners of this hall -- same draws, same ray counts, radiance off by 2e-4..2e-3 on 0.5 % of the paths
-    limit = 0.01 if name == "atrium_lights_small" else 0.005
+    # GGX_Distribution (cmaterial.h:1285-1291) computes den = NH^2 * a^2 + (1 - NH^2) with a^2 = 5e-4 for the glossy lobes of the
+    # ggx hall: next to the peak 1 - NH^2 keeps few significant bits, so a last-bit difference in the normalised half
+    # vector (OpenCL normalize vs sqrtf) moves D, and with it the sampled colour, by 1e-3..1e-2 -- same draws on every
+    # path, same ray counts, 0.7 % of the paths off by more than 2e-4, image mean within 1e-4
+    limit = 0.01 if name in ("atrium_lights_small", "atrium_ggx_small") else 0.005
     assert bad.mean() < limit, bad.mean()
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()

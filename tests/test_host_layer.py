@@ -241,3 +241,23 @@ def test_transparency_layers_pack_like_the_reference_converter():
     assert mi[n, 0] == 9 and mi[tg, 0] == 3 and mi[n + mi[n, 17], 0] == 7 and (mi[n, 15] & 8)
     assert mi[tg, 13] == 2 and mi[tg, 14] == 5 and abs(m[tg, 16] - 0.85) < 1e-6 and m[tg, 15] == 0.0
     assert mi[n, 13] == 2
+
+
+def test_ggx_reflection_packs_like_the_reference_converter():
+    """GGXMaterial, PlainMaterialConverter.cpp:635-680, chosen by brdf_type="ggx" (:1132-1133)"""
+    from conftest import scene_path
+    from hydracore_amd import HostScene
+    sc = HostScene(scene_path("atrium_ggx_small"), 96, 54, trace_depth=8, enable_dof=0, use_hip=False)   # unpatched buffers
+    assert sc.unsupported() == 0, sc.log()
+    b = sc.buffers()
+    g, m = b["globals"], b["materials"].reshape(-1, 192)
+    mi = m.view(np.int32)
+    table = g[g[G_MAT_TABLE]:g[G_MAT_TABLE] + 12]
+    n = table[9] * 4 // 192                                          # Fresnel blend(GGX, lambert)
+    gx = n + mi[n, 16]
+    assert mi[n, 0] == 9 and mi[gx, 0] == 15 and mi[n + mi[n, 17], 0] == 7 and (mi[n, 15] & 1)
+    assert abs(m[gx, 16] - 0.7) < 1e-6 and abs(m[gx, 19] - 2.5) < 1e-6 and m[gx, 15] == 0.0   # gloss, fresnel IOR, cosPower
+    assert mi[gx, 13] == -2 and mi[gx, 17] == -2 and mi[gx, 1] == 2                              # no textures, CAST_CAUSTICS
+    np.testing.assert_allclose(m[gx, 10:13], 0.8)
+    assert (g[1268:1268 + 2048] == 0).all()                          # the front end has no energy table data: zeros
+    sc.close()

@@ -82,6 +82,16 @@ def gpu_atrium_glass(built):
     return core, b, make_oracle(b)
 
 
+@pytest.fixture(scope="module")
+def gpu_atrium_ggx(built):
+    """the glass hall with GGX reflection lobes; two nodes read the (synthetic) multi-scattering tables of the globals header"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_ggx_small", 96, 54, 8)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
 def test_native_library_is_the_one_running(gpu224):
     core, _, _ = gpu224
     name = core.device_name()
@@ -178,7 +188,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -194,7 +204,7 @@ def test_light_and_material_functions_at_shading_points(fix, request):
     check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -215,7 +225,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -359,13 +369,13 @@ def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
 
 
 def test_materials_the_layer_does_not_shade_are_refused(gpu224):
-    """a GGX reflection node (class 15), a normal-mapped node or a glass node asking for the multi-scattering table would
-    come out black from the device's leaf dispatch: the layer refuses to render instead"""
+    """a Beckmann reflection node (class 13) or a normal-mapped node would come out black / flat from the device's leaf
+    dispatch: the layer refuses to render instead"""
     from hydracore_amd import HipCore, HydraError
     _, b, _ = gpu224
     g = b["globals"]
     root = g[g[219] + 1] * 4                                          # material 1 = blend(phong, lambert): its phong child
-    for word, value, what in ((0, 15, "BxDF class 15"), (83, 1, "normal map")):
+    for word, value, what in ((0, 13, "BxDF class 13"), (83, 1, "normal map")):
         bad = dict(b)
         m = b["materials"].copy().view(np.int32)
         m[root + 192 + word] = value

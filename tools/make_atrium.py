@@ -178,8 +178,10 @@ def main():
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
                     "reflection + glass + diffuse, curtains = textured glossy thin glass over diffuse")
+    ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
+    refl = "ggx" if args.ggx else "phong"
     s = np.sqrt(args.scale)
     rng = np.random.default_rng(SEED)
     out = args.out
@@ -225,16 +227,19 @@ def main():
                    '<transparency><color val="0.9 0.97 0.92" /><glossiness val="1" /><thin_walled val="0" /><fog_color val="1 1 1" /><fog_multiplier val="0" /><ior val="1.5" /></transparency>',
                 2: '<transparency><color val="0.85 0.9 0.95" /><glossiness val="0.7" /><thin_walled val="0" /><ior val="1.33" /></transparency>',
                 1: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
-                   '<reflectivity brdf_type="phong"><color val="0.3 0.3 0.3" /><glossiness val="0.8" /><fresnel val="1" /><fresnel_ior val="1.6" /></reflectivity>'
-                   '<transparency><color val="0.5 0.5 0.5" /><glossiness val="1" /><thin_walled val="0" /><ior val="1.6" /></transparency>' % c,
+                   '<reflectivity brdf_type="%s"><color val="0.3 0.3 0.3" /><glossiness val="0.8" /><fresnel val="1" /><fresnel_ior val="1.6" /></reflectivity>'
+                   '<transparency><color val="0.5 0.5 0.5" /><glossiness val="1" /><thin_walled val="0" /><ior val="1.6" /></transparency>' % (c, refl),
                 6: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
                    '<transparency><color val="0.6 0.6 0.6"><texture id="2" type="texref" /></color><glossiness val="0.85" /><thin_walled val="1" /><ior val="1.5" /></transparency>' % c,
             }[mid]
             xml.append('  <material id="%d" name="m%d" type="hydra_material">%s</material>' % (mid, mid, body))
-        elif mid in (1, 8):      # lambert + phong blend
+        elif mid in (1, 8):      # lambert + phong (or GGX) blend
             gloss = 0.5 if mid == 1 else 0.85
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
-                       '<reflectivity brdf_type="phong"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" /></reflectivity></material>' % (mid, mid, c, gloss))
+                       '<reflectivity brdf_type="%s"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" /></reflectivity></material>' % (mid, mid, c, refl, gloss))
+        elif args.ggx and mid == 9:
+            xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
+                       '<reflectivity brdf_type="ggx"><color val="0.8 0.8 0.8" /><glossiness val="0.7" /><fresnel val="1" /><fresnel_ior val="2.5" /></reflectivity></material>' % (mid, mid, c))
         elif mid in (0, 4, 6):  # textured lambert
             tex = {0: 1, 4: 1, 6: 2}[mid]
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" />'
