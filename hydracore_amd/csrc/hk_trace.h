@@ -69,15 +69,16 @@ struct HkStack {
 // kernels are bound by exactly that path, so on the device both arrays are raw buffers.
 #ifdef HK_HOST_EMU
 struct BvhView {
-  const float4* nodes; const float4* tris;
+  const float4* nodes; const float4* tris; bool leafEnc;
   HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
   HK_DEV_MEMBER float4 tri(int index) const { return tris[index]; }
 };
-HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned) { BvhView v; v.nodes = nodes; v.tris = tris; return v; }
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; return v; }
 #else
 typedef float hk_v4f __attribute__((ext_vector_type(4)));
 struct BvhView {
   __amdgpu_buffer_rsrc_t nodes, tris;
+  bool leafEnc;   // triangle-leaf links of the device copy carry the triangle count (see HK_LEAF_COUNT_SHIFT)
   HK_DEV_MEMBER float4 node(int quad, int piece) const {
     const hk_v4f v = __builtin_bit_cast(hk_v4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, uint32_t(quad) * 128u + uint32_t(piece) * 16u, 0, 0));
     return make_float4(v.x, v.y, v.z, v.w);
@@ -88,19 +89,31 @@ struct BvhView {
   }
 };
 // both sizes come from kernel arguments (wave-uniform), < 4 GiB each (checked by upload_bvh)
-HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes) {
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes, bool leafEnc = false) {
   BvhView v;
+  v.leafEnc = leafEnc;
   v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
   v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
   return v;
 }
 #endif
 
+// Device copy only (hydra_hip_upload_bvh): a link to a triangle leaf whose list starts right behind its header, holds 1..15
+// triangles and sits below float4 index 2^27 carries the count in bits 27..30, so the leaf test can issue its triangle loads
+// without first waiting for the header (one dependent memory round trip less per leaf visit).  Count 0 = read the header.
+#define HK_LEAF_COUNT_SHIFT 27
+#define HK_LEAF_OFFSET_MASK 0x07ffffff
+
 template <bool ANYHIT, bool COUNT>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,
                                   const BvhView& bv, int instId, bool useInstId, TravCounters& cnt) {
-  const float4 hdr = bv.tri(leaf_offset);
-  const int first = as_int(hdr.x), count = as_int(hdr.y);
+  int first, count;
+  const int enc = bv.leafEnc ? ((leaf_offset >> HK_LEAF_COUNT_SHIFT) & 15) : 0;
+  if (enc != 0) { first = (leaf_offset & HK_LEAF_OFFSET_MASK) + 1; count = enc; }
+  else {
+    const float4 hdr = bv.tri(bv.leafEnc ? (leaf_offset & HK_LEAF_OFFSET_MASK) : leaf_offset);
+    first = as_int(hdr.x); count = as_int(hdr.y);
+  }
   const int end = first + count * 3;
   if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; }
   for (int a = first; a < end; a += 3) {

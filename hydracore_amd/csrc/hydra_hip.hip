@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(S
   const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
   const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const float4 o = org4[i];
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_d
   uint32_t* fetchCounter = fetchCounters + it.seg * HK_CSTRIDE;
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes);
+  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
   TravState t;
   TravCounters c = {0, 0, 0, 0};
   int rayIdx = -1;
@@ -674,6 +674,7 @@ struct hydra_hip_ctx {
   int treesNum = 0, instNum = 0;
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
+  bool leafEnc[4] = {false, false, false, false};   // device node copy of tree i has triangle counts in its leaf links
   bool matDirty = true;              // material arena or material table changed since validate_materials last passed
   std::vector<float> hostMaterials;  // host copy of the material arena and table, for validate_materials only
   std::vector<int32_t> hostMatTable;
@@ -685,6 +686,7 @@ struct hydra_hip_ctx {
   int N = 0;                         // owned pixels = live paths at bounce 0
   int streamsWanted = 0;             // option "samples_in_flight": samples per pixel traced concurrently, 0 = by resolution
   int streams = 1;
+  int leafEncWanted = 1;             // option "leaf_count_links": read by the next upload_bvh
   int streamMajor = 1;               // option "path_order": 1 = stream-major (default), 0 = pixel-major (samples of a pixel share a wave); measured equal
   DevBuf ownedPixels;                // the N owned pixels in slot order (k_accumulate)
   int nsegWanted = 8;                // option "queue_segments"
@@ -768,6 +770,7 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.pdfStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_PDFS].p);
   s.bvh = static_cast<const float4*>(c->bvhNodes[0].p);
   s.bvhBytes = unsigned(c->bvhNodeBytes[0]);
+  s.leafEnc = c->leafEnc[0] ? 1 : 0;
   s.trisBytes = unsigned(c->bvhTriBytes[0]);
   s.tris = static_cast<const float4*>(c->bvhTris[0].p);
   s.haveInst = c->haveInst[0];
@@ -1071,6 +1074,7 @@ int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_
     c->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (const char* e = getenv("HYDRA_HIP_TRACE_MODE")) c->traceMode = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("HYDRA_HIP_LEAF_COUNT_LINKS")) c->leafEncWanted = atoi(e) ? 1 : 0;
   if (const char* e = getenv("HYDRA_HIP_TRACE_MIN_ACTIVE")) c->traceMinActive = std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("HYDRA_HIP_TRACE_BLOCKS_PER_CU")) c->traceBlocksPerCU = std::max(1, std::min(64, atoi(e)));
   c->stream = nullptr;   // the null stream: ordered with torch's default stream and with plain hipMemcpy
@@ -1187,6 +1191,51 @@ int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, siz
   }
   return dev_upload(c, c->storage[kind], data, bytes);
 }
+// Device copy of the node array: put the triangle count of every triangle leaf into bits 27..30 of the link that points at it
+// (hk_trace.h, HK_LEAF_COUNT_SHIFT).  Which leaves are triangle leaves follows from walking the tree the way BVH4InstTraverse
+// does (ctrace.h:841-1062): below the root every leaf is an instance quad when the tree is instanced, and the quad an
+// instance names (or a leaf link stored there directly) starts an object tree whose leaves are triangle lists.
+// Returns false (and leaves `nodes` untouched) when an index does not fit next to the count.
+static bool encode_leaf_counts(std::vector<HydraBVHNode>& nodes, const float* tri_f4, int tri_f4_num, bool haveInst) {
+  const size_t quads = nodes.size() / 4;
+  if (quads >= (size_t(1) << HK_LEAF_COUNT_SHIFT) || size_t(tri_f4_num) >= (size_t(1) << HK_LEAF_COUNT_SHIFT)) return false;
+  std::vector<HydraBVHNode> out = nodes;
+  auto encode = [&](uint32_t& link) {   // link has the leaf bit and names a triangle list header
+    const uint32_t off = link & 0x7fffffffu;
+    if (off + 1 >= uint32_t(tri_f4_num)) return;
+    int32_t hdr[2];
+    memcpy(hdr, tri_f4 + size_t(off) * 4, 8);
+    if (hdr[0] == int32_t(off) + 1 && hdr[1] >= 1 && hdr[1] <= 15 && size_t(hdr[0]) + size_t(hdr[1]) * 3 <= size_t(tri_f4_num))
+      link = HYDRA_BVH_LEAF | (uint32_t(hdr[1]) << HK_LEAF_COUNT_SHIFT) | off;
+  };
+  std::vector<uint8_t> seen(quads * 2, 0);   // [quad][level]
+  std::vector<std::pair<uint32_t, int>> stack;
+  stack.push_back({1u, haveInst ? 0 : 1});   // level 0 = scene tree of an instanced BVH, 1 = tree whose leaves are triangles
+  while (!stack.empty()) {
+    const uint32_t q = stack.back().first;
+    const int level = stack.back().second;
+    stack.pop_back();
+    if (q >= quads || seen[size_t(q) * 2 + level]) continue;
+    seen[size_t(q) * 2 + level] = 1;
+    for (int k = 0; k < 4; k++) {
+      const HydraBVHNode& n = nodes[size_t(q) * 4 + k];
+      if (n.leftOffsetAndLeaf == HYDRA_BVH_INVALID && n.escapeIndex == HYDRA_BVH_INVALID) continue;
+      const uint32_t off = n.leftOffsetAndLeaf & 0x7fffffffu;
+      if (!(n.leftOffsetAndLeaf & HYDRA_BVH_LEAF)) { stack.push_back({off, level}); continue; }
+      if (level == 1) { encode(out[size_t(q) * 4 + k].leftOffsetAndLeaf); continue; }
+      if (off >= quads) continue;                                  // instance quad: word 3 of its first float4 = where the object tree starts
+      const uint32_t next = nodes[size_t(off) * 4].leftOffsetAndLeaf;
+      if (next & HYDRA_BVH_LEAF) {
+        if (!seen[size_t(off) * 2 + 1]) { seen[size_t(off) * 2 + 1] = 1; encode(out[size_t(off) * 4].leftOffsetAndLeaf); }
+      } else stack.push_back({next, 1});
+    }
+  }
+  // a quad reached both as part of the scene tree and of an object tree would need two readings of the same link
+  for (size_t q = 0; q < quads; q++) if (seen[q * 2] && seen[q * 2 + 1]) return false;
+  nodes.swap(out);
+  return true;
+}
+
 int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes, int nodes_num, const float* tri_f4, int tri_f4_num,
                          const uint32_t* alpha, int alpha_num, int have_inst) {
   if (!c || tree < 0 || tree >= 4 || !nodes || nodes_num < 8 || !tri_f4 || tri_f4_num <= 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: bad arguments");
@@ -1196,7 +1245,9 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   // the traversal kernels address both arrays as raw buffers with 32-bit byte offsets
   if (size_t(nodes_num) * sizeof(HydraBVHNode) >= (size_t(1) << 32) || size_t(tri_f4_num) * 16 >= (size_t(1) << 32))
     return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: node or triangle arrays of 4 GiB and more are not supported");
-  int rc = dev_upload(c, c->bvhNodes[tree], nodes, size_t(nodes_num) * sizeof(HydraBVHNode));
+  std::vector<HydraBVHNode> devNodes(nodes, nodes + nodes_num);
+  c->leafEnc[tree] = (c->leafEncWanted != 0) && encode_leaf_counts(devNodes, tri_f4, tri_f4_num, have_inst != 0);
+  int rc = dev_upload(c, c->bvhNodes[tree], devNodes.data(), size_t(nodes_num) * sizeof(HydraBVHNode));
   if (rc) return rc;
   rc = dev_upload(c, c->bvhTris[tree], tri_f4, size_t(tri_f4_num) * 16);
   if (rc) return rc;
@@ -1424,6 +1475,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
   else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
   else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
+  else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
   else if (n == "fused_bounce") {
     if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "fused_bounce: 0 or 1");
     if (value != c->fusedBounce) { (void)hipStreamSynchronize(c->stream); c->fusedBounce = value; c->stateAllocated = false; }
@@ -1452,6 +1504,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "queue_segments") *value = c->nsegWanted;
   else if (n == "fused_bounce") *value = c->fusedBounce;
   else if (n == "path_order") *value = c->streamMajor;
+  else if (n == "leaf_count_links") *value = c->leafEncWanted;
   else if (n == "samples_in_flight") *value = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(size_t(c->w) * c->h);
   else return fail(c, HYDRA_HIP_EINVAL, "get_option: unknown option " + n);
   return HYDRA_HIP_OK;

@@ -357,6 +357,30 @@ def test_tuning_options_do_not_change_the_image(fix, request):
             core.set_option(k, v)
 
 
+@pytest.mark.parametrize("name,w,h,depth", [("test_224", 96, 96, 4), ("atrium_small", 96, 54, 5)])
+def test_leaf_count_links_do_not_change_hits_or_counters(built, name, w, h, depth):
+    """the device copy of the node array carries triangle counts in its leaf links (hk_trace.h): hits, per-ray visit counters,
+    shadow answers and the image are bit-identical with the plain copy (instanced and non-instanced tree walk)"""
+    from hydracore_amd import HipCore
+    _, b = host_scene(name, w, h, depth)
+    rk = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0) if name.startswith("atrium") else {}
+    pos4, dir4 = random_rays(30000, 77, **rk)
+    tfar = np.random.default_rng(4).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
+    outs = []
+    for links in (0, 1):
+        core = HipCore(w, h, device=0)
+        core.set_option("leaf_count_links", links)
+        core.upload_scene(b)
+        hits, cnt = core.stage_trace(pos4, dir4, counters=True)
+        vis = core.stage_shadow_trace(pos4, dir4, tfar)
+        core.init_path_tracing(5)
+        core.trace_pass(2)
+        outs.append((hits.copy(), cnt.copy(), vis.copy(), core.hdr_image(w, h).copy()))
+        core.close()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all() and (outs[0][2] == outs[1][2]).all()
+    assert (outs[0][3].view(np.uint32) == outs[1][3].view(np.uint32)).all()
+
+
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     from hydracore_amd import HipCore, HydraError
     core, b, _ = gpu224
