@@ -109,6 +109,9 @@ struct SceneDev {
   const float4* pdfStorage;
   const float4* bvh;           // tree 0: 2 float4 per node, 8 per quad
   unsigned      bvhBytes;      // size of the node array (< 4 GiB: the traversal kernels address it as a raw buffer)
+  const float4* bvhTop;        // second node copy whose links to the hottest quads are tagged (hk_trace.h, HK_TOP_FLAG); nullptr = none
+  const int*    topQuads;      // quad index of each cached slot, slot 0 = the root
+  int           topCount;      // 0..HK_TOP_QUADS
   int           leafEnc;       // 1: triangle-leaf links of the device node copy carry the triangle count (hk_trace.h, HK_LEAF_COUNT_SHIFT)
   const float4* tris;          // tree 0 triangle lists
   unsigned      trisBytes;

@@ -13,12 +13,27 @@
 // spill to scratch, keeping the reference's 80-entry semantics without paying for them in LDS occupancy.
 #pragma once
 #include "hk_common.h"
+#ifndef HK_HOST_EMU
+typedef float hk_v4f_t __attribute__((ext_vector_type(4)));
+#endif
 
 #define HK_STACK_SIZE 80
 #ifndef HK_LDS_DEPTH
 #define HK_LDS_DEPTH 24
 #endif
+#ifndef HK_TRACE_BLOCK
 #define HK_TRACE_BLOCK 128
+#endif
+// LDS copy of the quads rays visit most (persistent traversal kernels only): HK_TOP_QUADS quads, HK_TOP_STRIDE float4 apart
+// (one float4 of padding so that lanes reading the same piece of different quads spread over the banks).  In the node copy
+// those kernels walk, an inner link to cached quad `slot` reads HK_TOP_FLAG | slot (bit 31 clear: not a leaf).
+#ifndef HK_TOP_QUADS
+#define HK_TOP_QUADS 21
+#endif
+#ifndef HK_TOP_STRIDE
+#define HK_TOP_STRIDE 9
+#endif
+#define HK_TOP_FLAG 0x40000000
 
 struct TravCounters { uint32_t quads, insts, tris, leaves; };
 
@@ -45,8 +60,10 @@ HK_DEV float2 RayBox(f3 o, f3 inv, float4 lo4, float4 hi4) {
 // immediate stride (a generic int* makes the compiler emit flat_* accesses plus 64-bit address arithmetic).
 #ifdef HK_HOST_EMU
 typedef int hk_lds_int;
+typedef float4 hk_lds_f4;
 #else
 typedef __attribute__((address_space(3))) int hk_lds_int;
+typedef __attribute__((address_space(3))) hk_v4f_t hk_lds_f4;
 #endif
 
 struct HkStack {
@@ -69,16 +86,22 @@ struct HkStack {
 // kernels are bound by exactly that path, so on the device both arrays are raw buffers.
 #ifdef HK_HOST_EMU
 struct BvhView {
-  const float4* nodes; const float4* tris; bool leafEnc;
+  const float4* nodes; const float4* tris; bool leafEnc; const hk_lds_f4* top;
+  HK_DEV_MEMBER float4 topPiece(int link, int piece) const { return top[(link & 0xff) * HK_TOP_STRIDE + piece]; }
   HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
   HK_DEV_MEMBER float4 tri(int index) const { return tris[index]; }
 };
-HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; return v; }
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; return v; }
 #else
 typedef float hk_v4f __attribute__((ext_vector_type(4)));
 struct BvhView {
   __amdgpu_buffer_rsrc_t nodes, tris;
   bool leafEnc;   // triangle-leaf links of the device copy carry the triangle count (see HK_LEAF_COUNT_SHIFT)
+  const hk_lds_f4* top;   // LDS copy of the hottest quads (trav_run<.., TOPCACHE = true> only)
+  HK_DEV_MEMBER float4 topPiece(int link, int piece) const {
+    const hk_v4f_t v = top[(link & 0xff) * HK_TOP_STRIDE + piece];
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
   HK_DEV_MEMBER float4 node(int quad, int piece) const {
     const hk_v4f v = __builtin_bit_cast(hk_v4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, uint32_t(quad) * 128u + uint32_t(piece) * 16u, 0, 0));
     return make_float4(v.x, v.y, v.z, v.w);
@@ -92,6 +115,7 @@ struct BvhView {
 HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes, bool leafEnc = false) {
   BvhView v;
   v.leafEnc = leafEnc;
+  v.top = nullptr;
   v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
   v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
   return v;
@@ -147,23 +171,29 @@ struct TravState {
   int top, left, instDeep, instTop, instId;
   bool searching;
 };
-HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit) {
+HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int rootLink = 1) {
   t.pos = pos; t.dir = dir; t.inv = SafeInverse(dir);
   t.opos = mk3(0, 0, 0); t.odir = mk3(0, 0, 0); t.oinv = mk3(0, 0, 0);
   t.hit = hit;
-  t.top = 0; t.left = 1; t.instDeep = 0; t.instTop = 0; t.instId = -1;
+  t.top = 0; t.left = rootLink; t.instDeep = 0; t.instTop = 0; t.instId = -1;
   t.searching = true;
 }
 
 // returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
 // traversing (minActive <= 0: never suspend).
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false>
 HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
                      const float t_rayMin, HkStack& stack, TravCounters& cnt, const int minActive) {
   while (t.top >= 0) {
     while (t.searching) {
-      const float4 n0a = bv.node(t.left, 0), n0b = bv.node(t.left, 1), n1a = bv.node(t.left, 2), n1b = bv.node(t.left, 3);
-      const float4 n2a = bv.node(t.left, 4), n2b = bv.node(t.left, 5), n3a = bv.node(t.left, 6), n3b = bv.node(t.left, 7);
+      float4 n0a, n0b, n1a, n1b, n2a, n2b, n3a, n3b;
+      if (TOPCACHE && (t.left & HK_TOP_FLAG)) {   // one of the hottest quads: 8 LDS reads instead of 8 trips through the texture addresser
+        n0a = bv.topPiece(t.left, 0); n0b = bv.topPiece(t.left, 1); n1a = bv.topPiece(t.left, 2); n1b = bv.topPiece(t.left, 3);
+        n2a = bv.topPiece(t.left, 4); n2b = bv.topPiece(t.left, 5); n3a = bv.topPiece(t.left, 6); n3b = bv.topPiece(t.left, 7);
+      } else {
+        n0a = bv.node(t.left, 0); n0b = bv.node(t.left, 1); n1a = bv.node(t.left, 2); n1b = bv.node(t.left, 3);
+        n2a = bv.node(t.left, 4); n2b = bv.node(t.left, 5); n3a = bv.node(t.left, 6); n3b = bv.node(t.left, 7);
+      }
       if (COUNT) cnt.quads++;
       int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
 #ifdef HK_HOST_EMU

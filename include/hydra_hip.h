@@ -105,7 +105,9 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * "shade_blocks_per_cu", "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
  * (default 8); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
  * "path_order" 1 = stream-major slots (default), 0 = pixel-major; "leaf_count_links" 1 = the device copy of the node array carries
- * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
+ * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).
+ * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
+ * read by the next upload_bvh, HYDRA_HIP_TOP_QUADS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
  * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..64, 0 = chosen from the resolution:
  * 16 at 1080p).  Sample j of a trace_pass(spp) call draws from generator stream j % K of its pixel, stream k of pixel p
  * being RandomGenInit(seed + k * width * height + p) -- the per-slot seeding of the reference's wavefront layer
