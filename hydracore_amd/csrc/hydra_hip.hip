@@ -1598,7 +1598,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
     if (value != c->fusedBounce) { (void)hipStreamSynchronize(c->stream); c->fusedBounce = value; c->stateAllocated = false; }
   }
   else if (n == "samples_in_flight") {
-    if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight: 0 (by resolution) or 1..64");
+    if (value < 0 || value > 512) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight: 0 (by resolution) or 1..512");
     if (value != c->streamsWanted) { c->streamsWanted = value; c->stateAllocated = false; }   // generators are re-seeded by the next init_path_tracing
   }
   else if (n == "queue_segments") {

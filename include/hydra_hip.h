@@ -108,7 +108,7 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).
  * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
  * read by the next upload_bvh, HYDRA_HIP_TOP_QUADS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
- * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..64, 0 = chosen from the resolution:
+ * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..512, 0 = chosen from the resolution:
  * 16 at 1080p).  Sample j of a trace_pass(spp) call draws from generator stream j % K of its pixel, stream k of pixel p
  * being RandomGenInit(seed + k * width * height + p) -- the per-slot seeding of the reference's wavefront layer
  * (shaders/trace.cl:6-13) with K * width * height slots.  K = 1 gives one persistent generator per pixel.  Changing K
