@@ -13,10 +13,16 @@
 #ifdef HK_HOST_EMU
 #include <math.h>
 #define HK_DEV static inline
+#define HK_DEV_CALL static
 #define HK_DEV_MEMBER inline
 #define HK_WAVE_ACTIVE_LANES() 64
 #else
 #define HK_DEV __device__ __forceinline__
+#ifdef HK_INLINE_TEXTURE_FETCH
+#define HK_DEV_CALL __device__ __forceinline__
+#else
+#define HK_DEV_CALL __device__ __noinline__   /* a real call: the body appears once in a kernel instead of once per call site */
+#endif
 #define HK_DEV_MEMBER __device__ __forceinline__
 #define HK_WAVE_ACTIVE_LANES() __popcll(__ballot(1))
 #endif

@@ -353,7 +353,7 @@ HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   
                      f1.z * w1 + f2_.z * w2 + f3_.z * w3 + f4_.z * w4, f1.w * w1 + f2_.w * w2 + f3_.w * w3 + f4_.w * w4);
 }
 // sample2DExt, cfetch.h:677-709, without procedural textures.  blob = owning material/light node, int4-addressed.
-HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
+HK_DEV_CALL f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
   if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE || samplerOffset < 0) return mk3(1, 1, 1);
   const float* sm = blob + size_t(samplerOffset) * 4;
   const int flags = as_int(sm[HS_FLAGS]);

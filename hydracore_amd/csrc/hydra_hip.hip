@@ -473,7 +473,12 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
       gen.x = g2.x; gen.y = g2.y;
       const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
+#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 4)   /* timing experiment (profiles/r01/pass_bounce_phase_cost.log): phases left out, results invalid */
+      alive = true; surf.pos = xyz(pos4); surf.normal = mk3(0, 1, 0); surf.flatNormal = surf.normal; surf.tangent = mk3(1, 0, 0); surf.biTangent = mk3(0, 0, 1);
+      surf.texCoord = mk2(0, 0); surf.matId = 0; surf.t = hit.t; surf.sRayOff = 0.0f; surf.hfi = false;
+#else
       alive = surface_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
+#endif
     }
     // the slot of the survivor is reserved as soon as survival is known: the returning atomic then overlaps the light and
     // material fetches below instead of standing alone at the end of the iteration
@@ -484,7 +489,11 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
         contrib[gid] = mk4(finalColor, 0.0f);
         gens[gid] = make_uint2(gen.x, gen.y);
       } else {
+#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 1)
+        lp.lightOffset = -1; lp.shadowRayDir = mk3(0, 1, 0); lp.color = mk3(0, 0, 0); lp.pdfSigned = 1.0f; lp.pickProb = 1.0f;
+#else
         light_phase(s, surf, gen, lp);
+#endif
         const float* mat = materialAt(s, surf.matId);
         const f3 ray_dir = xyz(dir4);
         f3 pend = mk3(0, 0, 0);
@@ -492,7 +501,11 @@ __global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t*
           pend = xyz(thr4) * direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
         oPend = mk4(pend, 0.0f);
         oShDir = mk4(lp.shadowRayDir, 0.0f);
+#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
+        oPos = mk4(surf.pos, pos4.w); oDir = dir4; oThr = thr4; oAcc = acc4;
+#else
         next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
+#endif
       }
     }
 #ifdef HK_EXP_BOUNCE_EXTRA_VALU   /* timing experiment: N dependent multiply-adds per path, result parked in the unused pend4.w */
