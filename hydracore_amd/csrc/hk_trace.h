@@ -66,18 +66,28 @@ typedef __attribute__((address_space(3))) int hk_lds_int;
 typedef __attribute__((address_space(3))) hk_v4f_t hk_lds_f4;
 #endif
 
-struct HkStack {
+template <int LDS_DEPTH>
+struct HkStackT {
   hk_lds_int* lds;   // this lane's column in the block's LDS stack, stride = HK_TRACE_BLOCK entries
-  int spill[HK_STACK_SIZE - HK_LDS_DEPTH];
+  int spill[HK_STACK_SIZE - LDS_DEPTH];
   HK_DEV_MEMBER void init(int* sharedBase, int lane) { lds = (hk_lds_int*)sharedBase + lane; }
   HK_DEV_MEMBER void put(int top, int v) {
-    if (top < HK_LDS_DEPTH) lds[top * HK_TRACE_BLOCK] = v; else spill[top - HK_LDS_DEPTH] = v;
+    if (top < LDS_DEPTH) lds[top * HK_TRACE_BLOCK] = v; else spill[top - LDS_DEPTH] = v;
   }
   HK_DEV_MEMBER int get(int top) const {
     if (top < 0) return 0;   // the reference reads an unused slot here; the value is never acted on
-    return (top < HK_LDS_DEPTH) ? lds[top * HK_TRACE_BLOCK] : spill[top - HK_LDS_DEPTH];
+    return (top < LDS_DEPTH) ? lds[top * HK_TRACE_BLOCK] : spill[top - LDS_DEPTH];
   }
 };
+typedef HkStackT<HK_LDS_DEPTH> HkStack;
+// The persistent shadow kernel needs fewer registers than the closest-hit one (no hit ids to carry): with a shorter LDS part
+// of the stack its blocks are small enough for 12 of them (6 waves per SIMD) to be resident per CU instead of 10.
+#ifndef HK_LDS_DEPTH_SHADOW
+#define HK_LDS_DEPTH_SHADOW 19
+#endif
+#ifndef HK_TRACE_MIN_WAVES_SHADOW
+#define HK_TRACE_MIN_WAVES_SHADOW 6
+#endif
 
 // How the traversal reads the node and triangle arrays.  Measured on MI355X (tools/micro/ta_bench.hip,
 // profiles/r01/ta_microbench_divergent_loads.log): when every lane reads its own 128-byte line, a 16-byte global_load
@@ -181,9 +191,9 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
 
 // returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
 // traversing (minActive <= 0: never suspend).
-template <bool ANYHIT, bool COUNT, bool TOPCACHE = false>
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack>
 HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
-                     const float t_rayMin, HkStack& stack, TravCounters& cnt, const int minActive) {
+                     const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive) {
   while (t.top >= 0) {
     while (t.searching) {
       float4 n0a, n0b, n1a, n1b, n2a, n2b, n3a, n3b;

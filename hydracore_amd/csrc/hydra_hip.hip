@@ -176,11 +176,12 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
 template <bool ANYHIT, bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
+__global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
                                                                unsigned long long* __restrict__ totals5, int minActive, int raysPerLane) {
-  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
+  constexpr int LDS_DEPTH = (ANYHIT && !COUNT) ? HK_LDS_DEPTH_SHADOW : HK_LDS_DEPTH;
+  __shared__ int ldsStack[LDS_DEPTH * HK_TRACE_BLOCK];
   __shared__ float4 ldsTop[HK_TOP_QUADS * HK_TOP_STRIDE];
   const SegIter it = segq_iter(q);
   const int count = it.count, segBase = it.base;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_d
   // that every lane still gets ~raysPerLane rays to refill from (a thinly spread queue degenerates to one ray per lane)
   if ((int(blockIdx.x) / q.nseg) * (HK_TRACE_BLOCK * raysPerLane) >= count) return;
   uint32_t* fetchCounter = fetchCounters + it.seg * HK_CSTRIDE;
-  HkStack st;
+  HkStackT<LDS_DEPTH> st;
   st.init(ldsStack, threadIdx.x);
   // the hottest quads of the tree (chosen at upload) go to LDS once per block; the node copy walked here names them by slot
   const bool useTop = (s.topCount > 0);
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace_d
     }
     if (__ballot(busy) == 0ull) break;
     if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT, true>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
       if (done) {
         if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
         else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
