@@ -735,7 +735,7 @@ struct hydra_hip_ctx {
   int traceRaysPerLane = 1;   // persistent kernels: blocks beyond count / (128 * this) leave at once
   int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
   int shadeWaves = 3;         // launch-bounds variant of k_bounce / k_hit / k_shade (3, 4 or 5 waves per SIMD); 3 = no spills, measured fastest for the fused kernel
-  int shadeBlocksPerCU = 16;
+  int shadeBlocksPerCU = 256;        // grid cap of the bounce kernels: 16 -> 128..1024 takes 5 % off k_bounce (finer tail, pass_sweep_shade_blocks_final.log)
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
@@ -1600,7 +1600,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   if (n == "trace_mode") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "trace_mode: 0 or 1"); c->traceMode = value; }
   else if (n == "trace_min_active") { if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_min_active: 0..64"); c->traceMinActive = value; }
   else if (n == "shade_waves") { if (value < 3 || value > 5) return fail(c, HYDRA_HIP_EINVAL, "shade_waves: 3, 4 or 5"); c->shadeWaves = value; }
-  else if (n == "shade_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "shade_blocks_per_cu: 1..64"); c->shadeBlocksPerCU = value; }
+  else if (n == "shade_blocks_per_cu") { if (value < 1 || value > 4096) return fail(c, HYDRA_HIP_EINVAL, "shade_blocks_per_cu: 1..4096"); c->shadeBlocksPerCU = value; }
   else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
   else if (n == "trace_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_blocks_per_cu: 1..64"); c->traceBlocksPerCU = value; }
   else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
