@@ -715,7 +715,7 @@ struct hydra_hip_ctx {
   int leafEncWanted = 1;             // option "leaf_count_links": read by the next upload_bvh
   int streamMajor = 1;               // option "path_order": 1 = stream-major (default), 0 = pixel-major (samples of a pixel share a wave); measured equal
   DevBuf ownedPixels;                // the N owned pixels in slot order (k_accumulate)
-  int nsegWanted = 8;                // option "queue_segments"
+  int nsegWanted = 32;               // option "queue_segments" (a multiple of the 8 XCDs: segment s is always worked on by XCD s % 8)
   int nseg = 1, segCap = 0;          // segmented path queues (see SegQ): nseg * segCap slots
   DevBuf liveInit;                   // one counter row holding the initial per-segment path counts
   DevBuf gens, accumInternal, contrib, hits, live, shadowCnt, totals;

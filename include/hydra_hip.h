@@ -102,8 +102,8 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
  * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12);
  * "shade_waves" 3|4|5 = register budget variant of the bounce kernels (default 3);
- * "shade_blocks_per_cu", "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
- * (default 8); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
+ * "shade_blocks_per_cu" (default 256), "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
+ * (default 32); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
  * "path_order" 1 = stream-major slots (default), 0 = pixel-major; "leaf_count_links" 1 = the device copy of the node array carries
  * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).
  * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
