@@ -444,8 +444,11 @@ __global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M
 // this moves 228 B through HBM instead of 504 B and drops one launch (no M record).
 struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 
+#ifndef HK_BOUNCE_BLOCK
+#define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
+#endif
 template <int W>
-__global__ void __launch_bounds__(256, W) k_bounce(SceneDev s, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
+__global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
                                                     ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens) {
   const SegIter it = segq_iter(q);
@@ -1038,6 +1041,7 @@ struct BounceBufs {
 static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap, int maxDepth, BounceBufs bb, uint32_t* live, uint32_t* shadowCnt,
                        float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
+  const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
   HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
@@ -1051,9 +1055,9 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     int b = mark();
     if (fused) {
       switch (c->shadeWaves) {
-        case 3: hipLaunchKernelGGL(k_bounce<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        case 5: hipLaunchKernelGGL(k_bounce<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        default: hipLaunchKernelGGL(k_bounce<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 3: hipLaunchKernelGGL(k_bounce<3>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 5: hipLaunchKernelGGL(k_bounce<5>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        default: hipLaunchKernelGGL(k_bounce<4>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
       }
       std::swap(bb.A, bb.B);
     } else {
