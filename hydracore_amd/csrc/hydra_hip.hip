@@ -736,7 +736,7 @@ struct hydra_hip_ctx {
   bool travCounters = false;
   int traceMode = 1;          // 1 = persistent dynamic fetch (k_trace_dyn, default: 8-35 % faster once the refill counters are per segment), 0 = one ray per lane
   int traceRaysPerLane = 1;   // persistent kernels: blocks beyond count / (128 * this) leave at once
-  int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
+  int traceMinActive = 48;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
   int shadeWaves = 3;         // launch-bounds variant of k_bounce / k_hit / k_shade (3, 4 or 5 waves per SIMD); 3 = no spills, measured fastest for the fused kernel
   int shadeBlocksPerCU = 256;        // grid cap of the bounce kernels: 16 -> 128..1024 takes 5 % off k_bounce (finer tail, pass_sweep_shade_blocks_final.log)
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU

@@ -100,7 +100,7 @@ int hydra_hip_enable_stage_timing(hydra_hip_handle h, int enable);
 int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max_depth);
 /* Options.
  * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
- * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 40); "trace_blocks_per_cu" (default 12);
+ * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 48); "trace_blocks_per_cu" (default 12);
  * "shade_waves" 3|4|5 = register budget variant of the bounce kernels (default 3);
  * "shade_blocks_per_cu" (default 256), "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
  * (default 32); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
