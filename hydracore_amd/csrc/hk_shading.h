@@ -369,6 +369,10 @@ HK_DEV_CALL f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, co
   return mk3(c.x, c.y, c.z);
 }
 
+// Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
+// the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_ALL = 31 };
+
 // ================================================================================================ materials
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
 struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
@@ -796,6 +800,7 @@ HK_DEV bool isEyeRay(uint32_t flags) {   // cglobals.h:1366-1376
   return (((flags >> 8) & 0xFFu) == 0) || !nonSpec;
 }
 // MaterialSampleAndEvalBxDF, cmaterial.h:2345-2371 (random walk :2180-2207, leaf dispatch :2245-2335)
+template <int F = HK_FEAT_ALL>
 HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit& sh, f3 rayDir, uint32_t rayFlags, const SceneDev& s, MatSample& out) {
   const bool reflOnly = (((rayFlags >> 16) & 64u /*RAY_GRAMMAR_DIRECT_LIGHT*/) != 0) && ((matFlags(m) & HMF_CAN_SAMPLE_REFL_ONLY) != 0);
   float mixW = 1.0f;
@@ -810,10 +815,10 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_PHONG: PhongSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
-    case HMT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_GGX: GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_THIN_GLASS: ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_GLASS: GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out); break;
+    case HMT_OREN_NAYAR: if (F & HK_FEAT_OREN_NAYAR) OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_GGX: if (F & HK_FEAT_GGX) GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_THIN_GLASS: if (F & HK_FEAT_GLASS) ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
+    case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out); break;
     default: break;
   }
   if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
@@ -821,6 +826,7 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
   if ((matFlags(node) & HMF_SKIP_SKY_PORTAL) && isEyeRay(rayFlags)) { out.color = mk3(1, 1, 1); out.pdf = 1.0f; }
 }
 // materialEval, cmaterial.h:2554-2628 (leaf: :2425-2551)
+template <int F = HK_FEAT_ALL>
 HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const SceneDev& s) {
   BxDFResult val;
   val.brdf = mk3(0, 0, 0); val.btdf = mk3(0, 0, 0); val.pdfFwd = 0.0f; val.pdfRev = 0.0f; val.diffuse = true;
@@ -847,7 +853,7 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         brdf = phongEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
         pf = phongEvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
         pr = phongEvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
-      } else if (type == HMT_GGX) {
+      } else if ((F & HK_FEAT_GGX) && type == HMT_GGX) {
         brdf = ggxEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
         pf = ggx2EvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
         pr = ggx2EvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
@@ -856,7 +862,7 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
         pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
         diffuse = true;
-      } else if (type == HMT_OREN_NAYAR) {
+      } else if ((F & HK_FEAT_OREN_NAYAR) && type == HMT_OREN_NAYAR) {
         brdf = orennayarEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
         pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
         pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
@@ -1123,17 +1129,19 @@ HK_DEV void DirectLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out.cosAtLight = 1.0f;
 }
 // LightSampleRev, clight.h:1561-1610: the light types this layer accepts (upload_globals rejects the others)
+template <int F = HK_FEAT_ALL>
 HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
-  switch (as_int(L[HL_TYPE])) {
-    case HLT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
-    case HLT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
-    case HLT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
-    case HLT_POINT_OMNI: PointLightSampleRev(L, illum, out); break;
-    default: AreaLightSampleRev(L, rands, illum, out); break;
-  }
+  const int type = as_int(L[HL_TYPE]);
+  if ((F & HK_FEAT_SKY) && type == HLT_SKY_DOME) SkyLightSampleRev(s, L, rands, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_DIRECT) DirectLightSampleRev(L, rands, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_SPOT) SpotLightSampleRev(L, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev(L, illum, out);
+  else AreaLightSampleRev(L, rands, illum, out);
 }
 // environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)
+template <int F = HK_FEAT_ALL>
 HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool prevSpecular, uint32_t flags) {
+  if (!(F & HK_FEAT_SKY)) return mk3(0, 0, 0);   // a scene without a sky light: skyLightId == -1 (cbidir.h:498-499)
   const int skyId = s.globals[HG_SKY_LIGHT_ID];
   if (skyId == -1) return mk3(0, 0, 0);
   const float* L = lightAt(s, skyId);

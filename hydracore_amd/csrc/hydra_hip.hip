@@ -260,6 +260,7 @@ struct LightPick {
 
 // H1 + E1 + E2 -- surface, environment/emission with MIS, termination (kernel_HitEnvironment, kernel_EvalSurface,
 // kernel_EvalEmission).  Returns true when the path goes on (surf valid); false when it ended with radiance `finalColor`.
+template <int F = HK_FEAT_ALL>
 HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
                           const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
   const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
@@ -267,7 +268,7 @@ HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const floa
   f3 currColor = mk3(0, 0, 0);
   bool done = false;
   if (!HitSome(hit)) {              // kernel_HitEnvironment, PT_Loop.cpp:23-33
-    currColor = environmentColor(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
+    currColor = environmentColor<F>(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
     done = true;
   }
   else {
@@ -295,6 +296,7 @@ HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const floa
 }
 
 // L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample)
+template <int F = HK_FEAT_ALL>
 HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& gen, LightPick& lp) {
   const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
   lp.pickProb = 1.0f;
@@ -304,7 +306,7 @@ HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& ge
   ShadowSample sam;
   sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
   if (lp.lightOffset >= 0) {
-    LightSampleRev(s, lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // clight.h:1561-1610
+    LightSampleRev<F>(s, lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // clight.h:1561-1610
     lp.shadowRayDir = normalize(sam.pos - surf.pos);
     const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, lp.shadowRayDir, surf.sRayOff);
     lp.shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
@@ -314,11 +316,12 @@ HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& ge
 }
 
 // S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
+template <int F = HK_FEAT_ALL>
 HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const f3 surfNormal, const f2 texCoord, const f3 ray_dir,
                                   const f3 shadowRayDir, const f3 lightColor, const float pdfSigned, const float lightPickProb) {
   ShadeContext sc;
   sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = texCoord;
-  const BxDFResult ev = materialEval(mat, sc, s);
+  const BxDFResult ev = materialEval<F>(mat, sc, s);
   const float cos1 = fmaxf(+dot(shadowRayDir, surfNormal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surfNormal), 0.0f);
   const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
   const float samPdf = fabsf(pdfSigned);
@@ -329,6 +332,7 @@ HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const f3 
 }
 
 // S2 -- BSDF sampling of the next bounce (kernel_NextBounce); `accum` is the radiance carried on
+template <int F = HK_FEAT_ALL>
 HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
                               const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
   float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
@@ -338,7 +342,7 @@ HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const Surface
     for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
   }
   MatSample ms;
-  MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, flags, s, ms);
+  MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, flags, s, ms);
   const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
   const float cosTheta = fabsf(dot(ms.direction, surf.normal));
   const f3 newPos = OffsRayPos(surf.pos, surf.normal, ms.direction);
@@ -447,7 +451,7 @@ struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 #ifndef HK_BOUNCE_BLOCK
 #define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
 #endif
-template <int W>
+template <int W, int F = HK_FEAT_ALL>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*)
 __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
                                                     ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens) {
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ 
       alive = true; surf.pos = xyz(pos4); surf.normal = mk3(0, 1, 0); surf.flatNormal = surf.normal; surf.tangent = mk3(1, 0, 0); surf.biTangent = mk3(0, 0, 1);
       surf.texCoord = mk2(0, 0); surf.matId = 0; surf.t = hit.t; surf.sRayOff = 0.0f; surf.hfi = false;
 #else
-      alive = surface_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
+      alive = surface_phase<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
 #endif
     }
     // the slot of the survivor is reserved as soon as survival is known: the returning atomic then overlaps the light and
@@ -496,19 +500,19 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ 
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 1)
         lp.lightOffset = -1; lp.shadowRayDir = mk3(0, 1, 0); lp.color = mk3(0, 0, 0); lp.pdfSigned = 1.0f; lp.pickProb = 1.0f;
 #else
-        light_phase(s, surf, gen, lp);
+        light_phase<F>(s, surf, gen, lp);
 #endif
         const float* mat = materialAt(s, surf.matId);
         const f3 ray_dir = xyz(dir4);
         f3 pend = mk3(0, 0, 0);
         if (lp.lightOffset >= 0)
-          pend = xyz(thr4) * direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
+          pend = xyz(thr4) * direct_light_unoccluded<F>(s, mat, surf.normal, surf.texCoord, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
         oPend = mk4(pend, 0.0f);
         oShDir = mk4(lp.shadowRayDir, 0.0f);
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
         oPos = mk4(surf.pos, pos4.w); oDir = dir4; oThr = thr4; oAcc = acc4;
 #else
-        next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
+        next_bounce_phase<F>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
 #endif
       }
     }
@@ -704,6 +708,7 @@ struct hydra_hip_ctx {
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
   bool leafEnc[4] = {false, false, false, false};   // device node copy of tree i has triangle counts in its leaf links
+  int lightFeatures = HK_FEAT_ALL, matFeatures = HK_FEAT_ALL, sceneFeatures = HK_FEAT_ALL;   // HK_FEAT_* the uploaded scene needs; 0 => the lean k_bounce
   bool matDirty = true;              // material arena or material table changed since validate_materials last passed
   std::vector<float> hostMaterials;  // host copy of the material arena and table, for validate_materials only
   std::vector<int32_t> hostMatTable;
@@ -840,6 +845,7 @@ static int validate_materials(hydra_hip_ctx* c) {
   if (!c->matDirty) return HYDRA_HIP_OK;
   const size_t floats = c->hostMaterials.size();
   auto word = [](const float* m, int i) { int32_t v; memcpy(&v, m + i, 4); return v; };
+  int feat = 0;
   for (size_t id = 0; id < c->hostMatTable.size(); id++) {
     const int32_t offs = c->hostMatTable[id];
     if (offs < 0) continue;
@@ -861,6 +867,9 @@ static int validate_materials(hydra_hip_ctx* c) {
         stack[top++] = at + size_t(o2) * HM_NODE_FLOATS;
         continue;
       }
+      if (type == HMT_OREN_NAYAR) feat |= HK_FEAT_OREN_NAYAR;
+      if (type == HMT_GLASS || type == HMT_THIN_GLASS) feat |= HK_FEAT_GLASS;
+      if (type == HMT_GGX) feat |= HK_FEAT_GGX;
       const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
                           type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX);
       if (!known)
@@ -868,6 +877,8 @@ static int validate_materials(hydra_hip_ctx* c) {
                                              "; the HIP layer implements phong, GGX, mirror, thin glass, glass, lambert, oren-nayar, blend mask and emissive only");
     }
   }
+  c->matFeatures = feat;
+  c->sceneFeatures = c->matFeatures | c->lightFeatures;
   c->matDirty = false;
   return HYDRA_HIP_OK;
 }
@@ -1055,9 +1066,22 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     int b = mark();
     if (fused) {
       switch (c->shadeWaves) {
-        case 3: hipLaunchKernelGGL(k_bounce<3>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        case 5: hipLaunchKernelGGL(k_bounce<5>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        default: hipLaunchKernelGGL(k_bounce<4>, dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 3: {
+          // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
+          // the first three, 16 spilled for the full one)
+          const int f = c->sceneFeatures;
+#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens)
+          if (f == 0) HK_LAUNCH_BOUNCE(0);
+          else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
+          else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
+          else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL & ~HK_FEAT_GLASS);
+          else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL & ~HK_FEAT_GGX);
+          else HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+#undef HK_LAUNCH_BOUNCE
+          break;
+        }
+        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
       }
       std::swap(bb.A, bb.B);
     } else {
@@ -1195,6 +1219,7 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (blob[at + HL_TYPE] != HLT_SKY_DOME) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId does not name a sky light");
     if (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ) c->skyLightOk = false;
   }
+  int lightFeat = (skyId != -1 && lightsNum > 0) ? HK_FEAT_SKY : 0;
   for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sky-dome, point, spot and directional lights
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
@@ -1202,9 +1227,14 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT);
     if (!known)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sky-dome, point, spot and directional lights only");
+    if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
+    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT) lightFeat |= HK_FEAT_DELTA_LIGHTS;
     if (blob[at + HL_FLAGS] & HLF_HAS_IES)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
   }
+  c->lightFeatures = lightFeat;
+  c->sceneFeatures = c->matFeatures | c->lightFeatures;
+  c->matDirty = true;   // (re)derives sceneFeatures together with the material walk
   return dev_upload(c, c->globals, blob, words * 4);
 }
 int hydra_hip_update_globals_header(hydra_hip_handle c, const int32_t* blob, size_t words) {
@@ -1212,6 +1242,7 @@ int hydra_hip_update_globals_header(hydra_hip_handle c, const int32_t* blob, siz
   HCHECK(hipSetDevice(c->device));
   const size_t keep = std::min<size_t>(words, HG_TABLES_READY + 1);
   c->hostHeader.assign(blob, blob + keep);
+  if (words > HG_LIGHTS_NUM && blob[HG_SKY_LIGHT_ID] != -1 && blob[HG_LIGHTS_NUM] > 0) { c->lightFeatures |= HK_FEAT_SKY; c->sceneFeatures |= HK_FEAT_SKY; }
   HCHECK(hipMemcpyAsync(c->globals.p, blob, words * 4, hipMemcpyHostToDevice, c->stream));
   HCHECK(hipStreamSynchronize(c->stream));
   return HYDRA_HIP_OK;
