@@ -3,7 +3,7 @@
 // Behaviour contract (rows a/T1, a/T2): closest hit exactly as BVH4InstTraverse / BVH4Traverse
 // (hydra_drv/ctrace.h:841-1062, :669-838) over the reference's flattened layout: children tested with
 // RayBoxIntersectionLite2 (:32-53), ordered near->far by the same 5 compare-swaps (:906-960) so that equal-t ties
-// resolve to the same triangle, <=3 pushes per quad, 80-entry stack with silent drop, instance leaves re-express the
+// resolve to the same triangle, <=3 pushes per quad, 80-entry stack (+2, see HkStackT) with silent drop, instance leaves re-express the
 // ray in object space with the direction left un-normalised; leaf test :124-182 (u,v > -1e-6, u+v < 1+1e-6,
 // t_min < t < best).  The shadow form answers "any triangle with t_min < t < t_far" which is what
 // IntegratorCommon::shadowTrace computes from a closest hit (CPUExp_Integrators_Common.cpp:156-180).
@@ -66,10 +66,15 @@ typedef __attribute__((address_space(3))) int hk_lds_int;
 typedef __attribute__((address_space(3))) hk_v4f_t hk_lds_f4;
 #endif
 
+// Capacity: the reference tests `top < 80` ONCE per quad and then pushes up to three links (ctrace.h:964-985), so with
+// top == 79 it writes entries 79, 80 and 81 of an 80-entry array.  Entries 80 and 81 exist here (HK_STACK_SLACK), so a
+// tree deeper than the stack behaves like the reference does when its two stray writes land on harmless memory -- same
+// pushes, same pops, same visit order -- instead of corrupting the neighbouring scratch words.
+#define HK_STACK_SLACK 2
 template <int LDS_DEPTH>
 struct HkStackT {
   hk_lds_int* lds;   // this lane's column in the block's LDS stack, stride = HK_TRACE_BLOCK entries
-  int spill[HK_STACK_SIZE - LDS_DEPTH];
+  int spill[HK_STACK_SIZE + HK_STACK_SLACK - LDS_DEPTH];
   HK_DEV_MEMBER void init(int* sharedBase, int lane) { lds = (hk_lds_int*)sharedBase + lane; }
   HK_DEV_MEMBER void put(int top, int v) {
     if (top < LDS_DEPTH) lds[top * HK_TRACE_BLOCK] = v; else spill[top - LDS_DEPTH] = v;

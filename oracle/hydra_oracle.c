@@ -383,7 +383,11 @@ static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, floa
  * instancing steps are skipped for plain trees exactly as the reference's second function omits them. */
 static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, TravStat* st) {
   f3 invDir = SafeInverse(ray_dir);
-  int stackData[STACK_SIZE + 2];
+  /* the reference declares stackData[80] with stack = stackData + 2 and tests `top < 80` once before up to three pushes
+   * (ctrace.h:846-847,964-985): on a tree deeper than the stack it writes stack[78..81], i.e. up to four ints past its
+   * array.  Here those four words exist, which is the reference's behaviour whenever its stray writes land on harmless
+   * memory; the HIP kernels size their stack the same way (hk_trace.h, HK_STACK_SLACK). */
+  int stackData[STACK_SIZE + 4];
   int* stack = stackData + 2;
   stackData[0] = stackData[1] = 0;   /* the reference reads stack[-1] uninitialised after the last pop */
   int top = 0, leftNodeOffset = 1, searchingForLeaf = 1;

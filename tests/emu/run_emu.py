@@ -13,6 +13,54 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def deep_chain_case(lib, p):
+    """A degenerate tree deeper than the 80-entry traversal stack (the reference tests `top < 80` once and then
+    pushes up to three links, ctrace.h:964-985).  Quad q = {inner child -> quad q + 1 (entered first), three leaves}
+    (quad 1: one leaf): level 1 pushes one link and every further level three, so the test at level 27 sees top == 79 and the
+    three pushes land on entries 79, 80 and 81.  The device code (HkStackT, 80 + 2 entries) must
+    stay inside its arrays under ASan and visit exactly what the oracle visits."""
+    from oracle_lib import OrcScene, load
+    levels = 120
+    nodes = np.zeros(((levels + 2) * 4, 8), np.float32)
+    ni = nodes.view(np.int32)
+    ni[:, 3] = -1
+    ni[:, 7] = -1                                                    # invalid child: both words 0xFFFFFFFF
+    tris = []
+
+    def leaf(z):
+        at = len(tris)
+        tris.append([np.int32(at + 1).view(np.float32), np.int32(1).view(np.float32), np.int32(-1).view(np.float32), np.int32(-1).view(np.float32)])
+        tris.append([-2.0, -2.0, z, np.int32(len(tris)).view(np.float32)])          # w = primId
+        tris.append([2.0, -2.0, z, np.int32(0).view(np.float32)])
+        tris.append([0.0, 2.0, z, np.int32(0).view(np.float32)])
+        return at
+    for q in range(1, levels + 1):
+        zs = (0.5 + 0.001 * q, 0.7 + 0.001 * (levels - q), 0.9 + 0.0005 * q)
+        if q < levels:
+            nodes[4 * q, :3] = (-3, -3, -1.0); nodes[4 * q, 4:7] = (3, 3, 1.0); ni[4 * q, 3] = q + 1; ni[4 * q, 7] = 0
+        for k, z in enumerate(zs[:1] if q == 1 else zs, 1):
+            nodes[4 * q + k, :3] = (-3, -3, z - 1e-3); nodes[4 * q + k, 4:7] = (3, 3, z + 1e-3)
+            ni[4 * q + k, 3] = np.int32(np.uint32(0x80000000 | leaf(z)).astype(np.int64) - (1 << 32)); ni[4 * q + k, 7] = 0
+    tris = np.array(tris, np.float32)
+    rng = np.random.default_rng(9)
+    n = 2000
+    pos4 = np.zeros((n, 4), np.float32); dir4 = np.zeros((n, 4), np.float32)
+    pos4[:, :2] = rng.uniform(-1.5, 1.5, (n, 2)); pos4[:, 2] = -10.0
+    d = np.stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n), np.ones(n)], 1)
+    dir4[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    s = OrcScene()
+    s.bvh, s.tris, s.haveInst = nodes.ctypes.data, tris.ctypes.data, 0
+    dt = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
+    hits, cnt = np.empty(n, dt), np.empty((n, 4), np.uint32)
+    lib.emu_trace(C.byref(s), n, p(pos4), p(dir4), p(hits), p(cnt), 0, None, None)
+    ref, rcnt, rleaves = np.empty(n, dt), np.empty((n, 3), np.uint32), np.empty(n, np.uint32)
+    load().orc_trace(C.byref(s), n, p(pos4), p(dir4), p(ref), p(rcnt), p(rleaves))
+    assert (hits == ref).all(), "deep chain: closest hit differs"
+    assert (cnt[:, :3] == rcnt).all() and (cnt[:, 3] == rleaves).all(), "deep chain: visit counters differ"
+    assert cnt[:, 0].max() == levels and cnt[:, 3].max() > 80 and (hits["primId"] != -1).mean() > 0.5
+    print("deep chain (%d levels, stack overflows): %d rays ok, up to %d quads per ray" % (levels, n, cnt[:, 0].max()))
+
+
 def main():
     from conftest import host_scene, make_oracle, random_rays
     from oracle_lib import OrcScene
@@ -62,6 +110,7 @@ def main():
         assert same.mean() > 0.999, "RNG draw counts differ on %.3f%% of the paths" % (100 * (1 - same.mean()))
         assert (err.max(axis=1) > 1e-4).mean() < 0.001, "radiance differs"
         print("%s: %d rays + %d paths ok, worst rel err %.3g, identical draws %.4f" % (name, len(pos4), n, err.max(), same.mean()))
+    deep_chain_case(lib, p)
     print("EMU_OK worst %.3g" % worst)
 
 

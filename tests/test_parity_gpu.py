@@ -163,16 +163,18 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
     pos4, dir4 = random_rays(50000, 77)
     tfar = np.random.default_rng(3).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
     ref, refvis = orc.trace(pos4, dir4), orc.shadow_trace(pos4, dir4, tfar)
+    defaults = (core.get_option("trace_mode"), core.get_option("trace_min_active"))   # the shipped defaults, restored below
+    assert defaults == (1, 48)
     try:
-        for mode, min_active in ((0, 40), (1, 0), (1, 40), (1, 64)):
+        for mode, min_active in ((0, 40), (1, 0), (1, 40), (1, 48), (1, 64)):
             core.set_option("trace_mode", mode)
             core.set_option("trace_min_active", min_active)
             hits = core.stage_trace(pos4, dir4)
             assert (hits == ref).all(), (mode, min_active)
             assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active)
     finally:
-        core.set_option("trace_mode", 1)
-        core.set_option("trace_min_active", 40)
+        core.set_option("trace_mode", defaults[0])
+        core.set_option("trace_min_active", defaults[1])
 
 
 def test_surface_reconstruction(gpu224):
