@@ -40,7 +40,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_init_path_tracing", "hydra_hip_clear_accumulated_color", "hydra_hip_trace_pass", "hydra_hip_set_spp",
     "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_rays_stat",
     "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_get_stage_times_per_bounce", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
-    "hydra_hip_get_traversal_counters", "hydra_hip_stage_make_eye_rays",
+    "hydra_hip_get_traversal_counters", "hydra_hip_get_traversal_oob", "hydra_hip_stage_trace_totals", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
 ]
@@ -92,6 +92,8 @@ def load_hip_library():
         "hydra_hip_get_option": ([vp, C.c_char_p, C.POINTER(i32)], i32),
         "hydra_hip_enable_traversal_counters": ([vp, i32], i32),
         "hydra_hip_get_traversal_counters": ([vp, vp, i32], i32),
+        "hydra_hip_get_traversal_oob": ([vp, C.POINTER(C.c_uint64)], i32),
+        "hydra_hip_stage_trace_totals": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_make_eye_rays": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
@@ -280,7 +282,22 @@ class HipCore:
         self._ck(self.lib.hydra_hip_get_traversal_counters(self.h, _ptr(out), max_depth), "get_traversal_counters")
         return out
 
+    def traversal_oob(self):
+        """fetches the counting traversal kernels would have made out of range since enable_traversal_counters (must be 0)"""
+        v = C.c_uint64(0)
+        self._ck(self.lib.hydra_hip_get_traversal_oob(self.h, C.byref(v)), "get_traversal_oob")
+        return int(v.value)
+
     # ---- stage entry points
+    def stage_trace_totals(self, pos4, dir4, tfar=None):
+        """uint64 [6]: rays, quads, instance quads, leaves, triangles, out-of-range fetches of the persistent counting kernels"""
+        n = pos4.shape[0]
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        tf = np.ascontiguousarray(tfar, dtype=np.float32) if tfar is not None else None
+        out = np.zeros(6, np.uint64)
+        self._ck(self.lib.hydra_hip_stage_trace_totals(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(tf) if tf is not None else None, _ptr(out)), "stage_trace_totals")
+        return out
+
     def stage_random(self, seeds, draws):
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         n = seeds.size

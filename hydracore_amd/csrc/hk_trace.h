@@ -35,7 +35,7 @@ typedef float hk_v4f_t __attribute__((ext_vector_type(4)));
 #endif
 #define HK_TOP_FLAG 0x40000000
 
-struct TravCounters { uint32_t quads, insts, tris, leaves; };
+struct TravCounters { uint32_t quads, insts, tris, leaves, oob; };   // oob: fetches a range-checked buffer load would have answered with zeros (must stay 0)
 
 HK_DEV f3 SafeInverse(f3 d) {   // hydra_drv/cglobals.h:726-735
   const float ooeps = 1.0e-36f;
@@ -105,12 +105,15 @@ struct BvhView {
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const { return top[(link & 0xff) * HK_TOP_STRIDE + piece]; }
   HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
   HK_DEV_MEMBER float4 tri(int index) const { return tris[index]; }
+  HK_DEV_MEMBER bool nodeInRange(int) const { return true; }   // the host build runs under AddressSanitizer instead
+  HK_DEV_MEMBER bool triInRange(int, int) const { return true; }
 };
 HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; return v; }
 #else
 typedef float hk_v4f __attribute__((ext_vector_type(4)));
 struct BvhView {
   __amdgpu_buffer_rsrc_t nodes, tris;
+  uint32_t nodeBytes, triBytes;
   bool leafEnc;   // triangle-leaf links of the device copy carry the triangle count (see HK_LEAF_COUNT_SHIFT)
   const hk_lds_f4* top;   // LDS copy of the hottest quads (trav_run<.., TOPCACHE = true> only)
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const {
@@ -125,12 +128,17 @@ struct BvhView {
     const hk_v4f v = __builtin_bit_cast(hk_v4f, __builtin_amdgcn_raw_buffer_load_b128(tris, uint32_t(index) * 16u, 0, 0));
     return make_float4(v.x, v.y, v.z, v.w);
   }
+  // raw buffer loads answer an out-of-range offset with zeros instead of faulting; the counting kernel variants use these
+  // two predicates to prove that no fetch ever relies on that (TravCounters::oob, tests/test_parity_gpu.py)
+  HK_DEV_MEMBER bool nodeInRange(int quad) const { return quad >= 0 && (unsigned long long)(uint32_t)quad * 128ull + 128ull <= nodeBytes; }
+  HK_DEV_MEMBER bool triInRange(int first, int end) const { return first >= 0 && end >= first && (unsigned long long)(uint32_t)end * 16ull <= triBytes; }
 };
 // both sizes come from kernel arguments (wave-uniform), < 4 GiB each (checked by upload_bvh)
 HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes, bool leafEnc = false) {
   BvhView v;
   v.leafEnc = leafEnc;
   v.top = nullptr;
+  v.nodeBytes = nodeBytes; v.triBytes = triBytes;
   v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
   v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
   return v;
@@ -154,7 +162,7 @@ HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float
     first = as_int(hdr.x); count = as_int(hdr.y);
   }
   const int end = first + count * 3;
-  if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; }
+  if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; if (!bv.triInRange(first, end) || !bv.triInRange(leaf_offset & HK_LEAF_OFFSET_MASK, (leaf_offset & HK_LEAF_OFFSET_MASK) + 1)) cnt.oob++; }
   for (int a = first; a < end; a += 3) {
     const float4 d1 = bv.tri(a), d2 = bv.tri(a + 1), d3 = bv.tri(a + 2);
     const f3 A = xyz(d1), B = xyz(d2), C = xyz(d3);
@@ -209,7 +217,7 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
         n0a = bv.node(t.left, 0); n0b = bv.node(t.left, 1); n1a = bv.node(t.left, 2); n1b = bv.node(t.left, 3);
         n2a = bv.node(t.left, 4); n2b = bv.node(t.left, 5); n3a = bv.node(t.left, 6); n3b = bv.node(t.left, 7);
       }
-      if (COUNT) cnt.quads++;
+      if (COUNT) { cnt.quads++; if (!(TOPCACHE && (t.left & HK_TOP_FLAG)) && !bv.nodeInRange(t.left)) cnt.oob++; }
       int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
 #ifdef HK_HOST_EMU
       const bool v0 = !((uint32_t(c0) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n0b.w)) == HYDRA_BVH_INVALID));
@@ -272,7 +280,7 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       m44 matrix;
       matrix.c[0] = bv.node(t.left, 2); matrix.c[1] = bv.node(t.left, 3); matrix.c[2] = bv.node(t.left, 4); matrix.c[3] = bv.node(t.left, 5);
       t.instId = as_int(bv.node(t.left, 6).x);
-      if (COUNT) cnt.insts++;
+      if (COUNT) { cnt.insts++; if (!bv.nodeInRange(t.left)) cnt.oob++; }
       t.pos = mul4x3(matrix, t.pos);
       t.dir = mul3x3(matrix, t.dir);   // stays un-normalised so t keeps world units
       t.inv = SafeInverse(t.dir);

@@ -42,6 +42,7 @@ struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
 };
 
 #define HK_MAX_DEPTH 64
+#define HK_TT_ROW 12   // words per bounce in travTotals: 2 kernels x (rays, quads, insts, leaves, tris, out-of-range fetches)
 #ifndef HK_TRACE_MIN_BLOCKS
 #define HK_TRACE_MIN_BLOCKS 1   // resident 128-thread blocks per CU the traversal kernels are register-budgeted for
 #endif
@@ -131,13 +132,14 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(S
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
-    TravCounters c = {0, 0, 0, 0};
+    TravCounters c = {0, 0, 0, 0, 0};
     const HydraLiteHit hit = hk_traverse<false, COUNT>(bv, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
     reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
     if (COUNT && counters3) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
     if (COUNT && totals5) {   // algorithmic-work counters for the roofline byte model
       atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
       atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
     }
   }
 }
@@ -159,12 +161,13 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
     if (o.w >= 0.0f) {   // t_far < 0 marks "no light sample": shadow = 0 (PT_Loop.cpp:175-178)
       HydraLiteHit h = hk_miss_hit();
       h.t = o.w;
-      TravCounters c = {0, 0, 0, 0};
+      TravCounters c = {0, 0, 0, 0, 0};
       h = hk_traverse<true, COUNT>(bv, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
       v = (h.primId != -1) ? 0.0f : 1.0f;
       if (COUNT && totals5) {
         atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
         atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
       }
     }
     vis[i] = v;
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   bv.top = (const hk_lds_f4*)ldsTop;
   const int rootLink = useTop ? (HK_TOP_FLAG | 0) : 1;
   TravState t;
-  TravCounters c = {0, 0, 0, 0};
+  TravCounters c = {0, 0, 0, 0, 0};
   int rayIdx = -1;
   bool busy = false, queueEmpty = false;
   const int lane = int(__lane_id());
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
             if (skip) outVis[segBase + idx] = 0.0f;
             else {
               trav_init(t, xyz(a), xyz(b4[segBase + idx]), h, rootLink);
-              if (COUNT) { c.quads = c.insts = c.tris = c.leaves = 0; }
+              if (COUNT) { c.quads = c.insts = c.tris = c.leaves = c.oob = 0; }
               rayIdx = segBase + idx;
               busy = true;
             }
@@ -242,6 +245,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
         if (COUNT && totals5) {
           atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
           atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
         }
         busy = false;
       }
@@ -747,7 +751,7 @@ struct hydra_hip_ctx {
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
-  DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris]
+  DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris, out-of-range fetches]
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
   uint64_t nTrace = 0, nShadow = 0;   // launches folded into tTrace / tShadow
@@ -1058,7 +1062,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
     int a = mark();
-    unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * 10 : nullptr;
+    unsigned long long* tt = c->travCounters ? static_cast<unsigned long long*>(c->travTotals.p) + size_t(depth) * HK_TT_ROW : nullptr;
     const SegQ qIn = seg_q(live + size_t(depth) * HK_CROW, 0, nseg, segCap), qOut = seg_q(live + size_t(depth + 1) * HK_CROW, 0, nseg, segCap);
     uint32_t* nextCnt = live + size_t(depth + 1) * HK_CROW, *shCnt = shadowCnt + size_t(depth) * HK_CROW;
     const PathState S = bb.A;
@@ -1093,8 +1097,8 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     }
     int d = mark();
     if (depth + 1 < maxDepth) {
-      if (fused) launch_shadow(c, s, qOut, bb.sh.org4, bb.sh.dir4, bb.sh.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
-      else launch_shadow(c, s, qOut, bb.M.shadowOrg, bb.M.recC, bb.M.vis, tt ? tt + 5 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
+      if (fused) launch_shadow(c, s, qOut, bb.sh.org4, bb.sh.dir4, bb.sh.vis, tt ? tt + HK_TT_ROW / 2 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
+      else launch_shadow(c, s, qOut, bb.M.shadowOrg, bb.M.recC, bb.M.vis, tt ? tt + HK_TT_ROW / 2 : nullptr, fetch ? fetch + size_t(2 * depth + 1) * HK_CROW : nullptr);
       int e = mark();
       if (timing) c->spans.push_back({d, e, 3, depth});
       if (!fused) {
@@ -1680,9 +1684,9 @@ int hydra_hip_enable_traversal_counters(hydra_hip_handle c, int enable) {
   if (!c) return HYDRA_HIP_EINVAL;
   HCHECK(hipSetDevice(c->device));
   if (enable) {
-    int rc = dev_alloc(c, c->travTotals, size_t(HK_MAX_DEPTH) * 10 * 8);
+    int rc = dev_alloc(c, c->travTotals, size_t(HK_MAX_DEPTH) * HK_TT_ROW * 8);
     if (rc) return rc;
-    HCHECK(hipMemsetAsync(c->travTotals.p, 0, size_t(HK_MAX_DEPTH) * 10 * 8, c->stream));
+    HCHECK(hipMemsetAsync(c->travTotals.p, 0, size_t(HK_MAX_DEPTH) * HK_TT_ROW * 8, c->stream));
   }
   c->travCounters = (enable != 0);
   return HYDRA_HIP_OK;
@@ -1691,7 +1695,19 @@ int hydra_hip_get_traversal_counters(hydra_hip_handle c, uint64_t* out, int max_
   if (!c || !out || max_depth < 1 || max_depth > HK_MAX_DEPTH) return HYDRA_HIP_EINVAL;
   if (!c->travTotals.p) return fail(c, HYDRA_HIP_ESTATE, "get_traversal_counters: enable_traversal_counters first");
   HCHECK(hipSetDevice(c->device));
-  HCHECK(hipMemcpy(out, c->travTotals.p, size_t(max_depth) * 10 * 8, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> raw(size_t(max_depth) * HK_TT_ROW);
+  HCHECK(hipMemcpy(raw.data(), c->travTotals.p, raw.size() * 8, hipMemcpyDeviceToHost));
+  for (int d = 0; d < max_depth; d++) for (int k = 0; k < 2; k++) for (int j = 0; j < 5; j++) out[(size_t(d) * 2 + k) * 5 + j] = raw[size_t(d) * HK_TT_ROW + k * 6 + j];
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_get_traversal_oob(hydra_hip_handle c, uint64_t* out) {
+  if (!c || !out) return HYDRA_HIP_EINVAL;
+  if (!c->travTotals.p) return fail(c, HYDRA_HIP_ESTATE, "get_traversal_oob: enable_traversal_counters first");
+  HCHECK(hipSetDevice(c->device));
+  std::vector<uint64_t> raw(size_t(HK_MAX_DEPTH) * HK_TT_ROW);
+  HCHECK(hipMemcpy(raw.data(), c->travTotals.p, raw.size() * 8, hipMemcpyDeviceToHost));
+  *out = 0;
+  for (int d = 0; d < HK_MAX_DEPTH; d++) *out += raw[size_t(d) * HK_TT_ROW + 5] + raw[size_t(d) * HK_TT_ROW + 11];
   return HYDRA_HIP_OK;
 }
 int hydra_hip_enable_stage_timing(hydra_hip_handle c, int enable) { if (!c) return HYDRA_HIP_EINVAL; c->stageTiming = (enable != 0); return HYDRA_HIP_OK; }
@@ -1889,6 +1905,30 @@ int hydra_hip_bench_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   (void)hipEventDestroy(e1);
   HCHECK(hipGetLastError());
   *avg_ms = ms / float(iters);
+  return HYDRA_HIP_OK;
+}
+
+// the persistent COUNTING kernels (the ones bench.py prices its roofline bytes with) on caller-provided rays
+int hydra_hip_stage_trace_totals(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, const float* t_far, uint64_t* totals6) {
+  STAGE_PROLOG(true);
+  if (!ray_pos4 || !ray_dir4 || !totals6) return fail(c, HYDRA_HIP_EINVAL, "stage_trace_totals: null argument");
+  if (c->traceMode == 0) return fail(c, HYDRA_HIP_ESTATE, "stage_trace_totals: needs trace_mode 1 (the persistent kernels)");
+  std::vector<float> org(ray_pos4, ray_pos4 + size_t(n) * 4);
+  if (t_far) for (int i = 0; i < n; i++) org[4 * size_t(i) + 3] = t_far[i];
+  float4* dpos = (float4*)tb.up(c, org.data(), size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  unsigned long long* dt = (unsigned long long*)tb.up(c, nullptr, 6 * 8, rc);
+  if (rc) return rc;
+  HCHECK(hipMemsetAsync(dt, 0, 6 * 8, c->stream));
+  SceneDev s = make_scene(c);
+  if ((rc = ensure_fetch_counters(c))) return rc;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
+  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+  if (t_far) launch_shadow(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, reinterpret_cast<float*>(dh), dt, fetch);
+  else launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, nullptr, dt, fetch);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(totals6, dt, 6 * 8, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 

@@ -121,6 +121,10 @@ int hydra_hip_get_option(hydra_hip_handle h, const char* name, int* value);   /*
  * [bounce][0 = closest-hit | 1 = shadow][rays, quads visited, instance quads entered, leaves visited, triangles tested] */
 int hydra_hip_enable_traversal_counters(hydra_hip_handle h, int enable);
 int hydra_hip_get_traversal_counters(hydra_hip_handle h, uint64_t* out, int max_depth);
+/* The traversal kernels read nodes and triangles through range-checked raw buffer loads, which answer an out-of-range
+ * offset with zeros instead of faulting.  The counting variants also count every fetch that WOULD have been out of range,
+ * summed here over all bounces since enable_traversal_counters(1): must be 0 for a well-formed tree (tests assert it). */
+int hydra_hip_get_traversal_oob(hydra_hip_handle h, uint64_t* out);
 
 /* ---------------------------------------------------------------- stage entry points
  * One call = one wavefront kernel over n host-provided items; used by the parity tests and by the
@@ -157,6 +161,13 @@ int hydra_hip_stage_random(hydra_hip_handle h, int n, const int32_t* seeds, int 
  * launched `iters` times between two hipEvents on the context stream; returns average ms per launch. */
 int hydra_hip_bench_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                           int iters, int shadow, float* avg_ms);
+
+/* the persistent COUNTING traversal kernels (k_trace_dyn<*, true>: what bench.py prices the roofline bytes with) on n
+ * caller-provided rays: closest hit (t_far == NULL; IntegratorCommon::rayTrace, Common.cpp:122-154) or any-hit shadow rays
+ * (t_far[n]; Common.cpp:156-180, early-out form ctrace.h:1065-1294).  totals6 = rays traced, quads visited, instance quads
+ * entered, leaves visited, triangles tested, out-of-range fetches (see hydra_hip_get_traversal_oob). */
+int hydra_hip_stage_trace_totals(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
+                                 const float* t_far, uint64_t* totals6);
 
 #ifdef __cplusplus
 }

@@ -381,7 +381,9 @@ static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, floa
 
 /* ref: ctrace.h:841-1062 BVH4InstTraverse (haveInst) and :669-838 BVH4Traverse (!haveInst): one state machine, the
  * instancing steps are skipped for plain trees exactly as the reference's second function omits them. */
-static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, TravStat* st) {
+/* anyHit: the shadow form BVH4InstTraverseShadow (ref: ctrace.h:1065-1294): the caller seeds hit.t with the ray's far end and
+ * the walk stops behind the first leaf that produced a hit in (t_rayMin, far) (ref: :1243-1251, `top = 0`). */
+static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, int anyHit, TravStat* st) {
   f3 invDir = SafeInverse(ray_dir);
   /* the reference declares stackData[80] with stack = stackData + 2 and tests `top < 80` once before up to three pushes
    * (ctrace.h:846-847,964-985): on a tree deeper than the stack it writes stack[78..81], i.e. up to four ints past its
@@ -425,10 +427,12 @@ static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, 
     }
     if (!haveInst) {
       if (top >= 0) hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, 0, 0, st);
+      if (anyHit && hit.primId != -1) break;
       top--;
       leftNodeOffset = stack[top];
     } else if (top >= 0 && instDeep == 1) {
       hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, instId, 1, st);
+      if (anyHit && hit.primId != -1) break;
       top--;
       leftNodeOffset = stack[top];
     } else if (top >= 0 && instDeep == 0) {
@@ -457,7 +461,7 @@ static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, 
 /* ref: CPUExp_Integrators_Common.cpp:122-154 IntegratorCommon::rayTrace (tree 0; Make_Lite_Hit cglobals.h:1256-1266) */
 static OrcHit rayTrace(const OrcScene* s, f3 pos, f3 dir, TravStat* st) {
   OrcHit h; h.t = MAXFLOAT_T; h.primId = -1; h.instId = -1; h.geomId = (int32_t)(((uint32_t)(-1) << 30) & 0xC0000000u);
-  return BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, st);
+  return BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, 0, st);
 }
 static inline int HitSome(OrcHit h) { return (h.primId != -1) && isfinite(h.t); }
 /* ref: Common.cpp:156-180 IntegratorCommon::shadowTrace: full closest hit, then 0 < t < t_far */
@@ -473,6 +477,19 @@ void orc_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, O
     hits[i] = rayTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), &st);
     if (c3) { c3[3 * i] = st.quads; c3[3 * i + 1] = st.insts; c3[3 * i + 2] = st.tris; }
     if (leaves1) leaves1[i] = st.leaves;
+  }
+}
+/* ref: ctrace.h:1065-1294 BVH4InstTraverseShadow as launched by BVH4TraversalInstShadowKenrel (shaders/trace.cl:309-353):
+ * hit seeded with Make_Lite_Hit(maxDist, -1), visibility 0 when some triangle lies in (0, maxDist).  c4 (optional) = quads,
+ * instance quads, triangles, leaves visited by the early-out walk. */
+void orc_shadow_trace_anyhit(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis, uint32_t* c4) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int i = 0; i < n; i++) {
+    TravStat st = {0, 0, 0, 0};
+    OrcHit h; h.t = tfar[i]; h.primId = -1; h.instId = -1; h.geomId = (int32_t)0xC0000000u;
+    h = BVH4Traverse_(v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), 0.0f, h, s->bvh, s->tris, s->haveInst, 1, &st);
+    vis[i] = (h.primId != -1) ? 0.0f : 1.0f;
+    if (c4) { c4[4 * i] = st.quads; c4[4 * i + 1] = st.insts; c4[4 * i + 2] = st.tris; c4[4 * i + 3] = st.leaves; }
   }
 }
 void orc_shadow_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis) {

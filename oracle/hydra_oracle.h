@@ -54,6 +54,7 @@ void orc_make_eye_rays(const OrcScene* s, int n, int w, int h, const int32_t* xy
 void orc_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, OrcHit* hits, uint32_t* counters3, uint32_t* leaves1);
 /* T2 */
 void orc_shadow_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis);
+void orc_shadow_trace_anyhit(const OrcScene* s, int n, const float* pos4, const float* dir4, const float* tfar, float* vis, uint32_t* c4);
 /* H1: 24 floats per hit (layout in include/hydra_hip.h, hydra_hip_stage_eval_surface) */
 void orc_eval_surface(const OrcScene* s, int n, const float* pos4, const float* dir4, const OrcHit* hits, float* surf24);
 /* whole paths, per-path RandomGen state (updated in place); color4.w = number of rays traced (extension + shadow) */

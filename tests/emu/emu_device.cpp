@@ -44,7 +44,7 @@ void emu_trace(const EmuScene* e, int n, const float* pos4, const float* dir4, H
   for (int i = 0; i < n; i++) {
     HkStack st;
     st.init(lds.data(), i % HK_TRACE_BLOCK);
-    TravCounters c = {0, 0, 0, 0};
+    TravCounters c = {0, 0, 0, 0, 0};
     const f3 p = mk3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), d = mk3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
     if (anyhit) {
       HydraLiteHit h = hk_miss_hit();

@@ -5,7 +5,7 @@
 #pragma once
 
 HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_dir, RandomGen& gen, float& rays) {
-  TravCounters tc = {0, 0, 0, 0};
+  TravCounters tc = {0, 0, 0, 0, 0};
   f3 accumColor = mk3(0, 0, 0), thr = mk3(1, 1, 1), currColor = mk3(0, 0, 0);
   float misPdf = 1.0f; bool misSpec = true;
   uint32_t flags = 0;

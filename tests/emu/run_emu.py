@@ -88,8 +88,11 @@ def main():
         assert (cnt[:, :3] == rcnt).all() and (cnt[:, 3] == rleaves).all(), "visit counters differ"
         tfar = np.random.default_rng(2).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
         vis = np.empty(len(pos4), np.float32)
-        lib.emu_trace(C.byref(orc.s), len(pos4), p(pos4), p(dir4), None, None, 1, p(tfar), p(vis))
+        acnt = np.empty((len(pos4), 4), np.uint32)
+        lib.emu_trace(C.byref(orc.s), len(pos4), p(pos4), p(dir4), None, p(acnt), 1, p(tfar), p(vis))
         assert (vis == orc.shadow_trace(pos4, dir4, tfar)).all(), "shadow differs"
+        rvis, racnt = orc.shadow_trace_anyhit(pos4, dir4, tfar, counters=True)   # the early-out walk of ctrace.h:1065-1294
+        assert (vis == rvis).all() and (acnt == racnt).all(), "any-hit walk differs from the oracle's"
         # whole paths
         n = w * h
         ys, xs = np.divmod(np.arange(n), w)

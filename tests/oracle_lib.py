@@ -40,6 +40,7 @@ def load():
     lib.orc_make_eye_rays.argtypes = [sp, i32, i32, i32, vp, vp, vp, vp]
     lib.orc_trace.argtypes = [sp, i32, vp, vp, vp, vp, vp]
     lib.orc_shadow_trace.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_shadow_trace_anyhit.argtypes = [sp, i32, vp, vp, vp, vp, vp]
     lib.orc_eval_surface.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_path_trace.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
@@ -115,6 +116,16 @@ class Oracle:
         vis = np.empty(n, np.float32)
         self.lib.orc_shadow_trace(C.byref(self.s), n, _p(pos4), _p(dir4), _p(tfar), _p(vis))
         return vis
+
+    def shadow_trace_anyhit(self, pos4, dir4, tfar, counters=False):
+        """the early-out shadow walk (ref: ctrace.h:1065-1294); counters = uint32 [n, 4] quads, instance quads, triangles, leaves"""
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        tfar = np.ascontiguousarray(tfar, np.float32)
+        n = pos4.shape[0]
+        vis = np.empty(n, np.float32)
+        cnt = np.empty((n, 4), np.uint32) if counters else None
+        self.lib.orc_shadow_trace_anyhit(C.byref(self.s), n, _p(pos4), _p(dir4), _p(tfar), _p(vis), _p(cnt))
+        return (vis, cnt) if counters else vis
 
     def eval_surface(self, pos4, dir4, hits):
         pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)

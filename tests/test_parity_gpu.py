@@ -177,6 +177,35 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
         core.set_option("trace_min_active", defaults[1])
 
 
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium"])
+def test_persistent_counting_kernels_total_what_the_oracle_counts(fix, request):
+    """k_trace_dyn<*, true> -- the kernels bench.py prices its roofline bytes with -- against the oracle's per-ray counters
+    summed: rays, quads visited, instance quads entered, leaves visited, triangles tested; closest hit and the early-out
+    shadow walk (ctrace.h:1065-1294).  The sixth total counts fetches a range-checked buffer load would have answered with
+    zeros: none may exist."""
+    core, b, orc = request.getfixturevalue(fix)
+    pos4, dir4 = random_rays(65536, 91) if fix != "gpu_atrium" else random_rays(65536, 91, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
+    tfar = np.random.default_rng(6).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
+    assert core.get_option("trace_mode") == 1 and core.get_option("top_quads_in_lds") == 21
+    tot = core.stage_trace_totals(pos4, dir4)
+    _, rcnt, rleaves = orc.trace(pos4, dir4, counters=True)
+    want = [len(pos4), int(rcnt[:, 0].sum()), int(rcnt[:, 1].sum()), int(rleaves.sum()), int(rcnt[:, 2].sum()), 0]
+    assert [int(x) for x in tot] == want
+    stot = core.stage_trace_totals(pos4, dir4, tfar)
+    _, acnt = orc.shadow_trace_anyhit(pos4, dir4, tfar, counters=True)
+    want = [len(pos4), int(acnt[:, 0].sum()), int(acnt[:, 1].sum()), int(acnt[:, 3].sum()), int(acnt[:, 2].sum()), 0]
+    assert [int(x) for x in stot] == want
+    # and inside a pass: no out-of-range fetch in any bounce of a whole frame
+    core.set_tile_partition(0, 1, 64)
+    core.init_path_tracing(5)
+    core.enable_traversal_counters(True)
+    core.trace_pass(2)
+    core.finish()
+    cnt = core.traversal_counters(5)
+    core.enable_traversal_counters(False)
+    assert core.traversal_oob() == 0 and int(cnt[0, 0, 0]) == 2 * b["width"] * b["height"]
+
+
 def test_surface_reconstruction(gpu224):
     core, b, orc = gpu224
     pos4, dir4 = random_rays(16384, 45)
