@@ -29,6 +29,12 @@ class RaysStat(C.Structure):         # HydraRaysStat
                 ("traceLaunches", C.c_uint64), ("shadowLaunches", C.c_uint64)]
 
 
+class StatePlan(C.Structure):       # HydraStatePlan, include/hydra_hip.h
+    _fields_ = [("samples_in_flight", C.c_int32), ("pad_", C.c_int32), ("owned_pixels", C.c_int64), ("paths", C.c_int64),
+                ("segments", C.c_int64), ("segment_capacity", C.c_int64), ("path_state_bytes", C.c_int64),
+                ("generator_bytes", C.c_int64), ("contrib_bytes", C.c_int64), ("owned_map_bytes", C.c_int64), ("total_bytes", C.c_int64)]
+
+
 LITE_HIT_DTYPE = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
 
 # every entry point include/hydra_hip.h declares (checked by tests/test_capi_symbols.py against the header text)
@@ -36,9 +42,9 @@ C_ABI_SYMBOLS = [
     "hydra_hip_create", "hydra_hip_destroy", "hydra_hip_last_error", "hydra_hip_device_name", "hydra_hip_resize",
     "hydra_hip_available_memory", "hydra_hip_finish", "hydra_hip_upload_globals", "hydra_hip_update_globals_header",
     "hydra_hip_upload_storage", "hydra_hip_upload_bvh", "hydra_hip_set_bvh_trees_num", "hydra_hip_upload_instances",
-    "hydra_hip_upload_remap_lists", "hydra_hip_set_tile_partition", "hydra_hip_set_external_accumulator",
+    "hydra_hip_upload_remap_lists", "hydra_hip_set_tile_partition", "hydra_hip_tile_owners", "hydra_hip_plan_render_state", "hydra_hip_set_external_accumulator",
     "hydra_hip_init_path_tracing", "hydra_hip_clear_accumulated_color", "hydra_hip_trace_pass", "hydra_hip_set_spp",
-    "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_rays_stat",
+    "hydra_hip_get_spp", "hydra_hip_get_hdr_image", "hydra_hip_get_ldr_image", "hydra_hip_get_accumulator", "hydra_hip_get_rays_stat",
     "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_get_stage_times_per_bounce", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
     "hydra_hip_get_traversal_counters", "hydra_hip_get_traversal_oob", "hydra_hip_stage_trace_totals", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
@@ -77,6 +83,8 @@ def load_hip_library():
         "hydra_hip_upload_remap_lists": ([vp, vp, i32, vp, i32, vp, i32], i32),
         "hydra_hip_set_tile_partition": ([vp, i32, i32, i32], i32),
         "hydra_hip_set_external_accumulator": ([vp, vp, sz], i32),
+        "hydra_hip_tile_owners": ([i32, i32, i32, i32, vp, i32], i32),
+        "hydra_hip_plan_render_state": ([i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(StatePlan), C.c_char_p, i32], i32),
         "hydra_hip_init_path_tracing": ([vp, i32], i32),
         "hydra_hip_clear_accumulated_color": ([vp], i32),
         "hydra_hip_trace_pass": ([vp, i32], i32),
@@ -84,6 +92,7 @@ def load_hip_library():
         "hydra_hip_get_spp": ([vp], C.c_float),
         "hydra_hip_get_hdr_image": ([vp, vp, i32, i32], i32),
         "hydra_hip_get_ldr_image": ([vp, vp, i32, i32], i32),
+        "hydra_hip_get_accumulator": ([vp, vp, i32, i32], i32),
         "hydra_hip_get_rays_stat": ([vp, C.POINTER(RaysStat)], i32),
         "hydra_hip_reset_perf_counters": ([vp], i32),
         "hydra_hip_enable_stage_timing": ([vp, i32], i32),
@@ -109,6 +118,26 @@ def load_hip_library():
         fn.restype = res
     _hip = lib
     return lib
+
+
+def plan_render_state(width, height, rank=0, world=1, tile=64, samples_in_flight=0, queue_segments=32, fused_bounce=1):
+    """hydra_hip_plan_render_state: sizes of one rank's render state (host arithmetic, no device); raises HydraError on a limit"""
+    lib = load_hip_library()
+    plan, err = StatePlan(), C.create_string_buffer(256)
+    rc = lib.hydra_hip_plan_render_state(width, height, rank, world, tile, samples_in_flight, queue_segments, fused_bounce, C.byref(plan), err, 256)
+    if rc != 0:
+        raise HydraError("plan_render_state: %s" % err.value.decode())
+    return {k: getattr(plan, k) for k, _ in StatePlan._fields_ if k != "pad_"}
+
+
+def tile_owners(width, height, world, tile=64):
+    """int32 [tilesY, tilesX]: the rank that owns each tile (hydra_hip_tile_owners: Morton order, round-robin)"""
+    lib = load_hip_library()
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    out = np.zeros((ty, tx), np.int32)
+    if lib.hydra_hip_tile_owners(width, height, world, tile, out.ctypes.data_as(C.c_void_p), tx * ty) != 0:
+        raise HydraError("tile_owners: bad arguments")
+    return out
 
 
 def load_host_library():
@@ -141,6 +170,12 @@ def load_host_library():
     lib.hydra_host_get_hdr.restype = i32
     lib.hydra_host_get_spp.argtypes = [vp]
     lib.hydra_host_get_spp.restype = C.c_float
+    lib.hydra_host_shared_image_open.argtypes = [vp, vp, i32, i32, i32]
+    lib.hydra_host_shared_image_open.restype = vp
+    lib.hydra_host_shared_image_stat.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    lib.hydra_host_shared_image_stat.restype = i32
+    lib.hydra_host_shared_image_close.argtypes = [vp, vp]
+    lib.hydra_host_shared_image_close.restype = None
     lib.hydra_host_bvh_stats.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.hydra_host_bvh_stats.restype = i32
     _host = lib
@@ -238,6 +273,12 @@ class HipCore:
     def hdr_image(self, w, h):
         out = np.empty((h, w, 4), np.float32)
         self._ck(self.lib.hydra_hip_get_hdr_image(self.h, _ptr(out), w, h), "get_hdr_image")
+        return out
+
+    def accumulator(self, w, h):
+        """the float4 sums themselves (hydra_hip_get_accumulator)"""
+        out = np.empty((h, w, 4), np.float32)
+        self._ck(self.lib.hydra_hip_get_accumulator(self.h, _ptr(out), w, h), "get_accumulator")
         return out
 
     def ldr_image(self, w, h):
@@ -434,6 +475,23 @@ class HostScene:
 
     def spp(self):
         return float(self.lib.hydra_host_get_spp(self.p))
+
+    def shared_image(self, rgba, attach):
+        """drive IHWLayer::SetExternalImageAccumulator (attach=True) or one ContribToExternalImageAccumulator call (attach=False)
+        with an in-process shared accumulation image over the float32 [h, w, 4] array `rgba`; returns a handle for shared_image_stat / _close"""
+        assert rgba.dtype == np.float32 and rgba.shape == (self.height, self.width, 4) and rgba.flags["C_CONTIGUOUS"]
+        h = self.lib.hydra_host_shared_image_open(self.p, _ptr(rgba), self.width, self.height, 1 if attach else 0)
+        if not h:
+            raise HydraError("shared_image: %s" % self.lib.hydra_host_last_error(self.p).decode())
+        return h
+
+    def shared_image_stat(self, handle):
+        spp, rcv = C.c_float(0), C.c_int(0)
+        self.lib.hydra_host_shared_image_stat(handle, C.byref(spp), C.byref(rcv))
+        return float(spp.value), int(rcv.value)
+
+    def shared_image_close(self, handle):
+        self.lib.hydra_host_shared_image_close(self.p, handle)
 
     def bvh_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()

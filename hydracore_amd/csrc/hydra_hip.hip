@@ -20,6 +20,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <thread>
 #include "../../include/hydra_hip.h"
 #include "hk_common.h"
 #include "hk_trace.h"
@@ -91,11 +92,12 @@ HK_DEV SegIter segq_iter(const SegQ& q) {
 // default) or pixel-major (p = pixelIndex * ns + stream: the 64 lanes of a wave are 64 / ns neighbouring pixels x ns samples;
 // measured within noise of the default, profiles/r01/pass_path_order.log).  Paths are dealt to the queue segments in
 // chunks of 256: chunk c -> segment c % nseg, so slot idx of segment seg holds path ((idx / 256) * nseg + seg) * 256 + idx % 256.
-// gid = stream * (w*h) + pixel is the index of the path's RandomGen state and of its contribution record.
+// gid = stream * nOwned + pixelIndex is the index of the path's RandomGen state and of its contribution record: both arrays
+// hold only what this rank owns (1/world of the frame), while the generator itself is seeded from the GLOBAL slot
+// stream * (w*h) + pixel (k_init_gens), so the image does not depend on the partition.
 __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels, int nOwned, int ns, int streamMajor,
                          const uint2* __restrict__ gens, int w, int h, PathState S) {
   const SegIter it = segq_iter(q);
-  const int npix = w * h;
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const long long p = ((long long)(idx >> 8) * q.nseg + it.seg) * 256 + (idx & 255);
@@ -103,7 +105,7 @@ __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels
     if (streamMajor) { stream = int(p / nOwned); pixIdx = int(p - (long long)stream * nOwned); }
     else { pixIdx = int(p / ns); stream = int(p - (long long)pixIdx * ns); }
     const int pixel = ownedPixels[pixIdx];
-    const int gid = stream * npix + pixel;
+    const int gid = stream * nOwned + pixIdx;   // < 2^31: alloc_render_state checks nOwned * K
     const uint2 g2 = gens[gid];
     RandomGen gen; gen.x = g2.x; gen.y = g2.y;
     const float4 r = rndFloat4_Pseudo(gen);   // rndUniform(gen, -1, 1), crandom.h:617-620
@@ -541,12 +543,12 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ 
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
 // one thread per owned pixel adds the `streams` samples of this sub-pass in stream order, so the sum does not depend on
 // where the paths lived in the queues
-__global__ void k_accumulate(int n, const int* __restrict__ ownedPixels, const float4* __restrict__ contrib, float4* __restrict__ accum, int npix, int streams) {
+__global__ void k_accumulate(int n, const int* __restrict__ ownedPixels, const float4* __restrict__ contrib, float4* __restrict__ accum, int streams) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int pixel = ownedPixels[i];
     float4 a = accum[pixel];
     for (int k = 0; k < streams; k++) {
-      const float4 c = contrib[size_t(k) * npix + pixel];
+      const float4 c = contrib[size_t(k) * n + i];
       a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
     }
     accum[pixel] = a;
@@ -599,9 +601,14 @@ __global__ void k_prepare_bvh(int nodes, float4* __restrict__ bvh) {
     }
   }
 }
-__global__ void k_init_gens(int n, int seed, uint2* gens) {   // InitRandomGen, shaders/trace.cl:6-13 (slot = stream * pixels + pixel)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const RandomGen g = RandomGenInit(seed + i);
+// InitRandomGen, shaders/trace.cl:6-13, with slot = stream * (w*h) + pixel: generator `stream` of owned pixel i.  The slot is
+// formed in 32-bit wrap-around arithmetic like the reference's `a_seed + tid`; alloc_render_state keeps K * w * h below 2^32
+// so that no two slots coincide.
+__global__ void k_init_gens(int nOwned, int streams, const int* __restrict__ ownedPixels, unsigned npix, int seed, uint2* gens) {
+  const size_t total = size_t(nOwned) * size_t(streams);
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
+    const unsigned stream = unsigned(i / size_t(nOwned)), pixel = unsigned(ownedPixels[i - size_t(stream) * nOwned]);
+    const RandomGen g = RandomGenInit(int(unsigned(seed) + stream * npix + pixel));
     gens[i] = make_uint2(g.x, g.y);
   }
 }
@@ -921,21 +928,42 @@ static int prepare_geometry(hydra_hip_ctx* c) {
   return HYDRA_HIP_OK;
 }
 
-// slot -> pixel map: owned tiles (tile % world == rank), pixels inside a tile in 8x8 blocks so that one wave = one block
-static void build_slot_map(hydra_hip_ctx* c, std::vector<int>& out) {
-  out.clear();
-  const int T = c->tile, w = c->w, h = c->h;
+// Tile ownership: the T x T tiles of the image plane are ordered along the Morton (Z) curve of their tile
+// coordinates and dealt round-robin, the i-th tile of that order going to rank i % world.  Every rank then owns tiles from
+// all over the frame (path-length differences between image regions average out without any exchange of cost figures),
+// whatever the number of tiles per row, and walks its own tiles in an order that keeps neighbours together.
+static inline uint32_t morton2(uint32_t x, uint32_t y) {
+  auto spread = [](uint32_t v) { v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+  return spread(x) | (spread(y) << 1);
+}
+// tiles (row-major tile index) in Morton order
+static std::vector<int> morton_tile_order(int tilesX, int tilesY) {
+  std::vector<std::pair<uint32_t, int>> t;
+  t.reserve(size_t(tilesX) * tilesY);
+  for (int ty = 0; ty < tilesY; ty++) for (int tx = 0; tx < tilesX; tx++) t.push_back({morton2(uint32_t(tx), uint32_t(ty)), ty * tilesX + tx});
+  std::sort(t.begin(), t.end());
+  std::vector<int> out(t.size());
+  for (size_t i = 0; i < t.size(); i++) out[i] = t[i].second;
+  return out;
+}
+// slot -> pixel map: this rank's tiles in Morton order, pixels inside a tile in 8x8 blocks so that one wave = one block
+static void build_slot_map(int w, int h, int T, int rank, int world, std::vector<int>* out, long long* count) {
+  if (out) out->clear();
+  long long n = 0;
   const int tilesX = (w + T - 1) / T, tilesY = (h + T - 1) / T;
-  for (int ty = 0; ty < tilesY; ty++)
-    for (int tx = 0; tx < tilesX; tx++) {
-      const int t = ty * tilesX + tx;
-      if (c->world > 1 && (t % c->world) != c->rank) continue;
-      const int x0 = tx * T, y0 = ty * T, x1 = std::min(x0 + T, w), y1 = std::min(y0 + T, h);
-      for (int by = y0; by < y1; by += 8)
-        for (int bx = x0; bx < x1; bx += 8)
-          for (int y = by; y < std::min(by + 8, y1); y++)
-            for (int x = bx; x < std::min(bx + 8, x1); x++) out.push_back(y * w + x);
-    }
+  const std::vector<int> order = morton_tile_order(tilesX, tilesY);
+  for (size_t i = 0; i < order.size(); i++) {
+    if (world > 1 && int(i % size_t(world)) != rank) continue;
+    const int tx = order[i] % tilesX, ty = order[i] / tilesX;
+    const int x0 = tx * T, y0 = ty * T, x1 = std::min(x0 + T, w), y1 = std::min(y0 + T, h);
+    n += (long long)(x1 - x0) * (y1 - y0);
+    if (!out) continue;
+    for (int by = y0; by < y1; by += 8)
+      for (int bx = x0; bx < x1; bx += 8)
+        for (int y = by; y < std::min(by + 8, y1); y++)
+          for (int x = bx; x < std::min(bx + 8, x1); x++) out->push_back(y * w + x);
+  }
+  if (count) *count = n;
 }
 
 // samples per pixel in flight when the caller does not say: enough paths to keep late bounces (a few percent of the
@@ -947,23 +975,50 @@ static int auto_streams(size_t npix) {
   return k;
 }
 
+// Sizes of everything a render state holds; pure host arithmetic (no device), shared by alloc_render_state and by
+// hydra_hip_plan_render_state so that the limits can be checked without a GPU.
+static int plan_render_state(int w, int h, int rank, int world, int tile, int streamsWanted, int nsegWanted, int fused, HydraStatePlan* p, std::string* err) {
+  memset(p, 0, sizeof(*p));
+  if (w <= 0 || h <= 0 || world < 1 || rank < 0 || rank >= world || tile < 8 || (tile % 8) != 0) { *err = "plan_render_state: bad arguments"; return HYDRA_HIP_EINVAL; }
+  const size_t npix = size_t(w) * h;
+  long long owned = 0;
+  build_slot_map(w, h, tile, rank, world, nullptr, &owned);
+  const int K = streamsWanted > 0 ? streamsWanted : auto_streams(npix);
+  p->samples_in_flight = K;
+  p->owned_pixels = owned;
+  // generator slots stream * w * h + pixel are 32-bit (k_init_gens); path/record indices stream * N + pixelIndex are ints
+  if (size_t(K) * npix > size_t(0xffffffffu)) { *err = "samples_in_flight * width * height must stay below 2^32"; return HYDRA_HIP_EINVAL; }
+  if ((long long)K * owned > 0x7fffffffll) { *err = "samples_in_flight * owned pixels must stay below 2^31 (use more ranks or fewer samples in flight)"; return HYDRA_HIP_EINVAL; }
+  // Paths are dealt to the queue segments in 256-path chunks round-robin (see k_raygen), so every segment sees the whole
+  // image and path-length differences between image regions do not unbalance them.
+  const long long maxPaths = owned * K;
+  const long long maxChunks = (maxPaths + 255) / 256;
+  const int nseg = int(std::max<long long>(1, std::min<long long>(std::min(nsegWanted, HK_MAX_SEG), maxChunks)));
+  const long long cap = std::max<long long>(1, (maxChunks + nseg - 1) / nseg) * 256;
+  if (cap * nseg > 0x7fffffffll) { *err = "too many path slots"; return HYDRA_HIP_EINVAL; }
+  p->paths = maxPaths; p->segments = nseg; p->segment_capacity = cap;
+  const long long slots = cap * nseg;
+  // path state: only the arrays of the form in use are held (fused: 13 float4 + 2 uint2 + 1 float, split: 14 float4 + 2 uint2 + 1 float per slot)
+  p->path_state_bytes = slots * ((fused ? 13 : 14) * 16 + 2 * 8 + 4);
+  p->generator_bytes = std::max<long long>(1, owned) * K * 8;
+  p->contrib_bytes = std::max<long long>(1, owned) * K * 16;
+  p->owned_map_bytes = owned * 4;
+  p->total_bytes = p->path_state_bytes + p->generator_bytes + p->contrib_bytes + p->owned_map_bytes;
+  return HYDRA_HIP_OK;
+}
+
 static int alloc_render_state(hydra_hip_ctx* c) {
+  HydraStatePlan plan;
+  { std::string e; const int prc = plan_render_state(c->w, c->h, c->rank, c->world, c->tile, c->streamsWanted, c->nsegWanted, c->fusedBounce, &plan, &e); if (prc) return fail(c, prc, e); }
   std::vector<int> order;
-  build_slot_map(c, order);
+  build_slot_map(c->w, c->h, c->tile, c->rank, c->world, &order, nullptr);
   c->N = int(order.size());
   const size_t npix = size_t(c->w) * c->h;
-  const int K = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(npix);
+  const int K = plan.samples_in_flight;
   if (K != c->streams) c->gensReady = false;
   c->streams = K;
-  if (size_t(K) * npix > size_t(0x7fffffff)) return fail(c, HYDRA_HIP_EINVAL, "samples_in_flight * width * height must stay below 2^31");
-  // Paths are dealt to the queue segments in 256-path chunks round-robin (see k_raygen), so every segment sees the whole
-  // image and path-length differences between image regions do not unbalance them.  Row ns-1 of liveInit holds the
-  // per-segment path counts of a sub-pass that traces ns samples per pixel.
-  const long long maxPaths = (long long)c->N * K;
-  const long long maxChunks = (maxPaths + 255) / 256;
-  c->nseg = int(std::max<long long>(1, std::min<long long>(std::min(c->nsegWanted, HK_MAX_SEG), maxChunks)));
-  const long long cap = std::max<long long>(1, (maxChunks + c->nseg - 1) / c->nseg) * 256;
-  if (cap * c->nseg > 0x7fffffffll) return fail(c, HYDRA_HIP_EINVAL, "too many path slots");
+  c->nseg = int(plan.segments);
+  const long long cap = plan.segment_capacity;
   c->segCap = int(cap);
   std::vector<uint32_t> init(size_t(K) * HK_CROW, 0u);
   for (int ns = 1; ns <= K; ns++) {
@@ -980,8 +1035,8 @@ static int alloc_render_state(hydra_hip_ctx* c) {
   int rc;
   if ((rc = dev_upload(c, c->ownedPixels, order.data(), order.size() * 4)) != 0) return rc;
   if ((rc = dev_upload(c, c->liveInit, init.data(), init.size() * 4)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->gens, npix * K * 8)) != 0) return rc;
-  if ((rc = dev_alloc(c, c->contrib, npix * K * 16)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->gens, std::max<size_t>(1, size_t(c->N)) * K * 8)) != 0) return rc;      // per owned pixel: state scales with 1 / world
+  if ((rc = dev_alloc(c, c->contrib, std::max<size_t>(1, size_t(c->N)) * K * 16)) != 0) return rc;
   if (!c->externalAccum) {
     const bool fresh = (c->accumInternal.bytes < npix * 16);
     if ((rc = dev_alloc(c, c->accumInternal, npix * 16)) != 0) return rc;
@@ -1117,6 +1172,15 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   return HYDRA_HIP_OK;
 }
 
+// rows [y0, y1) of a frame on up to 16 host threads (readout only; nothing here is on the hot path)
+template <class F>
+static void parallel_rows(int height, F body) {
+  const int nt = std::max(1, std::min(16, std::min(height / 64, int(std::thread::hardware_concurrency()))));
+  if (nt <= 1) { body(0, height); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++) th.emplace_back([=]() { body(int((long long)height * t / nt), int((long long)height * (t + 1) / nt)); });
+  for (auto& t : th) t.join();
+}
 extern "C" {
 
 int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_handle* out) {
@@ -1458,8 +1522,25 @@ int hydra_hip_upload_remap_lists(hydra_hip_handle c, const int32_t* all_lists, i
 
 int hydra_hip_set_tile_partition(hydra_hip_handle c, int rank, int world, int tile) {
   if (!c || world < 1 || rank < 0 || rank >= world || tile < 8 || (tile % 8) != 0) return fail(c, HYDRA_HIP_EINVAL, "set_tile_partition: need 0 <= rank < world and tile a multiple of 8");
+  if (rank != c->rank || world != c->world || tile != c->tile) c->gensReady = false;   // generator states are kept per OWNED pixel: a new partition restarts the image
   c->rank = rank; c->world = world; c->tile = tile;
   c->stateAllocated = false;
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_plan_render_state(int width, int height, int rank, int world, int tile_size, int samples_in_flight, int queue_segments, int fused_bounce,
+                                HydraStatePlan* out, char* err, int err_len) {
+  if (!out) return HYDRA_HIP_EINVAL;
+  std::string e;
+  const int rc = plan_render_state(width, height, rank, world, tile_size, samples_in_flight, queue_segments > 0 ? queue_segments : 32, fused_bounce, out, &e);
+  if (rc && err && err_len > 0) { strncpy(err, e.c_str(), size_t(err_len - 1)); err[err_len - 1] = 0; }
+  return rc;
+}
+int hydra_hip_tile_owners(int width, int height, int world, int tile_size, int32_t* owner_of_tile, int tiles) {
+  if (width <= 0 || height <= 0 || world < 1 || tile_size < 8 || !owner_of_tile) return HYDRA_HIP_EINVAL;
+  const int tilesX = (width + tile_size - 1) / tile_size, tilesY = (height + tile_size - 1) / tile_size;
+  if (tiles != tilesX * tilesY) return HYDRA_HIP_EINVAL;
+  const std::vector<int> order = morton_tile_order(tilesX, tilesY);
+  for (size_t i = 0; i < order.size(); i++) owner_of_tile[order[i]] = int(i % size_t(world));
   return HYDRA_HIP_OK;
 }
 int hydra_hip_set_external_accumulator(hydra_hip_handle c, void* dev, size_t bytes) {
@@ -1475,8 +1556,11 @@ int hydra_hip_init_path_tracing(hydra_hip_handle c, int seed) {
   HCHECK(hipSetDevice(c->device));
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   c->seed = seed;
-  const int ngen = c->w * c->h * c->streams;
-  hipLaunchKernelGGL(k_init_gens, dim3(grid_for(c, ngen, 256, 8)), dim3(256), 0, c->stream, ngen, seed, static_cast<uint2*>(c->gens.p));
+  if (c->N > 0) {
+    const size_t ngen = size_t(c->N) * c->streams;
+    hipLaunchKernelGGL(k_init_gens, dim3(grid_for(c, int(std::min<size_t>(ngen, size_t(1) << 30)), 256, 8)), dim3(256), 0, c->stream, c->N, c->streams,
+                       static_cast<const int*>(c->ownedPixels.p), unsigned(c->w) * unsigned(c->h), seed, static_cast<uint2*>(c->gens.p));
+  }
   HCHECK(hipGetLastError());
   c->gensReady = true;
   return hydra_hip_clear_accumulated_color(c);
@@ -1555,7 +1639,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, bb, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
                            static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
     int g0 = mark();
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, c->w * c->h, ns);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, ns);
     hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, c->nseg, static_cast<unsigned long long*>(c->totals.p));
     int g1 = mark();
     if (timing) { c->spans.push_back({g0, g1, 5, -1}); c->spans.push_back({e0, g1, 6, -1}); }
@@ -1569,15 +1653,23 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
 int hydra_hip_set_spp(hydra_hip_handle c, float spp) { if (!c) return HYDRA_HIP_EINVAL; c->spp = spp; return HYDRA_HIP_OK; }
 float hydra_hip_get_spp(hydra_hip_handle c) { return c ? c->spp : 0.0f; }
 
+int hydra_hip_get_accumulator(hydra_hip_handle c, float* rgba_sums, int width, int height) {
+  if (!c || !rgba_sums) return HYDRA_HIP_EINVAL;
+  if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "get_accumulator: bad input resolution");
+  if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "get_accumulator: nothing rendered yet");
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->stream));
+  HCHECK(hipMemcpy(rgba_sums, c->accum, size_t(width) * height * 16, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
 int hydra_hip_get_hdr_image(hydra_hip_handle c, float* rgba, int width, int height) {
   if (!c || !rgba) return HYDRA_HIP_EINVAL;
   if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "get_hdr_image: bad input resolution");
   if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "get_hdr_image: nothing rendered yet");
-  HCHECK(hipSetDevice(c->device));
-  const size_t n = size_t(width) * height;
-  HCHECK(hipMemcpy(rgba, c->accum, n * 16, hipMemcpyDeviceToHost));
+  const int rc = hydra_hip_get_accumulator(c, rgba, width, height);
+  if (rc) return rc;
   const float inv = c->spp > 0.0f ? 1.0f / c->spp : 0.0f;
-  for (size_t i = 0; i < n * 4; i++) rgba[i] *= inv;
+  parallel_rows(height, [=](int y0, int y1) { for (size_t i = size_t(y0) * width * 4; i < size_t(y1) * width * 4; i++) rgba[i] *= inv; });
   return HYDRA_HIP_OK;
 }
 // IntegratorCommon::GetImageToLDR (Common.cpp:319-333): clamp to 1, linear -> sRGB, pack RGBA8
@@ -1586,14 +1678,17 @@ int hydra_hip_get_ldr_image(hydra_hip_handle c, uint32_t* out, int width, int he
   std::vector<float> hdr(size_t(width) * height * 4);
   const int rc = hydra_hip_get_hdr_image(c, hdr.data(), width, height);
   if (rc) return rc;
-  auto toSRGB = [](float l) { return (l <= 0.00313066844250063f) ? l * 12.92f : float(1.055 * double(powf(l, 1.0f / 2.4f)) - 0.055); };
-  for (size_t i = 0; i < size_t(width) * height; i++) {
-    float ch[4];
-    for (int k = 0; k < 4; k++) ch[k] = fminf(hdr[4 * i + k], 1.0f);
-    for (int k = 0; k < 3; k++) ch[k] = toSRGB(ch[k]);
-    const unsigned char r = (unsigned char)(ch[0] * 255.0f), g = (unsigned char)(ch[1] * 255.0f), b = (unsigned char)(ch[2] * 255.0f), a = (unsigned char)(ch[3] * 255.0f);
-    out[i] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | (uint32_t(a) << 24);
-  }
+  const float* src = hdr.data();
+  parallel_rows(height, [=](int y0, int y1) {
+    auto toSRGB = [](float l) { return (l <= 0.00313066844250063f) ? l * 12.92f : float(1.055 * double(powf(l, 1.0f / 2.4f)) - 0.055); };
+    for (size_t i = size_t(y0) * width; i < size_t(y1) * width; i++) {
+      float ch[4];
+      for (int k = 0; k < 4; k++) ch[k] = fminf(src[4 * i + k], 1.0f);
+      for (int k = 0; k < 3; k++) ch[k] = toSRGB(ch[k]);
+      const unsigned char r = (unsigned char)(ch[0] * 255.0f), g = (unsigned char)(ch[1] * 255.0f), b = (unsigned char)(ch[2] * 255.0f), a = (unsigned char)(ch[3] * 255.0f);
+      out[i] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | (uint32_t(a) << 24);
+    }
+  });
   return HYDRA_HIP_OK;
 }
 

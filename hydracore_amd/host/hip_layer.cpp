@@ -46,7 +46,7 @@ public:
     m_tablesUploaded = true;
   }
 
-  void SetAllBVH4(const ConvertionResult& cr, void* a_builder, int a_flags) override {
+  void SetAllBVH4(const ConvertionResult& cr, IBVHBuilder2* a_builder, int a_flags) override {
     SharedDataLayer::SetAllBVH4(cr, a_builder, a_flags);   // host copy for debugging / CPU cross-checks
     for (int i = 0; i < cr.treesNum; i++)
       check(hydra_hip_upload_bvh(m_h, i, cr.pBVH[i], cr.nodesNum[i], cr.pTriangleData[i], cr.trif4Num[i],
@@ -62,8 +62,8 @@ public:
     SharedDataLayer::SetAllInstLightInstId(ids, n);
     upload_instances();
   }
-  void SetAllRemapLists(const int* a_allLists, const int* a_tableInt2, int a_allSize, int a_tableSize) override {
-    SharedDataLayer::SetAllRemapLists(a_allLists, a_tableInt2, a_allSize, a_tableSize);
+  void SetAllRemapLists(const int* a_allLists, const int2* a_table, int a_allSize, int a_tableSize) override {
+    SharedDataLayer::SetAllRemapLists(a_allLists, a_table, a_allSize, a_tableSize);
     upload_remap();
   }
   void SetAllInstIdToRemapId(const int* a_allInstId, int a_instNum) override {
@@ -74,7 +74,9 @@ public:
   void InitPathTracing(int seed, std::vector<int32_t>* = nullptr) override { check(hydra_hip_init_path_tracing(m_h, seed), "InitPathTracing"); }
   void ClearAccumulatedColor() override { check(hydra_hip_clear_accumulated_color(m_h), "ClearAccumulatedColor"); }
   void BeginTracingPass() override { check(hydra_hip_trace_pass(m_h, GetRaysPerPixel()), "BeginTracingPass"); }
-  void EndTracingPass() override {}
+  // with a shared accumulation image attached, every pass ends by adding its samples to it (the reference's layers do
+  // this inside their per-pass contribution, GPUOCLLayerOther.cpp:259-283)
+  void EndTracingPass() override { if (m_pExternalImage != nullptr) ContribToExternalImageAccumulator(m_pExternalImage); }
   void FinishAll() override { check(hydra_hip_finish(m_h), "FinishAll"); }
   void SetRaysPerPixel(int a_num) override { m_spp = a_num > 0 ? a_num : 1; }
   int  GetRaysPerPixel() const override { return m_spp; }
@@ -87,7 +89,7 @@ public:
     return st;
   }
   // size mismatch: silently return, as CPUExpLayer does (hydra_drv/CPUExpLayer.cpp:133-147)
-  void GetHDRImage(float* data4, int width, int height) const override { hydra_hip_get_hdr_image(m_h, data4, width, height); }
+  void GetHDRImage(float4* data, int width, int height) const override { hydra_hip_get_hdr_image(m_h, &data->x, width, height); }
   void GetLDRImage(uint32_t* data, int width, int height) const override { hydra_hip_get_ldr_image(m_h, data, width, height); }
   float GetSPP() const override { return hydra_hip_get_spp(m_h); }
 
@@ -96,10 +98,30 @@ public:
     hydra_hip_available_memory(m_h, &f, &t);
     return allMem ? t : f;
   }
-  void SetExternalImageAccumulator(void* a_pImage, size_t a_bytes) override {
-    SharedDataLayer::SetExternalImageAccumulator(a_pImage, a_bytes);
-    check(hydra_hip_set_external_accumulator(m_h, a_pImage, a_bytes), "SetExternalImageAccumulator");
+  // IHWLayer::SetExternalImageAccumulator (:199) keeps the pointer (base class); the contribution itself:
+  // GPUOCLLayer::ContribToExternalImageAccumulator (GPUOCLLayerOther.cpp:365-429): internal sums += into the shared image
+  // under its lock, spp and the receive counter advance, the internal accumulator restarts.
+  void ContribToExternalImageAccumulator(IHRSharedAccumImage* a_pImage) override {
+    if (a_pImage == nullptr) return;
+    const float spp = hydra_hip_get_spp(m_h);
+    if (spp <= 0.0f) return;
+    m_sums.resize(size_t(m_width) * m_height * 4);
+    check(hydra_hip_get_accumulator(m_h, m_sums.data(), m_width, m_height), "ContribToExternalImageAccumulator");
+    if (!a_pImage->Lock(100)) return;                        // busy: the samples stay in the internal accumulator for the next call
+    HRSharedBufferHeader* hdr = a_pImage->Header();
+    if (hdr->width != m_width || hdr->height != m_height || hdr->channels != 4) { a_pImage->Unlock(); RunTimeError("HipHWLayer::ContribToExternalImageAccumulator: shared image does not match the frame"); }
+    float* out = a_pImage->ImageData(0);
+    for (size_t i = 0; i < m_sums.size(); i++) out[i] += m_sums[i];
+    hdr->counterRcv++;
+    hdr->spp += spp;
+    a_pImage->Unlock();
+    ClearAccumulatedColor();
+    m_sppContrib += spp;
   }
+  float GetSPPContrib() const override { return m_sppContrib; }
+  // multi-GPU tile partition: a caller-owned DEVICE accumulator (float4 sums), exchanged over RCCL by the caller or by
+  // hydra_hip_comm_* (include/hydra_hip.h); not part of IHWLayer
+  void SetExternalDeviceAccumulator(void* a_devFloat4, size_t a_bytes) { check(hydra_hip_set_external_accumulator(m_h, a_devFloat4, a_bytes), "SetExternalDeviceAccumulator"); }
   hydra_hip_handle Handle() const { return m_h; }
 
 private:
@@ -107,6 +129,8 @@ private:
   char m_devName[256] = {0};
   bool m_tablesUploaded = false;
   int m_spp = 1;
+  float m_sppContrib = 0.0f;
+  std::vector<float> m_sums;
 
   void check(int rc, const char* where) const {
     if (rc != HYDRA_HIP_OK) RunTimeError(std::string("HipHWLayer::") + where + ": " + hydra_hip_last_error(m_h));

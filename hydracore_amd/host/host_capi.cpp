@@ -4,6 +4,8 @@
 #include "render_driver_lite.h"
 #include <cstring>
 #include <cstdio>
+#include <mutex>
+#include <chrono>
 
 namespace hydra_host { void* HipLayerHandle(IHWLayer* layer); }
 using namespace hydra_host;
@@ -11,6 +13,20 @@ using namespace hydra_host;
 struct HostScene {
   RenderDriverLite* drv = nullptr;
   std::string err;
+};
+
+// an in-process IHRSharedAccumImage over caller memory: what HydraAPI's shared-memory image is to the reference's layers
+// (Lock with a time-out / Unlock around `+=`; header with spp and the receive counter).  Used by the harness to drive
+// IHWLayer::SetExternalImageAccumulator / ContribToExternalImageAccumulator.
+struct LocalAccumImage : public IHRSharedAccumImage {
+  LocalAccumImage(float* data, int w, int h) : m_data(data) { m_hdr = HRSharedBufferHeader{w, h, 1, 4, 0.0f, 0, 0}; }
+  bool Lock(int ms) override { return m_mutex.try_lock_for(std::chrono::milliseconds(ms)); }
+  void Unlock() override { m_mutex.unlock(); }
+  float* ImageData(int) override { return m_data; }
+  HRSharedBufferHeader* Header() override { return &m_hdr; }
+  float* m_data;
+  HRSharedBufferHeader m_hdr;
+  std::timed_mutex m_mutex;
 };
 
 static void set_err(char* err, int n, const std::string& s) {
@@ -108,6 +124,34 @@ int hydra_host_get_hdr(void* p, float* rgba, int w, int h) {
     s->err = e.what();
     return -1;
   }
+}
+
+// shared accumulation image over `rgba` (w*h*4 floats, caller-owned, zero it first).  attach = 1: SetExternalImageAccumulator
+// (every later Draw contributes at the end of its pass); attach = 0: one explicit ContribToExternalImageAccumulator call.
+// Returns an image handle; hydra_host_shared_image_stat reads its header; hydra_host_shared_image_close detaches and frees.
+void* hydra_host_shared_image_open(void* p, float* rgba, int w, int h, int attach) {
+  HostScene* s = static_cast<HostScene*>(p);
+  LocalAccumImage* img = new LocalAccumImage(rgba, w, h);
+  try {
+    if (attach) s->drv->Layer()->SetExternalImageAccumulator(img);
+    else { s->drv->Layer()->FinishAll(); s->drv->Layer()->ContribToExternalImageAccumulator(img); }
+    return img;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    delete img;
+    return nullptr;
+  }
+}
+int hydra_host_shared_image_stat(void* image, float* spp, int* counterRcv) {
+  LocalAccumImage* img = static_cast<LocalAccumImage*>(image);
+  if (!img) return -1;
+  *spp = img->m_hdr.spp; *counterRcv = img->m_hdr.counterRcv;
+  return 0;
+}
+void hydra_host_shared_image_close(void* p, void* image) {
+  HostScene* s = static_cast<HostScene*>(p);
+  if (s) s->drv->Layer()->SetExternalImageAccumulator(nullptr);
+  delete static_cast<LocalAccumImage*>(image);
 }
 
 float hydra_host_get_spp(void* p) { return static_cast<HostScene*>(p)->drv->Layer()->GetSPP(); }

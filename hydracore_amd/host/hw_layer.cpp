@@ -75,7 +75,7 @@ size_t CalcConstGlobDataOffsets(int32_t* g) {
   return cur;
 }
 
-IHWLayer::IHWLayer() : m_width(0), m_height(0), m_camNode(nullptr), m_settingsNode(nullptr), m_pExternalImage(nullptr) {
+IHWLayer::IHWLayer() : m_width(0), m_height(0), m_progressBar(nullptr), m_pExternalImage(nullptr) {
   // InitEngineGlobals (cfetch.h:83-93): zero, rmQMC = -1, tables-ready flag.  The GGX / transparency energy
   // tables (bakeBrdfEnergy/) are only read by GGX materials, which are outside this tier: kept zero.
   m_globsBuffHeader.assign(HG_HEADER_WORDS, 0);
@@ -162,7 +162,7 @@ void IHWLayer::PrepareEngineTables() {
   }
 }
 
-void IHWLayer::SetAllPODLights(const float* a_lights, size_t a_number) {
+void IHWLayer::SetAllPODLights(PlainLight* a_lights, size_t a_number) {
   m_globsBuffHeader[HG_LIGHTS_SIZE] = int(a_number) * HL_FLOATS;  // reference stores bytes here first, then words (Assembler.cpp:392,446)
   PrepareEngineGlobals();
   if (a_number > 0)
@@ -201,7 +201,7 @@ IMemoryStorage* SharedDataLayer::CreateMemStorage(uint64_t a_maxSizeInBytes, con
   return st;
 }
 
-void SharedDataLayer::SetAllBVH4(const ConvertionResult& cr, void* a_inBuilderAPI, int) {
+void SharedDataLayer::SetAllBVH4(const ConvertionResult& cr, IBVHBuilder2* a_inBuilderAPI, int) {
   if (cr.treesNum <= 0 || cr.treesNum > MAXBVHTREES) RunTimeError("SetAllBVH4: converted layout with 1..4 trees is required by the HIP layer");
   for (int i = 0; i < cr.treesNum; i++) {
     if (cr.pBVH[i] == nullptr || cr.pTriangleData[i] == nullptr) RunTimeError("SetAllBVH4: null tree data");
@@ -222,7 +222,8 @@ void SharedDataLayer::SetAllInstMatrices(const float4x4* a_matrices, int32_t n) 
 void SharedDataLayer::SetAllInstLightInstId(const int32_t* ids, int32_t n) {
   m_instLightInstId.assign(ids, ids + (n > 0 ? n : 0));
 }
-void SharedDataLayer::SetAllRemapLists(const int* a_allLists, const int* a_tableInt2, int a_allSize, int a_tableSize) {
+void SharedDataLayer::SetAllRemapLists(const int* a_allLists, const int2* a_table, int a_allSize, int a_tableSize) {
+  const int* a_tableInt2 = reinterpret_cast<const int*>(a_table);
   m_remapLists.assign(a_allLists, a_allLists + a_allSize);
   m_remapTable.assign(a_tableInt2, a_tableInt2 + size_t(a_tableSize) * 2);
 }

@@ -1,11 +1,12 @@
 // hw_layer.h -- host-side mirror of the reference's hardware-layer interface for the PT hot path.
 //
-// Same method names, argument meaning and error behaviour as hydra_drv/IHWLayer.h:97-246 so that a
-// maintainer can paste HipHWLayer into the reference tree, swap the include of this header for
-// IHWLayer.h, and register CreateHipImpl next to CreateOclImpl/CreateCPUExpImpl
-// (IHWLayer.h:256-257, RenderDriverRTE.cpp:85-88); see INTEGRATION.md.  HydraAPI/pugixml types that the
-// original signatures mention (pugi::xml_node, IHRSharedAccumImage) are not available in this image
-// and are replaced by opaque pointers.
+// Same method names, arity, argument meaning and error behaviour as hydra_drv/IHWLayer.h:97-246 so that a maintainer can
+// paste HipHWLayer into the reference tree, swap the include of this header for IHWLayer.h, and register CreateHipImpl
+// next to CreateOclImpl/CreateCPUExpImpl (IHWLayer.h:256-257, RenderDriverRTE.cpp:85-88); see INTEGRATION.md.
+// tests/test_boundary_drift.py parses the reference header and diffs the two method sets.  HydraAPI / pugixml types the
+// original signatures mention are not available in this image; they appear here under their own names as opaque or
+// minimal declarations (XmlNodeHandle for pugi::xml_node, IBVHBuilder2, HRRenderDeviceInfoListElem forward-declared,
+// IHRSharedAccumImage with the members the reference's layers call) -- the only differences the drift test whitelists.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -23,6 +24,8 @@ namespace hydra_host {
 [[noreturn]] inline void RunTimeError(const std::string& msg) { throw std::runtime_error(msg); }
 
 // hydra_drv/IHWLayer.h:23-45 (spelling kept)
+typedef int32_t EngineGlobals;   // the reference's struct (cfetch.h:21-81) is addressed as int words here: HG_* offsets in include/hydra_layouts.h
+
 struct AllRenderVarialbes {
   AllRenderVarialbes() : m_flags(0) {
     for (int i = 0; i < 64; i++) { m_varsI[i] = 0; m_varsF[i] = 0.0f; }
@@ -85,6 +88,23 @@ protected:
   LChunk AppendToTheEnd(const void* a_data, uint64_t a_sizeInBytes);
 };
 
+// ---- HydraAPI-side types the interface mentions (absent from this image; in the reference tree their headers take over)
+struct XmlNodeHandle { const void* node = nullptr; }; // stands for pugi::xml_node: passed by value, opaque to the layer
+class IBVHBuilder2;                                   // hydra_drv/IBVHBuilderAPI.h:35-68; the HIP layer consumes the converted layout only
+struct HRRenderDeviceInfoListElem;                    // HydraAPI device list element (ListDevices)
+typedef void (*RTE_PROGRESSBAR_CALLBACK)(const wchar_t* message, float a_progress);   // hydra_drv/IHWLayer.h:20
+typedef float PlainLight;                             // cfetch.h:6-13: a light is 128 floats; SetAllPODLights takes number of LIGHTS
+// Shared accumulation image: the members the reference's layers use (GPUOCLLayerOther.cpp:259-283 implicit contribution,
+// :365-429 ContribToExternalImageAccumulator): Lock(ms) / Unlock around `+=` into ImageData(0), Header()->spp and counterRcv.
+struct HRSharedBufferHeader { int width, height, depth, channels; float spp; int counterRcv, counterSnd; };
+struct IHRSharedAccumImage {
+  virtual ~IHRSharedAccumImage() {}
+  virtual bool   Lock(int a_miliseconds) = 0;
+  virtual void   Unlock() = 0;
+  virtual float* ImageData(int layerNum) = 0;
+  virtual HRSharedBufferHeader* Header() = 0;
+};
+
 // ------------------------------------------------------------------------------------------------
 // IHWLayer: the boundary class (hydra_drv/IHWLayer.h:97-246).  Base-class bodies assemble the globals
 // blob exactly as IHWLayerDataAssembler.cpp:66-452 does.
@@ -103,16 +123,16 @@ public:
 
   virtual void SetCamMatrices(float mProjInverse[16], float mWorldViewInverse[16], float mProj[16], float mWorldView[16],
                               float a_aspect, float a_fovX, float3 a_lookAt);
-  virtual void SetCamNode(const void* a_camNode) { m_camNode = a_camNode; }
-  virtual void SetSettingsNode(const void* a_node) { m_settingsNode = a_node; }
+  virtual void SetCamNode(XmlNodeHandle a_camNode) { m_camNode = a_camNode; }
+  virtual void SetSettingsNode(XmlNodeHandle a_node) { m_settingsNode = a_node; }
 
-  virtual void SetAllBVH4(const ConvertionResult& a_convertedBVH, void* a_inBuilderAPI, int a_flags) = 0;
+  virtual void SetAllBVH4(const ConvertionResult& a_convertedBVH, IBVHBuilder2* a_inBuilderAPI, int a_flags) = 0;
   virtual void SetAllInstMatrices(const float4x4* a_matrices, int32_t a_matrixNum) = 0;
   virtual void SetAllInstLightInstId(const int32_t* a_lightInstIds, int32_t a_instNum) = 0;
-  virtual void SetAllPODLights(const float* a_lights128, size_t a_number);
+  virtual void SetAllPODLights(PlainLight* a_lights2, size_t a_number);
 
   virtual void SetAllLightsSelectTable(const float* a_table, int32_t a_tableSize, bool a_fwd = false);
-  virtual void SetAllRemapLists(const int* a_allLists, const int* a_tableInt2, int a_allSize, int a_tableSize) {}
+  virtual void SetAllRemapLists(const int* a_allLists, const int2* a_table, int a_allSize, int a_tableSize) {}
   virtual void SetAllInstIdToRemapId(const int* a_allInstId, int a_instNum) {}
 
   virtual void SetAllFlagsAndVars(const AllRenderVarialbes& a_vars);
@@ -120,16 +140,18 @@ public:
 
   virtual void BeginTracingPass() = 0;
   virtual void EndTracingPass() = 0;
+  virtual void EvalGBuffer(IHRSharedAccumImage* a_pAccumImage, const std::vector<int32_t>& a_instIdByInstId) {}
   virtual void FinishAll() {}
 
   virtual void InitPathTracing(int seed, std::vector<int32_t>* pInstRemapTable = nullptr) = 0;
   virtual void ClearAccumulatedColor() = 0;
+  virtual void CPUPluginFinish() {}
 
   virtual void ResetPerfCounters() = 0;
   virtual void ResizeScreen(int w, int h, int a_flags) { m_width = w; m_height = h; }
 
   virtual void GetLDRImage(uint32_t* data, int width, int height) const = 0;
-  virtual void GetHDRImage(float* data4, int width, int height) const = 0;
+  virtual void GetHDRImage(float4* data, int width, int height) const = 0;
 
   virtual size_t GetAvaliableMemoryAmount(bool allMem = false) = 0;
   virtual size_t GetMaxBufferSizeInBytes() { return GetAvaliableMemoryAmount(); }
@@ -137,24 +159,36 @@ public:
   virtual HydraRaysStat GetRaysStat() = 0;
   virtual int32_t GetRayBuffSize() const { return 0; }
   virtual const char* GetDeviceName(int* pOCLVer = nullptr) const { return "host"; }
+  virtual const HRRenderDeviceInfoListElem* ListDevices() const { return nullptr; }
 
   virtual void SetRaysPerPixel(int a_num) {}
   virtual int  GetRaysPerPixel() const { return 1; }
 
   virtual void SetNamedBuffer(const char* a_name, void* a_data, size_t a_size) {}
   virtual void CallNamedFunc(const char* a_name, const char* a_args) {}
+  virtual void RenderFullScreenBuffer(const char* a_dataName, float4* a_data, int width, int height, int a_spp) {
+    std::vector<ushort2> pixels(size_t(m_width) * m_height);
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < m_width; x++) { pixels[size_t(y) * m_width + x].x = (unsigned short)x; pixels[size_t(y) * m_width + x].y = (unsigned short)y; }
+    renderSubPixelData(a_dataName, pixels, a_spp, a_data, nullptr);
+  }
 
+  virtual bool ImplementPhotonMapping() const { return false; }
   virtual bool StoreCPUData() const { return false; }
   virtual bool   MLT_IsAllocated() const { return true; }
   virtual size_t MLT_Alloc(int a_width, int a_height, int a_maxBounce) { return 0; }
   virtual void   MLT_Free() {}
+  virtual void   SetProgressBarCallback(RTE_PROGRESSBAR_CALLBACK a_pFunc) { m_progressBar = a_pFunc; }
 
-  // external accumulator: device pointer to float4 sums in this build (reference: IHRSharedAccumImage*)
-  virtual void SetExternalImageAccumulator(void* a_pImage, size_t a_bytes) { m_pExternalImage = a_pImage; }
-  virtual void ContribToExternalImageAccumulator(void* a_pImage) {}
+  virtual std::vector<uchar4> NormalMapFromDisplacement(int w, int h, const uchar4* a_data, float bumpAmt, bool invHeight, float smoothLvl) { return std::vector<uchar4>(); }
 
-  virtual const int32_t* GetEngineGlobals() const { return m_cdataPrepared.data(); }
-  virtual size_t GetEngineGlobalsSizeInWords() const { return m_cdataPrepared.size(); }
+  virtual void SetExternalImageAccumulator(IHRSharedAccumImage* a_pImage) { m_pExternalImage = a_pImage; }   ///< implicit contribution after every pass
+  virtual void ContribToExternalImageAccumulator(IHRSharedAccumImage* a_pImage) {}                            ///< explicit contribution
+
+  virtual EngineGlobals* GetEngineGlobals() { return m_cdataPrepared.data(); }   // EngineGlobals = the int blob [header | tables | lights], include/hydra_layouts.h
+  size_t GetEngineGlobalsSizeInWords() const { return m_cdataPrepared.size(); }
+
+  virtual void RecompileProcTexShaders(const std::string& a_shaderPath) {}
 
   virtual float GetSPP() const { return 0.0f; }
   virtual float GetSPPDone() const { return GetSPP(); }
@@ -166,12 +200,15 @@ public:
   }
 
 protected:
+  virtual void renderSubPixelData(const char* a_dataName, const std::vector<ushort2>& a_pixels, int spp, float4* a_pixValues, float4* a_subPixValues) {}
+
   int m_width, m_height;
-  const void* m_camNode;
-  const void* m_settingsNode;
+  XmlNodeHandle m_camNode;
+  XmlNodeHandle m_settingsNode;
   AllRenderVarialbes m_vars;
   std::vector<int32_t> m_globsBuffHeader;   // EngineGlobals header, HG_HEADER_WORDS words
-  void* m_pExternalImage;
+  RTE_PROGRESSBAR_CALLBACK m_progressBar;
+  IHRSharedAccumImage* m_pExternalImage;
   std::vector<int32_t> m_cdataPrepared;     // [header | tables | lights]
   std::unordered_map<std::string, IMemoryStorage*> m_allMemStorages;
   std::vector<float> m_lightSelectTableRev, m_lightSelectTableFwd;
@@ -190,10 +227,10 @@ public:
   void Clear(CLEAR_FLAGS a_flags) override;
   IMemoryStorage* CreateMemStorage(uint64_t a_maxSizeInBytes, const char* a_name) override;
 
-  void SetAllBVH4(const ConvertionResult& a_convertedBVH, void* a_inBuilderAPI, int a_flags) override;
+  void SetAllBVH4(const ConvertionResult& a_convertedBVH, IBVHBuilder2* a_inBuilderAPI, int a_flags) override;
   void SetAllInstMatrices(const float4x4* a_matrices, int32_t a_matrixNum) override;
   void SetAllInstLightInstId(const int32_t* a_lightInstIds, int32_t a_instNum) override;
-  void SetAllRemapLists(const int* a_allLists, const int* a_tableInt2, int a_allSize, int a_tableSize) override;
+  void SetAllRemapLists(const int* a_allLists, const int2* a_table, int a_allSize, int a_tableSize) override;
   void SetAllInstIdToRemapId(const int* a_allInstId, int a_instNum) override;
 
   void BeginTracingPass() override { RunTimeError("SharedDataLayer: no compute device behind this layer"); }
@@ -202,7 +239,7 @@ public:
   void ClearAccumulatedColor() override {}
   void ResetPerfCounters() override {}
   void GetLDRImage(uint32_t*, int, int) const override {}
-  void GetHDRImage(float*, int, int) const override {}
+  void GetHDRImage(float4*, int, int) const override {}
   size_t GetAvaliableMemoryAmount(bool = false) override { return size_t(8) << 30; }
   HydraRaysStat GetRaysStat() override { return HydraRaysStat(); }
   bool StoreCPUData() const override { return true; }

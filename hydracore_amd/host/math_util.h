@@ -25,6 +25,11 @@ inline float3 normalize(float3 a) { float l = length(a); return a * (1.0f / l); 
 inline float3 vmin(float3 a, float3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
 inline float3 vmax(float3 a, float3 b) { return {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
 
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct ushort2 { unsigned short x, y; };
+
 struct float4x4 {
   float c[4][4];  // c[col][row]
   float4x4() { identity(); }

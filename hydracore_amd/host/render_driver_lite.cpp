@@ -769,7 +769,7 @@ void RenderDriverLite::BeginScene() {
   m_lightsInstanced.clear();
   m_bvh.ClearScene();
   const int32_t dummyList[2] = {0, 0};
-  m_pHWLayer->SetAllRemapLists(dummyList, dummyList, 0, 0);
+  m_pHWLayer->SetAllRemapLists(dummyList, reinterpret_cast<const int2*>(dummyList), 0, 0);
 }
 
 void RenderDriverLite::InstanceMeshes(int32_t a_mesh_id, const float* a_matrices, int32_t a_instNum, const int* a_lightInstId,

@@ -29,7 +29,7 @@ public:
   void LoadSceneLibrary(const std::string& a_libPath, int a_width, int a_height, int a_traceDepth, int a_enableDof);
 
   void Draw();                         // one pass: SetCamMatrices, PrepareEngineGlobals, (InitPathTracing), BeginTracingPass
-  void GetFrameBufferHDR(float* rgba, int w, int h) { m_pHWLayer->GetHDRImage(rgba, w, h); }
+  void GetFrameBufferHDR(float* rgba, int w, int h) { m_pHWLayer->GetHDRImage(reinterpret_cast<float4*>(rgba), w, h); }
 
   IHWLayer* Layer() { return m_pHWLayer; }
   int Width() const { return m_width; }

@@ -1,20 +1,45 @@
 """Image-plane tile partition across the GPUs of one node + the single RCCL exchange of the float4 accumulator
 (SURVEY.md 8e).  One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 
-Every rank renders only the tiles t with t % world == rank (the same rule hydra_hip_set_tile_partition applies on the
-device), into a zero-initialised full-frame accumulator, so the frames of different ranks have disjoint supports and
+Tiles are ordered along the Morton curve of their tile coordinates and dealt round-robin: rank i % world owns the i-th
+tile (the same rule hydra_hip_set_tile_partition applies on the device).  Every rank renders only its tiles into a
+zero-initialised full-frame accumulator, so the frames of different ranks have disjoint supports and
 one sum-reduce to rank 0 assembles the image exactly (x + 0 = x): the N-GPU image is bit-identical to the 1-GPU image.
 Reference precedent: N processes adding whole frames into one shared-memory image (hydra_drv/GPUOCLLayerOther.cpp:365-429).
 """
 import numpy as np
 
 
+def _morton2(x, y):
+    def spread(v):
+        v = v.astype(np.uint32) & 0xffff
+        v = (v | (v << 8)) & 0x00ff00ff
+        v = (v | (v << 4)) & 0x0f0f0f0f
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+    return spread(x) | (spread(y) << 1)
+
+
+def tile_owner_table(width, height, world, tile=64):
+    """int32 [tilesY, tilesX]: tiles ordered along the Morton curve of (tx, ty), the i-th going to rank i % world
+    (the rule of hydra_hip_set_tile_partition, restated in numpy; tests compare it with hydra_hip_tile_owners)"""
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    ys, xs = np.mgrid[0:ty, 0:tx]
+    code = _morton2(xs.ravel(), ys.ravel())
+    order = np.argsort(code, kind="stable")
+    owner = np.empty(tx * ty, np.int32)
+    owner[order] = np.arange(tx * ty, dtype=np.int32) % max(world, 1)
+    return owner.reshape(ty, tx)
+
+
 def tile_owner_mask(width, height, rank, world, tile=64):
     """boolean [height, width] mask of the pixels rank owns"""
+    if world <= 1:
+        return np.ones((height, width), bool)
+    owner = tile_owner_table(width, height, world, tile)
     ys, xs = np.mgrid[0:height, 0:width]
-    tiles_x = (width + tile - 1) // tile
-    t = (ys // tile) * tiles_x + (xs // tile)
-    return (t % world) == rank if world > 1 else np.ones((height, width), bool)
+    return owner[ys // tile, xs // tile] == rank
 
 
 def reduce_accumulator(accum, dst=0):

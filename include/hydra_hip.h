@@ -72,9 +72,27 @@ int hydra_hip_upload_remap_lists(hydra_hip_handle h, const int32_t* all_lists, i
                                  const int32_t* inst_to_remap_id, int inst_num);
 
 /* ---------------------------------------------------------------- rendering */
-/* image-plane tile partition for multi-GPU: this context renders only tiles t with
- * t % world == rank, tiles are tile_size x tile_size pixels in row-major tile order. rank 0/world 1 = all. */
+/* image-plane tile partition for multi-GPU: tiles of tile_size x tile_size pixels are ordered along the
+ * Morton (Z) curve of their tile coordinates and dealt round-robin: the i-th tile of that order belongs to rank i % world.
+ * This context renders only its own tiles.  rank 0 / world 1 = the whole frame.  Changing the partition restarts the image
+ * (generator states are kept per owned pixel). */
 int hydra_hip_set_tile_partition(hydra_hip_handle h, int rank, int world, int tile_size);
+/* which rank owns which tile under that rule: owner_of_tile[ty * tilesX + tx], tiles = tilesX * tilesY (host arithmetic only) */
+int hydra_hip_tile_owners(int width, int height, int world, int tile_size, int32_t* owner_of_tile, int tiles);
+/* What one rank's render state will hold for a frame size, partition and sampling choice -- host arithmetic only, no device
+ * needed, the same routine trace_pass sizes its allocations with.  Returns HYDRA_HIP_EINVAL (text in err) when a limit is
+ * exceeded: samples_in_flight * width * height < 2^32 (generator slots), samples_in_flight * owned pixels < 2^31 (path
+ * slots).  Per-rank state scales with 1 / world: BASELINE configs[3] (3840x2160, 8 ranks, 512 samples in flight) plans
+ * 531 M paths and ~134 GB per rank. */
+typedef struct HydraStatePlan {
+  int32_t samples_in_flight;     /* K in effect (0 in the request = chosen from the resolution) */
+  int32_t pad_;
+  int64_t owned_pixels, paths;   /* paths = owned_pixels * K, all in flight in one sub-pass */
+  int64_t segments, segment_capacity;
+  int64_t path_state_bytes, generator_bytes, contrib_bytes, owned_map_bytes, total_bytes;
+} HydraStatePlan;
+int hydra_hip_plan_render_state(int width, int height, int rank, int world, int tile_size, int samples_in_flight,
+                                int queue_segments, int fused_bounce, HydraStatePlan* out, char* err, int err_len);
 /* IHWLayer::SetExternalImageAccumulator (:199): use caller-owned device memory (float4 sums, w*h*16 B)
  * instead of the internal accumulator, e.g. a torch tensor that is later reduced over RCCL. NULL restores. */
 int hydra_hip_set_external_accumulator(hydra_hip_handle h, void* dev_float4, size_t bytes);
@@ -90,6 +108,9 @@ float hydra_hip_get_spp(hydra_hip_handle h);                     /* IHWLayer::Ge
  * size mismatch returns HYDRA_HIP_EINVAL and leaves the buffer untouched (CPUExpLayer.cpp:133-147). */
 int hydra_hip_get_hdr_image(hydra_hip_handle h, float* rgba, int width, int height);
 int hydra_hip_get_ldr_image(hydra_hip_handle h, uint32_t* rgba8, int width, int height);
+/* the accumulated float4 SUMS themselves (not divided by the sample count): what IHWLayer::ContribToExternalImageAccumulator
+ * (:201; GPUOCLLayerOther.cpp:365-429) adds into the shared accumulation image */
+int hydra_hip_get_accumulator(hydra_hip_handle h, float* rgba_sums, int width, int height);
 /* IHWLayer::GetRaysStat / ResetPerfCounters (:145,155): per-stage HIP-event times and exact ray counters */
 int hydra_hip_get_rays_stat(hydra_hip_handle h, HydraRaysStat* out);
 int hydra_hip_reset_perf_counters(hydra_hip_handle h);

@@ -1779,24 +1779,44 @@ void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* di
 void orc_init_generators(int w, int h, int seed, uint32_t* gens) {
   for (int i = 0; i < w * h; i++) orc_random_init(seed + i, gens + 2 * (size_t)i);
 }
-static inline int pixel_owned(int x, int y, int w, int rank, int world, int tile) {
-  if (world <= 1) return 1;
-  const int tilesX = (w + tile - 1) / tile;
-  const int t = (y / tile) * tilesX + (x / tile);
-  return (t % world) == rank;
+/* Tile partition of the HIP layer (hydra_hip.h, set_tile_partition): tiles in Morton order of (tx, ty), the i-th tile of that
+ * order belongs to rank i % world.  No counterpart in the reference (replicas with different seeds). */
+static uint32_t morton_spread(uint32_t v) {
+  v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+typedef struct { uint32_t code; int tile; } MortonTile;
+static int morton_cmp(const void* a, const void* b) {
+  const uint32_t x = ((const MortonTile*)a)->code, y = ((const MortonTile*)b)->code;
+  return (x > y) - (x < y);
+}
+/* owner[ty * tilesX + tx]; caller frees */
+static int* tile_owner_table(int w, int h, int world, int tile, int* tilesXOut) {
+  const int tilesX = (w + tile - 1) / tile, tilesY = (h + tile - 1) / tile, n = tilesX * tilesY;
+  MortonTile* t = (MortonTile*)malloc((size_t)n * sizeof(MortonTile));
+  int* owner = (int*)malloc((size_t)n * sizeof(int));
+  for (int ty = 0; ty < tilesY; ty++)
+    for (int tx = 0; tx < tilesX; tx++) { t[ty * tilesX + tx].code = morton_spread((uint32_t)tx) | (morton_spread((uint32_t)ty) << 1); t[ty * tilesX + tx].tile = ty * tilesX + tx; }
+  qsort(t, (size_t)n, sizeof(MortonTile), morton_cmp);
+  for (int i = 0; i < n; i++) owner[t[i].tile] = i % (world > 0 ? world : 1);
+  free(t);
+  *tilesXOut = tilesX;
+  return owner;
 }
 /* ref: CPUExp_Integrators_Common.cpp:278-316 IntegratorCommon::DoPass + :347-359 makeEyeRay */
 uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float* image4, int spp_done, int sum_mode,
                          int rank, int world, int tile, int threads) {
   const float alpha = 1.0f / (float)(spp_done + 1);
   uint64_t totalRays = 0;
+  int tilesX = 1;
+  int* owner = (world > 1) ? tile_owner_table(w, h, world, tile, &tilesX) : NULL;
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
 #endif
 #pragma omp parallel for collapse(2) schedule(dynamic, 64) reduction(+ : totalRays)
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
-      if (!pixel_owned(x, y, w, rank, world, tile)) continue;
+      if (owner && owner[(y / tile) * tilesX + (x / tile)] != rank) continue;
       uint32_t* gen = gens + 2 * ((size_t)y * w + x);
       float r4[4], offs[4];
       orc_rnd_float4(gen, r4);   /* rndUniform(gen, -1, 1), crandom.h:617-620 */
@@ -1816,6 +1836,7 @@ uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float*
       }
     }
   }
+  free(owner);
   return totalRays;
 }
 

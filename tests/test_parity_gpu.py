@@ -418,6 +418,32 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
         assert (outs[0][3].view(np.uint32) == o[3].view(np.uint32)).all() and outs[0][4:] == o[4:]
 
 
+def test_shared_accumulation_image_contributions(built):
+    """IHWLayer::SetExternalImageAccumulator / ContribToExternalImageAccumulator (IHWLayer.h:199-201; GPUOCLLayerOther.cpp:259-283,
+    365-429) through the HipHWLayer adapter: the internal sums are added to the shared image under its lock, its spp and receive
+    counter advance, the internal accumulator restarts -- and two contributions of 2 samples equal one frame of 4."""
+    from hydracore_amd import HostScene
+    w, h = 96, 96
+    ref = HostScene(scene_path("test_224"), w, h, trace_depth=4, enable_dof=0, use_hip=True, device=0, seed=777)
+    ref.hip().set_option("samples_in_flight", 2)
+    ref.draw(passes=2, spp=2)
+    want = ref.hip().accumulator(w, h)
+    ref.close()
+    sc = HostScene(scene_path("test_224"), w, h, trace_depth=4, enable_dof=0, use_hip=True, device=0, seed=777)
+    sc.hip().set_option("samples_in_flight", 2)
+    shared = np.zeros((h, w, 4), np.float32)
+    sc.draw(passes=1, spp=2)
+    img = sc.shared_image(shared, attach=False)                    # explicit contribution of the first pass
+    assert sc.shared_image_stat(img) == (2.0, 1) and sc.hip().spp() == 0.0
+    sc.shared_image_close(img)
+    img = sc.shared_image(shared, attach=True)                     # attached: the next pass contributes at its end
+    sc.draw(passes=1, spp=2)
+    assert sc.shared_image_stat(img) == (2.0, 1) and sc.hip().spp() == 0.0
+    sc.shared_image_close(img)
+    assert (shared.view(np.uint32) == want.view(np.uint32)).all()  # a + b in float: same two addends per pixel either way
+    sc.close()
+
+
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     from hydracore_amd import HipCore, HydraError
     core, b, _ = gpu224
