@@ -22,21 +22,119 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def pmc_traffic(workload_key):
-    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc passes (profiles/*/pmc_traffic.json), or None"""
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth, same guide, "L2 (per XCD)"
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # wave64 VALU instructions per ns: 1024 SIMD-32 units, 2 cycles per wave-instruction, 2.4 GHz max clock
+L2_REQUEST_BYTES = 128    # one TCC request = one 128-byte line (calibrated on k_accumulate's known stream, profiles/r01/pmc_summary.csv)
+
+PMC_GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum",
+              "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_LDS"]
+
+
+def kernel_family(name):
+    """the three kernel families of a bounce; the counting variants (<.., true>) are not timed and not profiled"""
+    n = name.replace(" ", "")
+    if n.startswith("k_trace_dyn<false,false>") or n.startswith("voidk_trace_dyn<false,false>"):
+        return "closest"
+    if n.startswith("k_trace_dyn<true,false>") or n.startswith("voidk_trace_dyn<true,false>"):
+        return "shadow"
+    if n.startswith("k_bounce<") or n.startswith("voidk_bounce<"):
+        return "bounce"
+    return None
+
+
+def live_pmc(scene_dir, w, h, depth, spp, rank, world, tile, device, out_dir, budget_s=420.0):
+    """HBM / L2 / VALU counters of the timed launches, measured now: one `rocprofv3 --pmc` child run per counter group (the guide's
+    rule: never mix groups, no trace domains), each running ONE bench-shaped step (tools/pmc_child.py).  Returns
+    {family: {counter: average per launch, "launches": n}} or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    acc = {}
+    t0 = time.time()
+    env = dict(os.environ, TMPDIR="/tmp")
+    for gi, group in enumerate(PMC_GROUPS):
+        left = budget_s - (time.time() - t0)
+        if left < 30:
+            raise RuntimeError("PMC passes ran out of their time budget")
+        d = os.path.join(out_dir, "pass%d" % gi)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3", "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_child.py"),
+               "--scene", scene_dir, "--width", str(w), "--height", str(h), "--depth", str(depth), "--spp", str(spp),
+               "--rank", str(rank), "--world", str(world), "--tile", str(tile), "--device", str(device)]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=min(left, 240))
+        with open(os.path.join(out_dir, "pass%d.log" % gi), "w") as f:
+            f.write(" ".join(cmd) + "\n" + r.stdout[-4000:] + r.stderr[-4000:])
+        if r.returncode != 0:
+            raise RuntimeError("rocprofv3 --pmc %s failed (exit %d): %s" % (group, r.returncode, (r.stderr or r.stdout)[-300:]))
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            raise RuntimeError("rocprofv3 --pmc %s wrote no counter_collection.csv" % group)
+        for fn in files:
+            with open(fn, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    fam = kernel_family(row["Kernel_Name"])
+                    if fam is None:
+                        continue
+                    e = acc.setdefault(fam, {}).setdefault(row["Counter_Name"], [0, 0.0])
+                    e[0] += 1
+                    e[1] += float(row["Counter_Value"])
+    out = {}
+    for fam, cs in acc.items():
+        out[fam] = {c: tot / n for c, (n, tot) in cs.items()}
+        out[fam]["launches"] = max(n for n, _ in cs.values())
+    return out
+
+
+def committed_pmc(workload_key):
+    """the same record from a committed run (profiles/*/pmc_live_<key>.json), newest round first, or None"""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_live_*.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("workload_key") == workload_key:
-            best = d.get("k_trace_hbm_bytes_per_launch")
+            best = (d, os.path.relpath(path, ROOT))
     return best
 
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+def roofline_entry(kernel, launches, total_ms, pass_ms, algo_bytes_total, pmc, algo_is_hbm):
+    """one kernel family against the three ceilings it could hit: HBM (bytes that reached memory, PMC), L2 (requests x 128 B, PMC),
+    VALU issue (wave-instructions, PMC).  `bound` names the ceiling it is closest to; algorithmic bytes stay next to it."""
+    t = total_ms * 1e-3 / max(launches, 1)            # seconds per launch
+    e = {"kernel": kernel, "launches": int(launches), "avg_launch_ms": total_ms / max(launches, 1), "time_share_of_pass": total_ms / pass_ms if pass_ms > 0 else 0.0,
+         "algorithmic_bytes_per_launch": algo_bytes_total / max(launches, 1),
+         "achieved_algorithmic_GBs": algo_bytes_total / max(launches, 1) / t / 1e9 if t > 0 else 0.0}
+    fr = {}
+    if pmc and t > 0:
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads at 64 B (guide, HBM section): x 2; WRITE_SIZE is exact; both in KB
+            hb = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            e["hbm"] = {"bytes_per_launch": hb, "GBs": hb / t / 1e9, "peak_GBs": HBM_PEAK_GBS, "frac": hb / t / 1e9 / HBM_PEAK_GBS,
+                        "traffic_over_algorithmic": hb / e["algorithmic_bytes_per_launch"] if e["algorithmic_bytes_per_launch"] > 0 else None}
+            fr["hbm"] = e["hbm"]["frac"]
+        if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+            req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
+            e["l2"] = {"bytes_per_launch": req * L2_REQUEST_BYTES, "GBs": req * L2_REQUEST_BYTES / t / 1e9, "peak_GBs": L2_PEAK_GBS,
+                       "frac": req * L2_REQUEST_BYTES / t / 1e9 / L2_PEAK_GBS, "hit_rate": pmc["TCC_HIT_sum"] / req if req > 0 else None}
+            fr["l2"] = e["l2"]["frac"]
+        if "SQ_INSTS_VALU" in pmc:
+            gi = pmc["SQ_INSTS_VALU"] / t / 1e9
+            e["valu"] = {"wave_insts_per_launch": pmc["SQ_INSTS_VALU"], "Ginst_s": gi, "peak_Ginst_s": VALU_PEAK_GINST, "frac": gi / VALU_PEAK_GINST}
+            if pmc.get("SQ_WAVE_CYCLES", 0) > 0:
+                e["valu"]["wave_cycles_waiting_on_memory"] = pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"]
+                e["valu"]["wave_cycles_issue_stalled"] = pmc.get("SQ_WAIT_INST_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"]
+            fr["valu"] = e["valu"]["frac"]
+    if fr:
+        e["bound"] = max(fr, key=fr.get)
+    else:
+        e["bound"] = "hbm" if algo_is_hbm else "unmeasured"
+    return e
 
 
 def traversal_bytes(counters):
@@ -47,28 +145,30 @@ def traversal_bytes(counters):
     return c[..., 0] * (36 + 16) + c[..., 1] * 128 + c[..., 2] * 128 + c[..., 3] * 16 + c[..., 4] * 48
 
 
-def cpu_baseline(scene, depth, budget_s=15.0):
-    """the CPU oracle (kind "port") on a bounded sample of the same workload: a 320x180 frame of the same scene and
-    depth, as many spp as fit the budget, OpenMP over all host cores"""
+def cpu_baseline(scene, depth, budget_s=20.0):
+    """the CPU oracle (kind "port") on a bounded sample of the same workload: a 640x360 frame of the same scene and depth
+    (3 600 dynamically scheduled 64-pixel chunks per pass, so that every host thread stays loaded), as many spp as fit the
+    budget, OpenMP over all host cores"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hydracore_amd import HostScene
     from oracle_lib import Oracle
-    w, h = 320, 180
+    w, h = 640, 360
     sc = HostScene(scene, w, h, trace_depth=depth, enable_dof=0, use_hip=False)
     orc = Oracle(sc.buffers())
     gens = orc.init_generators(777)
-    img, _, gens = orc.render(1, gens=gens)          # warm-up pass (page-in, thread pool)
-    spp, rays, done = 0, 0, 1
+    img, _, gens = orc.render(2, gens=gens)          # warm-up passes (page-in, thread pool)
+    spp, rays, done = 0, 0, 2
     t0 = time.time()
     while time.time() - t0 < budget_s and spp < 4096:
-        img, r, gens = orc.render(8, gens=gens, image=img, spp_done=done)
-        spp += 8
-        done += 8
+        img, r, gens = orc.render(4, gens=gens, image=img, spp_done=done)
+        spp += 4
+        done += 4
         rays += r
     dt = time.time() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": orc.max_threads(), "kind": "port",
-            "sample": "%dx%d, %d bounces, %d spp of the same scene (%d rays, %.1f s); CPU oracle, own BVH4 walk (the stock "
-                      "reference CPU layer traces through Embree 2.17, absent here)" % (w, h, depth, spp, rays, dt)}
+    threads = orc.max_threads()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "per_core": rays / dt / 1e6 / max(threads, 1), "kind": "port",
+            "sample": "%dx%d, %d bounces, %d spp of the same scene (%d rays, %.1f s) on %d OpenMP threads; CPU oracle, own BVH4 walk (the stock "
+                      "reference CPU layer traces through Embree 2.17, absent here)" % (w, h, depth, spp, rays, dt, threads)}
 
 
 def main():
@@ -85,6 +185,8 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "test_224"),
                     help="scene library directory, or 'atrium250k' / 'atrium250k_sky' / 'atrium250k_glass' = BASELINE configs[2]/[3] and a glass variant (generated by tools/make_atrium.py on first use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc child runs (roofline then uses the committed profiles/*/pmc_live_*.json of this workload, if any)")
+    ap.add_argument("--pmc-out", default="", help="directory for the PMC child runs' output (default: gpurun_out/pmc_live if writable, else a temp dir)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of N ranks on one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal only)")
     args = ap.parse_args()
@@ -178,10 +280,12 @@ def main():
     rays_total = all_reduce_scalar(rays_local, cdev)
     t_max = all_reduce_max(elapsed, cdev)
     spp_total = args.steps * args.spp_per_step
-    trace_bytes = float(bytes_per_step[:, 0].sum()) * args.steps  # closest-hit launches of this rank in the timed region
-    trace_s = st.traversalTimeMs * 1e-3
-    achieved = trace_bytes / trace_s / 1e9 if trace_s > 0 else 0.0
-
+    # algorithmic bytes of the timed launches of this rank.  Traversal: the per-ray figure from the counting pass.
+    # Bounce kernel: the path state it must move: 108 B in per path (pos, dir, throughput, radiance, pending estimate float4s, generator 8 B, visibility 4 B,
+    # hit 16 B), 120 B out per survivor (5 float4 + generator + shadow origin/direction), 24 B per terminated path (contribution + generator).
+    paths_in = counters[:, 0, 0].astype("float64")
+    survivors = np.concatenate([paths_in[1:], [0.0]])
+    bounce_bytes_step = float((paths_in * 108 + survivors * 120 + (paths_in - survivors) * 24).sum())
     per_bounce_ms = core.stage_times_per_bounce(max_depth)        # [depth, 3] over the timed steps of this rank
     if rank == 0:
         img = accum.cpu().numpy() / float(spp_total)
@@ -198,13 +302,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload + ", %dx%d, %d bounces, %d spp, PT (MIS) integrator" % (w, h, depth, spp_total),
-                       "spp_per_step": args.spp_per_step, "samples_in_flight": core.samples_in_flight(), "tile": args.tile, "partition": "image tiles, t %% %d" % world,
+                       "spp_per_step": args.spp_per_step, "samples_in_flight": core.samples_in_flight(), "tile": args.tile, "partition": "image tiles in Morton order, i-th tile -> rank i %% %d" % world,
                        "rays": int(rays_total), "mean_radiance": float(img[..., :3].mean())},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_dyn<false,false> (closest-hit BVH4 traversal, persistent form)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("%s|%dx%d|d%d|spp%d" % (os.path.basename(args.scene), w, h, depth, args.spp_per_step // world)) if args.spp_per_step % world == 0 else None,
-                         "launches": int(st.traceLaunches), "avg_launch_ms": st.traversalTimeMs / max(int(st.traceLaunches), 1),
-                         "algorithmic_bytes_per_launch": trace_bytes / max(int(st.traceLaunches), 1)},
             "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "bounce_hit_light_bsdf": st.evalHitMs, "shadow": st.shadowTimeMs,
                          "shade_split_form_only": st.shadeTimeMs, "accumulate": st.accumTimeMs, "pass_total": st.passTimeMs},
         }
@@ -219,6 +318,54 @@ def main():
             "closest_primary": cls(0, 1, 0), "closest_bounce_1": cls(1, 2, 0), "closest_bounce_2plus": cls(2, max_depth, 0),
             "shadow_bounce_0": cls(0, 1, 1), "shadow_bounce_1plus": cls(1, max_depth, 1)}
         result["bounce_kernel_ms_per_bounce"] = [float(x) for x in per_bounce_ms[:, 1]]
+        # ---- roofline: each kernel family of a bounce against the HBM, L2 and VALU-issue ceilings, counters measured in this run
+        key = "%s|%dx%d|d%d|spp%d|w%d" % (os.path.basename(args.scene.rstrip("/")), w, h, depth, args.spp_per_step, world)
+        pmc, pmc_source = None, None
+        if world == 1 and not args.no_pmc:
+            out_dir = args.pmc_out or os.path.join(ROOT, "gpurun_out", "pmc_live")
+            try:
+                os.makedirs(out_dir, exist_ok=True)
+            except OSError:
+                import tempfile
+                out_dir = tempfile.mkdtemp(prefix="pmc_live_")
+            try:
+                pmc = live_pmc(args.scene, w, h, depth, args.spp_per_step, rank, world, args.tile, dev_id, out_dir)
+                pmc_source = "live: rocprofv3 --pmc child runs of tools/pmc_child.py, one counter group per run (%s)" % "; ".join(PMC_GROUPS)
+                with open(os.path.join(out_dir, "pmc_live_%s.json" % key.replace("|", "_")), "w") as f:
+                    json.dump({"workload_key": key, "source": pmc_source, "per_launch": pmc}, f, indent=1)
+            except Exception as e:   # profiler missing / refused / timed out: say so and fall back to the committed record
+                pmc_source = "live PMC failed (%s)" % str(e)[:200]
+        if pmc is None:
+            got = committed_pmc(key)
+            if got is not None:
+                pmc = got[0]["per_launch"]
+                pmc_source = (pmc_source + "; " if pmc_source else "") + "committed record " + got[1]
+        pass_ms = st.passTimeMs
+        fams = {
+            "closest": roofline_entry("k_trace_dyn<false,false> (closest-hit BVH4 traversal + Moeller-Trumbore, persistent form)", st.traceLaunches, st.traversalTimeMs, pass_ms,
+                                      float(bytes_per_step[:, 0].sum()) * args.steps, (pmc or {}).get("closest"), False),
+            "shadow": roofline_entry("k_trace_dyn<true,false> (any-hit shadow traversal, persistent form)", st.shadowLaunches, st.shadowTimeMs, pass_ms,
+                                     float(bytes_per_step[:, 1].sum()) * args.steps, (pmc or {}).get("shadow"), False),
+            "bounce": roofline_entry("k_bounce (hit, emission/MIS, light sample, next-event estimate, BSDF sample, compaction)", st.traceLaunches, st.evalHitMs, pass_ms,
+                                     bounce_bytes_step * args.steps, (pmc or {}).get("bounce"), True),
+        }
+        dom = max(fams, key=lambda k: fams[k]["avg_launch_ms"] * fams[k]["launches"])
+        d = fams[dom]
+        b = d["bound"]
+        if b in ("hbm", "l2"):
+            achieved, peak, unit = (d[b]["GBs"] if b in d else d["achieved_algorithmic_GBs"]), (HBM_PEAK_GBS if b == "hbm" else L2_PEAK_GBS), "GB/s"
+        elif b == "valu":
+            achieved, peak, unit = d["valu"]["Ginst_s"], VALU_PEAK_GINST, "G wave-instructions/s"
+        else:
+            achieved, peak, unit = d["achieved_algorithmic_GBs"], HBM_PEAK_GBS, "GB/s"
+        result["roofline"] = {"kernel": d["kernel"], "bound": b, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                              "traffic": d["hbm"]["bytes_per_launch"] if "hbm" in d else None, "counters": pmc_source,
+                              "launches": d["launches"], "avg_launch_ms": d["avg_launch_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                              "achieved_algorithmic_GBs": d["achieved_algorithmic_GBs"],
+                              "note": "dominant kernel family by time in the timed region; frac = achieved / peak of the ceiling it is closest to (HBM bytes, L2 requests x 128 B "
+                                      "and VALU wave-instructions from PMC counters); achieved_algorithmic_GBs is the SURVEY 8d byte model over the same launches, "
+                                      "which for traversal counts bytes served from LDS/L1/L2 and is not a fraction of HBM"}
+        result["roofline_kernels"] = fams
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.scene, depth)
         print(json.dumps(result))

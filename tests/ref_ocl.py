@@ -107,6 +107,26 @@ class RefScene:
         dt = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
         return self.m.down(hits, dt, (n,))
 
+    def shadow_trace(self, trace_mod, pos4, dir4, tfar):
+        """the reference's OWN shadow kernels of shaders/trace.cl, unmodified (oracle/_ref/trace.hsaco): BVH4TraversalInstShadowKenrel ->
+        BVH4InstTraverseShadow (ctrace.h:1065-1294) for instanced trees, BVH4TraversalShadowKenrel (closest hit below maxDist) otherwise.
+        Ray layout of those kernels: origin.w = maxDist, direction.w = target instance id as int bits (-1 = any); flags 0 = active.
+        Returns visibility 0/1 (their ushort4 output decompressed)."""
+        n = len(pos4)
+        org = np.ascontiguousarray(pos4, np.float32).copy()
+        org[:, 3] = np.ascontiguousarray(tfar, np.float32)
+        dr = np.ascontiguousarray(dir4, np.float32).copy()
+        dr[:, 3] = np.int32(-1).view(np.float32)
+        m = trace_mod
+        flags = m.up(np.zeros(n, np.uint32))
+        shadow = m.alloc(n * 8)
+        bvh, tris, glob = m.up(self.b["bvh_nodes"]), m.up(self.b["bvh_tris"]), m.up(self.b["globals"])
+        kern = "BVH4TraversalInstShadowKenrel" if self.have_inst else "BVH4TraversalShadowKenrel"
+        m.launch(kern, n, [("p", flags), ("p", m.up(org)), ("p", m.up(dr)), ("p", shadow), ("p", bvh), ("p", tris), ("p", glob), ("i", 0), ("i", n)], block=256)
+        out = m.down(shadow, np.uint16, (n, 4))
+        assert ((out[:, 0] == 0) | (out[:, 0] == 65535)).all()
+        return (out[:, 0] == 65535).astype(np.float32)
+
     def eval_surface(self, pos4, dir4, hits):
         n = len(pos4)
         out = self.m.alloc(n * 96)

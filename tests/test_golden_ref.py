@@ -29,6 +29,35 @@ def test_rng_matches_reference_bit_for_bit(t42_small):
     assert (st == g["state"]).all()
 
 
+def load_trace65k(name):
+    """65 536 seeded rays + the reference's answers (hits, shadow visibility); rays regenerated from the seed and checked by digest"""
+    import hashlib
+    from conftest import random_rays
+    g = load("ref_trace65k_%s.npz" % name)
+    kw = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0) if name.startswith("atrium") else {}
+    pos4, dir4 = random_rays(int(g["n"]), int(g["seed"]), **kw)
+    tfar = np.random.default_rng(int(g["tfar_seed"])).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
+    digest = np.frombuffer(hashlib.sha1(pos4.tobytes() + dir4.tobytes() + tfar.tobytes()).digest(), np.uint8)
+    if not (digest == g["rays_sha1"]).all():
+        pytest.skip("this numpy draws other random rays than the one the fixture was made with")
+    vis = np.unpackbits(g["vis"])[:len(pos4)].astype(np.float32)
+    return pos4, dir4, tfar, g, vis
+
+
+@pytest.mark.parametrize("name,cfg", [("test_224", (96, 96, 4, 0)), ("test_42", (96, 96, 4, 1)), ("atrium_small", (96, 54, 5, 0))])
+def test_oracle_traversal_matches_reference_on_65536_rays(name, cfg, built):
+    """SURVEY.md 8c fixture 2 at its stated size + fixture 3: closest hit and shadow visibility from the reference's own kernels"""
+    pos4, dir4, tfar, g, vis = load_trace65k(name)
+    _, b = host_scene(name, *cfg)
+    orc = make_oracle(b)
+    hits = orc.trace(pos4, dir4)
+    same = (hits["primId"] == g["primId"]) & (hits["instId"] == g["instId"]) & (hits["geomId"] == g["geomId"])
+    assert same.mean() >= 0.9999, same.mean()
+    m = same & (g["primId"] != -1)
+    np.testing.assert_allclose(hits["t"][m], g["t"][m], rtol=3e-6)
+    assert (orc.shadow_trace_anyhit(pos4, dir4, tfar) == vis).mean() >= 0.9999
+
+
 def check_shade_point(out, ref, frac=0.002):
     """columns: 0-2 sample pos, 3 pdf, 4-6 colour, 7 pick prob, 8 light offset, 9 isPoint, 10-12 brdf, 13 pdfFwd, 14-16 btdf,
     17-19 MatSample colour, 20 pdf, 21-23 direction, 24 flags, 25 next ray flags.  Integer columns exact; float columns
@@ -71,6 +100,13 @@ def test_oracle_matches_reference_functions(name, built):
     assert same.mean() >= 0.9999, same.mean()          # OpenCL dot/cross may round differently on an edge-on triangle
     m = same & (ref["primId"] != -1)
     np.testing.assert_allclose(hits["t"][m], ref["t"][m], rtol=3e-6)
+    # T2 fixture 3: the reference's own shadow kernel (BVH4InstTraverseShadow, ctrace.h:1065-1294) on the same rays
+    if "shadow_vis" in g:
+        want = np.unpackbits(g["shadow_vis"])[:len(g["ray_pos"])].astype(np.float32)
+        vis_any = orc.shadow_trace_anyhit(g["ray_pos"], g["ray_dir"], g["shadow_tfar"])      # the early-out walk
+        vis_cpu = orc.shadow_trace(g["ray_pos"], g["ray_dir"], g["shadow_tfar"])             # the CPU rule: closest hit, then 0 < t < t_far
+        assert (vis_any == vis_cpu).all()
+        assert (vis_any == want).mean() >= 0.9999, (vis_any == want).mean()                   # an edge-on triangle may round the other way
     # H1 surfaceEvalLS + instance transform
     surf = orc.eval_surface(g["ray_pos"], g["ray_dir"], ref)
     rs = g["surf"]
