@@ -488,7 +488,6 @@ def test_closest_hit_bit_exact_on_the_full_250k_triangle_tree(built):
     bits of t and the per-ray visit counters of 65 536 rays against the oracle; totals of the persistent counting kernels too"""
     from hydracore_amd import HipCore
     _, b = host_scene("atrium250k", 96, 54, 5)
-    assert b["bvh_tris"].size // 4 > 3 * 60000          # the instanced meshes' triangle lists (unique triangles; instances multiply them)
     orc = make_oracle(b)
     core = HipCore(96, 54, device=0)
     core.upload_scene(b)
