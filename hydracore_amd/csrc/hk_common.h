@@ -128,6 +128,17 @@ struct SceneDev {
   const int*    remapLists; int remapListsSize;
   const int*    remapTable; int remapTableSize;
   const int*    remapInst;  int remapInstSize;
+  // sRGBToLinear(byte / 255) for the 256 byte values, filled once per context ON THE DEVICE by the same device function the
+  // per-tap decode would call (k_fill_srgb_lut), so a look-up has the bits of the computation it replaces; nullptr = compute
+  const float*  srgbLut;
+  // The small, hot tables every shaded path walks through -- material arena, material-id and texture-id tables, lights -- by
+  // the pointers the shading code uses.  The host points them at the uploaded blobs; k_bounce re-points them at its block's
+  // LDS copy when the scene's tables fit (hydra_hip.hip, SceneStage): a dependent table read then costs an LDS access instead
+  // of a trip to L2, which is what the kernel spends its time waiting for (profiles/r02: 59 % of wave cycles on memory waits).
+  const float*  matBase;       // material arena, float-addressed (node = HM_NODE_FLOATS floats)
+  const int*    matTable;      // material id -> arena offset in float4 units (cfetch.h:192-197)
+  const float*  lightsBase;    // PlainLight[lightsNum], HL_FLOATS floats each (clight.h:1739-1749)
+  const int*    texTable;      // texture id -> texture arena offset in int4 units (cfetch.h:141-145)
 };
 
 HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.globals + HG_VARS_F); }

@@ -313,14 +313,17 @@ HK_DEV int4 bilinearOffsets(float ffx, float ffy, int flags, int w, int h) {   /
   }
   return make_int4(py_w0 * w + px_w0, py_w0 * w + px_w1, py_w1 * w + px_w0, py_w1 * w + px_w1);
 }
-HK_DEV float4 read_uchar4(const uchar4* data, int offset, bool srgb) {   // cfetch.h:298-303
+HK_DEV float srgbByteToLinear(unsigned char c) { return sRGBToLinear(0.003921568f * float(c)); }   // what read_uchar4 computes per channel
+HK_DEV float4 read_uchar4(const uchar4* data, int offset, bool srgb, const float* lut) {   // cfetch.h:298-303
   const float mult = 0.003921568f;
   const uchar4 c = data[offset];
+  // a tap decodes 4 channels through powf; the 256 possible results come from SceneDev::srgbLut instead (same bits, see hk_common.h)
+  if (srgb && lut != nullptr) return make_float4(lut[c.x], lut[c.y], lut[c.z], lut[c.w]);
   float4 r = make_float4(mult * float(c.x), mult * float(c.y), mult * float(c.z), mult * float(c.w));
   if (srgb) r = make_float4(sRGBToLinear(r.x), sRGBToLinear(r.y), sRGBToLinear(r.z), sRGBToLinear(r.w));
   return r;
 }
-HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   // cfetch.h:461-584 (4-channel textures)
+HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb, const float* lut) {   // cfetch.h:461-584 (4-channel textures)
   const int4 header = tex[0];
   const int w = header.x, h = header.y, bpp = header.w;
   float ffx = tc.x * float(w) - 0.5f, ffy = tc.y * float(h) - 0.5f;
@@ -333,7 +336,7 @@ HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   
     if (flags & HTEX_CLAMP_U) { px = (px >= w) ? w - 1 : px; px = (px < 0) ? 0 : px; } else { px = px % w; px = (px < 0) ? px + w : px; }
     if (flags & HTEX_CLAMP_V) { py = (py >= h) ? h - 1 : py; py = (py < 0) ? 0 : py; } else { py = py % h; py = (py < 0) ? py + h : py; }
     const int offset = py * w + px;
-    if (bpp == 4) return read_uchar4(bytes, offset, srgb);
+    if (bpp == 4) return read_uchar4(bytes, offset, srgb, lut);
     if (bpp == 16) return fdata[offset];
     return make_float4(0, 0, 0, 0);
   }
@@ -344,8 +347,8 @@ HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   
   const int4 offs = bilinearOffsets(ffx, ffy, flags, w, h);
   float4 f1, f2_, f3_, f4_;
   if (bpp == 4) {
-    f1 = read_uchar4(bytes, offs.x, srgb); f2_ = read_uchar4(bytes, offs.y, srgb);
-    f3_ = read_uchar4(bytes, offs.z, srgb); f4_ = read_uchar4(bytes, offs.w, srgb);
+    f1 = read_uchar4(bytes, offs.x, srgb, lut); f2_ = read_uchar4(bytes, offs.y, srgb, lut);
+    f3_ = read_uchar4(bytes, offs.z, srgb, lut); f4_ = read_uchar4(bytes, offs.w, srgb, lut);
   } else {
     f1 = fdata[offs.x]; f2_ = fdata[offs.y]; f3_ = fdata[offs.z]; f4_ = fdata[offs.w];
   }
@@ -353,7 +356,8 @@ HK_DEV float4 read_imagef_sw4(const int4* tex, f2 tc, int flags, bool srgb) {   
                      f1.z * w1 + f2_.z * w2 + f3_.z * w3 + f4_.z * w4, f1.w * w1 + f2_.w * w2 + f3_.w * w3 + f4_.w * w4);
 }
 // sample2DExt, cfetch.h:677-709, without procedural textures.  blob = owning material/light node, int4-addressed.
-HK_DEV_CALL f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
+// A real call (HK_DEV_CALL) with everything it needs passed by value: the body appears once per kernel.
+HK_DEV_CALL f3 sample2DExtCall(int samplerOffset, f2 texCoord, const float* blob, const int* texTable, const int4* texStorage, const float* srgbLut) {
   if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE || samplerOffset < 0) return mk3(1, 1, 1);
   const float* sm = blob + size_t(samplerOffset) * 4;
   const int flags = as_int(sm[HS_FLAGS]);
@@ -362,11 +366,15 @@ HK_DEV_CALL f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, co
   if (texId <= 0) return mk3(1, 1, 1);
   const f2 tct = mk2(sm[HS_ROW0] * texCoord.x + sm[HS_ROW0 + 1] * texCoord.y + sm[HS_ROW0 + 3],
                      sm[HS_ROW1] * texCoord.x + sm[HS_ROW1 + 1] * texCoord.y + sm[HS_ROW1 + 3]);
-  const int offset = s.globals[s.globals[HG_TEX_TABLE_OFFS] + texId];
+  const int offset = texTable[texId];
   float4 c = make_float4(1, 1, 1, 1);
-  if (offset >= 0) c = read_imagef_sw4(s.texStorage + offset, tct, flags, (gamma != 1.0f));
+  if (offset >= 0) c = read_imagef_sw4(texStorage + offset, tct, flags, (gamma != 1.0f), srgbLut);
   if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return mk3(c.x, c.y, c.z);
+}
+HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
+  if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE || samplerOffset < 0) return mk3(1, 1, 1);   // the common untextured node: no call
+  return sample2DExtCall(samplerOffset, texCoord, blob, s.texTable, s.texStorage, s.srgbLut);
 }
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
@@ -379,8 +387,7 @@ struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; 
 struct ShadeContext { f3 l, v, n; f2 tc; };                                 // cglobals.h:2282-2301 (fields used without normal maps)
 
 HK_DEV const float* materialAt(const SceneDev& s, int matId) {   // cfetch.h:192-213
-  const int matOffset = s.globals[s.globals[HG_MAT_TABLE_OFFS] + matId];
-  return reinterpret_cast<const float*>(s.matStorage + matOffset);
+  return s.matBase + size_t(s.matTable[matId]) * 4;
 }
 HK_DEV int matType(const float* m) { return as_int(m[HM_TYPE]); }
 HK_DEV int matFlags(const float* m) { return as_int(m[HM_FLAGS]); }
@@ -913,7 +920,7 @@ HK_DEV uint32_t flagsNextBounceLite(uint32_t flags, const MatSample& ms, const S
 // ================================================================================================ lights
 HK_DEV const float* lightAt(const SceneDev& s, int id) {   // clight.h:1739-1749
   if (id < 0) return nullptr;
-  return reinterpret_cast<const float*>(s.globals + s.globals[HG_LIGHTS_OFFS]) + size_t(id) * HL_FLOATS;
+  return s.lightsBase + size_t(id) * HL_FLOATS;
 }
 HK_DEV f3 lightPos(const float* L) { return mk3(L[HL_POS], L[HL_POS + 1], L[HL_POS + 2]); }
 HK_DEV f3 lightNorm(const float* L) { return mk3(L[HL_NORM], L[HL_NORM + 1], L[HL_NORM + 2]); }

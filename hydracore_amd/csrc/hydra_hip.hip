@@ -454,13 +454,37 @@ __global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M
 // this moves 228 B through HBM instead of 504 B and drops one launch (no M record).
 struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 
+// LDS staging of the scene's small hot tables (SceneDev::matBase ... texTable): sizes in 16-byte units, all zero = leave them in
+// global memory (tables too large for HK_SCENE_LDS_MAX_BYTES per block, or option "scene_tables_in_lds" 0)
+struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4; };
+#define HK_SCENE_LDS_MAX_BYTES (40 * 1024)   // x 3 resident 256-thread blocks per CU = 120 of the CU's 160 KB
+HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
+  const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4;
+  if (n3 == 0) return;                     // block-uniform
+  const float4* a = reinterpret_cast<const float4*>(s.matBase), *b = reinterpret_cast<const float4*>(s.matTable);
+  const float4* c = reinterpret_cast<const float4*>(s.lightsBase), *d = reinterpret_cast<const float4*>(s.texTable);
+  for (int i = int(threadIdx.x); i < n3; i += int(blockDim.x)) {
+    float4 v;
+    if (i < n0) v = a[i]; else if (i < n1) v = b[i - n0]; else if (i < n2) v = c[i - n1]; else v = d[i - n2];
+    lds[i] = v;
+  }
+  __syncthreads();
+  s.matBase = reinterpret_cast<const float*>(lds);
+  s.matTable = reinterpret_cast<const int*>(lds + n0);
+  if (st.lightsF4 > 0) s.lightsBase = reinterpret_cast<const float*>(lds + n1);
+  s.texTable = reinterpret_cast<const int*>(lds + n2);
+}
+
 #ifndef HK_BOUNCE_BLOCK
 #define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
 #endif
 template <int W, int F = HK_FEAT_ALL>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*)
-__global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev s, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
+__global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, SceneStage stage, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
                                                     ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens) {
+  extern __shared__ float4 hk_scene_lds[];
+  SceneDev s = sArg;
+  stage_scene_tables(s, stage, hk_scene_lds);
   const SegIter it = segq_iter(q);
   const int count = it.count;
   uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
@@ -604,6 +628,7 @@ __global__ void k_prepare_bvh(int nodes, float4* __restrict__ bvh) {
 // InitRandomGen, shaders/trace.cl:6-13, with slot = stream * (w*h) + pixel: generator `stream` of owned pixel i.  The slot is
 // formed in 32-bit wrap-around arithmetic like the reference's `a_seed + tid`; alloc_render_state keeps K * w * h below 2^32
 // so that no two slots coincide.
+__global__ void k_fill_srgb_lut(float* lut) { lut[threadIdx.x] = srgbByteToLinear((unsigned char)threadIdx.x); }   // SceneDev::srgbLut
 __global__ void k_init_gens(int nOwned, int streams, const int* __restrict__ ownedPixels, unsigned npix, int seed, uint2* gens) {
   const size_t total = size_t(nOwned) * size_t(streams);
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
@@ -709,6 +734,10 @@ struct hydra_hip_ctx {
   char devName[256] = {0};
   int numCU = 256;
 
+  size_t storageBytes[HYDRA_STORAGE_KINDS] = {0, 0, 0, 0, 0};   // bytes uploaded (a DevBuf may be larger)
+  int sceneTablesInLds = 1;          // option "scene_tables_in_lds"
+  DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
+  int srgbLutWanted = 1;
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
@@ -828,6 +857,12 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.remapLists = c->remapListsSize > 0 ? static_cast<const int*>(c->remapLists.p) : nullptr; s.remapListsSize = c->remapListsSize;
   s.remapTable = c->remapTableSize > 0 ? static_cast<const int*>(c->remapTable.p) : nullptr; s.remapTableSize = c->remapTableSize;
   s.remapInst = c->remapInstSize > 0 ? static_cast<const int*>(c->remapInst.p) : nullptr;   s.remapInstSize = c->remapInstSize;
+  s.srgbLut = c->srgbLutWanted ? static_cast<const float*>(c->srgbLut.p) : nullptr;
+  s.matBase = reinterpret_cast<const float*>(s.matStorage);
+  const bool hdr = c->hostHeader.size() > size_t(HG_LIGHTS_OFFS) && s.globals != nullptr;
+  s.matTable = hdr ? s.globals + c->hostHeader[HG_MAT_TABLE_OFFS] : nullptr;
+  s.lightsBase = hdr ? reinterpret_cast<const float*>(s.globals + c->hostHeader[HG_LIGHTS_OFFS]) : nullptr;
+  s.texTable = hdr ? s.globals + c->hostHeader[HG_TEX_TABLE_OFFS] : nullptr;
   return s;
 }
 static bool scene_ready(const hydra_hip_ctx* c) {
@@ -1097,6 +1132,20 @@ static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, co
 
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 
+// which of the scene's small tables k_bounce copies into LDS (all or none): the material arena as uploaded, the material-id and
+// texture-id tables and the lights of the globals blob
+static SceneStage scene_stage(const hydra_hip_ctx* c) {
+  SceneStage st = {0, 0, 0, 0};
+  if (!c->sceneTablesInLds || c->hostHeader.size() <= size_t(HG_LIGHTS_NUM)) return st;
+  const size_t matBytes = c->storageBytes[HYDRA_STORAGE_MATERIALS];
+  const int matTab = c->hostHeader[HG_MAT_TABLE_SIZE], texTab = c->hostHeader[HG_TEX_TABLE_SIZE], lights = c->hostHeader[HG_LIGHTS_NUM];
+  if (matBytes == 0 || (matBytes % 16) != 0 || matTab <= 0 || texTab < 0 || lights < 0) return st;
+  const size_t total = matBytes + size_t((matTab + 3) / 4 + (texTab + 3) / 4) * 16 + size_t(lights) * HL_FLOATS * 4;
+  if (total > HK_SCENE_LDS_MAX_BYTES) return st;
+  st.matF4 = int(matBytes / 16); st.matTabF4 = (matTab + 3) / 4; st.lightsF4 = lights * (HL_FLOATS / 4); st.texTabF4 = (texTab + 3) / 4;
+  return st;
+}
+
 // everything one sub-pass reads and writes besides the scene
 struct BounceBufs {
   PathState A, B;      // A = current path state; B = the other S set (fused form only)
@@ -1113,6 +1162,8 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
+  const SceneStage stage = scene_stage(c);
+  const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4) * 16;
   HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
@@ -1129,7 +1180,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
           // the first three, 16 spilled for the full one)
           const int f = c->sceneFeatures;
-#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens)
+#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens)
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
@@ -1139,8 +1190,8 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
 #undef HK_LAUNCH_BOUNCE
           break;
         }
-        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
       }
       std::swap(bb.A, bb.B);
     } else {
@@ -1207,6 +1258,9 @@ int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_
   if (const char* e = getenv("HYDRA_HIP_PRIVATE_STREAM")) {   // experiment only (tools/overlap_bench.py): two layers sharing one GPU on their own streams
     if (atoi(e) != 0 && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) c->stream = nullptr;
   }
+  if (dev_alloc(c, c->srgbLut, 256 * 4) != HYDRA_HIP_OK) { g_createError = c->err; delete c; return HYDRA_HIP_ENOMEM; }
+  hipLaunchKernelGGL(k_fill_srgb_lut, dim3(1), dim3(256), 0, c->stream, static_cast<float*>(c->srgbLut.p));
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { g_createError = "hydra_hip_create: filling the sRGB table failed"; dev_free(c->srgbLut); delete c; return HYDRA_HIP_EDEVICE; }
   *out = c;
   return HYDRA_HIP_OK;
 }
@@ -1215,7 +1269,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  DevBuf* all[] = {&c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
+  DevBuf* all[] = {&c->srgbLut, &c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);
@@ -1278,6 +1332,10 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     c->hostMatTable.assign(blob + to, blob + to + ts);
     c->matDirty = true;
   }
+  {
+    const int64_t to = blob[HG_TEX_TABLE_OFFS], ts = blob[HG_TEX_TABLE_SIZE];
+    if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: texture table runs past the blob");
+  }
   // the sky light (if any) must be one this layer implements: constant colour or lat-long texture, no Perez model
   c->skyLightOk = true;
   const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
@@ -1323,6 +1381,7 @@ int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, siz
     c->hostMaterials.assign(static_cast<const float*>(data), static_cast<const float*>(data) + bytes / 4);
     c->matDirty = true;
   }
+  c->storageBytes[kind] = bytes;
   return dev_upload(c, c->storage[kind], data, bytes);
 }
 // Device copy of the node array: put the triangle count of every triangle leaf into bits 27..30 of the link that points at it
@@ -1741,6 +1800,8 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
   else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
   else if (n == "top_quads_in_lds") { if (value < 0 || value > HK_TOP_QUADS) return fail(c, HYDRA_HIP_EINVAL, "top_quads_in_lds: 0.." + std::to_string(HK_TOP_QUADS)); c->topWanted = value; }
+  else if (n == "scene_tables_in_lds") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0 or 1"); c->sceneTablesInLds = value; }
+  else if (n == "srgb_table") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "srgb_table: 0 or 1"); c->srgbLutWanted = value; }
   else if (n == "fused_bounce") {
     if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "fused_bounce: 0 or 1");
     if (value != c->fusedBounce) { (void)hipStreamSynchronize(c->stream); c->fusedBounce = value; c->stateAllocated = false; }
@@ -1768,6 +1829,8 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "trace_blocks_per_cu") *value = c->traceBlocksPerCU;
   else if (n == "queue_segments") *value = c->nsegWanted;
   else if (n == "fused_bounce") *value = c->fusedBounce;
+  else if (n == "srgb_table") *value = c->srgbLutWanted;
+  else if (n == "scene_tables_in_lds") *value = c->sceneTablesInLds;
   else if (n == "path_order") *value = c->streamMajor;
   else if (n == "leaf_count_links") *value = c->leafEncWanted;
   else if (n == "top_quads_in_lds") *value = c->topWanted;

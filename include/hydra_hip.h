@@ -127,6 +127,7 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * (default 32); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
  * "path_order" 1 = stream-major slots (default), 0 = pixel-major; "leaf_count_links" 1 = the device copy of the node array carries
  * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).
+ * "srgb_table" 1 = sRGB texel decode through a 256-entry table filled on the device by the decode function itself (default), 0 = powf per tap;
  * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
  * read by the next upload_bvh, HYDRA_HIP_TOP_QUADS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
  * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..512, 0 = chosen from the resolution:

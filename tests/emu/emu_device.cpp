@@ -33,6 +33,11 @@ static SceneDev to_dev(const EmuScene* e) {
   s.remapLists = e->remapListsSize > 0 ? e->remapLists : nullptr; s.remapListsSize = e->remapListsSize;
   s.remapTable = e->remapTableSize > 0 ? e->remapTable : nullptr; s.remapTableSize = e->remapTableSize;
   s.remapInst = e->remapInstSize > 0 ? e->remapInst : nullptr;    s.remapInstSize = e->remapInstSize;
+  s.srgbLut = nullptr;
+  s.matBase = e->matStorage;
+  s.matTable = e->globals + e->globals[HG_MAT_TABLE_OFFS];
+  s.lightsBase = reinterpret_cast<const float*>(e->globals + e->globals[HG_LIGHTS_OFFS]);
+  s.texTable = e->globals + e->globals[HG_TEX_TABLE_OFFS];
   return s;
 }
 
