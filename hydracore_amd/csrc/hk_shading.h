@@ -211,7 +211,7 @@ HK_DEV TriData fetchTriFromMesh(const HydraLiteHit& hit, const float4* __restric
 // k_bounce is bound by the CU's address path, where the first touch of a line costs ~2.3 clk per lane and every further
 // load from it ~1 (tools/micro/ta_bench.hip), and this fetch was two thirds of its divergent loads.
 HK_DEV TriData fetchTriFromRecords(const HydraLiteHit& hit, const SceneDev& s) {
-  const size_t t = size_t(s.triBase[hit.geomId]) + size_t(hit.primId);
+  const size_t t = size_t(s.triBase[HK_GEOM_ID(hit.geomId)]) + size_t(hit.primId);
   const float4* r = s.triRec + t * 8;
   const float4* tg = s.triTan + t * 3;
   TriData d;
@@ -390,6 +390,23 @@ HK_DEV const float* materialAt(const SceneDev& s, int matId) {   // cfetch.h:192
   return s.matBase + size_t(s.matTable[matId]) * 4;
 }
 HK_DEV int matType(const float* m) { return as_int(m[HM_TYPE]); }
+// Shading class of a material root, 1..15 (0 is kept for "no hit"): paths of one class run the same code in k_bounce.  Only an
+// ordering hint -- nothing reads it for shading -- so per-instance remap lists that swap a material do not matter.
+HK_DEV int shadeClassOfMaterial(const float* m) {
+  const bool textured = (uint32_t(as_int(m[HM_TEXMATRIXID])) != HYDRA_INVALID_TEXTURE) && as_int(m[HM_TEXMATRIXID]) >= 0;
+  switch (as_int(m[HM_TYPE])) {
+    case HMT_EMISSIVE: return 1;
+    case HMT_LAMBERT: return textured ? 3 : 2;
+    case HMT_OREN_NAYAR: return 4;
+    case HMT_PHONG: return textured ? 6 : 5;
+    case HMT_MIRROR: return 7;
+    case HMT_GGX: return 8;
+    case HMT_BLEND_MASK: return 9 + (matType(m + size_t(as_int(m[HM_BLEND_MAT1])) * HM_NODE_FLOATS) == HMT_BLEND_MASK || matType(m + size_t(as_int(m[HM_BLEND_MAT2])) * HM_NODE_FLOATS) == HMT_BLEND_MASK ? 1 : 0);
+    case HMT_THIN_GLASS: return 11;
+    case HMT_GLASS: return 12;
+    default: return 13;
+  }
+}
 HK_DEV int matFlags(const float* m) { return as_int(m[HM_FLAGS]); }
 HK_DEV f3 matColor(const float* m) { return mk3(m[HM_COLOR], m[HM_COLOR + 1], m[HM_COLOR + 2]); }
 

@@ -150,6 +150,14 @@ HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const floa
 // without first waiting for the header (one dependent memory round trip less per leaf visit).  Count 0 = read the header.
 #define HK_LEAF_COUNT_SHIFT 27
 #define HK_LEAF_OFFSET_MASK 0x07ffffff
+// Device copy of the triangle lists only: bits 24..27 of a triangle's geomId word carry the shading class of its material
+// (hydra_hip.hip, k_tag_triangle_classes), so a closest hit arrives at the bounce kernel already labelled and the kernel can
+// group the paths of a workgroup by class before shading them.  HK_GEOM_ID() gives the reference's geomId back; the miss
+// value 0xC0000000 (Make_Lite_Hit, cglobals.h:1256-1266) has no class bits and stays as it is.
+#define HK_CLASS_SHIFT 24
+#define HK_CLASS_BITS 0x0f000000
+#define HK_GEOM_ID(g) ((g) & ~HK_CLASS_BITS)
+#define HK_GEOM_CLASS(g) (((g) >> HK_CLASS_SHIFT) & 15)
 
 template <bool ANYHIT, bool COUNT>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,

@@ -457,6 +457,7 @@ struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 // LDS staging of the scene's small hot tables (SceneDev::matBase ... texTable): sizes in 16-byte units, all zero = leave them in
 // global memory (tables too large for HK_SCENE_LDS_MAX_BYTES per block, or option "scene_tables_in_lds" 0)
 struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4; };
+#define HK_SORT_BINS 16
 #define HK_SCENE_LDS_MAX_BYTES (40 * 1024)   // x 3 resident 256-thread blocks per CU = 120 of the CU's 160 KB
 HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
   const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4;
@@ -481,8 +482,14 @@ HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
 template <int W, int F = HK_FEAT_ALL>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*)
 __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, SceneStage stage, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
-                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens) {
+                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens, int sortPaths) {
   extern __shared__ float4 hk_scene_lds[];
+  // workgroup-local grouping of the paths by shading class (sortPaths): counts per wave and class, slot offsets, permutation
+  constexpr int NW = HK_BOUNCE_BLOCK / 64;
+  static_assert(NW * HK_SORT_BINS <= 64, "the offset scan of the path grouping runs in one wave");
+  __shared__ int sCnt[NW][HK_SORT_BINS];
+  __shared__ int sOff[HK_SORT_BINS][NW];
+  __shared__ unsigned short sPerm[HK_BOUNCE_BLOCK];
   SceneDev s = sArg;
   stage_scene_tables(s, stage, hk_scene_lds);
   const SegIter it = segq_iter(q);
@@ -490,7 +497,39 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
   uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
   int shadowRaysOfWave = 0;
   for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {
-    const int idx = idx0 + int(threadIdx.x);
+    // Which path of this 256-path chunk the thread shades.  Closest hits arrive labelled with the shading class of their
+    // material (hk_trace.h, HK_CLASS_SHIFT): a counting sort of the chunk by class through LDS hands every wave paths that
+    // run the same code (after the first bounce a wave otherwise holds every material of the scene and pays for each of them
+    // in turn).  State is read and survivors are written by path index as before, so nothing but the order inside a chunk changes.
+    int src = int(threadIdx.x);
+    if (sortPaths) {
+      const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63;
+      int key = HK_SORT_BINS - 1;                             // past the end of the queue
+      if (idx0 + src < count) {
+        const float4 k4 = reinterpret_cast<const float4*>(hits)[it.base + idx0 + src];
+        const int cls = HK_GEOM_CLASS(as_int(k4.w));
+        key = (as_int(k4.y) == -1) ? 0 : (cls != 0 ? (cls < HK_SORT_BINS - 2 ? cls : HK_SORT_BINS - 2) : HK_SORT_BINS - 2);
+      }
+      int rank = 0;
+      for (int b = 0; b < HK_SORT_BINS; b++) {
+        const unsigned long long m = __ballot(key == b);
+        if (key == b) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) sCnt[wave][b] = __popcll(m);
+      }
+      __syncthreads();
+      if (wave == 0) {                                         // exclusive scan in class-major, wave-minor order
+        const int b = lane / NW, w = lane % NW;
+        const int v = (lane < NW * HK_SORT_BINS) ? sCnt[w][b] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int n = __shfl_up(incl, d); if (lane >= d) incl += n; }
+        if (lane < NW * HK_SORT_BINS) sOff[b][w] = incl - v;
+      }
+      __syncthreads();
+      sPerm[sOff[key][wave] + rank] = (unsigned short)threadIdx.x;
+      __syncthreads();
+      src = int(sPerm[threadIdx.x]);
+    }
+    const int idx = idx0 + src;
     const int i = it.base + idx;
     bool alive = false;
     float4 oPos = make_float4(0, 0, 0, 0), oDir = oPos, oThr = oPos, oAcc = oPos, oPend = oPos, oShDir = oPos;
@@ -628,6 +667,27 @@ __global__ void k_prepare_bvh(int nodes, float4* __restrict__ bvh) {
 // InitRandomGen, shaders/trace.cl:6-13, with slot = stream * (w*h) + pixel: generator `stream` of owned pixel i.  The slot is
 // formed in 32-bit wrap-around arithmetic like the reference's `a_seed + tid`; alloc_render_state keeps K * w * h below 2^32
 // so that no two slots coincide.
+// upload-time pass over the device copy of the triangle lists: label every triangle with the shading class of its material
+// (hk_trace.h, HK_CLASS_SHIFT).  One thread per triangle leaf; idempotent (the class bits are replaced, not or-ed).
+__global__ void k_tag_triangle_classes(int nLeaves, const int* __restrict__ headers, float4* __restrict__ tris, unsigned trisF4, SceneDev s, int geomTableSize) {
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < nLeaves; l += gridDim.x * blockDim.x) {
+    const float4 hdr = tris[headers[l]];
+    const int first = as_int(hdr.x), count = as_int(hdr.y);
+    for (int k = 0; k < count; k++) {
+      const unsigned a = unsigned(first + 3 * k);
+      if (a + 2 >= trisF4) break;
+      float4 d2 = tris[a + 1];
+      const int primId = as_int(tris[a].w), geomId = HK_GEOM_ID(as_int(d2.w));
+      int cls = 0;
+      if (geomId >= 0 && geomId < geomTableSize && primId >= 0 && s.triBase[geomId] + primId < s.triBase[geomId + 1]) {
+        const int matId = as_int(s.triRec[(size_t(s.triBase[geomId]) + size_t(primId)) * 8 + 6].x);
+        if (matId >= 0 && matId < s.globals[HG_MAT_TABLE_SIZE] && s.matTable[matId] >= 0) cls = shadeClassOfMaterial(materialAt(s, matId));
+      }
+      d2.w = as_float(geomId | (cls << HK_CLASS_SHIFT));
+      tris[a + 1] = d2;
+    }
+  }
+}
 __global__ void k_fill_srgb_lut(float* lut) { lut[threadIdx.x] = srgbByteToLinear((unsigned char)threadIdx.x); }   // SceneDev::srgbLut
 __global__ void k_init_gens(int nOwned, int streams, const int* __restrict__ ownedPixels, unsigned npix, int seed, uint2* gens) {
   const size_t total = size_t(nOwned) * size_t(streams);
@@ -735,9 +795,11 @@ struct hydra_hip_ctx {
   int numCU = 256;
 
   size_t storageBytes[HYDRA_STORAGE_KINDS] = {0, 0, 0, 0, 0};   // bytes uploaded (a DevBuf may be larger)
+  int sortPathsWanted = 1, sortPathsFromDepth = 1;   // options "sort_paths" / "sort_paths_from_bounce": group the paths of a workgroup by shading class in k_bounce
   int sceneTablesInLds = 1;          // option "scene_tables_in_lds"
   DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
   int srgbLutWanted = 1;
+  DevBuf leafHeaders; int leafHeadersNum = 0; bool classDirty = true;   // triangle-leaf headers of tree 0; the class labels in the device triangle lists must be (re)written
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
@@ -981,6 +1043,23 @@ static std::vector<int> morton_tile_order(int tilesX, int tilesY) {
   for (size_t i = 0; i < t.size(); i++) out[i] = t[i].second;
   return out;
 }
+// (re)label the triangles of the device triangle lists with their material's shading class; needs the per-triangle records
+// (prepare_geometry), the material arena and the globals blob.  Called by every entry point that traces.
+static int prepare_classes(hydra_hip_ctx* c) {
+  if (!c->classDirty) return HYDRA_HIP_OK;
+  if (c->leafHeadersNum > 0 && c->bvhTris[0].p && c->triRec.p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->hostHeader.size() > size_t(HG_GEOM_TABLE_SIZE)) {
+    const int tableSize = c->hostHeader[HG_GEOM_TABLE_SIZE];
+    if (tableSize > 0 && tableSize < (1 << HK_CLASS_SHIFT)) {
+      const SceneDev s = make_scene(c);
+      hipLaunchKernelGGL(k_tag_triangle_classes, dim3(grid_for(c, c->leafHeadersNum, 256, 8)), dim3(256), 0, c->stream, c->leafHeadersNum,
+                         static_cast<const int*>(c->leafHeaders.p), static_cast<float4*>(c->bvhTris[0].p), unsigned(c->bvhTriBytes[0] / 16), s, tableSize);
+      HCHECK(hipGetLastError());
+    }
+  }
+  c->classDirty = false;
+  return HYDRA_HIP_OK;
+}
+
 // slot -> pixel map: this rank's tiles in Morton order, pixels inside a tile in 8x8 blocks so that one wave = one block
 static void build_slot_map(int w, int h, int T, int rank, int world, std::vector<int>* out, long long* count) {
   if (out) out->clear();
@@ -1163,6 +1242,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
   const SceneStage stage = scene_stage(c);
+  const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
   const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4) * 16;
   HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
@@ -1175,12 +1255,13 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     launch_closest(c, s, qIn, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + size_t(2 * depth) * HK_CROW : nullptr);
     int b = mark();
     if (fused) {
+      const int sortPaths = (canSort && depth >= c->sortPathsFromDepth) ? 1 : 0;
       switch (c->shadeWaves) {
         case 3: {
           // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
           // the first three, 16 spilled for the full one)
           const int f = c->sceneFeatures;
-#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens)
+#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths)
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
@@ -1190,8 +1271,8 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
 #undef HK_LAUNCH_BOUNCE
           break;
         }
-        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
-        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens); break;
+        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
+        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
       }
       std::swap(bb.A, bb.B);
     } else {
@@ -1275,7 +1356,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
   for (auto& b : c->bvhNodes) dev_free(b);
-  dev_free(c->bvhNodesTop); dev_free(c->topQuads);
+  dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders);
   for (auto& b : c->bvhTris) dev_free(b);
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   delete c;
@@ -1326,6 +1407,7 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
   c->globalsWords = words;
   c->hostHeader.assign(blob, blob + HG_TABLES_READY + 1);
   c->geomDirty = true;
+  c->classDirty = true;
   {
     const int64_t to = blob[HG_MAT_TABLE_OFFS], ts = blob[HG_MAT_TABLE_SIZE];
     if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: material table runs past the blob");
@@ -1377,6 +1459,7 @@ int hydra_hip_upload_storage(hydra_hip_handle c, int kind, const void* data, siz
   if (!c || kind < 0 || kind >= HYDRA_STORAGE_KINDS || (bytes > 0 && !data)) return fail(c, HYDRA_HIP_EINVAL, "upload_storage: bad arguments");
   HCHECK(hipSetDevice(c->device));
   if (kind == HYDRA_STORAGE_GEOM) c->geomDirty = true;
+  if (kind == HYDRA_STORAGE_GEOM || kind == HYDRA_STORAGE_MATERIALS) c->classDirty = true;
   if (kind == HYDRA_STORAGE_MATERIALS) {
     c->hostMaterials.assign(static_cast<const float*>(data), static_cast<const float*>(data) + bytes / 4);
     c->matDirty = true;
@@ -1427,6 +1510,43 @@ static bool encode_leaf_counts(std::vector<HydraBVHNode>& nodes, const float* tr
   for (size_t q = 0; q < quads; q++) if (seen[q * 2] && seen[q * 2 + 1]) return false;
   nodes.swap(out);
   return true;
+}
+
+// float4 index of the header of every triangle leaf of the tree, found by the same walk as encode_leaf_counts (k_tag_triangle_classes)
+static std::vector<int> collect_leaf_headers(const std::vector<HydraBVHNode>& nodes, const float* tri_f4, int tri_f4_num, bool haveInst) {
+  std::vector<int> out;
+  const size_t quads = nodes.size() / 4;
+  auto leaf = [&](uint32_t link) {
+    const uint32_t off = link & 0x7fffffffu;
+    if (off + 1 >= uint32_t(tri_f4_num)) return;
+    int32_t hdr[2];
+    memcpy(hdr, tri_f4 + size_t(off) * 4, 8);
+    if (hdr[0] >= 0 && hdr[1] >= 1 && size_t(hdr[0]) + size_t(hdr[1]) * 3 <= size_t(tri_f4_num)) out.push_back(int(off));
+  };
+  std::vector<uint8_t> seen(quads * 2, 0);
+  std::vector<std::pair<uint32_t, int>> stack;
+  stack.push_back({1u, haveInst ? 0 : 1});
+  while (!stack.empty()) {
+    const uint32_t q = stack.back().first;
+    const int level = stack.back().second;
+    stack.pop_back();
+    if (q >= quads || seen[size_t(q) * 2 + level]) continue;
+    seen[size_t(q) * 2 + level] = 1;
+    for (int k = 0; k < 4; k++) {
+      const HydraBVHNode& n = nodes[size_t(q) * 4 + k];
+      if (n.leftOffsetAndLeaf == HYDRA_BVH_INVALID && n.escapeIndex == HYDRA_BVH_INVALID) continue;
+      const uint32_t off = n.leftOffsetAndLeaf & 0x7fffffffu;
+      if (!(n.leftOffsetAndLeaf & HYDRA_BVH_LEAF)) { stack.push_back({off, level}); continue; }
+      if (level == 1) { leaf(n.leftOffsetAndLeaf); continue; }
+      if (off >= quads) continue;
+      const uint32_t next = nodes[size_t(off) * 4].leftOffsetAndLeaf;
+      if (next & HYDRA_BVH_LEAF) { if (!seen[size_t(off) * 2 + 1]) { seen[size_t(off) * 2 + 1] = 1; leaf(next); } }
+      else stack.push_back({next, 1});
+    }
+  }
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+  return out;
 }
 
 // Choose the quads to keep in LDS: best-first walk from the root, a child's priority = its parent's times the ratio of the
@@ -1526,6 +1646,13 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   if (size_t(nodes_num) * sizeof(HydraBVHNode) >= (size_t(1) << 32) || size_t(tri_f4_num) * 16 >= (size_t(1) << 32))
     return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: node or triangle arrays of 4 GiB and more are not supported");
   std::vector<HydraBVHNode> devNodes(nodes, nodes + nodes_num);
+  {
+    const std::vector<int> headers = collect_leaf_headers(devNodes, tri_f4, tri_f4_num, have_inst != 0);
+    c->leafHeadersNum = int(headers.size());
+    const int hrc = dev_upload(c, c->leafHeaders, headers.data(), headers.size() * sizeof(int));
+    if (hrc) return hrc;
+    c->classDirty = true;
+  }
   c->leafEnc[tree] = (c->leafEncWanted != 0) && encode_leaf_counts(devNodes, tri_f4, tri_f4_num, have_inst != 0);
   int rc = dev_upload(c, c->bvhNodes[tree], devNodes.data(), size_t(nodes_num) * sizeof(HydraBVHNode));
   if (rc) return rc;
@@ -1544,7 +1671,7 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
       if (rc) return rc;
       hipLaunchKernelGGL(k_prepare_bvh, dim3(grid_for(c, nodes_num, 256, 8)), dim3(256), 0, c->stream, nodes_num, static_cast<float4*>(c->bvhNodesTop.p));
       HCHECK(hipGetLastError());
-    } else { dev_free(c->bvhNodesTop); dev_free(c->topQuads); }
+    } else { dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders); }
   }
   c->bvhTriBytes[tree] = size_t(tri_f4_num) * 16;
   c->haveInst[tree] = have_inst ? 1 : 0;
@@ -1660,6 +1787,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   HCHECK(hipSetDevice(c->device));
   { int rc = prepare_geometry(c); if (rc) return rc; }
   { int rc = validate_materials(c); if (rc) return rc; }
+  { int rc = prepare_classes(c); if (rc) return rc; }
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   if (!c->gensReady) { int rc = hydra_hip_init_path_tracing(c, c->seed); if (rc) return rc; }
   if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
@@ -1801,6 +1929,8 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
   else if (n == "top_quads_in_lds") { if (value < 0 || value > HK_TOP_QUADS) return fail(c, HYDRA_HIP_EINVAL, "top_quads_in_lds: 0.." + std::to_string(HK_TOP_QUADS)); c->topWanted = value; }
   else if (n == "scene_tables_in_lds") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0 or 1"); c->sceneTablesInLds = value; }
+  else if (n == "sort_paths") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "sort_paths: 0 or 1"); c->sortPathsWanted = value; }
+  else if (n == "sort_paths_from_bounce") { if (value < 0 || value > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "sort_paths_from_bounce: 0..64"); c->sortPathsFromDepth = value; }
   else if (n == "srgb_table") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "srgb_table: 0 or 1"); c->srgbLutWanted = value; }
   else if (n == "fused_bounce") {
     if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "fused_bounce: 0 or 1");
@@ -1830,6 +1960,8 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "queue_segments") *value = c->nsegWanted;
   else if (n == "fused_bounce") *value = c->fusedBounce;
   else if (n == "srgb_table") *value = c->srgbLutWanted;
+  else if (n == "sort_paths") *value = c->sortPathsWanted;
+  else if (n == "sort_paths_from_bounce") *value = c->sortPathsFromDepth;
   else if (n == "scene_tables_in_lds") *value = c->sceneTablesInLds;
   else if (n == "path_order") *value = c->streamMajor;
   else if (n == "leaf_count_links") *value = c->leafEncWanted;
@@ -1888,6 +2020,7 @@ struct TmpBufs {
   HCHECK(hipSetDevice(c->device));                                                                      \
   if (needScene) { const int prc_ = prepare_geometry(c); if (prc_) return prc_; }                       \
   if (needScene) { const int vrc_ = validate_materials(c); if (vrc_) return vrc_; }                      \
+  if (needScene) { const int crc_ = prepare_classes(c); if (crc_) return crc_; }                         \
   TmpBufs tb; int rc = HYDRA_HIP_OK;
 #define STAGE_EPILOG()                                                                                  \
   HCHECK(hipGetLastError());                                                                            \
@@ -1924,6 +2057,7 @@ int hydra_hip_stage_trace(hydra_hip_handle c, int n, const float* ray_pos4, cons
   launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, dc, nullptr, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(hits, dh, size_t(n) * 16, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) if (hits[i].primId != -1) hits[i].geomId = HK_GEOM_ID(hits[i].geomId);   // the device's class label is not part of Lite_Hit
   if (counters3) HCHECK(hipMemcpy(counters3, dc, size_t(n) * 12, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }

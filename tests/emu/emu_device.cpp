@@ -35,9 +35,9 @@ static SceneDev to_dev(const EmuScene* e) {
   s.remapInst = e->remapInstSize > 0 ? e->remapInst : nullptr;    s.remapInstSize = e->remapInstSize;
   s.srgbLut = nullptr;
   s.matBase = e->matStorage;
-  s.matTable = e->globals + e->globals[HG_MAT_TABLE_OFFS];
-  s.lightsBase = reinterpret_cast<const float*>(e->globals + e->globals[HG_LIGHTS_OFFS]);
-  s.texTable = e->globals + e->globals[HG_TEX_TABLE_OFFS];
+  s.matTable = e->globals ? e->globals + e->globals[HG_MAT_TABLE_OFFS] : nullptr;   // traversal-only callers pass no globals
+  s.lightsBase = e->globals ? reinterpret_cast<const float*>(e->globals + e->globals[HG_LIGHTS_OFFS]) : nullptr;
+  s.texTable = e->globals ? e->globals + e->globals[HG_TEX_TABLE_OFFS] : nullptr;
   return s;
 }
 

@@ -360,13 +360,15 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""
     core, b, _ = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
-    defaults = {k: core.get_option(k) for k in ("trace_mode", "fused_bounce", "path_order", "shade_waves", "trace_min_active")}
+    defaults = {k: core.get_option(k) for k in ("trace_mode", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
+                                                "scene_tables_in_lds", "srgb_table")}
+    assert (defaults["sort_paths"], defaults["scene_tables_in_lds"], defaults["srgb_table"]) == (1, 1, 1)
 
     def render():
         core.set_tile_partition(0, 1, 64)
@@ -377,7 +379,8 @@ def test_tuning_options_do_not_change_the_image(fix, request):
         return core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays)
     try:
         base = render()
-        for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8)):
+        for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
+                            ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("srgb_table", 0)):
             core.set_option(name, value)
             img, ext, sh = render()
             core.set_option(name, defaults[name])
@@ -479,7 +482,10 @@ def test_hip_traversal_against_the_reference_on_65536_rays(fix, request):
     same = (hits["primId"] == g["primId"]) & (hits["instId"] == g["instId"]) & (hits["geomId"] == g["geomId"])
     assert same.mean() >= 0.9999, same.mean()
     m = same & (g["primId"] != -1)
-    np.testing.assert_allclose(hits["t"][m], g["t"][m], rtol=3e-6)
+    rel = np.abs(hits["t"][m] - g["t"][m]) / np.abs(g["t"][m])
+    # + - * / only on both sides, but the reference build uses OpenCL's dot/cross: 3e-6, and up to 1e-4 on the few rays (< 1 in 10 000)
+    # that graze their triangle (1 / det amplifies the last bit)
+    assert (rel > 3e-6).mean() < 1e-4 and rel.max() < 1e-4, ((rel > 3e-6).mean(), rel.max())
     assert (core.stage_shadow_trace(pos4, dir4, tfar) == vis).mean() >= 0.9999
 
 
