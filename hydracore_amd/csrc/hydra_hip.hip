@@ -37,7 +37,7 @@ struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
   float4* surfB;      // shading normal xyz | texCoord.x
   float4* recC;       // direction to the light sample xyz | texCoord.y
   float4* recD;       // light radiance xyz | light pdf (negative when the sample is a point light)
-  float4* recE;       // light pick prob | lightOffset | pixel | unused
+  float4* recE;       // light pick prob | lightOffset | gid | hit from inside (0/1)
   float4* shadowOrg;  // shadow ray origin xyz | t_far
   float*  vis;        // shadow result
 };
@@ -402,7 +402,7 @@ HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ 
       M.surfB[dst] = mk4(surf.normal, surf.texCoord.x);
       M.recC[dst] = mk4(lp.shadowRayDir, surf.texCoord.y);
       M.recD[dst] = mk4(lp.color, lp.pdfSigned);
-      M.recE[dst] = make_float4(lp.pickProb, as_float(lp.lightOffset), pos4.w, 0.0f);
+      M.recE[dst] = make_float4(lp.pickProb, as_float(lp.lightOffset), pos4.w, surf.hfi ? 1.0f : 0.0f);   // hit-from-inside: the glass BxDF needs it
       M.shadowOrg[dst] = lp.shadowOrg;
     }
   }
@@ -431,6 +431,8 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
     const f3 ray_dir = xyz(dir4);
     SurfaceHit surf;
     surf.pos = xyz(sa); surf.matId = as_int(sa.w); surf.normal = xyz(sb); surf.texCoord = mk2(sb.w, rc.w);
+    surf.hfi = (re.w != 0.0f);
+    surf.flatNormal = surf.normal; surf.tangent = mk3(0, 0, 0); surf.biTangent = mk3(0, 0, 0); surf.t = 0.0f; surf.sRayOff = 0.0f;   // not read after the hit phase
     const float* mat = materialAt(s, surf.matId);
     f3 explicitColor = mk3(0, 0, 0);
     if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];
