@@ -1049,7 +1049,7 @@ static std::vector<int> morton_tile_order(int tilesX, int tilesY) {
 // (prepare_geometry), the material arena and the globals blob.  Called by every entry point that traces.
 static int prepare_classes(hydra_hip_ctx* c) {
   if (!c->classDirty) return HYDRA_HIP_OK;
-  if (c->leafHeadersNum > 0 && c->bvhTris[0].p && c->triRec.p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->hostHeader.size() > size_t(HG_GEOM_TABLE_SIZE)) {
+  if (c->leafHeadersNum > 0 && c->leafHeaders.p && c->bvhTris[0].p && c->triRec.p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->hostHeader.size() > size_t(HG_GEOM_TABLE_SIZE)) {
     const int tableSize = c->hostHeader[HG_GEOM_TABLE_SIZE];
     if (tableSize > 0 && tableSize < (1 << HK_CLASS_SHIFT)) {
       const SceneDev s = make_scene(c);
@@ -1673,7 +1673,7 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
       if (rc) return rc;
       hipLaunchKernelGGL(k_prepare_bvh, dim3(grid_for(c, nodes_num, 256, 8)), dim3(256), 0, c->stream, nodes_num, static_cast<float4*>(c->bvhNodesTop.p));
       HCHECK(hipGetLastError());
-    } else { dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders); }
+    } else { dev_free(c->bvhNodesTop); dev_free(c->topQuads); }
   }
   c->bvhTriBytes[tree] = size_t(tri_f4_num) * 16;
   c->haveInst[tree] = have_inst ? 1 : 0;
