@@ -458,26 +458,33 @@ struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 
 // LDS staging of the scene's small hot tables (SceneDev::matBase ... texTable): sizes in 16-byte units, all zero = leave them in
 // global memory (tables too large for HK_SCENE_LDS_MAX_BYTES per block, or option "scene_tables_in_lds" 0)
-struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4; };
+struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4, triBaseF4, instLightF4, instMatF4; };
 #define HK_SORT_BINS 16
-#define HK_SCENE_LDS_MAX_BYTES (40 * 1024)   // x 3 resident 256-thread blocks per CU = 120 of the CU's 160 KB
+#define HK_SCENE_LDS_MAX_BYTES (48 * 1024)   // x 3 resident 256-thread blocks per CU = 144 of the CU's 160 KB
 HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
   const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4;
-  if (n3 == 0) return;                     // block-uniform
+  const int n4 = n3 + st.triBaseF4, n5 = n4 + st.instLightF4, n6 = n5 + st.instMatF4;
+  if (n6 == 0) return;                     // block-uniform
   const float4* a = reinterpret_cast<const float4*>(s.matBase), *b = reinterpret_cast<const float4*>(s.matTable);
   const float4* c = reinterpret_cast<const float4*>(s.lightsBase), *d = reinterpret_cast<const float4*>(s.texTable);
-  for (int i = int(threadIdx.x); i < n3; i += int(blockDim.x)) {
+  const float4* e = reinterpret_cast<const float4*>(s.triBase), *f = reinterpret_cast<const float4*>(s.instLightInstId), *g = s.instMatrices;
+  for (int i = int(threadIdx.x); i < n6; i += int(blockDim.x)) {
     float4 v;
-    if (i < n0) v = a[i]; else if (i < n1) v = b[i - n0]; else if (i < n2) v = c[i - n1]; else v = d[i - n2];
+    if (i < n0) v = a[i]; else if (i < n1) v = b[i - n0]; else if (i < n2) v = c[i - n1]; else if (i < n3) v = d[i - n2];
+    else if (i < n4) v = e[i - n3]; else if (i < n5) v = f[i - n4]; else v = g[i - n5];
     lds[i] = v;
   }
   __syncthreads();
-  s.matBase = reinterpret_cast<const float*>(lds);
-  s.matTable = reinterpret_cast<const int*>(lds + n0);
-  if (st.lightsF4 > 0) s.lightsBase = reinterpret_cast<const float*>(lds + n1);
-  s.texTable = reinterpret_cast<const int*>(lds + n2);
+  if (st.matF4 > 0) {
+    s.matBase = reinterpret_cast<const float*>(lds);
+    s.matTable = reinterpret_cast<const int*>(lds + n0);
+    if (st.lightsF4 > 0) s.lightsBase = reinterpret_cast<const float*>(lds + n1);
+    s.texTable = reinterpret_cast<const int*>(lds + n2);
+  }
+  if (st.triBaseF4 > 0) s.triBase = reinterpret_cast<const int*>(lds + n3);
+  if (st.instLightF4 > 0) s.instLightInstId = reinterpret_cast<const int*>(lds + n4);
+  if (st.instMatF4 > 0) s.instMatrices = lds + n5;
 }
-
 #ifndef HK_BOUNCE_BLOCK
 #define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
 #endif
@@ -798,7 +805,7 @@ struct hydra_hip_ctx {
 
   size_t storageBytes[HYDRA_STORAGE_KINDS] = {0, 0, 0, 0, 0};   // bytes uploaded (a DevBuf may be larger)
   int sortPathsWanted = 1, sortPathsFromDepth = 1;   // options "sort_paths" / "sort_paths_from_bounce": group the paths of a workgroup by shading class in k_bounce
-  int sceneTablesInLds = 1;          // option "scene_tables_in_lds"
+  int sceneTablesInLds = 2;          // option "scene_tables_in_lds"
   DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
   int srgbLutWanted = 1;
   DevBuf leafHeaders; int leafHeadersNum = 0; bool classDirty = true;   // triangle-leaf headers of tree 0; the class labels in the device triangle lists must be (re)written
@@ -887,7 +894,7 @@ static int dev_alloc(hydra_hip_ctx* c, DevBuf& b, size_t bytes) {
   return HYDRA_HIP_OK;
 }
 static int dev_upload(hydra_hip_ctx* c, DevBuf& b, const void* src, size_t bytes) {
-  const size_t alloc = bytes > 0 ? bytes : 16;   // never hand a null pointer to a kernel
+  const size_t alloc = bytes > 0 ? (bytes + 15) / 16 * 16 : 16;   // never hand a null pointer to a kernel; whole float4s (LDS staging copies in 16-byte pieces)
   int rc = dev_alloc(c, b, alloc);
   if (rc != HYDRA_HIP_OK) return rc;
   if (bytes > 0) HCHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1000,7 +1007,7 @@ static int prepare_geometry(hydra_hip_ctx* c) {
   const int tableSize = c->hostHeader[HG_GEOM_TABLE_SIZE];
   if (tableSize <= 0 || tableSize > (1 << 24)) return fail(c, HYDRA_HIP_EINVAL, "geometry table size out of range");
   int rc;
-  if ((rc = dev_alloc(c, c->triBase, size_t(tableSize + 1) * 4)) != 0) return rc;
+  if ((rc = dev_alloc(c, c->triBase, (size_t(tableSize + 1) * 4 + 15) / 16 * 16)) != 0) return rc;   // whole float4s: k_bounce may stage it in LDS
   const int* globals = static_cast<const int*>(c->globals.p);
   const float4* geom = static_cast<const float4*>(c->storage[HYDRA_STORAGE_GEOM].p);
   hipLaunchKernelGGL(k_geom_count, dim3((tableSize + 255) / 256), dim3(256), 0, c->stream, globals, geom, tableSize, static_cast<int*>(c->triBase.p));
@@ -1216,14 +1223,28 @@ static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 // which of the scene's small tables k_bounce copies into LDS (all or none): the material arena as uploaded, the material-id and
 // texture-id tables and the lights of the globals blob
 static SceneStage scene_stage(const hydra_hip_ctx* c) {
-  SceneStage st = {0, 0, 0, 0};
+  SceneStage st = {0, 0, 0, 0, 0, 0, 0};
   if (!c->sceneTablesInLds || c->hostHeader.size() <= size_t(HG_LIGHTS_NUM)) return st;
+  size_t total = 0;
+  // the geometry-id -> first triangle record table and the per-instance light id / inverse matrix arrays: what a path needs
+  // between its hit record and its triangle record (option "scene_tables_in_lds" 2, the default, adds them when they fit 16 KB)
+  const int geomTab = c->hostHeader[HG_GEOM_TABLE_SIZE];
+  if (c->sceneTablesInLds >= 2 && geomTab > 0 && c->triBase.p && c->instNum > 0 && c->instMat.p && c->instLight.p) {
+    const size_t need = size_t((geomTab + 1 + 3) / 4 + (c->instNum + 3) / 4 + c->instNum * 4) * 16;
+    // the buffers are read in whole float4s: the int arrays must be allocated up to the next multiple of 16 bytes
+    if (need <= 16 * 1024 && c->triBase.bytes >= size_t((geomTab + 1 + 3) / 4) * 16 && c->instLight.bytes >= size_t((c->instNum + 3) / 4) * 16) {
+      st.triBaseF4 = (geomTab + 1 + 3) / 4; st.instLightF4 = (c->instNum + 3) / 4; st.instMatF4 = c->instNum * 4;
+      total += need;
+    }
+  }
   const size_t matBytes = c->storageBytes[HYDRA_STORAGE_MATERIALS];
   const int matTab = c->hostHeader[HG_MAT_TABLE_SIZE], texTab = c->hostHeader[HG_TEX_TABLE_SIZE], lights = c->hostHeader[HG_LIGHTS_NUM];
-  if (matBytes == 0 || (matBytes % 16) != 0 || matTab <= 0 || texTab < 0 || lights < 0) return st;
-  const size_t total = matBytes + size_t((matTab + 3) / 4 + (texTab + 3) / 4) * 16 + size_t(lights) * HL_FLOATS * 4;
-  if (total > HK_SCENE_LDS_MAX_BYTES) return st;
-  st.matF4 = int(matBytes / 16); st.matTabF4 = (matTab + 3) / 4; st.lightsF4 = lights * (HL_FLOATS / 4); st.texTabF4 = (texTab + 3) / 4;
+  if (matBytes > 0 && (matBytes % 16) == 0 && matTab > 0 && texTab >= 0 && lights >= 0) {
+    const size_t need = matBytes + size_t((matTab + 3) / 4 + (texTab + 3) / 4) * 16 + size_t(lights) * HL_FLOATS * 4;
+    if (total + need <= HK_SCENE_LDS_MAX_BYTES) {
+      st.matF4 = int(matBytes / 16); st.matTabF4 = (matTab + 3) / 4; st.lightsF4 = lights * (HL_FLOATS / 4); st.texTabF4 = (texTab + 3) / 4;
+    }
+  }
   return st;
 }
 
@@ -1245,7 +1266,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const bool fused = c->fusedBounce != 0;
   const SceneStage stage = scene_stage(c);
   const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
-  const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4) * 16;
+  const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4) * 16;
   HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
@@ -1930,7 +1951,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
   else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
   else if (n == "top_quads_in_lds") { if (value < 0 || value > HK_TOP_QUADS) return fail(c, HYDRA_HIP_EINVAL, "top_quads_in_lds: 0.." + std::to_string(HK_TOP_QUADS)); c->topWanted = value; }
-  else if (n == "scene_tables_in_lds") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0 or 1"); c->sceneTablesInLds = value; }
+  else if (n == "scene_tables_in_lds") { if (value < 0 || value > 2) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0, 1 or 2"); c->sceneTablesInLds = value; }
   else if (n == "sort_paths") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "sort_paths: 0 or 1"); c->sortPathsWanted = value; }
   else if (n == "sort_paths_from_bounce") { if (value < 0 || value > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "sort_paths_from_bounce: 0..64"); c->sortPathsFromDepth = value; }
   else if (n == "srgb_table") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "srgb_table: 0 or 1"); c->srgbLutWanted = value; }

@@ -129,7 +129,8 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).
  * "sort_paths" 1 = k_bounce groups the 256 paths of a workgroup by the shading class of the material they hit (labels travel in the hit
  * record; counting sort through LDS) from bounce "sort_paths_from_bounce" (default 1) on, 0 = paths are shaded in queue order;
- * "scene_tables_in_lds" 1 = k_bounce copies the material arena, the material / texture id tables and the lights into LDS when they fit 40 KB;
+ * "scene_tables_in_lds" 1 = k_bounce copies the material arena, the material / texture id tables and the lights into LDS when they fit 48 KB,
+ * 2 (default) = also the geometry-id -> triangle-record table, the per-instance light ids and inverse matrices when those fit 16 KB, 0 = nothing;
  * "srgb_table" 1 = sRGB texel decode through a 256-entry table filled on the device by the decode function itself (default), 0 = powf per tap;
  * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
  * read by the next upload_bvh, HYDRA_HIP_TOP_QUADS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.

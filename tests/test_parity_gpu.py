@@ -368,7 +368,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
     w, h = b["width"], b["height"]
     defaults = {k: core.get_option(k) for k in ("trace_mode", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
                                                 "scene_tables_in_lds", "srgb_table")}
-    assert (defaults["sort_paths"], defaults["scene_tables_in_lds"], defaults["srgb_table"]) == (1, 1, 1)
+    assert (defaults["sort_paths"], defaults["scene_tables_in_lds"], defaults["srgb_table"]) == (1, 2, 1)
 
     def render():
         core.set_tile_partition(0, 1, 64)
@@ -380,7 +380,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
     try:
         base = render()
         for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
-                            ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("srgb_table", 0)):
+                            ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("scene_tables_in_lds", 1), ("srgb_table", 0)):
             core.set_option(name, value)
             img, ext, sh = render()
             core.set_option(name, defaults[name])
