@@ -118,6 +118,8 @@ struct SceneDev {
   const float4* bvhTop;        // second node copy whose links to the hottest quads are tagged (hk_trace.h, HK_TOP_FLAG); nullptr = none
   const int*    topQuads;      // quad index of each cached slot, slot 0 = the root
   int           topCount;      // 0..HK_TOP_QUADS
+  const int*    topTriF4;      // float4 index (in tris) of every float4 of the triangle pool kept in LDS (3 per triangle)
+  int           topTriCount;   // triangles in that pool, 0..HK_TOP_TRIS
   int           leafEnc;       // 1: triangle-leaf links of the device node copy carry the triangle count (hk_trace.h, HK_LEAF_COUNT_SHIFT)
   const float4* tris;          // tree 0 triangle lists
   unsigned      trisBytes;

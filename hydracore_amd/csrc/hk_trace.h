@@ -34,6 +34,12 @@ typedef float hk_v4f_t __attribute__((ext_vector_type(4)));
 #define HK_TOP_STRIDE 9
 #endif
 #define HK_TOP_FLAG 0x40000000
+// LDS copy of the triangles of the leaves rays visit most (same kernels): a pool of HK_TOP_TRIS triangles (3 float4 each).  In the
+// node copy those kernels walk, the link to a cached leaf reads LEAF | count << 27 | HK_LEAF_LDS_FLAG | first triangle of the pool.
+#ifndef HK_TOP_TRIS
+#define HK_TOP_TRIS 16
+#endif
+#define HK_LEAF_LDS_FLAG 0x04000000
 
 struct TravCounters { uint32_t quads, insts, tris, leaves, oob; };   // oob: fetches a range-checked buffer load would have answered with zeros (must stay 0)
 
@@ -101,14 +107,15 @@ typedef HkStackT<HK_LDS_DEPTH> HkStack;
 // kernels are bound by exactly that path, so on the device both arrays are raw buffers.
 #ifdef HK_HOST_EMU
 struct BvhView {
-  const float4* nodes; const float4* tris; bool leafEnc; const hk_lds_f4* top;
+  const float4* nodes; const float4* tris; bool leafEnc; const hk_lds_f4* top; const hk_lds_f4* topTri;
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const { return top[(link & 0xff) * HK_TOP_STRIDE + piece]; }
+  HK_DEV_MEMBER float4 topTriPiece(int index) const { return topTri[index]; }
   HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
   HK_DEV_MEMBER float4 tri(int index) const { return tris[index]; }
   HK_DEV_MEMBER bool nodeInRange(int) const { return true; }   // the host build runs under AddressSanitizer instead
   HK_DEV_MEMBER bool triInRange(int, int) const { return true; }
 };
-HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; return v; }
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; v.topTri = nullptr; return v; }
 #else
 typedef float hk_v4f __attribute__((ext_vector_type(4)));
 struct BvhView {
@@ -116,8 +123,13 @@ struct BvhView {
   uint32_t nodeBytes, triBytes;
   bool leafEnc;   // triangle-leaf links of the device copy carry the triangle count (see HK_LEAF_COUNT_SHIFT)
   const hk_lds_f4* top;   // LDS copy of the hottest quads (trav_run<.., TOPCACHE = true> only)
+  const hk_lds_f4* topTri;   // LDS pool of the hottest leaves' triangles
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const {
     const hk_v4f_t v = top[(link & 0xff) * HK_TOP_STRIDE + piece];
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  HK_DEV_MEMBER float4 topTriPiece(int index) const {
+    const hk_v4f_t v = topTri[index];
     return make_float4(v.x, v.y, v.z, v.w);
   }
   HK_DEV_MEMBER float4 node(int quad, int piece) const {
@@ -137,7 +149,7 @@ struct BvhView {
 HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const float4* tris, unsigned triBytes, bool leafEnc = false) {
   BvhView v;
   v.leafEnc = leafEnc;
-  v.top = nullptr;
+  v.top = nullptr; v.topTri = nullptr;
   v.nodeBytes = nodeBytes; v.triBytes = triBytes;
   v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
   v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
@@ -159,20 +171,24 @@ HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const floa
 #define HK_GEOM_ID(g) ((g) & ~HK_CLASS_BITS)
 #define HK_GEOM_CLASS(g) (((g) >> HK_CLASS_SHIFT) & 15)
 
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,
                                   const BvhView& bv, int instId, bool useInstId, TravCounters& cnt) {
   int first, count;
   const int enc = bv.leafEnc ? ((leaf_offset >> HK_LEAF_COUNT_SHIFT) & 15) : 0;
-  if (enc != 0) { first = (leaf_offset & HK_LEAF_OFFSET_MASK) + 1; count = enc; }
+  const bool inLds = TOPCACHE && enc != 0 && (leaf_offset & HK_LEAF_LDS_FLAG) != 0;   // one of the hottest leaves: its triangles sit in LDS
+  if (inLds) { first = (leaf_offset & 0xff) * 3; count = enc; }
+  else if (enc != 0) { first = (leaf_offset & HK_LEAF_OFFSET_MASK) + 1; count = enc; }
   else {
     const float4 hdr = bv.tri(bv.leafEnc ? (leaf_offset & HK_LEAF_OFFSET_MASK) : leaf_offset);
     first = as_int(hdr.x); count = as_int(hdr.y);
   }
   const int end = first + count * 3;
-  if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; if (!bv.triInRange(first, end) || !bv.triInRange(leaf_offset & HK_LEAF_OFFSET_MASK, (leaf_offset & HK_LEAF_OFFSET_MASK) + 1)) cnt.oob++; }
+  if (COUNT) { cnt.tris += uint32_t(count); cnt.leaves++; if (!inLds && (!bv.triInRange(first, end) || !bv.triInRange(leaf_offset & HK_LEAF_OFFSET_MASK, (leaf_offset & HK_LEAF_OFFSET_MASK) + 1))) cnt.oob++; }
   for (int a = first; a < end; a += 3) {
-    const float4 d1 = bv.tri(a), d2 = bv.tri(a + 1), d3 = bv.tri(a + 2);
+    float4 d1, d2, d3;
+    if (inLds) { d1 = bv.topTriPiece(a); d2 = bv.topTriPiece(a + 1); d3 = bv.topTriPiece(a + 2); }
+    else { d1 = bv.tri(a); d2 = bv.tri(a + 1); d3 = bv.tri(a + 2); }
     const f3 A = xyz(d1), B = xyz(d2), C = xyz(d3);
     const f3 edge1 = B - A, edge2 = C - A;
     const f3 pvec = cross(ray_dir, edge2);
@@ -271,13 +287,13 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
     }
     if (!haveInst) {
       if (t.top >= 0) {
-        t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
+        t.hit = IntersectLeaf<ANYHIT, COUNT, TOPCACHE>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
         if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       }
       t.top--;
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 1) {
-      t.hit = IntersectLeaf<ANYHIT, COUNT>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
+      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPCACHE>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
       if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       t.top--;
       t.left = stack.get(t.top);

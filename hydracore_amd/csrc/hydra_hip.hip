@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   constexpr int LDS_DEPTH = (ANYHIT && !COUNT) ? HK_LDS_DEPTH_SHADOW : HK_LDS_DEPTH;
   __shared__ int ldsStack[LDS_DEPTH * HK_TRACE_BLOCK];
   __shared__ float4 ldsTop[HK_TOP_QUADS * HK_TOP_STRIDE];
+  __shared__ float4 ldsTri[HK_TOP_TRIS * 3];   // the LDS-staged triangle packets: the leaves rays visit most (chosen at upload)
   const SegIter it = segq_iter(q);
   const int count = it.count, segBase = it.base;
   // the live count is only known on the device: when it is small, let only the first blocks of the segment take part so
@@ -200,10 +201,12 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   const bool useTop = (s.topCount > 0);
   if (useTop) {
     for (int i = threadIdx.x; i < s.topCount * 8; i += HK_TRACE_BLOCK) ldsTop[(i >> 3) * HK_TOP_STRIDE + (i & 7)] = s.bvhTop[size_t(s.topQuads[i >> 3]) * 8 + (i & 7)];
+    for (int i = threadIdx.x; i < s.topTriCount * 3; i += HK_TRACE_BLOCK) ldsTri[i] = s.tris[s.topTriF4[i]];
     __syncthreads();
   }
   BvhView bv = make_bvh_view(useTop ? s.bvhTop : s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
   bv.top = (const hk_lds_f4*)ldsTop;
+  bv.topTri = (const hk_lds_f4*)ldsTri;
   const int rootLink = useTop ? (HK_TOP_FLAG | 0) : 1;
   TravState t;
   TravCounters c = {0, 0, 0, 0, 0};
@@ -810,6 +813,7 @@ struct hydra_hip_ctx {
   int srgbLutWanted = 1;
   DevBuf leafHeaders; int leafHeadersNum = 0; bool classDirty = true;   // triangle-leaf headers of tree 0; the class labels in the device triangle lists must be (re)written
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
+  DevBuf topTriF4; int topTriCount = 0, topTrisWanted = HK_TOP_TRIS;   // option "top_tris_in_lds" (0..HK_TOP_TRIS), read by the next upload_bvh
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
   size_t globalsWords = 0;
@@ -919,6 +923,8 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.bvhTop = static_cast<const float4*>(c->bvhNodesTop.p);
   s.topQuads = static_cast<const int*>(c->topQuads.p);
   s.topCount = (c->bvhNodesTop.p && c->topQuads.p) ? c->topCount : 0;
+  s.topTriF4 = static_cast<const int*>(c->topTriF4.p);
+  s.topTriCount = (s.topCount > 0 && c->topTriF4.p) ? c->topTriCount : 0;
   s.trisBytes = unsigned(c->bvhTriBytes[0]);
   s.tris = static_cast<const float4*>(c->bvhTris[0].p);
   s.haveInst = c->haveInst[0];
@@ -1356,6 +1362,7 @@ int hydra_hip_create(int width, int height, int flags, int device_id, hydra_hip_
   if (const char* e = getenv("HYDRA_HIP_TRACE_MODE")) c->traceMode = atoi(e) ? 1 : 0;
   if (const char* e = getenv("HYDRA_HIP_LEAF_COUNT_LINKS")) c->leafEncWanted = atoi(e) ? 1 : 0;
   if (const char* e = getenv("HYDRA_HIP_TOP_QUADS")) c->topWanted = std::max(0, std::min(atoi(e), HK_TOP_QUADS));
+  if (const char* e = getenv("HYDRA_HIP_TOP_TRIS")) c->topTrisWanted = std::max(0, std::min(atoi(e), HK_TOP_TRIS));
   if (const char* e = getenv("HYDRA_HIP_TRACE_MIN_ACTIVE")) c->traceMinActive = std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("HYDRA_HIP_TRACE_BLOCKS_PER_CU")) c->traceBlocksPerCU = std::max(1, std::min(64, atoi(e)));
   c->stream = nullptr;   // the null stream: ordered with torch's default stream and with plain hipMemcpy
@@ -1379,7 +1386,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
   for (auto& b : c->bvhNodes) dev_free(b);
-  dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders);
+  dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders); dev_free(c->topTriF4);
   for (auto& b : c->bvhTris) dev_free(b);
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   delete c;
@@ -1572,6 +1579,72 @@ static std::vector<int> collect_leaf_headers(const std::vector<HydraBVHNode>& no
   return out;
 }
 
+// Choose the triangle leaves to keep in LDS (the "triangle packets" of the persistent traversal kernels): the same best-first
+// walk and priorities as for the quads below, continued for a bounded number of quads; a triangle leaf's priority is its parent
+// quad's times its box-area ratio.  Leaves are taken in priority order while their triangles fit the pool.  Needs the triangle
+// counts in the leaf links (encode_leaf_counts).  Returns, per chosen leaf, where its link sits (node index) and the float4
+// indices of its triangles; `poolF4` receives the source index of every float4 of the pool.
+struct TopLeaf { size_t node; int count, poolStart; };
+static std::vector<TopLeaf> choose_top_leaves(const std::vector<HydraBVHNode>& nodes, bool haveInst, int triF4Num, int wantedTris, std::vector<int>& poolF4) {
+  std::vector<TopLeaf> out;
+  poolF4.clear();
+  const size_t quads = nodes.size() / 4;
+  if (wantedTris <= 0 || quads < 2 || triF4Num >= int(HK_LEAF_LDS_FLAG)) return out;
+  auto valid = [](const HydraBVHNode& n) { return !(n.leftOffsetAndLeaf == HYDRA_BVH_INVALID && n.escapeIndex == HYDRA_BVH_INVALID); };
+  auto area = [](const float* lo, const float* hi) {
+    const double dx = std::max(0.0f, hi[0] - lo[0]), dy = std::max(0.0f, hi[1] - lo[1]), dz = std::max(0.0f, hi[2] - lo[2]);
+    return 2.0 * (dx * dy + dy * dz + dx * dz);
+  };
+  struct Item { double w; uint32_t quad; int level; bool operator<(const Item& o) const { return w < o.w; } };
+  struct Cand { double w; size_t node; uint32_t link; };
+  std::priority_queue<Item> heap;
+  std::vector<Cand> cands;
+  heap.push({1.0, 1u, haveInst ? 0 : 1});
+  std::vector<uint8_t> seen(quads * 2, 0);
+  for (int pops = 0; !heap.empty() && pops < 4096; ) {
+    const Item it = heap.top();
+    heap.pop();
+    if (it.quad >= quads || seen[size_t(it.quad) * 2 + it.level]) continue;
+    seen[size_t(it.quad) * 2 + it.level] = 1;
+    pops++;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int k = 0; k < 4; k++) {
+      const HydraBVHNode& n = nodes[size_t(it.quad) * 4 + k];
+      if (!valid(n)) continue;
+      for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], n.boxMin[a]); hi[a] = std::max(hi[a], n.boxMax[a]); }
+    }
+    const double qa = std::max(area(lo, hi), 1e-30);
+    for (int k = 0; k < 4; k++) {
+      const size_t at = size_t(it.quad) * 4 + k;
+      const HydraBVHNode& n = nodes[at];
+      if (!valid(n)) continue;
+      const double w = it.w * std::min(area(n.boxMin, n.boxMax) / qa, 1.0);
+      const uint32_t off = n.leftOffsetAndLeaf & 0x7fffffffu;
+      if (!(n.leftOffsetAndLeaf & HYDRA_BVH_LEAF)) heap.push({w, off, it.level});
+      else if (it.level == 1) cands.push_back({w, at, n.leftOffsetAndLeaf});
+      else if (off < quads) {
+        const uint32_t next = nodes[size_t(off) * 4].leftOffsetAndLeaf;
+        if (!(next & HYDRA_BVH_LEAF)) heap.push({w, next, 1});
+        else cands.push_back({w, size_t(off) * 4, next});      // an object that is one leaf: the instance quad's own link
+      }
+    }
+  }
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.w > b.w; });
+  std::vector<uint8_t> taken(nodes.size(), 0);
+  int used = 0;
+  for (const Cand& cd : cands) {
+    const int count = int((cd.link >> HK_LEAF_COUNT_SHIFT) & 15u);
+    const int first = int(cd.link & HK_LEAF_OFFSET_MASK) + 1;
+    if (count == 0 || used + count > wantedTris || taken[cd.node] || first + 3 * count > triF4Num) continue;
+    taken[cd.node] = 1;
+    out.push_back({cd.node, count, used});
+    for (int i = 0; i < 3 * count; i++) poolF4.push_back(first + i);
+    used += count;
+    if (used == wantedTris) break;
+  }
+  return out;
+}
+
 // Choose the quads to keep in LDS: best-first walk from the root, a child's priority = its parent's times the ratio of the
 // child's box area to the area of the quad's union box (the surface-area estimate of how often a ray that visits the parent
 // goes on to the child); an instance leaf hands its priority to the root of the object tree it names.  On the reference's
@@ -1685,8 +1758,19 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   hipLaunchKernelGGL(k_prepare_bvh, dim3(grid_for(c, nodes_num, 256, 8)), dim3(256), 0, c->stream, nodes_num, static_cast<float4*>(c->bvhNodes[tree].p));
   HCHECK(hipGetLastError());
   {   // the copy the persistent kernels walk: same nodes, links to the quads kept in LDS tagged with their slot
+    std::vector<int> poolF4;
+    const std::vector<TopLeaf> topLeaves = (c->leafEnc[tree] && c->topWanted > 0) ? choose_top_leaves(devNodes, have_inst != 0, tri_f4_num, std::min(c->topTrisWanted, HK_TOP_TRIS), poolF4)
+                                                                                   : std::vector<TopLeaf>();
     const std::vector<int> top = choose_and_tag_top_quads(devNodes, have_inst != 0, std::min(c->topWanted, HK_TOP_QUADS));
     c->topCount = int(top.size());
+    c->topTriCount = 0;
+    if (c->topCount > 0 && !topLeaves.empty()) {   // leaf links are not touched by the quad tagging: rewrite them in the same copy
+      for (const TopLeaf& l : topLeaves)
+        devNodes[l.node].leftOffsetAndLeaf = HYDRA_BVH_LEAF | (uint32_t(l.count) << HK_LEAF_COUNT_SHIFT) | uint32_t(HK_LEAF_LDS_FLAG) | uint32_t(l.poolStart);
+      rc = dev_upload(c, c->topTriF4, poolF4.data(), poolF4.size() * sizeof(int));
+      if (rc) return rc;
+      c->topTriCount = int(poolF4.size() / 3);
+    }
     if (c->topCount > 0) {
       rc = dev_upload(c, c->bvhNodesTop, devNodes.data(), size_t(nodes_num) * sizeof(HydraBVHNode));
       if (rc) return rc;
@@ -1950,6 +2034,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_rays_per_lane: 1..64"); c->traceRaysPerLane = value; }
   else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
   else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
+  else if (n == "top_tris_in_lds") { if (value < 0 || value > HK_TOP_TRIS) return fail(c, HYDRA_HIP_EINVAL, "top_tris_in_lds: 0.." + std::to_string(HK_TOP_TRIS)); c->topTrisWanted = value; }
   else if (n == "top_quads_in_lds") { if (value < 0 || value > HK_TOP_QUADS) return fail(c, HYDRA_HIP_EINVAL, "top_quads_in_lds: 0.." + std::to_string(HK_TOP_QUADS)); c->topWanted = value; }
   else if (n == "scene_tables_in_lds") { if (value < 0 || value > 2) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0, 1 or 2"); c->sceneTablesInLds = value; }
   else if (n == "sort_paths") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "sort_paths: 0 or 1"); c->sortPathsWanted = value; }
@@ -1989,6 +2074,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "path_order") *value = c->streamMajor;
   else if (n == "leaf_count_links") *value = c->leafEncWanted;
   else if (n == "top_quads_in_lds") *value = c->topWanted;
+  else if (n == "top_tris_in_lds") *value = c->topTrisWanted;
   else if (n == "samples_in_flight") *value = c->streamsWanted > 0 ? c->streamsWanted : auto_streams(size_t(c->w) * c->h);
   else return fail(c, HYDRA_HIP_EINVAL, "get_option: unknown option " + n);
   return HYDRA_HIP_OK;

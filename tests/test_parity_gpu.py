@@ -395,26 +395,29 @@ def test_tuning_options_do_not_change_the_image(fix, request):
 def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, name, w, h, depth):
     """the device copies of the node array carry triangle counts in their leaf links and slot numbers in the links to the quads
     kept in LDS (hk_trace.h): hits, per-ray visit counters, shadow answers, the image and the ray counts are bit-identical
-    with the plain copy (instanced and non-instanced tree walk; 0, 5 and 21 cached quads)"""
+    with the plain copy (instanced and non-instanced tree walk; 0, 5 and 21 cached quads; 0, 5 and 16 triangles of the hottest leaves in LDS)"""
     from hydracore_amd import HipCore
     _, b = host_scene(name, w, h, depth)
     rk = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0) if name.startswith("atrium") else {}
     pos4, dir4 = random_rays(30000, 77, **rk)
     tfar = np.random.default_rng(4).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
     outs = []
-    for links, top in ((0, 0), (1, 0), (1, 5), (1, 21), (0, 21)):
+    for links, top, tris in ((0, 0, 0), (1, 0, 16), (1, 5, 0), (1, 21, 0), (0, 21, 16), (1, 21, 5), (1, 21, 16)):
         core = HipCore(w, h, device=0)
         core.set_option("leaf_count_links", links)
         core.set_option("top_quads_in_lds", top)
+        core.set_option("top_tris_in_lds", tris)
         core.upload_scene(b)
         hits, cnt = core.stage_trace(pos4, dir4, counters=True)
         vis = core.stage_shadow_trace(pos4, dir4, tfar)
         bh = core.bench_trace(pos4, dir4, iters=1)                 # the persistent kernels (the ones that use the LDS quads) on the same rays
+        tot = core.stage_trace_totals(pos4, dir4)                  # ... and their counting variants: same totals whatever sits in LDS
+        stot = core.stage_trace_totals(pos4, dir4, tfar)
         core.init_path_tracing(5)
         core.reset_perf_counters()
         core.trace_pass(2)
         st = core.rays_stat()
-        outs.append((hits.copy(), cnt.copy(), vis.copy(), core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays)))
+        outs.append((hits.copy(), cnt.copy(), vis.copy(), core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays), tuple(int(x) for x in tot), tuple(int(x) for x in stot)))
         core.close()
     for o in outs[1:]:
         assert (outs[0][0] == o[0]).all() and (outs[0][1] == o[1]).all() and (outs[0][2] == o[2]).all()
