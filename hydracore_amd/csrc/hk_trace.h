@@ -171,12 +171,12 @@ HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const floa
 #define HK_GEOM_ID(g) ((g) & ~HK_CLASS_BITS)
 #define HK_GEOM_CLASS(g) (((g) >> HK_CLASS_SHIFT) & 15)
 
-template <bool ANYHIT, bool COUNT, bool TOPCACHE = false>
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,
                                   const BvhView& bv, int instId, bool useInstId, TravCounters& cnt) {
   int first, count;
   const int enc = bv.leafEnc ? ((leaf_offset >> HK_LEAF_COUNT_SHIFT) & 15) : 0;
-  const bool inLds = TOPCACHE && enc != 0 && (leaf_offset & HK_LEAF_LDS_FLAG) != 0;   // one of the hottest leaves: its triangles sit in LDS
+  const bool inLds = TOPTRIS && enc != 0 && (leaf_offset & HK_LEAF_LDS_FLAG) != 0;   // one of the hottest leaves: its triangles sit in LDS
   if (inLds) { first = (leaf_offset & 0xff) * 3; count = enc; }
   else if (enc != 0) { first = (leaf_offset & HK_LEAF_OFFSET_MASK) + 1; count = enc; }
   else {
@@ -228,7 +228,7 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
 
 // returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
 // traversing (minActive <= 0: never suspend).
-template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack>
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false>
 HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
                      const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive) {
   while (t.top >= 0) {
@@ -287,13 +287,13 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
     }
     if (!haveInst) {
       if (t.top >= 0) {
-        t.hit = IntersectLeaf<ANYHIT, COUNT, TOPCACHE>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
+        t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
         if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       }
       t.top--;
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 1) {
-      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPCACHE>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
+      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
       if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       t.top--;
       t.left = stack.get(t.top);

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
 // (one atomic per wave per refill), and a wave whose active-lane count drops below `minActive` suspends traversal to
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   constexpr int LDS_DEPTH = (ANYHIT && !COUNT) ? HK_LDS_DEPTH_SHADOW : HK_LDS_DEPTH;
   __shared__ int ldsStack[LDS_DEPTH * HK_TRACE_BLOCK];
   __shared__ float4 ldsTop[HK_TOP_QUADS * HK_TOP_STRIDE];
-  __shared__ float4 ldsTri[HK_TOP_TRIS * 3];   // the LDS-staged triangle packets: the leaves rays visit most (chosen at upload)
+  __shared__ float4 ldsTri[TOPTRIS ? HK_TOP_TRIS * 3 : 1];   // the LDS-staged triangle packets: the leaves rays visit most (chosen at upload)
   const SegIter it = segq_iter(q);
   const int count = it.count, segBase = it.base;
   // the live count is only known on the device: when it is small, let only the first blocks of the segment take part so
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   const bool useTop = (s.topCount > 0);
   if (useTop) {
     for (int i = threadIdx.x; i < s.topCount * 8; i += HK_TRACE_BLOCK) ldsTop[(i >> 3) * HK_TOP_STRIDE + (i & 7)] = s.bvhTop[size_t(s.topQuads[i >> 3]) * 8 + (i & 7)];
-    for (int i = threadIdx.x; i < s.topTriCount * 3; i += HK_TRACE_BLOCK) ldsTri[i] = s.tris[s.topTriF4[i]];
+    if (TOPTRIS) for (int i = threadIdx.x; i < s.topTriCount * 3; i += HK_TRACE_BLOCK) ldsTri[i] = s.tris[s.topTriF4[i]];
     __syncthreads();
   }
   BvhView bv = make_bvh_view(useTop ? s.bvhTop : s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
     }
     if (__ballot(busy) == 0ull) break;
     if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
       if (done) {
         if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
         else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
@@ -813,7 +813,7 @@ struct hydra_hip_ctx {
   int srgbLutWanted = 1;
   DevBuf leafHeaders; int leafHeadersNum = 0; bool classDirty = true;   // triangle-leaf headers of tree 0; the class labels in the device triangle lists must be (re)written
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
-  DevBuf topTriF4; int topTriCount = 0, topTrisWanted = HK_TOP_TRIS;   // option "top_tris_in_lds" (0..HK_TOP_TRIS), read by the next upload_bvh
+  DevBuf topTriF4; int topTriCount = 0, topTrisWanted = 0;   // option "top_tris_in_lds" (0..HK_TOP_TRIS), read by the next upload_bvh
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
   size_t globalsWords = 0;
@@ -1208,8 +1208,11 @@ static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, c
   }
   const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
   float4* out = reinterpret_cast<float4*>(hits);
-  if (totals5) hipLaunchKernelGGL((k_trace_dyn<false, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive, c->traceRaysPerLane);
-  else hipLaunchKernelGGL((k_trace_dyn<false, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, static_cast<float*>(nullptr), totals5, c->traceMinActive, c->traceRaysPerLane);
+  float* nov = nullptr;
+#define HK_LAUNCH_DYN(CNT, TT) hipLaunchKernelGGL((k_trace_dyn<false, CNT, TT>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, nov, totals5, c->traceMinActive, c->traceRaysPerLane)
+  if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true); else HK_LAUNCH_DYN(false, true); }
+  else { if (totals5) HK_LAUNCH_DYN(true, false); else HK_LAUNCH_DYN(false, false); }
+#undef HK_LAUNCH_DYN
 }
 static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* org4, const float4* dir4,
                           float* vis, unsigned long long* totals5, uint32_t* fetchCounters) {
@@ -1220,8 +1223,11 @@ static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, co
     return;
   }
   const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
-  if (totals5) hipLaunchKernelGGL((k_trace_dyn<true, true>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive, c->traceRaysPerLane);
-  else hipLaunchKernelGGL((k_trace_dyn<true, false>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, static_cast<float4*>(nullptr), vis, totals5, c->traceMinActive, c->traceRaysPerLane);
+  float4* noh = nullptr;
+#define HK_LAUNCH_DYN(CNT, TT) hipLaunchKernelGGL((k_trace_dyn<true, CNT, TT>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, noh, vis, totals5, c->traceMinActive, c->traceRaysPerLane)
+  if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true); else HK_LAUNCH_DYN(false, true); }
+  else { if (totals5) HK_LAUNCH_DYN(true, false); else HK_LAUNCH_DYN(false, false); }
+#undef HK_LAUNCH_DYN
 }
 
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);

@@ -132,7 +132,8 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * "scene_tables_in_lds" 1 = k_bounce copies the material arena, the material / texture id tables and the lights into LDS when they fit 48 KB,
  * 2 (default) = also the geometry-id -> triangle-record table, the per-instance light ids and inverse matrices when those fit 16 KB, 0 = nothing;
  * "srgb_table" 1 = sRGB texel decode through a 256-entry table filled on the device by the decode function itself (default), 0 = powf per tap;
- * "top_tris_in_lds" 0..16 = size of the triangle pool the same kernels keep in LDS for the most visited leaves (default 16; read by the next upload_bvh);
+ * "top_tris_in_lds" 0..16 = size of the triangle pool the same kernels keep in LDS for the most visited leaves (default 0: measured to change nothing,
+ * DESIGN.md; read by the next upload_bvh, HYDRA_HIP_TOP_TRIS presets it);
  * "top_quads_in_lds" 0..21 = how many of the most visited BVH quads the persistent traversal kernels keep in LDS (default 21;
  * read by the next upload_bvh, HYDRA_HIP_TOP_QUADS presets it).  HYDRA_HIP_TRACE_MODE / _MIN_ACTIVE / _BLOCKS_PER_CU in the environment preset the first three.
  * Sampling: "samples_in_flight" K = samples per pixel traced concurrently (1..512, 0 = chosen from the resolution:
