@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc child runs (roofline then uses the committed profiles/*/pmc_live_*.json of this workload, if any)")
     ap.add_argument("--pmc-out", default="", help="directory for the PMC child runs' output (default: gpurun_out/pmc_live if writable, else a temp dir)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of N ranks on one GPU)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="how the N > 1 ranks exchange the accumulator: native = the HIP layer's own RCCL gather of owned tiles (hydra_hip_comm_gather_frame, "
+                         "rehearsed and checked against the torch path before the timed region, which is used instead if the check fails); torch = torch.distributed.reduce")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal only)")
     args = ap.parse_args()
 
@@ -195,7 +198,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hydracore_amd import HostScene
-    from hydracore_amd.multi_gpu import all_reduce_max, all_reduce_scalar, reduce_accumulator
+    from hydracore_amd.multi_gpu import all_reduce_max, all_reduce_scalar, native_comm_init, reduce_accumulator
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,6 +256,36 @@ def main():
 
     for _ in range(args.warmup):
         core.trace_pass(args.spp_per_step)
+    # N > 1: rehearse the layer's own RCCL exchange on the warm-up frame and check it, bit for bit, against torch.distributed.reduce
+    # of the same frame; every rank then takes the same decision
+    exchange = "none (one rank)"
+    if world > 1:
+        exchange = "torch.distributed.reduce(SUM) of the zero-padded full frame"
+        if args.exchange == "native" and args.backend == "nccl":
+            ok = torch.ones(1, device=dev)
+            why = ""
+            try:
+                native_comm_init(core, rank, world, dev)
+            except Exception as e:          # noqa: BLE001 -- any failure means: use the torch path
+                ok.zero_()
+                why = str(e)[:160]
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() > 0:
+                core.finish()
+                expected = accum.clone()
+                reduce_accumulator(expected, dst=0)
+                core.comm_gather_frame(0)
+                core.finish()
+                torch.cuda.synchronize()
+                if rank == 0 and not torch.equal(accum, expected):
+                    ok.zero_()
+                    why = "gathered frame differs from the reduced frame"
+                dist.broadcast(ok, src=0)
+            if ok.item() > 0:
+                exchange = "hydra_hip_comm_gather_frame: RCCL send/recv of every rank's own tiles (1/%d of the frame each) to rank 0" % world
+            elif rank == 0:
+                exchange += " (native gather not used: %s)" % (why or "another rank failed to initialise it")
+    use_native = exchange.startswith("hydra_hip_comm")
     core.clear()
     core.enable_stage_timing(True)
     core.reset_perf_counters()
@@ -267,6 +300,9 @@ def main():
         host = accum.cpu()
         reduce_accumulator(host, dst=0)
         accum.copy_(host)
+    elif use_native:
+        core.comm_gather_frame(0)                                  # the one RCCL exchange of the frame, on the layer's stream
+        core.finish()
     else:
         reduce_accumulator(accum, dst=0)                          # the one RCCL exchange of the frame
     torch.cuda.synchronize()
@@ -302,7 +338,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload + ", %dx%d, %d bounces, %d spp, PT (MIS) integrator" % (w, h, depth, spp_total),
-                       "spp_per_step": args.spp_per_step, "samples_in_flight": core.samples_in_flight(), "tile": args.tile, "partition": "image tiles in Morton order, i-th tile -> rank i %% %d" % world,
+                       "spp_per_step": args.spp_per_step, "samples_in_flight": core.samples_in_flight(), "tile": args.tile, "exchange": exchange, "partition": "image tiles in Morton order, i-th tile -> rank i %% %d" % world,
                        "rays": int(rays_total), "mean_radiance": float(img[..., :3].mean())},
             "stage_ms": {"raygen": st.raygenTimeMs, "trace": st.traversalTimeMs, "bounce_hit_light_bsdf": st.evalHitMs, "shadow": st.shadowTimeMs,
                          "shade_split_form_only": st.shadeTimeMs, "accumulate": st.accumTimeMs, "pass_total": st.passTimeMs},

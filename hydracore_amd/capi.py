@@ -49,6 +49,8 @@ C_ABI_SYMBOLS = [
     "hydra_hip_get_traversal_counters", "hydra_hip_get_traversal_oob", "hydra_hip_stage_trace_totals", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
+    "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
+    "hydra_hip_stage_pack_unpack",
 ]
 
 _hip = None
@@ -111,6 +113,12 @@ def load_hip_library():
         "hydra_hip_stage_path_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_random": ([vp, i32, vp, i32, vp, vp], i32),
         "hydra_hip_bench_trace": ([vp, i32, vp, vp, i32, i32, f32p], i32),
+        "hydra_hip_comm_unique_id": ([vp, vp], i32),
+        "hydra_hip_comm_init": ([vp, vp, i32, i32], i32),
+        "hydra_hip_comm_gather_frame": ([vp, i32], i32),
+        "hydra_hip_comm_reduce_frame": ([vp, i32], i32),
+        "hydra_hip_comm_destroy": ([vp], i32),
+        "hydra_hip_stage_pack_unpack": ([vp, vp, i32, i32], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -396,6 +404,31 @@ class HipCore:
         col = np.empty((n, 4), np.float32)
         self._ck(self.lib.hydra_hip_stage_path_trace(self.h, n, _ptr(pos4), _ptr(dir4), _ptr(rng2), _ptr(col)), "stage_path_trace")
         return col, rng2
+
+    # ---- multi-GPU exchange over RCCL (hydra_hip_comm_*)
+    def comm_unique_id(self):
+        buf = np.zeros(128, np.uint8)
+        self._ck(self.lib.hydra_hip_comm_unique_id(self.h, _ptr(buf)), "comm_unique_id")
+        return buf
+
+    def comm_init(self, id128, rank, world):
+        buf = np.ascontiguousarray(id128, dtype=np.uint8)
+        assert buf.size == 128
+        self._ck(self.lib.hydra_hip_comm_init(self.h, _ptr(buf), rank, world), "comm_init")
+
+    def comm_gather_frame(self, root=0):
+        self._ck(self.lib.hydra_hip_comm_gather_frame(self.h, root), "comm_gather_frame")
+
+    def comm_reduce_frame(self, root=0):
+        self._ck(self.lib.hydra_hip_comm_reduce_frame(self.h, root), "comm_reduce_frame")
+
+    def comm_destroy(self):
+        self._ck(self.lib.hydra_hip_comm_destroy(self.h), "comm_destroy")
+
+    def stage_pack_unpack(self, w, h):
+        out = np.empty((h, w, 4), np.float32)
+        self._ck(self.lib.hydra_hip_stage_pack_unpack(self.h, _ptr(out), w, h), "stage_pack_unpack")
+        return out
 
     def bench_trace(self, pos4, dir4, iters=20, shadow=False):
         n = pos4.shape[0]

@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is dlopen()ed by hydra_hip_comm_init
 #include "../../include/hydra_hip.h"
 #include "hk_common.h"
 #include "hk_trace.h"
@@ -629,6 +631,14 @@ __global__ void k_accumulate(int n, const int* __restrict__ ownedPixels, const f
     accum[pixel] = a;
   }
 }
+// multi-GPU exchange (hydra_hip_comm_gather_frame): a rank packs the accumulator values of its own pixels, slot order, for the root ...
+__global__ void k_pack_owned(int n, const int* __restrict__ ownedPixels, const float4* __restrict__ accum, float4* __restrict__ packed) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) packed[i] = accum[ownedPixels[i]];
+}
+// ... and the root drops what it received into its frame (supports are disjoint: plain stores, nothing is added)
+__global__ void k_unpack_owned(int n, const int* __restrict__ pixels, const float4* __restrict__ packed, float4* __restrict__ accum) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) accum[pixels[i]] = packed[i];
+}
 // counters are laid out [bounce][segment] with HK_CSTRIDE words between neighbours; one wave, lane = segment
 __global__ void k_tally(const uint32_t* __restrict__ live, const uint32_t* __restrict__ shadowCnt, int maxDepth, int nseg, unsigned long long* totals) {
   const int sg = int(threadIdx.x);
@@ -863,6 +873,23 @@ struct hydra_hip_ctx {
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
   DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris, out-of-range fetches]
+  // RCCL exchange of the accumulator without Python (hydra_hip_comm_*): function table of the dlopen()ed library, communicator, staging
+  struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  } rccl;
+  ncclComm_t comm = nullptr;
+  int commRank = -1, commWorld = 0;
+  DevBuf commPacked, commRecv, commPixels;     // this rank's packed pixels; (root) the other ranks' packed pixels and their pixel indices
+  std::vector<long long> commCount;            // (root) owned pixels per rank
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
   uint64_t nTrace = 0, nShadow = 0;   // launches folded into tTrace / tShadow
@@ -1386,6 +1413,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)hydra_hip_comm_destroy(c);
   DevBuf* all[] = {&c->srgbLut, &c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
@@ -1399,6 +1427,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   return HYDRA_HIP_OK;
 }
 
+int hydra_hip_comm_destroy(hydra_hip_handle c);
 const char* hydra_hip_last_error(hydra_hip_handle c) { return c ? c->err.c_str() : g_createError.c_str(); }
 
 int hydra_hip_device_name(hydra_hip_handle c, char* buf, int n) {
@@ -2336,6 +2365,144 @@ int hydra_hip_stage_trace_totals(hydra_hip_handle c, int n, const float* ray_pos
   else launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, nullptr, dt, fetch);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(totals6, dt, 6 * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU exchange (RCCL)
+// tiles of the image plane are partitioned over the GPUs of one node and the only exchange per frame is the float4
+// accumulator.  These entry points do that exchange for a host without Python or torch (a RenderDriverRTE-style C++ process per
+// GPU; precedent for "every process adds its frame into one image": hydra_drv/GPUOCLLayerOther.cpp:365-429): RCCL is dlopen()ed,
+// the communicator lives in the context, the collective runs on the context's stream behind the frame's kernels.
+static bool load_rccl(hydra_hip_ctx* c) {
+  if (c->rccl.lib) return true;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);   // an already loaded RCCL (e.g. torch's) is reused
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) { c->err = std::string("hydra_hip_comm: cannot load librccl.so: ") + dlerror(); return false; }
+  auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) c->err = std::string("hydra_hip_comm: librccl.so lacks ") + n; return p; };
+#define HK_RCCL_SYM(field, name) c->rccl.field = reinterpret_cast<decltype(c->rccl.field)>(sym(name)); if (!c->rccl.field) return false;
+  HK_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") HK_RCCL_SYM(CommInitRank, "ncclCommInitRank") HK_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  HK_RCCL_SYM(Reduce, "ncclReduce") HK_RCCL_SYM(Send, "ncclSend") HK_RCCL_SYM(Recv, "ncclRecv") HK_RCCL_SYM(GroupStart, "ncclGroupStart")
+  HK_RCCL_SYM(GroupEnd, "ncclGroupEnd") HK_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef HK_RCCL_SYM
+  c->rccl.lib = lib;
+  return true;
+}
+#define NCHECK(call)                                                                                   \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) { c->err = std::string(#call) + ": " + c->rccl.GetErrorString(r_); return HYDRA_HIP_EDEVICE; } \
+  } while (0)
+
+int hydra_hip_comm_unique_id(hydra_hip_handle c, char* id128) {
+  if (!c || !id128) return HYDRA_HIP_EINVAL;
+  if (!load_rccl(c)) return HYDRA_HIP_EDEVICE;
+  ncclUniqueId id;
+  NCHECK(c->rccl.GetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, 128);
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_comm_init(hydra_hip_handle c, const char* id128, int rank, int world) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, HYDRA_HIP_EINVAL, "comm_init: bad arguments");
+  if (rank != c->rank || world != c->world) return fail(c, HYDRA_HIP_ESTATE, "comm_init: rank / world differ from set_tile_partition");
+  if (c->comm) return fail(c, HYDRA_HIP_ESTATE, "comm_init: already initialised (comm_destroy first)");
+  HCHECK(hipSetDevice(c->device));
+  if (!load_rccl(c)) return HYDRA_HIP_EDEVICE;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  NCHECK(c->rccl.CommInitRank(&c->comm, world, id, rank));
+  c->commRank = rank; c->commWorld = world;
+  c->commCount.clear();
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_comm_destroy(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (c->comm) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  dev_free(c->commPacked); dev_free(c->commRecv); dev_free(c->commPixels);
+  c->commCount.clear(); c->commRank = -1; c->commWorld = 0;
+  return HYDRA_HIP_OK;
+}
+// the staging a gather needs: this rank's packed buffer; on the root also the receive buffer and every other rank's pixel list
+static int comm_prepare(hydra_hip_ctx* c, int root) {
+  if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
+  int rc;
+  if ((rc = dev_alloc(c, c->commPacked, std::max<size_t>(1, size_t(c->N)) * 16)) != 0) return rc;
+  if (c->commRank != root || !c->commCount.empty()) return HYDRA_HIP_OK;
+  std::vector<int> all, one;
+  c->commCount.assign(size_t(c->commWorld), 0);
+  for (int r = 0; r < c->commWorld; r++) {
+    if (r == root) continue;
+    build_slot_map(c->w, c->h, c->tile, r, c->commWorld, &one, nullptr);
+    c->commCount[size_t(r)] = (long long)one.size();
+    all.insert(all.end(), one.begin(), one.end());
+  }
+  if ((rc = dev_upload(c, c->commPixels, all.data(), all.size() * 4)) != 0) return rc;
+  return dev_alloc(c, c->commRecv, std::max<size_t>(1, all.size()) * 16);
+}
+int hydra_hip_comm_gather_frame(hydra_hip_handle c, int root) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (c->world == 1) return HYDRA_HIP_OK;                 // one rank owns the whole frame
+  if (!c->comm) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: comm_init first");
+  if (root < 0 || root >= c->commWorld) return fail(c, HYDRA_HIP_EINVAL, "comm_gather_frame: bad root");
+  if (c->rank != c->commRank || c->world != c->commWorld) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: the tile partition changed after comm_init");
+  HCHECK(hipSetDevice(c->device));
+  { int rc = comm_prepare(c, root); if (rc) return rc; }
+  if (c->commRank != root) {
+    if (c->N > 0) {
+      hipLaunchKernelGGL(k_pack_owned, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), c->accum, static_cast<float4*>(c->commPacked.p));
+      HCHECK(hipGetLastError());
+      NCHECK(c->rccl.Send(c->commPacked.p, size_t(c->N) * 4, ncclFloat, root, c->comm, c->stream));
+    }
+    return HYDRA_HIP_OK;
+  }
+  long long total = 0;
+  NCHECK(c->rccl.GroupStart());
+  for (int r = 0; r < c->commWorld; r++) {
+    if (r == root || c->commCount[size_t(r)] == 0) continue;
+    const ncclResult_t rr = c->rccl.Recv(static_cast<float4*>(c->commRecv.p) + total, size_t(c->commCount[size_t(r)]) * 4, ncclFloat, r, c->comm, c->stream);
+    if (rr != ncclSuccess) { (void)c->rccl.GroupEnd(); c->err = std::string("ncclRecv: ") + c->rccl.GetErrorString(rr); return HYDRA_HIP_EDEVICE; }
+    total += c->commCount[size_t(r)];
+  }
+  NCHECK(c->rccl.GroupEnd());
+  if (total > 0) {
+    hipLaunchKernelGGL(k_unpack_owned, dim3(grid_for(c, int(total), 256, 8)), dim3(256), 0, c->stream, int(total), static_cast<const int*>(c->commPixels.p),
+                       static_cast<const float4*>(c->commRecv.p), c->accum);
+    HCHECK(hipGetLastError());
+  }
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_comm_reduce_frame(hydra_hip_handle c, int root) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (c->world == 1) return HYDRA_HIP_OK;
+  if (!c->comm) return fail(c, HYDRA_HIP_ESTATE, "comm_reduce_frame: comm_init first");
+  if (root < 0 || root >= c->commWorld) return fail(c, HYDRA_HIP_EINVAL, "comm_reduce_frame: bad root");
+  if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "comm_reduce_frame: nothing rendered yet");
+  HCHECK(hipSetDevice(c->device));
+  NCHECK(c->rccl.Reduce(c->accum, c->accum, size_t(c->w) * c->h * 4, ncclFloat, ncclSum, root, c->comm, c->stream));
+  return HYDRA_HIP_OK;
+}
+// the pack / unpack kernels of comm_gather_frame without a second GPU: this rank's pixels are packed and dropped into a zeroed
+// frame, which is returned (test entry point: the result must equal the accumulator on the rank's tiles and be zero elsewhere)
+int hydra_hip_stage_pack_unpack(hydra_hip_handle c, float* rgba_frame, int width, int height) {
+  if (!c || !rgba_frame) return HYDRA_HIP_EINVAL;
+  if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "stage_pack_unpack: bad resolution");
+  if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "stage_pack_unpack: nothing rendered yet");
+  HCHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = dev_alloc(c, c->commPacked, std::max<size_t>(1, size_t(c->N)) * 16)) != 0) return rc;
+  DevBuf frame;
+  if ((rc = dev_alloc(c, frame, size_t(width) * height * 16)) != 0) return rc;
+  HCHECK(hipMemsetAsync(frame.p, 0, size_t(width) * height * 16, c->stream));
+  if (c->N > 0) {
+    hipLaunchKernelGGL(k_pack_owned, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), c->accum, static_cast<float4*>(c->commPacked.p));
+    hipLaunchKernelGGL(k_unpack_owned, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p),
+                       static_cast<const float4*>(c->commPacked.p), static_cast<float4*>(frame.p));
+  }
+  const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
+  const hipError_t e3 = (e1 == hipSuccess && e2 == hipSuccess) ? hipMemcpy(rgba_frame, frame.p, size_t(width) * height * 16, hipMemcpyDeviceToHost) : hipSuccess;
+  dev_free(frame);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, HYDRA_HIP_EDEVICE, "stage_pack_unpack: a HIP call failed");
   return HYDRA_HIP_OK;
 }
 

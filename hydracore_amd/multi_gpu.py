@@ -68,3 +68,16 @@ def all_reduce_max(value, device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def native_comm_init(core, rank, world, device):
+    """Bootstrap the HIP layer's own RCCL communicator (hydra_hip_comm_*): rank 0 draws the ncclUniqueId through the C-ABI and
+    the 128 bytes travel over the torch.distributed group that already exists (any other channel would do: a C++ host uses a
+    socket or a file).  Collective: every rank must call it."""
+    import torch
+    import torch.distributed as dist
+    ident = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        ident.copy_(torch.from_numpy(core.comm_unique_id()).to(device))
+    dist.broadcast(ident, src=0)
+    core.comm_init(ident.cpu().numpy(), rank, world)

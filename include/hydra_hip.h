@@ -154,6 +154,26 @@ int hydra_hip_get_traversal_counters(hydra_hip_handle h, uint64_t* out, int max_
  * summed here over all bounces since enable_traversal_counters(1): must be 0 for a well-formed tree (tests assert it). */
 int hydra_hip_get_traversal_oob(hydra_hip_handle h, uint64_t* out);
 
+/* ---------------------------------------------------------------- multi-GPU exchange
+ * One process per GPU, each with a context whose tile partition is (rank, world).  The only exchange per frame is the float4
+ * accumulator; these entry points do it over RCCL/xGMI without Python (RCCL is dlopen()ed on first use), on the context's own
+ * stream behind the frame's kernels.  Reference precedent: every render process adds its frame into one shared image,
+ * hydra_drv/GPUOCLLayerOther.cpp:365-429.
+ *   rank 0:      hydra_hip_comm_unique_id(h, id)  -> ship the 128 bytes to the other processes (socket, file, MPI, ...)
+ *   every rank:  hydra_hip_comm_init(h, id, rank, world)            (collective; rank/world = set_tile_partition's)
+ *   per frame:   hydra_hip_comm_gather_frame(h, root)               (collective) then hydra_hip_finish; root's accumulator is the frame
+ * gather_frame: every rank packs the sums of ITS pixels (1/world of the frame) and sends them to root, which drops them into its
+ * accumulator -- supports are disjoint, nothing is added, the result has the bits of the one-GPU frame.  reduce_frame is the
+ * ncclReduce(SUM) of the whole zero-padded frame instead (world times the bytes; kept for hosts that prefer one call on a caller-owned
+ * accumulator).  With world == 1 both return at once. */
+int hydra_hip_comm_unique_id(hydra_hip_handle h, char* id128);
+int hydra_hip_comm_init(hydra_hip_handle h, const char* id128, int rank, int world);
+int hydra_hip_comm_gather_frame(hydra_hip_handle h, int root);
+int hydra_hip_comm_reduce_frame(hydra_hip_handle h, int root);
+int hydra_hip_comm_destroy(hydra_hip_handle h);
+/* test entry point: the pack and unpack kernels of comm_gather_frame applied to this rank's own pixels into a zeroed frame */
+int hydra_hip_stage_pack_unpack(hydra_hip_handle h, float* rgba_frame, int width, int height);
+
 /* ---------------------------------------------------------------- stage entry points
  * One call = one wavefront kernel over n host-provided items; used by the parity tests and by the
  * traversal roofline bench.  All pointers are HOST pointers; float4 arrays are n*4 floats.           */

@@ -579,6 +579,39 @@ def test_one_rank_share_of_the_4k_frame(built):
     sc.close()
 
 
+def test_native_rccl_entry_points_on_one_rank(gpu224):
+    """hydra_hip_comm_*: RCCL is found and a communicator comes up (one rank: that is what one GPU allows), the collective calls
+    return at once for world 1; the pack / unpack kernels of the gather move exactly a rank's own tiles."""
+    from hydracore_amd import HydraError
+    from hydracore_amd.multi_gpu import tile_owner_mask
+    core, b, _ = gpu224
+    w, h = b["width"], b["height"]
+    core.set_tile_partition(0, 1, 16)
+    ident = core.comm_unique_id()
+    assert ident.shape == (128,) and ident.any()
+    core.comm_init(ident, 0, 1)
+    with pytest.raises(HydraError):
+        core.comm_init(ident, 0, 1)                  # already initialised
+    core.init_path_tracing(3)
+    core.trace_pass(2)
+    before = core.accumulator(w, h)
+    core.comm_gather_frame(0)
+    core.comm_reduce_frame(0)
+    core.finish()
+    assert (core.accumulator(w, h).view(np.uint32) == before.view(np.uint32)).all()
+    core.comm_destroy()
+    with pytest.raises(HydraError):
+        core.comm_init(ident, 1, 3)                  # not this context's partition
+    for r in (0, 2):
+        core.set_tile_partition(r, 3, 16)
+        core.init_path_tracing(3)
+        core.trace_pass(2)
+        acc, moved = core.accumulator(w, h), core.stage_pack_unpack(w, h)
+        mask = tile_owner_mask(w, h, r, 3, 16)
+        assert (moved[~mask] == 0).all() and (moved.view(np.uint32) == acc.view(np.uint32)).all() and acc[mask][:, :3].sum() > 0
+    core.set_tile_partition(0, 1, 64)
+
+
 def test_shared_accumulation_image_contributions(built):
     """IHWLayer::SetExternalImageAccumulator / ContribToExternalImageAccumulator (IHWLayer.h:199-201; GPUOCLLayerOther.cpp:259-283,
     365-429) through the HipHWLayer adapter: the internal sums are added to the shared image under its lock, its spp and receive
