@@ -1,9 +1,17 @@
-set -e
+#!/bin/bash
+# Round profile set (GPU box): GPU tests, the bench line (with its live PMC child runs), rocprofv3 kernel stats of the same command,
+# the other scenes.  usage: tools/final_profile.sh <outdir under gpurun_out>
+OUT=${1:-gpurun_out/final}
+mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -2 gpurun_out/gpu_tests.log
-timeout -k 10 400 python bench.py > gpurun_out/bench_final.log 2>&1; tail -1 gpurun_out/bench_final.log | cut -c1-160
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final3 -- python3 bench.py --steps 2 --no-cpu-baseline > gpurun_out/bench_under_rocprof_final3.log 2>&1; tail -1 gpurun_out/bench_under_rocprof_final3.log | cut -c1-160
-bash tools/pmc_traffic.sh gpurun_out/pmc_final3 > gpurun_out/pmc_final3.log 2>&1; tail -12 gpurun_out/pmc_final3.log
-timeout -k 10 300 python bench.py --no-cpu-baseline --scene atrium250k > gpurun_out/bench_final_atrium.log 2>&1; tail -1 gpurun_out/bench_final_atrium.log | cut -c90-140
-timeout -k 10 300 python bench.py --no-cpu-baseline --scene atrium250k_sky > gpurun_out/bench_final_atrium_sky.log 2>&1; tail -1 gpurun_out/bench_final_atrium_sky.log | cut -c90-140
-timeout -k 10 300 python bench.py --no-cpu-baseline --scene atrium250k_glass > gpurun_out/bench_final_atrium_glass.log 2>&1; tail -1 gpurun_out/bench_final_atrium_glass.log | cut -c90-140
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -2 $OUT/gpu_tests.log
+timeout -k 10 600 python bench.py --pmc-out $OUT/pmc_live > $OUT/bench_256spp.json.log 2>&1; tail -1 $OUT/bench_256spp.json.log | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 2 --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof_2x64spp.log 2>&1; tail -1 $OUT/bench_under_rocprof_2x64spp.log | cut -c1-160
+for sc in atrium250k atrium250k_sky atrium250k_glass tests/golden/scenes/test_42; do
+  n=$(basename $sc)
+  timeout -k 10 600 python bench.py --no-cpu-baseline --scene $sc --pmc-out $OUT/pmc_live_$n > $OUT/bench_${n}_256spp.json.log 2>&1; tail -1 $OUT/bench_${n}_256spp.json.log | cut -c1-200
+done
+find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_bench_2x64spp.csv
+find $OUT/prof -name "*domain_stats.csv" | head -1 | xargs -I{} cp {} $OUT/domain_stats_bench_2x64spp.csv
+rm -rf $OUT/prof
+ls $OUT
