@@ -162,7 +162,9 @@ def load_host_library():
     lib.hydra_host_open_scene.restype = vp
     lib.hydra_host_close_scene.argtypes = [vp]
     lib.hydra_host_close_scene.restype = None
-    for n in ("hydra_host_width", "hydra_host_height", "hydra_host_unsupported", "hydra_host_have_inst"):
+    lib.hydra_host_have_inst_tree.argtypes = [vp, i32]
+    lib.hydra_host_have_inst_tree.restype = i32
+    for n in ("hydra_host_width", "hydra_host_height", "hydra_host_unsupported", "hydra_host_have_inst", "hydra_host_trees_num"):
         getattr(lib, n).argtypes = [vp]
         getattr(lib, n).restype = i32
     for n in ("hydra_host_log", "hydra_host_last_error"):
@@ -244,10 +246,14 @@ class HipCore:
             a = np.ascontiguousarray(b[key])
             self._ck(L.hydra_hip_upload_storage(self.h, kind, _ptr(a) if a.size else None, a.nbytes), "upload_storage")
         self._ck(L.hydra_hip_upload_globals(self.h, _ptr(g), g.size), "upload_globals")
-        nodes, tris = np.ascontiguousarray(b["bvh_nodes"]), np.ascontiguousarray(b["bvh_tris"])
-        self._ck(L.hydra_hip_upload_bvh(self.h, 0, _ptr(nodes), nodes.nbytes // 32, _ptr(tris), tris.nbytes // 16, None, 0,
-                                        int(b["have_inst"])), "upload_bvh")
-        self._ck(L.hydra_hip_set_bvh_trees_num(self.h, 1), "set_bvh_trees_num")
+        trees = int(b.get("trees_num", 1))
+        for t in range(trees):
+            sfx = "" if t == 0 else str(t)
+            nodes, tris = np.ascontiguousarray(b["bvh_nodes" + sfx]), np.ascontiguousarray(b["bvh_tris" + sfx])
+            alpha = np.ascontiguousarray(b.get("bvh_alpha" + sfx, np.zeros(0, np.uint32)), dtype=np.uint32)
+            self._ck(L.hydra_hip_upload_bvh(self.h, t, _ptr(nodes), nodes.nbytes // 32, _ptr(tris), tris.nbytes // 16,
+                                            _ptr(alpha) if alpha.size else None, alpha.size // 2, int(b["have_inst" + sfx])), "upload_bvh")
+        self._ck(L.hydra_hip_set_bvh_trees_num(self.h, trees), "set_bvh_trees_num")
         im, il = np.ascontiguousarray(b["inst_matrices"], dtype=np.float32), np.ascontiguousarray(b["inst_light_id"], dtype=np.int32)
         if il.size < im.size // 16:
             il = np.concatenate([il, -np.ones(im.size // 16 - il.size, np.int32)])
@@ -441,7 +447,8 @@ class HipCore:
 _BUF_KINDS = [("globals", 0, np.int32), ("textures", 1, np.int32), ("textures_aux", 2, np.int32), ("geom", 3, np.float32),
               ("materials", 4, np.float32), ("pdfs", 5, np.float32), ("bvh_nodes", 6, np.float32), ("bvh_tris", 7, np.float32),
               ("inst_matrices", 8, np.float32), ("inst_light_id", 9, np.int32), ("remap_lists", 10, np.int32),
-              ("remap_table", 11, np.int32), ("remap_inst", 12, np.int32)]
+              ("remap_table", 11, np.int32), ("remap_inst", 12, np.int32), ("bvh_alpha", 13, np.uint32), ("bvh_nodes1", 14, np.float32),
+              ("bvh_tris1", 15, np.float32), ("bvh_alpha1", 16, np.uint32)]
 
 
 class HostScene:
@@ -487,6 +494,8 @@ class HostScene:
                 raw = (C.c_char * n.value).from_address(ptr.value)
                 out[name] = np.frombuffer(bytes(raw), dtype=dt).copy()
         out["have_inst"] = self.lib.hydra_host_have_inst(self.p)
+        out["trees_num"] = self.lib.hydra_host_trees_num(self.p)
+        out["have_inst1"] = self.lib.hydra_host_have_inst_tree(self.p, 1)
         out["width"], out["height"] = self.width, self.height
         return out
 

@@ -121,6 +121,7 @@ struct SceneDev {
   const int*    topTriF4;      // float4 index (in tris) of every float4 of the triangle pool kept in LDS (3 per triangle)
   int           topTriCount;   // triangles in that pool, 0..HK_TOP_TRIS
   int           leafEnc;       // 1: triangle-leaf links of the device node copy carry the triangle count (hk_trace.h, HK_LEAF_COUNT_SHIFT)
+  const uint2*  alpha;         // the tree's alpha table (ctrace.h:380-391), nullptr = no alpha-tested triangles
   const float4* tris;          // tree 0 triangle lists
   unsigned      trisBytes;
   int           haveInst;

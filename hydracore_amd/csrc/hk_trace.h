@@ -41,6 +41,9 @@ typedef float hk_v4f_t __attribute__((ext_vector_type(4)));
 #endif
 #define HK_LEAF_LDS_FLAG 0x04000000
 
+// the software texture fetch of hk_shading.h (declared here for the alpha test of the leaf loop)
+HK_DEV_CALL f3 sample2DExtCall(int samplerOffset, f2 texCoord, const float* blob, const int* texTable, const int4* texStorage, const float* srgbLut);
+
 struct TravCounters { uint32_t quads, insts, tris, leaves, oob; };   // oob: fetches a range-checked buffer load would have answered with zeros (must stay 0)
 
 HK_DEV f3 SafeInverse(f3 d) {   // hydra_drv/cglobals.h:726-735
@@ -108,6 +111,7 @@ typedef HkStackT<HK_LDS_DEPTH> HkStack;
 #ifdef HK_HOST_EMU
 struct BvhView {
   const float4* nodes; const float4* tris; bool leafEnc; const hk_lds_f4* top; const hk_lds_f4* topTri;
+  const uint2* alpha; const int* texTable; const int4* texStorage; const float* srgbLut;
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const { return top[(link & 0xff) * HK_TOP_STRIDE + piece]; }
   HK_DEV_MEMBER float4 topTriPiece(int index) const { return topTri[index]; }
   HK_DEV_MEMBER float4 node(int quad, int piece) const { return nodes[size_t(quad) * 8 + piece]; }
@@ -115,7 +119,7 @@ struct BvhView {
   HK_DEV_MEMBER bool nodeInRange(int) const { return true; }   // the host build runs under AddressSanitizer instead
   HK_DEV_MEMBER bool triInRange(int, int) const { return true; }
 };
-HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; v.topTri = nullptr; return v; }
+HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned, const float4* tris, unsigned, bool leafEnc = false) { BvhView v; v.nodes = nodes; v.tris = tris; v.leafEnc = leafEnc; v.top = nullptr; v.topTri = nullptr; v.alpha = nullptr; v.texTable = nullptr; v.texStorage = nullptr; v.srgbLut = nullptr; return v; }
 #else
 typedef float hk_v4f __attribute__((ext_vector_type(4)));
 struct BvhView {
@@ -124,6 +128,8 @@ struct BvhView {
   bool leafEnc;   // triangle-leaf links of the device copy carry the triangle count (see HK_LEAF_COUNT_SHIFT)
   const hk_lds_f4* top;   // LDS copy of the hottest quads (trav_run<.., TOPCACHE = true> only)
   const hk_lds_f4* topTri;   // LDS pool of the hottest leaves' triangles
+  // alpha-tested trees (IntersectLeaf<.., ALPHA = true>): the tree's alpha table and what its texture fetch needs
+  const uint2* alpha; const int* texTable; const int4* texStorage; const float* srgbLut;
   HK_DEV_MEMBER float4 topPiece(int link, int piece) const {
     const hk_v4f_t v = top[(link & 0xff) * HK_TOP_STRIDE + piece];
     return make_float4(v.x, v.y, v.z, v.w);
@@ -150,6 +156,7 @@ HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const floa
   BvhView v;
   v.leafEnc = leafEnc;
   v.top = nullptr; v.topTri = nullptr;
+  v.alpha = nullptr; v.texTable = nullptr; v.texStorage = nullptr; v.srgbLut = nullptr;
   v.nodeBytes = nodeBytes; v.triBytes = triBytes;
   v.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(nodes), 0, nodeBytes, 0x00020000);
   v.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tris), 0, triBytes, 0x00020000);
@@ -171,7 +178,25 @@ HK_DEV BvhView make_bvh_view(const float4* nodes, unsigned nodeBytes, const floa
 #define HK_GEOM_ID(g) ((g) & ~HK_CLASS_BITS)
 #define HK_GEOM_CLASS(g) (((g) >> HK_CLASS_SHIFT) & 15)
 
-template <bool ANYHIT, bool COUNT, bool TOPTRIS = false>
+// Alpha test of a candidate hit, IntersectAllPrimitivesInLeafAlpha (ctrace.h:330-412): the tree's alpha table holds one uint2 per
+// float4 of the triangle list -- {sampler position in the table | flags, texture coordinate of the vertex packed 2 x 16 bit}
+// (RenderDriverRTE_AlphaTestTable.cpp:65-224) -- and the opacity samplers behind them; the hit counts when the texel's largest
+// channel exceeds 0.5.  decompressTexCoord16: ctrace.h:316-325; sample2DLite: cfetch.h:738-760.
+HK_DEV f2 decompressTexCoord16(uint32_t packed) {
+  const float fx = (1.0f / 65535.0f) * float(packed & 0x0000FFFFu), fy = (1.0f / 65535.0f) * float((packed & 0xFFFF0000u) >> 16);
+  return mk2(2.0f * fx - 1.0f, 2.0f * fy - 1.0f);
+}
+HK_DEV bool alphaTestPasses(const BvhView& bv, int triAddress, float u, float v) {
+  const uint2 a0 = bv.alpha[triAddress], a1 = bv.alpha[triAddress + 1], a2 = bv.alpha[triAddress + 2];
+  const f2 A = decompressTexCoord16(a0.y), B = decompressTexCoord16(a1.y), C = decompressTexCoord16(a2.y);
+  const float w = 1.0f - u - v;
+  const f2 tc = mk2((w * A.x + v * B.x) + u * C.x, (w * A.y + v * B.y) + u * C.y);
+  if (a0.x == 0xFFFFFFFFu || a0.x == HYDRA_INVALID_TEXTURE || int(a0.x) <= 0) return true;   // no opacity texture: white, selector 1
+  const f3 c = sample2DExtCall(0, tc, reinterpret_cast<const float*>(bv.alpha + a0.x), bv.texTable, bv.texStorage, bv.srgbLut);
+  return fmaxf(c.x, fmaxf(c.y, c.z)) > 0.5f;
+}
+
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false>
 HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, HydraLiteHit res,
                                   const BvhView& bv, int instId, bool useInstId, TravCounters& cnt) {
   int first, count;
@@ -199,6 +224,7 @@ HK_DEV HydraLiteHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float
     const float u = dot(qvec, ray_dir) * invDet;
     const float t = dot(edge2, qvec) * invDet;
     if (v > -1e-6f && u > -1e-6f && (u + v < 1.0f + 1e-6f) && t > t_min && t < res.t) {
+      if (ALPHA && !alphaTestPasses(bv, a, u, v)) continue;
       res.t = t;
       res.primId = as_int(d1.w);
       res.geomId = as_int(d2.w);
@@ -228,7 +254,7 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
 
 // returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
 // traversing (minActive <= 0: never suspend).
-template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false>
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false>
 HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
                      const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive) {
   while (t.top >= 0) {
@@ -287,13 +313,13 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
     }
     if (!haveInst) {
       if (t.top >= 0) {
-        t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);
+        t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS, false>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);   // BVH4Traverse has no alpha form (Common.cpp:146)
         if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       }
       t.top--;
       t.left = stack.get(t.top);
     } else if (t.top >= 0 && t.instDeep == 1) {
-      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
+      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS, ALPHA>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
       if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
       t.top--;
       t.left = stack.get(t.top);
@@ -321,12 +347,12 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
   return true;
 }
 
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool ALPHA = false>
 HK_DEV HydraLiteHit hk_traverse(const BvhView& bv, const bool haveInst,
                                 f3 ray_pos, f3 ray_dir, const float t_rayMin, HydraLiteHit hit, HkStack& stack, TravCounters& cnt) {
   TravState t;
   trav_init(t, ray_pos, ray_dir, hit);
-  (void)trav_run<ANYHIT, COUNT>(t, bv, haveInst, t_rayMin, stack, cnt, 0);
+  (void)trav_run<ANYHIT, COUNT, false, HkStack, false, ALPHA>(t, bv, haveInst, t_rayMin, stack, cnt, 0);
   return t.hit;
 }
 

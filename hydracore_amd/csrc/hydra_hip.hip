@@ -122,26 +122,35 @@ __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels
   }
 }
 
-// T1 -- closest hit for every live path (kernel_RayTrace)
-template <bool COUNT>
+// T1 -- closest hit for every live path (kernel_RayTrace).  ALPHA: the tree carries an alpha table (BVH4InstTraverseAlpha,
+// ctrace.h:1297-1520).  carry: this launch walks one of trees 1..3 and starts from the hit the earlier trees left in `hits`
+// (IntegratorCommon::rayTrace loops over the trees with one running Lite_Hit, Common.cpp:128-150; per-ray counters add up).
+template <bool COUNT, bool ALPHA>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(SceneDev s, SegQ q,
                                                            const float4* __restrict__ pos4, const float4* __restrict__ dir4,
                                                            HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3,
-                                                           unsigned long long* __restrict__ totals5) {
+                                                           unsigned long long* __restrict__ totals5, int carry) {
   __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
   const SegIter it = segq_iter(q);
   HkStack st;
   st.init(ldsStack, threadIdx.x);
-  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
+  BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
+  bv.alpha = s.alpha; bv.texTable = s.texTable; bv.texStorage = s.texStorage; bv.srgbLut = s.srgbLut;
   for (int idx = it.first; idx < it.count; idx += it.step) {
     const int i = it.base + idx;
     const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
     TravCounters c = {0, 0, 0, 0, 0};
-    const HydraLiteHit hit = hk_traverse<false, COUNT>(bv, s.haveInst != 0, pos, dir, 0.0f, hk_miss_hit(), st, c);
+    HydraLiteHit h0 = hk_miss_hit();
+    if (carry) { const float4 p = reinterpret_cast<const float4*>(hits)[i]; h0.t = p.x; h0.primId = as_int(p.y); h0.instId = as_int(p.z); h0.geomId = as_int(p.w); }
+    const HydraLiteHit hit = hk_traverse<false, COUNT, ALPHA>(bv, s.haveInst != 0, pos, dir, 0.0f, h0, st, c);
     reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
-    if (COUNT && counters3) { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
+    if (COUNT && counters3) {
+      if (carry) { counters3[3 * i] += c.quads; counters3[3 * i + 1] += c.insts; counters3[3 * i + 2] += c.tris; }
+      else { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
+    }
     if (COUNT && totals5) {   // algorithmic-work counters for the roofline byte model
-      atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
+      if (!carry) atomicAdd(totals5 + 0, 1ull);
+      atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
       atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
       if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
     }
@@ -182,7 +191,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
 // (one atomic per wave per refill), and a wave whose active-lane count drops below `minActive` suspends traversal to
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
-template <bool ANYHIT, bool COUNT, bool TOPTRIS = false>
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
@@ -209,6 +218,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   BvhView bv = make_bvh_view(useTop ? s.bvhTop : s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
   bv.top = (const hk_lds_f4*)ldsTop;
   bv.topTri = (const hk_lds_f4*)ldsTri;
+  if (ALPHA) { bv.alpha = s.alpha; bv.texTable = s.texTable; bv.texStorage = s.texStorage; bv.srgbLut = s.srgbLut; }
   const int rootLink = useTop ? (HK_TOP_FLAG | 0) : 1;
   TravState t;
   TravCounters c = {0, 0, 0, 0, 0};
@@ -245,7 +255,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
     }
     if (__ballot(busy) == 0ull) break;
     if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
       if (done) {
         if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
         else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
@@ -821,10 +831,11 @@ struct hydra_hip_ctx {
   int sceneTablesInLds = 2;          // option "scene_tables_in_lds"
   DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
   int srgbLutWanted = 1;
-  DevBuf leafHeaders; int leafHeadersNum = 0; bool classDirty = true;   // triangle-leaf headers of tree 0; the class labels in the device triangle lists must be (re)written
+  DevBuf leafHeaders[4]; int leafHeadersNum[4] = {0, 0, 0, 0}; bool classDirty = true;   // triangle-leaf headers per tree; the class labels in the device triangle lists must be (re)written
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
   DevBuf topTriF4; int topTriCount = 0, topTrisWanted = 0;   // option "top_tris_in_lds" (0..HK_TOP_TRIS), read by the next upload_bvh
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
+  DevBuf bvhAlpha[4];                // alpha tables of the trees that have one (uint2 per float4 of the triangle list + the opacity samplers)
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
   size_t globalsWords = 0;
   int haveInst[4] = {0, 0, 0, 0};
@@ -934,7 +945,9 @@ static int dev_upload(hydra_hip_ctx* c, DevBuf& b, const void* src, size_t bytes
 }
 static void dev_free(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
 
-static SceneDev make_scene(const hydra_hip_ctx* c) {
+static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree);
+static SceneDev make_scene(const hydra_hip_ctx* c) { return make_scene_tree(c, 0); }
+static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree) {
   SceneDev s;
   s.globals = static_cast<const int*>(c->globals.p);
   s.texStorage = static_cast<const int4*>(c->storage[HYDRA_STORAGE_TEXTURES].p);
@@ -944,17 +957,18 @@ static SceneDev make_scene(const hydra_hip_ctx* c) {
   s.triBase = static_cast<const int*>(c->triBase.p);
   s.matStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_MATERIALS].p);
   s.pdfStorage = static_cast<const float4*>(c->storage[HYDRA_STORAGE_PDFS].p);
-  s.bvh = static_cast<const float4*>(c->bvhNodes[0].p);
-  s.bvhBytes = unsigned(c->bvhNodeBytes[0]);
-  s.leafEnc = c->leafEnc[0] ? 1 : 0;
-  s.bvhTop = static_cast<const float4*>(c->bvhNodesTop.p);
-  s.topQuads = static_cast<const int*>(c->topQuads.p);
-  s.topCount = (c->bvhNodesTop.p && c->topQuads.p) ? c->topCount : 0;
+  s.bvh = static_cast<const float4*>(c->bvhNodes[tree].p);
+  s.bvhBytes = unsigned(c->bvhNodeBytes[tree]);
+  s.leafEnc = c->leafEnc[tree] ? 1 : 0;
+  s.alpha = static_cast<const uint2*>(c->bvhAlpha[tree].p);
+  s.bvhTop = tree == 0 ? static_cast<const float4*>(c->bvhNodesTop.p) : nullptr;   // the LDS caches of the persistent kernels exist for tree 0 only
+  s.topQuads = tree == 0 ? static_cast<const int*>(c->topQuads.p) : nullptr;
+  s.topCount = (tree == 0 && c->bvhNodesTop.p && c->topQuads.p) ? c->topCount : 0;
   s.topTriF4 = static_cast<const int*>(c->topTriF4.p);
-  s.topTriCount = (s.topCount > 0 && c->topTriF4.p) ? c->topTriCount : 0;
-  s.trisBytes = unsigned(c->bvhTriBytes[0]);
-  s.tris = static_cast<const float4*>(c->bvhTris[0].p);
-  s.haveInst = c->haveInst[0];
+  s.topTriCount = (s.topCount > 0 && c->topTriF4.p && s.alpha == nullptr) ? c->topTriCount : 0;
+  s.trisBytes = unsigned(c->bvhTriBytes[tree]);
+  s.tris = static_cast<const float4*>(c->bvhTris[tree].p);
+  s.haveInst = c->haveInst[tree];
   s.instMatrices = static_cast<const float4*>(c->instMat.p);
   s.instLightInstId = static_cast<const int*>(c->instLight.p);
   s.instNum = c->instNum;
@@ -1089,12 +1103,13 @@ static std::vector<int> morton_tile_order(int tilesX, int tilesY) {
 // (prepare_geometry), the material arena and the globals blob.  Called by every entry point that traces.
 static int prepare_classes(hydra_hip_ctx* c) {
   if (!c->classDirty) return HYDRA_HIP_OK;
-  if (c->leafHeadersNum > 0 && c->leafHeaders.p && c->bvhTris[0].p && c->triRec.p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->hostHeader.size() > size_t(HG_GEOM_TABLE_SIZE)) {
+  if (c->triRec.p && c->storage[HYDRA_STORAGE_MATERIALS].p && c->hostHeader.size() > size_t(HG_GEOM_TABLE_SIZE)) {
     const int tableSize = c->hostHeader[HG_GEOM_TABLE_SIZE];
-    if (tableSize > 0 && tableSize < (1 << HK_CLASS_SHIFT)) {
+    for (int tree = 0; tree < 4 && tableSize > 0 && tableSize < (1 << HK_CLASS_SHIFT); tree++) {
+      if (c->leafHeadersNum[tree] <= 0 || !c->leafHeaders[tree].p || !c->bvhTris[tree].p) continue;
       const SceneDev s = make_scene(c);
-      hipLaunchKernelGGL(k_tag_triangle_classes, dim3(grid_for(c, c->leafHeadersNum, 256, 8)), dim3(256), 0, c->stream, c->leafHeadersNum,
-                         static_cast<const int*>(c->leafHeaders.p), static_cast<float4*>(c->bvhTris[0].p), unsigned(c->bvhTriBytes[0] / 16), s, tableSize);
+      hipLaunchKernelGGL(k_tag_triangle_classes, dim3(grid_for(c, c->leafHeadersNum[tree], 256, 8)), dim3(256), 0, c->stream, c->leafHeadersNum[tree],
+                         static_cast<const int*>(c->leafHeaders[tree].p), static_cast<float4*>(c->bvhTris[tree].p), unsigned(c->bvhTriBytes[tree] / 16), s, tableSize);
       HCHECK(hipGetLastError());
     }
   }
@@ -1224,22 +1239,37 @@ static int alloc_render_state(hydra_hip_ctx* c) {
 // ---- traversal launchers: one place decides between the one-ray-per-lane kernels and the persistent dynamic-fetch form
 static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetchCnt, size_t(2 * HK_MAX_DEPTH + 4) * HK_CROW * 4); }
 
-// `fetchCounters` is one zeroed counter row (HK_CROW words) for the persistent form, or nullptr to force the static form
+// `fetchCounters` is one zeroed counter row (HK_CROW words) for the persistent form, or nullptr to force the static form.
+// Tree 0 goes through the persistent kernel (or the static one); trees 1..3, if the scene has them, follow with the static kernel,
+// each starting from the hit the trees before it left behind (IntegratorCommon::rayTrace, Common.cpp:128-150).
+static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree);
 static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* pos4, const float4* dir4,
                            HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounters) {
+  const bool alpha0 = (s.alpha != nullptr);
   if (c->traceMode == 0 || perRay3 != nullptr || fetchCounters == nullptr) {
     const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-    if (perRay3 || totals5) hipLaunchKernelGGL(k_trace<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, pos4, dir4, hits, perRay3, totals5);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, pos4, dir4, hits, perRay3, totals5);
-    return;
-  }
-  const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
-  float4* out = reinterpret_cast<float4*>(hits);
-  float* nov = nullptr;
-#define HK_LAUNCH_DYN(CNT, TT) hipLaunchKernelGGL((k_trace_dyn<false, CNT, TT>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, nov, totals5, c->traceMinActive, c->traceRaysPerLane)
-  if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true); else HK_LAUNCH_DYN(false, true); }
-  else { if (totals5) HK_LAUNCH_DYN(true, false); else HK_LAUNCH_DYN(false, false); }
+#define HK_LAUNCH_STATIC(CNT, AL, SC, CARRY) hipLaunchKernelGGL((k_trace<CNT, AL>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, SC, q, pos4, dir4, hits, perRay3, totals5, CARRY)
+    if (perRay3 || totals5) { if (alpha0) HK_LAUNCH_STATIC(true, true, s, 0); else HK_LAUNCH_STATIC(true, false, s, 0); }
+    else { if (alpha0) HK_LAUNCH_STATIC(false, true, s, 0); else HK_LAUNCH_STATIC(false, false, s, 0); }
+  } else {
+    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+    float4* out = reinterpret_cast<float4*>(hits);
+    float* nov = nullptr;
+#define HK_LAUNCH_DYN(CNT, TT, AL) hipLaunchKernelGGL((k_trace_dyn<false, CNT, TT, AL>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, nov, totals5, c->traceMinActive, c->traceRaysPerLane)
+    if (alpha0) { if (totals5) HK_LAUNCH_DYN(true, false, true); else HK_LAUNCH_DYN(false, false, true); }
+    else if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true, false); else HK_LAUNCH_DYN(false, true, false); }
+    else { if (totals5) HK_LAUNCH_DYN(true, false, false); else HK_LAUNCH_DYN(false, false, false); }
 #undef HK_LAUNCH_DYN
+  }
+  for (int tree = 1; tree < c->treesNum; tree++) {
+    if (!c->bvhNodes[tree].p || !c->bvhTris[tree].p) continue;
+    const SceneDev st = make_scene_tree(c, tree);
+    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    const bool al = (st.alpha != nullptr);
+    if (perRay3 || totals5) { if (al) HK_LAUNCH_STATIC(true, true, st, 1); else HK_LAUNCH_STATIC(true, false, st, 1); }
+    else { if (al) HK_LAUNCH_STATIC(false, true, st, 1); else HK_LAUNCH_STATIC(false, false, st, 1); }
+  }
+#undef HK_LAUNCH_STATIC
 }
 static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* org4, const float4* dir4,
                           float* vis, unsigned long long* totals5, uint32_t* fetchCounters) {
@@ -1420,8 +1450,9 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   for (DevBuf* b : all) dev_free(*b);
   for (auto& b : c->storage) dev_free(b);
   for (auto& b : c->bvhNodes) dev_free(b);
-  dev_free(c->bvhNodesTop); dev_free(c->topQuads); dev_free(c->leafHeaders); dev_free(c->topTriF4);
+  dev_free(c->bvhNodesTop); dev_free(c->topQuads); for (auto& b : c->leafHeaders) dev_free(b); dev_free(c->topTriF4);
   for (auto& b : c->bvhTris) dev_free(b);
+  for (auto& b : c->bvhAlpha) dev_free(b);
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   delete c;
   return HYDRA_HIP_OK;
@@ -1770,17 +1801,33 @@ static std::vector<int> choose_and_tag_top_quads(std::vector<HydraBVHNode>& node
 int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes, int nodes_num, const float* tri_f4, int tri_f4_num,
                          const uint32_t* alpha, int alpha_num, int have_inst) {
   if (!c || tree < 0 || tree >= 4 || !nodes || nodes_num < 8 || !tri_f4 || tri_f4_num <= 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: bad arguments");
-  if (alpha != nullptr && alpha_num > 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: alpha-tested trees are not supported by the HIP layer yet");
-  if (tree != 0) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: only tree 0 is traversed by the HIP layer yet");
+  // alpha table: one uint2 per float4 of the triangle list, then the opacity samplers (RenderDriverRTE_AlphaTestTable.cpp:65-224)
+  if (alpha != nullptr && alpha_num > 0 && alpha_num < tri_f4_num) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: alpha table shorter than the triangle list");
+  if (alpha != nullptr && alpha_num > 0 && !have_inst) return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: an alpha table on a tree without instances (the reference has no such traversal, Common.cpp:140-146)");
   HCHECK(hipSetDevice(c->device));
+  if (alpha != nullptr && alpha_num > 0) {
+    // every sampler position a triangle names must lie inside the table (the traversal reads 6 uint2 from there)
+    for (int i = 0; i < tri_f4_num; i++) {
+      const uint32_t x = alpha[2 * size_t(i)];
+      int32_t w2, w3;
+      memcpy(&w2, tri_f4 + size_t(i) * 4 + 2, 4); memcpy(&w3, tri_f4 + size_t(i) * 4 + 3, 4);
+      const bool header = (w2 == -1 && w3 == -1);
+      if (header) { i += 0; continue; }
+      // only the first float4 of a triangle carries a sampler position; the other two carry flags (0 / 1)
+      if (x != 0xFFFFFFFFu && x != HYDRA_INVALID_TEXTURE && int32_t(x) > 1 && size_t(x) + 6 > size_t(alpha_num))
+        return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: alpha table entry " + std::to_string(i) + " points outside the table");
+    }
+    const int arc = dev_upload(c, c->bvhAlpha[tree], alpha, size_t(alpha_num) * 8);
+    if (arc) return arc;
+  } else dev_free(c->bvhAlpha[tree]);
   // the traversal kernels address both arrays as raw buffers with 32-bit byte offsets
   if (size_t(nodes_num) * sizeof(HydraBVHNode) >= (size_t(1) << 32) || size_t(tri_f4_num) * 16 >= (size_t(1) << 32))
     return fail(c, HYDRA_HIP_EINVAL, "upload_bvh: node or triangle arrays of 4 GiB and more are not supported");
   std::vector<HydraBVHNode> devNodes(nodes, nodes + nodes_num);
   {
     const std::vector<int> headers = collect_leaf_headers(devNodes, tri_f4, tri_f4_num, have_inst != 0);
-    c->leafHeadersNum = int(headers.size());
-    const int hrc = dev_upload(c, c->leafHeaders, headers.data(), headers.size() * sizeof(int));
+    c->leafHeadersNum[tree] = int(headers.size());
+    const int hrc = dev_upload(c, c->leafHeaders[tree], headers.data(), headers.size() * sizeof(int));
     if (hrc) return hrc;
     c->classDirty = true;
   }
@@ -1792,7 +1839,7 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   c->bvhNodeBytes[tree] = size_t(nodes_num) * sizeof(HydraBVHNode);
   hipLaunchKernelGGL(k_prepare_bvh, dim3(grid_for(c, nodes_num, 256, 8)), dim3(256), 0, c->stream, nodes_num, static_cast<float4*>(c->bvhNodes[tree].p));
   HCHECK(hipGetLastError());
-  {   // the copy the persistent kernels walk: same nodes, links to the quads kept in LDS tagged with their slot
+  if (tree == 0) {   // the copy the persistent kernels walk (tree 0 only): same nodes, links to the quads kept in LDS tagged with their slot
     std::vector<int> poolF4;
     const std::vector<TopLeaf> topLeaves = (c->leafEnc[tree] && c->topWanted > 0) ? choose_top_leaves(devNodes, have_inst != 0, tri_f4_num, std::min(c->topTrisWanted, HK_TOP_TRIS), poolF4)
                                                                                    : std::vector<TopLeaf>();
@@ -1822,8 +1869,9 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
 }
 int hydra_hip_set_bvh_trees_num(hydra_hip_handle c, int n) {
   if (!c || n < 1 || n > 4) return HYDRA_HIP_EINVAL;
-  if (n != 1) return fail(c, HYDRA_HIP_EINVAL, "set_bvh_trees_num: only one BVH tree is traversed by the HIP layer yet");
+  for (int t = 0; t < n; t++) if (!c->bvhNodes[t].p) return fail(c, HYDRA_HIP_ESTATE, "set_bvh_trees_num: tree " + std::to_string(t) + " was not uploaded");
   c->treesNum = n;
+  for (int t = n; t < 4; t++) { dev_free(c->bvhNodes[t]); dev_free(c->bvhTris[t]); dev_free(c->bvhAlpha[t]); dev_free(c->leafHeaders[t]); c->leafHeadersNum[t] = 0; }
   return HYDRA_HIP_OK;
 }
 int hydra_hip_upload_instances(hydra_hip_handle c, const float* inv16, const int32_t* lightInstId, int n) {

@@ -47,7 +47,7 @@ void BVH4Builder::ClearScene() {
 }
 
 int BVH4Builder::InstanceTriangleMeshes(InstanceInputData d, int a_treeId, int a_realInstIdBase) {
-  if (a_treeId != 0) RunTimeError("BVH4Builder: only tree 0 (opaque geometry) is supported in this tier");
+  (void)a_treeId;   // one builder object = one tree; the driver keeps a second builder for a second tree (render_driver_lite.cpp, EndScene)
   int slot = -1;
   for (size_t i = 0; i < m_meshes.size(); i++)
     if (m_meshes[i].meshId == d.meshId) slot = int(i);

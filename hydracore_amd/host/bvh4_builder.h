@@ -33,6 +33,7 @@ public:
   // a_realInstIdBase: id of the first instance of this call in the driver's global instance arrays
   int  InstanceTriangleMeshes(InstanceInputData a_data, int a_treeId, int a_realInstIdBase);
   void CommitScene();
+  bool HasInstances() const { return !m_insts.empty(); }
   void GetBounds(float a_bMin[3], float a_bMax[3]) const;
 
   ConvertionResult ConvertMap();   // pointers stay valid until ConvertUnmap()/ClearScene()

@@ -89,6 +89,10 @@ int hydra_host_get_buffer(void* p, int what, const void** ptr, size_t* bytes) {
   else if (what == 10) { *ptr = L->m_remapLists.data(); *bytes = L->m_remapLists.size() * 4; }
   else if (what == 11) { *ptr = L->m_remapTable.data(); *bytes = L->m_remapTable.size() * 4; }
   else if (what == 12) { *ptr = L->m_remapInst.data(); *bytes = L->m_remapInst.size() * 4; }
+  else if (what == 13) { *ptr = L->m_bvhTrees[0].m_atbl.data(); *bytes = L->m_bvhTrees[0].m_atbl.size() * 4; }     // alpha table of tree 0 (uint2 pairs)
+  else if (what == 14) { *ptr = L->m_bvhTrees[1].m_bvh.data(); *bytes = L->m_bvhTrees[1].m_bvh.size() * sizeof(HydraBVHNode); }
+  else if (what == 15) { *ptr = L->m_bvhTrees[1].m_tris.data(); *bytes = L->m_bvhTrees[1].m_tris.size() * 4; }
+  else if (what == 16) { *ptr = L->m_bvhTrees[1].m_atbl.data(); *bytes = L->m_bvhTrees[1].m_atbl.size() * 4; }
   else return -1;
   return 0;
 }
@@ -96,6 +100,15 @@ int hydra_host_get_buffer(void* p, int what, const void** ptr, size_t* bytes) {
 int hydra_host_have_inst(void* p) {
   SharedDataLayer* L = dynamic_cast<SharedDataLayer*>(static_cast<HostScene*>(p)->drv->Layer());
   return (L && L->m_bvhTrees[0].haveInst) ? 1 : 0;
+}
+
+int hydra_host_trees_num(void* p) {
+  SharedDataLayer* L = dynamic_cast<SharedDataLayer*>(static_cast<HostScene*>(p)->drv->Layer());
+  return L ? L->m_bvhTreesNum : 0;
+}
+int hydra_host_have_inst_tree(void* p, int tree) {
+  SharedDataLayer* L = dynamic_cast<SharedDataLayer*>(static_cast<HostScene*>(p)->drv->Layer());
+  return (L && tree >= 0 && tree < MAXBVHTREES && L->m_bvhTrees[tree].haveInst) ? 1 : 0;
 }
 
 // the hydra_hip_handle behind a HipHWLayer (NULL for the host-blob layer)

@@ -209,8 +209,11 @@ void SharedDataLayer::SetAllBVH4(const ConvertionResult& cr, IBVHBuilder2* a_inB
     m_bvhTrees[i].m_tris.assign(cr.pTriangleData[i], cr.pTriangleData[i] + size_t(cr.trif4Num[i]) * 4);
     if (cr.pTriangleAlpha[i] != nullptr)
       m_bvhTrees[i].m_atbl.assign(cr.pTriangleAlpha[i], cr.pTriangleAlpha[i] + size_t(cr.triAfNum[i]) * 2);
+    else
+      m_bvhTrees[i].m_atbl.clear();
     m_bvhTrees[i].haveInst = (std::string(cr.bvhType[i] ? cr.bvhType[i] : "") == "object");
   }
+  for (int i = cr.treesNum; i < MAXBVHTREES; i++) m_bvhTrees[i] = TreeCopy();
   m_bvhTreesNum = cr.treesNum;
   if (FindStorage("geom") == nullptr) RunTimeError("SharedDataLayer::SetAllBVH4: memory storage for 'geom' not found");
 }

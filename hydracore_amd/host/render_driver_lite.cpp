@@ -324,7 +324,21 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const float3 colorT = read_value3f(xchild(transpar, "color"));
   const float3 colorSSS = read_value3f(xchild(sss, "color"));
   if (length(colorSSS) > 1e-5f) Unsupported("translucency (material " + std::to_string(a_matId) + ")");
-  if (a_node->child("displacement") || a_node->child("opacity")) Unsupported("displacement/opacity (material " + std::to_string(a_matId) + ")");
+  if (a_node->child("displacement")) Unsupported("displacement (material " + std::to_string(a_matId) + ")");
+  m_matOpacity.erase(a_matId);
+  if (const XmlNode* op = a_node->child("opacity")) {   // PlainMaterialConverter.cpp:1429-1445: alpha-tested in the traversal, not a BxDF
+    Opacity o;
+    Sampler sm;
+    o.texId = int32_t(HYDRA_INVALID_TEXTURE);
+    if (const XmlNode* tx = xchild(op, "texture")) { sm = sampler_from_texref(tx, true); o.texId = sm.texId; }
+    float raw[12];
+    put_sampler_raw(raw, 0, sm);
+    memcpy(o.sampler, raw, sizeof(raw));
+    o.smooth = (op->attr_int("smooth") == 1);
+    o.skipShadow = (xchild(op, "skip_shadow") && xchild(op, "skip_shadow")->attr_int("val") == 1) || (op->attr_int("skip_shadow") == 1);
+    if (o.smooth) Unsupported("smooth opacity (material " + std::to_string(a_matId) + "): stochastic alpha is the OpenCL layer's BVH4InstTraverseAlphaS, the CPU path tests against 0.5");
+    m_matOpacity[a_matId] = o;
+  }
   if (length(colorD) <= 1e-5f) colorD = colorSSS;
 
   const bool haveFresnelRefl = (xchild(reflect, "fresnel") && xchild(reflect, "fresnel")->attr_int("val") == 1);
@@ -759,6 +773,7 @@ bool RenderDriverLite::UpdateSettings(const XmlNode* st) {
   if (xchild(st, "outgamma")) vars.m_varsF[HV_F_IMAGE_GAMMA] = strtof(xtext(xchild(st, "outgamma")).c_str(), nullptr);
   if (xchild(st, "trace_depth")) vars.m_varsI[HV_I_TRACE_DEPTH] = atoi(xtext(xchild(st, "trace_depth")).c_str()) + 1;
   if (xchild(st, "diff_trace_depth")) vars.m_varsI[HV_I_DIFFUSE_TRACE_DEPTH] = atoi(xtext(xchild(st, "diff_trace_depth")).c_str()) + 1;
+  m_splitAlphaTree = xchild(st, "split_alpha_tree") && atoi(xtext(xchild(st, "split_alpha_tree")).c_str()) == 1;
   m_pHWLayer->SetAllFlagsAndVars(vars);
   m_pHWLayer->ResizeScreen(m_width, m_height, 0);
   return true;
@@ -768,6 +783,7 @@ void RenderDriverLite::BeginScene() {
   m_instMatricesInv.clear(); m_instLightInstId.clear(); m_meshIdByInstId.clear(); m_meshRemapListId.clear();
   m_lightsInstanced.clear();
   m_bvh.ClearScene();
+  m_bvhAlpha.ClearScene();
   const int32_t dummyList[2] = {0, 0};
   m_pHWLayer->SetAllRemapLists(dummyList, reinterpret_cast<const int2*>(dummyList), 0, 0);
 }
@@ -786,7 +802,10 @@ void RenderDriverLite::InstanceMeshes(int32_t a_mesh_id, const float* a_matrices
   in.meshId = a_mesh_id;
   in.matrices = a_matrices;
   in.numInst = a_instNum;
-  m_bvh.InstanceTriangleMeshes(in, 0, int(m_meshIdByInstId.size()));
+  // Embree hands the reference up to four trees (bvh_access_dll2.cpp:547-600); this builder makes one, or -- when the scene's
+  // settings ask for it -- a second one for the instances of alpha-tested meshes, so that the multi-tree walk has a producer
+  if (m_splitAlphaTree && MeshHasOpacity(a_mesh_id)) m_bvhAlpha.InstanceTriangleMeshes(in, 1, int(m_meshIdByInstId.size()));
+  else m_bvh.InstanceTriangleMeshes(in, 0, int(m_meshIdByInstId.size()));
   for (int i = 0; i < a_instNum; i++) {
     float4x4 m;
     memcpy(m.c, a_matrices + 16 * i, 64);
@@ -883,15 +902,100 @@ std::vector<float> RenderDriverLite::CalcLightPickProbTable(bool a_fwd) {
   return pick;
 }
 
+// RenderDriverRTE::MeshHaveOpacity, RenderDriverRTE_AlphaTestTable.cpp:41-63
+bool RenderDriverLite::MeshHasOpacity(int32_t a_meshId) const {
+  const auto table = m_pGeomStorage->GetTable();
+  if (a_meshId < 0 || a_meshId >= int(table.size()) || table[a_meshId] < 0) return false;
+  const char* base = static_cast<const char*>(m_pGeomStorage->GetBegin()) + size_t(table[a_meshId]) * 16;
+  const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(base);
+  const int* mind = reinterpret_cast<const int*>(base + size_t(hdr->mIndicesOffset) * 16);
+  for (int i = 0; i < hdr->tIndicesNum / 3; i++) {
+    auto p = m_matOpacity.find(mind[i]);
+    if (p != m_matOpacity.end() && p->second.texId != int32_t(HYDRA_INVALID_TEXTURE)) return true;
+  }
+  return false;
+}
+// CompressTexCoord16 + WrapVal, RenderDriverRTE_AlphaTestTable.cpp:25-39, cglobals.h:3014-3022
+static uint32_t compress_tex_coord16(float x, float y) {
+  auto wrap = [](float v) { return v > 1.0f ? v - float(int(v)) : (v < -1.0f ? float(int(v)) - v : v); };
+  auto cl = [](float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); };
+  const float tx = cl(0.5f * wrap(x) + 0.5f), ty = cl(0.5f * wrap(y) + 0.5f);
+  return (uint32_t(ty * 65535.0f) << 16) | uint32_t(tx * 65535.0f);
+}
+// RenderDriverRTE::CreateAlphaTestTable, RenderDriverRTE_AlphaTestTable.cpp:65-224: per tree one uint2 for every float4 of the
+// triangle list -- triangle float4 0: {position of the opacity sampler in this table | INVALID_TEXTURE, uv of A}, 1: {smooth opacity
+// 0/1, uv of B}, 2: {skip shadow 0/1, uv of C}, header float4: {-1, -1} -- followed by the samplers (6 uint2 each)
+void RenderDriverLite::CreateAlphaTestTable(ConvertionResult& cr) {
+  int maxSamplers = 0;
+  for (const auto& kv : m_matOpacity) if (kv.second.texId != int32_t(HYDRA_INVALID_TEXTURE) || kv.second.skipShadow) maxSamplers++;
+  if (maxSamplers == 0) return;
+  const int INV = int32_t(HYDRA_INVALID_TEXTURE);
+  const auto geomTable = m_pGeomStorage->GetTable();
+  const char* geomBase = static_cast<const char*>(m_pGeomStorage->GetBegin());
+  std::vector<Opacity> samplers;                 // one list for all trees, as in the reference
+  std::map<int, int> samplerOf;
+  for (int tree = 0; tree < cr.treesNum && tree < 2; tree++) {
+    const int numPrims = cr.trif4Num[tree];
+    std::vector<uint32_t>& out = m_alphaTable[tree];
+    out.assign(size_t(numPrims + maxSamplers * 6) * 2, 0u);
+    bool haveOpacity = false;
+    const int32_t* i4 = reinterpret_cast<const int32_t*>(cr.pTriangleData[tree]);
+    for (int off = 0; off < numPrims;) {
+      if (i4[off * 4 + 2] == -1 && i4[off * 4 + 3] == -1) { out[size_t(off) * 2] = 0xFFFFFFFFu; out[size_t(off) * 2 + 1] = 0xFFFFFFFFu; off++; continue; }
+      const int primId = i4[off * 4 + 3], geomId = i4[(off + 1) * 4 + 3];
+      const char* base = geomBase + size_t(geomTable[geomId]) * 16;
+      const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(base);
+      const int* vind = reinterpret_cast<const int*>(base + size_t(hdr->vIndicesOffset) * 16);
+      const float* vpos = reinterpret_cast<const float*>(base + size_t(hdr->vPosOffset) * 16);
+      const float* vnrm = reinterpret_cast<const float*>(base + size_t(hdr->vNormOffset) * 16);
+      const int* mind = reinterpret_cast<const int*>(base + size_t(hdr->mIndicesOffset) * 16);
+      auto p = m_matOpacity.find(mind[primId]);
+      const bool tested = (p != m_matOpacity.end()) && (p->second.texId != INV || p->second.skipShadow);
+      for (int k = 0; k < 3; k++) { out[size_t(off + k) * 2] = uint32_t(INV); out[size_t(off + k) * 2 + 1] = 0xFFFFFFFFu; }
+      if (tested) {
+        haveOpacity = true;
+        int rel;
+        auto q = samplerOf.find(mind[primId]);
+        if (q == samplerOf.end()) { rel = int(samplers.size()); samplerOf[mind[primId]] = rel; samplers.push_back(p->second); } else rel = q->second;
+        out[size_t(off) * 2] = (p->second.texId != INV) ? uint32_t(numPrims + rel * 6) : uint32_t(INV);
+        out[size_t(off + 1) * 2] = p->second.smooth ? 1u : 0u;
+        out[size_t(off + 2) * 2] = p->second.skipShadow ? 1u : 0u;
+        for (int k = 0; k < 3; k++) {
+          const int v = vind[primId * 3 + k];
+          out[size_t(off + k) * 2 + 1] = compress_tex_coord16(vpos[v * 4 + 3], vnrm[v * 4 + 3]);   // u rides in pos.w, v in norm.w
+        }
+      }
+      off += 3;
+    }
+    for (size_t i = 0; i < samplers.size(); i++) memcpy(&out[size_t(numPrims + int(i) * 6) * 2], samplers[i].sampler, 48);
+    if (haveOpacity) { cr.pTriangleAlpha[tree] = out.data(); cr.triAfNum[tree] = int(out.size() / 2); }
+    else { cr.pTriangleAlpha[tree] = nullptr; cr.triAfNum[tree] = 0; }
+  }
+}
+
 void RenderDriverLite::EndScene() {
   m_bvh.CommitScene();
   {
     ConvertionResult cr = m_bvh.ConvertMap();
+    if (m_splitAlphaTree && m_bvhAlpha.HasInstances()) {
+      m_bvhAlpha.CommitScene();
+      const ConvertionResult cr2 = m_bvhAlpha.ConvertMap();
+      cr.bvhType[1] = cr2.bvhType[0]; cr.pBVH[1] = cr2.pBVH[0]; cr.pTriangleData[1] = cr2.pTriangleData[0];
+      cr.nodesNum[1] = cr2.nodesNum[0]; cr.trif4Num[1] = cr2.trif4Num[0];
+      cr.treesNum = 2;
+    }
+    CreateAlphaTestTable(cr);
     m_pHWLayer->SetAllBVH4(cr, nullptr, 0);
     m_bvh.ConvertUnmap();
+    m_bvhAlpha.ConvertUnmap();
   }
   float bmin[3], bmax[3];
   m_bvh.GetBounds(bmin, bmax);
+  if (m_splitAlphaTree && m_bvhAlpha.HasInstances()) {
+    float b2[3], t2[3];
+    m_bvhAlpha.GetBounds(b2, t2);
+    for (int a = 0; a < 3; a++) { bmin[a] = std::min(bmin[a], b2[a]); bmax[a] = std::max(bmax[a], t2[a]); }
+  }
   const float3 half = 0.5f * (float3(bmax[0], bmax[1], bmax[2]) - float3(bmin[0], bmin[1], bmin[2]));
   const float3 center = 0.5f * (float3(bmax[0], bmax[1], bmax[2]) + float3(bmin[0], bmin[1], bmin[2]));
 

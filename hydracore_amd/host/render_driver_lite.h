@@ -68,6 +68,13 @@ private:
   IMemoryStorage *m_pTexStorage = nullptr, *m_pTexStorageAux = nullptr, *m_pGeomStorage = nullptr,
                  *m_pMaterialStorage = nullptr, *m_pPdfStorage = nullptr;
   BVH4Builder m_bvh;
+  BVH4Builder m_bvhAlpha;              // second tree for the instances of alpha-tested meshes when the scene asks for one (<split_alpha_tree>)
+  bool m_splitAlphaTree = false;
+  struct Opacity { int32_t texId; float sampler[12]; bool smooth, skipShadow; };
+  std::map<int, Opacity> m_matOpacity; // materials with an <opacity> node (PlainMaterialConverter.cpp:1429-1445)
+  std::vector<uint32_t> m_alphaTable[2];   // uint2 per float4 of the triangle list + the opacity samplers, per tree
+  bool MeshHasOpacity(int32_t a_meshId) const;
+  void CreateAlphaTestTable(ConvertionResult& cr);
 
   struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0}; } m_camera;
 

@@ -355,8 +355,28 @@ static inline f2 RayBox(f3 o, f3 inv, const float* node) {
   f2 r = {tmin, tmax};
   return r;
 }
-/* ref: ctrace.h:63-182 IntersectAllPrimitivesInLeaf(1): Moeller-Trumbore, first-found wins ties (t < best) */
-static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, OrcHit res, const float* tris, int instIdOverride, int useOverride, TravStat* st) {
+static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const OrcScene* s);
+/* ref: ctrace.h:316-325 decompressTexCoord16 */
+static inline f2 decompressTexCoord16(uint32_t packed) {
+  const float fx = (1.0f / 65535.0f) * (float)(packed & 0x0000FFFFu), fy = (1.0f / 65535.0f) * (float)((packed & 0xFFFF0000u) >> 16);
+  f2 r = {2.0f * fx - 1.0f, 2.0f * fy - 1.0f};
+  return r;
+}
+/* ref: ctrace.h:330-412 IntersectAllPrimitivesInLeafAlpha, the part behind a geometric hit: texture coordinate from the packed
+ * per-vertex ones, opacity texel through sample2DLite (cfetch.h:738-760; the sampler sits in the alpha table itself), accept when the
+ * largest channel exceeds 0.5 */
+static inline int alphaTestPasses(const OrcScene* s, const uint32_t* alpha, int triAddress, float u, float v) {
+  const uint32_t* a0 = alpha + 2 * (size_t)triAddress, *a1 = a0 + 2, *a2 = a0 + 4;
+  const f2 A = decompressTexCoord16(a0[1]), B = decompressTexCoord16(a1[1]), C = decompressTexCoord16(a2[1]);
+  const float w = 1.0f - u - v;
+  const f2 tc = {(w * A.x + v * B.x) + u * C.x, (w * A.y + v * B.y) + u * C.y};
+  if (a0[0] == 0xFFFFFFFFu || a0[0] == 0xFFFFFFFEu || (int32_t)a0[0] <= 0) return 1;
+  const f3 c = sample2DExt(0, tc, (const float*)(alpha + 2 * (size_t)a0[0]), s);
+  return fmaxf(c.x, fmaxf(c.y, c.z)) > 0.5f;
+}
+/* ref: ctrace.h:63-182 IntersectAllPrimitivesInLeaf(1): Moeller-Trumbore, first-found wins ties (t < best); alpha != NULL: :330-412 */
+static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, float t_min, OrcHit res, const float* tris, int instIdOverride, int useOverride, TravStat* st,
+                                   const OrcScene* s, const uint32_t* alpha) {
   const int first = as_int(tris[leaf_offset * 4 + 0]), count = as_int(tris[leaf_offset * 4 + 1]);
   const int end = first + count * 3;
   if (st) { st->leaves++; st->tris += (uint32_t)count; }
@@ -372,6 +392,7 @@ static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, floa
     const float u = dot3(qvec, ray_dir) * invDet;
     const float t = dot3(edge2, qvec) * invDet;
     if (v > -1e-6f && u > -1e-6f && (u + v < 1.0f + 1e-6f) && t > t_min && t < res.t) {
+      if (alpha != NULL && !alphaTestPasses(s, alpha, a, u, v)) continue;
       res.t = t; res.primId = as_int(d1[3]); res.geomId = as_int(d2[3]);
       res.instId = useOverride ? instIdOverride : as_int(d3[3]);
     }
@@ -383,7 +404,8 @@ static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, floa
  * instancing steps are skipped for plain trees exactly as the reference's second function omits them. */
 /* anyHit: the shadow form BVH4InstTraverseShadow (ref: ctrace.h:1065-1294): the caller seeds hit.t with the ray's far end and
  * the walk stops behind the first leaf that produced a hit in (t_rayMin, far) (ref: :1243-1251, `top = 0`). */
-static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, int anyHit, TravStat* st) {
+static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, int anyHit, TravStat* st,
+                            const OrcScene* s, const uint32_t* alpha) {   /* alpha: BVH4InstTraverseAlpha, ref: ctrace.h:1297-1520 (instanced trees only) */
   f3 invDir = SafeInverse(ray_dir);
   /* the reference declares stackData[80] with stack = stackData + 2 and tests `top < 80` once before up to three pushes
    * (ctrace.h:846-847,964-985): on a tree deeper than the stack it writes stack[78..81], i.e. up to four ints past its
@@ -426,12 +448,12 @@ static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, 
       }
     }
     if (!haveInst) {
-      if (top >= 0) hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, 0, 0, st);
+      if (top >= 0) hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, 0, 0, st, s, NULL);
       if (anyHit && hit.primId != -1) break;
       top--;
       leftNodeOffset = stack[top];
     } else if (top >= 0 && instDeep == 1) {
-      hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, instId, 1, st);
+      hit = IntersectLeaf(ray_pos, ray_dir, leftNodeOffset, t_rayMin, hit, tris, instId, 1, st, s, alpha);
       if (anyHit && hit.primId != -1) break;
       top--;
       leftNodeOffset = stack[top];
@@ -461,12 +483,16 @@ static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, 
 /* ref: CPUExp_Integrators_Common.cpp:122-154 IntegratorCommon::rayTrace (tree 0; Make_Lite_Hit cglobals.h:1256-1266) */
 static OrcHit rayTrace(const OrcScene* s, f3 pos, f3 dir, TravStat* st) {
   OrcHit h; h.t = MAXFLOAT_T; h.primId = -1; h.instId = -1; h.geomId = (int32_t)(((uint32_t)(-1) << 30) & 0xC0000000u);
-  return BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, 0, st);
+  h = BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, 0, st, s, s->haveInst ? s->alpha[0] : NULL);
+  for (int i = 1; i < s->treesNum && i < 4; i++)   /* one running Lite_Hit over all trees */
+    if (s->bvhN[i - 1] != NULL) h = BVH4Traverse_(pos, dir, 0.0f, h, s->bvhN[i - 1], s->trisN[i - 1], s->haveInstN[i - 1], 0, st, s, s->haveInstN[i - 1] ? s->alpha[i] : NULL);
+  return h;
 }
 static inline int HitSome(OrcHit h) { return (h.primId != -1) && isfinite(h.t); }
 /* ref: Common.cpp:156-180 IntegratorCommon::shadowTrace: full closest hit, then 0 < t < t_far */
 static float shadowTrace(const OrcScene* s, f3 pos, f3 dir, float t_far) {
-  const OrcHit h = rayTrace(s, pos, dir, NULL);
+  OrcHit h; h.t = MAXFLOAT_T; h.primId = -1; h.instId = -1; h.geomId = (int32_t)0xC0000000u;
+  h = BVH4Traverse_(pos, dir, 0.0f, h, s->bvh, s->tris, s->haveInst, 0, NULL, s, NULL);   /* tree 0 only, plain BVH4InstTraverse: no alpha test for shadow rays on the CPU path */
   return (HitSome(h) && h.t > 0.0f && h.t < t_far) ? 0.0f : 1.0f;
 }
 
@@ -487,7 +513,7 @@ void orc_shadow_trace_anyhit(const OrcScene* s, int n, const float* pos4, const 
   for (int i = 0; i < n; i++) {
     TravStat st = {0, 0, 0, 0};
     OrcHit h; h.t = tfar[i]; h.primId = -1; h.instId = -1; h.geomId = (int32_t)0xC0000000u;
-    h = BVH4Traverse_(v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), 0.0f, h, s->bvh, s->tris, s->haveInst, 1, &st);
+    h = BVH4Traverse_(v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), 0.0f, h, s->bvh, s->tris, s->haveInst, 1, &st, s, NULL);
     vis[i] = (h.primId != -1) ? 0.0f : 1.0f;
     if (c4) { c4[4 * i] = st.quads; c4[4 * i + 1] = st.insts; c4[4 * i + 2] = st.tris; c4[4 * i + 3] = st.leaves; }
   }

@@ -38,6 +38,12 @@ typedef struct OrcScene {
   const int32_t* remapLists;  int32_t remapListsSize;
   const int32_t* remapTable;  int32_t remapTableSize;   /* int2 entries */
   const int32_t* remapInst;   int32_t remapInstSize;
+  /* trees 1..3 of a multi-tree scene (IntegratorCommon::rayTrace walks all of them, Common.cpp:128-150) and the alpha tables */
+  int32_t        treesNum;       /* 0 or 1: tree 0 only */
+  const float*   bvhN[3];
+  const float*   trisN[3];
+  int32_t        haveInstN[3];
+  const uint32_t* alpha[4];      /* per tree: uint2 per float4 of the triangle list + opacity samplers, NULL = none */
 } OrcScene;
 
 typedef struct OrcHit { float t; int32_t primId, instId, geomId; } OrcHit;

@@ -39,23 +39,70 @@ __kernel void ref_make_eye_rays(__global const int2* xy, __global const float4* 
   dir4[i] = to_float4(d, 0.0f);
 }
 
-/* IntegratorCommon::rayTrace, CPUExp_Integrators_Common.cpp:122-154 (tree 0) */
-static inline Lite_Hit ref_rayTrace(float3 pos, float3 dir, __global const float4* bvh, __global const float4* tris, int haveInst)
+/* IntegratorCommon::rayTrace, CPUExp_Integrators_Common.cpp:122-154: one running Lite_Hit over the scene's trees (two here), the alpha
+ * form on an instanced tree that has an alpha table.  Pointers of an absent tree / table are 0. */
+typedef struct RefTreesT
 {
-  Lite_Hit hit = Make_Lite_Hit(MAXFLOAT, -1);
+  __global const float4* bvh0; __global const float4* tris0; __global const uint2* alpha0; int haveInst0;
+  __global const float4* bvh1; __global const float4* tris1; __global const uint2* alpha1; int haveInst1;
+  __global const int4* texStorage; __global const EngineGlobals* globals;
+} RefTrees;
+
+static inline Lite_Hit ref_traceOneTree(float3 pos, float3 dir, Lite_Hit hit, __global const float4* bvh, __global const float4* tris, __global const uint2* alpha, int haveInst,
+                                        __global const int4* texStorage, __global const EngineGlobals* globals)
+{
   if (haveInst)
-    hit = BVH4InstTraverse(pos, dir, 0.0f, hit, bvh, tris);
+  {
+    if (alpha != 0)
+      hit = BVH4InstTraverseAlpha(pos, dir, 0.0f, hit, bvh, tris, alpha, texStorage, globals);
+    else
+      hit = BVH4InstTraverse(pos, dir, 0.0f, hit, bvh, tris);
+  }
   else
     hit = BVH4Traverse(pos, dir, 0.0f, hit, bvh, tris);
   return hit;
 }
 
+static inline Lite_Hit ref_rayTrace(float3 pos, float3 dir, const RefTrees t)
+{
+  Lite_Hit hit = Make_Lite_Hit(MAXFLOAT, -1);
+  hit = ref_traceOneTree(pos, dir, hit, t.bvh0, t.tris0, t.alpha0, t.haveInst0, t.texStorage, t.globals);
+  if (t.bvh1 != 0)
+    hit = ref_traceOneTree(pos, dir, hit, t.bvh1, t.tris1, t.alpha1, t.haveInst1, t.texStorage, t.globals);
+  return hit;
+}
+
+/* IntegratorCommon::shadowTrace, Common.cpp:156-180: tree 0 only, the plain closest-hit walk (no alpha test) */
+static inline Lite_Hit ref_shadowClosest(float3 pos, float3 dir, const RefTrees t)
+{
+  Lite_Hit hit = Make_Lite_Hit(MAXFLOAT, -1);
+  if (t.haveInst0)
+    hit = BVH4InstTraverse(pos, dir, 0.0f, hit, t.bvh0, t.tris0);
+  else
+    hit = BVH4Traverse(pos, dir, 0.0f, hit, t.bvh0, t.tris0);
+  return hit;
+}
+
+static inline RefTrees ref_makeTrees(__global const float4* bvh, __global const float4* tris, __global const uint2* alpha, int haveInst,
+                                     __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1,
+                                     __global const int4* texStorage, __global const EngineGlobals* globals)
+{
+  RefTrees t;
+  t.bvh0 = bvh; t.tris0 = tris; t.alpha0 = alpha; t.haveInst0 = haveInst;
+  t.bvh1 = bvh1; t.tris1 = tris1; t.alpha1 = alpha1; t.haveInst1 = haveInst1;
+  t.texStorage = texStorage; t.globals = globals;
+  return t;
+}
+
 __kernel void ref_trace(__global const float4* pos4, __global const float4* dir4, __global const float4* bvh, __global const float4* tris,
-                        __global Lite_Hit* hits, int haveInst, int n)
+                        __global Lite_Hit* hits, int haveInst, int n,
+                        __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1,
+                        __global const int4* in_texStorage, __global const EngineGlobals* a_globals)
 {
   const int i = get_global_id(0);
   if (i >= n) return;
-  hits[i] = ref_rayTrace(to_float3(pos4[i]), to_float3(dir4[i]), bvh, tris, haveInst);
+  const RefTrees t = ref_makeTrees(bvh, tris, alpha, haveInst, bvh1, tris1, alpha1, haveInst1, in_texStorage, a_globals);
+  hits[i] = ref_rayTrace(to_float3(pos4[i]), to_float3(dir4[i]), t);
 }
 
 /* kernel_EvalSurface, CPUExp_Integrators_PT_Loop.cpp:35-84 */
@@ -106,10 +153,12 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
                              __global const float4* in_matrices, __global const int* instLightInstId,
                              __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
                              __global const int4* in_texStorage, __global const float4* in_pdfStorage,
-                             __global const EngineGlobals* a_globals, __global float4* color4, int n)
+                             __global const EngineGlobals* a_globals, __global float4* color4, int n,
+                             __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1)
 {
   const int i = get_global_id(0);
   if (i >= n) return;
+  const RefTrees trees = ref_makeTrees(bvh, tris, alpha, haveInst, bvh1, tris1, alpha1, haveInst1, in_texStorage, a_globals);
 
   float3 ray_pos = to_float3(pos4[i]);
   float3 ray_dir = to_float3(dir4[i]);
@@ -127,7 +176,7 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
   for (int depth = 0; depth < maxDepth; depth++)
   {
     /* kernel_RayTrace */
-    const Lite_Hit hit = ref_rayTrace(ray_pos, ray_dir, bvh, tris, haveInst);
+    const Lite_Hit hit = ref_rayTrace(ray_pos, ray_dir, trees);
     rays += 1.0f;
 
     /* kernel_HitEnvironment */
@@ -197,7 +246,7 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
     if (lightOffset >= 0)
     {
       const float t_far = length(shadowRayPos - explicitSam.pos)*0.995f;
-      const Lite_Hit sh = ref_rayTrace(shadowRayPos, shadowRayDir, bvh, tris, haveInst);
+      const Lite_Hit sh = ref_shadowClosest(shadowRayPos, shadowRayDir, trees);
       rays += 1.0f;
       shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
     }

@@ -15,6 +15,7 @@ struct EmuScene {   // mirrors tests/oracle_lib.OrcScene field for field
   const int* globals; const float* matStorage; const int* texStorage; const float* geomStorage; const float* pdfStorage;
   const float* bvh; const float* tris; int haveInst; const float* instMatrices; const int* instLightInstId; int instNum;
   const int* remapLists; int remapListsSize; const int* remapTable; int remapTableSize; const int* remapInst; int remapInstSize;
+  int treesNum; const float* bvhN[3]; const float* trisN[3]; int haveInstN[3]; const unsigned* alpha[4];
 };
 
 static SceneDev to_dev(const EmuScene* e) {
@@ -34,6 +35,7 @@ static SceneDev to_dev(const EmuScene* e) {
   s.remapTable = e->remapTableSize > 0 ? e->remapTable : nullptr; s.remapTableSize = e->remapTableSize;
   s.remapInst = e->remapInstSize > 0 ? e->remapInst : nullptr;    s.remapInstSize = e->remapInstSize;
   s.srgbLut = nullptr;
+  s.alpha = reinterpret_cast<const uint2*>(e->alpha[0]);
   s.matBase = e->matStorage;
   s.matTable = e->globals ? e->globals + e->globals[HG_MAT_TABLE_OFFS] : nullptr;   // traversal-only callers pass no globals
   s.lightsBase = e->globals ? reinterpret_cast<const float*>(e->globals + e->globals[HG_LIGHTS_OFFS]) : nullptr;
@@ -56,8 +58,20 @@ void emu_trace(const EmuScene* e, int n, const float* pos4, const float* dir4, H
       h.t = tfar[i];
       h = hk_traverse<true, true>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, p, d, 0.0f, h, st, c);
       vis[i] = (h.primId != -1) ? 0.0f : 1.0f;
-    } else
-      hits[i] = hk_traverse<false, true>(make_bvh_view(s.bvh, 0, s.tris, 0), s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c);
+    } else {
+      BvhView bv = make_bvh_view(s.bvh, 0, s.tris, 0);
+      bv.alpha = s.alpha; bv.texTable = s.texTable; bv.texStorage = s.texStorage; bv.srgbLut = nullptr;
+      HydraLiteHit h = (s.alpha != nullptr) ? hk_traverse<false, true, true>(bv, s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c)
+                                            : hk_traverse<false, true, false>(bv, s.haveInst != 0, p, d, 0.0f, hk_miss_hit(), st, c);
+      for (int tr = 1; tr < e->treesNum && tr < 4; tr++) {   // further trees carry the hit on (IntegratorCommon::rayTrace, Common.cpp:128-150)
+        if (e->bvhN[tr - 1] == nullptr) continue;
+        BvhView bt = make_bvh_view(reinterpret_cast<const float4*>(e->bvhN[tr - 1]), 0, reinterpret_cast<const float4*>(e->trisN[tr - 1]), 0);
+        bt.alpha = reinterpret_cast<const uint2*>(e->alpha[tr]); bt.texTable = s.texTable; bt.texStorage = s.texStorage; bt.srgbLut = nullptr;
+        h = (bt.alpha != nullptr) ? hk_traverse<false, true, true>(bt, e->haveInstN[tr - 1] != 0, p, d, 0.0f, h, st, c)
+                                  : hk_traverse<false, true, false>(bt, e->haveInstN[tr - 1] != 0, p, d, 0.0f, h, st, c);
+      }
+      hits[i] = h;
+    }
     if (counters4) { counters4[4 * i] = c.quads; counters4[4 * i + 1] = c.insts; counters4[4 * i + 2] = c.tris; counters4[4 * i + 3] = c.leaves; }
   }
 }

@@ -15,7 +15,8 @@ class OrcScene(C.Structure):
                 ("pdfStorage", C.c_void_p), ("bvh", C.c_void_p), ("tris", C.c_void_p), ("haveInst", C.c_int32),
                 ("instMatrices", C.c_void_p), ("instLightInstId", C.c_void_p), ("instNum", C.c_int32),
                 ("remapLists", C.c_void_p), ("remapListsSize", C.c_int32), ("remapTable", C.c_void_p),
-                ("remapTableSize", C.c_int32), ("remapInst", C.c_void_p), ("remapInstSize", C.c_int32)]
+                ("remapTableSize", C.c_int32), ("remapInst", C.c_void_p), ("remapInstSize", C.c_int32),
+                ("treesNum", C.c_int32), ("bvhN", C.c_void_p * 3), ("trisN", C.c_void_p * 3), ("haveInstN", C.c_int32 * 3), ("alpha", C.c_void_p * 4)]
 
 
 _lib = None
@@ -74,6 +75,14 @@ class Oracle:
         s.remapLists, s.remapListsSize = _p(b["remap_lists"]), b["remap_lists"].size
         s.remapTable, s.remapTableSize = _p(b["remap_table"]), b["remap_table"].size // 2
         s.remapInst, s.remapInstSize = _p(b["remap_inst"]), b["remap_inst"].size
+        # alpha table of tree 0 and, for two-tree scenes, tree 1 with its own (keys absent in single-tree buffer sets)
+        s.treesNum = int(b.get("trees_num", 1))
+        if "bvh_alpha" in b and b["bvh_alpha"].size:
+            s.alpha[0] = b["bvh_alpha"].ctypes.data
+        if s.treesNum > 1:
+            s.bvhN[0], s.trisN[0], s.haveInstN[0] = b["bvh_nodes1"].ctypes.data, b["bvh_tris1"].ctypes.data, int(b["have_inst1"])
+            if b["bvh_alpha1"].size:
+                s.alpha[1] = b["bvh_alpha1"].ctypes.data
         self.s = s
         self.w, self.h = b["width"], b["height"]
 

@@ -84,6 +84,12 @@ class RefScene:
         self.matrices, self.light_id = up(b["inst_matrices"]), up(b["inst_light_id"])
         self.have_inst = int(b["have_inst"])
         self.w, self.h = b["width"], b["height"]
+        # alpha table of tree 0, and a second tree with its own table (0 = absent: the kernels test the pointers)
+        self.alpha = up(b["bvh_alpha"]) if b.get("bvh_alpha", np.zeros(0)).size else 0
+        two = int(b.get("trees_num", 1)) > 1
+        self.bvh1, self.tris1 = (up(b["bvh_nodes1"]), up(b["bvh_tris1"])) if two else (0, 0)
+        self.alpha1 = up(b["bvh_alpha1"]) if two and b["bvh_alpha1"].size else 0
+        self.have_inst1 = int(b.get("have_inst1", 0)) if two else 0
 
     def random(self, seeds, draws):
         seeds = np.ascontiguousarray(seeds, np.int32)
@@ -103,7 +109,8 @@ class RefScene:
         n = len(pos4)
         hits = self.m.alloc(n * 16)
         self.m.launch("ref_trace", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
-                                       ("p", self.bvh), ("p", self.tris), ("p", hits), ("i", self.have_inst), ("i", n)])
+                                       ("p", self.bvh), ("p", self.tris), ("p", hits), ("i", self.have_inst), ("i", n),
+                                       ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.tex), ("p", self.globals)])
         dt = np.dtype([("t", np.float32), ("primId", np.int32), ("instId", np.int32), ("geomId", np.int32)])
         return self.m.down(hits, dt, (n,))
 
@@ -150,5 +157,6 @@ class RefScene:
         col = self.m.alloc(n * 16)
         self.m.launch("ref_path_trace", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
                                             ("p", rng), ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
-                                            ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", col), ("i", n)])
+                                            ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", col), ("i", n),
+                                            ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1)])
         return self.m.down(col, np.float32, (n, 4)), self.m.down(rng, np.uint32, (n, 2))

@@ -92,6 +92,29 @@ def gpu_atrium_ggx(built):
     return core, b, make_oracle(b)
 
 
+@pytest.fixture(scope="module")
+def gpu_atrium_cutouts(built):
+    """the hall with 61 instanced plants made of crossed cards behind a leaf mask (<opacity> texture): alpha-tested closest hit,
+    BVH4InstTraverseAlpha (ctrace.h:1297-1520), shadow rays without the test (Common.cpp:156-180)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_cutouts_small", 96, 54, 5)
+    assert b["bvh_alpha"].size > 0 and b["trees_num"] == 1
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
+def gpu_atrium_cutouts2(built):
+    """the same scene with the alpha-tested instances in a second BVH tree: IntegratorCommon::rayTrace's loop over the trees (Common.cpp:128-150)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_cutouts2_small", 96, 54, 5)
+    assert b["trees_num"] == 2 and b["bvh_alpha1"].size > 0 and b["bvh_alpha"].size == 0
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
 def test_native_library_is_the_one_running(gpu224):
     core, _, _ = gpu224
     name = core.device_name()
@@ -123,10 +146,10 @@ def test_eye_rays(fix, request):
     np.testing.assert_allclose(dr[:, :3], rdr[:, :3], atol=2e-6)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_closest_hit_bit_exact(fix, request):
     core, b, orc = request.getfixturevalue(fix)
-    pos4, dir4 = random_rays(65536, 21) if fix != "gpu_atrium" else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
+    pos4, dir4 = random_rays(65536, 21) if not fix.startswith("gpu_atrium") else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
     hits, cnt = core.stage_trace(pos4, dir4, counters=True)
     ref, rcnt, _ = orc.trace(pos4, dir4, counters=True)
     assert (hits["primId"] == ref["primId"]).all()
@@ -177,14 +200,14 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
         core.set_option("trace_min_active", defaults[1])
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_persistent_counting_kernels_total_what_the_oracle_counts(fix, request):
     """k_trace_dyn<*, true> -- the kernels bench.py prices its roofline bytes with -- against the oracle's per-ray counters
     summed: rays, quads visited, instance quads entered, leaves visited, triangles tested; closest hit and the early-out
     shadow walk (ctrace.h:1065-1294).  The sixth total counts fetches a range-checked buffer load would have answered with
     zeros: none may exist."""
     core, b, orc = request.getfixturevalue(fix)
-    pos4, dir4 = random_rays(65536, 91) if fix != "gpu_atrium" else random_rays(65536, 91, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
+    pos4, dir4 = random_rays(65536, 91) if not fix.startswith("gpu_atrium") else random_rays(65536, 91, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
     tfar = np.random.default_rng(6).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
     assert core.get_option("trace_mode") == 1 and core.get_option("top_quads_in_lds") == 21
     tot = core.stage_trace_totals(pos4, dir4)
@@ -219,7 +242,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -235,7 +258,7 @@ def test_light_and_material_functions_at_shading_points(fix, request):
     check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -256,7 +279,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -360,7 +383,7 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""
@@ -425,7 +448,8 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
 
 
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small",
-              "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small"}
+              "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
+              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small"}
 
 
 @pytest.mark.parametrize("fix", list(FIXTURE_OF))

@@ -132,6 +132,34 @@ def light_quad(hl, hw):
     return m
 
 
+def plant(cards=6, height=1.6, width=0.9):
+    """crossed vertical cards around the y axis, uv = the whole mask on every card, material 11"""
+    pos, uv, tri = [], [], []
+    for k in range(cards):
+        a = np.pi * k / cards
+        dx, dz = 0.5 * width * np.cos(a), 0.5 * width * np.sin(a)
+        b = len(pos)
+        pos += [[-dx, 0, -dz], [dx, 0, dz], [dx, height, dz], [-dx, height, -dz]]
+        uv += [[0.02, 0.02], [0.98, 0.02], [0.98, 0.98], [0.02, 0.98]]
+        tri += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
+    return finish_mesh(np.array(pos, float), np.array(uv, float), np.array(tri, np.int32), np.full(len(tri), 11))
+
+
+def leaf_mask(n=128):
+    """RGBA8: opaque green blobs (alpha 255) on a transparent ground (alpha 0); the material reads alpha as the opacity (input_alpha="alpha")"""
+    rng = np.random.default_rng(SEED + 7)
+    y, x = np.meshgrid((np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n, indexing="ij")
+    a = np.zeros((n, n))
+    for _ in range(40):
+        cx, cy, r = rng.uniform(0.1, 0.9), rng.uniform(0.05, 0.95), rng.uniform(0.04, 0.11)
+        a = np.maximum(a, ((x - cx) ** 2 / r ** 2 + (y - cy) ** 2 / (1.6 * r) ** 2 < 1.0).astype(float))
+    a = np.maximum(a, (np.abs(x - 0.5) < 0.03).astype(float))      # the stem
+    img = np.zeros((n, n, 4), np.uint8)
+    img[..., 0] = 40; img[..., 1] = 150; img[..., 2] = 60
+    img[..., 3] = (a * 255).astype(np.uint8)
+    return img
+
+
 def write_vsgf(path, m):
     vn, tn = len(m["pos"]), len(m["idx"]) // 3
     blobs = [m["pos"].tobytes(), m["norm"].tobytes(), m["tan"].tobytes(), m["uv"].tobytes(), m["idx"].tobytes(), m["mat"].tobytes()]
@@ -178,6 +206,10 @@ def main():
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
                     "reflection + glass + diffuse, curtains = textured glossy thin glass over diffuse")
+    ap.add_argument("--cutouts", action="store_true", help="adds 60 instanced plants made of crossed cards whose material has an <opacity> leaf mask (alpha-tested traversal, "
+                    "BVH4InstTraverseAlpha) and hangs a perforated screen (same mask) in front of the camera")
+    ap.add_argument("--two-trees", action="store_true", help="with --cutouts: the render settings ask the front end to put the instances of alpha-tested meshes into a second BVH "
+                    "tree (<split_alpha_tree>), the way Embree hands the reference several trees")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
@@ -191,6 +223,8 @@ def main():
         return max(lo, int(round(n * s)))
     meshes = [("column", column(r(64, 8), r(32, 4))), ("arch", arch(r(32, 4), r(32, 4))), ("pot", pot(r(20, 4), r(10, 2))),
               ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky or args.delta_lights)), ("light", light_quad(2.0, 0.5))]
+    if args.cutouts:
+        meshes.append(("plant", plant()))
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -205,6 +239,10 @@ def main():
         env[..., :3] = np.clip(env[..., :3] + sun[..., None] * np.array([1.0, 0.95, 0.8]), 0, 1)
         env[..., 3] = 1.0
         texs.append((None, (env * 255.0 + 0.5).astype(np.uint8)))
+    mask_tex = None
+    if args.cutouts:
+        mask_tex = len(texs)
+        texs.append((None, leaf_mask()))
     xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
     chunk = 0
     for tid, (n, img) in enumerate(texs):
@@ -249,6 +287,9 @@ def main():
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
     xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
+    if args.cutouts:   # leaves: textured lambert, the mask's alpha channel is the opacity
+        xml.append('  <material id="11" name="leaves" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" /><texture id="%d" type="texref" /></diffuse>'
+                   '<opacity smooth="0"><skip_shadow val="0" /><texture id="%d" type="texref" input_alpha="alpha" input_gamma="1" /></opacity></material>' % (mask_tex, mask_tex))
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
@@ -282,7 +323,8 @@ def main():
         chunk += 1
     xml.append("</geometry_lib>")
     xml.append('<render_lib>\n  <render_settings type="HydraModern" id="0"><width>%d</width><height>%d</height><method_primary>pathtracing</method_primary>'
-               '<trace_depth>8</trace_depth><diff_trace_depth>8</diff_trace_depth><maxRaysPerPixel>1024</maxRaysPerPixel></render_settings>\n</render_lib>' % (args.width, args.height))
+               '<trace_depth>8</trace_depth><diff_trace_depth>8</diff_trace_depth><maxRaysPerPixel>1024</maxRaysPerPixel>%s</render_settings>\n</render_lib>'
+               % (args.width, args.height, "<split_alpha_tree>1</split_alpha_tree>" if args.two_trees else ""))
 
     inst, total_tris = [], 0
 
@@ -302,6 +344,10 @@ def main():
     for k, x in enumerate((-12.0, -4.0, 4.0, 12.0)):
         add(4, mat4(t=(x, 1.8, -9.2 if k % 2 == 0 else 9.2), yaw=0.0 if k % 2 == 0 else np.pi))
     add(5, mat4())
+    if args.cutouts:
+        for _ in range(60):
+            add(7, mat4(scale=rng.uniform(0.8, 1.6), yaw=rng.uniform(0, 2 * np.pi), t=(rng.uniform(-18.0, 18.0), 0.0, rng.uniform(-8.5, 8.5))))
+        add(7, mat4(scale=2.2, yaw=np.pi / 2, t=(-9.0, 0.1, 2.5)))       # a big one in the camera's view
     light_m = mat4(t=(2.0, 9.6, 0.0))
     add(6, light_m, ' light_id="0" linst_id="0"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
