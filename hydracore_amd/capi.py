@@ -50,7 +50,8 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
-    "hydra_hip_stage_pack_unpack",
+    "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
+    "hydra_hip_stage_mutate_kelemen",
 ]
 
 _hip = None
@@ -119,6 +120,10 @@ def load_hip_library():
         "hydra_hip_comm_reduce_frame": ([vp, i32], i32),
         "hydra_hip_comm_destroy": ([vp], i32),
         "hydra_hip_stage_pack_unpack": ([vp, vp, i32, i32], i32),
+        "hydra_hip_stage_light_sample_forward": ([vp, i32, vp, vp, vp], i32),
+        "hydra_hip_stage_light_pdf_fwd": ([vp, i32, vp, vp, vp], i32),
+        "hydra_hip_stage_camera_connect": ([vp, i32, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_mutate_kelemen": ([vp, i32, vp, vp, C.c_float, C.c_float, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -434,6 +439,31 @@ class HipCore:
     def stage_pack_unpack(self, w, h):
         out = np.empty((h, w, 4), np.float32)
         self._ck(self.lib.hydra_hip_stage_pack_unpack(self.h, _ptr(out), w, h), "stage_pack_unpack")
+        return out
+
+    # ---- bidirectional building blocks (row f3)
+    def stage_light_sample_forward(self, light_ids, rands4):
+        ids, r = np.ascontiguousarray(light_ids, np.int32), np.ascontiguousarray(rands4, np.float32)
+        out = np.zeros((ids.size, 16), np.float32)
+        self._ck(self.lib.hydra_hip_stage_light_sample_forward(self.h, ids.size, _ptr(ids), _ptr(r), _ptr(out)), "stage_light_sample_forward")
+        return out
+
+    def stage_light_pdf_fwd(self, light_ids, cos_theta):
+        ids, ct = np.ascontiguousarray(light_ids, np.int32), np.ascontiguousarray(cos_theta, np.float32)
+        out = np.zeros((ids.size, 4), np.float32)
+        self._ck(self.lib.hydra_hip_stage_light_pdf_fwd(self.h, ids.size, _ptr(ids), _ptr(ct), _ptr(out)), "stage_light_pdf_fwd")
+        return out
+
+    def stage_camera_connect(self, pos4, norm4, disk2):
+        p, nn, d = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(norm4, np.float32), np.ascontiguousarray(disk2, np.float32)
+        out = np.zeros((len(p), 8), np.float32)
+        self._ck(self.lib.hydra_hip_stage_camera_connect(self.h, len(p), _ptr(p), _ptr(nn), _ptr(d), _ptr(out)), "stage_camera_connect")
+        return out
+
+    def stage_mutate_kelemen(self, values, rands2, p2=64.0, p1=1024.0):
+        v, r = np.ascontiguousarray(values, np.float32), np.ascontiguousarray(rands2, np.float32)
+        out = np.zeros(v.size, np.float32)
+        self._ck(self.lib.hydra_hip_stage_mutate_kelemen(self.h, v.size, _ptr(v), _ptr(r), p2, p1, _ptr(out)), "stage_mutate_kelemen")
         return out
 
     def bench_trace(self, pos4, dir4, iters=20, shadow=False):

@@ -27,6 +27,7 @@
 #include "hk_common.h"
 #include "hk_trace.h"
 #include "hk_shading.h"
+#include "hk_bidir.h"
 
 // ================================================================================================ device state
 struct PathState {   // S arrays
@@ -793,6 +794,37 @@ __global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__
   o[17] = ms.color.x; o[18] = ms.color.y; o[19] = ms.color.z; o[20] = ms.pdf;
   o[21] = ms.direction.x; o[22] = ms.direction.y; o[23] = ms.direction.z;
   o[24] = as_float(ms.flags); o[25] = as_float(int(flagsNextBounceLite(flags, ms, s)));
+}
+// ---- bidirectional building blocks (row f3, first milestone), one call per item with the random numbers handed in
+__global__ void k_stage_light_fwd(SceneDev s, int n, const int* __restrict__ lightIds, const float4* __restrict__ rands4, float* __restrict__ out16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LightSampleFwd sam;
+  LightSampleForward(lightAt(s, lightIds[i]), rands4[i], sam);
+  float* o = out16 + size_t(i) * 16;
+  o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
+  o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
+  o[12] = sam.pdfA; o[13] = sam.pdfW; o[14] = sam.cosTheta; o[15] = sam.isPoint ? 1.0f : 0.0f;
+}
+__global__ void k_stage_light_pdf_fwd(SceneDev s, int n, const int* __restrict__ lightIds, const float* __restrict__ cosTheta, float4* __restrict__ out4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const LightPdfFwd p = lightPdfFwd(lightAt(s, lightIds[i]), cosTheta[i]);
+  out4[i] = make_float4(p.pdfA, p.pdfW, p.pickProb, 0.0f);
+}
+__global__ void k_stage_camera_connect(SceneDev s, int n, const float4* __restrict__ pos4, const float4* __restrict__ norm4, const float2* __restrict__ disk2, float* __restrict__ out8) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f3 camDir; float zDepth;
+  const float f = CameraImageToSurfaceFactor(s, xyz(pos4[i]), xyz(norm4[i]), mk2(disk2[i].x, disk2[i].y), camDir, zDepth);
+  const f2 scr = worldPosToScreenSpace(s, xyz(pos4[i]));
+  float* o = out8 + size_t(i) * 8;
+  o[0] = f; o[1] = camDir.x; o[2] = camDir.y; o[3] = camDir.z; o[4] = zDepth; o[5] = scr.x; o[6] = scr.y; o[7] = 0.0f;
+}
+__global__ void k_stage_mutate_kelemen(int n, const float* __restrict__ values, const float2* __restrict__ rands2, float p2, float p1, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = MutateKelemen(values[i], mk2(rands2[i].x, rands2[i].y), p2, p1);
 }
 __global__ void k_stage_random(int n, const int* seeds, int draws, float4* out4, uint2* state2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2342,6 +2374,65 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   STAGE_EPILOG();
   HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));
   HCHECK(hipMemcpy(rng_state2, gensOut, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+// f3 building blocks: LightSampleForward, lightPdfFwd, camera connection, Kelemen mutation
+int hydra_hip_stage_light_sample_forward(hydra_hip_handle c, int n, const int32_t* light_ids, const float* rands4, float* out16) {
+  if (!c || n <= 0 || !light_ids || !rands4 || !out16 || !c->globals.p) return fail(c, HYDRA_HIP_ESTATE, "stage_light_sample_forward: globals are not uploaded / null argument");
+  HCHECK(hipSetDevice(c->device));
+  const int lightsNum = c->hostHeader[HG_LIGHTS_NUM];
+  for (int i = 0; i < n; i++) if (light_ids[i] < 0 || light_ids[i] >= lightsNum) return fail(c, HYDRA_HIP_EINVAL, "stage_light_sample_forward: light id out of range");
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  int* dl = (int*)tb.up(c, light_ids, size_t(n) * 4, rc);
+  float4* dr = (float4*)tb.up(c, rands4, size_t(n) * 16, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 64, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_light_fwd, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_scene(c), n, dl, dr, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out16, dout, size_t(n) * 64, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_stage_light_pdf_fwd(hydra_hip_handle c, int n, const int32_t* light_ids, const float* cos_theta, float* out4) {
+  if (!c || n <= 0 || !light_ids || !cos_theta || !out4 || !c->globals.p) return fail(c, HYDRA_HIP_ESTATE, "stage_light_pdf_fwd: globals are not uploaded / null argument");
+  HCHECK(hipSetDevice(c->device));
+  const int lightsNum = c->hostHeader[HG_LIGHTS_NUM];
+  for (int i = 0; i < n; i++) if (light_ids[i] < 0 || light_ids[i] >= lightsNum) return fail(c, HYDRA_HIP_EINVAL, "stage_light_pdf_fwd: light id out of range");
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  int* dl = (int*)tb.up(c, light_ids, size_t(n) * 4, rc);
+  float* dc = (float*)tb.up(c, cos_theta, size_t(n) * 4, rc);
+  float4* dout = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_light_pdf_fwd, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_scene(c), n, dl, dc, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out4, dout, size_t(n) * 16, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_stage_camera_connect(hydra_hip_handle c, int n, const float* pos4, const float* norm4, const float* disk2, float* out8) {
+  if (!c || n <= 0 || !pos4 || !norm4 || !disk2 || !out8 || !c->globals.p) return fail(c, HYDRA_HIP_ESTATE, "stage_camera_connect: globals are not uploaded / null argument");
+  HCHECK(hipSetDevice(c->device));
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  float4* dp = (float4*)tb.up(c, pos4, size_t(n) * 16, rc);
+  float4* dn = (float4*)tb.up(c, norm4, size_t(n) * 16, rc);
+  float2* dd = (float2*)tb.up(c, disk2, size_t(n) * 8, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 32, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_camera_connect, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_scene(c), n, dp, dn, dd, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out8, dout, size_t(n) * 32, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_stage_mutate_kelemen(hydra_hip_handle c, int n, const float* values, const float* rands2, float p2, float p1, float* out) {
+  if (!c || n <= 0 || !values || !rands2 || !out) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  TmpBufs tb; int rc = HYDRA_HIP_OK;
+  float* dv = (float*)tb.up(c, values, size_t(n) * 4, rc);
+  float2* dr = (float2*)tb.up(c, rands2, size_t(n) * 8, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_mutate_kelemen, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dv, dr, p2, p1, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out, dout, size_t(n) * 4, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 

@@ -202,6 +202,16 @@ int hydra_hip_stage_shade_point(hydra_hip_handle h, int n, const float* surf24, 
  * through the production wavefront kernels: IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb, w = 0 */
 int hydra_hip_stage_path_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                                uint32_t* rng_state2, float* color4);
+/* Row f3 (MMLT / SBDPT, hydra_drv/CPUExp_Integrators_MMLT.cpp), first milestone: the building blocks one call at a time.
+ * LightSampleForward (clight.h:1064-1110): light id + 4 randoms -> out16 = pos xyz, dir xyz, normal xyz, colour xyz, pdfA, pdfW, cosTheta, isPoint */
+int hydra_hip_stage_light_sample_forward(hydra_hip_handle h, int n, const int32_t* light_ids, const float* rands4, float* out16);
+/* lightPdfFwd (clight.h:1117-1175): light id + cosine at the light -> out4 = pdfA, pdfW, pick probability (forward), 0 */
+int hydra_hip_stage_light_pdf_fwd(hydra_hip_handle h, int n, const int32_t* light_ids, const float* cos_theta, float* out4);
+/* CameraImageToSurfaceFactor + worldPosToScreenSpace (cbidir.h:78-131): surface point, normal (float4 each), lens offset (2 floats) ->
+ * out8 = image-to-surface factor, direction to the camera xyz, distance, screen x, screen y, 0 */
+int hydra_hip_stage_camera_connect(hydra_hip_handle h, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
+/* MutateKelemen (crandom.h:189-210): primary-space values + 2 randoms each, step parameters p2 < p1 (defaults 64, 1024) */
+int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* values, const float* rands2, float p2, float p1, float* out);
 /* R1  RandomGenInit + rndFloat4_Pseudo (crandom.h:20-63): for each seed the first `draws` float4 outputs */
 int hydra_hip_stage_random(hydra_hip_handle h, int n, const int32_t* seeds, int draws, float* out4, uint32_t* state2);
 

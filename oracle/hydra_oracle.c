@@ -1602,6 +1602,193 @@ static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum
   }
 }
 
+/* ------------------------------------------------------------------------------------------------ f3: bidirectional building blocks */
+enum { G_MPROJ = 0, G_MWORLDVIEW = 16, G_CAM_FORWARD = 208, G_CAM_UP = 211, G_IMAGE_PLANE_DIST = 217,
+       HRT_FOV_X = 23, HRT_FOV_Y = 24, HRT_WIDTH_F = 25, HRT_HEIGHT_F = 26, PL_PICK_PROB_FWD = 106 };   /* cfetch.h:21-81, cglobals.h varsF names, clight.h:164 */
+typedef struct { f3 pos, dir, norm, color; float pdfA, pdfW, cosTheta; int isPoint; } LightSampleFwd;   /* clight.h:632-643 */
+/* ref: cglobals.h:1160-1168 */
+static f3 UniformSampleSphere(float u1, float u2) {
+  const float z = 1.0f - 2.0f * u1;
+  const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+  const float phi = 2.0f * ORC_PI * u2;
+  return v3(r * cosf(phi), r * sinf(phi), z);
+}
+/* ref: clight.h:654-719 AreaLightSampleForward (no IES, no sky portal in the subset) */
+static void AreaLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+  const float offsetX = r[0] * 2.0f - 1.0f, offsetY = r[1] * 2.0f - 1.0f;
+  f3 sp = v3(offsetX * L[AL_SIZE_X], 0.0f, offsetY * L[AL_SIZE_Y]);
+  if (as_int(L[AL_IS_DISK]) != 0) {
+    f2 in = {offsetX, offsetY};
+    const f2 xz = MapSamplesToDisc(in);
+    sp = v3(xz.x * L[AL_SIZE_X], 0.0f, xz.y * L[AL_SIZE_X]);
+  }
+  const float* M = L + AL_MATRIX;
+  sp = v3(M[0] * sp.x + M[1] * sp.y + M[2] * sp.z, M[3] * sp.x + M[4] * sp.y + M[5] * sp.z, M[6] * sp.x + M[7] * sp.y + M[8] * sp.z);
+  sp = add3(sp, lightPos(L));
+  const f3 ln = lightNorm(L);
+  f3 sampleDir = MapSampleToCosineDistribution(r[2], r[3], ln, ln, 1.0f);
+  float cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
+  float pdfW = cosTheta * INV_PI;
+  if (as_int(L[AL_SPOT_DISTR]) != 0) {
+    const float cos2 = L[AL_SPOT_COS2];
+    f2 sm = {r[2], r[3]};
+    sampleDir = MapSamplesToCone(cos2, sm, ln);
+    pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
+  }
+  cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
+  const f3 color = areaDiffuseLightGetIntensity(L, scale3(sampleDir, -1.0f), 0);
+  out->isPoint = 0;
+  out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
+  out->dir = sampleDir;
+  out->color = scale3(color, cosTheta);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = pdfW;
+  out->cosTheta = cosTheta;
+  out->norm = ln;
+}
+/* ref: clight.h:838-862 PointLightSampleForward (pointLightGetIntensity :486-495 is the base colour without IES) */
+static void PointLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+  const f3 sampleDir = UniformSampleSphere(r[0], r[1]);
+  const f3 samplePos = lightPos(L);
+  out->isPoint = 1;
+  out->pos = add3(samplePos, scale3(sampleDir, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(lightColor(L), 1.0f / L[PL_SURFACE_AREA]);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = INV_PI * 0.25f;
+  out->cosTheta = 1.0f;
+  out->norm = sampleDir;
+}
+/* ref: clight.h:865-890 PointSpotSampleForward */
+static void PointSpotSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+  const f3 ln = lightNorm(L), samplePos = lightPos(L);
+  const float cos1 = L[POINT_LIGHT_SPOT_COS1], cos2 = L[POINT_LIGHT_SPOT_COS2];
+  f2 sm = {r[0], r[1]};
+  const f3 sampleDir = MapSamplesToCone(cos2, sm, ln);
+  const float cosThetaOut = fmaxf(dot3(sampleDir, ln), 0.0f);
+  const float k1 = mylocalsmoothstep(cos2, cos1, cosThetaOut);
+  out->isPoint = 1;
+  out->pos = add3(samplePos, scale3(sampleDir, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(scale3(lightColor(L), k1), 1.0f / L[PL_SURFACE_AREA]);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
+  out->cosTheta = cosThetaOut;
+  out->norm = sampleDir;
+}
+/* ref: clight.h:915-958 DirectLightSampleForward */
+static void DirectLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+  const f3 ln = lightNorm(L), lcenter = lightPos(L);
+  const float radius1 = L[DIRECT_LIGHT_RADIUS1], radius2 = L[DIRECT_LIGHT_RADIUS2];
+  f2 in = {2.0f * (r[0] - 0.5f), 2.0f * (r[1] - 0.5f)};
+  const f2 d0 = MapSamplesToDisc(in);
+  const f2 diskSam = {radius2 * d0.x, radius2 * d0.y};
+  const float d = sqrtf(diskSam.x * diskSam.x + diskSam.y * diskSam.y);
+  const float atten = mylocalsmoothstep(fmaxf(radius2, radius1), fminf(radius2, radius1), d);
+  f3 nx, nz;
+  CoordinateSystem(ln, &nx, &nz);
+  const f3 samplePos = add3(add3(lcenter, scale3(nx, diskSam.x)), scale3(nz, diskSam.y));
+  f3 sampleDir = ln;
+  const float pdfW = 1.0f;
+  if (L[DIRECT_LIGHT_SSOFTNESS] > 1e-5f) { f2 sm = {r[2], r[3]}; sampleDir = MapSamplesToCone(L[DIRECT_LIGHT_ALPHA_COS], sm, ln); }
+  out->isPoint = 1;
+  out->pos = add3(samplePos, scale3(sampleDir, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(scale3(lightColor(L), atten), pdfW);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = pdfW;
+  out->cosTheta = 1.0f;
+  out->norm = sampleDir;
+}
+/* ref: clight.h:1064-1110 LightSampleForward over the light types the layer accepts -> out16 = pos, dir, norm, colour, pdfA, pdfW, cosTheta, isPoint */
+void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds, const float* rands4, float* out16) {
+  for (int i = 0; i < n; i++) {
+    const float* L = lightAt(s, lightIds[i]);
+    LightSampleFwd sam;
+    switch (as_int(L[PL_TYPE])) {
+      case LT_DIRECT: DirectLightSampleForward(L, rands4 + 4 * i, &sam); break;
+      case LT_POINT_SPOT: PointSpotSampleForward(L, rands4 + 4 * i, &sam); break;
+      case LT_POINT_OMNI: PointLightSampleForward(L, rands4 + 4 * i, &sam); break;
+      default: AreaLightSampleForward(L, rands4 + 4 * i, &sam); break;
+    }
+    float* o = out16 + 16 * (size_t)i;
+    o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
+    o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
+    o[12] = sam.pdfA; o[13] = sam.pdfW; o[14] = sam.cosTheta; o[15] = sam.isPoint ? 1.0f : 0.0f;
+  }
+}
+/* ref: clight.h:1117-1175 lightPdfFwd (no IES) -> out4 = pdfA, pdfW, pickProb, 0 */
+void orc_light_pdf_fwd(const OrcScene* s, int n, const int32_t* lightIds, const float* cosTheta, float* out4) {
+  for (int i = 0; i < n; i++) {
+    const float* L = lightAt(s, lightIds[i]);
+    const float ct = cosTheta[i];
+    float pdfA = 1.0f / L[PL_SURFACE_AREA], pdfW = fmaxf(ct * INV_PI, 0.0f);
+    const int ltype = as_int(L[PL_TYPE]);
+    if (ltype == LT_POINT_OMNI) pdfW = INV_PI * 0.25f;
+    else if (ltype == LT_POINT_SPOT) {
+      const float cos2 = L[POINT_LIGHT_SPOT_COS2];
+      pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
+      if (ct < cos2) pdfW = 0.0f;
+    } else if (ltype == LT_DIRECT) {
+      const float radius2 = L[DIRECT_LIGHT_RADIUS2];
+      pdfA = 1.0f / (ORC_PI * radius2 * radius2);
+      pdfW = 0.0f;
+    }
+    if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) {
+      const float cos2 = L[AL_SPOT_COS2];
+      pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
+      if (ct < cos2) pdfW = 0.0f;
+    }
+    out4[4 * i + 0] = pdfA; out4[4 * i + 1] = pdfW; out4[4 * i + 2] = L[PL_PICK_PROB_FWD]; out4[4 * i + 3] = 0.0f;
+  }
+}
+/* ref: cbidir.h:78-115 CameraImageToSurfaceFactor, :117-131 worldPosToScreenSpace -> out8 = factor, camDir xyz, zDepth, screen xy, 0 */
+void orc_camera_connect(const OrcScene* s, int n, const float* pos4, const float* norm4, const float* disk2, float* out8) {
+  const float* gf = (const float*)s->globals;
+  const m44 wvInv = load_m44(gf + G_MWORLDVIEW_INV), wv = load_m44(gf + G_MWORLDVIEW), proj = load_m44(gf + G_MPROJ);
+  const f3 camForward = v3(gf[G_CAM_FORWARD], gf[G_CAM_FORWARD + 1], gf[G_CAM_FORWARD + 2]);
+  const f3 camUp = v3(gf[G_CAM_UP], gf[G_CAM_UP + 1], gf[G_CAM_UP + 2]);
+  const f3 camLeft = normalize3(cross3(camForward, camUp));
+  const float imagePlaneDist = gf[G_IMAGE_PLANE_DIST], lensR = g_varsF(s)[HRT_DOF_LENS_RADIUS];
+  const float fw = g_varsF(s)[HRT_WIDTH_F], fh = g_varsF(s)[HRT_HEIGHT_F];
+  for (int i = 0; i < n; i++) {
+    const f3 hitPos = v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), hitNorm = v3(norm4[4 * i], norm4[4 * i + 1], norm4[4 * i + 2]);
+    const float dx = disk2[2 * i], dy = disk2[2 * i + 1];
+    const f3 camPos = add3(add3(mul4x3(wvInv, v3(0, 0, 0)), scale3(scale3(camUp, dy), lensR)), scale3(scale3(camLeft, dx), lensR));
+    const float zDepth = length3(sub3(camPos, hitPos));
+    const f3 camDir = scale3(sub3(camPos, hitPos), 1.0f / zDepth);
+    const float cosToCamera = fabsf(dot3(hitNorm, camDir));
+    const float cosAtCamera = dot3(camForward, scale3(camDir, -1.0f));
+    const float relation = fw / fh;
+    const float fov = relation * fmaxf(g_varsF(s)[HRT_FOV_X], g_varsF(s)[HRT_FOV_Y]);
+    float factor = 0.0f;
+    if (!(cosAtCamera <= cosf(fov))) {
+      const float imagePointToCameraDist = imagePlaneDist / cosAtCamera;
+      const float imageToSolidAngleFactor = (imagePointToCameraDist * imagePointToCameraDist) / cosAtCamera;
+      const float imageToSurfaceFactor = imageToSolidAngleFactor * cosToCamera / (zDepth * zDepth);
+      factor = isfinite(imageToSurfaceFactor) ? imageToSurfaceFactor / (relation * relation) : 0.0f;
+    }
+    const f4 pw = {hitPos.x, hitPos.y, hitPos.z, 1.0f};
+    const f4 ndc = mul4x4x4(proj, mul4x4x4(wv, pw));
+    const float inv = 1.0f / fmaxf(ndc.w, DEPSILON);
+    float* o = out8 + 8 * (size_t)i;
+    o[0] = factor; o[1] = camDir.x; o[2] = camDir.y; o[3] = camDir.z; o[4] = zDepth;
+    o[5] = (ndc.x * inv * 0.5f + 0.5f) * fw; o[6] = (ndc.y * inv * 0.5f + 0.5f) * fh; o[7] = 0.0f;
+  }
+}
+/* ref: crandom.h:189-210 MutateKelemen */
+void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p2, float p1, float* out) {
+  const float s1 = 1.0f / p1, s2 = 1.0f / p2;
+  const float power = -logf(s2 / s1);
+  for (int i = 0; i < n; i++) {
+    float x = values[i];
+    const float dv = fmaxf(s2 * (expf(power * sqrtf(rands2[2 * i])) - expf(power)), 0.0f);
+    if (rands2[2 * i + 1] < 0.5f) { x += dv; if (x > 1.0f) x -= 1.0f; }
+    else { x -= dv; if (x < 0.0f) x += 1.0f; }
+    out[i] = x;
+  }
+}
+
 /* ref: cbidir.h:492-533 environmentColor; misPrev.prevMaterialOffset is -1 on this path (PT_Loop.cpp:247-249) */
 static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prevSpecular, uint32_t flags) {
   const int skyId = s->globals[G_SKY_LIGHT_ID];

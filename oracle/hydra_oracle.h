@@ -78,6 +78,11 @@ uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float*
 void orc_init_generators(int w, int h, int seed, uint32_t* gens);
 /* dump the live rays of a given bounce (0 = primary) for the first sample of every pixel: returns count */
 int64_t orc_collect_rays(const OrcScene* s, int w, int h, int seed, int bounce, int shadow, float* pos4, float* dir4, float* tfar, int64_t cap);
+/* f3 building blocks (MMLT / SBDPT): clight.h:1064-1110, :1117-1175, cbidir.h:78-131, crandom.h:189-210 */
+void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds, const float* rands4, float* out16);
+void orc_light_pdf_fwd(const OrcScene* s, int n, const int32_t* lightIds, const float* cosTheta, float* out4);
+void orc_camera_connect(const OrcScene* s, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
+void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p2, float p1, float* out);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -373,3 +373,48 @@ __kernel void ref_shade_point(__global const float* surf24, __global const float
   o[21] = matSam.direction.x; o[22] = matSam.direction.y; o[23] = matSam.direction.z;
   o[24] = as_float(matSam.flags); o[25] = as_float((int)flagsNextBounceLite(flags, matSam, a_globals));
 }
+
+/* ---- row f3 building blocks: the reference's own LightSampleForward / lightPdfFwd / CameraImageToSurfaceFactor /
+   worldPosToScreenSpace / MutateKelemen, one call per item with the random numbers handed in. */
+__kernel void ref_light_sample_forward(__global const int* lightIds, __global const float4* rands4, __global const int4* in_texStorage,
+                                       __global const float4* in_pdfStorage, __global const EngineGlobals* a_globals, __global float* out16, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global const PlainLight* pLight = lightAt(a_globals, lightIds[i]);
+  LightSampleFwd sam;
+  LightSampleForward(pLight, rands4[i], make_float2(0.0f, 0.0f), a_globals, in_texStorage, in_pdfStorage, &sam);
+  __global float* o = out16 + i * 16;
+  o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
+  o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
+  o[12] = sam.pdfA; o[13] = sam.pdfW; o[14] = sam.cosTheta; o[15] = sam.isPoint ? 1.0f : 0.0f;
+}
+
+__kernel void ref_light_pdf_fwd(__global const int* lightIds, __global const float* cosTheta, __global const int4* in_texStorage,
+                                __global const float4* in_pdfStorage, __global const EngineGlobals* a_globals, __global float4* out4, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global const PlainLight* pLight = lightAt(a_globals, lightIds[i]);
+  const LightPdfFwd p = lightPdfFwd(pLight, make_float3(0.0f, 0.0f, 1.0f), cosTheta[i], a_globals, in_texStorage, in_pdfStorage);
+  out4[i] = make_float4(p.pdfA, p.pdfW, p.pickProb, 0.0f);
+}
+
+__kernel void ref_camera_connect(__global const float4* pos4, __global const float4* norm4, __global const float2* disk2,
+                                 __global const EngineGlobals* a_globals, __global float* out8, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  float3 camDir; float zDepth;
+  const float f = CameraImageToSurfaceFactor(to_float3(pos4[i]), to_float3(norm4[i]), a_globals, disk2[i], &camDir, &zDepth);
+  const float2 scr = worldPosToScreenSpace(to_float3(pos4[i]), a_globals);
+  __global float* o = out8 + i * 8;
+  o[0] = f; o[1] = camDir.x; o[2] = camDir.y; o[3] = camDir.z; o[4] = zDepth; o[5] = scr.x; o[6] = scr.y; o[7] = 0.0f;
+}
+
+__kernel void ref_mutate_kelemen(__global const float* values, __global const float2* rands2, float p2, float p1, __global float* out, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  out[i] = MutateKelemen(values[i], rands2[i], p2, p1);
+}

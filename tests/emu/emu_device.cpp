@@ -9,6 +9,7 @@
 #include "../../hydracore_amd/csrc/hk_common.h"
 #include "../../hydracore_amd/csrc/hk_trace.h"
 #include "../../hydracore_amd/csrc/hk_shading.h"
+#include "../../hydracore_amd/csrc/hk_bidir.h"
 #include "emu_integrator.h"
 
 struct EmuScene {   // mirrors tests/oracle_lib.OrcScene field for field
@@ -97,6 +98,29 @@ void emu_eye_rays(const EmuScene* e, int n, int w, int h, const int* xy, const f
     MakeRandEyeRay(xy[2 * i], xy[2 * i + 1], w, h, make_float4(offs4[4 * i], offs4[4 * i + 1], offs4[4 * i + 2], offs4[4 * i + 3]), s, p, d);
     pos4[4 * i] = p.x; pos4[4 * i + 1] = p.y; pos4[4 * i + 2] = p.z; pos4[4 * i + 3] = 0;
     dir4[4 * i] = d.x; dir4[4 * i + 1] = d.y; dir4[4 * i + 2] = d.z; dir4[4 * i + 3] = 0;
+  }
+}
+
+// row f3 building blocks (hk_bidir.h), same record layouts as the stage calls of the C-ABI
+void emu_bidir(const EmuScene* e, int n, const int* lightIds, const float* rands4, const float* cosTheta, const float* pos4, const float* norm4,
+               const float* disk2, const float* values, const float* rands2, float p2, float p1, float* fwd16, float* pdf4, float* cam8, float* mut) {
+  const SceneDev s = to_dev(e);
+  for (int i = 0; i < n; i++) {
+    LightSampleFwd sam;
+    LightSampleForward(lightAt(s, lightIds[i]), make_float4(rands4[4 * i], rands4[4 * i + 1], rands4[4 * i + 2], rands4[4 * i + 3]), sam);
+    float* o = fwd16 + 16 * size_t(i);
+    o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
+    o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
+    o[12] = sam.pdfA; o[13] = sam.pdfW; o[14] = sam.cosTheta; o[15] = sam.isPoint ? 1.0f : 0.0f;
+    const LightPdfFwd p = lightPdfFwd(lightAt(s, lightIds[i]), cosTheta[i]);
+    pdf4[4 * i] = p.pdfA; pdf4[4 * i + 1] = p.pdfW; pdf4[4 * i + 2] = p.pickProb; pdf4[4 * i + 3] = 0.0f;
+    f3 camDir; float zDepth;
+    const f3 hp = mk3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]);
+    const float f = CameraImageToSurfaceFactor(s, hp, mk3(norm4[4 * i], norm4[4 * i + 1], norm4[4 * i + 2]), mk2(disk2[2 * i], disk2[2 * i + 1]), camDir, zDepth);
+    const f2 scr = worldPosToScreenSpace(s, hp);
+    float* c = cam8 + 8 * size_t(i);
+    c[0] = f; c[1] = camDir.x; c[2] = camDir.y; c[3] = camDir.z; c[4] = zDepth; c[5] = scr.x; c[6] = scr.y; c[7] = 0.0f;
+    mut[i] = MutateKelemen(values[i], mk2(rands2[2 * i], rands2[2 * i + 1]), p2, p1);
   }
 }
 

@@ -69,6 +69,7 @@ def main():
     lib.emu_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, i32, vp, vp]
     lib.emu_path_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp]
     lib.emu_eye_rays.argtypes = [C.POINTER(OrcScene), i32, i32, i32, vp, vp, vp, vp]
+    lib.emu_bidir.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
 
     def p(a):
         return a.ctypes.data_as(C.c_void_p)
@@ -93,6 +94,22 @@ def main():
         assert (vis == orc.shadow_trace(pos4, dir4, tfar)).all(), "shadow differs"
         rvis, racnt = orc.shadow_trace_anyhit(pos4, dir4, tfar, counters=True)   # the early-out walk of ctrace.h:1065-1294
         assert (vis == rvis).all() and (acnt == racnt).all(), "any-hit walk differs from the oracle's"
+        # row f3 building blocks (hk_bidir.h) against the oracle's, seeded inputs
+        brng = np.random.default_rng(31)
+        nb = 4096
+        ids = brng.integers(0, int(b["globals"][238]), nb).astype(np.int32)
+        r4, ct = brng.uniform(0, 1, (nb, 4)).astype(np.float32), brng.uniform(-0.25, 1, nb).astype(np.float32)
+        surf = orc.eval_surface(pos4[:nb], dir4[:nb], ref[:nb])
+        bp, bn = np.zeros((nb, 4), np.float32), np.zeros((nb, 4), np.float32)
+        bp[:, :3], bn[:, :3] = surf[:, 0:3], surf[:, 3:6]
+        bn[np.abs(bn[:, :3]).sum(axis=1) == 0, 1] = 1.0            # rays that missed: any unit normal
+        dk, vals, r2 = brng.uniform(-1, 1, (nb, 2)).astype(np.float32), brng.uniform(0, 1, nb).astype(np.float32), brng.uniform(0, 1, (nb, 2)).astype(np.float32)
+        fwd, pdf, cam, mut = np.empty((nb, 16), np.float32), np.empty((nb, 4), np.float32), np.empty((nb, 8), np.float32), np.empty(nb, np.float32)
+        lib.emu_bidir(C.byref(orc.s), nb, p(ids), p(r4), p(ct), p(bp), p(bn), p(dk), p(vals), p(r2), 64.0, 1024.0, p(fwd), p(pdf), p(cam), p(mut))
+        for got, want, what in ((fwd, orc.light_sample_forward(ids, r4), "LightSampleForward"), (pdf, orc.light_pdf_fwd(ids, ct), "lightPdfFwd"),
+                                (cam, orc.camera_connect(bp, bn, dk), "camera connection"), (mut, orc.mutate_kelemen(vals, r2, 64.0, 1024.0), "MutateKelemen")):
+            bad = ~np.isclose(got, want, rtol=2e-6, atol=2e-6, equal_nan=True)   # a sky dome takes the area-light branch, as in the reference: NaN on both sides
+            assert not bad.any(), "%s differs from the oracle on %s: %d values, columns %s, e.g. %s vs %s" % (what, name, bad.sum(), np.unique(np.nonzero(bad.reshape(len(got), -1))[1]), got[bad][:4], want[bad][:4])
         # whole paths
         n = w * h
         ys, xs = np.divmod(np.arange(n), w)

@@ -47,6 +47,10 @@ def load():
     lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.orc_render_pass.restype = C.c_uint64
+    lib.orc_light_sample_forward.argtypes = [sp, i32, vp, vp, vp]
+    lib.orc_light_pdf_fwd.argtypes = [sp, i32, vp, vp, vp]
+    lib.orc_camera_connect.argtypes = [sp, i32, vp, vp, vp, vp]
+    lib.orc_mutate_kelemen.argtypes = [i32, vp, vp, C.c_float, C.c_float, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
     lib.orc_collect_rays.restype = C.c_int64
@@ -153,6 +157,31 @@ class Oracle:
         rands10 = np.ascontiguousarray(rands10, np.float32)
         out = np.zeros((n, 28), np.float32)
         self.lib.orc_shade_point(C.byref(self.s), n, _p(surf24), _p(dir4), _p(flags), _p(rnd_light4), _p(rands10), _p(out))
+        return out
+
+    # ---- row f3 building blocks
+    def light_sample_forward(self, light_ids, rands4):
+        ids, r = np.ascontiguousarray(light_ids, np.int32), np.ascontiguousarray(rands4, np.float32)
+        out = np.zeros((ids.size, 16), np.float32)
+        self.lib.orc_light_sample_forward(C.byref(self.s), ids.size, _p(ids), _p(r), _p(out))
+        return out
+
+    def light_pdf_fwd(self, light_ids, cos_theta):
+        ids, ct = np.ascontiguousarray(light_ids, np.int32), np.ascontiguousarray(cos_theta, np.float32)
+        out = np.zeros((ids.size, 4), np.float32)
+        self.lib.orc_light_pdf_fwd(C.byref(self.s), ids.size, _p(ids), _p(ct), _p(out))
+        return out
+
+    def camera_connect(self, pos4, norm4, disk2):
+        p, nn, d = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(norm4, np.float32), np.ascontiguousarray(disk2, np.float32)
+        out = np.zeros((len(p), 8), np.float32)
+        self.lib.orc_camera_connect(C.byref(self.s), len(p), _p(p), _p(nn), _p(d), _p(out))
+        return out
+
+    def mutate_kelemen(self, values, rands2, p2=64.0, p1=1024.0):
+        v, r = np.ascontiguousarray(values, np.float32), np.ascontiguousarray(rands2, np.float32)
+        out = np.zeros(v.size, np.float32)
+        self.lib.orc_mutate_kelemen(v.size, _p(v), _p(r), p2, p1, _p(out))
         return out
 
     def path_trace(self, pos4, dir4, rng2):

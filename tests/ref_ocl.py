@@ -51,12 +51,12 @@ class RefModule:
         return out
 
     def launch(self, kernel, n, args, block=64):
-        """args: list of ('p', devptr) | ('i', int).  One work-item per element, 1-D."""
+        """args: list of ('p', devptr) | ('i', int) | ('f', float).  One work-item per element, 1-D."""
         fn = C.c_void_p()
         self._ck(self.hip.hipModuleGetFunction(C.byref(fn), self.mod, kernel.encode()), "hipModuleGetFunction(%s)" % kernel)
         holders = []
         for kind, v in args:
-            holders.append(C.c_void_p(v) if kind == "p" else C.c_int(v))
+            holders.append(C.c_void_p(v) if kind == "p" else C.c_float(v) if kind == "f" else C.c_int(v))
         params = (C.c_void_p * len(holders))(*[C.cast(C.byref(h), C.c_void_p) for h in holders])
         grid = (n + block - 1) // block
         self._ck(self.hip.hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, None, params, None), "hipModuleLaunchKernel(%s)" % kernel)
@@ -150,6 +150,35 @@ class RefScene:
                                              ("p", self.m.up(np.ascontiguousarray(rands10, np.float32))), ("p", self.mat), ("p", self.tex), ("p", self.pdf),
                                              ("p", self.globals), ("p", out), ("i", n)])
         return self.m.down(out, np.float32, (n, 28))
+
+    # ---- row f3 building blocks
+    def light_sample_forward(self, light_ids, rands4):
+        n = len(light_ids)
+        out = self.m.alloc(n * 64)
+        self.m.launch("ref_light_sample_forward", n, [("p", self.m.up(np.ascontiguousarray(light_ids, np.int32))), ("p", self.m.up(np.ascontiguousarray(rands4, np.float32))),
+                                                      ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 16))
+
+    def light_pdf_fwd(self, light_ids, cos_theta):
+        n = len(light_ids)
+        out = self.m.alloc(n * 16)
+        self.m.launch("ref_light_pdf_fwd", n, [("p", self.m.up(np.ascontiguousarray(light_ids, np.int32))), ("p", self.m.up(np.ascontiguousarray(cos_theta, np.float32))),
+                                               ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 4))
+
+    def camera_connect(self, pos4, norm4, disk2):
+        n = len(pos4)
+        out = self.m.alloc(n * 32)
+        self.m.launch("ref_camera_connect", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(norm4, np.float32))),
+                                                ("p", self.m.up(np.ascontiguousarray(disk2, np.float32))), ("p", self.globals), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 8))
+
+    def mutate_kelemen(self, values, rands2, p2, p1):
+        n = len(values)
+        out = self.m.alloc(n * 4)
+        self.m.launch("ref_mutate_kelemen", n, [("p", self.m.up(np.ascontiguousarray(values, np.float32))), ("p", self.m.up(np.ascontiguousarray(rands2, np.float32))),
+                                                ("f", p2), ("f", p1), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n,))
 
     def path_trace(self, pos4, dir4, rng2):
         n = len(pos4)

@@ -146,3 +146,43 @@ def test_oracle_matches_reference_functions(name, built):
     limit = 0.01 if name in ("atrium_lights_small", "atrium_ggx_small") else 0.005
     assert bad.mean() < limit, bad.mean()
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
+
+
+BIDIR_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small"]
+
+
+def check_bidir(got, g, exact_pdf=True):
+    """the four f3 building blocks against ref_bidir_<scene>.npz (the reference's own functions run through oracle/_ref)"""
+    fwd, pdf, cam, mut, mut2 = got
+    rf = g["fwd"]
+    assert (fwd[:, 15] == rf[:, 15]).all()                                              # isPoint
+    np.testing.assert_allclose(fwd[:, 0:9], rf[:, 0:9], rtol=2e-5, atol=2e-5)           # position, direction, normal
+    np.testing.assert_allclose(fwd[:, 9:12], rf[:, 9:12], rtol=1e-4, atol=1e-6)         # colour (x cosTheta for area lights)
+    np.testing.assert_allclose(fwd[:, 12:15], rf[:, 12:15], rtol=2e-5, atol=1e-6)       # pdfA, pdfW, cosTheta
+    np.testing.assert_allclose(pdf, g["pdf"], rtol=2e-6, atol=0)
+    rc = g["cam"]
+    assert ((cam[:, 0] > 0) == (rc[:, 0] > 0)).mean() > 0.999                           # the field-of-view cut may round the other way on its edge
+    m = (cam[:, 0] > 0) & (rc[:, 0] > 0)
+    np.testing.assert_allclose(cam[m, 0], rc[m, 0], rtol=2e-5)
+    np.testing.assert_allclose(cam[:, 1:5], rc[:, 1:5], rtol=1e-5, atol=2e-6)           # direction to the camera, distance
+    front = rc[:, 4] > 0
+    np.testing.assert_allclose(cam[front, 5:7], rc[front, 5:7], rtol=1e-4, atol=2e-3)   # screen position in pixels
+    np.testing.assert_allclose(mut, g["mut"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(mut2, g["mut2"], rtol=0, atol=2e-7)
+    assert (np.abs(mut - g["values"]) > 0).mean() > 0.99 and ((mut >= 0) & (mut <= 1)).all()
+
+
+def run_bidir(impl, g):
+    return (impl.light_sample_forward(g["light_ids"], g["rands4"]), impl.light_pdf_fwd(g["light_ids"], g["cos_theta"]),
+            impl.camera_connect(g["pos4"], g["norm4"], g["disk2"]), impl.mutate_kelemen(g["values"], g["rands2"], 64.0, 1024.0),
+            impl.mutate_kelemen(g["values"], g["rands2"], 32.0, 2048.0))
+
+
+@pytest.mark.parametrize("name", BIDIR_SCENES)
+def test_oracle_matches_reference_bidirectional_blocks(name, built):
+    """row f3, first milestone: LightSampleForward (clight.h:1064-1110), lightPdfFwd (:1117-1175), CameraImageToSurfaceFactor +
+    worldPosToScreenSpace (cbidir.h:78-131), MutateKelemen (crandom.h:189-210)"""
+    g = load("ref_bidir_%s.npz" % name)
+    r = load("ref_%s.npz" % name)
+    _, b = host_scene(name, int(r["width"]), int(r["height"]), int(r["depth"]), int(r["dof"]))
+    check_bidir(run_bidir(make_oracle(b), g), g)

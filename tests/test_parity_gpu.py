@@ -258,6 +258,30 @@ def test_light_and_material_functions_at_shading_points(fix, request):
     check_shade_point(core.stage_shade_point(surf, dir4, flags, rl, rands), orc.shade_point(surf, dir4, flags, rl, rands))
 
 
+class _HipBidir:
+    """the four f3 stage calls under the names the oracle wrapper uses, so that one checker serves both"""
+    def __init__(self, core):
+        self.light_sample_forward, self.light_pdf_fwd = core.stage_light_sample_forward, core.stage_light_pdf_fwd
+        self.camera_connect, self.mutate_kelemen = core.stage_camera_connect, core.stage_mutate_kelemen
+
+
+@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small")])
+def test_bidirectional_building_blocks(fix, name, request):
+    """row f3, first milestone: LightSampleForward, lightPdfFwd, CameraImageToSurfaceFactor + worldPosToScreenSpace and
+    MutateKelemen on the device, against the oracle (same inputs, float-exact up to exp/log/sin/cos) and against the
+    reference's own functions (tests/golden/ref_bidir_<scene>.npz)"""
+    from test_golden_ref import check_bidir, run_bidir, load
+    core, b, orc = request.getfixturevalue(fix)
+    g = load("ref_bidir_%s.npz" % name)
+    got = run_bidir(_HipBidir(core), g)
+    check_bidir(got, g)
+    want = run_bidir(orc, g)
+    for a, w, tol in zip(got, want, (5e-6, 1e-6, 5e-6, 2e-7, 2e-7)):   # sinf/cosf of the device library vs glibc near a zero crossing
+        np.testing.assert_allclose(a, w, rtol=tol, atol=tol)
+    with pytest.raises(RuntimeError):
+        core.stage_light_sample_forward(np.array([int(b["globals"][238])], np.int32), np.zeros((1, 4), np.float32))   # light id out of range
+
+
 @pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
