@@ -51,7 +51,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
-    "hydra_hip_stage_mutate_kelemen",
+    "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f",
 ]
 
 _hip = None
@@ -124,6 +124,7 @@ def load_hip_library():
         "hydra_hip_stage_light_pdf_fwd": ([vp, i32, vp, vp, vp], i32),
         "hydra_hip_stage_camera_connect": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_mutate_kelemen": ([vp, i32, vp, vp, C.c_float, C.c_float, vp], i32),
+        "hydra_hip_stage_mmlt_f": ([vp, i32, vp, vp, i32, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -464,6 +465,13 @@ class HipCore:
         v, r = np.ascontiguousarray(values, np.float32), np.ascontiguousarray(rands2, np.float32)
         out = np.zeros(v.size, np.float32)
         self._ck(self.lib.hydra_hip_stage_mutate_kelemen(self.h, v.size, _ptr(v), _ptr(r), p2, p1, _ptr(out)), "stage_mutate_kelemen")
+        return out
+
+    def stage_mmlt_f(self, depth, xvec):
+        """IntegratorMMLT::F for the rows of xvec -> (n, 8): colour, x, y, split, MIS weight, contribFunc"""
+        d, x = np.ascontiguousarray(depth, np.int32), np.ascontiguousarray(xvec, np.float32)
+        out = np.zeros((d.size, 8), np.float32)
+        self._ck(self.lib.hydra_hip_stage_mmlt_f(self.h, d.size, _ptr(d), _ptr(x), x.shape[1], _ptr(out)), "stage_mmlt_f")
         return out
 
     def bench_trace(self, pos4, dir4, iters=20, shadow=False):

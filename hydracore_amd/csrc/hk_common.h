@@ -52,6 +52,11 @@ HK_DEV float as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 HK_DEV int   as_int(float f) { return __float_as_int(f); }
 HK_DEV float as_float(int i) { return __int_as_float(i); }
 #endif
+#ifdef HK_HOST_EMU
+HK_DEV void hk_atomic_add(float* p, float v) { *p += v; }   // the emulation runs one lane at a time
+#else
+HK_DEV void hk_atomic_add(float* p, float v) { atomicAdd(p, v); }
+#endif
 HK_DEV bool  finite3(f3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
 
 // reference: mul4x3 / mul3x3, hydra_drv/cglobals.h:288-304; mul4x4x4 :828-836

@@ -384,7 +384,7 @@ enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEA
 // ================================================================================================ materials
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
 struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
-struct ShadeContext { f3 l, v, n; f2 tc; };                                 // cglobals.h:2282-2301 (fields used without normal maps)
+struct ShadeContext { f3 l, v, n; f2 tc; f3 fn; };                          // cglobals.h:2282-2301 (fields used without normal maps; fn only by the light-tracing form of materialEval)
 
 HK_DEV const float* materialAt(const SceneDev& s, int matId) {   // cfetch.h:192-213
   return s.matBase + size_t(s.matTable[matId]) * 4;
@@ -640,7 +640,7 @@ HK_DEV f3 GgxVndf(f3 wo, float roughness, float u1, float u2) {   // :1220-1245 
   const f3 n = ((t1 * p1) + (t2 * p2)) + (v * sqrtf(fmaxf(0.0f, 1.0f - p1 * p1 - p2 * p2)));
   return normalize(mk3(roughness * n.x, roughness * n.y, fmaxf(0.0f, n.z)));
 }
-HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray_dir, f3 n, f2 tc, bool hitFromInside, const SceneDev& s, MatSample& out) {   // :775-882, a_isFwdDir = false
+HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray_dir, f3 n, f2 tc, bool hitFromInside, const SceneDev& s, MatSample& out, bool isFwdDir = false) {   // :775-882
   const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
   const f3 color = clamp3(matColor(m) * tex, 0.0f, 1.0f);
   const float gloss = transpGloss(m, HM_GLASS_GLOSINESS, HM_GLASS_GLOSS_TEXMATRIXID, tc, s);
@@ -679,7 +679,7 @@ HK_DEV void GlassGGXSampleAndEvalBRDF(const float* m, const float* rands, f3 ray
   const float cosOut = dot(refr.ray_dir, n);
   const float cosMult = 1.0f / fmaxf(fabsf(cosOut), 1e-6f);
   out.direction = refr.ray_dir;
-  const float adjointBtdfMult = refr.eta * refr.eta;   // camera paths: radiance flows against the walk (:867-869)
+  const float adjointBtdfMult = isFwdDir ? 1.0f : (refr.eta * refr.eta);   // camera paths: radiance flows against the walk (:867-869)
   if (refr.success) out.color = (((color * adjointBtdfMult) * Pss) * Pms) * cosMult;
   else out.color = ((mk3(1, 1, 1) * Pss) * Pms) * cosMult;
   out.flags = spec ? (HRE_S | HRE_T) : (HRE_G | HRE_T);
@@ -825,7 +825,7 @@ HK_DEV bool isEyeRay(uint32_t flags) {   // cglobals.h:1366-1376
 }
 // MaterialSampleAndEvalBxDF, cmaterial.h:2345-2371 (random walk :2180-2207, leaf dispatch :2245-2335)
 template <int F = HK_FEAT_ALL>
-HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit& sh, f3 rayDir, uint32_t rayFlags, const SceneDev& s, MatSample& out) {
+HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit& sh, f3 rayDir, uint32_t rayFlags, const SceneDev& s, MatSample& out, bool isFwdDir = false) {
   const bool reflOnly = (((rayFlags >> 16) & 64u /*RAY_GRAMMAR_DIRECT_LIGHT*/) != 0) && ((matFlags(m) & HMF_CAN_SAMPLE_REFL_ONLY) != 0);
   float mixW = 1.0f;
   const float* node = m;
@@ -842,16 +842,25 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_OREN_NAYAR: if (F & HK_FEAT_OREN_NAYAR) OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_GGX: if (F & HK_FEAT_GGX) GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
     case HMT_THIN_GLASS: if (F & HK_FEAT_GLASS) ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out); break;
+    case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
     default: break;
   }
   if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
   out.color = out.color * (1.0f / fmaxf(mixW, 0.015625f));
   if ((matFlags(node) & HMF_SKIP_SKY_PORTAL) && isEyeRay(rayFlags)) { out.color = mk3(1, 1, 1); out.pdf = 1.0f; }
 }
-// materialEval, cmaterial.h:2554-2628 (leaf: :2425-2551)
+// adjointBsdfShadeNormalFix, cmaterial.h:2398-2417 (Veach 5.3.2: shading normals make light tracing non-symmetric)
+HK_DEV float adjointBsdfShadeNormalFix(f3 toLightWo, f3 toCamWi, f3 shadeNorm, f3 geomNorm, float maxVal) {
+  if (dot(shadeNorm, geomNorm) < 0) geomNorm = geomNorm * (-1.0f);
+  if (1.0f - fabsf(dot(shadeNorm, geomNorm)) <= 1e-6f) return 1.0f;
+  else if (dot(toCamWi, geomNorm) * dot(toCamWi, shadeNorm) <= 0 || dot(toLightWo, geomNorm) * dot(toLightWo, shadeNorm) <= 0) return 1.0f;
+  const float k1 = dot(toLightWo, shadeNorm), k2 = dot(toCamWi, geomNorm), k3 = dot(toLightWo, geomNorm), k4 = dot(toCamWi, shadeNorm);
+  const float res = (k1 * k2) / fmaxf(k3 * k4, HK_DEPSILON2);
+  return fminf(fmaxf(res, 0.1f), maxVal);
+}
+// materialEval, cmaterial.h:2554-2628 (leaf: :2425-2551); fwdDir = EVAL_FLAG_FWD_DIR (light tracing: the adjoint fix of the leaf, needs sc.fn)
 template <int F = HK_FEAT_ALL>
-HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const SceneDev& s) {
+HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const SceneDev& s, bool fwdDir = false) {
   BxDFResult val;
   val.brdf = mk3(0, 0, 0); val.btdf = mk3(0, 0, 0); val.pdfFwd = 0.0f; val.pdfRev = 0.0f; val.diffuse = true;
   float stackW[7]; int stackO[7];
@@ -892,6 +901,7 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
         diffuse = true;
       }
+      if (fwdDir) brdf = brdf * adjointBsdfShadeNormalFix(sc.v, sc.l, sc.n, sc.fn, diffuse ? 20.0f : 2.0f);
       val.brdf = val.brdf + (brdf * currW);
       val.pdfFwd += currW * pf;
       val.pdfRev += currW * pr;

@@ -826,6 +826,29 @@ __global__ void k_stage_mutate_kelemen(int n, const float* __restrict__ values, 
   if (i >= n) return;
   out[i] = MutateKelemen(values[i], mk2(rands2[i].x, rands2[i].y), p2, p1);
 }
+// ---- IntegratorMMLT::F in wavefront form (hk_bidir.h): one thread per chain between the traversal launches
+__global__ void k_mmlt_begin(SceneDev s, MmltView v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v.n) mmltBegin(s, v, i);
+}
+__global__ void k_mmlt_step(SceneDev s, MmltView v, int currDepth) {   // first n threads: camera sub-paths, next n: light sub-paths
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < v.n) mmltCameraStep(s, v, j, currDepth);
+  else if (j < 2 * v.n) mmltLightStep(s, v, j - v.n, currDepth);
+}
+__global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v.n) mmltConnectBegin(s, v, i);
+}
+__global__ void k_mmlt_connect_end(SceneDev s, MmltView v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v.n) mmltConnectEnd(s, v, i);
+}
+__global__ void k_mmlt_transpose_in(int n, int stride, int floats, const float* __restrict__ rows, float* __restrict__ planes) {   // rows[i][j] -> planes[j][i]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = 0; j < floats; j++) planes[size_t(j) * n + i] = rows[size_t(i) * stride + j];
+}
 __global__ void k_stage_random(int n, const int* seeds, int draws, float4* out4, uint2* state2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -2374,6 +2397,71 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   STAGE_EPILOG();
   HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));
   HCHECK(hipMemcpy(rng_state2, gensOut, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
+// The device buffers of one evaluation of F for n chains (hk_bidir.h MmltView), owned by the caller.
+struct MmltBufs {
+  MmltView v;
+  HydraLiteHit* hits; HydraLiteHit* eyeHit; float* shVis;   // the writable twins of v.hits / v.eyeHit / v.shVis
+};
+static int mmlt_alloc(hydra_hip_ctx* c, TmpBufs& tb, int n, int maxD, MmltBufs& b) {
+  int rc = HYDRA_HIP_OK;
+  b.v.n = n; b.v.maxD = maxD;
+  b.v.st = (float*)tb.up(c, nullptr, size_t(mmltPlanes(maxD)) * n * 4, rc);
+  b.v.rayPos = (float4*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc); b.v.rayDir = (float4*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc);
+  b.hits = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc);
+  b.v.eyePos = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc); b.v.eyeDir = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  b.eyeHit = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  b.v.shPos = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc); b.v.shDir = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  b.shVis = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
+  b.v.hits = b.hits; b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis;
+  return rc;
+}
+// F for every chain of the view: v.x, v.depth and v.out8 are set by the caller; maxDepth = the largest d among the chains
+static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int maxDepth) {
+  const MmltView& v = b.v;
+  const int n = v.n;
+  int rc = ensure_fetch_counters(c);
+  if (rc) return rc;
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
+  hipLaunchKernelGGL(k_mmlt_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  for (int k = 1; k <= maxDepth; k++) {
+    HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+    launch_closest(c, s, seg_q(nullptr, 2 * n, 1, 2 * n), v.rayPos, v.rayDir, b.hits, nullptr, nullptr, fetch);
+    hipLaunchKernelGGL(k_mmlt_step, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, s, v, k);
+  }
+  hipLaunchKernelGGL(k_mmlt_connect_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+  launch_closest(c, s, seg_q(nullptr, n, 1, n), v.eyePos, v.eyeDir, b.eyeHit, nullptr, nullptr, fetch);
+  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+  launch_shadow(c, s, seg_q(nullptr, n, 1, n), v.shPos, v.shDir, b.shVis, nullptr, fetch);
+  hipLaunchKernelGGL(k_mmlt_connect_end, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  HCHECK(hipGetLastError());
+  return HYDRA_HIP_OK;
+}
+int hydra_hip_stage_mmlt_f(hydra_hip_handle c, int n, const int32_t* depth, const float* xvec, int stride, float* out8) {
+  STAGE_PROLOG(true);
+  if (!depth || !xvec || !out8) return fail(c, HYDRA_HIP_EINVAL, "stage_mmlt_f: null argument");
+  int maxD = 0;
+  for (int i = 0; i < n; i++) {
+    if (depth[i] < 1 || depth[i] > HK_MMLT_MAX_DEPTH || stride < HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * depth[i]) return fail(c, HYDRA_HIP_EINVAL, "stage_mmlt_f: depth must be 1..16 and stride >= 12 + 10 * depth");
+    maxD = depth[i] > maxD ? depth[i] : maxD;
+  }
+  MmltBufs b;
+  if ((rc = mmlt_alloc(c, tb, n, maxD, b))) return rc;
+  float* drows = (float*)tb.up(c, xvec, size_t(n) * stride * 4, rc);
+  float* dx = (float*)tb.up(c, nullptr, size_t(mmltStride(maxD)) * n * 4, rc);
+  int* dd = (int*)tb.up(c, depth, size_t(n) * 4, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 32, rc);
+  if (rc) return rc;
+  HCHECK(hipMemsetAsync(dx, 0, size_t(mmltStride(maxD)) * n * 4, c->stream));
+  const int floats = (stride < mmltStride(maxD)) ? stride : mmltStride(maxD);
+  hipLaunchKernelGGL(k_mmlt_transpose_in, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, stride, floats, drows, dx);
+  b.v.x = dx; b.v.depth = dd; b.v.out8 = dout;
+  if ((rc = mmlt_eval(c, make_scene(c), b, maxD))) return rc;
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out8, dout, size_t(n) * 32, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
 }
 

@@ -212,6 +212,12 @@ int hydra_hip_stage_light_pdf_fwd(hydra_hip_handle h, int n, const int32_t* ligh
 int hydra_hip_stage_camera_connect(hydra_hip_handle h, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
 /* MutateKelemen (crandom.h:189-210): primary-space values + 2 randoms each, step parameters p2 < p1 (defaults 64, 1024) */
 int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* values, const float* rands2, float p2, float p1, float* out);
+/* IntegratorMMLT::F (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315; sub-paths :637-929, connections :931-1047 + cbidir.h:190-477): the
+ * contribution of n primary-sample vectors.  xvec = n rows of `stride` floats laid out as the reference's PSSampleV (cglobals.h:102-128:
+ * lens 0..3, light 4..10, split 11, then 10 floats per bounce, light part first), depth[i] = d (path length in segments, 1..16),
+ * stride >= 12 + 10 * d.  out8 per vector = colour xyz (MIS-weighted), pixel x, y, split s, MIS weight, contribFunc(colour).
+ * Runs the traversal kernels of the path tracer between per-chain stage kernels (2n rays per level, n + n connection rays). */
+int hydra_hip_stage_mmlt_f(hydra_hip_handle h, int n, const int32_t* depth, const float* xvec, int stride, float* out8);
 /* R1  RandomGenInit + rndFloat4_Pseudo (crandom.h:20-63): for each seed the first `draws` float4 outputs */
 int hydra_hip_stage_random(hydra_hip_handle h, int n, const int32_t* seeds, int draws, float* out4, uint32_t* state2);
 

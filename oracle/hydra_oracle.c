@@ -1218,7 +1218,7 @@ static BRDFSelector materialRandomWalkBRDF(const float* m, const float* rands, f
   return res;
 }
 /* ref: cmaterial.h:2245-2335 MaterialLeafSampleAndEvalBRDF (no normal maps in the subset) */
-static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, f3 ray_dir, const float* rands, const OrcScene* s, MatSample* out) {
+static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, f3 ray_dir, const float* rands, int a_isFwdDir, const OrcScene* s, MatSample* out) {
   const f3 n = sh->normal;
   out->color = v3(0, 0, 0); out->direction = v3(0, 1, 0); out->pdf = 1.0f; out->flags = 0;
   switch (matType(m)) {
@@ -1228,7 +1228,7 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_GGX: GGXSample2AndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
-    case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, /*a_isFwdDir*/ 0, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false */
+    case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */
     default: break;
   }
   if (out->pdf <= 0.0f) out->color = v3(0, 0, 0);
@@ -1240,18 +1240,30 @@ static inline int isEyeRay(uint32_t flags) {
   return (((flags & 0x0000FF00u) >> 8) == 0) || !nonSpec;
 }
 /* ref: cmaterial.h:2345-2371 MaterialSampleAndEvalBxDF */
-static void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit* sh, f3 rayDir, uint32_t rayFlags, const OrcScene* s, MatSample* out) {
+static void MaterialSampleAndEvalBxDFEx(const float* m, const float* rands, const SurfaceHit* sh, f3 rayDir, uint32_t rayFlags, int a_isFwdDir, const OrcScene* s, MatSample* out) {
   const uint32_t other = (rayFlags & 0xFFFF0000u) >> 16;
   const int canReflOnly = (matFlags(m) & MF_CAN_SAMPLE_REFL_ONLY) != 0;
   const int reflOnly = ((other & RAY_GRAMMAR_DIRECT_LIGHT) != 0) && canReflOnly;
   const BRDFSelector mix = materialRandomWalkBRDF(m, rands, rayDir, sh->normal, sh->texCoord, s, reflOnly);
   const float* leaf = m + (size_t)mix.localOffs * MAT_FLOATS;
-  MaterialLeafSampleAndEvalBRDF(leaf, sh, rayDir, rands, s, out);
+  MaterialLeafSampleAndEvalBRDF(leaf, sh, rayDir, rands, a_isFwdDir, s, out);
   out->color = scale3(out->color, 1.0f / fmaxf(mix.w, 0.015625f));
   if ((matFlags(leaf) & MF_SKIP_SKY_PORTAL) && isEyeRay(rayFlags)) { out->color = v3(1, 1, 1); out->pdf = 1.0f; }
 }
+static void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const SurfaceHit* sh, f3 rayDir, uint32_t rayFlags, const OrcScene* s, MatSample* out) {
+  MaterialSampleAndEvalBxDFEx(m, rands, sh, rayDir, rayFlags, 0, s, out);
+}
 /* ref: cmaterial.h:2425-2551 materialLeafEval (EVAL_FLAG_DEFAULT: no forward-direction fix, no normal map) */
-static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const OrcScene* s) {
+/* ref: cmaterial.h:2398-2417 adjointBsdfShadeNormalFix */
+static float adjointBsdfShadeNormalFix(f3 toLightWo, f3 toCamWi, f3 shadeNorm, f3 geomNorm, float maxVal) {
+  if (dot3(shadeNorm, geomNorm) < 0) geomNorm = scale3(geomNorm, -1.0f);
+  if (1.0f - fabsf(dot3(shadeNorm, geomNorm)) <= 1e-6f) return 1.0f;
+  else if (dot3(toCamWi, geomNorm) * dot3(toCamWi, shadeNorm) <= 0 || dot3(toLightWo, geomNorm) * dot3(toLightWo, shadeNorm) <= 0) return 1.0f;
+  const float k1 = dot3(toLightWo, shadeNorm), k2 = dot3(toCamWi, geomNorm), k3 = dot3(toLightWo, geomNorm), k4 = dot3(toCamWi, shadeNorm);
+  const float res = (k1 * k2) / fmaxf(k3 * k4, DEPSILON2);
+  return fminf(fmaxf(res, 0.1f), maxVal);
+}
+static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, int a_fwdDir, const OrcScene* s) {
   BxDFResult r;
   r.brdf = v3(0, 0, 0); r.btdf = v3(0, 0, 0); r.pdfFwd = 0.0f; r.pdfRev = 0.0f; r.diffuse = 0;
   const float cosMult = 1.0f;
@@ -1282,10 +1294,11 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, const
       break;
     default: break;
   }
+  if (a_fwdDir) r.brdf = scale3(r.brdf, adjointBsdfShadeNormalFix(sc->v, sc->l, sc->n, sc->fn, r.diffuse ? 20.0f : 2.0f));   /* cmaterial.h:2540-2548 */
   return r;
 }
 /* ref: cmaterial.h:2554-2628 materialEval: explicit-stack walk over the blend tree */
-static BxDFResult materialEval(const float* a_m, const ShadeContext* sc, const OrcScene* s) {
+static BxDFResult materialEvalEx(const float* a_m, const ShadeContext* sc, int a_fwdDir, const OrcScene* s) {
   BxDFResult val;
   val.brdf = v3(0, 0, 0); val.btdf = v3(0, 0, 0); val.pdfFwd = 0.0f; val.pdfRev = 0.0f; val.diffuse = 1;
   float stackW[MIX_TREE_MAX_DEEP]; int stackO[MIX_TREE_MAX_DEEP];
@@ -1303,7 +1316,7 @@ static BxDFResult materialEval(const float* a_m, const ShadeContext* sc, const O
       if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w1; stackO[top] = currOffset + o1; top++; }
       if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w2; stackO[top] = currOffset + o2; top++; }
     } else {
-      const BxDFResult b = materialLeafEval(m, sc, s);
+      const BxDFResult b = materialLeafEval(m, sc, a_fwdDir, s);
       val.brdf = add3(val.brdf, scale3(b.brdf, currW));
       val.btdf = add3(val.btdf, scale3(b.btdf, currW));
       val.pdfFwd += currW * b.pdfFwd;
@@ -1313,6 +1326,7 @@ static BxDFResult materialEval(const float* a_m, const ShadeContext* sc, const O
   } while (top > 0);
   return val;
 }
+static BxDFResult materialEval(const float* a_m, const ShadeContext* sc, const OrcScene* s) { return materialEvalEx(a_m, sc, 0, s); }   /* EVAL_FLAG_DEFAULT */
 /* ref: cmaterial.h:2918-2978 materialEvalEmission; leaf: :20-26 */
 static f3 materialEvalEmission(const float* a_m, f3 v, f3 n, f2 tc, const OrcScene* s) {
   f3 val = v3(0, 0, 0);
@@ -1983,6 +1997,392 @@ void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* di
     const f3 c = PathTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), rng2 + 2 * (size_t)i, &st, NULL);
     color4[4 * i] = c.x; color4[4 * i + 1] = c.y; color4[4 * i + 2] = c.z; color4[4 * i + 3] = (float)st.rays;
   }
+}
+
+/* ------------------------------------------------------------------------------------------------ f3: IntegratorMMLT::F */
+/* The contribution function of multiplexed MLT over the simplified bidirectional sampler, restated from
+ * CPUExp_Integrators_MMLT.cpp:146-315 (F), :637-754 (LightPath, TraceLightPath), :756-929 (CameraPath), :931-1047 (ConnectEye,
+ * ConnectShadow, ConnectEndPoints) and cbidir.h:190-477 (ConnectEyeP, ConnectShadowP, ConnectEndPointsP).  Every random number
+ * comes from the primary-sample vector (gen.rptr != 0 in crandom.h:340-520), so F is a pure function of (xVec, d).  The two
+ * recursions are unrolled into loops; CameraPath's colour is multiplied on the way back up exactly as the recursion does.
+ * Not restated: m_mask, the debug ray recorder, and the reuse of the previous sub-path for a one-sided mutation (:160-161, :178,
+ * :209: both vertices are recomputed whenever they are used, so the result does not depend on it). */
+enum { MMLT_HEAD_TOTAL_SIZE = 12, MMLT_FLOATS_PER_BOUNCE = 10, MMLT_DIM_LGT_X = 4, MMLT_DIM_LGT_N = 10, MMLT_DIM_SPLIT = 11, MMLT_MAX_DEPTH = 16,
+       G_LSEL_FWD_OFFS = 232, G_LSEL_FWD_SIZE = 233, HRT_MMLT_FIRST_BOUNCE = 34, MF_HAVE_BTDF = 8192 };   /* cglobals.h:2644 */
+typedef struct { float pdfFwd, pdfRev; } PdfVertex;
+typedef struct { SurfaceHit hit; f3 ray_dir, accColor; float lastGTerm; int valid, wasSpecOnly; } PathVertex;
+typedef struct { float matSamplePdf, cosThetaPrev; int isSpecular; } MisDataB;
+static inline f3 div3s(f3 a, float b) { return v3(a.x / b, a.y / b, a.z / b); }   /* vector / scalar as the OpenCL branch (the pinned build) computes it */
+static inline int mapRndFloatToInt(float a_val, int a, int b) {   /* crandom.h:507-518 */
+  const float fa = (float)(a + 0), fb = (float)(b + 1);
+  const int res = (int)(fa + a_val * (fb - fa));
+  return (res > b) ? b : res;
+}
+static inline int isPureSpecularSam(const MatSample* ms) { return (ms->flags & RAY_EVENT_S) != 0 || (ms->flags & RAY_EVENT_T) != 0; }   /* cglobals.h:1342 */
+static inline int flagsHaveOnlySpecular(uint32_t flags) {   /* cmaterial.h:3295-3301 */
+  const uint32_t other = (flags & 0xFFFF0000u) >> 16;
+  return ((other & RAY_EVENT_G) == 0) && ((other & RAY_EVENT_D) == 0);
+}
+/* ref: cfetch.h:933-968 MakeEyeRayFromF4Rnd */
+static void MakeEyeRayFromF4Rnd(const float lensOffs[4], const OrcScene* s, f3* pRayPos, f3* pRayDir, float* pX, float* pY) {
+  const float fwidth = g_varsF(s)[HRT_WIDTH_F], fheight = g_varsF(s)[HRT_HEIGHT_F];
+  const float x = fwidth * lensOffs[0], y = fheight * lensOffs[1];
+  const m44 projInv = load_m44((const float*)(s->globals + G_MPROJ_INV));
+  const m44 wvInv = load_m44((const float*)(s->globals + G_MWORLDVIEW_INV));
+  f3 ray_pos = v3(0.0f, 0.0f, 0.0f);
+  f3 ray_dir = EyeRayDirNormalized(x / fwidth, y / fheight, projInv);
+  ray_dir = tiltCorrection(ray_pos, ray_dir, s);
+  if (g_varsI(s)[HRT_ENABLE_DOF] == 1) {
+    const float tFocus = g_varsF(s)[HRT_DOF_FOCAL_PLANE_DIST] / (-ray_dir.z);
+    const f3 focusPosition = add3(ray_pos, scale3(ray_dir, tFocus));
+    f2 in = {lensOffs[2] - 0.5f, lensOffs[3] - 0.5f};
+    const f2 d = MapSamplesToDisc(in);
+    const float k = g_varsF(s)[HRT_DOF_LENS_RADIUS] * 2.0f;
+    ray_pos.x += k * d.x;
+    ray_pos.y += k * d.y;
+    ray_dir = normalize3(sub3(focusPosition, ray_pos));
+  }
+  {
+    const f3 pos = mul4x3(wvInv, ray_pos);
+    const f3 pos2 = mul4x3(wvInv, add3(ray_pos, scale3(ray_dir, 100.0f)));
+    *pRayPos = pos;
+    *pRayDir = normalize3(sub3(pos2, pos));
+  }
+  *pX = lensOffs[0] * fwidth;
+  *pY = lensOffs[1] * fheight;
+}
+/* ref: clight.h:1808-1822 SelectRandomLightFwd */
+static int SelectRandomLightFwd(float r, const OrcScene* s, float* pickProb) {
+  const int tableSize = s->globals[G_LSEL_FWD_SIZE];
+  *pickProb = 1.0f;
+  if (tableSize <= 2) return 0;
+  return SelectIndexPropToOpt(r, (const float*)(s->globals + s->globals[G_LSEL_FWD_OFFS]), tableSize, pickProb);
+}
+static void LightSampleForwardAny(const float* L, const float r[4], LightSampleFwd* sam) {
+  switch (as_int(L[PL_TYPE])) {
+    case LT_DIRECT: DirectLightSampleForward(L, r, sam); break;
+    case LT_POINT_SPOT: PointSpotSampleForward(L, r, sam); break;
+    case LT_POINT_OMNI: PointLightSampleForward(L, r, sam); break;
+    default: AreaLightSampleForward(L, r, sam); break;
+  }
+}
+static void lightPdfFwdOne(const float* L, float ct, float* pdfA, float* pdfW) {
+  float out4[4];
+  const int ltype = as_int(L[PL_TYPE]);
+  out4[0] = 1.0f / L[PL_SURFACE_AREA]; out4[1] = fmaxf(ct * INV_PI, 0.0f);
+  if (ltype == LT_POINT_OMNI) out4[1] = INV_PI * 0.25f;
+  else if (ltype == LT_POINT_SPOT) { const float cos2 = L[POINT_LIGHT_SPOT_COS2]; out4[1] = 1.0f / (2.0f * ORC_PI * (1.0f - cos2)); if (ct < cos2) out4[1] = 0.0f; }
+  else if (ltype == LT_DIRECT) { const float r2 = L[DIRECT_LIGHT_RADIUS2]; out4[0] = 1.0f / (ORC_PI * r2 * r2); out4[1] = 0.0f; }
+  if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) { const float cos2 = L[AL_SPOT_COS2]; out4[1] = 1.0f / (2.0f * ORC_PI * (1.0f - cos2)); if (ct < cos2) out4[1] = 0.0f; }
+  *pdfA = out4[0]; *pdfW = out4[1];
+}
+static ShadeContext makeShadeContext(const SurfaceHit* h, f3 l, f3 v) {
+  ShadeContext sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.l = l; sc.v = v; sc.n = h->normal; sc.fn = h->flatNormal; sc.tg = h->tangent; sc.bn = h->biTangent; sc.tc = h->texCoord;
+  return sc;
+}
+static void InitPathVertex(PathVertex* v) { memset(v, 0, sizeof(*v)); v->lastGTerm = 1.0f; v->accColor = v3(1, 1, 1); }
+/* camera connection factor for one point (orc_camera_connect above holds the same arithmetic for arrays) */
+static float cameraImageToSurfaceFactor1(const OrcScene* s, f3 hitPos, f3 hitNorm, f3* camDir, float* zDepth, float* scrX, float* scrY) {
+  float p4[4] = {hitPos.x, hitPos.y, hitPos.z, 0}, n4[4] = {hitNorm.x, hitNorm.y, hitNorm.z, 0}, d2[2] = {0, 0}, o[8];
+  orc_camera_connect(s, 1, p4, n4, d2, o);
+  *camDir = v3(o[1], o[2], o[3]); *zDepth = o[4]; *scrX = o[5]; *scrY = o[6];
+  return o[0];
+}
+/* out8 = colour xyz (MIS-weighted), x, y, split s, MIS weight, contribFunc(colour) */
+static void mmltF(const OrcScene* s, const float* xVec, int d, float* out8) {
+  PdfVertex pdfArray[MMLT_MAX_DEPTH + 2];
+  memset(pdfArray, 0, sizeof(pdfArray));
+  const int width = (int)g_varsF(s)[HRT_WIDTH_F], height = (int)g_varsF(s)[HRT_HEIGHT_F];
+  const float mLightSubPathCount = (float)(width * height);
+  const int splitDLByGrammar = g_varsI(s)[HRT_MMLT_FIRST_BOUNCE] > 3;   /* Common.cpp:28 */
+  const int sp = mapRndFloatToInt(xVec[MMLT_DIM_SPLIT], 0, d), t = d - sp;
+  const int lightTraceDepth = sp - 1, camTraceDepth = t;
+  const float* lensOffs = xVec;
+  int x = (int)(lensOffs[0] * (float)width + 0.5f), y = (int)(lensOffs[1] * (float)height + 0.5f);
+
+  /* (1) camera sub-path, CameraPath :756-929 */
+  PathVertex cv;
+  InitPathVertex(&cv);
+  if (camTraceDepth > 0) {
+    const float* rptr = xVec + MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * sp;
+    float fx, fy;
+    f3 ray_pos, ray_dir;
+    MakeEyeRayFromF4Rnd(lensOffs, s, &ray_pos, &ray_dir, &fx, &fy);
+    x = (int)(fx + 0.5f); y = (int)(fy + 0.5f);
+    if (x >= width) x = width - 1;
+    if (y >= height) y = height - 1;
+    const int haveToHitLight = (lightTraceDepth == -1);
+    MisDataB misPrev = {1.0f, 1.0f, 1};
+    uint32_t flags = 0;
+    f3 factors[MMLT_MAX_DEPTH + 2];
+    int nFactors = 0, zeroFrom = -1;
+    cv.valid = 0; cv.accColor = v3(0, 0, 0);
+    for (int currDepth = 1; currDepth <= camTraceDepth; currDepth++) {
+      const int prevVertexId = d - currDepth + 1;
+      const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
+      if (!HitSome(hit)) break;
+      const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
+      const float cosHere = fabsf(dot3(ray_dir, surf.normal)), cosPrev = fabsf(misPrev.cosThetaPrev);
+      float GTerm = 1.0f;
+      if (currDepth == 1) {
+        f3 cd; float zd, sx, sy;
+        const float imageToSurfaceFactor = cameraImageToSurfaceFactor1(s, surf.pos, surf.normal, &cd, &zd, &sx, &sy);
+        pdfArray[d].pdfRev = imageToSurfaceFactor / mLightSubPathCount;
+        pdfArray[d].pdfFwd = 1.0f;
+      } else {
+        const float dist = length3(sub3(ray_pos, surf.pos));
+        GTerm = cosHere * cosPrev / fmaxf(dist * dist, DEPSILON2);
+      }
+      const float* mat = materialAt(s, surf.matId);
+      const float* pLight = lightAt(s, s->instLightInstId[hit.instId]);
+      const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, pLight, mat);
+      if (dot3(emission, emission) > 1e-6f) {
+        if (currDepth == camTraceDepth && haveToHitLight) {
+          float pdfA, pdfW;
+          lightPdfFwdOne(pLight, cosHere, &pdfA, &pdfW);
+          const float pdfLightWP = pdfW / fmaxf(cosHere, DEPSILON);
+          const float pdfMatRevWP = misPrev.matSamplePdf / fmaxf(cosPrev, DEPSILON);
+          pdfArray[0].pdfFwd = pdfA / (float)s->globals[G_LIGHTS_NUM];
+          pdfArray[0].pdfRev = 1.0f;
+          pdfArray[1].pdfFwd = pdfLightWP * GTerm;
+          pdfArray[1].pdfRev = misPrev.isSpecular ? -1.0f * GTerm : pdfMatRevWP * GTerm;
+          cv.hit = surf; cv.ray_dir = ray_dir; cv.accColor = emission; cv.valid = 1;
+        }
+        break;
+      } else if (currDepth == camTraceDepth && !haveToHitLight) {
+        cv.hit = surf; cv.ray_dir = ray_dir; cv.valid = 1; cv.accColor = v3(1, 1, 1);
+        cv.wasSpecOnly = splitDLByGrammar ? flagsHaveOnlySpecular(flags) : 0;
+        if (camTraceDepth != 1) {
+          const float lastPdfWP = misPrev.matSamplePdf / fmaxf(cosPrev, DEPSILON);
+          cv.lastGTerm = GTerm;
+          pdfArray[prevVertexId].pdfRev = misPrev.isSpecular ? -1.0f * GTerm : GTerm * lastPdfWP;
+        } else cv.lastGTerm = 1.0f;
+        break;
+      }
+      /* (3) sample the next direction; random numbers of this bounce: rptr + rndMatOffsetMMLT(currDepth - 1) */
+      MatSample matSam;
+      MaterialSampleAndEvalBxDFEx(mat, rptr + MMLT_FLOATS_PER_BOUNCE * (currDepth - 1), &surf, ray_dir, (uint32_t)(currDepth - 1) << 8, 0, s, &matSam);
+      const float cosNext = fabsf(dot3(matSam.direction, surf.normal));
+      if (currDepth == 1) {
+        if (isPureSpecularSam(&matSam)) pdfArray[d].pdfFwd = 0.0f;
+      } else {
+        if (!isPureSpecularSam(&matSam)) {
+          const ShadeContext sc = makeShadeContext(&surf, scale3(ray_dir, -1.0f), matSam.direction);
+          const float pdfFwdW = materialEval(mat, &sc, s).pdfFwd;
+          pdfArray[prevVertexId].pdfFwd = (pdfFwdW / fmaxf(cosHere, DEPSILON)) * GTerm;
+        } else pdfArray[prevVertexId].pdfFwd = -1.0f * GTerm;
+        const float pdfCamPrevWP = misPrev.matSamplePdf / fmaxf(cosPrev, DEPSILON);
+        pdfArray[prevVertexId].pdfRev = misPrev.isSpecular ? -1.0f * GTerm : pdfCamPrevWP * GTerm;
+      }
+      const int stopDL = splitDLByGrammar ? flagsHaveOnlySpecular(flags) : 0;
+      factors[nFactors] = div3s(scale3(matSam.color, cosNext), fmaxf(matSam.pdf, DEPSILON2));
+      if (stopDL && haveToHitLight && currDepth + 1 == camTraceDepth) zeroFrom = nFactors;
+      nFactors++;
+      ray_pos = OffsRayPos(surf.pos, surf.normal, matSam.direction);
+      ray_dir = matSam.direction;
+      misPrev.isSpecular = isPureSpecularSam(&matSam);
+      misPrev.matSamplePdf = matSam.pdf;
+      misPrev.cosThetaPrev = dot3(ray_dir, surf.normal);
+      flags = flagsNextBounceLite(flags, &matSam, s);
+    }
+    /* the recursion multiplies on the way back: deepest factor first; an invalid vertex carries colour 0 through */
+    if (!cv.valid) cv.accColor = v3(0, 0, 0);
+    for (int k = nFactors - 1; k >= 0; k--) {
+      cv.accColor = mul3(cv.accColor, factors[k]);
+      if (k == zeroFrom) cv.accColor = v3(0, 0, 0);
+    }
+  }
+
+  /* (2) light sub-path, LightPath :637-669 + TraceLightPath :671-754 */
+  PathVertex lv;
+  InitPathVertex(&lv);
+  if (lightTraceDepth > 0) {
+    float lightPickProb = 1.0f;
+    const int lightId = SelectRandomLightFwd(xVec[MMLT_DIM_LGT_N], s, &lightPickProb);
+    const float* pLight = lightAt(s, lightId);
+    LightSampleFwd sample;
+    LightSampleForwardAny(pLight, xVec + MMLT_DIM_LGT_X, &sample);
+    pdfArray[0].pdfFwd = sample.pdfA * lightPickProb;
+    pdfArray[0].pdfRev = 1.0f;
+    f3 color = div3s(scale3(sample.color, 1.0f / lightPickProb), sample.pdfA * sample.pdfW);
+    const float* rptr = xVec + MMLT_HEAD_TOTAL_SIZE;
+    f3 ray_pos = sample.pos, ray_dir = sample.dir;
+    float prevLightCos = sample.cosTheta, prevPdf = sample.pdfW;
+    int wasSpecular = 0;
+    for (int currDepth = 1; currDepth <= lightTraceDepth; currDepth++) {
+      const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
+      if (!HitSome(hit)) break;
+      const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
+      const float cosCurr = fabsf(-dot3(ray_dir, surf.normal));
+      const float dist = length3(sub3(surf.pos, ray_pos));
+      const float GTermPrev = (prevLightCos * cosCurr / fmaxf(dist * dist, DEPSILON2));
+      const float prevPdfWP = prevPdf / fmaxf(prevLightCos, DEPSILON);
+      pdfArray[currDepth].pdfFwd = !wasSpecular ? prevPdfWP * GTermPrev : -1.0f * GTermPrev;
+      const float* mat = materialAt(s, surf.matId);
+      MatSample matSam;
+      MaterialSampleAndEvalBxDFEx(mat, rptr + MMLT_FLOATS_PER_BOUNCE * (currDepth - 1), &surf, ray_dir, (uint32_t)(currDepth - 1) << 8, 1, s, &matSam);
+      const f3 nextRay_dir = matSam.direction;
+      const f3 nextRay_pos = OffsRayPos(surf.pos, surf.normal, matSam.direction);
+      const float cosNext = fabsf(+dot3(nextRay_dir, surf.normal));
+      if (currDepth == lightTraceDepth) {
+        lv.hit = surf; lv.ray_dir = ray_dir; lv.accColor = color; lv.valid = 1; lv.lastGTerm = GTermPrev;
+        break;
+      }
+      if (!isPureSpecularSam(&matSam)) {
+        const ShadeContext sc = makeShadeContext(&surf, scale3(ray_dir, -1.0f), scale3(nextRay_dir, -1.0f));
+        const float pdfW = materialEval(mat, &sc, s).pdfFwd;
+        pdfArray[currDepth].pdfRev = (pdfW / fmaxf(cosCurr, DEPSILON)) * GTermPrev;
+      } else pdfArray[currDepth].pdfRev = -1.0f * GTermPrev;
+      color = mul3(color, scale3(scale3(matSam.color, cosNext), (1.0f / fmaxf(matSam.pdf, DEPSILON2))));
+      ray_pos = nextRay_pos; ray_dir = nextRay_dir;
+      prevLightCos = cosNext; prevPdf = matSam.pdf; wasSpecular = isPureSpecularSam(&matSam);
+    }
+  }
+
+  /* (3) connect */
+  f3 sampleColor = v3(0, 0, 0);
+  if (lightTraceDepth == -1) sampleColor = cv.accColor;
+  else if (camTraceDepth == 0) {   /* ConnectEye :931-958 + ConnectEyeP cbidir.h:190-253 */
+    if (lv.valid) {
+      f3 camDir; float zDepth, scrX, scrY;
+      const float imageToSurfaceFactor = cameraImageToSurfaceFactor1(s, lv.hit.pos, lv.hit.normal, &camDir, &zDepth, &scrX, &scrY);
+      const float* mat = materialAt(s, lv.hit.matId);
+      float signOfNormal = 1.0f;
+      if ((matFlags(mat) & MF_HAVE_BTDF) != 0 && dot3(camDir, lv.hit.normal) < -0.01f) signOfNormal = -1.0f;
+      const OrcHit hit = rayTrace(s, add3(lv.hit.pos, scale3(lv.hit.normal, epsilonOfPos(lv.hit.pos) * signOfNormal)), camDir, NULL);
+      if (imageToSurfaceFactor <= 0.0f || (HitSome(hit) && hit.t <= zDepth)) { x = -1; y = -1; }
+      else {
+        const float surfaceToImageFactor = 1.f / imageToSurfaceFactor;
+        const ShadeContext sc = makeShadeContext(&lv.hit, camDir, scale3(lv.ray_dir, -1.0f));
+        const BxDFResult colorAndPdf = materialEvalEx(mat, &sc, 1, s);
+        const f3 colorConnect = add3(colorAndPdf.brdf, colorAndPdf.btdf);
+        const float pdfRevW = colorAndPdf.pdfRev;
+        const float cosCurr = fabsf(dot3(lv.ray_dir, lv.hit.normal));
+        const float pdfRevWP = pdfRevW / fmaxf(cosCurr, DEPSILON2);
+        const float cameraPdfA = imageToSurfaceFactor / mLightSubPathCount;
+        pdfArray[lightTraceDepth].pdfRev = (pdfRevW == 0.0f) ? -1.0f * lv.lastGTerm : pdfRevWP * lv.lastGTerm;
+        pdfArray[lightTraceDepth + 1].pdfFwd = 1.0f;
+        pdfArray[lightTraceDepth + 1].pdfRev = cameraPdfA;
+        const f3 sc3 = mul3(lv.accColor, div3s(colorConnect, mLightSubPathCount * surfaceToImageFactor));
+        if (dot3(sc3, sc3) > 1e-12f) { x = (int)scrX; y = (int)scrY; sampleColor = sc3; }
+      }
+    }
+  } else if (lightTraceDepth == 0) {   /* ConnectShadow :962-1009 + ConnectShadowP cbidir.h:285-345 */
+    if (cv.valid && !cv.wasSpecOnly) {
+      f3 explicitColor = v3(0, 0, 0);
+      float lightPickProb = 1.0f;
+      const int lightOffset = SelectRandomLightRev(xVec[MMLT_DIM_LGT_N], s, &lightPickProb);
+      if (lightOffset >= 0) {
+        const float* pLight = lightAt(s, lightOffset);
+        ShadowSample explicitSam;
+        LightSampleRev(s, pLight, v3(xVec[MMLT_DIM_LGT_X], xVec[MMLT_DIM_LGT_X + 1], xVec[MMLT_DIM_LGT_X + 2]), cv.hit.pos, &explicitSam);
+        const f3 shadowRayDir = normalize3(sub3(explicitSam.pos, cv.hit.pos));
+        const f3 shadowRayPos = OffsRayPos(cv.hit.pos, cv.hit.normal, shadowRayDir);
+        const float shadow = shadowTrace(s, shadowRayPos, shadowRayDir, explicitSam.maxDist * 0.9995f);
+        if (shadow * shadow * 3.0f > 1e-12f) {
+          const float* mat = materialAt(s, cv.hit.matId);
+          const ShadeContext sc = makeShadeContext(&cv.hit, shadowRayDir, scale3(cv.ray_dir, -1.0f));
+          const BxDFResult evalData = materialEval(mat, &sc, s);
+          const float pdfFwdAt1W = evalData.pdfRev;
+          const float cosThetaOut1 = fmaxf(+dot3(shadowRayDir, cv.hit.normal), DEPSILON), cosThetaOut2 = fmaxf(-dot3(shadowRayDir, cv.hit.normal), DEPSILON);
+          const int inverseCos = ((matFlags(mat) & MF_HAVE_BTDF) != 0 && dot3(shadowRayDir, cv.hit.normal) < -0.01f);
+          const float cosThetaOut = inverseCos ? cosThetaOut2 : cosThetaOut1;
+          const float cosAtLight = fmaxf(explicitSam.cosAtLight, DEPSILON);
+          const float cosThetaPrev = fmaxf(-dot3(cv.ray_dir, cv.hit.normal), DEPSILON);
+          const f3 brdfVal = add3(scale3(evalData.brdf, cosThetaOut1), scale3(evalData.btdf, cosThetaOut2));
+          const float pdfRevWP = evalData.pdfFwd / fmaxf(cosThetaOut, DEPSILON);
+          const float shadowDist = length3(sub3(cv.hit.pos, explicitSam.pos));
+          const float GTerm = cosThetaOut * cosAtLight / fmaxf(shadowDist * shadowDist, DEPSILON2);
+          float pdfA, pdfW;
+          lightPdfFwdOne(pLight, cosAtLight, &pdfA, &pdfW);
+          pdfArray[0].pdfFwd = pdfA * lightPickProb;
+          pdfArray[0].pdfRev = 1.0f;
+          pdfArray[1].pdfFwd = (pdfW / cosAtLight) * GTerm;
+          pdfArray[1].pdfRev = (evalData.pdfFwd == 0) ? -1.0f * GTerm : pdfRevWP * GTerm;
+          if (t > 1) pdfArray[2].pdfFwd = (pdfFwdAt1W == 0.0f) ? -1.0f * cv.lastGTerm : (pdfFwdAt1W / cosThetaPrev) * cv.lastGTerm;
+          float envMisMult = 1.0f;
+          if (as_int(pLight[PL_TYPE]) == LT_SKY_DOME) envMisMult = misWeightHeuristic(explicitSam.pdf * lightPickProb, evalData.pdfFwd);
+          const float explicitPdfW = fmaxf(explicitSam.pdf, DEPSILON2);
+          explicitColor = scale3(div3s(mul3(scale3(scale3(explicitSam.color, envMisMult), 1.0f / lightPickProb), brdfVal), explicitPdfW), shadow);
+        }
+      }
+      sampleColor = mul3(cv.accColor, explicitColor);
+    }
+  } else {   /* ConnectEndPoints :1011-1047 + ConnectEndPointsP cbidir.h:366-477 */
+    if (cv.valid) {
+      f3 explicitColor = v3(0, 0, 0);
+      if (lv.valid) {
+        const f3 diff = sub3(cv.hit.pos, lv.hit.pos);
+        const float dist2 = fmaxf(dot3(diff, diff), DEPSILON2);
+        const float dist = sqrtf(dist2);
+        const f3 lToC = div3s(diff, dist);
+        const float GTerm0 = (+dot3(lv.hit.normal, lToC)) * (-dot3(cv.hit.normal, lToC)) / dist2;
+        if (!(GTerm0 < 0.0f)) {
+          const f3 shadowRayPos = OffsRayPos(lv.hit.pos, lv.hit.normal, lToC);
+          const float shadow = shadowTrace(s, shadowRayPos, lToC, dist * 0.9995f);
+          if (!(shadow * shadow * 3.0f < 1e-12f)) {
+            PdfVertex* vSplitBefore = &pdfArray[sp - 1]; PdfVertex* vSplit = &pdfArray[sp]; PdfVertex* vSplitAfter = &pdfArray[sp + 1];
+            const float* matL = materialAt(s, lv.hit.matId);
+            const ShadeContext scL = makeShadeContext(&lv.hit, lToC, scale3(lv.ray_dir, -1.0f));
+            const BxDFResult evL = materialEvalEx(matL, &scL, 1, s);
+            const f3 lightBRDF = add3(evL.brdf, evL.btdf);
+            const float lightVPdfFwdW = evL.pdfFwd, lightVPdfRevW = evL.pdfRev;
+            float signOfNormalL = 1.0f, signOfNormalC = 1.0f;
+            if ((matFlags(matL) & MF_HAVE_BTDF) != 0 && dot3(lToC, lv.hit.normal) < -0.01f) signOfNormalL = -1.0f;
+            const float* matC = materialAt(s, cv.hit.matId);
+            const ShadeContext scC = makeShadeContext(&cv.hit, scale3(lToC, -1.0f), scale3(cv.ray_dir, -1.0f));
+            const BxDFResult evC = materialEval(matC, &scC, s);
+            const f3 camBRDF = add3(evC.brdf, evC.btdf);
+            const float camVPdfRevW = evC.pdfFwd, camVPdfFwdW = evC.pdfRev;
+            if ((matFlags(matC) & MF_HAVE_BTDF) != 0 && dot3(scale3(lToC, -1.0f), cv.hit.normal) < -0.01f) signOfNormalC = -1.0f;
+            const float cosAtLightVertex = +signOfNormalL * dot3(lv.hit.normal, lToC), cosAtCameraVertex = -signOfNormalC * dot3(cv.hit.normal, lToC);
+            const float cosAtLightVertexPrev = -dot3(lv.hit.normal, lv.ray_dir), cosAtCameraVertexPrev = -dot3(cv.hit.normal, cv.ray_dir);
+            const float GTerm = cosAtLightVertex * cosAtCameraVertex / dist2;
+            if (!(GTerm < 0.0f)) {
+              const float lightPdfFwdWP = lightVPdfFwdW / fmaxf(cosAtLightVertex, DEPSILON2);
+              const float cameraPdfRevWP = camVPdfRevW / fmaxf(cosAtCameraVertex, DEPSILON2);
+              vSplit->pdfFwd = (lightPdfFwdWP == 0.0f) ? -1.0f * GTerm : lightPdfFwdWP * GTerm;
+              vSplit->pdfRev = (cameraPdfRevWP == 0.0f) ? -1.0f * GTerm : cameraPdfRevWP * GTerm;
+              vSplitBefore->pdfRev = (lightVPdfRevW == 0.0f) ? -1.0f * lv.lastGTerm : lv.lastGTerm * (lightVPdfRevW / fmaxf(cosAtLightVertexPrev, DEPSILON));
+              if (d > 3) vSplitAfter->pdfFwd = (camVPdfFwdW == 0.0f) ? -1.0f * cv.lastGTerm : cv.lastGTerm * (camVPdfFwdW / fmaxf(cosAtCameraVertexPrev, DEPSILON));
+              const int fwdCanNotBeEvaluated = (lightPdfFwdWP < DEPSILON2) || (d > 3 && camVPdfFwdW < DEPSILON2);
+              const int revCanNotBeEvaluated = (cameraPdfRevWP < DEPSILON2) || (lightVPdfRevW < DEPSILON2);
+              if (!(fwdCanNotBeEvaluated && revCanNotBeEvaluated)) explicitColor = scale3(scale3(mul3(lightBRDF, camBRDF), GTerm), shadow);
+            }
+          }
+        }
+      }
+      sampleColor = mul3(mul3(cv.accColor, explicitColor), lv.accColor);
+    }
+  }
+
+  /* (4) MIS weight :252-285 */
+  float misWeight = 1.0f;
+  if (dot3(sampleColor, sampleColor) > 1e-12f) {
+    float pdfThisWay = 1.0f, pdfSumm = 0.0f;
+    for (int split = 0; split <= d; split++) {
+      const int s1 = split, t1 = d - split;
+      const int specularMet = (split > 0) && (split < d) && (pdfArray[split].pdfRev < 0.0f || pdfArray[split].pdfFwd < 0.0f);
+      float pdfOtherWay = specularMet ? 0.0f : 1.0f;
+      if (split == d) pdfOtherWay = misHeuristicPower1(pdfArray[d].pdfFwd);
+      for (int i = 0; i < s1; i++) pdfOtherWay *= misHeuristicPower1(pdfArray[i].pdfFwd);
+      for (int i = s1 + 1; i <= d; i++) pdfOtherWay *= misHeuristicPower1(pdfArray[i].pdfRev);
+      if (s1 == sp && t1 == t) pdfThisWay = pdfOtherWay;
+      pdfSumm += pdfOtherWay;
+    }
+    misWeight = pdfThisWay / fmaxf(pdfSumm, DEPSILON2);
+  }
+  sampleColor = scale3(sampleColor, misWeight);
+  if (!(x >= 0 && x < width && y >= 0 && y < height)) { x = 0; y = 0; sampleColor = v3(0, 0, 0); }
+  out8[0] = sampleColor.x; out8[1] = sampleColor.y; out8[2] = sampleColor.z; out8[3] = (float)x; out8[4] = (float)y; out8[5] = (float)sp;
+  out8[6] = misWeight; out8[7] = fmaxf(0.33334f * (sampleColor.x + sampleColor.y + sampleColor.z), 0.0f);   /* contribFunc, cglobals.h:1929-1932 */
+}
+/* xvec: n rows of `stride` floats (stride >= 12 + 10 * depth[i]), depth[i] in 1..MMLT_MAX_DEPTH */
+void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xvec, int stride, float* out8) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n; i++) mmltF(s, xvec + (size_t)i * stride, depth[i], out8 + 8 * (size_t)i);
 }
 
 /* ------------------------------------------------------------------------------------------------ P0: passes */

@@ -83,6 +83,8 @@ void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds,
 void orc_light_pdf_fwd(const OrcScene* s, int n, const int32_t* lightIds, const float* cosTheta, float* out4);
 void orc_camera_connect(const OrcScene* s, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
 void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p2, float p1, float* out);
+/* IntegratorMMLT::F (CPUExp_Integrators_MMLT.cpp:146-315): n primary-sample vectors of `stride` floats, path length depth[i] -> out8 = colour, x, y, split, MIS weight, contribFunc */
+void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xvec, int stride, float* out8);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -418,3 +418,353 @@ __kernel void ref_mutate_kelemen(__global const float* values, __global const fl
   if (i >= n) return;
   out[i] = MutateKelemen(values[i], rands2[i], p2, p1);
 }
+
+/* IntegratorMMLT::F, CPUExp_Integrators_MMLT.cpp:146-315: the control flow of F, LightPath/TraceLightPath (:637-754), CameraPath (:756-929),
+ * ConnectEye / ConnectShadow / ConnectEndPoints (:931-1047) around the reference's own inline functions (rndSplitMMLT, rndLens, RndLightMMLT,
+ * RndMatAll, MakeEyeRayFromF4Rnd, LightSampleForward, lightPdfFwd, MaterialSampleAndEvalBxDF, materialEval, emissionEval,
+ * CameraImageToSurfaceFactor, ConnectEyeP, ConnectShadowP, ConnectEndPointsP).  OpenCL has no recursion: the two recursions are loops and
+ * CameraPath's return-trip products are applied afterwards, deepest level first.  out8 = colour, x, y, split, MIS weight, contribFunc. */
+#define REF_MMLT_MAX_DEPTH 16
+__kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, int stride,
+                         __global const float4* bvh, __global const float4* tris, int haveInst,
+                         __global const float4* in_matrices, __global const int* instLightInstId,
+                         __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
+                         __global const int4* in_texStorage, __global const float4* in_pdfStorage,
+                         __global const EngineGlobals* a_globals, __global float* out8, int n,
+                         __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1)
+{
+  const int tid = get_global_id(0);
+  if (tid >= n) return;
+  const RefTrees trees = ref_makeTrees(bvh, tris, alpha, haveInst, bvh1, tris1, alpha1, haveInst1, in_texStorage, a_globals);
+  __global const float* rptr0 = xvec + (size_t)tid * stride;
+  const int d = depth[tid];
+  RandomGen gen;
+  gen.state = (uint2)(1, 2);   /* never drawn from: every rnd* call below has its rptr set */
+  ProcTextureList ptlDummy;
+  InitProcTextureList(&ptlDummy);
+
+  PdfVertex pdfArray[REF_MMLT_MAX_DEPTH + 2];
+  for (int k = 0; k < REF_MMLT_MAX_DEPTH + 2; k++) { pdfArray[k].pdfFwd = 0.0f; pdfArray[k].pdfRev = 0.0f; }
+
+  const int m_width  = (int)(a_globals->varsF[HRT_WIDTH_F]);
+  const int m_height = (int)(a_globals->varsF[HRT_HEIGHT_F]);
+  const float mLightSubPathCount = (float)(m_width*m_height);
+  const bool m_splitDLByGrammar  = (a_globals->varsI[HRT_MMLT_FIRST_BOUNCE] > 3);
+
+  const int s = rndSplitMMLT(&gen, rptr0, d);
+  const int t = d - s;
+  const int lightTraceDepth = s - 1;
+  const int camTraceDepth   = t;
+  const float4 lensOffs = rndLens(&gen, rptr0, make_float2(1.0f, 1.0f), 0, 0, 0);
+  int x = (int)(lensOffs.x*(float)(m_width)  + 0.5f);
+  int y = (int)(lensOffs.y*(float)(m_height) + 0.5f);
+
+  /* (1) camera sub-path */
+  PathVertex cv;
+  InitPathVertex(&cv);
+  if (camTraceDepth > 0)
+  {
+    __global const float* rptr = rptr0 + camOffsetInRandArrayMMLT(s);
+    float fx, fy;
+    float3 ray_pos, ray_dir;
+    MakeEyeRayFromF4Rnd(lensOffs, a_globals, &ray_pos, &ray_dir, &fx, &fy);
+    x = (int)(fx + 0.5f);
+    y = (int)(fy + 0.5f);
+    if (x >= m_width)  x = m_width - 1;
+    if (y >= m_height) y = m_height - 1;
+    const bool haveToHitLight = (lightTraceDepth == -1);
+    MisData misPrev = makeInitialMisData();
+    uint flags = 0;
+    float3 factors[REF_MMLT_MAX_DEPTH + 2];
+    int nFactors = 0, zeroFrom = -1;
+    cv.valid = false; cv.accColor = make_float3(0, 0, 0);
+    for (int a_currDepth = 1; a_currDepth <= camTraceDepth; a_currDepth++)
+    {
+      const int prevVertexId = d - a_currDepth + 1;
+      const Lite_Hit hit = ref_rayTrace(ray_pos, ray_dir, trees);
+      if (HitNone(hit)) break;
+      const SurfaceHit surfElem = ref_evalSurface(ray_pos, ray_dir, hit, in_matrices, in_geomStorage, a_globals);
+      const float cosHere = fabs(dot(ray_dir, surfElem.normal));
+      const float cosPrev = fabs(misPrev.cosThetaPrev);
+      float GTerm = 1.0f;
+      if (a_currDepth == 1)
+      {
+        float3 camDirDummy; float zDepthDummy;
+        const float imageToSurfaceFactor = CameraImageToSurfaceFactor(surfElem.pos, surfElem.normal, a_globals, make_float2(0,0), &camDirDummy, &zDepthDummy);
+        const float cameraPdfA = imageToSurfaceFactor / mLightSubPathCount;
+        pdfArray[d].pdfRev = cameraPdfA;
+        pdfArray[d].pdfFwd = 1.0f;
+      }
+      else
+      {
+        const float dist = length(ray_pos - surfElem.pos);
+        GTerm = cosHere*cosPrev / fmax(dist*dist, DEPSILON2);
+      }
+      __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, surfElem.matId);
+      const int lightOffset0 = instLightInstId[hit.instId];
+      __global const PlainLight* pLightHit = lightAt(a_globals, lightOffset0);
+      ProcTextureList ptl;
+      InitProcTextureList(&ptl);
+      const float3 emission = emissionEval(ray_pos, ray_dir, &surfElem, flags, (misPrev.isSpecular == 1), pLightHit, pHitMaterial,
+                                           in_texStorage, in_pdfStorage, a_globals, &ptl);
+      if (dot(emission, emission) > 1e-6f)
+      {
+        if (a_currDepth == camTraceDepth && haveToHitLight)
+        {
+          const LightPdfFwd lPdfFwd = lightPdfFwd(pLightHit, ray_dir, cosHere, a_globals, in_texStorage, in_pdfStorage);
+          const float pdfLightWP    = lPdfFwd.pdfW / fmax(cosHere, DEPSILON);
+          const float pdfMatRevWP   = misPrev.matSamplePdf / fmax(cosPrev, DEPSILON);
+          pdfArray[0].pdfFwd = lPdfFwd.pdfA / (float)(a_globals->lightsNum);
+          pdfArray[0].pdfRev = 1.0f;
+          pdfArray[1].pdfFwd = pdfLightWP*GTerm;
+          pdfArray[1].pdfRev = misPrev.isSpecular ? -1.0f*GTerm : pdfMatRevWP*GTerm;
+          cv.hit = surfElem; cv.ray_dir = ray_dir; cv.accColor = emission; cv.valid = true;
+        }
+        break;
+      }
+      else if (a_currDepth == camTraceDepth && !haveToHitLight)
+      {
+        cv.hit = surfElem; cv.ray_dir = ray_dir; cv.valid = true; cv.accColor = make_float3(1, 1, 1);
+        cv.wasSpecOnly = m_splitDLByGrammar ? flagsHaveOnlySpecular(flags) : false;
+        if (camTraceDepth != 1)
+        {
+          const float lastPdfWP = misPrev.matSamplePdf / fmax(cosPrev, DEPSILON);
+          cv.lastGTerm = GTerm;
+          pdfArray[prevVertexId].pdfRev = misPrev.isSpecular ? -1.0f*GTerm : GTerm*lastPdfWP;
+        }
+        else
+          cv.lastGTerm = 1.0f;
+        break;
+      }
+
+      float allRands[MMLT_FLOATS_PER_BOUNCE];
+      RndMatAll(&gen, rptr + rndMatOffsetMMLT(a_currDepth - 1), a_currDepth - 1, a_globals->rmQMC, 0, 0, allRands);
+      MatSample matSam; int matOffset;
+      MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), packBounceNum(0, a_currDepth - 1), false,
+                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+      const float3 bxdfVal = matSam.color;
+      const float cosNext  = fabs(dot(matSam.direction, surfElem.normal));
+      if (a_currDepth == 1)
+      {
+        if (isPureSpecular(matSam))
+          pdfArray[d].pdfFwd = 0.0f;
+      }
+      else
+      {
+        if (!isPureSpecular(matSam))
+        {
+          ShadeContext sc;
+          sc.wp = surfElem.pos; sc.l = (-1.0f)*ray_dir; sc.v = matSam.direction; sc.n = surfElem.normal; sc.fn = surfElem.flatNormal;
+          sc.tg = surfElem.tangent; sc.bn = surfElem.biTangent; sc.tc = surfElem.texCoord; sc.tccp = surfElem.texCoordCamProj; sc.hfi = surfElem.hfi;
+          const float pdfFwdW  = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlDummy).pdfFwd;
+          const float pdfFwdWP = pdfFwdW / fmax(cosHere, DEPSILON);
+          pdfArray[prevVertexId].pdfFwd = pdfFwdWP*GTerm;
+        }
+        else
+          pdfArray[prevVertexId].pdfFwd = -1.0f*GTerm;
+        const float pdfCamPrevWP = misPrev.matSamplePdf / fmax(cosPrev, DEPSILON);
+        pdfArray[prevVertexId].pdfRev = misPrev.isSpecular ? -1.0f*GTerm : pdfCamPrevWP*GTerm;
+      }
+      const bool stopDL = m_splitDLByGrammar ? flagsHaveOnlySpecular(flags) : false;
+      factors[nFactors] = (bxdfVal*cosNext / fmax(matSam.pdf, DEPSILON2));
+      if (stopDL && haveToHitLight && a_currDepth + 1 == camTraceDepth) zeroFrom = nFactors;
+      nFactors++;
+
+      const float3 nextRay_dir = matSam.direction;
+      const float3 nextRay_pos = OffsRayPos(surfElem.pos, surfElem.normal, matSam.direction);
+      MisData thisBounce       = makeInitialMisData();
+      thisBounce.isSpecular    = isPureSpecular(matSam);
+      thisBounce.matSamplePdf  = matSam.pdf;
+      thisBounce.cosThetaPrev  = dot(nextRay_dir, surfElem.normal);
+      flags   = flagsNextBounceLite(flags, matSam, a_globals);
+      misPrev = thisBounce;
+      ray_pos = nextRay_pos;
+      ray_dir = nextRay_dir;
+    }
+    if (!cv.valid) cv.accColor = make_float3(0, 0, 0);
+    for (int k = nFactors - 1; k >= 0; k--)
+    {
+      cv.accColor *= factors[k];
+      if (k == zeroFrom) cv.accColor = make_float3(0, 0, 0);
+    }
+  }
+
+  /* (2) light sub-path */
+  PathVertex lv;
+  InitPathVertex(&lv);
+  if (lightTraceDepth > 0)
+  {
+    LightGroup2 lightSelector;
+    RndLightMMLT(&gen, rptr0, &lightSelector);
+    float lightPickProb = 1.0f;
+    const int lightId = SelectRandomLightFwd(lightSelector.group2.z, a_globals, &lightPickProb);
+    __global const PlainLight* pLight = lightAt(a_globals, lightId);
+    LightSampleFwd sample;
+    LightSampleForward(pLight, lightSelector.group1, make_float2(lightSelector.group2.x, lightSelector.group2.y), a_globals, in_texStorage, in_pdfStorage, &sample);
+    pdfArray[0].pdfFwd = sample.pdfA*lightPickProb;
+    pdfArray[0].pdfRev = 1.0f;
+    float3 a_color = (1.0f/lightPickProb)*sample.color/(sample.pdfA*sample.pdfW);
+    __global const float* rptr = rptr0 + MMLT_HEAD_TOTAL_SIZE;
+    float3 ray_pos = sample.pos, ray_dir = sample.dir;
+    float a_prevLightCos = sample.cosTheta, a_prevPdf = sample.pdfW;
+    bool a_wasSpecular = false;
+    for (int a_currDepth = 1; a_currDepth <= lightTraceDepth; a_currDepth++)
+    {
+      const Lite_Hit hit = ref_rayTrace(ray_pos, ray_dir, trees);
+      if (!HitSome(hit)) break;
+      const SurfaceHit surfElem = ref_evalSurface(ray_pos, ray_dir, hit, in_matrices, in_geomStorage, a_globals);
+      const float cosCurr = fabs(-dot(ray_dir, surfElem.normal));
+      const float dist    = length(surfElem.pos - ray_pos);
+      const float GTermPrev = (a_prevLightCos*cosCurr / fmax(dist*dist, DEPSILON2));
+      const float prevPdfWP = a_prevPdf / fmax(a_prevLightCos, DEPSILON);
+      if (!a_wasSpecular)
+        pdfArray[a_currDepth].pdfFwd = prevPdfWP*GTermPrev;
+      else
+        pdfArray[a_currDepth].pdfFwd = -1.0f*GTermPrev;
+      __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, surfElem.matId);
+      float allRands[MMLT_FLOATS_PER_BOUNCE];
+      RndMatAll(&gen, rptr + rndMatOffsetMMLT(a_currDepth - 1), a_currDepth - 1, a_globals->rmQMC, 0, 0, allRands);
+      MatSample matSam; int matOffset;
+      MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), packBounceNum(0, a_currDepth - 1), true,
+                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+      const float3 nextRay_dir = matSam.direction;
+      const float3 nextRay_pos = OffsRayPos(surfElem.pos, surfElem.normal, matSam.direction);
+      const float cosNext = fabs(+dot(nextRay_dir, surfElem.normal));
+      if (a_currDepth == lightTraceDepth)
+      {
+        lv.hit = surfElem; lv.ray_dir = ray_dir; lv.accColor = a_color; lv.valid = true; lv.lastGTerm = GTermPrev;
+        break;
+      }
+      if (!isPureSpecular(matSam))
+      {
+        ShadeContext sc;
+        sc.wp = surfElem.pos; sc.l = (-1.0f)*ray_dir; sc.v = (-1.0f)*nextRay_dir; sc.n = surfElem.normal; sc.fn = surfElem.flatNormal;
+        sc.tg = surfElem.tangent; sc.bn = surfElem.biTangent; sc.tc = surfElem.texCoord; sc.tccp = surfElem.texCoordCamProj; sc.hfi = surfElem.hfi;
+        const float pdfW         = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlDummy).pdfFwd;
+        const float prevPdfRevWP = pdfW / fmax(cosCurr, DEPSILON);
+        pdfArray[a_currDepth].pdfRev = prevPdfRevWP*GTermPrev;
+      }
+      else
+        pdfArray[a_currDepth].pdfRev = -1.0f*GTermPrev;
+      a_color *= matSam.color*cosNext*(1.0f / fmax(matSam.pdf, DEPSILON2));
+      ray_pos = nextRay_pos; ray_dir = nextRay_dir;
+      a_prevLightCos = cosNext; a_prevPdf = matSam.pdf; a_wasSpecular = isPureSpecular(matSam);
+    }
+  }
+
+  /* (3) connect */
+  float3 sampleColor = make_float3(0, 0, 0);
+  if (lightTraceDepth == -1)
+    sampleColor = cv.accColor;
+  else
+  {
+    if (camTraceDepth == 0)
+    {
+      if (lv.valid)
+      {
+        float3 camDir; float zDepth;
+        const float imageToSurfaceFactor = CameraImageToSurfaceFactor(lv.hit.pos, lv.hit.normal, a_globals, make_float2(0,0), &camDir, &zDepth);
+        __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, lv.hit.matId);
+        float signOfNormal = 1.0f;
+        if ((materialGetFlags(pHitMaterial) & PLAIN_MATERIAL_HAVE_BTDF) != 0 && dot(camDir, lv.hit.normal) < -0.01f)
+          signOfNormal = -1.0f;
+        const Lite_Hit hit = ref_rayTrace(lv.hit.pos + epsilonOfPos(lv.hit.pos)*signOfNormal*lv.hit.normal, camDir, trees);
+        if (imageToSurfaceFactor <= 0.0f || (HitSome(hit) && hit.t <= zDepth))
+        {
+          x = -1; y = -1;
+        }
+        else
+          sampleColor = ConnectEyeP(&lv, mLightSubPathCount, camDir, imageToSurfaceFactor, a_globals, in_mtlStorage, in_texStorage, in_texStorage, &ptlDummy,
+                                    &pdfArray[lightTraceDepth + 0], &pdfArray[lightTraceDepth + 1], &x, &y);
+      }
+    }
+    else if (lightTraceDepth == 0)
+    {
+      if (cv.valid && !cv.wasSpecOnly)
+      {
+        float3 explicitColor = make_float3(0, 0, 0);
+        LightGroup2 lightSelector;
+        RndLightMMLT(&gen, rptr0, &lightSelector);
+        float lightPickProb = 1.0f;
+        const int lightOffset = SelectRandomLightRev(lightSelector.group2.z, cv.hit.pos, a_globals, &lightPickProb);
+        if (lightOffset >= 0)
+        {
+          __global const PlainLight* pLight = lightAt(a_globals, lightOffset);
+          ShadowSample explicitSam;
+          LightSampleRev(pLight, to_float3(lightSelector.group1), cv.hit.pos, a_globals, in_pdfStorage, in_texStorage, &explicitSam);
+          const float3 shadowRayDir = normalize(explicitSam.pos - cv.hit.pos);
+          const float3 shadowRayPos = OffsRayPos(cv.hit.pos, cv.hit.normal, shadowRayDir);
+          const Lite_Hit sh = ref_shadowClosest(shadowRayPos, shadowRayDir, trees);
+          const float t_far = explicitSam.maxDist*0.9995f;
+          const float3 shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
+          if (dot(shadow, shadow) > 1e-12f)
+            explicitColor = shadow*ConnectShadowP(&cv, t, pLight, explicitSam, lightPickProb, a_globals, in_mtlStorage, in_texStorage, in_texStorage, in_pdfStorage, &ptlDummy,
+                                                  &pdfArray[0], &pdfArray[1], &pdfArray[2]);
+        }
+        sampleColor = cv.accColor*explicitColor;
+      }
+    }
+    else
+    {
+      if (cv.valid)
+      {
+        float3 explicitColor = make_float3(0, 0, 0);
+        if (lv.valid)
+        {
+          const float3 diff = cv.hit.pos - lv.hit.pos;
+          const float dist2 = fmax(dot(diff, diff), DEPSILON2);
+          const float  dist = sqrt(dist2);
+          const float3 lToC = diff / dist;
+          const float cosAtLightVertex  = +dot(lv.hit.normal, lToC);
+          const float cosAtCameraVertex = -dot(cv.hit.normal, lToC);
+          const float GTerm = cosAtLightVertex*cosAtCameraVertex / dist2;
+          if (!(GTerm < 0.0f))
+          {
+            const float3 shadowRayPos = OffsRayPos(lv.hit.pos, lv.hit.normal, lToC);
+            const Lite_Hit sh = ref_shadowClosest(shadowRayPos, lToC, trees);
+            const float t_far = dist*0.9995f;
+            const float3 shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
+            if (!(dot(shadow, shadow) < 1e-12f))
+              explicitColor = shadow*ConnectEndPointsP(&lv, &cv, d, a_globals, in_mtlStorage, in_texStorage, in_texStorage, &ptlDummy,
+                                                       &pdfArray[s - 1], &pdfArray[s + 0], &pdfArray[s + 1]);
+          }
+        }
+        sampleColor = cv.accColor*explicitColor*lv.accColor;
+      }
+    }
+  }
+
+  /* (4) MIS weight */
+  float misWeight = 1.0f;
+  if (dot(sampleColor, sampleColor) > 1e-12f)
+  {
+    float pdfThisWay = 1.0f;
+    float pdfSumm    = 0.0f;
+    for (int split = 0; split <= d; split++)
+    {
+      const int s1 = split;
+      const int t1 = d - split;
+      const bool specularMet = (split > 0) && (split < d) && (pdfArray[split].pdfRev < 0.0f || pdfArray[split].pdfFwd < 0.0f);
+      float pdfOtherWay = specularMet ? 0.0f : 1.0f;
+      if (split == d)
+        pdfOtherWay = misHeuristicPower1(pdfArray[d].pdfFwd);
+      for (int i = 0; i < s1; i++)
+        pdfOtherWay *= misHeuristicPower1(pdfArray[i].pdfFwd);
+      for (int i = s1 + 1; i <= d; i++)
+        pdfOtherWay *= misHeuristicPower1(pdfArray[i].pdfRev);
+      if (s1 == s && t1 == t)
+        pdfThisWay = pdfOtherWay;
+      pdfSumm += pdfOtherWay;
+    }
+    misWeight = pdfThisWay / fmax(pdfSumm, DEPSILON2);
+  }
+  sampleColor *= misWeight;
+  if (!(x >= 0 && x < m_width && y >= 0 && y < m_height))
+  {
+    x = 0; y = 0;
+    sampleColor = make_float3(0, 0, 0);
+  }
+  __global float* o = out8 + (size_t)tid * 8;
+  o[0] = sampleColor.x; o[1] = sampleColor.y; o[2] = sampleColor.z; o[3] = (float)x; o[4] = (float)y; o[5] = (float)s;
+  o[6] = misWeight; o[7] = contribFunc(sampleColor);
+}

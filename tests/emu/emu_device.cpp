@@ -124,4 +124,29 @@ void emu_bidir(const EmuScene* e, int n, const int* lightIds, const float* rands
   }
 }
 
+// IntegratorMMLT::F through the wavefront functions of hk_bidir.h: the stage order hydra_hip.hip runs on the device, with this file's
+// per-ray traversal between the stages.  xvec: n rows of `stride` floats; out8 as hydra_hip_stage_mmlt_f.
+void emu_mmlt_f(const EmuScene* e, int n, const int* depth, const float* xvec, int stride, float* out8) {
+  const SceneDev s = to_dev(e);
+  int maxD = 1;
+  for (int i = 0; i < n; i++) maxD = depth[i] > maxD ? depth[i] : maxD;
+  std::vector<float> st(size_t(mmltPlanes(maxD)) * n, 0.0f), x(size_t(mmltStride(maxD)) * n, 0.0f);
+  for (int i = 0; i < n; i++) for (int j = 0; j < HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * depth[i]; j++) x[size_t(j) * n + i] = xvec[size_t(i) * stride + j];
+  std::vector<float4> rayPos(2 * size_t(n)), rayDir(2 * size_t(n)), eyePos(n), eyeDir(n), shPos(n), shDir(n);
+  std::vector<HydraLiteHit> hits(2 * size_t(n)), eyeHit(n);
+  std::vector<float> shVis(n), tfar(n);
+  MmltView v;
+  v.n = n; v.maxD = maxD; v.st = st.data(); v.x = x.data(); v.depth = depth; v.rayPos = rayPos.data(); v.rayDir = rayDir.data(); v.hits = hits.data();
+  v.eyePos = eyePos.data(); v.eyeDir = eyeDir.data(); v.eyeHit = eyeHit.data(); v.shPos = shPos.data(); v.shDir = shDir.data(); v.shVis = shVis.data(); v.out8 = out8;
+  for (int i = 0; i < n; i++) mmltBegin(s, v, i);
+  for (int k = 1; k <= maxD; k++) {
+    emu_trace(e, 2 * n, reinterpret_cast<const float*>(rayPos.data()), reinterpret_cast<const float*>(rayDir.data()), hits.data(), nullptr, 0, nullptr, nullptr);
+    for (int i = 0; i < n; i++) { mmltCameraStep(s, v, i, k); mmltLightStep(s, v, i, k); }
+  }
+  for (int i = 0; i < n; i++) { mmltConnectBegin(s, v, i); tfar[i] = shPos[i].w; }
+  emu_trace(e, n, reinterpret_cast<const float*>(eyePos.data()), reinterpret_cast<const float*>(eyeDir.data()), eyeHit.data(), nullptr, 0, nullptr, nullptr);
+  emu_trace(e, n, reinterpret_cast<const float*>(shPos.data()), reinterpret_cast<const float*>(shDir.data()), nullptr, nullptr, 1, tfar.data(), shVis.data());
+  for (int i = 0; i < n; i++) mmltConnectEnd(s, v, i);
+}
+
 }  // extern "C"

@@ -69,6 +69,7 @@ def main():
     lib.emu_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, i32, vp, vp]
     lib.emu_path_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp]
     lib.emu_eye_rays.argtypes = [C.POINTER(OrcScene), i32, i32, i32, vp, vp, vp, vp]
+    lib.emu_mmlt_f.argtypes = [C.POINTER(OrcScene), i32, vp, vp, i32, vp]
     lib.emu_bidir.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
 
     def p(a):
@@ -110,6 +111,17 @@ def main():
                                 (cam, orc.camera_connect(bp, bn, dk), "camera connection"), (mut, orc.mutate_kelemen(vals, r2, 64.0, 1024.0), "MutateKelemen")):
             bad = ~np.isclose(got, want, rtol=2e-6, atol=2e-6, equal_nan=True)   # a sky dome takes the area-light branch, as in the reference: NaN on both sides
             assert not bad.any(), "%s differs from the oracle on %s: %d values, columns %s, e.g. %s vs %s" % (what, name, bad.sum(), np.unique(np.nonzero(bad.reshape(len(got), -1))[1]), got[bad][:4], want[bad][:4])
+        # IntegratorMMLT::F through the wavefront stage functions against the oracle's restatement: every split of d = 1..5
+        mrng = np.random.default_rng(41)
+        md = np.repeat(np.arange(1, 6), 600).astype(np.int32)
+        mxv = mrng.uniform(0, 1, (len(md), 12 + 10 * 5)).astype(np.float32)
+        mout = np.empty((len(md), 8), np.float32)
+        lib.emu_mmlt_f(C.byref(orc.s), len(md), p(md), p(mxv), mxv.shape[1], p(mout))
+        mref = orc.mmlt_f(md, mxv)
+        assert (mout[:, 3:6] == mref[:, 3:6]).all(), "MMLT F: pixel or split differs from the oracle on " + name
+        mbad = ~np.isclose(mout, mref, rtol=2e-5, atol=1e-7)
+        assert not mbad.any(), "MMLT F differs from the oracle on %s: %d values, rows %s" % (name, mbad.sum(), np.nonzero(mbad.any(axis=1))[0][:8])
+        assert (mref[:, 7] > 0).mean() > 0.05, "MMLT F is zero nearly everywhere on " + name
         # whole paths
         n = w * h
         ys, xs = np.divmod(np.arange(n), w)

@@ -51,6 +51,7 @@ def load():
     lib.orc_light_pdf_fwd.argtypes = [sp, i32, vp, vp, vp]
     lib.orc_camera_connect.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_mutate_kelemen.argtypes = [i32, vp, vp, C.c_float, C.c_float, vp]
+    lib.orc_mmlt_f.argtypes = [sp, i32, vp, vp, i32, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
     lib.orc_collect_rays.restype = C.c_int64
@@ -182,6 +183,14 @@ class Oracle:
         v, r = np.ascontiguousarray(values, np.float32), np.ascontiguousarray(rands2, np.float32)
         out = np.zeros(v.size, np.float32)
         self.lib.orc_mutate_kelemen(v.size, _p(v), _p(r), p2, p1, _p(out))
+        return out
+
+    def mmlt_f(self, depth, xvec):
+        """IntegratorMMLT::F for n primary-sample vectors (rows of xvec, >= 12 + 10 * depth floats) -> (n, 8): colour, x, y, split, MIS weight, contribFunc"""
+        d, x = np.ascontiguousarray(depth, np.int32), np.ascontiguousarray(xvec, np.float32)
+        assert x.ndim == 2 and x.shape[0] == d.size and x.shape[1] >= 12 + 10 * int(d.max()) and 1 <= int(d.min()) and int(d.max()) <= 16
+        out = np.zeros((d.size, 8), np.float32)
+        self.lib.orc_mmlt_f(C.byref(self.s), d.size, _p(d), _p(x), x.shape[1], _p(out))
         return out
 
     def path_trace(self, pos4, dir4, rng2):

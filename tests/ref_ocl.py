@@ -180,6 +180,16 @@ class RefScene:
                                                 ("f", p2), ("f", p1), ("p", out), ("i", n)])
         return self.m.down(out, np.float32, (n,))
 
+    def mmlt_f(self, depth, xvec):
+        d, x = np.ascontiguousarray(depth, np.int32), np.ascontiguousarray(xvec, np.float32)
+        n = d.size
+        out = self.m.alloc(n * 32)
+        self.m.launch("ref_mmlt_f", n, [("p", self.m.up(d)), ("p", self.m.up(x)), ("i", x.shape[1]),
+                                        ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
+                                        ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", out), ("i", n),
+                                        ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1)])
+        return self.m.down(out, np.float32, (n, 8))
+
     def path_trace(self, pos4, dir4, rng2):
         n = len(pos4)
         rng = self.m.up(np.ascontiguousarray(rng2, np.uint32))

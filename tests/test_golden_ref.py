@@ -186,3 +186,47 @@ def test_oracle_matches_reference_bidirectional_blocks(name, built):
     r = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(r["width"]), int(r["height"]), int(r["depth"]), int(r["dof"]))
     check_bidir(run_bidir(make_oracle(b), g), g)
+
+
+MMLT_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_glass_small", "atrium_cutouts2_small"]
+
+
+def load_mmlt(name):
+    """the seeded primary-sample vectors (regenerated, checked by digest) and the reference's F for them"""
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import mmlt_inputs
+    g = load("ref_mmlt_%s.npz" % name)
+    depth, xvec = mmlt_inputs()
+    digest = np.frombuffer(hashlib.sha1(depth.tobytes() + xvec.tobytes()).digest(), np.uint8)
+    assert (digest == g["inputs_sha1"]).all(), "the seeded inputs differ from the ones the fixture was made with"
+    return depth, xvec, g["out"]
+
+
+def check_mmlt_f(got, want, frac=0.002):
+    """out8 rows: colour, x, y, split, MIS weight, contribFunc.  The split is integer arithmetic on one float; everything else hangs on
+    traversal + shading in float, so a small share of rows may take another branch (a grazing hit, a light edge)."""
+    assert (got[:, 5] == want[:, 5]).all()
+    same_px = (got[:, 3] == want[:, 3]) & (got[:, 4] == want[:, 4])
+    assert same_px.mean() > 1 - frac, same_px.mean()
+    # same decisions on every row; the colour is a product of up to six BxDF values, and a glossy lobe's pow(cos, power) turns a last-bit
+    # difference of its argument into 1e-4 (OpenCL pow / normalize against libm): 0.4 % of the rows of the textured halls are off by
+    # 5e-4..4e-3 relative; 8 rows of 12 288 (paths of 5 and 6 segments that evaluate such a lobe far off its peak at a connection)
+    # by 0.4..2 %, one by 35 % on a value of 6e-5
+    scale = np.maximum(np.abs(want[:, :3]), 1e-3)
+    err = np.abs(got[:, :3] - want[:, :3]) / scale
+    assert (err.max(axis=1) > 5e-4).mean() < 0.006, (err.max(axis=1) > 5e-4).mean()
+    assert (err.max(axis=1) > 4e-3).mean() < 0.001, (err.max(axis=1) > 4e-3).mean()
+    assert (np.abs(got[:, 6] - want[:, 6]) > 5e-4).mean() < frac
+    assert abs(got[:, 7].mean() - want[:, 7].mean()) < 2e-3 * want[:, 7].mean()
+    assert (want[:, 7] > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("name", MMLT_SCENES)
+def test_oracle_matches_reference_mmlt_contribution_function(name, built):
+    """row f3: IntegratorMMLT::F (CPUExp_Integrators_MMLT.cpp:146-315) for path lengths 1..6, every split, 12 288 seeded vectors per scene"""
+    depth, xvec, want = load_mmlt(name)
+    r = load("ref_%s.npz" % name)
+    _, b = host_scene(name, int(r["width"]), int(r["height"]), int(r["depth"]), int(r["dof"]))
+    check_mmlt_f(make_oracle(b).mmlt_f(depth, xvec), want)
