@@ -34,11 +34,14 @@ PMC_GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum",
 def kernel_family(name):
     """the three kernel families of a bounce; the counting variants (<.., true>) are not timed and not profiled"""
     n = name.replace(" ", "")
-    if n.startswith("k_trace_dyn<false,false>") or n.startswith("voidk_trace_dyn<false,false>"):
+    if n.startswith("void"):
+        n = n[4:]
+    # k_trace_dyn<ANYHIT, COUNT, TOPTRIS, ALPHA>: the first two arguments name the family, the others are variants of it
+    if n.startswith("k_trace_dyn<false,false,") or n.startswith("k_trace_dyn<false,false>"):
         return "closest"
-    if n.startswith("k_trace_dyn<true,false>") or n.startswith("voidk_trace_dyn<true,false>"):
+    if n.startswith("k_trace_dyn<true,false,") or n.startswith("k_trace_dyn<true,false>"):
         return "shadow"
-    if n.startswith("k_bounce<") or n.startswith("voidk_bounce<"):
+    if n.startswith("k_bounce<"):
         return "bounce"
     return None
 

@@ -51,7 +51,8 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
-    "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f",
+    "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end",
 ]
 
 _hip = None
@@ -125,6 +126,11 @@ def load_hip_library():
         "hydra_hip_stage_camera_connect": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_mutate_kelemen": ([vp, i32, vp, vp, C.c_float, C.c_float, vp], i32),
         "hydra_hip_stage_mmlt_f": ([vp, i32, vp, vp, i32, vp], i32),
+        "hydra_hip_mmlt_begin": ([vp, i32, i32, i32, i32, i32], i32),
+        "hydra_hip_mmlt_pass": ([vp, i32], i32),
+        "hydra_hip_mmlt_get_image": ([vp, vp, vp], i32),
+        "hydra_hip_mmlt_get_state": ([vp, vp, vp, vp, vp], i32),
+        "hydra_hip_mmlt_end": ([vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -473,6 +479,33 @@ class HipCore:
         out = np.zeros((d.size, 8), np.float32)
         self._ck(self.lib.hydra_hip_stage_mmlt_f(self.h, d.size, _ptr(d), _ptr(x), x.shape[1], _ptr(out)), "stage_mmlt_f")
         return out
+
+    # ---- IntegratorMMLT (row f3)
+    def mmlt_begin(self, chains, seed=777, first_bounce=0, max_depth=0, estimate_passes=0):
+        self._ck(self.lib.hydra_hip_mmlt_begin(self.h, chains, seed, first_bounce, max_depth, estimate_passes), "mmlt_begin")
+        self._mmlt = (chains, max_depth)
+
+    def mmlt_pass(self, mutations=1):
+        self._ck(self.lib.hydra_hip_mmlt_pass(self.h, mutations), "mmlt_pass")
+
+    def mmlt_image(self, width, height):
+        """(kScale x indirect image (h, w, 4), info dict)"""
+        img, info = np.zeros((height, width, 4), np.float32), np.zeros(8, np.float32)
+        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, _ptr(img), _ptr(info)), "mmlt_get_image")
+        keys = ("avg_brightness", "k_scale", "acceptance", "mutations", "chains", "first_bounce", "max_depth")
+        return img, dict(zip(keys, (float(v) for v in info[:7])))
+
+    def mmlt_state(self):
+        """chain planes (11, n), d per chain, current x vectors (n, 12 + 10 * max_depth), average brightness per path length"""
+        info8 = np.zeros(8, np.float32)
+        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, None, _ptr(info8)), "mmlt_get_image")
+        n, max_d = int(info8[4]), int(info8[6])
+        ch, depth, x, avg = np.zeros((11, n), np.float32), np.zeros(n, np.int32), np.zeros((n, 12 + 10 * max_d), np.float32), np.zeros(max_d + 1, np.float32)
+        self._ck(self.lib.hydra_hip_mmlt_get_state(self.h, _ptr(ch), _ptr(depth), _ptr(x), _ptr(avg)), "mmlt_get_state")
+        return ch, depth, x, avg
+
+    def mmlt_end(self):
+        self._ck(self.lib.hydra_hip_mmlt_end(self.h), "mmlt_end")
 
     def bench_trace(self, pos4, dir4, iters=20, shadow=False):
         n = pos4.shape[0]

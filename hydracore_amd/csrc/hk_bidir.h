@@ -189,9 +189,12 @@ enum {
   MP_CV_GTERM = 7, MP_CV_DIR = 8, MP_CV_ACC = 11, MP_CV_HIT = 14,            // hit record: pos 3, normal 3, flat normal 3, uv 2, matId, t, sRayOff, hfi = 15 planes
   MP_L_COLOR = 29, MP_L_COS = 32, MP_L_PDF = 33,
   MP_LV_GTERM = 34, MP_LV_DIR = 35, MP_LV_ACC = 38, MP_LV_HIT = 41,
-  MP_NFAC = 56, MP_ZERO_FROM = 57, MP_PDF = 58                               // then 2 * (maxD + 1) pdf planes and 3 * maxD factor planes
+  MP_NFAC = 56, MP_ZERO_FROM = 57, MP_LBITS = 58, MP_PDF = 59                // then 2 * (maxD + 1) pdf planes and 3 * maxD factor planes
 };
-enum { MB_CAM_ACTIVE = 1, MB_LIGHT_ACTIVE = 2, MB_CV_VALID = 4, MB_LV_VALID = 8, MB_CV_SPEC_ONLY = 16, MB_MIS_SPECULAR = 32, MB_LIGHT_SPECULAR = 64 };
+// the camera and the light sub-path of a chain advance in different threads of one launch: each side owns its flag word (MP_BITS / MP_LBITS),
+// its rays and its pdf entries (camera: s+1..d, light: 0..s-1), so the two never write the same word
+enum { MB_CAM_ACTIVE = 1, MB_CV_VALID = 4, MB_CV_SPEC_ONLY = 16, MB_MIS_SPECULAR = 32 };   // MP_BITS
+enum { MB_LIGHT_ACTIVE = 2, MB_LV_VALID = 8, MB_LIGHT_SPECULAR = 64 };                      // MP_LBITS
 #define mmltPlanes(maxD) (MP_PDF + 2 * ((maxD) + 1) + 3 * (maxD))
 #define mmltStride(maxD) (HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * (maxD))   // randArraySizeOfDepthMMLT, crandom.h:630-633
 
@@ -285,7 +288,7 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i) {
   const int lightTraceDepth = sp - 1, camTraceDepth = t;
   const float4 lensOffs = make_float4(mx(v, 0, i), mx(v, 1, i), mx(v, 2, i), mx(v, 3, i));   // rndLens
   int x = int(lensOffs.x * float(width) + 0.5f), y = int(lensOffs.y * float(height) + 0.5f);
-  int bits = 0;
+  int bits = 0, lbits = 0;
   float4 cpos, cdir, lpos, ldir;
   mmltDeadRay(cpos, cdir); mmltDeadRay(lpos, ldir);
   // InitPathVertex, cbidir.h:26-33
@@ -313,9 +316,9 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i) {
     mstSet3(v, MP_L_COLOR, i, div3s(sam.color * (1.0f / pick), sam.pdfA * sam.pdfW));
     mst(v, MP_L_COS, i) = sam.cosTheta; mst(v, MP_L_PDF, i) = sam.pdfW;
     lpos = make_float4(sam.pos.x, sam.pos.y, sam.pos.z, 0.0f); ldir = make_float4(sam.dir.x, sam.dir.y, sam.dir.z, 0.0f);
-    bits |= MB_LIGHT_ACTIVE;
+    lbits |= MB_LIGHT_ACTIVE;
   }
-  msti(v, MP_S, i) = sp; msti(v, MP_BITS, i) = bits; msti(v, MP_X, i) = x; msti(v, MP_Y, i) = y;
+  msti(v, MP_S, i) = sp; msti(v, MP_BITS, i) = bits; msti(v, MP_LBITS, i) = lbits; msti(v, MP_X, i) = x; msti(v, MP_Y, i) = y;
   v.rayPos[i] = cpos; v.rayDir[i] = cdir; v.rayPos[v.n + i] = lpos; v.rayDir[v.n + i] = ldir;
 }
 
@@ -406,7 +409,7 @@ HK_DEV void mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
 
 // one level of TraceLightPath (:671-754) for the hit of the ray in rayPos[n + i]
 HK_DEV void mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currDepth) {
-  int bits = msti(v, MP_BITS, i);
+  int bits = msti(v, MP_LBITS, i);
   if (!(bits & MB_LIGHT_ACTIVE)) return;
   const int sp = msti(v, MP_S, i), lightTraceDepth = sp - 1;
   const f3 ray_pos = xyz(v.rayPos[v.n + i]), ray_dir = xyz(v.rayDir[v.n + i]);
@@ -444,7 +447,7 @@ HK_DEV void mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currD
       bits = (bits & ~MB_LIGHT_SPECULAR) | (isPureSpecular(ms) ? MB_LIGHT_SPECULAR : 0) | MB_LIGHT_ACTIVE;
     }
   }
-  msti(v, MP_BITS, i) = bits;
+  msti(v, MP_LBITS, i) = bits;
   v.rayPos[v.n + i] = npos; v.rayDir[v.n + i] = ndir;
 }
 
@@ -473,7 +476,7 @@ HK_DEV f3 mmltCameraColor(const MmltView& v, int i) {   // the products CameraPa
 }
 
 HK_DEV void mmltConnectBegin(const SceneDev& s, const MmltView& v, int i) {
-  const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i);
+  const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i) | msti(v, MP_LBITS, i);
   const int lightTraceDepth = sp - 1, camTraceDepth = d - sp;
   float4 epos, edir, spos, sdir;
   mmltDeadRay(epos, edir); mmltDeadRay(spos, sdir);
@@ -511,7 +514,7 @@ HK_DEV void mmltConnectBegin(const SceneDev& s, const MmltView& v, int i) {
 }
 
 HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
-  const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i);
+  const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i) | msti(v, MP_LBITS, i);
   const int t = d - sp, lightTraceDepth = sp - 1, camTraceDepth = t;
   const int width = int(g_varsF(s)[HV_F_WIDTH_F]), height = int(g_varsF(s)[HV_F_HEIGHT_F]);
   const float mLightSubPathCount = g_varsF(s)[HV_F_WIDTH_F] * g_varsF(s)[HV_F_HEIGHT_F];

@@ -844,6 +844,52 @@ __global__ void k_mmlt_connect_end(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.n) mmltConnectEnd(s, v, i);
 }
+// ---- the Markov chains of IntegratorMMLT (hk_bidir.h): one thread per chain
+__global__ void k_mmlt_init_chains(MmltChains c, int seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) mmltInitChain(c, i, seed);
+}
+__global__ void k_mmlt_pick_depth(MmltChains c, int* __restrict__ depth, const float* __restrict__ accum, int accumSize, int fixedDepth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.n) return;
+  if (fixedDepth > 0) { depth[i] = fixedDepth; return; }
+  RandomGen g = mchGen(c, CH_GEN, i);   // DoPassIndirectMLT(float4*), :348-356: d proportional to the average brightness of its paths
+  float pdf = 1.0f;
+  depth[i] = SelectIndexPropToOpt(rndFloat1_Pseudo(g), accum, accumSize, pdf);
+  mchSetGen(c, CH_GEN, i, g);
+}
+__global__ void k_mmlt_fresh(MmltChains c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) mmltFreshSample(c, i, c.xNew);
+}
+__global__ void k_mmlt_seed(MmltChains c, const float* __restrict__ out8) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.n) return;
+  const int size = mmltStride(c.depth[i]);
+  for (int j = 0; j < size; j++) c.xCur[size_t(j) * c.n + i] = c.xNew[size_t(j) * c.n + i];
+  mmltSeedChain(c, i, out8);
+}
+__global__ void k_mmlt_mutate(MmltChains c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) mmltMutate(c, i);
+}
+__global__ void k_mmlt_accept(MmltChains c, const float* __restrict__ out8, float bkScale, float* __restrict__ image4, int w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) mmltAcceptReject(c, i, out8, bkScale, image4, w);
+}
+__global__ void k_mmlt_sum(int n, const float* __restrict__ values, int stride, int offset, double* __restrict__ sum) {   // sum += values[i * stride + offset]
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += double(values[size_t(i) * stride + offset]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (int(threadIdx.x) < k) part[threadIdx.x] += part[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(sum, part[0]);
+}
+__global__ void k_mmlt_scale_image(int n, const float4* __restrict__ in, float scale, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float4(in[i].x * scale, in[i].y * scale, in[i].z * scale, in[i].w);
+}
 __global__ void k_mmlt_transpose_in(int n, int stride, int floats, const float* __restrict__ rows, float* __restrict__ planes) {   // rows[i][j] -> planes[j][i]
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -937,6 +983,16 @@ struct hydra_hip_ctx {
   int shadeBlocksPerCU = 256;        // grid cap of the bounce kernels: 16 -> 128..1024 takes 5 % off k_bounce (finer tail, pass_sweep_shade_blocks_final.log)
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
   int traceBlocksPerCU = 12;  // resident 128-thread blocks per CU for the persistent kernels
+  // IntegratorMMLT run (hydra_hip_mmlt_*): chain planes, the two x-vector sets, the work buffers of F, the indirect image
+  struct MmltRun {
+    bool active = false;
+    int n = 0, maxD = 0, firstBounce = 0;
+    DevBuf ch, depth, xCur, xNew, out8, image, accum, sum, scaled;
+    DevBuf st, rayPos, rayDir, hits, eyePos, eyeDir, eyeHit, shPos, shDir, shVis;
+    float avgB[HK_MMLT_MAX_DEPTH + 2] = {0};
+    float avgBrightness = 0.0f;
+    unsigned long long mutations = 0;
+  } mmlt;
   DevBuf fetchCnt;            // refill counters of the persistent kernels: [2*bounce + (shadow ? 1 : 0)], + 1 spare for stage calls
   DevBuf travTotals;   // [bounce][ext|shadow][rays, quads, insts, leaves, tris, out-of-range fetches]
   // RCCL exchange of the accumulator without Python (hydra_hip_comm_*): function table of the dlopen()ed library, communicator, staging
@@ -1499,6 +1555,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hydra_hip_comm_destroy(c);
+  (void)hydra_hip_mmlt_end(c);
   DevBuf* all[] = {&c->srgbLut, &c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
@@ -2440,9 +2497,184 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
   HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
 }
+// ------------------------------------------------------------------------------------------------ IntegratorMMLT, the product path of row f3
+static MmltChains mmlt_chains(hydra_hip_ctx* c) {
+  MmltChains ch;
+  ch.n = c->mmlt.n; ch.maxD = c->mmlt.maxD;
+  ch.ch = (float*)c->mmlt.ch.p; ch.depth = (const int*)c->mmlt.depth.p; ch.xCur = (float*)c->mmlt.xCur.p; ch.xNew = (float*)c->mmlt.xNew.p;
+  return ch;
+}
+static MmltBufs mmlt_run_bufs(hydra_hip_ctx* c) {
+  MmltBufs b;
+  auto& m = c->mmlt;
+  b.v.n = m.n; b.v.maxD = m.maxD; b.v.st = (float*)m.st.p; b.v.x = (const float*)m.xNew.p; b.v.depth = (const int*)m.depth.p;
+  b.v.rayPos = (float4*)m.rayPos.p; b.v.rayDir = (float4*)m.rayDir.p; b.hits = (HydraLiteHit*)m.hits.p;
+  b.v.eyePos = (float4*)m.eyePos.p; b.v.eyeDir = (float4*)m.eyeDir.p; b.eyeHit = (HydraLiteHit*)m.eyeHit.p;
+  b.v.shPos = (float4*)m.shPos.p; b.v.shDir = (float4*)m.shDir.p; b.shVis = (float*)m.shVis.p;
+  b.v.hits = b.hits; b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis; b.v.out8 = (float*)m.out8.p;
+  return b;
+}
+static bool mmlt_camera_ready(const hydra_hip_ctx* c) {   // F projects light-path vertices with varsF[HRT_WIDTH_F / HEIGHT_F] and mProj / mWorldView
+  if (c->hostHeader.size() <= size_t(HG_VARS_F + HV_F_HEIGHT_F)) return false;
+  float wf, hf;
+  memcpy(&wf, &c->hostHeader[HG_VARS_F + HV_F_WIDTH_F], 4); memcpy(&hf, &c->hostHeader[HG_VARS_F + HV_F_HEIGHT_F], 4);
+  return wf >= 1.0f && hf >= 1.0f;
+}
+int hydra_hip_mmlt_end(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  auto& m = c->mmlt;
+  DevBuf* all[] = {&m.ch, &m.depth, &m.xCur, &m.xNew, &m.out8, &m.image, &m.accum, &m.sum, &m.scaled, &m.st, &m.rayPos, &m.rayDir, &m.hits, &m.eyePos, &m.eyeDir, &m.eyeHit, &m.shPos, &m.shDir, &m.shVis};
+  for (DevBuf* b : all) dev_free(*b);
+  m.active = false; m.n = 0; m.mutations = 0;
+  return HYDRA_HIP_OK;
+}
+// DoPassEstimateAvgBrightness (:463-520) + the start of every chain (DoPassIndirectMLT :348-356, :371-377)
+int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bounce, int max_depth, int estimate_passes) {
+  int n = chains;
+  STAGE_PROLOG(true);
+  if (c->w <= 0 || c->h <= 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: set the image size first");
+  if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header holds no camera yet (IHWLayer::SetCamMatrices + PrepareEngineGlobals: the caller's Draw does both)");
+  const int maxD = max_depth > 0 ? max_depth : c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
+  int first = first_bounce > 0 ? first_bounce : c->hostHeader[HG_VARS_I + HV_I_MMLT_FIRST_BOUNCE];
+  if (first > 3) first = 3;   // :481-483
+  if (first < 2) first = 2;
+  if (maxD < first || maxD > HK_MMLT_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "mmlt_begin: max depth must lie in [first bounce, 16]");
+  if (estimate_passes <= 0) estimate_passes = 4;
+  hydra_hip_mmlt_end(c);
+  auto& m = c->mmlt;
+  m.n = n; m.maxD = maxD; m.firstBounce = first;
+  const size_t N = size_t(n);
+  struct { DevBuf* b; size_t bytes; } allocs[] = {
+    {&m.ch, N * CH_PLANES * 4}, {&m.depth, N * 4}, {&m.xCur, N * mmltStride(maxD) * 4}, {&m.xNew, N * mmltStride(maxD) * 4}, {&m.out8, N * 32},
+    {&m.image, size_t(c->w) * c->h * 16}, {&m.scaled, size_t(c->w) * c->h * 16}, {&m.accum, size_t(maxD + 2) * 4}, {&m.sum, 8},
+    {&m.st, N * mmltPlanes(maxD) * 4}, {&m.rayPos, N * 32}, {&m.rayDir, N * 32}, {&m.hits, N * 32}, {&m.eyePos, N * 16}, {&m.eyeDir, N * 16}, {&m.eyeHit, N * 16},
+    {&m.shPos, N * 16}, {&m.shDir, N * 16}, {&m.shVis, N * 4}};
+  for (auto& a : allocs) if ((rc = dev_alloc(c, *a.b, a.bytes))) { hydra_hip_mmlt_end(c); return rc; }
+  HCHECK(hipMemsetAsync(m.image.p, 0, size_t(c->w) * c->h * 16, c->stream));
+  HCHECK(hipMemsetAsync(m.xCur.p, 0, N * mmltStride(maxD) * 4, c->stream));
+  HCHECK(hipMemsetAsync(m.xNew.p, 0, N * mmltStride(maxD) * 4, c->stream));
+  const MmltChains ch = mmlt_chains(c);
+  const MmltBufs b = mmlt_run_bufs(c);
+  const SceneDev s = make_scene(c);
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(k_mmlt_init_chains, grid, block, 0, c->stream, ch, seed);
+  // average brightness of the paths of every length: estimate_passes x n fresh samples of F per d, each weighted by its selector's 1/pdf = d + 1
+  for (int d = 0; d <= maxD + 1; d++) m.avgB[d] = 0.0f;
+  for (int pass = 0; pass < estimate_passes; pass++) {
+    for (int d = first; d <= maxD; d++) {
+      hipLaunchKernelGGL(k_mmlt_pick_depth, grid, block, 0, c->stream, ch, (int*)m.depth.p, (const float*)nullptr, 0, d);
+      hipLaunchKernelGGL(k_mmlt_fresh, grid, block, 0, c->stream, ch);
+      if ((rc = mmlt_eval(c, s, b, d))) return rc;
+      HCHECK(hipMemsetAsync(m.sum.p, 0, 8, c->stream));
+      hipLaunchKernelGGL(k_mmlt_sum, dim3(256), dim3(256), 0, c->stream, n, (const float*)m.out8.p, 8, 7, (double*)m.sum.p);
+      double sum = 0.0;
+      HCHECK(hipMemcpyAsync(&sum, m.sum.p, 8, hipMemcpyDeviceToHost, c->stream));
+      HCHECK(hipStreamSynchronize(c->stream));
+      m.avgB[d] += float(sum * double(d + 1));
+    }
+  }
+  m.avgBrightness = 0.0f;
+  std::vector<float> accum(size_t(maxD) + 2, 0.0f);   // PrefixSumm(m_avgBPerBounce), :317-328
+  float acc = 0.0f;
+  for (int d = 0; d <= maxD; d++) {
+    m.avgB[d] *= 1.0f / float(size_t(estimate_passes) * N);
+    m.avgBrightness += m.avgB[d];
+    accum[d] = acc;
+    acc += m.avgB[d];
+  }
+  accum[size_t(maxD) + 1] = acc;
+  if (!(m.avgBrightness > 0.0f)) {
+    std::string per = "";
+    for (int d = first; d <= maxD; d++) per += (d > first ? ", " : "") + std::to_string(m.avgB[d]);
+    hydra_hip_mmlt_end(c);
+    return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: no light reaches the camera on paths of the requested lengths (average brightness per length: " + per + ")");
+  }
+  HCHECK(hipMemcpyAsync(m.accum.p, accum.data(), accum.size() * 4, hipMemcpyHostToDevice, c->stream));
+  // every chain: its path length, a fresh sample, F of it
+  hipLaunchKernelGGL(k_mmlt_pick_depth, grid, block, 0, c->stream, ch, (int*)m.depth.p, (const float*)m.accum.p, maxD + 2, 0);
+  hipLaunchKernelGGL(k_mmlt_fresh, grid, block, 0, c->stream, ch);
+  if ((rc = mmlt_eval(c, s, b, maxD))) return rc;
+  hipLaunchKernelGGL(k_mmlt_seed, grid, block, 0, c->stream, ch, (const float*)m.out8.p);
+  STAGE_EPILOG();
+  m.active = true; m.mutations = 0;
+  return HYDRA_HIP_OK;
+}
+// `mutations` steps of every chain: propose, F, accept / reject, two contributions to the indirect image (DoPassIndirectMLT :379-447)
+int hydra_hip_mmlt_pass(hydra_hip_handle c, int mutations) {
+  if (!c || mutations <= 0) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_pass: call mmlt_begin first");
+  HCHECK(hipSetDevice(c->device));
+  auto& m = c->mmlt;
+  const MmltChains ch = mmlt_chains(c);
+  const MmltBufs b = mmlt_run_bufs(c);
+  const SceneDev s = make_scene(c);
+  const dim3 grid((m.n + 255) / 256), block(256);
+  for (int k = 0; k < mutations; k++) {
+    hipLaunchKernelGGL(k_mmlt_mutate, grid, block, 0, c->stream, ch);
+    const int rc = mmlt_eval(c, s, b, m.maxD);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mmlt_accept, grid, block, 0, c->stream, ch, (const float*)m.out8.p, 1.0f, (float*)m.image.p, c->w);
+  }
+  HCHECK(hipGetLastError());
+  m.mutations += (unsigned long long)mutations * (unsigned long long)m.n;
+  return HYDRA_HIP_OK;
+}
+// image4 = kScale x the indirect image (GetImageHDR :616-635 without the direct part; kScale = EstimateScaleCoeff :548-552);
+// info8 = average brightness, kScale, acceptance rate, mutations so far, chains, first bounce, max depth, 0
+int hydra_hip_mmlt_get_image(hydra_hip_handle c, float* image4, float* info8) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_get_image: call mmlt_begin first");
+  HCHECK(hipSetDevice(c->device));
+  auto& m = c->mmlt;
+  const int npix = c->w * c->h;
+  double sums[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++) {
+    HCHECK(hipMemsetAsync(m.sum.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_mmlt_sum, dim3(256), dim3(256), 0, c->stream, npix, (const float*)m.image.p, 4, k, (double*)m.sum.p);
+    HCHECK(hipMemcpyAsync(&sums[k], m.sum.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HCHECK(hipStreamSynchronize(c->stream));
+  }
+  float avgB = fmaxf(0.33334f * float((sums[0] + sums[1] + sums[2]) / double(npix)), 0.0f);   // EstimateAverageBrightness2, :26-33
+  if (avgB < 1e-20f) avgB = 1e-20f;
+  const float kScale = m.avgBrightness / avgB;
+  double accepted = 0.0;
+  HCHECK(hipMemsetAsync(m.sum.p, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_mmlt_sum, dim3(256), dim3(256), 0, c->stream, m.n, (const float*)m.ch.p + size_t(CH_ACCEPTED) * m.n, 1, 0, (double*)m.sum.p);
+  HCHECK(hipMemcpyAsync(&accepted, m.sum.p, 8, hipMemcpyDeviceToHost, c->stream));
+  if (image4) {
+    hipLaunchKernelGGL(k_mmlt_scale_image, dim3((npix + 255) / 256), dim3(256), 0, c->stream, npix, (const float4*)m.image.p, kScale, (float4*)m.scaled.p);
+    HCHECK(hipMemcpyAsync(image4, m.scaled.p, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
+  }
+  HCHECK(hipStreamSynchronize(c->stream));
+  if (info8) {
+    info8[0] = m.avgBrightness; info8[1] = kScale; info8[2] = m.mutations ? float(accepted / double(m.mutations)) : 0.0f; info8[3] = float(m.mutations);
+    info8[4] = float(m.n); info8[5] = float(m.firstBounce); info8[6] = float(m.maxD); info8[7] = 0.0f;
+  }
+  return HYDRA_HIP_OK;
+}
+// test hook: chain planes (CH_PLANES x n), path lengths (n) and current x vectors (n rows of 12 + 10 * maxD), average brightness per length (maxD + 1)
+int hydra_hip_mmlt_get_state(hydra_hip_handle c, float* chains, int32_t* depth, float* xrows, float* avg_b) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_get_state: call mmlt_begin first");
+  HCHECK(hipSetDevice(c->device));
+  auto& m = c->mmlt;
+  HCHECK(hipStreamSynchronize(c->stream));
+  if (chains) HCHECK(hipMemcpy(chains, m.ch.p, size_t(m.n) * CH_PLANES * 4, hipMemcpyDeviceToHost));
+  if (depth) HCHECK(hipMemcpy(depth, m.depth.p, size_t(m.n) * 4, hipMemcpyDeviceToHost));
+  if (xrows) {
+    const int stride = mmltStride(m.maxD);
+    std::vector<float> planes(size_t(m.n) * stride);
+    HCHECK(hipMemcpy(planes.data(), m.xCur.p, planes.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m.n; i++) for (int j = 0; j < stride; j++) xrows[size_t(i) * stride + j] = planes[size_t(j) * m.n + i];
+  }
+  if (avg_b) for (int d = 0; d <= m.maxD; d++) avg_b[d] = m.avgB[d];
+  return HYDRA_HIP_OK;
+}
+
 int hydra_hip_stage_mmlt_f(hydra_hip_handle c, int n, const int32_t* depth, const float* xvec, int stride, float* out8) {
   STAGE_PROLOG(true);
   if (!depth || !xvec || !out8) return fail(c, HYDRA_HIP_EINVAL, "stage_mmlt_f: null argument");
+  if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "stage_mmlt_f: the globals header holds no camera yet (SetCamMatrices + PrepareEngineGlobals)");
   int maxD = 0;
   for (int i = 0; i < n; i++) {
     if (depth[i] < 1 || depth[i] > HK_MMLT_MAX_DEPTH || stride < HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * depth[i]) return fail(c, HYDRA_HIP_EINVAL, "stage_mmlt_f: depth must be 1..16 and stride >= 12 + 10 * depth");

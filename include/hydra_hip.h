@@ -212,6 +212,24 @@ int hydra_hip_stage_light_pdf_fwd(hydra_hip_handle h, int n, const int32_t* ligh
 int hydra_hip_stage_camera_connect(hydra_hip_handle h, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
 /* MutateKelemen (crandom.h:189-210): primary-space values + 2 randoms each, step parameters p2 < p1 (defaults 64, 1024) */
 int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* values, const float* rands2, float p2, float p1, float* out);
+/* ---- IntegratorMMLT (row f3; hydra_drv/CPUExp_Integrators_MMLT.cpp): multiplexed MLT over the simplified bidirectional sampler --------------
+ * The reference runs 8 chains (one per OpenMP thread, :583-585) of width*height mutations per pass; here every chain is a GPU thread and a
+ * pass advances all of them together: mutate (MutatePrimarySpace :93-144), F (:146-315) through the traversal kernels, accept / reject with
+ * the two expected-value contributions (:379-447, atomic adds into one float4 image).  The clock()-driven stirring of the generators
+ * (:97-103, :362-368) is not reproduced: a run is a function of (scene, chains, seed).
+ * mmlt_begin: DoPassEstimateAvgBrightness (:463-520, estimate_passes x chains samples per path length; 0 = 4 passes), then for every chain
+ *   its path length d ~ average brightness (:348-356), a fresh sample (InitialSamplePS :51-57) and F of it.  first_bounce / max_depth 0 =
+ *   varsI[HRT_MMLT_FIRST_BOUNCE] clamped to 2..3 (:481-483) / varsI[HRT_TRACE_DEPTH]; shorter paths are the direct-light pass's
+ *   (DoPassDirectLight :522-546 = the path tracer of this layer at trace depth first_bounce - 1).
+ * mmlt_pass: `mutations` steps of every chain.  mmlt_get_image: kScale x indirect image (GetImageHDR :616-635, EstimateScaleCoeff :548-552),
+ *   info8 = average brightness, kScale, acceptance rate, mutations so far, chains, first bounce, max depth, 0.
+ * mmlt_get_state (test hook): chain planes [11][chains] (y, colour, pixel, two generators, accepted), d per chain, current x vectors as rows of
+ *   12 + 10 * max_depth floats, average brightness per path length [max_depth + 1]; any pointer may be null. */
+int hydra_hip_mmlt_begin(hydra_hip_handle h, int chains, int seed, int first_bounce, int max_depth, int estimate_passes);
+int hydra_hip_mmlt_pass(hydra_hip_handle h, int mutations);
+int hydra_hip_mmlt_get_image(hydra_hip_handle h, float* image4, float* info8);
+int hydra_hip_mmlt_get_state(hydra_hip_handle h, float* chains, int32_t* depth, float* xrows, float* avg_b);
+int hydra_hip_mmlt_end(hydra_hip_handle h);
 /* IntegratorMMLT::F (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315; sub-paths :637-929, connections :931-1047 + cbidir.h:190-477): the
  * contribution of n primary-sample vectors.  xvec = n rows of `stride` floats laid out as the reference's PSSampleV (cglobals.h:102-128:
  * lens 0..3, light 4..10, split 11, then 10 floats per bounce, light part first), depth[i] = d (path length in segments, 1..16),

@@ -2385,6 +2385,77 @@ void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xve
   for (int i = 0; i < n; i++) mmltF(s, xvec + (size_t)i * stride, depth[i], out8 + 8 * (size_t)i);
 }
 
+/* The Markov chains: InitialSamplePS :51-57, MutatePrimarySpace :93-144 (MutateLightPart :59-73, MutateCameraPart :75-90), the accept /
+ * contribute loop of DoPassIndirectMLT :379-447, for n independent chains (the HIP layer runs one chain per GPU thread; the reference one
+ * per OpenMP thread).  gens4[i] = the two generator states of chain i (mutations, accept tests), in and out; xrows[i] = its current x vector
+ * (stride floats), in and out; depth[i] = its d.  The clock()-driven stirring (:97-103, :362-368) is left out.  Outputs: image4 (w*h*4,
+ * contributions added), chains6 = y, colour, pixel x, y per chain, accepted = count per chain. */
+static float mutateKelemen1(float x, float r0, float r1, float p2, float p1) { float v = x, rr[2] = {r0, r1}, o; orc_mutate_kelemen(1, &v, rr, p2, p1, &o); return o; }
+void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int32_t* accepted) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n; i++) {
+    uint32_t* gen = gens4 + 4 * (size_t)i;
+    uint32_t* gen2 = gen + 2;
+    const int d = depth[i], size = MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * d;
+    float xCur[MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * MMLT_MAX_DEPTH], xNew[MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * MMLT_MAX_DEPTH], o[8];
+    memcpy(xCur, xrows + (size_t)i * stride, sizeof(float) * (size_t)size);
+    mmltF(s, xCur, d, o);
+    float y = o[7], yColor[3] = {o[0], o[1], o[2]};
+    int xScr = (int)o[3], yScr = (int)o[4], acc = 0;
+    for (int k = 0; k < mutations; k++) {
+      const float plarge = 0.33f, plight = 0.20f, pmultiChain = 0.16f;
+      const float selector = orc_rnd_float1(gen);
+      if (selector < plarge) { for (int j = 0; j < size; j++) xNew[j] = orc_rnd_float1(gen); }
+      else {
+        memcpy(xNew, xCur, sizeof(float) * (size_t)size);
+        const int currSplit = mapRndFloatToInt(xCur[MMLT_DIM_SPLIT], 0, d);
+        const int camBegin = MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * currSplit;
+        const int lightPart = (plarge < selector && selector <= plarge + plight + pmultiChain);
+        const int cameraPart = !(plarge < selector && selector <= plarge + plight);
+        if (lightPart) {
+          for (int j = 4; j < 10; j++) { const float r0 = orc_rnd_float1(gen), r1 = orc_rnd_float1(gen); xNew[j] = mutateKelemen1(xNew[j], r0, r1, 64.0f, 1024.0f); }
+          for (int j = MMLT_HEAD_TOTAL_SIZE; j < camBegin; j++) { const float r0 = orc_rnd_float1(gen), r1 = orc_rnd_float1(gen); xNew[j] = mutateKelemen1(xNew[j], r0, r1, 64.0f, 1024.0f); }
+        }
+        if (cameraPart) {
+          for (int j = 0; j < 4; j++) { const float r0 = orc_rnd_float1(gen), r1 = orc_rnd_float1(gen); xNew[j] = mutateKelemen1(xNew[j], r0, r1, j < 2 ? 128.0f : 64.0f, 1024.0f); }
+          for (int j = camBegin; j < size; j++) { const float r0 = orc_rnd_float1(gen), r1 = orc_rnd_float1(gen); xNew[j] = mutateKelemen1(xNew[j], r0, r1, 64.0f, 1024.0f); }
+        }
+      }
+      mmltF(s, xNew, d, o);
+      const float yNew = o[7], yOld = y;
+      const float yOldColor[3] = {yColor[0], yColor[1], yColor[2]};
+      const int xScrOld = xScr, yScrOld = yScr, xScrNew = (int)o[3], yScrNew = (int)o[4];
+      const float a = (yOld == 0.0f) ? 1.0f : fminf(1.0f, yNew / yOld);
+      const float p = orc_rnd_float1(gen2);
+      if (p <= a) { memcpy(xCur, xNew, sizeof(float) * (size_t)size); y = yNew; yColor[0] = o[0]; yColor[1] = o[1]; yColor[2] = o[2]; xScr = xScrNew; yScr = yScrNew; acc++; }
+      const float kx = (1.0f / fmaxf(yOld, 1e-6f)), ky = (1.0f / fmaxf(yNew, 1e-6f));
+      const float cX[3] = {yOldColor[0] * 1.0f * kx * (1.0f - a), yOldColor[1] * 1.0f * kx * (1.0f - a), yOldColor[2] * 1.0f * kx * (1.0f - a)};
+      const float cY[3] = {o[0] * 1.0f * ky * a, o[1] * 1.0f * ky * a, o[2] * 1.0f * ky * a};
+      if (cX[0] * cX[0] + cX[1] * cX[1] + cX[2] * cX[2] > 1e-12f) {
+        float* px = image4 + 4 * (size_t)(yScrOld * w + xScrOld);
+        for (int q = 0; q < 3; q++) {
+#pragma omp atomic
+          px[q] += cX[q];
+        }
+#pragma omp atomic
+        px[3] += (1.0f - a);
+      }
+      if (cY[0] * cY[0] + cY[1] * cY[1] + cY[2] * cY[2] > 1e-12f) {
+        float* px = image4 + 4 * (size_t)(yScrNew * w + xScrNew);
+        for (int q = 0; q < 3; q++) {
+#pragma omp atomic
+          px[q] += cY[q];
+        }
+#pragma omp atomic
+        px[3] += a;
+      }
+    }
+    if (chains6) { float* c6 = chains6 + 6 * (size_t)i; c6[0] = y; c6[1] = yColor[0]; c6[2] = yColor[1]; c6[3] = yColor[2]; c6[4] = (float)xScr; c6[5] = (float)yScr; }
+    memcpy(xrows + (size_t)i * stride, xCur, sizeof(float) * (size_t)size);
+    if (accepted) accepted[i] = acc;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------ P0: passes */
 /* generator of pixel i = RandomGenInit(seed + i): the per-slot seeding of the reference's wavefront layer
  * (shaders/trace.cl:6-13 InitRandomGen) with slot = pixel, instead of the CPU layer's per-OpenMP-thread generators

@@ -85,6 +85,8 @@ void orc_camera_connect(const OrcScene* s, int n, const float* pos4, const float
 void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p2, float p1, float* out);
 /* IntegratorMMLT::F (CPUExp_Integrators_MMLT.cpp:146-315): n primary-sample vectors of `stride` floats, path length depth[i] -> out8 = colour, x, y, split, MIS weight, contribFunc */
 void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xvec, int stride, float* out8);
+/* n Markov chains of IntegratorMMLT (DoPassIndirectMLT :358-461): `mutations` mutate / F / accept steps each from the given states */
+void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int32_t* accepted);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -149,4 +149,39 @@ void emu_mmlt_f(const EmuScene* e, int n, const int* depth, const float* xvec, i
   for (int i = 0; i < n; i++) mmltConnectEnd(s, v, i);
 }
 
+// the Markov chains through hk_bidir.h's chain functions (what k_mmlt_mutate / k_mmlt_accept run), F through emu_mmlt_f above
+void emu_mmlt_run(const EmuScene* e, int n, unsigned* gens4, const int* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int* accepted) {
+  int maxD = 1;
+  for (int i = 0; i < n; i++) maxD = depth[i] > maxD ? depth[i] : maxD;
+  const int planes = mmltStride(maxD);
+  std::vector<float> ch(size_t(CH_PLANES) * n, 0.0f), xCur(size_t(planes) * n, 0.0f), xNew(size_t(planes) * n, 0.0f), rows(size_t(n) * planes, 0.0f), out8(size_t(n) * 8);
+  MmltChains c;
+  c.n = n; c.maxD = maxD; c.ch = ch.data(); c.depth = depth; c.xCur = xCur.data(); c.xNew = xNew.data();
+  for (int i = 0; i < n; i++) {
+    mmltInitChain(c, i, 0);
+    RandomGen g; g.x = gens4[4 * i]; g.y = gens4[4 * i + 1]; mchSetGen(c, CH_GEN, i, g);
+    g.x = gens4[4 * i + 2]; g.y = gens4[4 * i + 3]; mchSetGen(c, CH_GEN2, i, g);
+    for (int j = 0; j < mmltStride(depth[i]); j++) { xCur[size_t(j) * n + i] = xrows[size_t(i) * stride + j]; xNew[size_t(j) * n + i] = xCur[size_t(j) * n + i]; }
+  }
+  auto evalNew = [&]() {
+    for (int i = 0; i < n; i++) for (int j = 0; j < planes; j++) rows[size_t(i) * planes + j] = xNew[size_t(j) * n + i];
+    emu_mmlt_f(e, n, depth, rows.data(), planes, out8.data());
+  };
+  evalNew();
+  for (int i = 0; i < n; i++) mmltSeedChain(c, i, out8.data());
+  for (int k = 0; k < mutations; k++) {
+    for (int i = 0; i < n; i++) mmltMutate(c, i);
+    evalNew();
+    for (int i = 0; i < n; i++) mmltAcceptReject(c, i, out8.data(), 1.0f, image4, w);
+  }
+  for (int i = 0; i < n; i++) {
+    float* c6 = chains6 + 6 * size_t(i);
+    c6[0] = mch(c, CH_Y, i); c6[1] = mch(c, CH_COLOR, i); c6[2] = mch(c, CH_COLOR + 1, i); c6[3] = mch(c, CH_COLOR + 2, i); c6[4] = mch(c, CH_XS, i); c6[5] = mch(c, CH_YS, i);
+    accepted[i] = int(mch(c, CH_ACCEPTED, i));
+    RandomGen g = mchGen(c, CH_GEN, i); gens4[4 * i] = g.x; gens4[4 * i + 1] = g.y;
+    g = mchGen(c, CH_GEN2, i); gens4[4 * i + 2] = g.x; gens4[4 * i + 3] = g.y;
+    for (int j = 0; j < mmltStride(depth[i]); j++) xrows[size_t(i) * stride + j] = xCur[size_t(j) * n + i];
+  }
+}
+
 }  // extern "C"

@@ -69,6 +69,7 @@ def main():
     lib.emu_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, i32, vp, vp]
     lib.emu_path_trace.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp]
     lib.emu_eye_rays.argtypes = [C.POINTER(OrcScene), i32, i32, i32, vp, vp, vp, vp]
+    lib.emu_mmlt_run.argtypes = [C.POINTER(OrcScene), i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.emu_mmlt_f.argtypes = [C.POINTER(OrcScene), i32, vp, vp, i32, vp]
     lib.emu_bidir.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
 
@@ -122,6 +123,16 @@ def main():
         mbad = ~np.isclose(mout, mref, rtol=2e-5, atol=1e-7)
         assert not mbad.any(), "MMLT F differs from the oracle on %s: %d values, rows %s" % (name, mbad.sum(), np.nonzero(mbad.any(axis=1))[0][:8])
         assert (mref[:, 7] > 0).mean() > 0.05, "MMLT F is zero nearly everywhere on " + name
+        # ... and the Markov chains (InitialSamplePS, MutatePrimarySpace, accept / contribute) against the oracle's, 5 steps of 512 chains
+        cd = mrng.integers(2, 5, 512).astype(np.int32)
+        g_o = orc.mmlt_chain_gens(len(cd), 31)
+        x_o = orc.mmlt_fresh(g_o, cd, 4)
+        g_e, x_e = g_o.copy(), x_o.copy()
+        img_o, ch_o, acc_o = orc.mmlt_run(cd, g_o, x_o, 5)
+        img_e, ch_e, acc_e = np.zeros((h, w, 4), np.float32), np.zeros((len(cd), 6), np.float32), np.zeros(len(cd), np.int32)
+        lib.emu_mmlt_run(C.byref(orc.s), len(cd), p(g_e), p(cd), 5, w, p(img_e), p(ch_e), p(x_e), x_e.shape[1], p(acc_e))
+        assert (g_e == g_o).all() and (acc_e == acc_o).all() and np.allclose(x_e, x_o, atol=1e-7), "chains differ from the oracle's on " + name
+        assert np.allclose(ch_e, ch_o, rtol=2e-5, atol=1e-7) and np.allclose(img_e, img_o, rtol=1e-4, atol=1e-6), "chain contributions differ on " + name
         # whole paths
         n = w * h
         ys, xs = np.divmod(np.arange(n), w)

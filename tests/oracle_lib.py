@@ -52,6 +52,7 @@ def load():
     lib.orc_camera_connect.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_mutate_kelemen.argtypes = [i32, vp, vp, C.c_float, C.c_float, vp]
     lib.orc_mmlt_f.argtypes = [sp, i32, vp, vp, i32, vp]
+    lib.orc_mmlt_run.argtypes = [sp, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
     lib.orc_collect_rays.restype = C.c_int64
@@ -192,6 +193,33 @@ class Oracle:
         out = np.zeros((d.size, 8), np.float32)
         self.lib.orc_mmlt_f(C.byref(self.s), d.size, _p(d), _p(x), x.shape[1], _p(out))
         return out
+
+    def mmlt_chain_gens(self, n, seed):
+        """generator states of n chains as the HIP layer seeds them: RandomGenInit(seed + 2i) for mutations, (seed + 2i + 1) for accept tests"""
+        g = np.zeros((n, 4), np.uint32)
+        for i in range(n):
+            self.lib.orc_random_init(int(seed + 2 * i), _p(g[i, 0:2]))
+            self.lib.orc_random_init(int(seed + 2 * i + 1), _p(g[i, 2:4]))
+        return g
+
+    def mmlt_fresh(self, gens4, depth, max_depth):
+        """InitialSamplePS for every chain: 12 + 10 d draws from its first generator (advanced in place)"""
+        x = np.zeros((len(depth), 12 + 10 * max_depth), np.float32)
+        for i, d in enumerate(depth):
+            st = np.ascontiguousarray(gens4[i, 0:2])
+            for j in range(12 + 10 * int(d)):
+                x[i, j] = self.lib.orc_rnd_float1(_p(st))
+            gens4[i, 0:2] = st
+        return x
+
+    def mmlt_run(self, depth, gens4, xrows, mutations):
+        """`mutations` steps of the chains from the given states -> (image (h, w, 4), chains (n, 6) = y, colour, pixel, accepted counts); gens4 and xrows advance in place"""
+        d = np.ascontiguousarray(depth, np.int32)
+        assert gens4.dtype == np.uint32 and gens4.flags.c_contiguous and xrows.dtype == np.float32 and xrows.flags.c_contiguous
+        img = np.zeros((self.h, self.w, 4), np.float32)
+        ch, acc = np.zeros((d.size, 6), np.float32), np.zeros(d.size, np.int32)
+        self.lib.orc_mmlt_run(C.byref(self.s), d.size, _p(gens4), _p(d), mutations, self.w, _p(img), _p(ch), _p(xrows), xrows.shape[1], _p(acc))
+        return img, ch, acc
 
     def path_trace(self, pos4, dir4, rng2):
         pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)

@@ -129,3 +129,36 @@ def test_energy_is_bounded_in_closed_box(t42_small):
     orc = make_oracle(b)
     img, _, _ = orc.render(4, seed=1)
     assert img[..., :3].max() <= 31.4 * 1.0001 and img[..., :3].min() >= 0.0
+
+
+def test_mmlt_chains_converge_to_the_path_tracer(built):
+    """row f3 property: the image the Markov chains of IntegratorMMLT build (paths of 2..4 segments, every split, MIS over the splits,
+    scaled by the separately estimated average brightness, CPUExp_Integrators_MMLT.cpp:358-461, 548-552) is the path tracer's image of
+    the same path lengths, PT(trace depth 4) - PT(trace depth 1)"""
+    from conftest import host_scene, make_oracle
+
+    def pt(depth, spp=192):
+        _, b = host_scene("test_42", 96, 96, depth, 0)          # the front end stores trace depth = depth + 1
+        return make_oracle(b).render(spp, seed=777)[0][..., :3]
+    ref = pt(3) - pt(0)
+    _, b = host_scene("test_42", 96, 96, 3, 0)
+    orc = make_oracle(b)
+    rng = np.random.default_rng(1)
+    avg = np.zeros(5)
+    for d in (2, 3, 4):       # DoPassEstimateAvgBrightness
+        x = rng.uniform(0, 1, (100000, 12 + 10 * d)).astype(np.float32)
+        avg[d] = orc.mmlt_f(np.full(len(x), d, np.int32), x)[:, 7].mean() * (d + 1)
+    assert abs(avg.sum() - (0.33334 * ref.sum(axis=2)).mean()) < 0.03 * avg.sum()      # sum over path lengths of E[F (d + 1)] = mean radiance
+    n = 4096
+    depth = rng.choice(5, size=n, p=avg / avg.sum()).astype(np.int32)
+    gens = orc.mmlt_chain_gens(n, 1234)
+    x = orc.mmlt_fresh(gens, depth, 4)
+    img, ch, acc = orc.mmlt_run(depth, gens, x, 400)
+    assert 0.5 < acc.mean() / 400 < 0.95
+    ind = img[..., :3] * (avg.sum() / (0.33334 * img[..., :3].sum(axis=2).mean()))
+
+    def down(a, f=8):
+        return a.reshape(96 // f, f, 96 // f, f, 3).mean(axis=(1, 3))
+    a, r = down(ind), down(ref)
+    assert np.corrcoef(a.ravel(), r.ravel())[0, 1] > 0.99
+    assert np.abs(a - r).sum() / r.sum() < 0.08
