@@ -186,6 +186,8 @@ def load_host_library():
     lib.hydra_host_get_buffer.restype = i32
     lib.hydra_host_hip_handle.argtypes = [vp]
     lib.hydra_host_hip_handle.restype = vp
+    lib.hydra_host_set_render_method.argtypes = [vp, C.c_char_p]
+    lib.hydra_host_set_render_method.restype = i32
     lib.hydra_host_draw.argtypes = [vp, i32, i32]
     lib.hydra_host_draw.restype = i32
     lib.hydra_host_get_hdr.argtypes = [vp, vp, i32, i32]
@@ -548,6 +550,12 @@ class HostScene:
 
     def unsupported(self):
         return self.lib.hydra_host_unsupported(self.p)
+
+    def set_method(self, method):
+        """'mmlt': HRT_ENABLE_MMLT in the layer's flags (RenderDriverRTE.cpp:196-202), every draw() pass is then the direct-light pass +
+        32 mutations of every Markov chain; anything else: the path tracer.  The accumulated image restarts."""
+        if self.lib.hydra_host_set_render_method(self.p, method.encode()) != 0:
+            raise HydraError("set_render_method: " + self.lib.hydra_host_last_error(self.p).decode())
 
     def log(self):
         return self.lib.hydra_host_log(self.p).decode()

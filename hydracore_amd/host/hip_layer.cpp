@@ -71,9 +71,36 @@ public:
     upload_remap();
   }
 
-  void InitPathTracing(int seed, std::vector<int32_t>* = nullptr) override { check(hydra_hip_init_path_tracing(m_h, seed), "InitPathTracing"); }
-  void ClearAccumulatedColor() override { check(hydra_hip_clear_accumulated_color(m_h), "ClearAccumulatedColor"); }
-  void BeginTracingPass() override { check(hydra_hip_trace_pass(m_h, GetRaysPerPixel()), "BeginTracingPass"); }
+  void InitPathTracing(int seed, std::vector<int32_t>* = nullptr) override { m_mmltSeed = seed; MLT_Free(); check(hydra_hip_init_path_tracing(m_h, seed), "InitPathTracing"); }
+  void ClearAccumulatedColor() override { MLT_Free(); check(hydra_hip_clear_accumulated_color(m_h), "ClearAccumulatedColor"); }
+  // HRT_ENABLE_MMLT (cglobals.h:419, set by RenderDriverRTE::UpdateSettings for method_secondary = "mmlt", RenderDriverRTE.cpp:196-202):
+  // the pass is the reference layer's DL_Pass + MMLT_Pass (GPUOCLLayer.cpp:1368-1375): the path tracer limited to the paths
+  // shorter than HRT_MMLT_FIRST_BOUNCE for the direct part, then NUM_MMLT_PASS (= 32, GPUOCLLayer.h:681) mutations of every chain.
+  // Chains: the init flags' GPU_MMLT_THREADS_* (GPUOCLLayer.cpp:859-870), 524 288 without one.
+  void BeginTracingPass() override {
+    if ((m_vars.m_flags & HF_ENABLE_MMLT) == 0) { check(hydra_hip_trace_pass(m_h, GetRaysPerPixel()), "BeginTracingPass"); return; }
+    int first = m_vars.m_varsI[HV_I_MMLT_FIRST_BOUNCE];
+    first = first > 3 ? 3 : (first < 2 ? 2 : first);
+    const int maxDepth = m_vars.m_varsI[HV_I_TRACE_DEPTH];
+    if (!m_tablesUploaded || m_cdataPrepared.empty()) RunTimeError("HipHWLayer::BeginTracingPass(MMLT): EngineGlobals were not prepared");
+    {   // direct part: paths of fewer than `first` segments
+      std::vector<int32_t> hdr(m_cdataPrepared.begin(), m_cdataPrepared.begin() + HG_TABLES_READY + 1);
+      hdr[HG_VARS_I + HV_I_TRACE_DEPTH] = first - 1;
+      check(hydra_hip_update_globals_header(m_h, hdr.data(), HG_TABLES_READY + 1), "BeginTracingPass(MMLT direct)");
+      check(hydra_hip_trace_pass(m_h, GetRaysPerPixel()), "BeginTracingPass(MMLT direct)");
+      check(hydra_hip_update_globals_header(m_h, m_cdataPrepared.data(), HG_TABLES_READY + 1), "BeginTracingPass(MMLT direct)");
+    }
+    if (!m_mmltRunning) {
+      int chains = 524288;
+      if (m_initFlags & 65536) chains = 262144; else if (m_initFlags & 65536 * 2) chains = 131072; else if (m_initFlags & 65536 * 4) chains = 65536; else if (m_initFlags & 65536 * 8) chains = 16384;
+      check(hydra_hip_mmlt_begin(m_h, chains, m_mmltSeed, first, maxDepth, 0), "BeginTracingPass(MMLT begin)");
+      m_mmltRunning = true;
+    }
+    check(hydra_hip_mmlt_pass(m_h, 32), "BeginTracingPass(MMLT)");
+  }
+  bool   MLT_IsAllocated() const override { return m_mmltRunning; }
+  size_t MLT_Alloc(int, int, int) override { return 0; }   // the run allocates with its first pass, when the chain count and path lengths are known
+  void   MLT_Free() override { if (m_mmltRunning) { hydra_hip_mmlt_end(m_h); m_mmltRunning = false; } }
   // with a shared accumulation image attached, every pass ends by adding its samples to it (the reference's layers do
   // this inside their per-pass contribution, GPUOCLLayerOther.cpp:259-283)
   void EndTracingPass() override { if (m_pExternalImage != nullptr) ContribToExternalImageAccumulator(m_pExternalImage); }
@@ -89,7 +116,15 @@ public:
     return st;
   }
   // size mismatch: silently return, as CPUExpLayer does (hydra_drv/CPUExpLayer.cpp:133-147)
-  void GetHDRImage(float4* data, int width, int height) const override { hydra_hip_get_hdr_image(m_h, &data->x, width, height); }
+  // with MMLT running: direct (path tracer's mean) + kScale x indirect (IntegratorMMLT::GetImageHDR, CPUExp_Integrators_MMLT.cpp:616-635)
+  void GetHDRImage(float4* data, int width, int height) const override {
+    hydra_hip_get_hdr_image(m_h, &data->x, width, height);
+    if (!m_mmltRunning || width != m_width || height != m_height) return;
+    std::vector<float> ind(size_t(width) * height * 4);
+    float info[8];
+    if (hydra_hip_mmlt_get_image(m_h, ind.data(), info) != HYDRA_HIP_OK) return;
+    for (size_t i = 0; i < size_t(width) * height; i++) { data[i].x += ind[4 * i]; data[i].y += ind[4 * i + 1]; data[i].z += ind[4 * i + 2]; }
+  }
   void GetLDRImage(uint32_t* data, int width, int height) const override { hydra_hip_get_ldr_image(m_h, data, width, height); }
   float GetSPP() const override { return hydra_hip_get_spp(m_h); }
 
@@ -128,6 +163,8 @@ private:
   hydra_hip_handle m_h;
   char m_devName[256] = {0};
   bool m_tablesUploaded = false;
+  bool m_mmltRunning = false;
+  int m_mmltSeed = 777;
   int m_spp = 1;
   float m_sppContrib = 0.0f;
   std::vector<float> m_sums;

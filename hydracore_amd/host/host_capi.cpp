@@ -115,6 +115,24 @@ int hydra_host_have_inst_tree(void* p, int tree) {
 void* hydra_host_hip_handle(void* p) { return HipLayerHandle(static_cast<HostScene*>(p)->drv->Layer()); }
 
 // RenderDriverRTE::Draw, `passes` times with `spp` samples per pixel each
+// "mmlt" sets HRT_ENABLE_MMLT in the layer's flags, anything else clears it (what RenderDriverRTE::UpdateSettings does for
+// <method_secondary>, RenderDriverRTE.cpp:196-202); the accumulated image restarts
+int hydra_host_set_render_method(void* p, const char* method) {
+  HostScene* s = static_cast<HostScene*>(p);
+  try {
+    IHWLayer* L = s->drv->Layer();
+    auto vars = L->GetAllFlagsAndVars();
+    const std::string m = method ? method : "";
+    if (m == "mmlt" || m == "MMLT" || m == "mlt") vars.m_flags |= HF_ENABLE_MMLT; else vars.m_flags &= ~unsigned(HF_ENABLE_MMLT);
+    L->SetAllFlagsAndVars(vars);
+    L->ClearAccumulatedColor();
+    return 0;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return -1;
+  }
+}
+
 int hydra_host_draw(void* p, int passes, int spp) {
   HostScene* s = static_cast<HostScene*>(p);
   try {

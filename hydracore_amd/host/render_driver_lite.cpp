@@ -770,6 +770,11 @@ bool RenderDriverLite::UpdateSettings(const XmlNode* st) {
   vars.m_varsF[3 /*HRT_TRACE_PROCEEDINGS_TRESHOLD*/] = 1e-8f;
   vars.m_varsF[16 /*HRT_PATH_TRACE_CLAMPING*/] = 1e6f;
   vars.m_varsI[33 /*HRT_MMLT_BURN_ITERS*/] = 1024;
+  vars.m_varsI[HV_I_MMLT_FIRST_BOUNCE] = 3;   // RenderDriverRTE.cpp:263
+  {   // RenderDriverRTE.cpp:196-202
+    const std::string ms = xtext(xchild(st, "method_secondary"));
+    if (ms == "mmlt" || ms == "MMLT" || ms == "mlt") vars.m_flags |= HF_ENABLE_MMLT; else vars.m_flags &= ~unsigned(HF_ENABLE_MMLT);
+  }
   if (xchild(st, "outgamma")) vars.m_varsF[HV_F_IMAGE_GAMMA] = strtof(xtext(xchild(st, "outgamma")).c_str(), nullptr);
   if (xchild(st, "trace_depth")) vars.m_varsI[HV_I_TRACE_DEPTH] = atoi(xtext(xchild(st, "trace_depth")).c_str()) + 1;
   if (xchild(st, "diff_trace_depth")) vars.m_varsI[HV_I_DIFFUSE_TRACE_DEPTH] = atoi(xtext(xchild(st, "diff_trace_depth")).c_str()) + 1;

@@ -86,6 +86,7 @@ enum {
 enum {
   HF_COMPUTE_SHADOWS    = 1,
   HF_USE_MIS            = 32,
+  HF_ENABLE_MMLT        = 16384,        /* HRT_ENABLE_MMLT, cglobals.h:419 */
   HF_STUPID_PT_MODE     = 65536 * 8,
   HF_ENABLE_PT_CAUSTICS = 65536 * 2048
 };

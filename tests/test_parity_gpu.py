@@ -361,6 +361,30 @@ def test_mmlt_image_converges_to_the_path_tracer(gpu42):
     assert np.abs(a - r).sum() / r.sum() < 0.08
 
 
+def test_mmlt_through_the_ihwlayer_adapter(built):
+    """row f3 behind the boundary: with HRT_ENABLE_MMLT in the layer's flags (the reference's <method_secondary>mmlt) every
+    BeginTracingPass of the adapter is the direct-light pass + 32 mutations per chain (GPUOCLLayer.cpp:1368-1375) and GetHDRImage
+    returns direct + scaled indirect; the frame must converge to the path tracer's frame of the same scene"""
+    from hydracore_amd import HostScene
+    sc = HostScene(scene_path("test_42"), 128, 128, trace_depth=4, enable_dof=0, use_hip=True, device=0, seed=777)
+    sc.draw(passes=8, spp=64)
+    pt = sc.hdr_image()[..., :3].copy()
+    sc.set_method("mmlt")
+    sc.draw(passes=12, spp=16)
+    mm = sc.hdr_image()[..., :3].copy()
+    sc.set_method("pt")
+    sc.draw(passes=1, spp=4)                       # back to the path tracer: the chains are gone, the image restarts
+    again = sc.hdr_image()[..., :3].copy()
+    sc.close()
+
+    def down(a, f=8):
+        return a.reshape(128 // f, f, 128 // f, f, 3).mean(axis=(1, 3))
+    assert abs(mm.mean() - pt.mean()) < 0.04 * pt.mean()
+    assert np.corrcoef(down(mm).ravel(), down(pt).ravel())[0, 1] > 0.995
+    assert np.abs(down(mm) - down(pt)).sum() / down(pt).sum() < 0.06
+    assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
+
+
 @pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
