@@ -52,7 +52,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image",
-    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image",
 ]
 
 _hip = None
@@ -131,6 +131,8 @@ def load_hip_library():
         "hydra_hip_mmlt_get_image": ([vp, vp, vp], i32),
         "hydra_hip_mmlt_get_state": ([vp, vp, vp, vp, vp], i32),
         "hydra_hip_mmlt_end": ([vp], i32),
+        "hydra_hip_sbdpt_pass": ([vp, i32], i32),
+        "hydra_hip_sbdpt_get_image": ([vp, vp, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -505,6 +507,14 @@ class HipCore:
         ch, depth, x, avg = np.zeros((11, n), np.float32), np.zeros(n, np.int32), np.zeros((n, 12 + 10 * max_d), np.float32), np.zeros(max_d + 1, np.float32)
         self._ck(self.lib.hydra_hip_mmlt_get_state(self.h, _ptr(ch), _ptr(depth), _ptr(x), _ptr(avg)), "mmlt_get_state")
         return ch, depth, x, avg
+
+    def sbdpt_pass(self, passes=1):
+        self._ck(self.lib.hydra_hip_sbdpt_pass(self.h, passes), "sbdpt_pass")
+
+    def sbdpt_image(self, width, height):
+        img, n = np.zeros((height, width, 4), np.float32), C.c_double(0)
+        self._ck(self.lib.hydra_hip_sbdpt_get_image(self.h, _ptr(img), C.byref(n)), "sbdpt_get_image")
+        return img, n.value
 
     def mmlt_end(self):
         self._ck(self.lib.hydra_hip_mmlt_end(self.h), "mmlt_end")

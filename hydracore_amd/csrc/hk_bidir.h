@@ -741,3 +741,28 @@ HK_DEV void mmltAcceptReject(const MmltChains& c, int i, const float* out8, floa
     hk_atomic_add(px + 0, contribAtY.x); hk_atomic_add(px + 1, contribAtY.y); hk_atomic_add(px + 2, contribAtY.z); hk_atomic_add(px + 3, a);
   }
 }
+
+// ================================================================================================ IntegratorSBDPT::DoPass through F
+// The stochastic-connection bidirectional pass (hydra_drv/CPUExp_Integrators_SBDPT.cpp:11-216): every sample picks a path length d uniformly in
+// 2..maxDepth (:21) and a split uniformly in 0..d (:22), builds the two sub-paths, connects, weights by MIS over the splits and by the selector's
+// 1/pdf = (d + 1)(maxDepth - 1) (:24), and splats.  Its sub-path, connection and MIS code is IntegratorMMLT's (the reference keeps two copies),
+// so a sample here is F of a fresh primary-sample vector: the split comes from x[MMLT_DIM_SPLIT] and the pixel from the lens dimensions instead of
+// rndInt draws (:22, :40-41) -- the same estimator with its random numbers laid out as MMLT's.
+HK_DEV int rndIntFromFloat(float r, int a, int b) {   // crandom.h:594-606: integers a .. b-1
+  const int res = int(float(a) + r * (float(b) - float(a)));
+  return (res > b - 1) ? b - 1 : res;
+}
+HK_DEV void sbdptPickDepth(const MmltChains& c, int i, int* depth, int maxDepth) {
+  RandomGen g = mchGen(c, CH_GEN, i);
+  depth[i] = rndIntFromFloat(rndFloat1_Pseudo(g), 2, maxDepth + 1);
+  mchSetGen(c, CH_GEN, i, g);
+}
+HK_DEV void sbdptSplat(int i, const int* depth, int maxDepth, const float* out8, float* image4, int w) {
+  const float* o = out8 + size_t(i) * 8;
+  const float selectorInvPdf = float((depth[i] + 1) * (maxDepth - 1));
+  const f3 c = mk3(o[0], o[1], o[2]) * selectorInvPdf;
+  if (dot(c, c) > 1e-20f) {
+    float* px = image4 + 4 * size_t(int(o[4]) * w + int(o[3]));
+    hk_atomic_add(px + 0, c.x); hk_atomic_add(px + 1, c.y); hk_atomic_add(px + 2, c.z);
+  }
+}

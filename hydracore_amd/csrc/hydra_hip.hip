@@ -877,6 +877,14 @@ __global__ void k_mmlt_accept(MmltChains c, const float* __restrict__ out8, floa
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < c.n) mmltAcceptReject(c, i, out8, bkScale, image4, w);
 }
+__global__ void k_sbdpt_pick_depth(MmltChains c, int* __restrict__ depth, int maxDepth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) sbdptPickDepth(c, i, depth, maxDepth);
+}
+__global__ void k_sbdpt_splat(int n, const int* __restrict__ depth, int maxDepth, const float* __restrict__ out8, float* __restrict__ image4, int w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sbdptSplat(i, depth, maxDepth, out8, image4, w);
+}
 __global__ void k_mmlt_sum(int n, const float* __restrict__ values, int stride, int offset, double* __restrict__ sum) {   // sum += values[i * stride + offset]
   __shared__ double part[256];
   double acc = 0.0;
@@ -988,6 +996,7 @@ struct hydra_hip_ctx {
     bool active = false;
     int n = 0, maxD = 0, firstBounce = 0;
     DevBuf ch, depth, xCur, xNew, out8, image, accum, sum, scaled;
+    DevBuf sbDepth, sbImage; unsigned long long sbSamples = 0;   // the SBDPT passes of the same run (hydra_hip_sbdpt_pass)
     DevBuf st, rayPos, rayDir, hits, eyePos, eyeDir, eyeHit, shPos, shDir, shVis;
     float avgB[HK_MMLT_MAX_DEPTH + 2] = {0};
     float avgBrightness = 0.0f;
@@ -2523,6 +2532,7 @@ static bool mmlt_camera_ready(const hydra_hip_ctx* c) {   // F projects light-pa
 int hydra_hip_mmlt_end(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   auto& m = c->mmlt;
+  dev_free(m.sbDepth); dev_free(m.sbImage); m.sbSamples = 0;
   DevBuf* all[] = {&m.ch, &m.depth, &m.xCur, &m.xNew, &m.out8, &m.image, &m.accum, &m.sum, &m.scaled, &m.st, &m.rayPos, &m.rayDir, &m.hits, &m.eyePos, &m.eyeDir, &m.eyeHit, &m.shPos, &m.shDir, &m.shVis};
   for (DevBuf* b : all) dev_free(*b);
   m.active = false; m.n = 0; m.mutations = 0;
@@ -2650,6 +2660,51 @@ int hydra_hip_mmlt_get_image(hydra_hip_handle c, float* image4, float* info8) {
     info8[0] = m.avgBrightness; info8[1] = kScale; info8[2] = m.mutations ? float(accepted / double(m.mutations)) : 0.0f; info8[3] = float(m.mutations);
     info8[4] = float(m.n); info8[5] = float(m.firstBounce); info8[6] = float(m.maxD); info8[7] = 0.0f;
   }
+  return HYDRA_HIP_OK;
+}
+// IntegratorSBDPT::DoPass (CPUExp_Integrators_SBDPT.cpp:11-216) on the buffers of the MMLT run: `passes` x chains samples, each a path
+// length drawn uniformly from 2..max_depth, a fresh primary-sample vector, F, a splat weighted by (d + 1)(max_depth - 1)
+int hydra_hip_sbdpt_pass(hydra_hip_handle c, int passes) {
+  if (!c || passes <= 0) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "sbdpt_pass: call mmlt_begin first (it owns the buffers and the generators)");
+  HCHECK(hipSetDevice(c->device));
+  auto& m = c->mmlt;
+  int rc;
+  if (m.sbImage.p == nullptr) {
+    if ((rc = dev_alloc(c, m.sbDepth, size_t(m.n) * 4)) || (rc = dev_alloc(c, m.sbImage, size_t(c->w) * c->h * 16))) return rc;
+    HCHECK(hipMemsetAsync(m.sbImage.p, 0, size_t(c->w) * c->h * 16, c->stream));
+    m.sbSamples = 0;
+  }
+  MmltChains ch = mmlt_chains(c);
+  ch.depth = (const int*)m.sbDepth.p;            // fresh samples are as long as this pass's d, not the chain's
+  MmltBufs b = mmlt_run_bufs(c);
+  b.v.depth = (const int*)m.sbDepth.p;
+  const SceneDev s = make_scene(c);
+  const dim3 grid((m.n + 255) / 256), block(256);
+  for (int k = 0; k < passes; k++) {
+    hipLaunchKernelGGL(k_sbdpt_pick_depth, grid, block, 0, c->stream, ch, (int*)m.sbDepth.p, m.maxD);
+    hipLaunchKernelGGL(k_mmlt_fresh, grid, block, 0, c->stream, ch);
+    if ((rc = mmlt_eval(c, s, b, m.maxD))) return rc;
+    hipLaunchKernelGGL(k_sbdpt_splat, grid, block, 0, c->stream, m.n, (const int*)m.sbDepth.p, m.maxD, (const float*)m.out8.p, (float*)m.sbImage.p, c->w);
+  }
+  HCHECK(hipGetLastError());
+  m.sbSamples += (unsigned long long)passes * (unsigned long long)m.n;
+  return HYDRA_HIP_OK;
+}
+// image4 = splats x width*height / samples (the reference's m_hdrData / spp with width*height samples per pass, :18-19, :192); samples so far
+int hydra_hip_sbdpt_get_image(hydra_hip_handle c, float* image4, double* samples) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active || c->mmlt.sbImage.p == nullptr) return fail(c, HYDRA_HIP_ESTATE, "sbdpt_get_image: no SBDPT pass has run");
+  HCHECK(hipSetDevice(c->device));
+  auto& m = c->mmlt;
+  const int npix = c->w * c->h;
+  if (image4) {
+    const float scale = m.sbSamples ? float(double(npix) / double(m.sbSamples)) : 0.0f;
+    hipLaunchKernelGGL(k_mmlt_scale_image, dim3((npix + 255) / 256), dim3(256), 0, c->stream, npix, (const float4*)m.sbImage.p, scale, (float4*)m.scaled.p);
+    HCHECK(hipMemcpyAsync(image4, m.scaled.p, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
+  }
+  HCHECK(hipStreamSynchronize(c->stream));
+  if (samples) *samples = double(m.sbSamples);
   return HYDRA_HIP_OK;
 }
 // test hook: chain planes (CH_PLANES x n), path lengths (n) and current x vectors (n rows of 12 + 10 * maxD), average brightness per length (maxD + 1)

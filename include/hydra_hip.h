@@ -230,6 +230,13 @@ int hydra_hip_mmlt_pass(hydra_hip_handle h, int mutations);
 int hydra_hip_mmlt_get_image(hydra_hip_handle h, float* image4, float* info8);
 int hydra_hip_mmlt_get_state(hydra_hip_handle h, float* chains, int32_t* depth, float* xrows, float* avg_b);
 int hydra_hip_mmlt_end(hydra_hip_handle h);
+/* IntegratorSBDPT::DoPass (hydra_drv/CPUExp_Integrators_SBDPT.cpp:11-216) on the buffers and generators of the MMLT run: `passes` x chains
+ * samples, each with a path length drawn uniformly from 2..max_depth (:21), a fresh primary-sample vector, F (the reference's SBDPT keeps its own
+ * copies of the sub-path / connection / MIS code of MMLT), and a splat weighted by the selector's (d + 1)(max_depth - 1) (:24).  Differs from the
+ * reference in where the split and the pixel come from (x[MMLT_DIM_SPLIT] and the lens dimensions instead of two rndInt draws, :22, :40-41).
+ * sbdpt_get_image: splats x width*height / samples (paths of 2..max_depth segments; directly visible emitters are not part of this pass). */
+int hydra_hip_sbdpt_pass(hydra_hip_handle h, int passes);
+int hydra_hip_sbdpt_get_image(hydra_hip_handle h, float* image4, double* samples);
 /* IntegratorMMLT::F (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315; sub-paths :637-929, connections :931-1047 + cbidir.h:190-477): the
  * contribution of n primary-sample vectors.  xvec = n rows of `stride` floats laid out as the reference's PSSampleV (cglobals.h:102-128:
  * lens 0..3, light 4..10, split 11, then 10 floats per bounce, light part first), depth[i] = d (path length in segments, 1..16),

@@ -2456,6 +2456,31 @@ void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* dept
   }
 }
 
+/* ref: CPUExp_Integrators_SBDPT.cpp:11-216 IntegratorSBDPT::DoPass expressed through F (its sub-path, connection and MIS code is IntegratorMMLT's):
+ * sample i draws d = rndInt(2, maxDepth + 1) (:21, crandom.h:594-611), then a fresh primary-sample vector, from gens4[i][0..1]; the split is
+ * x[MMLT_DIM_SPLIT] and the pixel comes from the lens dimensions (the reference draws both with rndInt, :22, :40-41); splat = F (d + 1)(maxDepth - 1) */
+void orc_sbdpt_pass(const OrcScene* s, int n, uint32_t* gens4, int maxDepth, int w, float* image4) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n; i++) {
+    uint32_t* gen = gens4 + 4 * (size_t)i;
+    const float r = orc_rnd_float1(gen);
+    int d = (int)(2.0f + r * ((float)(maxDepth + 1) - 2.0f));
+    if (d > maxDepth) d = maxDepth;
+    float x[MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * MMLT_MAX_DEPTH], o[8];
+    for (int j = 0; j < MMLT_HEAD_TOTAL_SIZE + MMLT_FLOATS_PER_BOUNCE * d; j++) x[j] = orc_rnd_float1(gen);
+    mmltF(s, x, d, o);
+    const float k = (float)((d + 1) * (maxDepth - 1));
+    const float c[3] = {o[0] * k, o[1] * k, o[2] * k};
+    if (c[0] * c[0] + c[1] * c[1] + c[2] * c[2] > 1e-20f) {
+      float* px = image4 + 4 * (size_t)((int)o[4] * w + (int)o[3]);
+      for (int q = 0; q < 3; q++) {
+#pragma omp atomic
+        px[q] += c[q];
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------ P0: passes */
 /* generator of pixel i = RandomGenInit(seed + i): the per-slot seeding of the reference's wavefront layer
  * (shaders/trace.cl:6-13 InitRandomGen) with slot = pixel, instead of the CPU layer's per-OpenMP-thread generators

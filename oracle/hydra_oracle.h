@@ -87,6 +87,8 @@ void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p
 void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xvec, int stride, float* out8);
 /* n Markov chains of IntegratorMMLT (DoPassIndirectMLT :358-461): `mutations` mutate / F / accept steps each from the given states */
 void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int32_t* accepted);
+/* IntegratorSBDPT::DoPass through F: n samples, generator of sample i = gens4[i][0..1] (advanced), image4 += splats */
+void orc_sbdpt_pass(const OrcScene* s, int n, uint32_t* gens4, int maxDepth, int w, float* image4);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

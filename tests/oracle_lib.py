@@ -52,6 +52,7 @@ def load():
     lib.orc_camera_connect.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_mutate_kelemen.argtypes = [i32, vp, vp, C.c_float, C.c_float, vp]
     lib.orc_mmlt_f.argtypes = [sp, i32, vp, vp, i32, vp]
+    lib.orc_sbdpt_pass.argtypes = [sp, i32, vp, i32, i32, vp]
     lib.orc_mmlt_run.argtypes = [sp, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
@@ -220,6 +221,14 @@ class Oracle:
         ch, acc = np.zeros((d.size, 6), np.float32), np.zeros(d.size, np.int32)
         self.lib.orc_mmlt_run(C.byref(self.s), d.size, _p(gens4), _p(d), mutations, self.w, _p(img), _p(ch), _p(xrows), xrows.shape[1], _p(acc))
         return img, ch, acc
+
+    def sbdpt_pass(self, gens4, max_depth, image=None):
+        """one IntegratorSBDPT pass of len(gens4) samples (generators advance in place); returns the splat image (h, w, 4)"""
+        assert gens4.dtype == np.uint32 and gens4.flags.c_contiguous
+        if image is None:
+            image = np.zeros((self.h, self.w, 4), np.float32)
+        self.lib.orc_sbdpt_pass(C.byref(self.s), len(gens4), _p(gens4), max_depth, self.w, _p(image))
+        return image
 
     def path_trace(self, pos4, dir4, rng2):
         pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)

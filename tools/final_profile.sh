@@ -14,4 +14,9 @@ done
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_bench_2x64spp.csv
 find $OUT/prof -name "*domain_stats.csv" | head -1 | xargs -I{} cp {} $OUT/domain_stats_bench_2x64spp.csv
 rm -rf $OUT/prof
+# row f3: throughput of the MMLT path and its kernel breakdown
+timeout -k 10 300 python tools/mmlt_bench.py > $OUT/mmlt_bench_test_42_1080p_1M_chains.log 2>&1; tail -1 $OUT/mmlt_bench_test_42_1080p_1M_chains.log | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mmlt -- python3 tools/mmlt_bench.py --passes 8 > $OUT/mmlt_bench_under_rocprof.log 2>&1
+find $OUT/prof_mmlt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_mmlt_8_passes.csv
+rm -rf $OUT/prof_mmlt
 ls $OUT
