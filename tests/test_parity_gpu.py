@@ -361,6 +361,40 @@ def test_mmlt_image_converges_to_the_path_tracer(gpu42):
     assert np.abs(a - r).sum() / r.sum() < 0.08
 
 
+def test_sbdpt_pass_follows_the_oracle_and_converges(gpu42):
+    """row f3, IntegratorSBDPT::DoPass through F: one pass of 16 384 samples against the oracle's pass from the same generator states,
+    then 40 passes against the path tracer's image of the same path lengths (2..4 segments)"""
+    core, b, orc = gpu42
+    w, h = b["width"], b["height"]
+    n = 16384
+    core.mmlt_begin(n, seed=31, first_bounce=2, max_depth=4, estimate_passes=1)
+    ch0, _, _, _ = core.mmlt_state()
+    gens = np.ascontiguousarray(ch0[6:10].T).view(np.uint32).copy()
+    core.sbdpt_pass(1)
+    img, samples = core.sbdpt_image(w, h)
+    assert samples == n
+    ref = orc.sbdpt_pass(gens, 4) * (w * h / n)
+    ch1, _, _, _ = core.mmlt_state()
+    assert (np.ascontiguousarray(ch1[6:8].T).view(np.uint32) == gens[:, 0:2]).all()          # same draws: d, then 12 + 10 d numbers
+    assert abs(img[..., :3].sum() - ref[..., :3].sum()) < 2e-3 * ref[..., :3].sum()
+    assert np.abs(img[..., :3] - ref[..., :3]).sum() < 0.01 * ref[..., :3].sum()             # a handful of samples may take another branch
+    core.sbdpt_pass(40)
+    img, samples = core.sbdpt_image(w, h)
+    core.mmlt_end()
+    from conftest import host_scene, make_oracle
+
+    def pt(depth):
+        _, bb = host_scene("test_42", w, h, depth, 1)
+        return make_oracle(bb).render(128, seed=777)[0][..., :3]
+    want = pt(3) - pt(0)
+
+    def down(a, f=8):
+        return a[:h // f * f, :w // f * f].reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
+    a, r = down(img[..., :3]), down(want)
+    assert abs(a.mean() - r.mean()) < 0.03 * r.mean()
+    assert np.corrcoef(a.ravel(), r.ravel())[0, 1] > 0.99
+
+
 def test_mmlt_through_the_ihwlayer_adapter(built):
     """row f3 behind the boundary: with HRT_ENABLE_MMLT in the layer's flags (the reference's <method_secondary>mmlt) every
     BeginTracingPass of the adapter is the direct-light pass + 32 mutations per chain (GPUOCLLayer.cpp:1368-1375) and GetHDRImage
