@@ -186,10 +186,10 @@ HK_DEV float MutateKelemen(float valueX, f2 rands, float p2, float p1) {
 #define HK_MMLT_PER_BOUNCE 10      // MMLT_FLOATS_PER_BOUNCE, cglobals.h:126-128
 enum {
   MP_S = 0, MP_BITS = 1, MP_X = 2, MP_Y = 3, MP_FLAGS = 4, MP_MIS_PDF = 5, MP_MIS_COS = 6,
-  MP_CV_GTERM = 7, MP_CV_DIR = 8, MP_CV_ACC = 11, MP_CV_HIT = 14,            // hit record: pos 3, normal 3, flat normal 3, uv 2, matId, t, sRayOff, hfi = 15 planes
-  MP_L_COLOR = 29, MP_L_COS = 32, MP_L_PDF = 33,
-  MP_LV_GTERM = 34, MP_LV_DIR = 35, MP_LV_ACC = 38, MP_LV_HIT = 41,
-  MP_NFAC = 56, MP_ZERO_FROM = 57, MP_LBITS = 58, MP_PDF = 59                // then 2 * (maxD + 1) pdf planes and 3 * maxD factor planes
+  MP_CV_GTERM = 7, MP_CV_DIR = 8, MP_CV_ACC = 11, MP_CV_HIT = 14,            // hit record: pos 3, normal 3, flat normal 3, uv 2, matId, t, sRayOff, hfi, tangent 3, bitangent 3 = 21 planes
+  MP_L_COLOR = 35, MP_L_COS = 38, MP_L_PDF = 39,
+  MP_LV_GTERM = 40, MP_LV_DIR = 41, MP_LV_ACC = 44, MP_LV_HIT = 47,
+  MP_NFAC = 68, MP_ZERO_FROM = 69, MP_LBITS = 70, MP_PDF = 71                // then 2 * (maxD + 1) pdf planes and 3 * maxD factor planes
 };
 // the camera and the light sub-path of a chain advance in different threads of one launch: each side owns its flag word (MP_BITS / MP_LBITS),
 // its rays and its pdf entries (camera: s+1..d, light: 0..s-1), so the two never write the same word
@@ -220,11 +220,12 @@ HK_DEV void mstoreHit(const MmltView& v, int plane, int i, const SurfaceHit& h) 
   mstSet3(v, plane, i, h.pos); mstSet3(v, plane + 3, i, h.normal); mstSet3(v, plane + 6, i, h.flatNormal);
   mst(v, plane + 9, i) = h.texCoord.x; mst(v, plane + 10, i) = h.texCoord.y;
   msti(v, plane + 11, i) = h.matId; mst(v, plane + 12, i) = h.t; mst(v, plane + 13, i) = h.sRayOff; msti(v, plane + 14, i) = h.hfi ? 1 : 0;
+  mstSet3(v, plane + 15, i, h.tangent); mstSet3(v, plane + 18, i, h.biTangent);
 }
 HK_DEV SurfaceHit mloadHit(const MmltView& v, int plane, int i) {
   SurfaceHit h;
   h.pos = mst3(v, plane, i); h.normal = mst3(v, plane + 3, i); h.flatNormal = mst3(v, plane + 6, i);
-  h.tangent = mk3(0, 0, 0); h.biTangent = mk3(0, 0, 0);
+  h.tangent = mst3(v, plane + 15, i); h.biTangent = mst3(v, plane + 18, i);
   h.texCoord = mk2(mst(v, plane + 9, i), mst(v, plane + 10, i));
   h.matId = msti(v, plane + 11, i); h.t = mst(v, plane + 12, i); h.sRayOff = mst(v, plane + 13, i); h.hfi = msti(v, plane + 14, i) != 0;
   return h;
@@ -273,7 +274,7 @@ HK_DEV int SelectRandomLightFwd(float r, const SceneDev& s, float& pickProb) {  
 }
 HK_DEV ShadeContext mmltShadeContext(const SurfaceHit& h, f3 l, f3 v) {
   ShadeContext sc;
-  sc.l = l; sc.v = v; sc.n = h.normal; sc.tc = h.texCoord; sc.fn = h.flatNormal;
+  sc.l = l; sc.v = v; sc.n = h.normal; sc.tc = h.texCoord; sc.fn = h.flatNormal; sc.tg = h.tangent; sc.bn = h.biTangent;
   return sc;
 }
 HK_DEV void mmltRands(const MmltView& v, int i, int base, float* rands) {   // RndMatAll with rptr set, crandom.h:478-494

@@ -147,6 +147,8 @@ struct SceneDev {
   const int*    matTable;      // material id -> arena offset in float4 units (cfetch.h:192-197)
   const float*  lightsBase;    // PlainLight[lightsNum], HL_FLOATS floats each (clight.h:1739-1749)
   const int*    texTable;      // texture id -> texture arena offset in int4 units (cfetch.h:141-145)
+  const int4*   texAuxStorage; // the second texture arena (normal maps, RenderDriverRTE_AuxTextures.cpp:195-216)
+  const int*    texAuxTable;   // aux texture id -> offset in it (textureAuxHeaderOffset, cfetch.h:147-151)
 };
 
 HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.globals + HG_VARS_F); }

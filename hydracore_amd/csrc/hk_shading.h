@@ -379,12 +379,48 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
-enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_ALL = 31 };
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_ALL = 63,
+       HK_FEAT_CLASSIC = 31 /* everything but normal maps */ };
 
 // ================================================================================================ materials
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
 struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
-struct ShadeContext { f3 l, v, n; f2 tc; f3 fn; };                          // cglobals.h:2282-2301 (fields used without normal maps; fn only by the light-tracing form of materialEval)
+struct ShadeContext { f3 l, v, n; f2 tc; f3 fn, tg, bn; };                  // cglobals.h:2282-2301 (fn: light-tracing form of materialEval and normal maps; tg, bn: normal maps)
+
+// ---- normal maps (cmaterial.h:2208-2243; sample2DAuxExt cfetch.h:795-820 without procedural textures) ----
+HK_DEV bool hasNormalMap(const float* m) { return uint32_t(as_int(m[HM_NORMAL_TEX])) != HYDRA_INVALID_TEXTURE; }
+HK_DEV f3 sample2DAuxExt(int auxTexId, int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
+  if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE) return mk3(1, 1, 1);
+  const float* sm = blob + size_t(samplerOffset) * 4;
+  const int flags = as_int(sm[HS_FLAGS]);
+  const f2 tct = mk2(sm[HS_ROW0] * texCoord.x + sm[HS_ROW0 + 1] * texCoord.y + sm[HS_ROW0 + 3],
+                     sm[HS_ROW1] * texCoord.x + sm[HS_ROW1 + 1] * texCoord.y + sm[HS_ROW1 + 3]);
+  if (as_int(sm[HS_TEXID]) == 0) return mk3(1, 1, 1);
+  const int offset = s.texAuxTable[auxTexId];
+  float4 c = read_imagef_sw4(s.texAuxStorage + offset, tct, flags, (sm[HS_GAMMA] != 1.0f), s.srgbLut);
+  if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
+  return mk3(c.x, c.y, c.z);
+}
+HK_DEV f3 materialNormalMapFetch(const float* m, f2 tc, const SceneDev& s) {   // cmaterial.h:2208-2233
+  const int flags = as_int(m[HM_FLAGS]);
+  const f3 t = sample2DAuxExt(as_int(m[HM_NORMAL_TEX]), as_int(m[HM_NORMAL_TEX_MATRIX]), tc, m, s);
+  f3 normalTS = mk3(2.0f * t.x - 1.0f, 2.0f * t.y - 1.0f, t.z);
+  if (flags & HMF_INVERT_NMAP_Y) normalTS.y *= (-1.0f);
+  if (flags & HMF_INVERT_NMAP_X) normalTS.x *= (-1.0f);
+  if (flags & HMF_INVERT_SWAP_NMAP_XY) { const float tmp = normalTS.x; normalTS.x = normalTS.y; normalTS.y = tmp; }
+  return normalize(normalTS);
+}
+HK_DEV f3 BumpMapping(f3 tangent, f3 bitangent, f3 normal, f2 tc, const float* m, const SceneDev& s) {   // cmaterial.h:2235-2243, inverse cglobals.h:893-918
+  const f3 nts = materialNormalMapFetch(m, tc, s);
+  const f3 r0 = tangent, r1 = bitangent, r2 = normal;   // make_float3x3: rows
+  const float det = r0.x * (r1.y * r2.z - r1.z * r2.y) - r0.y * (r1.x * r2.z - r1.z * r2.x) + r0.z * (r1.x * r2.y - r1.y * r2.x);
+  f3 b0 = mk3((r1.y * r2.z - r1.z * r2.y), -(r0.y * r2.z - r0.z * r2.y), (r0.y * r1.z - r0.z * r1.y));
+  f3 b1 = mk3(-(r1.x * r2.z - r1.z * r2.x), (r0.x * r2.z - r0.z * r2.x), -(r0.x * r1.z - r0.z * r1.x));
+  f3 b2 = mk3((r1.x * r2.y - r1.y * r2.x), -(r0.x * r2.y - r0.y * r2.x), (r0.x * r1.y - r0.y * r1.x));
+  const float sc = 1.0f / det;
+  b0 = b0 * sc; b1 = b1 * sc; b2 = b2 * sc;
+  return normalize(mk3(b0.x * nts.x + b0.y * nts.y + b0.z * nts.z, b1.x * nts.x + b1.y * nts.y + b1.z * nts.z, b2.x * nts.x + b2.y * nts.y + b2.z * nts.z));
+}
 
 HK_DEV const float* materialAt(const SceneDev& s, int matId) {   // cfetch.h:192-213
   return s.matBase + size_t(s.matTable[matId]) * 4;
@@ -835,15 +871,25 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     node = node + size_t(sel.localOffs) * HM_NODE_FLOATS;
   }
   out.color = mk3(0, 0, 0); out.direction = mk3(0, 1, 0); out.pdf = 1.0f; out.flags = 0;
+  f3 hitNorm = sh.normal;
+  const bool nmap = (F & HK_FEAT_NMAP) && hasNormalMap(node);
+  if (nmap) {   // :2252-2259: the bumped normal is built on the flat normal (turned over when hit from inside, except for glass)
+    const f3 flatNorm = (sh.hfi && matType(node) != HMT_GLASS) ? sh.flatNormal * (-1.0f) : sh.flatNormal;
+    hitNorm = BumpMapping(sh.tangent, sh.biTangent, flatNorm, sh.texCoord, node, s);
+  }
   switch (matType(node)) {
-    case HMT_PHONG: PhongSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], sh.normal, sh.texCoord, s, out); break;
-    case HMT_OREN_NAYAR: if (F & HK_FEAT_OREN_NAYAR) OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_GGX: if (F & HK_FEAT_GGX) GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_THIN_GLASS: if (F & HK_FEAT_GLASS) ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, sh.normal, sh.texCoord, s, out); break;
-    case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, sh.normal, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
+    case HMT_PHONG: PhongSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_MIRROR: MirrorSampleAndEvalBRDF(node, rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_LAMBERT: LambertSampleAndEvalBRDF(node, rands[0], rands[1], hitNorm, sh.texCoord, s, out); break;
+    case HMT_OREN_NAYAR: if (F & HK_FEAT_OREN_NAYAR) OrennayarSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_GGX: if (F & HK_FEAT_GGX) GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_THIN_GLASS: if (F & HK_FEAT_GLASS) ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, hitNorm, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
     default: break;
+  }
+  if (nmap) {   // :2322-2327: the caller multiplies by the cosine to the shading normal
+    const float cosThetaOut1 = fabsf(dot(out.direction, sh.normal)), cosThetaOut2 = fabsf(dot(out.direction, hitNorm));
+    out.color = out.color * (cosThetaOut2 / fmaxf(cosThetaOut1, HK_DEPSILON2));
   }
   if (out.pdf <= 0.0f) out.color = mk3(0, 0, 0);
   out.color = out.color * (1.0f / fmaxf(mixW, 0.015625f));
@@ -882,23 +928,34 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
       float pf = 0.0f, pr = 0.0f;
       bool diffuse = false;
       const int type = matType(m);
+      f3 n = sc.n;
+      float cosMult = 1.0f;
+      if ((F & HK_FEAT_NMAP) && hasNormalMap(m)) {   // :2431-2459: the cosine the caller applies is to sc.n, the lobe sees the bumped normal
+        n = BumpMapping(sc.tg, sc.bn, sc.fn, sc.tc, m, s);
+        const f3 lDir = fwdDir ? sc.v : sc.l;
+        const float clampVal = fwdDir ? 0.15f : 1e-6f;
+        const float cosThetaOut1 = fmaxf(dot(lDir, sc.n), 0.0f), cosThetaOut2 = fmaxf(dot(lDir, n), 0.0f);
+        cosMult = (cosThetaOut2 / fmaxf(cosThetaOut1, clampVal));
+        if (cosThetaOut1 <= 0.0f) cosMult = 0.0f;
+        if (fwdDir && dot(sc.l, sc.fn) <= 0.0f) cosMult = 0.0f;
+      }
       if (type == HMT_PHONG) {
-        brdf = phongEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
-        pf = phongEvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
-        pr = phongEvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
+        brdf = phongEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
+        pf = phongEvalPDF(m, sc.l, sc.v, n, sc.tc, s);
+        pr = phongEvalPDF(m, sc.v, sc.l, n, sc.tc, s);
       } else if ((F & HK_FEAT_GGX) && type == HMT_GGX) {
-        brdf = ggxEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
-        pf = ggx2EvalPDF(m, sc.l, sc.v, sc.n, sc.tc, s);
-        pr = ggx2EvalPDF(m, sc.v, sc.l, sc.n, sc.tc, s);
+        brdf = ggxEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
+        pf = ggx2EvalPDF(m, sc.l, sc.v, n, sc.tc, s);
+        pr = ggx2EvalPDF(m, sc.v, sc.l, n, sc.tc, s);
       } else if (type == HMT_LAMBERT) {
-        brdf = (lambertColor(m, sc.tc, s) * HK_INV_PI) * 1.0f;
-        pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
-        pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
+        brdf = (lambertColor(m, sc.tc, s) * HK_INV_PI) * cosMult;
+        pf = fabsf(dot(sc.l, n)) * HK_INV_PI;
+        pr = fabsf(dot(sc.v, n)) * HK_INV_PI;
         diffuse = true;
       } else if ((F & HK_FEAT_OREN_NAYAR) && type == HMT_OREN_NAYAR) {
-        brdf = orennayarEvalBxDF(m, sc.l, sc.v, sc.n, sc.tc, s) * 1.0f;
-        pf = fabsf(dot(sc.l, sc.n)) * HK_INV_PI;
-        pr = fabsf(dot(sc.v, sc.n)) * HK_INV_PI;
+        brdf = orennayarEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
+        pf = fabsf(dot(sc.l, n)) * HK_INV_PI;
+        pr = fabsf(dot(sc.v, n)) * HK_INV_PI;
         diffuse = true;
       }
       if (fwdDir) brdf = brdf * adjointBsdfShadeNormalFix(sc.v, sc.l, sc.n, sc.fn, diffuse ? 20.0f : 2.0f);

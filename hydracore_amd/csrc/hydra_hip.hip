@@ -339,10 +339,12 @@ HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& ge
 
 // S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
 template <int F = HK_FEAT_ALL>
-HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const f3 surfNormal, const f2 texCoord, const f3 ray_dir,
+HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir,
                                   const f3 shadowRayDir, const f3 lightColor, const float pdfSigned, const float lightPickProb) {
+  const f3 surfNormal = surf.normal;
   ShadeContext sc;
-  sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = texCoord;
+  sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = surf.texCoord;
+  if (F & HK_FEAT_NMAP) { sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent; }
   const BxDFResult ev = materialEval<F>(mat, sc, s);
   const float cos1 = fmaxf(+dot(shadowRayDir, surfNormal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surfNormal), 0.0f);
   const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
@@ -451,7 +453,7 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
     surf.flatNormal = surf.normal; surf.tangent = mk3(0, 0, 0); surf.biTangent = mk3(0, 0, 0); surf.t = 0.0f; surf.sRayOff = 0.0f;   // not read after the hit phase
     const float* mat = materialAt(s, surf.matId);
     f3 explicitColor = mk3(0, 0, 0);
-    if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded(s, mat, surf.normal, surf.texCoord, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];
+    if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded<HK_FEAT_CLASSIC>(s, mat, surf, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];   // the split form carries no tangent frame: scenes with normal maps use the fused kernel
     const f3 accum = xyz(acc4) + (xyz(thr4) * explicitColor);
     float4 oPos, oDir, oThr, oAcc;
     next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, accum, re.z, oPos, oDir, oThr, oAcc);
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
         const f3 ray_dir = xyz(dir4);
         f3 pend = mk3(0, 0, 0);
         if (lp.lightOffset >= 0)
-          pend = xyz(thr4) * direct_light_unoccluded<F>(s, mat, surf.normal, surf.texCoord, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
+          pend = xyz(thr4) * direct_light_unoccluded<F>(s, mat, surf, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
         oPend = mk4(pend, 0.0f);
         oShDir = mk4(lp.shadowRayDir, 0.0f);
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
@@ -782,7 +784,7 @@ __global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__
     o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.pdf;
     o[4] = sam.color.x; o[5] = sam.color.y; o[6] = sam.color.z; o[9] = sam.isPoint ? 1.0f : 0.0f;
     ShadeContext sc;
-    sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
+    sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord; sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent;
     const BxDFResult ev = materialEval(mat, sc, s);
     o[10] = ev.brdf.x; o[11] = ev.brdf.y; o[12] = ev.brdf.z; o[13] = ev.pdfFwd;
     o[14] = ev.btdf.x; o[15] = ev.btdf.y; o[16] = ev.btdf.z;
@@ -953,10 +955,11 @@ struct hydra_hip_ctx {
   int remapListsSize = 0, remapTableSize = 0, remapInstSize = 0;
   std::vector<int32_t> hostHeader;   // copy of the first words of the globals blob (trace depth, ...)
   bool leafEnc[4] = {false, false, false, false};   // device node copy of tree i has triangle counts in its leaf links
-  int lightFeatures = HK_FEAT_ALL, matFeatures = HK_FEAT_ALL, sceneFeatures = HK_FEAT_ALL;   // HK_FEAT_* the uploaded scene needs; 0 => the lean k_bounce
+  int lightFeatures = HK_FEAT_CLASSIC, matFeatures = HK_FEAT_CLASSIC, sceneFeatures = HK_FEAT_CLASSIC;   // HK_FEAT_* the uploaded scene needs; 0 => the lean k_bounce
   bool matDirty = true;              // material arena or material table changed since validate_materials last passed
   std::vector<float> hostMaterials;  // host copy of the material arena and table, for validate_materials only
   std::vector<int32_t> hostMatTable;
+  std::vector<int32_t> hostTexAuxTable;   // aux texture id -> offset in the aux arena (normal maps), for validate_materials
   bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
   bool skyLightOk = true;            // false when the uploaded sky light needs a model this layer lacks
 
@@ -1101,6 +1104,8 @@ static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree) {
   s.matTable = hdr ? s.globals + c->hostHeader[HG_MAT_TABLE_OFFS] : nullptr;
   s.lightsBase = hdr ? reinterpret_cast<const float*>(s.globals + c->hostHeader[HG_LIGHTS_OFFS]) : nullptr;
   s.texTable = hdr ? s.globals + c->hostHeader[HG_TEX_TABLE_OFFS] : nullptr;
+  s.texAuxStorage = static_cast<const int4*>(c->storage[HYDRA_STORAGE_TEXTURES_AUX].p);
+  s.texAuxTable = hdr ? s.globals + c->hostHeader[HG_TEXAUX_TABLE_OFFS] : nullptr;
   return s;
 }
 static bool scene_ready(const hydra_hip_ctx* c) {
@@ -1143,7 +1148,13 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (++visited > 64) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": blend tree with more than 64 nodes (cycle?)");
       const float* m = c->hostMaterials.data() + at;
       const int type = word(m, HM_TYPE);
-      if (uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has a normal map, which the HIP layer does not implement");
+      if (type != HMT_BLEND_MASK && uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) {   // normal-mapped leaf (a blend node may carry the ids too: never read)
+        const int auxId = word(m, HM_NORMAL_TEX);
+        if (auxId < 0 || size_t(auxId) >= c->hostTexAuxTable.size()) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": normal-map id outside the aux texture table");
+        const int offs = c->hostTexAuxTable[size_t(auxId)];
+        if (offs < 0 || (size_t(offs) + 1) * 16 > c->storageBytes[HYDRA_STORAGE_TEXTURES_AUX]) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": its normal map is not in the aux texture arena");
+        feat |= HK_FEAT_NMAP;
+      }
       if (type == HMT_BLEND_MASK) {
         const int o1 = word(m, HM_BLEND_MAT1), o2 = word(m, HM_BLEND_MAT2);
         if (o1 <= 0 || o2 <= 0 || top + 2 > 16) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": bad blend children");
@@ -1453,6 +1464,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
+  if (!fused && (c->sceneFeatures & HK_FEAT_NMAP)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has normal-mapped materials; the split bounce form (fused_bounce = 0) carries no tangent frame in its record, use the fused kernel");
   const SceneStage stage = scene_stage(c);
   const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
   const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4) * 16;
@@ -1477,9 +1489,10 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
-          else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL & ~HK_FEAT_GLASS);
-          else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL & ~HK_FEAT_GGX);
-          else HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+          else if (f & HK_FEAT_NMAP) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+          else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
+          else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
+          else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);
 #undef HK_LAUNCH_BOUNCE
           break;
         }
@@ -1630,6 +1643,11 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: material table runs past the blob");
     c->hostMatTable.assign(blob + to, blob + to + ts);
     c->matDirty = true;
+  }
+  {
+    const int64_t to = blob[HG_TEXAUX_TABLE_OFFS], ts = blob[HG_TEXAUX_TABLE_SIZE];
+    if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: aux texture table runs past the blob");
+    c->hostTexAuxTable.assign(blob + to, blob + to + ts);
   }
   {
     const int64_t to = blob[HG_TEX_TABLE_OFFS], ts = blob[HG_TEX_TABLE_SIZE];

@@ -265,6 +265,24 @@ bool read_file(const std::string& path, std::vector<char>& out) {
   return true;
 }
 
+// PushDownNormalMaps, PlainMaterialConverter.cpp:1240-1282: ids, sampler and the invert flags of a normal map go to every leaf of the blend tree
+void push_down_normal_map(MatTree* node, int32_t auxId, int32_t samplerOffset, int flags, const Sampler& sm) {
+  const int mask = HMF_INVERT_NMAP_X | HMF_INVERT_NMAP_Y | HMF_INVERT_SWAP_NMAP_XY | HMF_INVERT_HEIGHT;
+  if (node->isBlend) {
+    if (!node->c1 || !node->c2) return;
+    for (MatTree* child : {node->c1.get(), node->c2.get()}) {
+      const int32_t own = get_i(child->plain, HM_NORMAL_TEX);
+      if (uint32_t(own) != HYDRA_INVALID_TEXTURE) push_down_normal_map(child, own, get_i(child->plain, HM_NORMAL_TEX_MATRIX), get_i(child->plain, HM_FLAGS) & mask, sm);
+      else push_down_normal_map(child, auxId, samplerOffset, flags, sm);
+    }
+  } else if (uint32_t(auxId) != HYDRA_INVALID_TEXTURE) {
+    put_i(node->plain, HM_NORMAL_TEX, auxId);
+    put_i(node->plain, HM_NORMAL_TEX_MATRIX, samplerOffset);
+    put_i(node->plain, HM_FLAGS, (get_i(node->plain, HM_FLAGS) & ~mask) | flags);
+  }
+  put_sampler_at(node->plain, auxId, sm, HM_NORMAL_TEX, HM_NORMAL_TEX_MATRIX, HM_NORMAL_SAMPLER);   // IMaterial::SetNormalSampler
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -308,6 +326,29 @@ bool RenderDriverLite::UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_
   return true;
 }
 
+// the aux copy of a normal map: one per texture id (the reference keys on texture id + bump parameters, which normal_bump does not have);
+// UpdateImageAux, RenderDriverRTE_AuxTextures.cpp:195-216; ids count up from 0 (AuxNormalTexPerMaterial, PlainMaterialConverter.cpp:1883-1902)
+int32_t RenderDriverLite::AuxNormalMapFor(int32_t texId, int32_t a_matId) {
+  auto found = m_auxNormalMaps.find(texId);
+  if (found != m_auxNormalMaps.end()) return found->second;
+  int32_t auxId = int32_t(HYDRA_INVALID_TEXTURE);
+  const std::vector<int32_t> table = m_pTexStorage->GetTable();
+  if (texId >= 0 && size_t(texId) < table.size() && table[size_t(texId)] >= 0) {
+    const int32_t* header = reinterpret_cast<const int32_t*>(m_pTexStorage->GetBegin()) + size_t(table[size_t(texId)]) * 4;
+    if (header[3] != 4) Unsupported("normal map " + std::to_string(texId) + " is not an 8-bit RGBA texture (material " + std::to_string(a_matId) + ")");
+    else {
+      auxId = m_auxImageNumber++;
+      const size_t inBytes = size_t(header[0]) * size_t(header[1]) * 4, headerSize = 16, total = ((inBytes + 15) / 16) * 16 + headerSize;
+      const int32_t auxHeader[4] = {header[0], header[1], 4, 4};   // SWTextureHeader: width, height, depth = 4, bpp
+      m_pTexStorageAux->Update(auxId, nullptr, total);
+      m_pTexStorageAux->UpdatePartial(auxId, auxHeader, 0, 16);
+      m_pTexStorageAux->UpdatePartial(auxId, header + 4, headerSize, inBytes);
+    }
+  }
+  m_auxNormalMaps[texId] = auxId;
+  return auxId;
+}
+
 // CreateFromHydraMaterialXmlNode + CreateMaterialFromXmlNode, PlainMaterialConverter.cpp:1502-1738
 bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const std::string mtype = a_node->attr("type");
@@ -324,7 +365,10 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const float3 colorT = read_value3f(xchild(transpar, "color"));
   const float3 colorSSS = read_value3f(xchild(sss, "color"));
   if (length(colorSSS) > 1e-5f) Unsupported("translucency (material " + std::to_string(a_matId) + ")");
-  if (a_node->child("displacement")) Unsupported("displacement (material " + std::to_string(a_matId) + ")");
+  if (const XmlNode* displ = a_node->child("displacement")) {
+    const std::string btype = displ->attr("type");
+    if (btype != "normal_bump") Unsupported("displacement type '" + btype + "' (material " + std::to_string(a_matId) + "): only normal_bump is built (height maps go through IHWLayer::NormalMapFromDisplacement, an OpenCL-layer function)");
+  }
   m_matOpacity.erase(a_matId);
   if (const XmlNode* op = a_node->child("opacity")) {   // PlainMaterialConverter.cpp:1429-1445: alpha-tested in the traversal, not a BxDF
     Opacity o;
@@ -452,6 +496,23 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     const int mask = HMF_CAST_CAUSTICS | HMF_HAS_TRANSPARENCY;
     const int f = (get_i(pResult->c1->plain, HM_FLAGS) & mask) | (get_i(pResult->c2->plain, HM_FLAGS) & mask);
     put_i(pResult->plain, HM_FLAGS, get_i(pResult->plain, HM_FLAGS) | f);
+  }
+  // RenderDriverRTE::ReadBumpAndOpacity, the normal-map half (PlainMaterialConverter.cpp:1340-1424, 1447-1455), <displacement type="normal_bump">
+  if (const XmlNode* displ = a_node->child("displacement")) {
+    const XmlNode* nm = displ->child("normal_map");
+    const XmlNode* texNode = nm ? nm->child("texture") : nullptr;
+    if (std::string(displ->attr("type")) == "normal_bump" && texNode != nullptr) {
+      Sampler sm = sampler_from_texref(texNode);
+      if (!texNode->has_attr("input_gamma")) sm.gamma = 1.0f;
+      const int32_t auxId = AuxNormalMapFor(sm.texId, a_matId);
+      int flags = 0;
+      const XmlNode* invert = nm->child("invert");
+      if (invert && invert->attr_int("x") == 1) flags |= HMF_INVERT_NMAP_X;
+      if (invert && invert->attr_int("y") == 1) flags |= HMF_INVERT_NMAP_Y;
+      if (invert && invert->attr_int("swap_xy") == 1) flags |= HMF_INVERT_SWAP_NMAP_XY;
+      put_i(pResult->plain, HM_FLAGS, get_i(pResult->plain, HM_FLAGS) | flags);
+      push_down_normal_map(pResult.get(), auxId, HM_NORMAL_SAMPLER / 4, flags, sm);
+    }
   }
   // PutAbstractMaterialToStorage :1848-1881
   PlainMaterialVec mdata = flatten(pResult);

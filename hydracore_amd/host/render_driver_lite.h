@@ -43,6 +43,7 @@ public:
   void AllocAll(int imgNum, int matNum, int lightNum, int meshNum);
   bool UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_t bpp, int32_t chan, const void* a_data);
   bool UpdateMaterial(int32_t a_matId, const XmlNode* a_materialNode);
+  int32_t AuxNormalMapFor(int32_t a_texId, int32_t a_matId);   // aux-arena copy of a normal map (GetCachedAuxNormalMatId, RenderDriverRTE_AuxTextures.cpp:46-77)
   bool UpdateLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateSkyLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_lightNode);
@@ -72,6 +73,8 @@ private:
   bool m_splitAlphaTree = false;
   struct Opacity { int32_t texId; float sampler[12]; bool smooth, skipShadow; };
   std::map<int, Opacity> m_matOpacity; // materials with an <opacity> node (PlainMaterialConverter.cpp:1429-1445)
+  std::map<int32_t, int32_t> m_auxNormalMaps;   // texture id -> aux texture id of its copy in the aux arena (m_texturesProcessedNM, RenderDriverRTE_AuxTextures.cpp:50-73)
+  int32_t m_auxImageNumber = 0;
   std::vector<uint32_t> m_alphaTable[2];   // uint2 per float4 of the triangle list + the opacity samplers, per tree
   bool MeshHasOpacity(int32_t a_meshId) const;
   void CreateAlphaTestTable(ConvertionResult& cr);

@@ -151,6 +151,7 @@ enum { /* PLAIN_MAT_TYPES cglobals.h:2604-2621 */
 };
 enum { /* PLAIN_MAT_FLAGS cglobals.h:2624-2655 */
   HMF_CAST_CAUSTICS = 2, HMF_HAS_DIFFUSE = 4, HMF_HAS_TRANSPARENCY = 8, HMF_FORBID_EMISSIVE_GI = 512,
+  HMF_INVERT_NMAP_X = 16, HMF_INVERT_NMAP_Y = 32, HMF_INVERT_SWAP_NMAP_XY = 64, HMF_INVERT_HEIGHT = 128,   /* cglobals.h:2631-2634 */
   HMF_SKIP_SKY_PORTAL = 1024, HMF_HAVE_BTDF = 8192, HMF_CAN_SAMPLE_REFL_ONLY = 32768,
   HMF_ENERGY_FIX = 32768 * 256
 };

@@ -728,6 +728,43 @@ static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const O
   if (flags & TEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return v3(c.x, c.y, c.z);
 }
+/* ---- normal maps: sample2DAuxExt cfetch.h:795-820 (no procedural textures), materialNormalMapFetch cmaterial.h:2208-2233,
+ * BumpMapping :2235-2243 with make_float3x3 / inverse / mul3x3x3 of cglobals.h:849-918 ---- */
+enum { NORMAL_TEX_OFFSET = 83, NORMAL_TEX_MATRIX = 84, G_TEXAUX_TABLE = 222, MF_INVERT_NMAP_X = 16, MF_INVERT_NMAP_Y = 32, MF_INVERT_SWAP_NMAP_XY = 64 };   /* cglobals.h:2631-2633, 2681-2682 */
+static inline int hasNormalMap(const float* m) { return (uint32_t)as_int(m[NORMAL_TEX_OFFSET]) != INVALID_TEXTURE; }
+static f3 sample2DAuxExt(int auxTexId, int samplerOffset, f2 texCoord, const float* blob, const OrcScene* s) {
+  if ((uint32_t)samplerOffset == INVALID_TEXTURE) return v3(1, 1, 1);
+  const float* sm = blob + (size_t)samplerOffset * 4;
+  const int flags = as_int(sm[0]); const float gamma = sm[1]; const int texId = as_int(sm[2]);
+  f2 tct;
+  tct.x = sm[4] * texCoord.x + sm[5] * texCoord.y + sm[7];
+  tct.y = sm[8] * texCoord.x + sm[9] * texCoord.y + sm[11];
+  if (texId == 0) return v3(1, 1, 1);
+  const int offset = s->globals[s->globals[G_TEXAUX_TABLE] + auxTexId];
+  f4 c = read_imagef_sw4(s->texAuxStorage + (size_t)offset * 4, tct, flags, (gamma != 1.0f));
+  if (flags & TEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
+  return v3(c.x, c.y, c.z);
+}
+static f3 materialNormalMapFetch(const float* m, f2 tc, const OrcScene* s) {
+  const int flags = as_int(m[1]);
+  const f3 t = sample2DAuxExt(as_int(m[NORMAL_TEX_OFFSET]), as_int(m[NORMAL_TEX_MATRIX]), tc, m, s);
+  f3 normalTS = v3(2.0f * t.x - 1.0f, 2.0f * t.y - 1.0f, t.z);
+  if (flags & MF_INVERT_NMAP_Y) normalTS.y *= (-1.0f);
+  if (flags & MF_INVERT_NMAP_X) normalTS.x *= (-1.0f);
+  if (flags & MF_INVERT_SWAP_NMAP_XY) { const float tmp = normalTS.x; normalTS.x = normalTS.y; normalTS.y = tmp; }
+  return normalize3(normalTS);
+}
+static f3 BumpMapping(f3 tangent, f3 bitangent, f3 normal, f2 tc, const float* m, const OrcScene* s) {
+  const f3 nts = materialNormalMapFetch(m, tc, s);
+  const f3 r0 = tangent, r1 = bitangent, r2 = normal;
+  const float det = r0.x * (r1.y * r2.z - r1.z * r2.y) - r0.y * (r1.x * r2.z - r1.z * r2.x) + r0.z * (r1.x * r2.y - r1.y * r2.x);
+  f3 b0 = v3((r1.y * r2.z - r1.z * r2.y), -(r0.y * r2.z - r0.z * r2.y), (r0.y * r1.z - r0.z * r1.y));
+  f3 b1 = v3(-(r1.x * r2.z - r1.z * r2.x), (r0.x * r2.z - r0.z * r2.x), -(r0.x * r1.z - r0.z * r1.x));
+  f3 b2 = v3((r1.x * r2.y - r1.y * r2.x), -(r0.x * r2.y - r0.y * r2.x), (r0.x * r1.y - r0.y * r1.x));
+  const float sc = 1.0f / det;
+  b0 = scale3(b0, sc); b1 = scale3(b1, sc); b2 = scale3(b2, sc);
+  return normalize3(v3(b0.x * nts.x + b0.y * nts.y + b0.z * nts.z, b1.x * nts.x + b1.y * nts.y + b1.z * nts.z, b2.x * nts.x + b2.y * nts.y + b2.z * nts.z));
+}
 /* sampler flags for the TEX_COORD_CAM_PROJ test in lambert (cmaterial.h:224-226, 240-242).  With no texture the
  * reference reads the sampler at int4 index -2 (out of the node); that word is zero for every material after the
  * first arena entry, so the flags are taken as 0 here. */
@@ -1217,9 +1254,15 @@ static BRDFSelector materialRandomWalkBRDF(const float* m, const float* rands, f
   }
   return res;
 }
-/* ref: cmaterial.h:2245-2335 MaterialLeafSampleAndEvalBRDF (no normal maps in the subset) */
+/* ref: cmaterial.h:2245-2335 MaterialLeafSampleAndEvalBRDF */
 static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, f3 ray_dir, const float* rands, int a_isFwdDir, const OrcScene* s, MatSample* out) {
-  const f3 n = sh->normal;
+  f3 n = sh->normal;
+  const int nmap = hasNormalMap(m);
+  if (nmap) {
+    const int isGlass = (matType(m) == MT_GLASS);
+    const f3 flatNorm = (sh->hfi && !isGlass) ? scale3(sh->flatNormal, -1.0f) : sh->flatNormal;
+    n = BumpMapping(sh->tangent, sh->biTangent, flatNorm, sh->texCoord, m, s);
+  }
   out->color = v3(0, 0, 0); out->direction = v3(0, 1, 0); out->pdf = 1.0f; out->flags = 0;
   switch (matType(m)) {
     case MT_PHONG: PhongSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
@@ -1230,6 +1273,10 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */
     default: break;
+  }
+  if (nmap) {
+    const float cosThetaOut1 = fabsf(dot3(out->direction, sh->normal)), cosThetaOut2 = fabsf(dot3(out->direction, n));
+    out->color = scale3(out->color, (cosThetaOut2 / fmaxf(cosThetaOut1, DEPSILON2)));
   }
   if (out->pdf <= 0.0f) out->color = v3(0, 0, 0);
 }
@@ -1263,10 +1310,22 @@ static float adjointBsdfShadeNormalFix(f3 toLightWo, f3 toCamWi, f3 shadeNorm, f
   const float res = (k1 * k2) / fmaxf(k3 * k4, DEPSILON2);
   return fminf(fmaxf(res, 0.1f), maxVal);
 }
-static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, int a_fwdDir, const OrcScene* s) {
+static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc0, int a_fwdDir, const OrcScene* s) {
   BxDFResult r;
   r.brdf = v3(0, 0, 0); r.btdf = v3(0, 0, 0); r.pdfFwd = 0.0f; r.pdfRev = 0.0f; r.diffuse = 0;
-  const float cosMult = 1.0f;
+  float cosMult = 1.0f;
+  ShadeContext scn = *sc0;
+  if (hasNormalMap(m)) {   /* :2431-2459 */
+    const f3 nb = BumpMapping(sc0->tg, sc0->bn, sc0->fn, sc0->tc, m, s);
+    const f3 lDir = a_fwdDir ? sc0->v : sc0->l;
+    const float clampVal = a_fwdDir ? 0.15f : 1e-6f;
+    const float cosThetaOut1 = fmaxf(dot3(lDir, sc0->n), 0.0f), cosThetaOut2 = fmaxf(dot3(lDir, nb), 0.0f);
+    cosMult = (cosThetaOut2 / fmaxf(cosThetaOut1, clampVal));
+    if (cosThetaOut1 <= 0.0f) cosMult = 0.0f;
+    if (a_fwdDir && dot3(sc0->l, sc0->fn) <= 0.0f) cosMult = 0.0f;
+    scn.n = nb;
+  }
+  const ShadeContext* sc = &scn;
   switch (matType(m)) {
     case MT_PHONG:
       r.brdf = scale3(phongEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
@@ -1294,7 +1353,7 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc, int a
       break;
     default: break;
   }
-  if (a_fwdDir) r.brdf = scale3(r.brdf, adjointBsdfShadeNormalFix(sc->v, sc->l, sc->n, sc->fn, r.diffuse ? 20.0f : 2.0f));   /* cmaterial.h:2540-2548 */
+  if (a_fwdDir) r.brdf = scale3(r.brdf, adjointBsdfShadeNormalFix(sc0->v, sc0->l, sc0->n, sc0->fn, r.diffuse ? 20.0f : 2.0f));   /* cmaterial.h:2540-2548: the shading normal, not the bumped one */
   return r;
 }
 /* ref: cmaterial.h:2554-2628 materialEval: explicit-stack walk over the blend tree */

@@ -44,6 +44,7 @@ typedef struct OrcScene {
   const float*   trisN[3];
   int32_t        haveInstN[3];
   const uint32_t* alpha[4];      /* per tree: uint2 per float4 of the triangle list + opacity samplers, NULL = none */
+  const int32_t* texAuxStorage;  /* the second texture arena (normal maps), NULL = none */
 } OrcScene;
 
 typedef struct OrcHit { float t; int32_t primId, instId, geomId; } OrcHit;

@@ -154,7 +154,8 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
                              __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
                              __global const int4* in_texStorage, __global const float4* in_pdfStorage,
                              __global const EngineGlobals* a_globals, __global float4* color4, int n,
-                             __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1)
+                             __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1,
+                             __global const int4* in_texStorageAux)
 {
   const int i = get_global_id(0);
   if (i >= n) return;
@@ -269,7 +270,7 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
       ProcTextureList ptlCopy;
       InitProcTextureList(&ptlCopy);
       GetProcTexturesIdListFromMaterialHead(pHitMaterial, &ptlCopy);
-      const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlCopy);
+      const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorageAux, &ptlCopy);
 
       const float cosThetaOut1 = fmax(+dot(shadowRayDir, surfElem.normal), 0.0f);
       const float cosThetaOut2 = fmax(-dot(shadowRayDir, surfElem.normal), 0.0f);
@@ -291,7 +292,7 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
       InitProcTextureList(&ptlDummy);
       MatSample matSam; int matOffset;
       MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), flags, false,
-                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+                                a_globals, in_texStorage, in_texStorageAux, &ptlDummy, &matSam, &matOffset);
 
       const float3 bxdfVal = matSam.color * (1.0f / fmax(matSam.pdf, 1e-20f));
       const float cosTheta = fabs(dot(matSam.direction, surfElem.normal));
@@ -319,7 +320,7 @@ __kernel void ref_path_trace(__global const float4* pos4, __global const float4*
 __kernel void ref_shade_point(__global const float* surf24, __global const float4* dir4, __global const int* flagsIn,
                               __global const float4* rndLight4, __global const float* rands10,
                               __global const float4* in_mtlStorage, __global const int4* in_texStorage, __global const float4* in_pdfStorage,
-                              __global const EngineGlobals* a_globals, __global float* out28, int n)
+                              __global const EngineGlobals* a_globals, __global float* out28, int n, __global const int4* in_texStorageAux)
 {
   const int i = get_global_id(0);
   if (i >= n) return;
@@ -357,7 +358,7 @@ __kernel void ref_shade_point(__global const float* surf24, __global const float
     ProcTextureList ptlCopy;
     InitProcTextureList(&ptlCopy);
     GetProcTexturesIdListFromMaterialHead(pHitMaterial, &ptlCopy);
-    const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlCopy);
+    const BxDFResult evalData = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorageAux, &ptlCopy);
     o[10] = evalData.brdf.x; o[11] = evalData.brdf.y; o[12] = evalData.brdf.z; o[13] = evalData.pdfFwd;
     o[14] = evalData.btdf.x; o[15] = evalData.btdf.y; o[16] = evalData.btdf.z;
   }
@@ -368,7 +369,7 @@ __kernel void ref_shade_point(__global const float* surf24, __global const float
   InitProcTextureList(&ptlDummy);
   MatSample matSam; int matOffset;
   MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), flags, false,
-                            a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+                            a_globals, in_texStorage, in_texStorageAux, &ptlDummy, &matSam, &matOffset);
   o[17] = matSam.color.x; o[18] = matSam.color.y; o[19] = matSam.color.z; o[20] = matSam.pdf;
   o[21] = matSam.direction.x; o[22] = matSam.direction.y; o[23] = matSam.direction.z;
   o[24] = as_float(matSam.flags); o[25] = as_float((int)flagsNextBounceLite(flags, matSam, a_globals));
@@ -431,7 +432,8 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
                          __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
                          __global const int4* in_texStorage, __global const float4* in_pdfStorage,
                          __global const EngineGlobals* a_globals, __global float* out8, int n,
-                         __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1)
+                         __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1,
+                         __global const int4* in_texStorageAux)
 {
   const int tid = get_global_id(0);
   if (tid >= n) return;
@@ -541,7 +543,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
       RndMatAll(&gen, rptr + rndMatOffsetMMLT(a_currDepth - 1), a_currDepth - 1, a_globals->rmQMC, 0, 0, allRands);
       MatSample matSam; int matOffset;
       MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), packBounceNum(0, a_currDepth - 1), false,
-                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+                                a_globals, in_texStorage, in_texStorageAux, &ptlDummy, &matSam, &matOffset);
       const float3 bxdfVal = matSam.color;
       const float cosNext  = fabs(dot(matSam.direction, surfElem.normal));
       if (a_currDepth == 1)
@@ -556,7 +558,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
           ShadeContext sc;
           sc.wp = surfElem.pos; sc.l = (-1.0f)*ray_dir; sc.v = matSam.direction; sc.n = surfElem.normal; sc.fn = surfElem.flatNormal;
           sc.tg = surfElem.tangent; sc.bn = surfElem.biTangent; sc.tc = surfElem.texCoord; sc.tccp = surfElem.texCoordCamProj; sc.hfi = surfElem.hfi;
-          const float pdfFwdW  = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlDummy).pdfFwd;
+          const float pdfFwdW  = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorageAux, &ptlDummy).pdfFwd;
           const float pdfFwdWP = pdfFwdW / fmax(cosHere, DEPSILON);
           pdfArray[prevVertexId].pdfFwd = pdfFwdWP*GTerm;
         }
@@ -626,7 +628,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
       RndMatAll(&gen, rptr + rndMatOffsetMMLT(a_currDepth - 1), a_currDepth - 1, a_globals->rmQMC, 0, 0, allRands);
       MatSample matSam; int matOffset;
       MaterialSampleAndEvalBxDF(pHitMaterial, allRands, &surfElem, ray_dir, make_float3(0, 0, 0), packBounceNum(0, a_currDepth - 1), true,
-                                a_globals, in_texStorage, in_texStorage, &ptlDummy, &matSam, &matOffset);
+                                a_globals, in_texStorage, in_texStorageAux, &ptlDummy, &matSam, &matOffset);
       const float3 nextRay_dir = matSam.direction;
       const float3 nextRay_pos = OffsRayPos(surfElem.pos, surfElem.normal, matSam.direction);
       const float cosNext = fabs(+dot(nextRay_dir, surfElem.normal));
@@ -640,7 +642,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
         ShadeContext sc;
         sc.wp = surfElem.pos; sc.l = (-1.0f)*ray_dir; sc.v = (-1.0f)*nextRay_dir; sc.n = surfElem.normal; sc.fn = surfElem.flatNormal;
         sc.tg = surfElem.tangent; sc.bn = surfElem.biTangent; sc.tc = surfElem.texCoord; sc.tccp = surfElem.texCoordCamProj; sc.hfi = surfElem.hfi;
-        const float pdfW         = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorage, &ptlDummy).pdfFwd;
+        const float pdfW         = materialEval(pHitMaterial, &sc, (EVAL_FLAG_DEFAULT), a_globals, in_texStorage, in_texStorageAux, &ptlDummy).pdfFwd;
         const float prevPdfRevWP = pdfW / fmax(cosCurr, DEPSILON);
         pdfArray[a_currDepth].pdfRev = prevPdfRevWP*GTermPrev;
       }
@@ -674,7 +676,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
           x = -1; y = -1;
         }
         else
-          sampleColor = ConnectEyeP(&lv, mLightSubPathCount, camDir, imageToSurfaceFactor, a_globals, in_mtlStorage, in_texStorage, in_texStorage, &ptlDummy,
+          sampleColor = ConnectEyeP(&lv, mLightSubPathCount, camDir, imageToSurfaceFactor, a_globals, in_mtlStorage, in_texStorage, in_texStorageAux, &ptlDummy,
                                     &pdfArray[lightTraceDepth + 0], &pdfArray[lightTraceDepth + 1], &x, &y);
       }
     }
@@ -698,7 +700,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
           const float t_far = explicitSam.maxDist*0.9995f;
           const float3 shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
           if (dot(shadow, shadow) > 1e-12f)
-            explicitColor = shadow*ConnectShadowP(&cv, t, pLight, explicitSam, lightPickProb, a_globals, in_mtlStorage, in_texStorage, in_texStorage, in_pdfStorage, &ptlDummy,
+            explicitColor = shadow*ConnectShadowP(&cv, t, pLight, explicitSam, lightPickProb, a_globals, in_mtlStorage, in_texStorage, in_texStorageAux, in_pdfStorage, &ptlDummy,
                                                   &pdfArray[0], &pdfArray[1], &pdfArray[2]);
         }
         sampleColor = cv.accColor*explicitColor;
@@ -725,7 +727,7 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
             const float t_far = dist*0.9995f;
             const float3 shadow = (HitSome(sh) && sh.t > 0.0f && sh.t < t_far) ? make_float3(0.0f, 0.0f, 0.0f) : make_float3(1.0f, 1.0f, 1.0f);
             if (!(dot(shadow, shadow) < 1e-12f))
-              explicitColor = shadow*ConnectEndPointsP(&lv, &cv, d, a_globals, in_mtlStorage, in_texStorage, in_texStorage, &ptlDummy,
+              explicitColor = shadow*ConnectEndPointsP(&lv, &cv, d, a_globals, in_mtlStorage, in_texStorage, in_texStorageAux, &ptlDummy,
                                                        &pdfArray[s - 1], &pdfArray[s + 0], &pdfArray[s + 1]);
           }
         }

@@ -17,6 +17,7 @@ struct EmuScene {   // mirrors tests/oracle_lib.OrcScene field for field
   const float* bvh; const float* tris; int haveInst; const float* instMatrices; const int* instLightInstId; int instNum;
   const int* remapLists; int remapListsSize; const int* remapTable; int remapTableSize; const int* remapInst; int remapInstSize;
   int treesNum; const float* bvhN[3]; const float* trisN[3]; int haveInstN[3]; const unsigned* alpha[4];
+  const int* texAuxStorage;
 };
 
 static SceneDev to_dev(const EmuScene* e) {
@@ -41,6 +42,8 @@ static SceneDev to_dev(const EmuScene* e) {
   s.matTable = e->globals ? e->globals + e->globals[HG_MAT_TABLE_OFFS] : nullptr;   // traversal-only callers pass no globals
   s.lightsBase = e->globals ? reinterpret_cast<const float*>(e->globals + e->globals[HG_LIGHTS_OFFS]) : nullptr;
   s.texTable = e->globals ? e->globals + e->globals[HG_TEX_TABLE_OFFS] : nullptr;
+  s.texAuxStorage = reinterpret_cast<const int4*>(e->texAuxStorage);
+  s.texAuxTable = e->globals ? e->globals + e->globals[HG_TEXAUX_TABLE_OFFS] : nullptr;
   return s;
 }
 

@@ -45,7 +45,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
       rays += 1.0f;
       const float shadow = (sh.primId != -1) ? 0.0f : 1.0f;
       ShadeContext sc;
-      sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord;
+      sc.l = sdir; sc.v = ray_dir * (-1.0f); sc.n = surf.normal; sc.tc = surf.texCoord; sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent;
       const BxDFResult ev = materialEval(mat, sc, s);
       const float cos1 = fmaxf(+dot(sdir, surf.normal), 0.0f), cos2 = fmaxf(-dot(sdir, surf.normal), 0.0f);
       const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);

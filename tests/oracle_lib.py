@@ -16,7 +16,8 @@ class OrcScene(C.Structure):
                 ("instMatrices", C.c_void_p), ("instLightInstId", C.c_void_p), ("instNum", C.c_int32),
                 ("remapLists", C.c_void_p), ("remapListsSize", C.c_int32), ("remapTable", C.c_void_p),
                 ("remapTableSize", C.c_int32), ("remapInst", C.c_void_p), ("remapInstSize", C.c_int32),
-                ("treesNum", C.c_int32), ("bvhN", C.c_void_p * 3), ("trisN", C.c_void_p * 3), ("haveInstN", C.c_int32 * 3), ("alpha", C.c_void_p * 4)]
+                ("treesNum", C.c_int32), ("bvhN", C.c_void_p * 3), ("trisN", C.c_void_p * 3), ("haveInstN", C.c_int32 * 3), ("alpha", C.c_void_p * 4),
+                ("texAuxStorage", C.c_void_p)]
 
 
 _lib = None
@@ -90,6 +91,8 @@ class Oracle:
             s.bvhN[0], s.trisN[0], s.haveInstN[0] = b["bvh_nodes1"].ctypes.data, b["bvh_tris1"].ctypes.data, int(b["have_inst1"])
             if b["bvh_alpha1"].size:
                 s.alpha[1] = b["bvh_alpha1"].ctypes.data
+        if "textures_aux" in b and b["textures_aux"].size:
+            s.texAuxStorage = b["textures_aux"].ctypes.data
         self.s = s
         self.w, self.h = b["width"], b["height"]
 

@@ -90,6 +90,7 @@ class RefScene:
         self.bvh1, self.tris1 = (up(b["bvh_nodes1"]), up(b["bvh_tris1"])) if two else (0, 0)
         self.alpha1 = up(b["bvh_alpha1"]) if two and b["bvh_alpha1"].size else 0
         self.have_inst1 = int(b.get("have_inst1", 0)) if two else 0
+        self.texaux = up(b["textures_aux"]) if b.get("textures_aux", np.zeros(0)).size else self.tex   # the aux arena (normal maps); never read without one
 
     def random(self, seeds, draws):
         seeds = np.ascontiguousarray(seeds, np.int32)
@@ -148,7 +149,7 @@ class RefScene:
         self.m.launch("ref_shade_point", n, [("p", self.m.up(np.ascontiguousarray(surf24, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
                                              ("p", self.m.up(np.ascontiguousarray(flags, np.int32))), ("p", self.m.up(np.ascontiguousarray(rnd_light4, np.float32))),
                                              ("p", self.m.up(np.ascontiguousarray(rands10, np.float32))), ("p", self.mat), ("p", self.tex), ("p", self.pdf),
-                                             ("p", self.globals), ("p", out), ("i", n)])
+                                             ("p", self.globals), ("p", out), ("i", n), ("p", self.texaux)])
         return self.m.down(out, np.float32, (n, 28))
 
     # ---- row f3 building blocks
@@ -187,7 +188,7 @@ class RefScene:
         self.m.launch("ref_mmlt_f", n, [("p", self.m.up(d)), ("p", self.m.up(x)), ("i", x.shape[1]),
                                         ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
                                         ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", out), ("i", n),
-                                        ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1)])
+                                        ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.texaux)])
         return self.m.down(out, np.float32, (n, 8))
 
     def path_trace(self, pos4, dir4, rng2):
@@ -197,5 +198,5 @@ class RefScene:
         self.m.launch("ref_path_trace", n, [("p", self.m.up(np.ascontiguousarray(pos4, np.float32))), ("p", self.m.up(np.ascontiguousarray(dir4, np.float32))),
                                             ("p", rng), ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
                                             ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", col), ("i", n),
-                                            ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1)])
+                                            ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.texaux)])
         return self.m.down(col, np.float32, (n, 4)), self.m.down(rng, np.uint32, (n, 2))

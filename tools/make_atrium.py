@@ -160,6 +160,23 @@ def leaf_mask(n=128):
     return img
 
 
+def tile_normal_map(n=256, periods=2, amp=0.04):
+    """tangent-space normal map of smooth round bumps: height = amp sin(2 pi k u) sin(2 pi k v), normal = (-dh/du, -dh/dv, 1) normalised.
+    Low frequency on purpose: a normal map multiplies a path's sensitivity to its inputs by |dn/duv| per bounce, and the parity fixtures
+    compare implementations whose floats differ in the last bit."""
+    u = (np.arange(n) + 0.5) / n
+    k = 2.0 * np.pi * periods
+    dhdu = amp * k * np.cos(k * u)[None, :] * np.sin(k * u)[:, None]
+    dhdv = amp * k * np.sin(k * u)[None, :] * np.cos(k * u)[:, None]
+    nrm = np.stack([-dhdu, -dhdv, np.ones_like(dhdu)], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    img = np.empty((n, n, 4), np.uint8)
+    img[..., :2] = np.clip((nrm[..., :2] * 0.5 + 0.5) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    img[..., 2] = np.clip(nrm[..., 2] * 255.0 + 0.5, 0, 255).astype(np.uint8)    # the fetch reads z as it is, x and y as 2c - 1 (cmaterial.h:2216)
+    img[..., 3] = 255
+    return img
+
+
 def write_vsgf(path, m):
     vn, tn = len(m["pos"]), len(m["idx"]) // 3
     blobs = [m["pos"].tobytes(), m["norm"].tobytes(), m["tan"].tobytes(), m["uv"].tobytes(), m["idx"].tobytes(), m["mat"].tobytes()]
@@ -210,6 +227,8 @@ def main():
                     "BVH4InstTraverseAlpha) and hangs a perforated screen (same mask) in front of the camera")
     ap.add_argument("--two-trees", action="store_true", help="with --cutouts: the render settings ask the front end to put the instances of alpha-tested meshes into a second BVH "
                     "tree (<split_alpha_tree>), the way Embree hands the reference several trees")
+    ap.add_argument("--normal-maps", action="store_true", help="materials 0, 1, 4, 5, 8 and 9 (floor, walls, columns: lambert, textured lambert and lambert + glossy blends) get "
+                    "<displacement type='normal_bump'> with a generated 256x256 normal map (smooth round bumps), y inverted on two of them")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
@@ -243,6 +262,10 @@ def main():
     if args.cutouts:
         mask_tex = len(texs)
         texs.append((None, leaf_mask()))
+    nmap_tex = None
+    if args.normal_maps:
+        nmap_tex = len(texs)
+        texs.append((None, tile_normal_map()))
     xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
     chunk = 0
     for tid, (n, img) in enumerate(texs):
@@ -286,6 +309,13 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    if args.normal_maps:
+        for i, line in enumerate(xml):
+            for mid in (0, 1, 4, 5, 8, 9):
+                if line.startswith('  <material id="%d" ' % mid):
+                    bump = ('<displacement type="normal_bump"><normal_map><invert x="0" y="%d" swap_xy="0" /><texture id="%d" type="texref" '
+                            'matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" /></normal_map></displacement>' % (1 if mid in (4, 9) else 0, nmap_tex))
+                    xml[i] = line.replace("</material>", bump + "</material>")
     xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
     if args.cutouts:   # leaves: textured lambert, the mask's alpha channel is the opacity
         xml.append('  <material id="11" name="leaves" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" /><texture id="%d" type="texref" /></diffuse>'
