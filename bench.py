@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--trace-depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "test_224"),
-                    help="scene library directory, or 'atrium250k' / 'atrium250k_sky' / 'atrium250k_glass' = BASELINE configs[2]/[3] and a glass variant (generated by tools/make_atrium.py on first use)")
+                    help="scene library directory, or 'atrium250k' / 'atrium250k_sky' / 'atrium250k_glass' / 'atrium250k_nmap' / 'atrium250k_cutouts' = BASELINE configs[2]/[3] and its glass, normal-map and cut-out variants (generated by tools/make_atrium.py on first use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc child runs (roofline then uses the committed profiles/*/pmc_live_*.json of this workload, if any)")
     ap.add_argument("--pmc-out", default="", help="directory for the PMC child runs' output (default: gpurun_out/pmc_live if writable, else a temp dir)")
@@ -225,7 +225,7 @@ def main():
     weak = (args.spp_per_step == 64 * world)
     w, h, depth = args.width, args.height, args.trace_depth
     workload = "configs[1]: Cornell-box-style test scene (reference hydra_app/tests/test_224, 25.6k-tri teapot)"
-    if args.scene in ("atrium250k", "atrium250k_sky", "atrium250k_glass"):
+    if args.scene in ("atrium250k", "atrium250k_sky", "atrium250k_glass", "atrium250k_nmap", "atrium250k_cutouts"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from conftest import scene_path
         name = args.scene
@@ -236,7 +236,9 @@ def main():
         args.scene = scene_path(name)
         workload = "configs[2]: generated Sponza-class atrium (tools/make_atrium.py, 249k triangles, 173 instances, textured; %s)" % (
             "open roof + constant sky light 0.5 next to the roof light" if name.endswith("_sky") else
-            "closed hall, roof light only; glass pots, rough-glass arches, layered glass bands, thin-glass curtains" if name.endswith("_glass") else "closed hall, roof light only")
+            "closed hall, roof light only; glass pots, rough-glass arches, layered glass bands, thin-glass curtains" if name.endswith("_glass") else
+            "closed hall, roof light only; normal-mapped floor, walls and columns" if name.endswith("_nmap") else
+            "closed hall, roof light only; 60 instanced plants of alpha-tested cards" if name.endswith("_cutouts") else "closed hall, roof light only")
     sc = HostScene(args.scene, w, h, trace_depth=depth, enable_dof=0, use_hip=True, device=dev_id, seed=777)
     if sc.unsupported():
         raise SystemExit("bench.py: scene uses features outside the HIP layer's subset:\n" + sc.log())
