@@ -175,6 +175,7 @@ HK_DEV float MutateKelemen(float valueX, f2 rands, float p2, float p1) {
 // The contribution function of multiplexed MLT (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315) for many chains at once, cut where the
 // reference calls rayTrace / shadowTrace so that the traversal kernels of the path tracer do that work:
 //   mmltBegin        F :150-199 up to the first camera ray, LightPath :637-669 up to the first light ray
+//   (the callers keep the rays: hydra_hip.hip in compacted per-level queues, the host emulation in plain arrays)
 //   mmltCameraStep   one level of CameraPath :756-929 (the recursion's return-trip products are kept per level and applied in mmltConnectEnd)
 //   mmltLightStep    one level of TraceLightPath :671-754
 //   mmltConnectBegin the rays of ConnectEye :931-958 (closest hit towards the camera), ConnectShadow :962-1009 and ConnectEndPoints :1011-1047 (shadow rays)
@@ -203,8 +204,6 @@ struct MmltView {
   float* st;                        // mmltPlanes(maxD) planes of n floats
   const float* x;                   // mmltStride(maxD) planes of n floats: the primary-sample vectors
   const int* depth;                 // d per chain, 1..maxD
-  float4* rayPos; float4* rayDir;   // 2n: camera rays, then light rays
-  const HydraLiteHit* hits;         // 2n
   float4* eyePos; float4* eyeDir; const HydraLiteHit* eyeHit;   // n: connection towards the camera (closest hit)
   float4* shPos; float4* shDir; const float* shVis;             // n: shadow connections, t_far in shPos.w
   float* out8;                      // n x 8: colour, x, y, split, MIS weight, contribFunc
@@ -230,7 +229,7 @@ HK_DEV SurfaceHit mloadHit(const MmltView& v, int plane, int i) {
   h.matId = msti(v, plane + 11, i); h.t = mst(v, plane + 12, i); h.sRayOff = mst(v, plane + 13, i); h.hfi = msti(v, plane + 14, i) != 0;
   return h;
 }
-HK_DEV void mmltDeadRay(float4& pos, float4& dir) {   // misses the root box of any scene; the traversal kernels take every ray of the array
+HK_DEV void mmltDeadRay(float4& pos, float4& dir) {   // misses the root box of any scene; the traversal kernels take every ray of the connection arrays; sub-path rays are compacted instead
   pos = make_float4(1e18f, 1e18f, 1e18f, 0.0f);
   dir = make_float4(0.57735026f, 0.57735026f, 0.57735026f, 0.0f);
 }
@@ -281,7 +280,8 @@ HK_DEV void mmltRands(const MmltView& v, int i, int base, float* rands) {   // R
   for (int k = 0; k < HK_MMLT_PER_BOUNCE; k++) rands[k] = mx(v, base + k, i);
 }
 
-HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i) {
+// returns the first camera ray and the first light ray of chain i (camActive / lightActive say which exist)
+HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i, float4& cpos, float4& cdir, bool& camActive, float4& lpos, float4& ldir, bool& lightActive) {
   const int d = v.depth[i];
   for (int k = 0; k <= d; k++) { mpdfFwd(v, k, i) = 0.0f; mpdfRev(v, k, i) = 0.0f; }
   const int width = int(g_varsF(s)[HV_F_WIDTH_F]), height = int(g_varsF(s)[HV_F_HEIGHT_F]);
@@ -290,7 +290,6 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i) {
   const float4 lensOffs = make_float4(mx(v, 0, i), mx(v, 1, i), mx(v, 2, i), mx(v, 3, i));   // rndLens
   int x = int(lensOffs.x * float(width) + 0.5f), y = int(lensOffs.y * float(height) + 0.5f);
   int bits = 0, lbits = 0;
-  float4 cpos, cdir, lpos, ldir;
   mmltDeadRay(cpos, cdir); mmltDeadRay(lpos, ldir);
   // InitPathVertex, cbidir.h:26-33
   mst(v, MP_CV_GTERM, i) = 1.0f; mstSet3(v, MP_CV_ACC, i, mk3(1, 1, 1));
@@ -320,21 +319,20 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i) {
     lbits |= MB_LIGHT_ACTIVE;
   }
   msti(v, MP_S, i) = sp; msti(v, MP_BITS, i) = bits; msti(v, MP_LBITS, i) = lbits; msti(v, MP_X, i) = x; msti(v, MP_Y, i) = y;
-  v.rayPos[i] = cpos; v.rayDir[i] = cdir; v.rayPos[v.n + i] = lpos; v.rayDir[v.n + i] = ldir;
+  camActive = (bits & MB_CAM_ACTIVE) != 0; lightActive = (lbits & MB_LIGHT_ACTIVE) != 0;
 }
 
 // one level of CameraPath (:756-929) for the hit of the ray in rayPos[i]; currDepth counts from 1
-HK_DEV void mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int currDepth) {
+// (ray, hit) in, next ray out; returns whether the sub-path goes on
+HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int currDepth, float4 rayPos4, float4 rayDir4, const HydraLiteHit& hit, float4& npos, float4& ndir) {
   int bits = msti(v, MP_BITS, i);
-  if (!(bits & MB_CAM_ACTIVE)) return;
+  mmltDeadRay(npos, ndir);
+  if (!(bits & MB_CAM_ACTIVE)) return false;
   const int d = v.depth[i], sp = msti(v, MP_S, i), camTraceDepth = d - sp;
   const bool haveToHitLight = (sp == 0);
   const int prevVertexId = d - currDepth + 1;
-  const f3 ray_pos = xyz(v.rayPos[i]), ray_dir = xyz(v.rayDir[i]);
-  const HydraLiteHit hit = v.hits[i];
+  const f3 ray_pos = xyz(rayPos4), ray_dir = xyz(rayDir4);
   bits &= ~MB_CAM_ACTIVE;                                  // every exit but the last one ends the sub-path
-  float4 npos, ndir;
-  mmltDeadRay(npos, ndir);
   if (HitSome(hit)) {
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float cosHere = fabsf(dot(ray_dir, surf.normal)), cosPrev = fabsf(mst(v, MP_MIS_COS, i));
@@ -405,19 +403,17 @@ HK_DEV void mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
     }
   }
   msti(v, MP_BITS, i) = bits;
-  v.rayPos[i] = npos; v.rayDir[i] = ndir;
+  return (bits & MB_CAM_ACTIVE) != 0;
 }
 
 // one level of TraceLightPath (:671-754) for the hit of the ray in rayPos[n + i]
-HK_DEV void mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currDepth) {
+HK_DEV bool mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currDepth, float4 rayPos4, float4 rayDir4, const HydraLiteHit& hit, float4& npos, float4& ndir) {
   int bits = msti(v, MP_LBITS, i);
-  if (!(bits & MB_LIGHT_ACTIVE)) return;
-  const int sp = msti(v, MP_S, i), lightTraceDepth = sp - 1;
-  const f3 ray_pos = xyz(v.rayPos[v.n + i]), ray_dir = xyz(v.rayDir[v.n + i]);
-  const HydraLiteHit hit = v.hits[v.n + i];
-  bits &= ~MB_LIGHT_ACTIVE;
-  float4 npos, ndir;
   mmltDeadRay(npos, ndir);
+  if (!(bits & MB_LIGHT_ACTIVE)) return false;
+  const int sp = msti(v, MP_S, i), lightTraceDepth = sp - 1;
+  const f3 ray_pos = xyz(rayPos4), ray_dir = xyz(rayDir4);
+  bits &= ~MB_LIGHT_ACTIVE;
   if (HitSome(hit)) {
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float prevLightCos = mst(v, MP_L_COS, i), prevPdf = mst(v, MP_L_PDF, i);
@@ -449,7 +445,7 @@ HK_DEV void mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currD
     }
   }
   msti(v, MP_LBITS, i) = bits;
-  v.rayPos[v.n + i] = npos; v.rayDir[v.n + i] = ndir;
+  return (bits & MB_LIGHT_ACTIVE) != 0;
 }
 
 // what mmltConnectBegin and mmltConnectEnd both need of a shadow connection to a sampled light (ConnectShadow :962-990)

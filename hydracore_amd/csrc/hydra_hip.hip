@@ -829,14 +829,38 @@ __global__ void k_stage_mutate_kelemen(int n, const float* __restrict__ values, 
   out[i] = MutateKelemen(values[i], mk2(rands2[i].x, rands2[i].y), p2, p1);
 }
 // ---- IntegratorMMLT::F in wavefront form (hk_bidir.h): one thread per chain between the traversal launches
-__global__ void k_mmlt_begin(SceneDev s, MmltView v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < v.n) mmltBegin(s, v, i);
+// The sub-path rays of a level live in segmented, compacted queues like the path tracer's (SegQ): a ray slot holds origin, direction and its
+// owner (chain * 2 + side, side 1 = light sub-path); a finished sub-path simply appends nothing, so a level traces only the live rays.
+struct MmltRays { float4* pos; float4* dir; int* owner; };
+__global__ void k_mmlt_begin(SceneDev s, MmltView v, int nseg, int cap, MmltRays out, uint32_t* __restrict__ outCount) {
+  const int seg = int(blockIdx.x) % nseg, bis = int(blockIdx.x) / nseg;
+  const int i = (bis * nseg + seg) * int(blockDim.x) + int(threadIdx.x);   // chains are dealt to the segments in chunks of one block
+  float4 cpos, cdir, lpos, ldir;
+  bool ca = false, la = false;
+  if (i < v.n) mmltBegin(s, v, i, cpos, cdir, ca, lpos, ldir, la);
+  uint32_t* counter = outCount + seg * HK_CSTRIDE;
+  const int dc = seg * cap + wave_compact_index(ca, counter);
+  if (ca) { out.pos[dc] = cpos; out.dir[dc] = cdir; out.owner[dc] = i * 2; }
+  const int dl = seg * cap + wave_compact_index(la, counter);
+  if (la) { out.pos[dl] = lpos; out.dir[dl] = ldir; out.owner[dl] = i * 2 + 1; }
 }
-__global__ void k_mmlt_step(SceneDev s, MmltView v, int currDepth) {   // first n threads: camera sub-paths, next n: light sub-paths
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < v.n) mmltCameraStep(s, v, j, currDepth);
-  else if (j < 2 * v.n) mmltLightStep(s, v, j - v.n, currDepth);
+__global__ void k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
+  const SegIter it = segq_iter(q);
+  uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
+  for (int idx = it.first; idx - int(__lane_id()) < it.count; idx += it.step) {   // whole waves iterate together: the compaction is a wave ballot
+    bool alive = false;
+    float4 npos, ndir;
+    int owner = 0;
+    if (idx < it.count) {
+      const int j = it.base + idx;
+      owner = in.owner[j];
+      const int chain = owner >> 1;
+      alive = (owner & 1) ? mmltLightStep(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir)
+                          : mmltCameraStep(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir);
+    }
+    const int dst = it.base + wave_compact_index(alive, counter);
+    if (alive) { out.pos[dst] = npos; out.dir[dst] = ndir; out.owner[dst] = owner; }
+  }
 }
 __global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1000,7 +1024,7 @@ struct hydra_hip_ctx {
     int n = 0, maxD = 0, firstBounce = 0;
     DevBuf ch, depth, xCur, xNew, out8, image, accum, sum, scaled;
     DevBuf sbDepth, sbImage; unsigned long long sbSamples = 0;   // the SBDPT passes of the same run (hydra_hip_sbdpt_pass)
-    DevBuf st, rayPos, rayDir, hits, eyePos, eyeDir, eyeHit, shPos, shDir, shVis;
+    DevBuf st, rayPos[2], rayDir[2], rayOwner[2], hits, counts, eyePos, eyeDir, eyeHit, shPos, shDir, shVis;
     float avgB[HK_MMLT_MAX_DEPTH + 2] = {0};
     float avgBrightness = 0.0f;
     unsigned long long mutations = 0;
@@ -2487,19 +2511,33 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
 // The device buffers of one evaluation of F for n chains (hk_bidir.h MmltView), owned by the caller.
 struct MmltBufs {
   MmltView v;
-  HydraLiteHit* hits; HydraLiteHit* eyeHit; float* shVis;   // the writable twins of v.hits / v.eyeHit / v.shVis
+  MmltRays rays[2];        // ping-pong ray queues, nseg segments of cap slots
+  HydraLiteHit* hits;      // per ray slot
+  uint32_t* counts;        // (HK_MMLT_MAX_DEPTH + 2) counter rows of HK_CROW words: live rays per level and segment
+  int nseg, cap;
+  HydraLiteHit* eyeHit; float* shVis;   // the writable twins of v.eyeHit / v.shVis
 };
+static void mmlt_queue_shape(int n, int& nseg, int& cap) {
+  const int blocks = (n + 255) / 256;
+  nseg = std::max(1, std::min(32, blocks));
+  cap = ((blocks + nseg - 1) / nseg) * 256 * 2;      // every chain of a segment may start a camera and a light sub-path; a level never grows
+}
 static int mmlt_alloc(hydra_hip_ctx* c, TmpBufs& tb, int n, int maxD, MmltBufs& b) {
   int rc = HYDRA_HIP_OK;
   b.v.n = n; b.v.maxD = maxD;
   b.v.st = (float*)tb.up(c, nullptr, size_t(mmltPlanes(maxD)) * n * 4, rc);
-  b.v.rayPos = (float4*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc); b.v.rayDir = (float4*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc);
-  b.hits = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 2 * 16, rc);
+  mmlt_queue_shape(n, b.nseg, b.cap);
+  const size_t slots = size_t(b.nseg) * b.cap;
+  for (int k = 0; k < 2; k++) {
+    b.rays[k].pos = (float4*)tb.up(c, nullptr, slots * 16, rc); b.rays[k].dir = (float4*)tb.up(c, nullptr, slots * 16, rc); b.rays[k].owner = (int*)tb.up(c, nullptr, slots * 4, rc);
+  }
+  b.hits = (HydraLiteHit*)tb.up(c, nullptr, slots * 16, rc);
+  b.counts = (uint32_t*)tb.up(c, nullptr, size_t(HK_MMLT_MAX_DEPTH + 2) * HK_CROW * 4, rc);
   b.v.eyePos = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc); b.v.eyeDir = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
   b.eyeHit = (HydraLiteHit*)tb.up(c, nullptr, size_t(n) * 16, rc);
   b.v.shPos = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc); b.v.shDir = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
   b.shVis = (float*)tb.up(c, nullptr, size_t(n) * 4, rc);
-  b.v.hits = b.hits; b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis;
+  b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis;
   return rc;
 }
 // F for every chain of the view: v.x, v.depth and v.out8 are set by the caller; maxDepth = the largest d among the chains
@@ -2509,11 +2547,15 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
   int rc = ensure_fetch_counters(c);
   if (rc) return rc;
   uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
-  hipLaunchKernelGGL(k_mmlt_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  HCHECK(hipMemsetAsync(b.counts, 0, size_t(maxDepth + 2) * HK_CROW * 4, c->stream));
+  const int bps = ((n + 255) / 256 + b.nseg - 1) / b.nseg;
+  hipLaunchKernelGGL(k_mmlt_begin, dim3(bps * b.nseg), dim3(256), 0, c->stream, s, v, b.nseg, b.cap, b.rays[0], b.counts);
   for (int k = 1; k <= maxDepth; k++) {
-    HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-    launch_closest(c, s, seg_q(nullptr, 2 * n, 1, 2 * n), v.rayPos, v.rayDir, b.hits, nullptr, nullptr, fetch);
-    hipLaunchKernelGGL(k_mmlt_step, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, s, v, k);
+    const MmltRays in = b.rays[(k - 1) & 1], out = b.rays[k & 1];
+    const SegQ q = seg_q(b.counts + size_t(k - 1) * HK_CROW, 0, b.nseg, b.cap);
+    HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
+    launch_closest(c, s, q, in.pos, in.dir, b.hits, nullptr, nullptr, fetch);
+    hipLaunchKernelGGL(k_mmlt_step, dim3(seg_grid(c, q, 256, 64)), dim3(256), 0, c->stream, s, v, k, q, in, b.hits, out, b.counts + size_t(k) * HK_CROW);
   }
   hipLaunchKernelGGL(k_mmlt_connect_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
   HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
@@ -2535,10 +2577,12 @@ static MmltBufs mmlt_run_bufs(hydra_hip_ctx* c) {
   MmltBufs b;
   auto& m = c->mmlt;
   b.v.n = m.n; b.v.maxD = m.maxD; b.v.st = (float*)m.st.p; b.v.x = (const float*)m.xNew.p; b.v.depth = (const int*)m.depth.p;
-  b.v.rayPos = (float4*)m.rayPos.p; b.v.rayDir = (float4*)m.rayDir.p; b.hits = (HydraLiteHit*)m.hits.p;
+  mmlt_queue_shape(m.n, b.nseg, b.cap);
+  for (int k = 0; k < 2; k++) { b.rays[k].pos = (float4*)m.rayPos[k].p; b.rays[k].dir = (float4*)m.rayDir[k].p; b.rays[k].owner = (int*)m.rayOwner[k].p; }
+  b.hits = (HydraLiteHit*)m.hits.p; b.counts = (uint32_t*)m.counts.p;
   b.v.eyePos = (float4*)m.eyePos.p; b.v.eyeDir = (float4*)m.eyeDir.p; b.eyeHit = (HydraLiteHit*)m.eyeHit.p;
   b.v.shPos = (float4*)m.shPos.p; b.v.shDir = (float4*)m.shDir.p; b.shVis = (float*)m.shVis.p;
-  b.v.hits = b.hits; b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis; b.v.out8 = (float*)m.out8.p;
+  b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis; b.v.out8 = (float*)m.out8.p;
   return b;
 }
 static bool mmlt_camera_ready(const hydra_hip_ctx* c) {   // F projects light-path vertices with varsF[HRT_WIDTH_F / HEIGHT_F] and mProj / mWorldView
@@ -2551,7 +2595,7 @@ int hydra_hip_mmlt_end(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   auto& m = c->mmlt;
   dev_free(m.sbDepth); dev_free(m.sbImage); m.sbSamples = 0;
-  DevBuf* all[] = {&m.ch, &m.depth, &m.xCur, &m.xNew, &m.out8, &m.image, &m.accum, &m.sum, &m.scaled, &m.st, &m.rayPos, &m.rayDir, &m.hits, &m.eyePos, &m.eyeDir, &m.eyeHit, &m.shPos, &m.shDir, &m.shVis};
+  DevBuf* all[] = {&m.ch, &m.depth, &m.xCur, &m.xNew, &m.out8, &m.image, &m.accum, &m.sum, &m.scaled, &m.st, &m.rayPos[0], &m.rayPos[1], &m.rayDir[0], &m.rayDir[1], &m.rayOwner[0], &m.rayOwner[1], &m.hits, &m.counts, &m.eyePos, &m.eyeDir, &m.eyeHit, &m.shPos, &m.shDir, &m.shVis};
   for (DevBuf* b : all) dev_free(*b);
   m.active = false; m.n = 0; m.mutations = 0;
   return HYDRA_HIP_OK;
@@ -2572,10 +2616,15 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
   auto& m = c->mmlt;
   m.n = n; m.maxD = maxD; m.firstBounce = first;
   const size_t N = size_t(n);
+  int qseg = 1, qcap = 0;
+  mmlt_queue_shape(n, qseg, qcap);
+  const size_t slots = size_t(qseg) * qcap;
   struct { DevBuf* b; size_t bytes; } allocs[] = {
     {&m.ch, N * CH_PLANES * 4}, {&m.depth, N * 4}, {&m.xCur, N * mmltStride(maxD) * 4}, {&m.xNew, N * mmltStride(maxD) * 4}, {&m.out8, N * 32},
     {&m.image, size_t(c->w) * c->h * 16}, {&m.scaled, size_t(c->w) * c->h * 16}, {&m.accum, size_t(maxD + 2) * 4}, {&m.sum, 8},
-    {&m.st, N * mmltPlanes(maxD) * 4}, {&m.rayPos, N * 32}, {&m.rayDir, N * 32}, {&m.hits, N * 32}, {&m.eyePos, N * 16}, {&m.eyeDir, N * 16}, {&m.eyeHit, N * 16},
+    {&m.st, N * mmltPlanes(maxD) * 4}, {&m.rayPos[0], slots * 16}, {&m.rayPos[1], slots * 16}, {&m.rayDir[0], slots * 16}, {&m.rayDir[1], slots * 16},
+    {&m.rayOwner[0], slots * 4}, {&m.rayOwner[1], slots * 4}, {&m.hits, slots * 16}, {&m.counts, size_t(HK_MMLT_MAX_DEPTH + 2) * HK_CROW * 4},
+    {&m.eyePos, N * 16}, {&m.eyeDir, N * 16}, {&m.eyeHit, N * 16},
     {&m.shPos, N * 16}, {&m.shDir, N * 16}, {&m.shVis, N * 4}};
   for (auto& a : allocs) if ((rc = dev_alloc(c, *a.b, a.bytes))) { hydra_hip_mmlt_end(c); return rc; }
   HCHECK(hipMemsetAsync(m.image.p, 0, size_t(c->w) * c->h * 16, c->stream));

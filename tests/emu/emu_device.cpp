@@ -139,12 +139,16 @@ void emu_mmlt_f(const EmuScene* e, int n, const int* depth, const float* xvec, i
   std::vector<HydraLiteHit> hits(2 * size_t(n)), eyeHit(n);
   std::vector<float> shVis(n), tfar(n);
   MmltView v;
-  v.n = n; v.maxD = maxD; v.st = st.data(); v.x = x.data(); v.depth = depth; v.rayPos = rayPos.data(); v.rayDir = rayDir.data(); v.hits = hits.data();
+  v.n = n; v.maxD = maxD; v.st = st.data(); v.x = x.data(); v.depth = depth;
   v.eyePos = eyePos.data(); v.eyeDir = eyeDir.data(); v.eyeHit = eyeHit.data(); v.shPos = shPos.data(); v.shDir = shDir.data(); v.shVis = shVis.data(); v.out8 = out8;
-  for (int i = 0; i < n; i++) mmltBegin(s, v, i);
-  for (int k = 1; k <= maxD; k++) {
+  for (int i = 0; i < n; i++) { bool ca, la; mmltBegin(s, v, i, rayPos[i], rayDir[i], ca, rayPos[n + i], rayDir[n + i], la); }
+  for (int k = 1; k <= maxD; k++) {   // plain arrays here: a finished sub-path keeps a ray that misses the scene
     emu_trace(e, 2 * n, reinterpret_cast<const float*>(rayPos.data()), reinterpret_cast<const float*>(rayDir.data()), hits.data(), nullptr, 0, nullptr, nullptr);
-    for (int i = 0; i < n; i++) { mmltCameraStep(s, v, i, k); mmltLightStep(s, v, i, k); }
+    for (int i = 0; i < n; i++) {
+      float4 np, nd;
+      mmltCameraStep(s, v, i, k, rayPos[i], rayDir[i], hits[i], np, nd); rayPos[i] = np; rayDir[i] = nd;
+      mmltLightStep(s, v, i, k, rayPos[n + i], rayDir[n + i], hits[n + i], np, nd); rayPos[n + i] = np; rayDir[n + i] = nd;
+    }
   }
   for (int i = 0; i < n; i++) { mmltConnectBegin(s, v, i); tfar[i] = shPos[i].w; }
   emu_trace(e, n, reinterpret_cast<const float*>(eyePos.data()), reinterpret_cast<const float*>(eyeDir.data()), eyeHit.data(), nullptr, 0, nullptr, nullptr);
