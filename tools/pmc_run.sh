@@ -2,6 +2,10 @@
 # Counter passes for the traversal kernels (GPU box).  Each --pmc set is its own rocprofv3 run (no trace domains mixed in).
 # The TA_*/TCP_* sets are left out on purpose: `--pmc TA_BUSY_avr TA_TA_BUSY_sum ...` made the HIP runtime abort inside
 # hipMemcpy under rocprofv3 on this pool and the run hung until the silence guard killed it.
+# Cause not established: the round-1 log of that run was not kept, and the rule for this pool is not to provoke a hang again, so the set was not
+# re-run with one TA counter per pass.  What is known: the same command with SQ_* / TCC_* / FETCH_SIZE / WRITE_SIZE sets, one set per run, has
+# worked in every run since (bench.py's live PMC child runs use exactly those), and the product's hipMemcpy path runs clean under them -- which
+# points at the profiler's handling of that counter set (eight TA/TCP block counters in one group), not at the product.
 # usage: tools/pmc_run.sh <outdir under gpurun_out> [pass_bench args...]
 set -e
 OUT=$1; shift
