@@ -3,6 +3,7 @@
 // :604-717 (root quad, mesh subtrees shared between instances).  The build algorithm itself is ours.
 #include <cstdlib>
 #include "bvh4_builder.h"
+#include "../../include/hydra_hip.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -168,6 +169,7 @@ int BVH4Builder::BuildTree(std::vector<PrimRef>& prims, int leafMax) {
 
 void BVH4Builder::CommitScene() {
   m_nodes.clear(); m_primIds.clear();
+  statGpuBuildMs = 0.0f;
   // (1) one tree per mesh, over its non-degenerate triangles (zero-area triangles are dropped, bvh_access_dll2.cpp:354-355)
   for (auto& mesh : m_meshes) {
     const int triNum = int(mesh.indices.size() / 3);
@@ -189,7 +191,29 @@ void BVH4Builder::CommitScene() {
     if (prims.empty()) RunTimeError("BVH4Builder::CommitScene: mesh without valid triangles");
     int leafMax = maxLeafSize;
     if (const char* e = getenv("HYDRA_BVH_MAX_LEAF")) leafMax = std::max(1, std::min(16, atoi(e)));   // tuning sweeps only
-    mesh.rootNode = BuildTree(prims, leafMax);
+    if (gpuBuildDevice >= 0) {   // the tree of this mesh comes from the device in build form; node and primitive indices are rebased into the shared arrays
+      std::vector<HydraBuildNode> gn(size_t(triNum) * 2);
+      std::vector<int32_t> order(static_cast<size_t>(triNum));
+      int32_t nodeCount = 0, primCount = 0;
+      float ms = 0.0f;
+      const int rc = hydra_hip_bvh_build_mesh(gpuBuildDevice, mesh.vert4f.data(), int(mesh.vert4f.size() / 4), mesh.indices.data(), int(mesh.indices.size()), leafMax,
+                                              gn.data(), &nodeCount, order.data(), &primCount, &ms);
+      if (rc != HYDRA_HIP_OK) RunTimeError(std::string("BVH4Builder::CommitScene: GPU build failed: ") + hydra_hip_bvh_last_error());
+      statGpuBuildMs += ms;
+      const int nodeBase = int(m_nodes.size()), primBase = int(m_primIds.size());
+      for (int k = 0; k < nodeCount; k++) {
+        TmpNode tn;
+        tn.box.mn = float3(gn[k].boxMin[0], gn[k].boxMin[1], gn[k].boxMin[2]);
+        tn.box.mx = float3(gn[k].boxMax[0], gn[k].boxMax[1], gn[k].boxMax[2]);
+        for (int c = 0; c < 4; c++) tn.child[c] = gn[k].child[c] >= 0 ? nodeBase + gn[k].child[c] : -1;
+        tn.first = gn[k].count > 0 ? primBase + gn[k].first : 0;
+        tn.count = gn[k].count;
+        m_nodes.push_back(tn);
+      }
+      m_primIds.insert(m_primIds.end(), order.begin(), order.begin() + primCount);
+      mesh.rootNode = nodeBase;
+    } else
+      mesh.rootNode = BuildTree(prims, leafMax);
     mesh.bounds = m_nodes[mesh.rootNode].box;
   }
   // (2) top level over instances

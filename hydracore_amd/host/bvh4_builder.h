@@ -40,6 +40,10 @@ public:
   void ConvertUnmap();
 
   // build statistics (for DESIGN.md / tests)
+  // >= 0: the per-mesh trees are built on that GPU (hydra_hip_bvh_build_mesh: LBVH, hydracore_amd/csrc/hydra_bvh.hip) instead of by the binned-SAH
+  // build below; the top level over the instances and the emission stay here.  Set by RenderDriverLite from HYDRA_GPU_BVH / its option.
+  int gpuBuildDevice = -1;
+  float statGpuBuildMs = 0.0f;   // device time of the GPU builds of the last CommitScene
   int maxLeafSize = 2;   // measured on MI355X (profiles/r01/pass_bvh_leaf_size.log): closest-hit traversal 11 % faster than with 4, shadow rays equal
   size_t statInnerQuads = 0, statLeaves = 0, statTriangles = 0;
 

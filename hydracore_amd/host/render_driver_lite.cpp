@@ -1040,7 +1040,10 @@ void RenderDriverLite::CreateAlphaTestTable(ConvertionResult& cr) {
 }
 
 void RenderDriverLite::EndScene() {
+  // HYDRA_GPU_BVH=<device>: the mesh trees are built on that GPU (LBVH, hydracore_amd/csrc/hydra_bvh.hip) instead of by the host's binned-SAH build
+  if (const char* e = getenv("HYDRA_GPU_BVH")) { m_bvh.gpuBuildDevice = atoi(e); m_bvhAlpha.gpuBuildDevice = atoi(e); }
   m_bvh.CommitScene();
+  if (m_bvh.gpuBuildDevice >= 0) m_log += "BVH: mesh trees built on GPU " + std::to_string(m_bvh.gpuBuildDevice) + " in " + std::to_string(m_bvh.statGpuBuildMs) + " ms of device time\n";
   {
     ConvertionResult cr = m_bvh.ConvertMap();
     if (m_splitAlphaTree && m_bvhAlpha.HasInstances()) {

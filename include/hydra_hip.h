@@ -212,6 +212,17 @@ int hydra_hip_stage_light_pdf_fwd(hydra_hip_handle h, int n, const int32_t* ligh
 int hydra_hip_stage_camera_connect(hydra_hip_handle h, int n, const float* pos4, const float* norm4, const float* disk2, float* out8);
 /* MutateKelemen (crandom.h:189-210): primary-space values + 2 randoms each, step parameters p2 < p1 (defaults 64, 1024) */
 int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* values, const float* rands2, float p2, float p1, float* out);
+/* ---- GPU-side BVH build (row f2).  The reference builds through IBVHBuilder2 (hydra_drv/IBVHBuilderAPI.h:35-68: InstanceTriangleMeshes /
+ * CommitScene / ConvertMap, Embree 2.17 behind it); this entry builds the tree of ONE mesh on the device -- Morton codes, a hand-written stable
+ * radix sort, the binary radix tree of Karras 2012, bottom-up boxes, level-synchronous collapse to 4-wide nodes with leaves of <= leaf_max
+ * triangles -- and returns it in build form: node 0 is the root; an inner node has count == 0 and up to four children (-1 = none), a leaf owns
+ * prim_order[first .. first + count).  Degenerate triangles are dropped (bvh_access_dll2.cpp:354-355).  Emission into the reference's quad /
+ * triangle-list layout (ConvertMap, bvh_access_dll2.cpp:604-717) is the host builder's (hydracore_amd/host/bvh4_builder.cpp), which its own
+ * SAH build shares.  Needs no layer handle; nodes_out holds up to 2 x triangles nodes, prim_order_out up to `triangles` ids. */
+typedef struct HydraBuildNode { float boxMin[3]; int32_t first; float boxMax[3]; int32_t count; int32_t child[4]; } HydraBuildNode;
+int hydra_hip_bvh_build_mesh(int device, const float* vert4f, int num_vert, const int32_t* indices, int num_indices, int leaf_max,
+                             HydraBuildNode* nodes_out, int32_t* node_count_out, int32_t* prim_order_out, int32_t* prim_count_out, float* build_ms_out);
+const char* hydra_hip_bvh_last_error(void);
 /* ---- IntegratorMMLT (row f3; hydra_drv/CPUExp_Integrators_MMLT.cpp): multiplexed MLT over the simplified bidirectional sampler --------------
  * The reference runs 8 chains (one per OpenMP thread, :583-585) of width*height mutations per pass; here every chain is a GPU thread and a
  * pass advances all of them together: mutate (MutatePrimarySpace :93-144), F (:146-315) through the traversal kernels, accept / reject with

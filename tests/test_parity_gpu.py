@@ -5,6 +5,8 @@ frame): bit-exact or 1 ulp.  Anything that passes through sinf/cosf/powf (device
 path, and at most 0.5% of the paths may diverge (a last-bit difference in a sampled direction can flip a later
 hit/shadow decision).  Tolerances are written at each assert.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -404,6 +406,94 @@ def test_sbdpt_pass_follows_the_oracle_and_converges(gpu42):
     a, r = down(img[..., :3]), down(want)
     assert abs(a.mean() - r.mean()) < 0.03 * r.mean()
     assert np.corrcoef(a.ravel(), r.ravel())[0, 1] > 0.99
+
+
+def _check_build_tree(nodes, order, verts, idx, leaf_max):
+    """structure of a build-form BVH4: every valid triangle in exactly one leaf, leaf sizes, boxes that hold their triangles / children"""
+    tri = idx.reshape(-1, 3)
+    p = verts[:, :3][tri]                                                       # (T, 3, 3)
+    area = 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
+    valid = np.nonzero(area > 0)[0]
+    assert sorted(order.tolist()) == valid.tolist()                             # a permutation of the non-degenerate triangles
+    leaves = nodes["count"] > 0
+    assert 1 <= nodes["count"][leaves].min() and nodes["count"][leaves].max() <= leaf_max
+    covered = np.zeros(len(order), np.int32)
+    for f, c in zip(nodes["first"][leaves], nodes["count"][leaves]):
+        covered[f:f + c] += 1
+    assert (covered == 1).all()
+    tmin, tmax = p.min(axis=1), p.max(axis=1)
+    for k in np.nonzero(leaves)[0]:
+        ids = order[nodes["first"][k]:nodes["first"][k] + nodes["count"][k]]
+        assert (tmin[ids] >= nodes["boxMin"][k]).all() and (tmax[ids] <= nodes["boxMax"][k]).all()
+    seen = np.zeros(len(nodes), np.int32)
+    seen[0] = 1
+    for k in np.nonzero(~leaves)[0]:
+        ch = nodes["child"][k]
+        ch = ch[ch >= 0]
+        assert 2 <= len(ch) <= 4
+        seen[ch] += 1
+        assert (nodes["boxMin"][ch] >= nodes["boxMin"][k]).all() and (nodes["boxMax"][ch] <= nodes["boxMax"][k]).all()
+    assert (seen == 1).all()                                                    # a tree: every node has one parent, the root none
+
+
+def test_gpu_bvh_builder_structure(built):
+    """row f2: hydra_hip_bvh_build_mesh (Morton codes, radix sort, Karras hierarchy, refit, collapse to 4-wide) on synthetic meshes with
+    duplicated centroids, degenerate triangles, one and two triangles, and a 200 k-triangle height field"""
+    from hydracore_amd.capi import bvh_build_mesh
+    rng = np.random.default_rng(3)
+    # (a) random soup with exact duplicates and degenerate triangles
+    verts = np.zeros((3000, 4), np.float32)
+    verts[:, :3] = rng.uniform(-1, 1, (3000, 3))
+    idx = rng.integers(0, 3000, (5000, 3)).astype(np.int32)
+    idx[100:200] = idx[0:100]                                                    # duplicates: equal Morton codes, the index tie-break of the hierarchy
+    idx[300:320, 2] = idx[300:320, 1]                                            # degenerate: dropped
+    for leaf_max in (1, 2, 4):
+        nodes, order, ms = bvh_build_mesh(verts, idx, leaf_max)
+        _check_build_tree(nodes, order, verts, idx.ravel(), leaf_max)
+    # (b) one triangle, two triangles
+    for t in (1, 2):
+        nodes, order, ms = bvh_build_mesh(verts, idx[:t], 2)
+        _check_build_tree(nodes, order, verts, idx[:t].ravel(), 2)
+    # (c) a regular grid (many equal coordinates) of 200 k triangles: timing is printed for the log
+    n = 317
+    gx, gz = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32))
+    gv = np.zeros((n * n, 4), np.float32)
+    gv[:, 0], gv[:, 2], gv[:, 1] = gx.ravel(), gz.ravel(), np.sin(gx.ravel() * 0.1) * np.cos(gz.ravel() * 0.07)
+    q = (np.arange(n - 1)[:, None] * n + np.arange(n - 1)[None, :]).ravel()
+    gi = np.concatenate([np.stack([q, q + 1, q + n], 1), np.stack([q + 1, q + n + 1, q + n], 1)]).astype(np.int32)
+    nodes, order, ms = bvh_build_mesh(gv, gi, 2)
+    _check_build_tree(nodes, order, gv, gi.ravel(), 2)
+    print("GPU LBVH: %d triangles in %.3f ms of device time (%.1f Mtris/s), %d nodes" % (len(gi), ms, len(gi) / ms / 1e3, len(nodes)))
+    with pytest.raises(RuntimeError):
+        bvh_build_mesh(verts, np.array([[0, 1, 3000]], np.int32), 2)             # vertex index out of range
+
+
+def test_scene_on_gpu_built_trees_matches_the_sah_scene(built):
+    """row f2 end to end: the front end with HYDRA_GPU_BVH builds every mesh tree on the device; the HIP traversal on those arrays is bit-exact
+    against the oracle on the same arrays, and the closest hits are those of the host-built (SAH) scene"""
+    from hydracore_amd import HostScene, HipCore
+    import conftest
+    os.environ["HYDRA_GPU_BVH"] = "0"
+    try:
+        sc = HostScene(scene_path("atrium_small"), 96, 54, trace_depth=5, enable_dof=0, use_hip=False)
+        bg = sc.buffers()
+        assert "mesh trees built on GPU" in sc.log()
+    finally:
+        del os.environ["HYDRA_GPU_BVH"]
+    _, bs = host_scene("atrium_small", 96, 54, 5)
+    assert bg["bvh_nodes"].size != bs["bvh_nodes"].size or not np.array_equal(bg["bvh_nodes"], bs["bvh_nodes"])      # a different tree ...
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(bg)
+    orc_g, orc_s = make_oracle(bg), make_oracle(bs)
+    pos4, dir4 = random_rays(65536, 77, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
+    hits = core.stage_trace(pos4, dir4)
+    ref_g = orc_g.trace(pos4, dir4)
+    assert (hits == ref_g).all()                                                 # ... traversed identically by device and oracle
+    ref_s = orc_s.trace(pos4, dir4)
+    same = (hits["primId"] == ref_s["primId"]) & (hits["instId"] == ref_s["instId"]) & (hits["geomId"] == ref_s["geomId"])
+    assert same.mean() > 0.9999, same.mean()                                     # ... with the same closest hits (ties between coplanar triangles aside)
+    assert np.abs(hits["t"][same] - ref_s["t"][same]).max() == 0.0
+    core.close()
 
 
 def test_mmlt_through_the_ihwlayer_adapter(built):
