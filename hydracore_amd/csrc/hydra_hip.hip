@@ -832,7 +832,7 @@ __global__ void k_stage_mutate_kelemen(int n, const float* __restrict__ values, 
 // The sub-path rays of a level live in segmented, compacted queues like the path tracer's (SegQ): a ray slot holds origin, direction and its
 // owner (chain * 2 + side, side 1 = light sub-path); a finished sub-path simply appends nothing, so a level traces only the live rays.
 struct MmltRays { float4* pos; float4* dir; int* owner; };
-__global__ void k_mmlt_begin(SceneDev s, MmltView v, int nseg, int cap, MmltRays out, uint32_t* __restrict__ outCount) {
+__global__ void __launch_bounds__(256) k_mmlt_begin(SceneDev s, MmltView v, int nseg, int cap, MmltRays out, uint32_t* __restrict__ outCount) {
   const int seg = int(blockIdx.x) % nseg, bis = int(blockIdx.x) / nseg;
   const int i = (bis * nseg + seg) * int(blockDim.x) + int(threadIdx.x);   // chains are dealt to the segments in chunks of one block
   float4 cpos, cdir, lpos, ldir;
@@ -844,7 +844,7 @@ __global__ void k_mmlt_begin(SceneDev s, MmltView v, int nseg, int cap, MmltRays
   const int dl = seg * cap + wave_compact_index(la, counter);
   if (la) { out.pos[dl] = lpos; out.dir[dl] = ldir; out.owner[dl] = i * 2 + 1; }
 }
-__global__ void k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
+__global__ void __launch_bounds__(256, 3) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
   const SegIter it = segq_iter(q);
   uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
   for (int idx = it.first; idx - int(__lane_id()) < it.count; idx += it.step) {   // whole waves iterate together: the compaction is a wave ballot
@@ -866,7 +866,7 @@ __global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.n) mmltConnectBegin(s, v, i);
 }
-__global__ void k_mmlt_connect_end(SceneDev s, MmltView v) {
+__global__ void __launch_bounds__(256, 3) k_mmlt_connect_end(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.n) mmltConnectEnd(s, v, i);
 }
