@@ -160,4 +160,5 @@ HK_DEV const int*   g_varsI(const SceneDev& s) { return s.globals + HG_VARS_I; }
 #define HK_PI 3.14159265358979323846f   /* the pinned build of the reference compiles with -cl-single-precision-constant */
 #define HK_INV_PI    0.31830988618379067154f
 #define HK_INV_TWOPI 0.15915494309189533577f
+#define HK_TWOPI     6.28318530717958647692f
 #define HK_MAXFLOAT  FLT_MAX   /* ctrace.h:665-667: MAXFLOAT is glibc's FLT_MAX on the CPU path */

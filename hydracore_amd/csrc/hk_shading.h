@@ -379,8 +379,8 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
-enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_ALL = 63,
-       HK_FEAT_CLASSIC = 31 /* everything but normal maps */ };
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ALL = 255,
+       HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent and Blinn nodes */ };
 
 // ================================================================================================ materials
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
@@ -440,6 +440,8 @@ HK_DEV int shadeClassOfMaterial(const float* m) {
     case HMT_BLEND_MASK: return 9 + (matType(m + size_t(as_int(m[HM_BLEND_MAT1])) * HM_NODE_FLOATS) == HMT_BLEND_MASK || matType(m + size_t(as_int(m[HM_BLEND_MAT2])) * HM_NODE_FLOATS) == HMT_BLEND_MASK ? 1 : 0);
     case HMT_THIN_GLASS: return 11;
     case HMT_GLASS: return 12;
+    case HMT_TRANSLUCENT: return 14;
+    case HMT_BLINN: return 5;      // shaded next to phong
     default: return 13;
   }
 }
@@ -457,6 +459,13 @@ __device__ static const float hk_glosscoeff[10][4] = {   // cmaterial.h:435-450
     {45037.7068059246f, 9161.90096119855f, 813.432835820895f, 82.0f},
     {167903.678757035f, 183240.189801913f, 3996.94423223835f, 300.0f},
     {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
+// translucent (diffuse transmission), cmaterial.h:1852-1909; colour and sampler sit at the lambert offsets
+HK_DEV f3 lambertColorFwd(const float* m, f2 tc, const SceneDev& s);
+HK_DEV float translucentEvalPDF(f3 l, f3 v, f3 n) {
+  const float sign1 = dot(l, n) > 0 ? 1.0f : -1.0f, sign2 = dot(v, n) > 0 ? 1.0f : -1.0f;
+  const float coeff = (sign1 * sign2 < 0.0f) ? 1.0f : 0.0f;
+  return fabsf(dot(l, n)) * HK_INV_PI * coeff;
+}
 HK_DEV float cosPowerFromGlosiness(float x) {   // cmaterial.h:453-466
   const int k = (fabsf(x - 1.0f) < 1e-5f) ? 10 : int(x * 10.0f);
   const float x1 = (x - float(k) * 0.1f);
@@ -467,6 +476,23 @@ HK_DEV float cosPowerFromGlosiness(float x) {   // cmaterial.h:453-466
 // ---- lambert, cmaterial.h:219-263
 HK_DEV f3 lambertColor(const float* m, f2 tc, const SceneDev& s) {
   return clamp3(sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s) * matColor(m), 0.0f, 1.0f);
+}
+HK_DEV f3 lambertColorFwd(const float* m, f2 tc, const SceneDev& s) { return lambertColor(m, tc, s); }
+HK_DEV f3 translucentEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  const float sign1 = dot(l, n) > 0 ? 1.0f : -1.0f, sign2 = dot(v, n) > 0 ? 1.0f : -1.0f;
+  const float coeff = (sign1 * sign2 < 0.0f) ? 1.0f : 0.0f;
+  return (lambertColor(m, tc, s) * coeff) * HK_INV_PI;
+}
+HK_DEV void TranslucentSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 kd = lambertColor(m, tc, s);
+  const f3 nn = n * (-1.0f);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, nn, nn, 1.0f);
+  const float cosTheta = dot(newDir, nn);
+  out.direction = newDir;
+  out.pdf = cosTheta * HK_INV_PI;
+  out.color = kd * HK_INV_PI;
+  if (cosTheta <= 1e-6f) out.color = mk3(0, 0, 0);
+  out.flags = (HRE_D | HRE_T);
 }
 HK_DEV void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
   const f3 color = lambertColor(m, tc, s);
@@ -556,6 +582,70 @@ HK_DEV void PhongSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_di
   out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
 }
 // ---- mirror, cmaterial.h:395-430
+// ---- Blinn distribution in a Torrance-Sparrow microfacet model (brdf_type "torranse_sparrow"), cmaterial.h:1020-1168, cmatpbrt.h:33-103;
+// colour, gloss and the two samplers sit at the phong offsets
+HK_DEV float TorranceSparrowG1(f3 wo, f3 wi, f3 wh) {   // PBRT frame
+  const float NdotWh = fabsf(wh.z), NdotWo = fabsf(wo.z), NdotWi = fabsf(wi.z);
+  const float WOdotWh = fmaxf(fabsf(dot(wo, wh)), HK_DEPSILON);
+  return fminf(1.f, fminf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+}
+HK_DEV float TorranceSparrowGF1(f3 wo, f3 wi) {   // PBRT frame; the Fresnel factor of the reference is the constant 1
+  const float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+  if (cosThetaI == 0.0f || cosThetaO == 0.0f) return 0.0f;
+  f3 wh = wi + wo;
+  if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+  wh = normalize(wh);
+  return fminf(TorranceSparrowG1(wo, wi, wh) * 1.0f / fmaxf(4.0f * cosThetaI * cosThetaO, HK_DEPSILON), 250.0f);
+}
+HK_DEV float TorranceSparrowGF2(f3 wo, f3 wi, f3 n) {   // world frame
+  const float cosThetaO = fabsf(dot(wo, n)), cosThetaI = fabsf(dot(wi, n));
+  if (cosThetaI == 0.f || cosThetaO == 0.0f) return 0.0f;
+  f3 wh = wi + wo;
+  if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+  wh = normalize(wh);
+  const float NdotWh = fabsf(dot(wh, n)), WOdotWh = fmaxf(fabsf(dot(wo, wh)), HK_DEPSILON);
+  const float G = fminf(1.f, fminf((2.f * NdotWh * cosThetaO / WOdotWh), (2.f * NdotWh * cosThetaI / WOdotWh)));
+  return fminf(G * 1.0f / fmaxf(4.0f * cosThetaI * cosThetaO, HK_DEPSILON), 10.0f);
+}
+HK_DEV float blinnEvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return 1.0f;
+  const float exponent = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 wh = normalize(l + v);
+  const float costheta = fabsf(dot(wh, n));
+  return ((exponent + 1.0f) * powf(costheta, exponent)) / (HK_TWOPI * 4.0f * dot(l, wh));
+}
+HK_DEV f3 blinnEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const SceneDev& s) {
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return mk3(0, 0, 0);
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float exponent = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 wh = normalize(l + v);
+  const float D = (exponent + 2.0f) * HK_INV_TWOPI * powf(fabsf(dot(wh, n)), exponent);
+  return (color * D) * TorranceSparrowGF2(l, v, n);
+}
+HK_DEV void BlinnSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
+  const f3 color = clamp3(matColor(m) * sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s), 0.0f, 1.0f);
+  const float gloss = phongGlosiness(m, tc, s);
+  f3 nx, ny;
+  const f3 nz = n;
+  CoordinateSystem(nz, nx, ny);
+  const f3 wo = mk3(-dot(ray_dir, nx), -dot(ray_dir, ny), -dot(ray_dir, nz));
+  const float exponent = cosPowerFromGlosiness(gloss);
+  const float costheta = powf(r1, 1.0f / (exponent + 1.0f));
+  const float sintheta = sqrtf(fmaxf(0.0f, 1.0f - costheta * costheta));
+  const float phi = r2 * HK_TWOPI;
+  const f3 wh = mk3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);   // SphericalDirectionPBRT
+  const f3 wi = (wh * (2.0f * dot(wo, wh))) - wo;
+  const f3 newDir = normalize(((nx * wi.x) + (ny * wi.y)) + (nz * wi.z));
+  const f3 v = ray_dir * (-1.0f);
+  if (dot(n, v) < 1e-6f || dot(n, newDir) < 1e-6f) { out.color = mk3(0, 0, 0); out.pdf = 1.0f; }
+  else {
+    const float D = ((exponent + 2.0f) * HK_INV_TWOPI * powf(costheta, exponent));
+    out.color = (color * D) * TorranceSparrowGF1(wo, wi);
+    out.pdf = ((exponent + 1.0f) * powf(costheta, exponent)) / fmaxf(HK_TWOPI * 4.0f * dot(wo, wh), HK_DEPSILON);
+  }
+  out.direction = newDir;
+  out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
+}
 HK_DEV void MirrorSampleAndEvalBRDF(const float* m, f3 ray_dir, f3 n, f2 tc, const SceneDev& s, MatSample& out) {
   const f3 tex = sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s);
   f3 newDir = reflect3(ray_dir, n);
@@ -885,6 +975,8 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_GGX: if (F & HK_FEAT_GGX) GGXSample2AndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
     case HMT_THIN_GLASS: if (F & HK_FEAT_GLASS) ThinglassSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
     case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, hitNorm, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
+    case HMT_TRANSLUCENT: if (F & HK_FEAT_TRANSLUCENT) TranslucentSampleAndEvalBRDF(node, rands[0], rands[1], hitNorm, sh.texCoord, s, out); break;
+    case HMT_BLINN: if (F & HK_FEAT_BLINN) BlinnSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
     default: break;
   }
   if (nmap) {   // :2322-2327: the caller multiplies by the cosine to the shading normal
@@ -929,7 +1021,8 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
       bool diffuse = false;
       const int type = matType(m);
       f3 n = sc.n;
-      float cosMult = 1.0f;
+      f3 btdf = mk3(0, 0, 0);
+      float cosMult = 1.0f, cosMult2 = 1.0f;
       if ((F & HK_FEAT_NMAP) && hasNormalMap(m)) {   // :2431-2459: the cosine the caller applies is to sc.n, the lobe sees the bumped normal
         n = BumpMapping(sc.tg, sc.bn, sc.fn, sc.tc, m, s);
         const f3 lDir = fwdDir ? sc.v : sc.l;
@@ -937,7 +1030,10 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         const float cosThetaOut1 = fmaxf(dot(lDir, sc.n), 0.0f), cosThetaOut2 = fmaxf(dot(lDir, n), 0.0f);
         cosMult = (cosThetaOut2 / fmaxf(cosThetaOut1, clampVal));
         if (cosThetaOut1 <= 0.0f) cosMult = 0.0f;
-        if (fwdDir && dot(sc.l, sc.fn) <= 0.0f) cosMult = 0.0f;
+        const float cosThetaOut3 = fmaxf(-dot(lDir, sc.n), 0.0f), cosThetaOut4 = fmaxf(-dot(lDir, n), 0.0f);
+        cosMult2 = (cosThetaOut4 / fmaxf(cosThetaOut3, clampVal));
+        if (cosThetaOut3 <= 0.0f) cosMult2 = 0.0f;
+        if (fwdDir && dot(sc.l, sc.fn) <= 0.0f) { cosMult = 0.0f; cosMult2 = 0.0f; }
       }
       if (type == HMT_PHONG) {
         brdf = phongEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
@@ -957,9 +1053,19 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         pf = fabsf(dot(sc.l, n)) * HK_INV_PI;
         pr = fabsf(dot(sc.v, n)) * HK_INV_PI;
         diffuse = true;
+      } else if ((F & HK_FEAT_BLINN) && type == HMT_BLINN) {
+        brdf = blinnEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
+        pf = blinnEvalPDF(m, sc.l, sc.v, n, sc.tc, s);
+        pr = blinnEvalPDF(m, sc.v, sc.l, n, sc.tc, s);
+      } else if ((F & HK_FEAT_TRANSLUCENT) && type == HMT_TRANSLUCENT) {
+        btdf = translucentEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult2;
+        pf = translucentEvalPDF(sc.l, sc.v, n);
+        pr = translucentEvalPDF(sc.v, sc.l, n);
+        diffuse = true;
       }
       if (fwdDir) brdf = brdf * adjointBsdfShadeNormalFix(sc.v, sc.l, sc.n, sc.fn, diffuse ? 20.0f : 2.0f);
       val.brdf = val.brdf + (brdf * currW);
+      if (F & HK_FEAT_TRANSLUCENT) val.btdf = val.btdf + (btdf * currW);
       val.pdfFwd += currW * pf;
       val.pdfRev += currW * pr;
       val.diffuse = val.diffuse && diffuse;

@@ -456,7 +456,7 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
     if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded<HK_FEAT_CLASSIC>(s, mat, surf, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];   // the split form carries no tangent frame: scenes with normal maps use the fused kernel
     const f3 accum = xyz(acc4) + (xyz(thr4) * explicitColor);
     float4 oPos, oDir, oThr, oAcc;
-    next_bounce_phase(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, accum, re.z, oPos, oDir, oThr, oAcc);
+    next_bounce_phase<HK_FEAT_CLASSIC>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, accum, re.z, oPos, oDir, oThr, oAcc);
     S.pos4[i] = oPos; S.dir4[i] = oDir; S.thr4[i] = oThr; S.acc4[i] = oAcc;
     S.rng2[i] = make_uint2(gen.x, gen.y);
   }
@@ -1189,11 +1189,13 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (type == HMT_OREN_NAYAR) feat |= HK_FEAT_OREN_NAYAR;
       if (type == HMT_GLASS || type == HMT_THIN_GLASS) feat |= HK_FEAT_GLASS;
       if (type == HMT_GGX) feat |= HK_FEAT_GGX;
+      if (type == HMT_TRANSLUCENT) feat |= HK_FEAT_TRANSLUCENT;
+      if (type == HMT_BLINN) feat |= HK_FEAT_BLINN;
       const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
-                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX);
+                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX || type == HMT_TRANSLUCENT || type == HMT_BLINN);
       if (!known)
         return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has BxDF class " + std::to_string(type) +
-                                             "; the HIP layer implements phong, GGX, mirror, thin glass, glass, lambert, oren-nayar, blend mask and emissive only");
+                                             "; the HIP layer implements phong, Blinn (Torrance-Sparrow), GGX, mirror, thin glass, glass, translucent, lambert, oren-nayar, blend mask and emissive only");
     }
   }
   c->matFeatures = feat;
@@ -1488,6 +1490,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
+  if (!fused && (c->sceneFeatures & (HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN))) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has translucent or Blinn materials, which only the fused bounce kernel contains (fused_bounce = 1)");
   if (!fused && (c->sceneFeatures & HK_FEAT_NMAP)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has normal-mapped materials; the split bounce form (fused_bounce = 0) carries no tangent frame in its record, use the fused kernel");
   const SceneStage stage = scene_stage(c);
   const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
@@ -1513,7 +1516,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
-          else if (f & HK_FEAT_NMAP) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
           else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
           else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
           else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);

@@ -2,6 +2,7 @@
 #include "render_driver_lite.h"
 #include <fstream>
 #include <sstream>
+#include <functional>
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -111,6 +112,14 @@ typedef std::shared_ptr<MatTree> MatPtr;
 MatPtr new_node() { auto p = std::make_shared<MatTree>(); init_material_node(p->plain); return p; }
 
 // LambertMaterial, PlainMaterialConverter.cpp:96-136
+MatPtr make_lambert(float3 color, int32_t texId, const Sampler& s);
+// TranslucentMaterial, PlainMaterialConverter.cpp:182-213: the lambert node's slots with class TRANSLUCENT
+MatPtr make_translucent(float3 color, int32_t texId, const Sampler& s) {
+  MatPtr m = make_lambert(color, texId, s);
+  put_i(m->plain, HM_TYPE, HMT_TRANSLUCENT);
+  put_i(m->plain, HM_FLAGS, HMF_HAS_DIFFUSE);
+  return m;
+}
 MatPtr make_lambert(float3 color, int32_t texId, const Sampler& s) {
   MatPtr p = new_node();
   float* d = p->plain;
@@ -145,6 +154,13 @@ MatPtr make_phong(float3 color, int32_t texId, const Sampler& sc, float cosPower
   put_sampler_at(d, glossTexId, sg, HM_PHONG_GLOSS_TEXID, HM_PHONG_GLOSS_TEXMATRIXID, HM_PHONG_SAMPLER1);
   put_i(d, HM_TYPE, HMT_PHONG);
   put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS);
+  return p;
+}
+// BlinnTorranceSrappowMaterial, PlainMaterialConverter.cpp:462-498: the phong offsets plus the anisotropy value at 19, which the shading never reads
+MatPtr make_blinn(float3 color, int32_t texId, const Sampler& sc, float cosPower, int32_t glossTexId, const Sampler& sg, float gloss, float aniso) {
+  MatPtr p = make_phong(color, texId, sc, cosPower, glossTexId, sg, gloss);
+  p->plain[HM_BLINN_ANISOTROPY] = aniso;
+  put_i(p->plain, HM_TYPE, HMT_BLINN);
   return p;
 }
 // GGXMaterial, PlainMaterialConverter.cpp:635-680 (the anisotropy arguments of the constructor are never stored)
@@ -364,7 +380,6 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const float3 colorS = read_value3f(xchild(reflect, "color"));
   const float3 colorT = read_value3f(xchild(transpar, "color"));
   const float3 colorSSS = read_value3f(xchild(sss, "color"));
-  if (length(colorSSS) > 1e-5f) Unsupported("translucency (material " + std::to_string(a_matId) + ")");
   if (const XmlNode* displ = a_node->child("displacement")) {
     const std::string btype = displ->attr("type");
     if (btype != "normal_bump") Unsupported("displacement type '" + btype + "' (material " + std::to_string(a_matId) + "): only normal_bump is built (height maps go through IHWLayer::NormalMapFromDisplacement, an OpenCL-layer function)");
@@ -398,6 +413,15 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
       pMaterialD = make_orennayar(read_value3f(xchild(diffuse, "color")), read_value1f(xchild(diffuse, "roughness")), texId, s);
     else
       pMaterialD = make_lambert(read_value3f(xchild(diffuse, "color")), texId, s);
+    // DiffuseAndTranslucentBlendMaterialFromHydraMtl :1024-1059: translucency alone replaces the diffuse node, both blend by the translucency colour
+    // (plain mask, strong extrusion); TranslucentMaterialFromHydraMtl :1003-1022 halves the colour
+    if (length(colorSSS) > 1e-5f) {
+      Sampler st; int32_t ttexId = int32_t(HYDRA_INVALID_TEXTURE);
+      if (sampler_node(sss)) { st = sampler_from_texref(sampler_node(sss)); ttexId = st.texId; }
+      MatPtr pTrans = make_translucent(colorSSS * 0.5f, ttexId, st);
+      if (length(read_value3f(xchild(diffuse, "color"))) > 1e-5f) pMaterialD = make_blend(pTrans, pMaterialD, colorSSS, ttexId, st, false, true, HBF_EXTRUSION_STRONG, 1.5f);
+      else pMaterialD = pTrans;
+    }
   }
   // ReflectiveMaterialFromHydraMtl :1061-1149
   MatPtr pMaterialS;
@@ -412,6 +436,10 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     const std::string brdf = xattr(reflect, "brdf_type");
     if (texGloss == int32_t(HYDRA_INVALID_TEXTURE) && glossVal >= 0.995f)
       pMaterialS = make_mirror(colorS, texReflId, samplRefl);
+    else if (brdf == "torranse_sparrow") {   // sic, PlainMaterialConverter.cpp:1130
+      const XmlNode* an = xchild(reflect, "anisotropy");
+      pMaterialS = make_blinn(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal, an ? read_value1f(an) : 0.0f);
+    }
     else if (brdf == "ggx" || brdf == "GGX")
       pMaterialS = make_ggx(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal, fresnelIOR);
     else {
@@ -490,6 +518,10 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     memcpy(dst + HM_EMISSIVE_COLOR, src + HM_EMISSIVE_COLOR, 12);
     memcpy(dst + HM_EMISSIVE_TEXID, src + HM_EMISSIVE_TEXID, 12);
     memcpy(dst + HM_EMISSIVE_SAMPLER, src + HM_EMISSIVE_SAMPLER, 48);
+  }
+  {   // HaveAnyNodeWithBTDF :1306-1326, :1729-1730
+    std::function<bool(const MatTree*)> anyBtdf = [&](const MatTree* n) { return n && (n->isBlend ? (anyBtdf(n->c1.get()) || anyBtdf(n->c2.get())) : get_i(n->plain, HM_TYPE) == HMT_TRANSLUCENT); };
+    if (anyBtdf(pResult.get())) put_i(pResult->plain, HM_FLAGS, get_i(pResult->plain, HM_FLAGS) | HMF_HAVE_BTDF);
   }
   // PopUpTransparencyAndCaustics :1284-1304 (one level)
   if (pResult->isBlend) {

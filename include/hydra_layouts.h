@@ -132,6 +132,7 @@ enum {
   HM_ORENNAYAR_ROUGHNESS = 15, HM_ORENNAYAR_A = 16, HM_ORENNAYAR_B = 17, HM_ORENNAYAR_SAMPLER = 20,   /* cmaterial.h:264-276 */
   HM_PHONG_COSPOWER = 15, HM_PHONG_GLOSINESS = 16, HM_PHONG_GLOSS_TEXID = 17, HM_PHONG_GLOSS_TEXMATRIXID = 18,
   HM_PHONG_SAMPLER0 = 20, HM_PHONG_SAMPLER1 = 32,
+  HM_BLINN_ANISOTROPY = 19,   /* BLINN_ANISOTROPY_OFFSET, cmaterial.h:1034; Blinn shares every phong offset */
   HM_MIRROR_SAMPLER = 16,
   HM_GGX_COSPOWER = 15, HM_GGX_GLOSINESS = 16, HM_GGX_GLOSS_TEXID = 17, HM_GGX_GLOSS_TEXMATRIXID = 18, HM_GGX_FRESNEL_IOR = 19,   /* cmaterial.h:1165-1185 */
   HM_GGX_SAMPLER0 = 20, HM_GGX_SAMPLER1 = 32,

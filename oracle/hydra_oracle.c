@@ -20,6 +20,7 @@
 #define M_PI_F      3.14159265358979323846f
 #define INV_PI      0.31830988618379067154f
 #define INV_TWOPI   0.15915494309189533577f
+#define M_TWOPI_F   6.28318530717958647692f
 #define GEPSILON    5e-6f
 #define DEPSILON    1e-20f
 #define DEPSILON2   1e-30f
@@ -39,7 +40,7 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_GGX = 15 };
+enum { MT_PHONG = 0, MT_BLINN = 1, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_TRANSLUCENT = 5, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_GGX = 15 };
 enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };
 enum { THINGLASS_GLOSINESS = 16, THINGLASS_GLOSINESS_TEXMATRIXID = 18,                  /* cmaterial.h:472-491 */
        GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23,         /* cmaterial.h:566-590 */
@@ -827,6 +828,96 @@ static void LambertSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f
   if (cosTheta <= DEPSILON) out->color = v3(0, 0, 0);
   out->flags = RAY_EVENT_D;
 }
+static float phongGlosiness(const float* m, f2 tc, const OrcScene* s);
+/* ---- Blinn distribution in a Torrance-Sparrow model, ref: cmaterial.h:1020-1168 (offsets = phong's), cmatpbrt.h:33-103 */
+static float TorranceSparrowG1(f3 wo, f3 wi, f3 wh) {
+  const float NdotWh = fabsf(wh.z), NdotWo = fabsf(wo.z), NdotWi = fabsf(wi.z);
+  const float WOdotWh = fmaxf(fabsf(dot3(wo, wh)), DEPSILON);
+  return fminf(1.f, fminf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+}
+static float TorranceSparrowGF1(f3 wo, f3 wi) {
+  const float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+  if (cosThetaI == 0.0f || cosThetaO == 0.0f) return 0.0f;
+  f3 wh = add3(wi, wo);
+  if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+  wh = normalize3(wh);
+  const float F = 1.0f;
+  return fminf(TorranceSparrowG1(wo, wi, wh) * F / fmaxf(4.0f * cosThetaI * cosThetaO, DEPSILON), 250.0f);
+}
+static float TorranceSparrowGF2(f3 wo, f3 wi, f3 n) {
+  const float cosThetaO = fabsf(dot3(wo, n)), cosThetaI = fabsf(dot3(wi, n));
+  if (cosThetaI == 0.f || cosThetaO == 0.0f) return 0.0f;
+  f3 wh = add3(wi, wo);
+  if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+  wh = normalize3(wh);
+  const float NdotWh = fabsf(dot3(wh, n)), WOdotWh = fmaxf(fabsf(dot3(wo, wh)), DEPSILON);
+  const float G = fminf(1.f, fminf((2.f * NdotWh * cosThetaO / WOdotWh), (2.f * NdotWh * cosThetaI / WOdotWh)));
+  const float F = 1.0f;
+  return fminf(G * F / fmaxf(4.0f * cosThetaI * cosThetaO, DEPSILON), 10.0f);
+}
+static float blinnEvalPDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  if (dot3(n, v) < 1e-6f || dot3(n, l) < 1e-6f) return 1.0f;
+  const float exponent = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 wh = normalize3(add3(l, v));
+  const float costheta = fabsf(dot3(wh, n));
+  return ((exponent + 1.0f) * powf(costheta, exponent)) / (M_TWOPI_F * 4.0f * dot3(l, wh));
+}
+static f3 blinnEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  if (dot3(n, v) < 1e-6f || dot3(n, l) < 1e-6f) return v3(0, 0, 0);
+  const f3 color = clamp3(mul3(matColor(m), sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s)), 0.0f, 1.0f);
+  const float exponent = cosPowerFromGlosiness(phongGlosiness(m, tc, s));
+  const f3 wh = normalize3(add3(l, v));
+  const float D = (exponent + 2.0f) * INV_TWOPI * powf(fabsf(dot3(wh, n)), exponent);
+  return scale3(scale3(color, D), TorranceSparrowGF2(l, v, n));
+}
+static void BlinnSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 color = clamp3(mul3(matColor(m), sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s)), 0.0f, 1.0f);
+  const float gloss = phongGlosiness(m, tc, s);
+  f3 nx, ny;
+  const f3 nz = n;
+  CoordinateSystem(nz, &nx, &ny);
+  const f3 wo = v3(-dot3(ray_dir, nx), -dot3(ray_dir, ny), -dot3(ray_dir, nz));
+  const float exponent = cosPowerFromGlosiness(gloss);
+  const float costheta = powf(r1, 1.0f / (exponent + 1.0f));
+  const float sintheta = sqrtf(fmaxf(0.0f, 1.0f - costheta * costheta));
+  const float phi = r2 * M_TWOPI_F;
+  const f3 wh = v3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
+  const f3 wi = sub3(scale3(wh, 2.0f * dot3(wo, wh)), wo);
+  const f3 newDir = normalize3(add3(add3(scale3(nx, wi.x), scale3(ny, wi.y)), scale3(nz, wi.z)));
+  const f3 v = scale3(ray_dir, -1.0f);
+  if (dot3(n, v) < 1e-6f || dot3(n, newDir) < 1e-6f) { out->color = v3(0, 0, 0); out->pdf = 1.0f; }
+  else {
+    const float D = ((exponent + 2.0f) * INV_TWOPI * powf(costheta, exponent));
+    out->color = scale3(scale3(color, D), TorranceSparrowGF1(wo, wi));
+    out->pdf = ((exponent + 1.0f) * powf(costheta, exponent)) / fmaxf(M_TWOPI_F * 4.0f * dot3(wo, wh), DEPSILON);
+  }
+  out->direction = newDir;
+  out->flags = (gloss >= 0.99f) ? RAY_EVENT_S : RAY_EVENT_G;
+}
+/* ---- translucent (diffuse transmission), ref: cmaterial.h:1852-1909; colour and sampler at the lambert offsets */
+static float translucentEvalPDF(f3 l, f3 v, f3 n) {
+  const float sign1 = dot3(l, n) > 0 ? 1.0f : -1.0f, sign2 = dot3(v, n) > 0 ? 1.0f : -1.0f;
+  const float coeff = (sign1 * sign2 < 0.0f) ? 1.0f : 0.0f;
+  return fabsf(dot3(l, n)) * INV_PI * coeff;
+}
+static f3 translucentEvalBxDF(const float* m, f3 l, f3 v, f3 n, f2 tc, const OrcScene* s) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const float sign1 = dot3(l, n) > 0 ? 1.0f : -1.0f, sign2 = dot3(v, n) > 0 ? 1.0f : -1.0f;
+  const float coeff = (sign1 * sign2 < 0.0f) ? 1.0f : 0.0f;
+  return scale3(scale3(clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f), coeff), INV_PI);
+}
+static void TranslucentSampleAndEvalBRDF(const float* m, float r1, float r2, f3 n, f2 tc, const OrcScene* s, MatSample* out) {
+  const f3 tex = sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s);
+  const f3 kd = clamp3(mul3(tex, matColor(m)), 0.0f, 1.0f);
+  const f3 nn = scale3(n, -1.0f);
+  const f3 newDir = MapSampleToCosineDistribution(r1, r2, nn, nn, 1.0f);
+  const float cosTheta = dot3(newDir, nn);
+  out->direction = newDir;
+  out->pdf = cosTheta * INV_PI;
+  out->color = scale3(kd, INV_PI);
+  if (cosTheta <= 1e-6f) out->color = v3(0, 0, 0);
+  out->flags = (RAY_EVENT_D | RAY_EVENT_T);
+}
 /* ---- oren-nayar, ref: cmaterial.h:288-371; CosPhiPBRT1 / SinPhiPBRT1 cmatpbrt.h:17-31 */
 static float orennayarFunc(f3 l, f3 v, f3 n, float A, float B) {
   const float cosTheta_wi = dot3(l, n), cosTheta_wo = dot3(v, n);
@@ -1271,6 +1362,8 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_OREN_NAYAR: OrennayarSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_GGX: GGXSample2AndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_TRANSLUCENT: TranslucentSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
+    case MT_BLINN: BlinnSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */
     default: break;
   }
@@ -1313,7 +1406,7 @@ static float adjointBsdfShadeNormalFix(f3 toLightWo, f3 toCamWi, f3 shadeNorm, f
 static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc0, int a_fwdDir, const OrcScene* s) {
   BxDFResult r;
   r.brdf = v3(0, 0, 0); r.btdf = v3(0, 0, 0); r.pdfFwd = 0.0f; r.pdfRev = 0.0f; r.diffuse = 0;
-  float cosMult = 1.0f;
+  float cosMult = 1.0f, cosMult2 = 1.0f;
   ShadeContext scn = *sc0;
   if (hasNormalMap(m)) {   /* :2431-2459 */
     const f3 nb = BumpMapping(sc0->tg, sc0->bn, sc0->fn, sc0->tc, m, s);
@@ -1322,7 +1415,10 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc0, int 
     const float cosThetaOut1 = fmaxf(dot3(lDir, sc0->n), 0.0f), cosThetaOut2 = fmaxf(dot3(lDir, nb), 0.0f);
     cosMult = (cosThetaOut2 / fmaxf(cosThetaOut1, clampVal));
     if (cosThetaOut1 <= 0.0f) cosMult = 0.0f;
-    if (a_fwdDir && dot3(sc0->l, sc0->fn) <= 0.0f) cosMult = 0.0f;
+    const float cosThetaOut3 = fmaxf(-dot3(lDir, sc0->n), 0.0f), cosThetaOut4 = fmaxf(-dot3(lDir, nb), 0.0f);
+    cosMult2 = (cosThetaOut4 / fmaxf(cosThetaOut3, clampVal));
+    if (cosThetaOut3 <= 0.0f) cosMult2 = 0.0f;
+    if (a_fwdDir && dot3(sc0->l, sc0->fn) <= 0.0f) { cosMult = 0.0f; cosMult2 = 0.0f; }
     scn.n = nb;
   }
   const ShadeContext* sc = &scn;
@@ -1343,6 +1439,17 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc0, int 
       r.brdf = scale3(lambertEvalBxDF(m, sc->tc, s), cosMult);
       r.pdfFwd = lambertEvalPDF(sc->l, sc->n);
       r.pdfRev = lambertEvalPDF(sc->v, sc->n);
+      r.diffuse = 1;
+      break;
+    case MT_BLINN:
+      r.brdf = scale3(blinnEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult);
+      r.pdfFwd = blinnEvalPDF(m, sc->l, sc->v, sc->n, sc->tc, s);
+      r.pdfRev = blinnEvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
+      break;
+    case MT_TRANSLUCENT:
+      r.btdf = scale3(translucentEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult2);
+      r.pdfFwd = translucentEvalPDF(sc->l, sc->v, sc->n);
+      r.pdfRev = translucentEvalPDF(sc->v, sc->l, sc->n);
       r.diffuse = 1;
       break;
     case MT_OREN_NAYAR:

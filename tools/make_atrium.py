@@ -227,12 +227,15 @@ def main():
                     "BVH4InstTraverseAlpha) and hangs a perforated screen (same mask) in front of the camera")
     ap.add_argument("--two-trees", action="store_true", help="with --cutouts: the render settings ask the front end to put the instances of alpha-tested meshes into a second BVH "
                     "tree (<split_alpha_tree>), the way Embree hands the reference several trees")
+    ap.add_argument("--translucent", action="store_true", help="material 6 (curtains) becomes diffuse + translucency (a blend of a lambert and a translucent node), "
+                    "material 7 translucency alone (diffuse transmission, cmaterial.h:1852-1909); the reflectivity lobes of materials 1 and 8 become "
+                    "Blinn/Torrance-Sparrow (cmaterial.h:1020-1168)")
     ap.add_argument("--normal-maps", action="store_true", help="materials 0, 1, 4, 5, 8 and 9 (floor, walls, columns: lambert, textured lambert and lambert + glossy blends) get "
                     "<displacement type='normal_bump'> with a generated 256x256 normal map (smooth round bumps), y inverted on two of them")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
-    refl = "ggx" if args.ggx else "phong"
+    refl = "ggx" if args.ggx else "torranse_sparrow" if args.translucent else "phong"   # "torranse_sparrow" (sic) = Blinn in a Torrance-Sparrow model
     s = np.sqrt(args.scale)
     rng = np.random.default_rng(SEED)
     out = args.out
@@ -309,6 +312,12 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    if args.translucent:
+        for i, line in enumerate(xml):
+            if line.startswith('  <material id="6" '):
+                xml[i] = line.replace("</material>", '<translucency><color val="0.6 0.7 0.5" /></translucency></material>')
+            if line.startswith('  <material id="7" '):
+                xml[i] = '  <material id="7" name="m7" type="hydra_material"><diffuse brdf_type="lambert"><color val="0 0 0" /></diffuse><translucency><color val="0.8 0.8 0.7" /></translucency></material>'
     if args.normal_maps:
         for i, line in enumerate(xml):
             for mid in (0, 1, 4, 5, 8, 9):
