@@ -266,10 +266,10 @@ HK_DEV void MakeEyeRayFromF4Rnd(float4 lensOffs, const SceneDev& s, f3& outPos, 
   pY = lensOffs.y * fheight;
 }
 HK_DEV int SelectRandomLightFwd(float r, const SceneDev& s, float& pickProb) {   // clight.h:1808-1822
-  const int tableSize = s.globals[HG_LSEL_FWD_SIZE];
+  const int tableSize = s.hdr[HG_LSEL_FWD_SIZE];
   pickProb = 1.0f;
   if (tableSize <= 2) return 0;
-  return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.globals[HG_LSEL_FWD_OFFS]), tableSize, pickProb);
+  return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.hdr[HG_LSEL_FWD_OFFS]), tableSize, pickProb);
 }
 HK_DEV ShadeContext mmltShadeContext(const SurfaceHit& h, f3 l, f3 v) {
   ShadeContext sc;
@@ -350,7 +350,7 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
       GTerm = cosHere * cosPrev / fmaxf(dist * dist, HK_DEPSILON2);
     }
     const float* mat = materialAt(s, surf.matId);
-    const int lightOffset = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
+    const int lightOffset = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
     const float* pLight = lightAt(s, lightOffset);
     const f3 emission = emissionEval(s, ray_dir, surf, flags, pLight, mat);
     const bool splitDL = g_varsI(s)[HV_I_MMLT_FIRST_BOUNCE] > 3;   // m_splitDLByGrammar, Common.cpp:28
@@ -359,7 +359,7 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
         const LightPdfFwd lp = lightPdfFwd(pLight, cosHere);
         const float pdfLightWP = lp.pdfW / fmaxf(cosHere, HK_DEPSILON);
         const float pdfMatRevWP = misPdf / fmaxf(cosPrev, HK_DEPSILON);
-        mpdfFwd(v, 0, i) = lp.pdfA / float(s.globals[HG_LIGHTS_NUM]);
+        mpdfFwd(v, 0, i) = lp.pdfA / float(s.hdr[HG_LIGHTS_NUM]);
         mpdfRev(v, 0, i) = 1.0f;
         mpdfFwd(v, 1, i) = pdfLightWP * GTerm;
         mpdfRev(v, 1, i) = misSpec ? -1.0f * GTerm : pdfMatRevWP * GTerm;

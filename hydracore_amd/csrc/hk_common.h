@@ -149,10 +149,15 @@ struct SceneDev {
   const int*    texTable;      // texture id -> texture arena offset in int4 units (cfetch.h:141-145)
   const int4*   texAuxStorage; // the second texture arena (normal maps, RenderDriverRTE_AuxTextures.cpp:195-216)
   const int*    texAuxTable;   // aux texture id -> offset in it (textureAuxHeaderOffset, cfetch.h:147-151)
+  // the scalar part of EngineGlobals (matrices, variables, table offsets and sizes: words 0..HK_HDR_WORDS-1 of `globals`) and the
+  // reverse light-selection table (clight.h:1774-1793), by their own pointers for the same reason: every shaded path reads them
+  const int*    hdr;
+  const float*  lselRev;
 };
+#define HK_HDR_WORDS 240   /* HG_MPROJ .. HG_DUMMY1, include/hydra_layouts.h */
 
-HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.globals + HG_VARS_F); }
-HK_DEV const int*   g_varsI(const SceneDev& s) { return s.globals + HG_VARS_I; }
+HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.hdr + HG_VARS_F); }
+HK_DEV const int*   g_varsI(const SceneDev& s) { return s.hdr + HG_VARS_I; }
 
 #define HK_GEPSILON  5e-6f
 #define HK_DEPSILON  1e-20f

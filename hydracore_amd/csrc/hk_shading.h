@@ -267,14 +267,16 @@ HK_DEV SurfaceHit surfaceEvalLS(f3 a_rpos, f3 a_rdir, const HydraLiteHit& hit, c
   return sh;
 }
 
-HK_DEV SurfaceHit evalSurface(const SceneDev& s, f3 ray_pos, f3 ray_dir, const HydraLiteHit& hit) {   // CPUExp_Integrators_PT_Loop.cpp:35-84
-  const m44 instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4);
-  const f3 posLS = mul4x3(instInv, ray_pos), dirLS = mul3x3(instInv, ray_dir);
+// the two fetches of evalSurface, separately, so that a kernel can issue them together with its other loads (k_bounce)
+HK_DEV TriData fetchTri(const SceneDev& s, const HydraLiteHit& hit) {
 #ifdef HK_HOST_EMU
-  const TriData td = fetchTriFromMesh(hit, s.geomStorage + s.globals[s.globals[HG_GEOM_TABLE_OFFS] + hit.geomId]);
+  return fetchTriFromMesh(hit, s.geomStorage + s.globals[s.hdr[HG_GEOM_TABLE_OFFS] + hit.geomId]);
 #else
-  const TriData td = fetchTriFromRecords(hit, s);
+  return fetchTriFromRecords(hit, s);
 #endif
+}
+HK_DEV SurfaceHit evalSurfaceWith(const SceneDev& s, f3 ray_pos, f3 ray_dir, const HydraLiteHit& hit, const TriData& td, const m44& instInv) {   // CPUExp_Integrators_PT_Loop.cpp:35-84
+  const f3 posLS = mul4x3(instInv, ray_pos), dirLS = mul3x3(instInv, ray_dir);
   const SurfaceHit ls = surfaceEvalLS(posLS, dirLS, hit, td);
   const m44 inst = inverse_affine(instInv);
   SurfaceHit ws = ls;
@@ -290,6 +292,11 @@ HK_DEV SurfaceHit evalSurface(const SceneDev& s, f3 ray_pos, f3 ray_dir, const H
   ws.sRayOff = length(shadowStart);
   ws.matId = remapMaterialId(ws.matId, hit.instId, s);
   return ws;
+}
+HK_DEV SurfaceHit evalSurface(const SceneDev& s, f3 ray_pos, f3 ray_dir, const HydraLiteHit& hit) {
+  const m44 instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4);
+  const TriData td = fetchTri(s, hit);
+  return evalSurfaceWith(s, ray_pos, ray_dir, hit, td, instInv);
 }
 
 // ================================================================================================ textures
@@ -920,7 +927,7 @@ HK_DEV float blendMaskAlpha2(const float* m, f3 v, f3 n, f2 tc, const SceneDev& 
   float faloff = 0.0f;
   if (bflags & HBF_FALOFF) {
     const int start = as_int(m[HM_BLEND_FALOFF_OFFSET]), size = as_int(m[HM_BLEND_FALOFF_SIZE]);
-    const float* points = reinterpret_cast<const float*>(s.globals + s.globals[HG_FLOAT_ARRAYS_OFFS]) + start;
+    const float* points = reinterpret_cast<const float*>(s.globals + s.hdr[HG_FLOAT_ARRAYS_OFFS]) + start;
     const float param = (as_int(m[HM_BLEND_FLAGS2]) & 1) ? normAngle : 1.0f - normAngle;
     faloff = hermiteSplineEvalT(param, points, points + size / 2, size / 4);
   }
@@ -1177,11 +1184,11 @@ HK_DEV int SelectIndexPropToOpt(float a_r, const float* a_accum, int N, float& p
   return currPos;
 }
 HK_DEV int SelectRandomLightRev(float r, const SceneDev& s, float& pickProb) {   // clight.h:1774-1793
-  const int tableSize = s.globals[HG_LSEL_REV_SIZE];
+  const int tableSize = s.hdr[HG_LSEL_REV_SIZE];
   pickProb = 1.0f;
   if (tableSize == 0) return -1;
   if (tableSize <= 2) return 0;
-  return SelectIndexPropToOpt(r, reinterpret_cast<const float*>(s.globals + s.globals[HG_LSEL_REV_OFFS]), tableSize, pickProb);
+  return SelectIndexPropToOpt(r, s.lselRev, tableSize, pickProb);
 }
 // ---- sky dome light: constant colour or lat-long texture (clight.h:285-306, 308-364, 384-462; cfetch.h:259-296) ----
 HK_DEV f2 sphereMapTo2DTexCoord(f3 ray_dir, float& sinTheta) {   // cfetch.h:259-281
@@ -1202,7 +1209,7 @@ HK_DEV f3 texCoord2DToSphereMap(f2 tc, float& sinThetaOut) {   // cfetch.h:283-2
   return mk3(y, -z, x);
 }
 HK_DEV const float* pdfTableHeader(const SceneDev& s, int tableId) {   // cfetch.h:153-163
-  const int offset = s.globals[s.globals[HG_PDF_TABLE_OFFS] + tableId];
+  const int offset = s.globals[s.hdr[HG_PDF_TABLE_OFFS] + tableId];
   return reinterpret_cast<const float*>(s.pdfStorage + offset);
 }
 HK_DEV float evalMap2DPdf(f2 tc, const float* intervals, const int sizeX, const int sizeY) {   // clight.h:308-337
@@ -1339,12 +1346,12 @@ HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum
 template <int F = HK_FEAT_ALL>
 HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool prevSpecular, uint32_t flags) {
   if (!(F & HK_FEAT_SKY)) return mk3(0, 0, 0);   // a scene without a sky light: skyLightId == -1 (cbidir.h:498-499)
-  const int skyId = s.globals[HG_SKY_LIGHT_ID];
+  const int skyId = s.hdr[HG_SKY_LIGHT_ID];
   if (skyId == -1) return mk3(0, 0, 0);
   const float* L = lightAt(s, skyId);
   f3 envColor = skyLightIntensity(s, L, rayDir);
   const uint32_t rayBounceNum = (flags >> 8) & 0xFFu;   // unpackBounceNum, cglobals.h:1330-1340
-  if (rayBounceNum > 0 && !(uint32_t(s.globals[HG_FLAGS]) & HF_STUPID_PT_MODE) && !prevSpecular) {
+  if (rayBounceNum > 0 && !(uint32_t(s.hdr[HG_FLAGS]) & HF_STUPID_PT_MODE) && !prevSpecular) {
     const float lgtPdf = L[HL_PICK_PROB_REV] * skyLightEvalPDF(s, L, rayDir);
     envColor = envColor * misWeightHeuristic(prevPdf, lgtPdf);
   }
@@ -1354,7 +1361,7 @@ HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool pre
 // emissionEval, cbidir.h:653-678 (+ lightGetIntensity clight.h:1661-1706 for area lights)
 HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_dir, const SurfaceHit& sh, uint32_t flags, const float* pLight, const float* mat) {
   const f3 normal = sh.hfi ? sh.normal * (-1.0f) : sh.normal;
-  const int lightsNum = s.globals[HG_LIGHTS_NUM];
+  const int lightsNum = s.hdr[HG_LIGHTS_NUM];
   bool hasIES = false;
   if (lightsNum > 0 && pLight != nullptr) hasIES = (as_int(pLight[HL_FLAGS]) & HLF_HAS_IES) != 0;
   if (dot(ray_dir, normal) >= 0.0f && !hasIES) return mk3(0, 0, 0);

@@ -282,9 +282,10 @@ struct LightPick {
 
 // H1 + E1 + E2 -- surface, environment/emission with MIS, termination (kernel_HitEnvironment, kernel_EvalSurface,
 // kernel_EvalEmission).  Returns true when the path goes on (surf valid); false when it ended with radiance `finalColor`.
+// `td` / `instInv`: the triangle record and the instance matrix of the hit, fetched by the caller (valid when HitSome(hit))
 template <int F = HK_FEAT_ALL>
-HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
+HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
+                               const HydraLiteHit& hit, const TriData& td, const m44& instInv, SurfaceHit& surf, f3& finalColor) {
   const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
   const uint32_t flags = uint32_t(as_int(dir4.w));
   f3 currColor = mk3(0, 0, 0);
@@ -294,9 +295,9 @@ HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const floa
     done = true;
   }
   else {
-    surf = evalSurface(s, ray_pos, ray_dir, hit);
+    surf = evalSurfaceWith(s, ray_pos, ray_dir, hit, td, instInv);
     const float* mat = materialAt(s, surf.matId);
-    const int lightOffset0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
+    const int lightOffset0 = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
     const float* pLightHit = lightAt(s, lightOffset0);
     const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
     if (dot(emission, emission) > 1e-3f) {
@@ -315,6 +316,15 @@ HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const floa
     return false;
   }
   return true;
+}
+
+template <int F = HK_FEAT_ALL>
+HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
+                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
+  TriData td;
+  m44 instInv;
+  if (HitSome(hit)) { instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4); td = fetchTri(s, hit); }
+  return surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
 }
 
 // L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample)
@@ -476,37 +486,74 @@ struct ShadowQ { float4* org4; float4* dir4; float* vis; };
 
 // LDS staging of the scene's small hot tables (SceneDev::matBase ... texTable): sizes in 16-byte units, all zero = leave them in
 // global memory (tables too large for HK_SCENE_LDS_MAX_BYTES per block, or option "scene_tables_in_lds" 0)
-struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4, triBaseF4, instLightF4, instMatF4; };
+struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4, hdrF4, lselF4, triBaseF4, instLightF4, instMatF4; const float4* img; };
 #define HK_SORT_BINS 16
-#define HK_SCENE_LDS_MAX_BYTES (48 * 1024)   // x 3 resident 256-thread blocks per CU = 144 of the CU's 160 KB
-HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
-  const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4;
-  const int n4 = n3 + st.triBaseF4, n5 = n4 + st.instLightF4, n6 = n5 + st.instMatF4;
-  if (n6 == 0) return;                     // block-uniform
+#define HK_SCENE_LDS_MAX_BYTES (44 * 1024)   // + 5.3 KB of sort arrays, x 3 resident 256-thread blocks per CU = 148 of the CU's 160 KB
+// STG (compile time): bit 0 = the material group is staged (material arena, material-id table, lights, texture-id table, the scalar
+// header and the light-selection table), bit 1 = the path group (triBase, per-instance light ids and matrices).  The pointers of a
+// staged group are re-pointed UNCONDITIONALLY, so that the compiler sees every access through them start at the LDS array and
+// emits ds_read instead of flat_load: a flat load is routed through the CU's vector-memory address path, the very unit this
+// kernel saturates, and waits on vmcnt and lgkmcnt together, i.e. for every global load in flight as well.
+// The staged tables gathered into one array in the order of the LDS copy (k_build_stage_image, once per pass): a block then fills
+// its LDS from ONE contiguous range with four loads in flight per thread, instead of choosing among nine sources per float4.
+__global__ void k_build_stage_image(SceneDev s, SceneStage st, float4* __restrict__ img) {
+  const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4, n3a = n3 + st.hdrF4, n3b = n3a + st.lselF4;
+  const int n4 = n3b + st.triBaseF4, n5 = n4 + st.instLightF4, n6 = n5 + st.instMatF4;
   const float4* a = reinterpret_cast<const float4*>(s.matBase), *b = reinterpret_cast<const float4*>(s.matTable);
   const float4* c = reinterpret_cast<const float4*>(s.lightsBase), *d = reinterpret_cast<const float4*>(s.texTable);
+  const float4* d1 = reinterpret_cast<const float4*>(s.hdr), *d2 = reinterpret_cast<const float4*>(s.lselRev);
   const float4* e = reinterpret_cast<const float4*>(s.triBase), *f = reinterpret_cast<const float4*>(s.instLightInstId), *g = s.instMatrices;
-  for (int i = int(threadIdx.x); i < n6; i += int(blockDim.x)) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n6; i += gridDim.x * blockDim.x) {
     float4 v;
     if (i < n0) v = a[i]; else if (i < n1) v = b[i - n0]; else if (i < n2) v = c[i - n1]; else if (i < n3) v = d[i - n2];
-    else if (i < n4) v = e[i - n3]; else if (i < n5) v = f[i - n4]; else v = g[i - n5];
-    lds[i] = v;
+    else if (i < n3a) v = d1[i - n3]; else if (i < n3b) v = d2[i - n3a];
+    else if (i < n4) v = e[i - n3b]; else if (i < n5) v = f[i - n4]; else v = g[i - n5];
+    img[i] = v;
   }
+}
+template <int STG>
+HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
+  if (STG == 0) return;
+  const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4, n3a = n3 + st.hdrF4, n3b = n3a + st.lselF4;
+  const int n4 = n3b + st.triBaseF4, n5 = n4 + st.instLightF4, n6 = n5 + st.instMatF4;
+  const float4* __restrict__ img = st.img;
+  const int B = int(blockDim.x);
+  int i = int(threadIdx.x);
+  for (; i + 3 * B < n6; i += 4 * B) {
+    const float4 v0 = img[i], v1 = img[i + B], v2 = img[i + 2 * B], v3 = img[i + 3 * B];
+    lds[i] = v0; lds[i + B] = v1; lds[i + 2 * B] = v2; lds[i + 3 * B] = v3;
+  }
+  for (; i < n6; i += B) lds[i] = img[i];
   __syncthreads();
-  if (st.matF4 > 0) {
+  if (STG & 1) {
     s.matBase = reinterpret_cast<const float*>(lds);
     s.matTable = reinterpret_cast<const int*>(lds + n0);
-    if (st.lightsF4 > 0) s.lightsBase = reinterpret_cast<const float*>(lds + n1);
+    s.lightsBase = reinterpret_cast<const float*>(lds + n1);   // lightsF4 == 0: never dereferenced (no light ids exist)
     s.texTable = reinterpret_cast<const int*>(lds + n2);
+    s.hdr = reinterpret_cast<const int*>(lds + n3);
+    s.lselRev = reinterpret_cast<const float*>(lds + n3a);
   }
-  if (st.triBaseF4 > 0) s.triBase = reinterpret_cast<const int*>(lds + n3);
-  if (st.instLightF4 > 0) s.instLightInstId = reinterpret_cast<const int*>(lds + n4);
-  if (st.instMatF4 > 0) s.instMatrices = lds + n5;
+  if (STG & 2) {
+    s.triBase = reinterpret_cast<const int*>(lds + n3b);
+    s.instLightInstId = reinterpret_cast<const int*>(lds + n4);
+    s.instMatrices = lds + n5;
+  }
 }
+#ifdef HK_EXP_BOUNCE_STAMPS   /* timing experiment (tools/bounce_stamps.py): s_memtime at the phase boundaries of k_bounce, summed per wave */
+__device__ unsigned long long hk_bounce_stamps[16];
+extern "C" int hydra_hip_debug_bounce_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hk_bounce_stamps), sizeof(hk_bounce_stamps)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hk_bounce_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define HK_STAMP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); stampAcc[k] += now_ - stampT; stampT = now_; }
+#else
+#define HK_STAMP(k)
+#endif
 #ifndef HK_BOUNCE_BLOCK
 #define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
 #endif
-template <int W, int F = HK_FEAT_ALL>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*)
+template <int W, int F = HK_FEAT_ALL, int STG = 0>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*); STG: see stage_scene_tables
 __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, SceneStage stage, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
                                                     ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens, int sortPaths) {
@@ -517,25 +564,32 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
   __shared__ int sCnt[NW][HK_SORT_BINS];
   __shared__ int sOff[HK_SORT_BINS][NW];
   __shared__ unsigned short sPerm[HK_BOUNCE_BLOCK];
+  __shared__ float4 sHit[HK_BOUNCE_BLOCK];   // the hit records travel with the permutation: no second fetch, and the triangle fetch can leave with the state loads
   SceneDev s = sArg;
-  stage_scene_tables(s, stage, hk_scene_lds);
+#ifdef HK_EXP_BOUNCE_STAMPS
+  unsigned long long stampAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stampT = __builtin_readcyclecounter();
+#endif
   const SegIter it = segq_iter(q);
   const int count = it.count;
+  if (it.first - int(threadIdx.x) >= count) return;   // block-uniform: nothing in this block's stride (late bounces leave most of the grid idle) -- before the tables are staged
+  stage_scene_tables<STG>(s, stage, hk_scene_lds);
   uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
   int shadowRaysOfWave = 0;
+  HK_STAMP(0)
   for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {
     // Which path of this 256-path chunk the thread shades.  Closest hits arrive labelled with the shading class of their
     // material (hk_trace.h, HK_CLASS_SHIFT): a counting sort of the chunk by class through LDS hands every wave paths that
     // run the same code (after the first bounce a wave otherwise holds every material of the scene and pays for each of them
     // in turn).  State is read and survivors are written by path index as before, so nothing but the order inside a chunk changes.
     int src = int(threadIdx.x);
+    float4 h4 = make_float4(0.0f, as_float(-1), as_float(-1), 0.0f);
+    if (idx0 + src < count) h4 = reinterpret_cast<const float4*>(hits)[it.base + idx0 + src];
     if (sortPaths) {
       const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63;
       int key = HK_SORT_BINS - 1;                             // past the end of the queue
       if (idx0 + src < count) {
-        const float4 k4 = reinterpret_cast<const float4*>(hits)[it.base + idx0 + src];
-        const int cls = HK_GEOM_CLASS(as_int(k4.w));
-        key = (as_int(k4.y) == -1) ? 0 : (cls != 0 ? (cls < HK_SORT_BINS - 2 ? cls : HK_SORT_BINS - 2) : HK_SORT_BINS - 2);
+        const int cls = HK_GEOM_CLASS(as_int(h4.w));
+        key = (as_int(h4.y) == -1) ? 0 : (cls != 0 ? (cls < HK_SORT_BINS - 2 ? cls : HK_SORT_BINS - 2) : HK_SORT_BINS - 2);
       }
       int rank = 0;
       for (int b = 0; b < HK_SORT_BINS; b++) {
@@ -552,10 +606,14 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
         if (lane < NW * HK_SORT_BINS) sOff[b][w] = incl - v;
       }
       __syncthreads();
-      sPerm[sOff[key][wave] + rank] = (unsigned short)threadIdx.x;
+      const int slot = sOff[key][wave] + rank;
+      sPerm[slot] = (unsigned short)threadIdx.x;
+      sHit[slot] = h4;
       __syncthreads();
       src = int(sPerm[threadIdx.x]);
+      h4 = sHit[threadIdx.x];
     }
+    HK_STAMP(1)
     const int idx = idx0 + src;
     const int i = it.base + idx;
     bool alive = false;
@@ -575,18 +633,34 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
       }
       const uint2 g2 = Sin.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
-      const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
+      // the triangle record and the instance matrix are requested here, behind the state loads and before anything waits for those:
+      // one round trip to memory for both instead of two in a row
+#ifdef HK_EXP_BOUNCE_PRELOAD
+      TriData td;
+      m44 instInv;
+      if (HitSome(hit)) { instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4); td = fetchTri(s, hit); }
+#endif
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 4)   /* timing experiment (profiles/r01/pass_bounce_phase_cost.log): phases left out, results invalid */
       alive = true; surf.pos = xyz(pos4); surf.normal = mk3(0, 1, 0); surf.flatNormal = surf.normal; surf.tangent = mk3(1, 0, 0); surf.biTangent = mk3(0, 0, 1);
       surf.texCoord = mk2(0, 0); surf.matId = 0; surf.t = hit.t; surf.sRayOff = 0.0f; surf.hfi = false;
 #else
+#ifdef HK_EXP_BOUNCE_PRELOAD
+      alive = surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
+#else
       alive = surface_phase<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
+#endif
 #endif
     }
     // the slot of the survivor is reserved as soon as survival is known: the returning atomic then overlaps the light and
     // material fetches below instead of standing alone at the end of the iteration
-    const int dst = it.base + wave_compact_index(alive, nextCount);
+    HK_STAMP(2)
+    // issued here, read just before the stores: the atomic's round trip runs under the light and material work
+    const unsigned long long aliveMask = __ballot(alive);
+    const int aliveLeader = aliveMask != 0ull ? __ffsll((long long)aliveMask) - 1 : 0;
+    int slotBase = 0;
+    if (aliveMask != 0ull && int(__lane_id()) == aliveLeader) slotBase = int(atomicAdd(nextCount, uint32_t(__popcll(aliveMask))));
+    HK_STAMP(3)
     if (idx < count) {
       if (!alive) {
         const int gid = as_int(pos4.w);
@@ -598,6 +672,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
 #else
         light_phase<F>(s, surf, gen, lp);
 #endif
+        HK_STAMP(4)
         const float* mat = materialAt(s, surf.matId);
         const f3 ray_dir = xyz(dir4);
         f3 pend = mk3(0, 0, 0);
@@ -605,6 +680,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
           pend = xyz(thr4) * direct_light_unoccluded<F>(s, mat, surf, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
         oPend = mk4(pend, 0.0f);
         oShDir = mk4(lp.shadowRayDir, 0.0f);
+        HK_STAMP(5)
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
         oPos = mk4(surf.pos, pos4.w); oDir = dir4; oThr = thr4; oAcc = acc4;
 #else
@@ -619,15 +695,21 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
       oPend.w = x;
     }
 #endif
+    HK_STAMP(6)
     shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
+    const int dst = it.base + __builtin_amdgcn_readlane(slotBase, aliveLeader) + __popcll(aliveMask & ((1ull << __lane_id()) - 1ull));
     if (alive) {
       Sout.pos4[dst] = oPos; Sout.dir4[dst] = oDir; Sout.thr4[dst] = oThr; Sout.acc4[dst] = oAcc;
       Sout.rng2[dst] = make_uint2(gen.x, gen.y);
       Sout.pend4[dst] = oPend;
       sh.org4[dst] = lp.shadowOrg; sh.dir4[dst] = oShDir;
     }
+    HK_STAMP(7)
   }
   if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
+#ifdef HK_EXP_BOUNCE_STAMPS
+  if (__lane_id() == 0) { for (int k = 0; k < 8; k++) atomicAdd(&hk_bounce_stamps[k], stampAcc[k]); atomicAdd(&hk_bounce_stamps[8], 1ull); }
+#endif
 }
 
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
@@ -964,6 +1046,7 @@ struct hydra_hip_ctx {
   size_t storageBytes[HYDRA_STORAGE_KINDS] = {0, 0, 0, 0, 0};   // bytes uploaded (a DevBuf may be larger)
   int sortPathsWanted = 1, sortPathsFromDepth = 1;   // options "sort_paths" / "sort_paths_from_bounce": group the paths of a workgroup by shading class in k_bounce
   int sceneTablesInLds = 2;          // option "scene_tables_in_lds"
+  DevBuf stageImg;                   // the staged scene tables gathered in LDS order (k_build_stage_image), HK_SCENE_LDS_MAX_BYTES
   DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
   int srgbLutWanted = 1;
   DevBuf leafHeaders[4]; int leafHeadersNum[4] = {0, 0, 0, 0}; bool classDirty = true;   // triangle-leaf headers per tree; the class labels in the device triangle lists must be (re)written
@@ -1130,6 +1213,8 @@ static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree) {
   s.texTable = hdr ? s.globals + c->hostHeader[HG_TEX_TABLE_OFFS] : nullptr;
   s.texAuxStorage = static_cast<const int4*>(c->storage[HYDRA_STORAGE_TEXTURES_AUX].p);
   s.texAuxTable = hdr ? s.globals + c->hostHeader[HG_TEXAUX_TABLE_OFFS] : nullptr;
+  s.hdr = s.globals;
+  s.lselRev = hdr ? reinterpret_cast<const float*>(s.globals + c->hostHeader[HG_LSEL_REV_OFFS]) : nullptr;
   return s;
 }
 static bool scene_ready(const hydra_hip_ctx* c) {
@@ -1449,7 +1534,7 @@ static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
 // which of the scene's small tables k_bounce copies into LDS (all or none): the material arena as uploaded, the material-id and
 // texture-id tables and the lights of the globals blob
 static SceneStage scene_stage(const hydra_hip_ctx* c) {
-  SceneStage st = {0, 0, 0, 0, 0, 0, 0};
+  SceneStage st = {0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr};
   if (!c->sceneTablesInLds || c->hostHeader.size() <= size_t(HG_LIGHTS_NUM)) return st;
   size_t total = 0;
   // the geometry-id -> first triangle record table and the per-instance light id / inverse matrix arrays: what a path needs
@@ -1466,9 +1551,13 @@ static SceneStage scene_stage(const hydra_hip_ctx* c) {
   const size_t matBytes = c->storageBytes[HYDRA_STORAGE_MATERIALS];
   const int matTab = c->hostHeader[HG_MAT_TABLE_SIZE], texTab = c->hostHeader[HG_TEX_TABLE_SIZE], lights = c->hostHeader[HG_LIGHTS_NUM];
   if (matBytes > 0 && (matBytes % 16) == 0 && matTab > 0 && texTab >= 0 && lights >= 0) {
-    const size_t need = matBytes + size_t((matTab + 3) / 4 + (texTab + 3) / 4) * 16 + size_t(lights) * HL_FLOATS * 4;
-    if (total + need <= HK_SCENE_LDS_MAX_BYTES) {
+    const int lsel = c->hostHeader[HG_LSEL_REV_SIZE];
+    // the tables are read in whole float4s: they end inside the globals blob (the lights follow them), so rounding their length up stays in it
+    const size_t need = matBytes + size_t((matTab + 3) / 4 + (texTab + 3) / 4 + HK_HDR_WORDS / 4 + (lsel + 3) / 4) * 16 + size_t(lights) * HL_FLOATS * 4;
+    const bool aligned = (c->hostHeader[HG_MAT_TABLE_OFFS] % 4) == 0 && (c->hostHeader[HG_TEX_TABLE_OFFS] % 4) == 0 && (c->hostHeader[HG_LIGHTS_OFFS] % 4) == 0 && (lsel == 0 || (c->hostHeader[HG_LSEL_REV_OFFS] % 4) == 0);
+    if (total + need <= HK_SCENE_LDS_MAX_BYTES && aligned && lsel >= 0) {
       st.matF4 = int(matBytes / 16); st.matTabF4 = (matTab + 3) / 4; st.lightsF4 = lights * (HL_FLOATS / 4); st.texTabF4 = (texTab + 3) / 4;
+      st.hdrF4 = HK_HDR_WORDS / 4; st.lselF4 = (lsel + 3) / 4;
     }
   }
   return st;
@@ -1492,9 +1581,16 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const bool fused = c->fusedBounce != 0;
   if (!fused && (c->sceneFeatures & (HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN))) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has translucent or Blinn materials, which only the fused bounce kernel contains (fused_bounce = 1)");
   if (!fused && (c->sceneFeatures & HK_FEAT_NMAP)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has normal-mapped materials; the split bounce form (fused_bounce = 0) carries no tangent frame in its record, use the fused kernel");
-  const SceneStage stage = scene_stage(c);
+  SceneStage stage = scene_stage(c);
+  if (stage.matF4 + stage.triBaseF4 > 0) {   // gather the staged tables (the header changes with the camera, so once per pass)
+    if (!c->stageImg.p) { const int rc = dev_alloc(c, c->stageImg, HK_SCENE_LDS_MAX_BYTES); if (rc != 0) return rc; }
+    stage.img = static_cast<const float4*>(c->stageImg.p);
+    const int nF4 = stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.hdrF4 + stage.lselF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4;
+    hipLaunchKernelGGL(k_build_stage_image, dim3((nF4 + 255) / 256), dim3(256), 0, c->stream, s, stage, static_cast<float4*>(c->stageImg.p));
+  }
   const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
-  const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4) * 16;
+  const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.hdrF4 + stage.lselF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4) * 16;
+  const int stg = (stage.matF4 > 0 ? 1 : 0) | (stage.triBaseF4 > 0 ? 2 : 0);
   HydraLiteHit* hits = bb.hits;
   auto mark = [&]() -> int { if (!timing) return -1; hipEvent_t e = next_event(c, c->evCursor); (void)hipEventRecord(e, c->stream); return int(c->evCursor) - 1; };
   for (int depth = 0; depth < maxDepth; depth++) {
@@ -1512,7 +1608,11 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
           // the first three, 16 spilled for the full one)
           const int f = c->sceneFeatures;
-#define HK_LAUNCH_BOUNCE(F) hipLaunchKernelGGL((k_bounce<3, F>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths)
+#define HK_LAUNCH_BOUNCE_W(W_, F, G) hipLaunchKernelGGL((k_bounce<W_, F, G>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths)
+#ifndef HK_BOUNCE_W
+#define HK_BOUNCE_W 3   /* register budget of the default variants in waves per SIMD (an experiment build can ask for 4) */
+#endif
+#define HK_LAUNCH_BOUNCE(F) do { switch (stg) { case 3: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 3); break; case 2: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 2); break; case 1: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 1); break; default: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 0); break; } } while (0)
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
@@ -1520,11 +1620,11 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
           else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
           else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);
-#undef HK_LAUNCH_BOUNCE
           break;
         }
-        case 5: hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
-        default: hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
+        // the 4- and 5-wave register budgets exist as experiment switches only: everything staged, or nothing
+        case 5: if (stg == 3) HK_LAUNCH_BOUNCE_W(5, HK_FEAT_ALL, 3); else hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL, 0>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
+        default: if (stg == 3) HK_LAUNCH_BOUNCE_W(4, HK_FEAT_ALL, 3); else hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL, 0>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
       }
       std::swap(bb.A, bb.B);
     } else {
@@ -1605,7 +1705,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   (void)hipDeviceSynchronize();
   (void)hydra_hip_comm_destroy(c);
   (void)hydra_hip_mmlt_end(c);
-  DevBuf* all[] = {&c->srgbLut, &c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
+  DevBuf* all[] = {&c->srgbLut, &c->stageImg, &c->globals, &c->instMat, &c->instLight, &c->triRec, &c->triTan, &c->triBase, &c->remapLists, &c->remapTable, &c->remapInst, &c->ownedPixels, &c->liveInit, &c->gens, &c->accumInternal,
                    &c->contrib, &c->hits, &c->live, &c->shadowCnt, &c->totals, &c->sPos, &c->sDir, &c->sThr, &c->sAcc, &c->sRng, &c->tPos, &c->tDir, &c->tThr, &c->tAcc, &c->tRng, &c->sPend, &c->tPend, &c->shDir, &c->mDir, &c->mThr, &c->mAcc,
                    &c->mRng, &c->travTotals, &c->fetchCnt, &c->mSurfA, &c->mSurfB, &c->mRecC, &c->mRecD, &c->mRecE, &c->mShadowOrg, &c->mVis};
   for (DevBuf* b : all) dev_free(*b);

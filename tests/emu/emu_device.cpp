@@ -44,6 +44,8 @@ static SceneDev to_dev(const EmuScene* e) {
   s.texTable = e->globals ? e->globals + e->globals[HG_TEX_TABLE_OFFS] : nullptr;
   s.texAuxStorage = reinterpret_cast<const int4*>(e->texAuxStorage);
   s.texAuxTable = e->globals ? e->globals + e->globals[HG_TEXAUX_TABLE_OFFS] : nullptr;
+  s.hdr = e->globals;
+  s.lselRev = e->globals ? reinterpret_cast<const float*>(e->globals + e->globals[HG_LSEL_REV_OFFS]) : nullptr;
   return s;
 }
 
