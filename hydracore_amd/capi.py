@@ -52,7 +52,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image",
-    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
 ]
 
 _hip = None
@@ -133,6 +133,7 @@ def load_hip_library():
         "hydra_hip_mmlt_end": ([vp], i32),
         "hydra_hip_sbdpt_pass": ([vp, i32], i32),
         "hydra_hip_sbdpt_get_image": ([vp, vp, vp], i32),
+        "hydra_hip_eval_gbuffer": ([vp, vp, vp, vp, i32, vp], i32),
         "hydra_hip_bvh_build_mesh": ([i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_bvh_last_error": ([], C.c_char_p),
     }
@@ -204,6 +205,8 @@ def load_host_library():
     lib.hydra_host_shared_image_stat.restype = i32
     lib.hydra_host_shared_image_close.argtypes = [vp, vp]
     lib.hydra_host_shared_image_close.restype = None
+    lib.hydra_host_eval_gbuffer.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    lib.hydra_host_eval_gbuffer.restype = i32
     lib.hydra_host_bvh_stats.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.hydra_host_bvh_stats.restype = i32
     _host = lib
@@ -537,6 +540,15 @@ class HipCore:
     def mmlt_end(self):
         self._ck(self.lib.hydra_hip_mmlt_end(self.h), "mmlt_end")
 
+    def eval_gbuffer(self, width, height, inst_remap=None, raw=False):
+        """IHWLayer::EvalGBuffer: the two packed float4 layers (+ the unpacked record per pixel when `raw`)"""
+        d1, d2 = np.zeros((height, width, 4), np.float32), np.zeros((height, width, 4), np.float32)
+        r14 = np.zeros((height, width, 14), np.float32) if raw else None
+        rm = np.ascontiguousarray(inst_remap, np.int32) if inst_remap is not None else None
+        self._ck(self.lib.hydra_hip_eval_gbuffer(self.h, _ptr(d1), _ptr(d2), _ptr(rm) if rm is not None else None, 0 if rm is None else rm.size,
+                                                 _ptr(r14) if raw else None), "eval_gbuffer")
+        return (d1, d2, r14) if raw else (d1, d2)
+
     def bench_trace(self, pos4, dir4, iters=20, shadow=False):
         n = pos4.shape[0]
         pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
@@ -633,6 +645,15 @@ class HostScene:
         if not h:
             raise HydraError("shared_image: %s" % self.lib.hydra_host_last_error(self.p).decode())
         return h
+
+    def eval_gbuffer(self, depth=3, inst_remap=None, is_empty=1):
+        """IHWLayer::EvalGBuffer through the adapter into a shared image of `depth` layers; returns (layers [depth, h, w, 4], gbufferIsEmpty after)"""
+        layers = np.zeros((depth, self.height, self.width, 4), np.float32)
+        rm = np.ascontiguousarray(inst_remap, np.int32) if inst_remap is not None else None
+        st = C.c_int32(is_empty)
+        if self.lib.hydra_host_eval_gbuffer(self.p, _ptr(layers), self.width, self.height, depth, _ptr(rm) if rm is not None else None, 0 if rm is None else rm.size, C.byref(st)) != 0:
+            raise HydraError("eval_gbuffer: %s" % self.lib.hydra_host_last_error(self.p).decode())
+        return layers, int(st.value)
 
     def shared_image_stat(self, handle):
         spp, rcv = C.c_float(0), C.c_int(0)

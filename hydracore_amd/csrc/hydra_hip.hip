@@ -28,6 +28,7 @@
 #include "hk_trace.h"
 #include "hk_shading.h"
 #include "hk_bidir.h"
+#include "hk_gbuffer.h"
 
 // ================================================================================================ device state
 struct PathState {   // S arrays
@@ -2877,6 +2878,97 @@ int hydra_hip_sbdpt_get_image(hydra_hip_handle c, float* image4, double* samples
   if (samples) *samples = double(m.sbSamples);
   return HYDRA_HIP_OK;
 }
+// ---------------------------------------------------------------------------------------- G-buffer (IHWLayer::EvalGBuffer)
+__global__ void k_gbuffer_rays(SceneDev s, int w, int pix0, int nPix, float4* __restrict__ pos4, float4* __restrict__ dir4) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nPix * HK_GBUFFER_SAMPLES) return;
+  const int pixel = pix0 + r / HK_GBUFFER_SAMPLES, k = r % HK_GBUFFER_SAMPLES;
+  f3 pos, dir;
+  gbufferEyeRay(s, pixel % w, pixel / w, k, w, pos, dir);
+  pos4[r] = mk4(pos, 0.0f);
+  dir4[r] = mk4(dir, 0.0f);
+}
+// one wavefront per pixel, lane = sample: every lane compares its sample with the 64 of the wave (v_readlane broadcasts), in the order
+// of the reference's inner loop so that the float sums are the same; the first lane with the smallest sum writes the pixel
+__global__ void __launch_bounds__(256) k_gbuffer_resolve(SceneDev s, int w, int h, int pix0, int nPix, const float4* __restrict__ pos4, const float4* __restrict__ dir4,
+                                                         const HydraLiteHit* __restrict__ hits, const int* __restrict__ remap, int remapSize,
+                                                         float4* __restrict__ out1, float4* __restrict__ out2, float* __restrict__ raw14) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = int(__lane_id());
+  if (wave >= nPix) return;   // wave-uniform
+  const int r = wave * HK_GBUFFER_SAMPLES + lane;
+  HydraLiteHit hit = hits[r];
+  if (hit.primId != -1) hit.geomId = HK_GEOM_ID(hit.geomId);   // the device's class label is not part of Lite_Hit
+  GBufferSample g = gbufferSampleOf(s, xyz(pos4[r]), xyz(dir4[r]), hit);
+  const GBufferKey mine = gbufferKey(g);
+  float diff = 0.0f, coverage = 0.0f;
+  for (int j = 0; j < HK_GBUFFER_SAMPLES; j++) {
+    GBufferKey o;
+    o.norm.x = as_float(__builtin_amdgcn_readlane(as_int(mine.norm.x), j)); o.norm.y = as_float(__builtin_amdgcn_readlane(as_int(mine.norm.y), j));
+    o.norm.z = as_float(__builtin_amdgcn_readlane(as_int(mine.norm.z), j)); o.depth = as_float(__builtin_amdgcn_readlane(as_int(mine.depth), j));
+    o.instId = __builtin_amdgcn_readlane(mine.instId, j); o.objId = __builtin_amdgcn_readlane(mine.objId, j);
+    o.matId = __builtin_amdgcn_readlane(mine.matId, j); o.alpha = as_float(__builtin_amdgcn_readlane(as_int(mine.alpha), j));
+    const float thisDiff = gbuffDiff(mine, o, HK_GBUFFER_FOV, float(w), float(h));
+    diff += thisDiff;
+    if (thisDiff < 1.0f) coverage += 1.0f;
+  }
+  g.coverage = coverage * (1.0f / float(HK_GBUFFER_SAMPLES));
+  const bool cand = diff < 100000000.0f;          // `diff < minDiff` against the initial minimum (NaN never wins)
+  float m = cand ? diff : 3.0e38f;
+  for (int d = 32; d >= 1; d >>= 1) m = fminf(m, __shfl_xor(m, d));
+  const unsigned long long winners = __ballot(cand && diff == m);
+  const int winner = winners != 0ull ? __ffsll((long long)winners) - 1 : 0;
+  if (lane == winner) {
+    const int pixel = pix0 + wave;
+    if (remap != nullptr && g.instId >= 0 && g.instId < remapSize) g.instId = remap[g.instId];   // a_instIdByInstId, GPUOCLLayerOther.cpp:846-853
+    out1[pixel] = packGBuffer1(g);
+    out2[pixel] = packGBuffer2(g);
+    if (raw14) {
+      float* o = raw14 + size_t(pixel) * 14;
+      o[0] = g.depth; o[1] = g.norm.x; o[2] = g.norm.y; o[3] = g.norm.z; o[4] = g.rgba.x; o[5] = g.rgba.y; o[6] = g.rgba.z; o[7] = g.rgba.w;
+      o[8] = as_float(g.matId); o[9] = g.coverage; o[10] = g.texCoord.x; o[11] = g.texCoord.y; o[12] = as_float(g.objId); o[13] = as_float(g.instId);
+    }
+  }
+}
+int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, const int32_t* inst_remap, int inst_remap_size, float* raw14) {
+  if (!c || !data1 || !data2 || inst_remap_size < 0) return HYDRA_HIP_EINVAL;
+  if (!scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: scene is not uploaded");
+  if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: the globals header holds no camera yet (SetCamMatrices + PrepareEngineGlobals)");
+  HCHECK(hipSetDevice(c->device));
+  { const int prc = prepare_geometry(c); if (prc) return prc; }
+  { const int vrc = validate_materials(c); if (vrc) return vrc; }
+  { const int crc = prepare_classes(c); if (crc) return crc; }
+  int rc = HYDRA_HIP_OK;
+  if ((rc = ensure_fetch_counters(c))) return rc;
+  const int npix = c->w * c->h;
+  const int pixPerBlock = npix < 65536 ? npix : 65536;   // 4 M rays per block of rows (GPUOCLLayer works in MEGABLOCKSIZE lines the same way, :743-757)
+  const size_t rays = size_t(pixPerBlock) * HK_GBUFFER_SAMPLES;
+  TmpBufs tb;
+  float4* dpos = (float4*)tb.up(c, nullptr, rays * 16, rc);
+  float4* ddir = (float4*)tb.up(c, nullptr, rays * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, rays * 16, rc);
+  float4* d1 = (float4*)tb.up(c, nullptr, size_t(npix) * 16, rc);
+  float4* d2 = (float4*)tb.up(c, nullptr, size_t(npix) * 16, rc);
+  float* draw = raw14 ? (float*)tb.up(c, nullptr, size_t(npix) * 14 * 4, rc) : nullptr;
+  int* dremap = (inst_remap && inst_remap_size > 0) ? (int*)tb.up(c, inst_remap, size_t(inst_remap_size) * 4, rc) : nullptr;
+  if (rc) return rc;
+  const SceneDev s = make_scene(c);
+  uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
+  for (int pix0 = 0; pix0 < npix; pix0 += pixPerBlock) {
+    const int nPix = (npix - pix0 < pixPerBlock) ? npix - pix0 : pixPerBlock;
+    const int n = nPix * HK_GBUFFER_SAMPLES;
+    hipLaunchKernelGGL(k_gbuffer_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, c->w, pix0, nPix, dpos, ddir);
+    HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
+    launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, nullptr, nullptr, fetch);
+    hipLaunchKernelGGL(k_gbuffer_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, c->w, c->h, pix0, nPix, dpos, ddir, dh, dremap, inst_remap_size, d1, d2, draw);
+  }
+  HCHECK(hipGetLastError());
+  HCHECK(hipMemcpyAsync(data1, d1, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
+  HCHECK(hipMemcpyAsync(data2, d2, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
+  if (raw14) HCHECK(hipMemcpyAsync(raw14, draw, size_t(npix) * 14 * 4, hipMemcpyDeviceToHost, c->stream));
+  HCHECK(hipStreamSynchronize(c->stream));
+  return HYDRA_HIP_OK;
+}
+
 // test hook: chain planes (CH_PLANES x n), path lengths (n) and current x vectors (n rows of 12 + 10 * maxD), average brightness per length (maxD + 1)
 int hydra_hip_mmlt_get_state(hydra_hip_handle c, float* chains, int32_t* depth, float* xrows, float* avg_b) {
   if (!c) return HYDRA_HIP_EINVAL;

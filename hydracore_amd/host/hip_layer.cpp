@@ -154,6 +154,29 @@ public:
     m_sppContrib += spp;
   }
   float GetSPPContrib() const override { return m_sppContrib; }
+  // GPUOCLLayer::EvalGBuffer (GPUOCLLayerOther.cpp:694-870): the hand-shake over Header()->gbufferIsEmpty under the image lock, the two
+  // layers chosen by the image's depth (:725-741), instance ids mapped through a_instIdByInstId (:846-853); the records themselves come
+  // from hydra_hip_eval_gbuffer (IntegratorCommon::gbufferEval, CPUExp_GBuffer.cpp:15-113)
+  void EvalGBuffer(IHRSharedAccumImage* a_pAccumImage, const std::vector<int32_t>& a_instIdByInstId) override {
+    if (a_pAccumImage == nullptr) return;
+    if (a_pAccumImage->Header()->gbufferIsEmpty != 1) return;
+    bool locked = false;
+    for (int i = 0; i < 20 && !locked; i++) locked = a_pAccumImage->Lock(100);
+    if (!locked) return;
+    HRSharedBufferHeader* hdr = a_pAccumImage->Header();
+    if (hdr->gbufferIsEmpty != 1) { a_pAccumImage->Unlock(); return; }   // another process has computed it meanwhile
+    float* data1 = nullptr, *data2 = nullptr;
+    if (hdr->depth == 4) { data1 = a_pAccumImage->ImageData(2); data2 = a_pAccumImage->ImageData(3); }
+    else if (hdr->depth == 3) { data1 = a_pAccumImage->ImageData(1); data2 = a_pAccumImage->ImageData(2); }
+    if (data1 == nullptr || data2 == nullptr || hdr->width != m_width || hdr->height != m_height) {
+      a_pAccumImage->Unlock();
+      RunTimeError("HipHWLayer::EvalGBuffer: the shared image has no G-buffer layers (depth 3 or 4) of the frame's size");
+    }
+    const int rc = hydra_hip_eval_gbuffer(m_h, data1, data2, a_instIdByInstId.empty() ? nullptr : a_instIdByInstId.data(), int(a_instIdByInstId.size()), nullptr);
+    if (rc != HYDRA_HIP_OK) { a_pAccumImage->Unlock(); check(rc, "EvalGBuffer"); }
+    hdr->gbufferIsEmpty = 0;
+    a_pAccumImage->Unlock();
+  }
   // multi-GPU tile partition: a caller-owned DEVICE accumulator (float4 sums), exchanged over RCCL by the caller or by
   // hydra_hip_comm_* (include/hydra_hip.h); not part of IHWLayer
   void SetExternalDeviceAccumulator(void* a_devFloat4, size_t a_bytes) { check(hydra_hip_set_external_accumulator(m_h, a_devFloat4, a_bytes), "SetExternalDeviceAccumulator"); }

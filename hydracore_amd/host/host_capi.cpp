@@ -19,10 +19,10 @@ struct HostScene {
 // (Lock with a time-out / Unlock around `+=`; header with spp and the receive counter).  Used by the harness to drive
 // IHWLayer::SetExternalImageAccumulator / ContribToExternalImageAccumulator.
 struct LocalAccumImage : public IHRSharedAccumImage {
-  LocalAccumImage(float* data, int w, int h) : m_data(data) { m_hdr = HRSharedBufferHeader{w, h, 1, 4, 0.0f, 0, 0}; }
+  LocalAccumImage(float* data, int w, int h, int depth = 1) : m_data(data) { m_hdr = HRSharedBufferHeader{w, h, depth, 4, 0.0f, 0, 0, 1}; }
   bool Lock(int ms) override { return m_mutex.try_lock_for(std::chrono::milliseconds(ms)); }
   void Unlock() override { m_mutex.unlock(); }
-  float* ImageData(int) override { return m_data; }
+  float* ImageData(int layer) override { return (layer >= 0 && layer < m_hdr.depth) ? m_data + size_t(layer) * size_t(m_hdr.width) * size_t(m_hdr.height) * 4 : nullptr; }
   HRSharedBufferHeader* Header() override { return &m_hdr; }
   float* m_data;
   HRSharedBufferHeader m_hdr;
@@ -171,6 +171,22 @@ void* hydra_host_shared_image_open(void* p, float* rgba, int w, int h, int attac
     s->err = e.what();
     delete img;
     return nullptr;
+  }
+}
+// IHWLayer::EvalGBuffer into an in-process shared image of `depth` float4 layers over `layers` (depth * w * h * 4 floats): depth 3 -> the G-buffer
+// goes to layers 1 and 2, depth 4 -> layers 2 and 3 (GPUOCLLayerOther.cpp:725-741).  state_io: in = Header()->gbufferIsEmpty before the call, out = after.
+int hydra_host_eval_gbuffer(void* p, float* layers, int w, int h, int depth, const int32_t* inst_remap, int remap_size, int* state_io) {
+  HostScene* s = static_cast<HostScene*>(p);
+  if (!s || !layers || !state_io) return -1;
+  LocalAccumImage img(layers, w, h, depth);
+  img.m_hdr.gbufferIsEmpty = *state_io;
+  try {
+    s->drv->Layer()->EvalGBuffer(&img, std::vector<int32_t>(inst_remap, inst_remap + (inst_remap ? remap_size : 0)));
+    *state_io = img.m_hdr.gbufferIsEmpty;
+    return 0;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return -1;
   }
 }
 int hydra_host_shared_image_stat(void* image, float* spp, int* counterRcv) {

@@ -96,7 +96,7 @@ typedef void (*RTE_PROGRESSBAR_CALLBACK)(const wchar_t* message, float a_progres
 typedef float PlainLight;                             // cfetch.h:6-13: a light is 128 floats; SetAllPODLights takes number of LIGHTS
 // Shared accumulation image: the members the reference's layers use (GPUOCLLayerOther.cpp:259-283 implicit contribution,
 // :365-429 ContribToExternalImageAccumulator): Lock(ms) / Unlock around `+=` into ImageData(0), Header()->spp and counterRcv.
-struct HRSharedBufferHeader { int width, height, depth, channels; float spp; int counterRcv, counterSnd; };
+struct HRSharedBufferHeader { int width, height, depth, channels; float spp; int counterRcv, counterSnd; int gbufferIsEmpty; };   // gbufferIsEmpty: EvalGBuffer's hand-shake (GPUOCLLayerOther.cpp:699-716, 846; RenderDriverRTE.h:332)
 struct IHRSharedAccumImage {
   virtual ~IHRSharedAccumImage() {}
   virtual bool   Lock(int a_miliseconds) = 0;

@@ -248,6 +248,15 @@ int hydra_hip_mmlt_end(hydra_hip_handle h);
  * sbdpt_get_image: splats x width*height / samples (paths of 2..max_depth segments; directly visible emitters are not part of this pass). */
 int hydra_hip_sbdpt_pass(hydra_hip_handle h, int passes);
 int hydra_hip_sbdpt_get_image(hydra_hip_handle h, float* image4, double* samples);
+/* IHWLayer::EvalGBuffer (hydra_drv/IHWLayer.h:136; GPUOCLLayer::EvalGBuffer, GPUOCLLayerOther.cpp:694-870), following the CPU restatement
+ * IntegratorCommon::gbufferEval / gbufferSample (hydra_drv/CPUExp_GBuffer.cpp:15-113): per pixel 64 Hammersley-placed primary rays, one
+ * surface sample each (depth, normal, diffuse colour, material / object / instance id, texture coordinate), the sample most similar to all
+ * others wins (gbuffDiff, cglobals.h:2193-2205) and carries the share of samples like it as coverage.  data1 / data2 = width*height float4
+ * each, the two layers the reference writes into the shared accumulation image (packGBuffer1 / packGBuffer2, cglobals.h:2098-2145);
+ * inst_remap (may be null) = a_instIdByInstId, applied to the instance id (:846-853).  raw14 (may be null; tests) = per pixel depth, normal xyz,
+ * rgba, matId (int bits), coverage, texCoord xy, objId, instId (int bits).  Alpha is 0 on every hit, as in the CPU form.
+ * Needs the camera in the globals header (SetCamMatrices + PrepareEngineGlobals). */
+int hydra_hip_eval_gbuffer(hydra_hip_handle h, float* data1, float* data2, const int32_t* inst_remap, int inst_remap_size, float* raw14);
 /* IntegratorMMLT::F (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315; sub-paths :637-929, connections :931-1047 + cbidir.h:190-477): the
  * contribution of n primary-sample vectors.  xvec = n rows of `stride` floats laid out as the reference's PSSampleV (cglobals.h:102-128:
  * lens 0..3, light 4..10, split 11, then 10 floats per bounce, light part first), depth[i] = d (path length in segments, 1..16),

@@ -2651,6 +2651,149 @@ void orc_sbdpt_pass(const OrcScene* s, int n, uint32_t* gens4, int maxDepth, int
 /* generator of pixel i = RandomGenInit(seed + i): the per-slot seeding of the reference's wavefront layer
  * (shaders/trace.cl:6-13 InitRandomGen) with slot = pixel, instead of the CPU layer's per-OpenMP-thread generators
  * (CPUExp_Integrators_Common.cpp:43-44), which make the reference image thread-count dependent. */
+/* ------------------------------------------------------------------------------------------------ G-buffer (IHWLayer::EvalGBuffer) */
+/* IntegratorCommon::gbufferEval / gbufferSample, CPUExp_GBuffer.cpp:15-113, with GBufferAll, initGBufferAll, packGBuffer1/2, projectedPixelSize,
+ * surfaceSimilarity, gbuffDiff (cglobals.h:2057-2205), encodeNormal (:1401-1411), RealColorToUint32 (:711-724), PlaneHammersley
+ * (globals_sys.cpp:45-61) and materialEvalDiffuse / materialLeafEvalDiffuse (cmaterial.h:2830-2916). */
+#define GBUFFER_SAMPLES 64
+typedef struct { float depth; f3 norm; float rgba[4]; int matId; float coverage; f2 texCoord; int objId, instId; } GBufferAll;
+static void initGBufferAll(GBufferAll* g) {
+  g->depth = 1e+6f; g->norm = v3(0, 0, 0); g->rgba[0] = g->rgba[1] = g->rgba[2] = 0.0f; g->rgba[3] = 1.0f; g->matId = -1; g->coverage = 0.0f;
+  g->texCoord.x = g->texCoord.y = 0.0f; g->objId = -1; g->instId = -1;
+}
+static void PlaneHammersley(float* result, int n) {
+  for (int k = 0; k < n; k++) {
+    float u = 0;
+    int kk = k;
+    for (float p = 0.5f; kk; p *= 0.5f, kk >>= 1)
+      if (kk & 1) u += p;
+    const float v = (k + 0.5f) / n;
+    result[2 * k + 0] = u;
+    result[2 * k + 1] = v;
+  }
+}
+static f3 materialLeafEvalDiffuse(const float* m, f2 tc, const OrcScene* s) {
+  if (matType(m) == MT_LAMBERT || matType(m) == MT_OREN_NAYAR)   /* colour at 10..12, sampler ids at 13/14 in both (cmaterial.h:200-218, 264-284) */
+    return mul3(sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s), matColor(m));
+  return v3(0, 0, 0);
+}
+static f3 materialEvalDiffuse(const float* a_m, f3 l, f3 n, f2 tc, const OrcScene* s) {
+  f3 val = v3(0, 0, 0);
+  float stackW[MIX_TREE_MAX_DEEP]; int stackO[MIX_TREE_MAX_DEEP];
+  int top = 0, currOffset = 0;
+  float currW = 1.0f;
+  do {
+    if (top > 0) { top--; currOffset = stackO[top]; currW = stackW[top]; }
+    const float* m = a_m + (size_t)currOffset * MAT_FLOATS;
+    if (matType(m) == MT_BLEND_MASK) {
+      const float alpha = blendMaskAlpha2(m, l, n, tc, s);
+      const int o1 = as_int(m[BLEND_MAT1]), o2 = as_int(m[BLEND_MAT2]);
+      float w1 = alpha;
+      const float w2 = 1.0f - alpha;
+      if ((as_int(m[BLEND_FLAGS_OFFSET]) & BMF_REFL_WEIGHT_IS_ONE) && matType(m + (size_t)o1 * MAT_FLOATS) != MT_BLEND_MASK) w1 = 1.0f;
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w1; stackO[top] = currOffset + o1; top++; }
+      if (top < MIX_TREE_MAX_DEEP) { stackW[top] = currW * w2; stackO[top] = currOffset + o2; top++; }
+    } else
+      val = add3(val, scale3(materialLeafEvalDiffuse(m, tc, s), currW));
+  } while (top > 0);
+  return val;
+}
+static GBufferAll gbufferSample(const OrcScene* s, f3 ray_pos, f3 ray_dir) {
+  GBufferAll r;
+  initGBufferAll(&r);
+  const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
+  if (!HitSome(hit)) { r.rgba[0] = r.rgba[1] = r.rgba[2] = 0.0f; r.rgba[3] = 1.0f; return r; }
+  const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
+  const f3 c = materialEvalDiffuse(materialAt(s, surf.matId), ray_dir, surf.normal, surf.texCoord, s);   /* evalDiffuseColor, Common.cpp:244-251 */
+  r.depth = hit.t; r.norm = surf.normal;
+  r.rgba[0] = c.x; r.rgba[1] = c.y; r.rgba[2] = c.z; r.rgba[3] = 0.0f;
+  r.matId = surf.matId; r.coverage = 1.0f;
+  r.texCoord = surf.texCoord; r.objId = hit.geomId; r.instId = hit.instId;
+  return r;
+}
+static float projectedPixelSize(float dist, float FOV, float w, float h) {
+  const float ppx = (FOV / w) * dist, ppy = (FOV / h) * dist;
+  return (dist > 0.0f) ? 2.0f * fmaxf(ppx, ppy) : 1000.0f;
+}
+static float surfaceSimilarity(f3 n1, float d1, f3 n2, float d2, const float MADXDIFF) {
+  const float MANXDIFF = 0.15f;
+  const float dist = length3(sub3(n1, n2));
+  if (dist >= MANXDIFF) return 0.0f;
+  if (fabsf(d1 - d2) >= MADXDIFF) return 0.0f;
+  const float normalSimilar = sqrtf(1.0f - (dist / MANXDIFF));
+  const float depthSimilar = sqrtf(1.0f - fabsf(d1 - d2) / MADXDIFF);
+  return normalSimilar * depthSimilar;
+}
+static float gbuffDiff(const GBufferAll* s1, const GBufferAll* s2, const float a_fov, float w, float h) {
+  const float ppSize = projectedPixelSize(s1->depth, a_fov, w, h);
+  const float surfaceSimilar = surfaceSimilarity(s1->norm, s1->depth, s2->norm, s2->depth, ppSize * 2.0f);
+  const float surfaceDiff = 1.0f - surfaceSimilar;
+  const float objDiff = (s1->instId == s2->instId && s1->objId == s2->objId) ? 0.0f : 1.0f;
+  const float matDiff = (s1->matId == s2->matId) ? 0.0f : 1.0f;
+  const float alphaDiff = fabsf(s1->rgba[3] - s2->rgba[3]);
+  return surfaceDiff + objDiff + matDiff + alphaDiff;
+}
+static GBufferAll gbufferEval(const OrcScene* s, int x, int y, int m_width, int m_height) {
+  const float fov = (M_PI_F / 180.f) * 90.0f;   /* DEG_TO_RAD * 90 */
+  GBufferAll samples[GBUFFER_SAMPLES];
+  float qmc[2 * GBUFFER_SAMPLES];
+  PlaneHammersley(qmc, GBUFFER_SAMPLES);
+  const float sizeInvX = 1.0f / (float)(m_width), sizeInvY = 1.0f / (float)(m_width);   /* sic: both by the width */
+  for (int i = 0; i < GBUFFER_SAMPLES; i++) {
+    float lensOffs[4] = {qmc[2 * i], qmc[2 * i + 1], 0, 0};
+    lensOffs[0] = sizeInvX * (lensOffs[0] + (float)x);
+    lensOffs[1] = sizeInvY * (lensOffs[1] + (float)y);
+    float fx, fy;
+    f3 ray_pos, ray_dir;
+    MakeEyeRayFromF4Rnd(lensOffs, s, &ray_pos, &ray_dir, &fx, &fy);
+    samples[i] = gbufferSample(s, ray_pos, ray_dir);
+  }
+  float minDiff = 100000000.0f;
+  int minDiffId = 0;
+  for (int i = 0; i < GBUFFER_SAMPLES; i++) {
+    float diff = 0.0f, coverage = 0.0f;
+    for (int j = 0; j < GBUFFER_SAMPLES; j++) {
+      const float thisDiff = gbuffDiff(&samples[i], &samples[j], fov, (float)m_width, (float)m_height);
+      diff += thisDiff;
+      if (thisDiff < 1.0f) coverage += 1.0f;
+    }
+    coverage *= (1.0f / (float)GBUFFER_SAMPLES);
+    samples[i].coverage = coverage;
+    if (diff < minDiff) { minDiff = diff; minDiffId = i; }
+  }
+  return samples[minDiffId];
+}
+static uint32_t encodeNormal(f3 n) {
+  const int x = (int)(n.x * 32767.0f), y = (int)(n.y * 32767.0f);
+  const uint32_t sign = (n.z >= 0) ? 0 : 1;
+  const uint32_t sx = ((uint32_t)(x & 0xfffe) | sign), sy = ((uint32_t)(y & 0xffff) << 16);
+  return sx | sy;
+}
+static uint32_t RealColorToUint32(const float c[4]) {   /* (unsigned char) of a float: the integer conversion's low byte, as the x86 build of the reference does */
+  const uint32_t r = (uint32_t)(int)(c[0] * 255.0f) & 255u, g = (uint32_t)(int)(c[1] * 255.0f) & 255u;
+  const uint32_t b = (uint32_t)(int)(c[2] * 255.0f) & 255u, a = (uint32_t)(int)(c[3] * 255.0f) & 255u;
+  return r | (g << 8) | (b << 16) | (a << 24);
+}
+/* pixels [x0, x0+nx) x [y0, y0+ny) of a width x height frame; data1 / data2 = packGBuffer1 / packGBuffer2 per pixel of the window (row-major),
+ * raw14 (may be null) = depth, normal, rgba, matId, coverage, texCoord, objId, instId */
+void orc_gbuffer(const OrcScene* s, int width, int height, int x0, int y0, int nx, int ny, float* data1, float* data2, float* raw14) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int p = 0; p < nx * ny; p++) {
+    const GBufferAll g = gbufferEval(s, x0 + p % nx, y0 + p / nx, width, height);
+    const float clampedCoverage = fminf(fmaxf(g.coverage * 255.0f, 0.0f), 255.0f);
+    const int compressedCoverage = (int)((uint32_t)((int)clampedCoverage) << 24);
+    const int packedMIdAncCov = (g.matId & 0x00FFFFFF) | (compressedCoverage & (int)0xFF000000u);
+    float* d1 = data1 + 4 * (size_t)p, *d2 = data2 + 4 * (size_t)p;
+    d1[0] = g.depth; d1[1] = as_float((int)encodeNormal(g.norm)); d1[2] = as_float(packedMIdAncCov); d1[3] = as_float((int)RealColorToUint32(g.rgba));
+    d2[0] = g.texCoord.x; d2[1] = g.texCoord.y; d2[2] = as_float(g.objId); d2[3] = as_float(g.instId);
+    if (raw14) {
+      float* o = raw14 + 14 * (size_t)p;
+      o[0] = g.depth; o[1] = g.norm.x; o[2] = g.norm.y; o[3] = g.norm.z; o[4] = g.rgba[0]; o[5] = g.rgba[1]; o[6] = g.rgba[2]; o[7] = g.rgba[3];
+      o[8] = as_float(g.matId); o[9] = g.coverage; o[10] = g.texCoord.x; o[11] = g.texCoord.y; o[12] = as_float(g.objId); o[13] = as_float(g.instId);
+    }
+  }
+}
+
 void orc_init_generators(int w, int h, int seed, uint32_t* gens) {
   for (int i = 0; i < w * h; i++) orc_random_init(seed + i, gens + 2 * (size_t)i);
 }

@@ -90,6 +90,8 @@ void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xve
 void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int32_t* accepted);
 /* IntegratorSBDPT::DoPass through F: n samples, generator of sample i = gens4[i][0..1] (advanced), image4 += splats */
 void orc_sbdpt_pass(const OrcScene* s, int n, uint32_t* gens4, int maxDepth, int w, float* image4);
+/* IntegratorCommon::gbufferEval (CPUExp_GBuffer.cpp:15-113) for the pixel window [x0, x0+nx) x [y0, y0+ny): packGBuffer1 / packGBuffer2 per pixel (+ the unpacked record) */
+void orc_gbuffer(const OrcScene* s, int width, int height, int x0, int y0, int nx, int ny, float* data1, float* data2, float* raw14);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

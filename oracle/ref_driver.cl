@@ -770,3 +770,97 @@ __kernel void ref_mmlt_f(__global const int* depth, __global const float* xvec, 
   o[0] = sampleColor.x; o[1] = sampleColor.y; o[2] = sampleColor.z; o[3] = (float)x; o[4] = (float)y; o[5] = (float)s;
   o[6] = misWeight; o[7] = contribFunc(sampleColor);
 }
+
+/* IntegratorCommon::gbufferEval / gbufferSample (CPUExp_GBuffer.cpp:15-113) with the reference's functions as bodies: MakeEyeRayFromF4Rnd,
+ * the traversal and surface evaluation of the path tracer, materialEvalDiffuse (evalDiffuseColor, Common.cpp:244-251), initGBufferAll,
+ * gbuffDiff, packGBuffer1 / packGBuffer2.  qmc = PlaneHammersley(64) (host code, globals_sys.cpp:45-61: handed in).  One work-item per pixel
+ * of the window [x0, x0+nx) x [y0, y0+ny); out1 / out2 = the packed layers, raw14 = the winning sample unpacked. */
+__kernel void ref_gbuffer(__global const float2* qmc, int x0, int y0, int nx, int ny,
+                          __global const float4* bvh, __global const float4* tris, int haveInst,
+                          __global const float4* in_matrices, __global const int* instLightInstId,
+                          __global const float4* in_geomStorage, __global const float4* in_mtlStorage,
+                          __global const int4* in_texStorage, __global const float4* in_pdfStorage,
+                          __global const EngineGlobals* a_globals, __global float4* out1, __global float4* out2, __global float* raw14,
+                          __global const uint2* alpha, __global const float4* bvh1, __global const float4* tris1, __global const uint2* alpha1, int haveInst1,
+                          __global const int4* in_texStorageAux)
+{
+  const int p = get_global_id(0);
+  if (p >= nx*ny) return;
+  const RefTrees trees = ref_makeTrees(bvh, tris, alpha, haveInst, bvh1, tris1, alpha1, haveInst1, in_texStorage, a_globals);
+  const int x = x0 + p % nx, y = y0 + p / nx;
+  const int m_width  = (int)(a_globals->varsF[HRT_WIDTH_F]);
+  const int m_height = (int)(a_globals->varsF[HRT_HEIGHT_F]);
+
+  const float fov = DEG_TO_RAD*90.0f;
+  GBufferAll samples[GBUFFER_SAMPLES];
+
+  const float sizeInvX = 1.0f / (float)(m_width);
+  const float sizeInvY = 1.0f / (float)(m_width);
+
+  for (int i = 0; i < GBUFFER_SAMPLES; i++)
+  {
+    float4 lensOffs = make_float4(qmc[i].x, qmc[i].y, 0, 0);
+    lensOffs.x = sizeInvX * (lensOffs.x + (float)x);
+    lensOffs.y = sizeInvY * (lensOffs.y + (float)y);
+
+    float  fx, fy;
+    float3 ray_pos, ray_dir;
+    MakeEyeRayFromF4Rnd(lensOffs, a_globals, &ray_pos, &ray_dir, &fx, &fy);
+
+    /* gbufferSample */
+    GBufferAll result;
+    initGBufferAll(&result);
+    const Lite_Hit liteHit = ref_rayTrace(ray_pos, ray_dir, trees);
+    if (HitNone(liteHit))
+    {
+      result.data1.rgba = make_float4(0, 0, 0, 1);
+    }
+    else
+    {
+      const SurfaceHit surfHit = ref_evalSurface(ray_pos, ray_dir, liteHit, in_matrices, in_geomStorage, a_globals);
+      __global const PlainMaterial* pHitMaterial = materialAt(a_globals, in_mtlStorage, surfHit.matId);
+      ProcTextureList ptl;
+      InitProcTextureList(&ptl);
+      result.data1.depth    = liteHit.t;
+      result.data1.norm     = surfHit.normal;
+      result.data1.rgba     = to_float4(materialEvalDiffuse(pHitMaterial, ray_dir, surfHit.normal, surfHit.texCoord, a_globals, in_texStorage, &ptl), 0.0f);
+      result.data1.matId    = surfHit.matId;
+      result.data1.coverage = 1.0f;
+      result.data2.texCoord = surfHit.texCoord;
+      result.data2.objId    = liteHit.geomId;
+      result.data2.instId   = liteHit.instId;
+    }
+    samples[i] = result;
+  }
+
+  float minDiff   = 100000000.0f;
+  int   minDiffId = 0;
+  for (int i = 0; i < GBUFFER_SAMPLES; i++)
+  {
+    float diff     = 0.0f;
+    float coverage = 0.0f;
+    for (int j = 0; j < GBUFFER_SAMPLES; j++)
+    {
+      const float thisDiff = gbuffDiff(samples[i], samples[j], fov, (float)(m_width), (float)(m_height));
+      diff += thisDiff;
+      if (thisDiff < 1.0f)
+        coverage += 1.0f;
+    }
+    coverage *= (1.0f / (float)GBUFFER_SAMPLES);
+    samples[i].data1.coverage = coverage;
+    if (diff < minDiff)
+    {
+      minDiff   = diff;
+      minDiffId = i;
+    }
+  }
+
+  const GBufferAll g = samples[minDiffId];
+  out1[p] = packGBuffer1(g.data1);
+  out2[p] = packGBuffer2(g.data2);
+  __global float* o = raw14 + (size_t)p*14;
+  o[0] = g.data1.depth; o[1] = g.data1.norm.x; o[2] = g.data1.norm.y; o[3] = g.data1.norm.z;
+  o[4] = g.data1.rgba.x; o[5] = g.data1.rgba.y; o[6] = g.data1.rgba.z; o[7] = g.data1.rgba.w;
+  o[8] = as_float(g.data1.matId); o[9] = g.data1.coverage; o[10] = g.data2.texCoord.x; o[11] = g.data2.texCoord.y;
+  o[12] = as_float(g.data2.objId); o[13] = as_float(g.data2.instId);
+}

@@ -10,6 +10,7 @@
 #include "../../hydracore_amd/csrc/hk_trace.h"
 #include "../../hydracore_amd/csrc/hk_shading.h"
 #include "../../hydracore_amd/csrc/hk_bidir.h"
+#include "../../hydracore_amd/csrc/hk_gbuffer.h"
 #include "emu_integrator.h"
 
 struct EmuScene {   // mirrors tests/oracle_lib.OrcScene field for field
@@ -190,6 +191,30 @@ void emu_mmlt_run(const EmuScene* e, int n, unsigned* gens4, const int* depth, i
     RandomGen g = mchGen(c, CH_GEN, i); gens4[4 * i] = g.x; gens4[4 * i + 1] = g.y;
     g = mchGen(c, CH_GEN2, i); gens4[4 * i + 2] = g.x; gens4[4 * i + 3] = g.y;
     for (int j = 0; j < mmltStride(depth[i]); j++) xrows[size_t(i) * stride + j] = xCur[size_t(j) * n + i];
+  }
+}
+
+// IHWLayer::EvalGBuffer through hk_gbuffer.h: the rays, the per-sample record and the packing the device kernels use, with the serial
+// form of the cluster vote (the device runs it one wavefront per pixel).  Whole frame; out = packGBuffer1, packGBuffer2, raw record.
+void emu_gbuffer(const EmuScene* e, int w, int h, float* data1, float* data2, float* raw14) {
+  const SceneDev s = to_dev(e);
+  std::vector<float4> pos(HK_GBUFFER_SAMPLES), dir(HK_GBUFFER_SAMPLES);
+  std::vector<HydraLiteHit> hits(HK_GBUFFER_SAMPLES);
+  GBufferSample samples[HK_GBUFFER_SAMPLES];
+  for (int pixel = 0; pixel < w * h; pixel++) {
+    for (int k = 0; k < HK_GBUFFER_SAMPLES; k++) {
+      f3 rp, rd;
+      gbufferEyeRay(s, pixel % w, pixel / w, k, w, rp, rd);
+      pos[k] = mk4(rp, 0.0f); dir[k] = mk4(rd, 0.0f);
+    }
+    emu_trace(e, HK_GBUFFER_SAMPLES, reinterpret_cast<const float*>(pos.data()), reinterpret_cast<const float*>(dir.data()), hits.data(), nullptr, 0, nullptr, nullptr);
+    for (int k = 0; k < HK_GBUFFER_SAMPLES; k++) samples[k] = gbufferSampleOf(s, xyz(pos[k]), xyz(dir[k]), hits[k]);
+    const GBufferSample g = gbufferResolve(samples, float(w), float(h));
+    const float4 p1 = packGBuffer1(g), p2 = packGBuffer2(g);
+    float* d1 = data1 + 4 * size_t(pixel), *d2 = data2 + 4 * size_t(pixel), *o = raw14 + 14 * size_t(pixel);
+    d1[0] = p1.x; d1[1] = p1.y; d1[2] = p1.z; d1[3] = p1.w; d2[0] = p2.x; d2[1] = p2.y; d2[2] = p2.z; d2[3] = p2.w;
+    o[0] = g.depth; o[1] = g.norm.x; o[2] = g.norm.y; o[3] = g.norm.z; o[4] = g.rgba.x; o[5] = g.rgba.y; o[6] = g.rgba.z; o[7] = g.rgba.w;
+    o[8] = as_float(g.matId); o[9] = g.coverage; o[10] = g.texCoord.x; o[11] = g.texCoord.y; o[12] = as_float(g.objId); o[13] = as_float(g.instId);
   }
 }
 

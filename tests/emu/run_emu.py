@@ -71,6 +71,7 @@ def main():
     lib.emu_eye_rays.argtypes = [C.POINTER(OrcScene), i32, i32, i32, vp, vp, vp, vp]
     lib.emu_mmlt_run.argtypes = [C.POINTER(OrcScene), i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.emu_mmlt_f.argtypes = [C.POINTER(OrcScene), i32, vp, vp, i32, vp]
+    lib.emu_gbuffer.argtypes = [C.POINTER(OrcScene), i32, i32, vp, vp, vp]
     lib.emu_bidir.argtypes = [C.POINTER(OrcScene), i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
 
     def p(a):
@@ -133,6 +134,12 @@ def main():
         lib.emu_mmlt_run(C.byref(orc.s), len(cd), p(g_e), p(cd), 5, w, p(img_e), p(ch_e), p(x_e), x_e.shape[1], p(acc_e))
         assert (g_e == g_o).all() and (acc_e == acc_o).all() and np.allclose(x_e, x_o, atol=1e-7), "chains differ from the oracle's on " + name
         assert np.allclose(ch_e, ch_o, rtol=2e-5, atol=1e-7) and np.allclose(img_e, img_o, rtol=1e-4, atol=1e-6), "chain contributions differ on " + name
+        # IHWLayer::EvalGBuffer through hk_gbuffer.h against the oracle's gbufferEval, whole frame
+        if name in ("test_42", "atrium_transl_small"):
+            from test_golden_ref import check_gbuffer
+            e1, e2, eraw = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32), np.zeros((h, w, 14), np.float32)
+            lib.emu_gbuffer(C.byref(orc.s), w, h, p(e1), p(e2), p(eraw))
+            check_gbuffer((e1, e2, eraw), orc.gbuffer(), frac=0.005)
         # whole paths
         n = w * h
         ys, xs = np.divmod(np.arange(n), w)

@@ -54,6 +54,7 @@ def load():
     lib.orc_mutate_kelemen.argtypes = [i32, vp, vp, C.c_float, C.c_float, vp]
     lib.orc_mmlt_f.argtypes = [sp, i32, vp, vp, i32, vp]
     lib.orc_sbdpt_pass.argtypes = [sp, i32, vp, i32, i32, vp]
+    lib.orc_gbuffer.argtypes = [sp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.orc_mmlt_run.argtypes = [sp, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
@@ -232,6 +233,13 @@ class Oracle:
             image = np.zeros((self.h, self.w, 4), np.float32)
         self.lib.orc_sbdpt_pass(C.byref(self.s), len(gens4), _p(gens4), max_depth, self.w, _p(image))
         return image
+
+    def gbuffer(self, x0=0, y0=0, nx=None, ny=None):
+        """IntegratorCommon::gbufferEval for a pixel window (default: the frame): (data1, data2, raw14)"""
+        nx, ny = self.w - x0 if nx is None else nx, self.h - y0 if ny is None else ny
+        d1, d2, raw = np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 14), np.float32)
+        self.lib.orc_gbuffer(C.byref(self.s), self.w, self.h, x0, y0, nx, ny, _p(d1), _p(d2), _p(raw))
+        return d1, d2, raw
 
     def path_trace(self, pos4, dir4, rng2):
         pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)

@@ -191,6 +191,17 @@ class RefScene:
                                         ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.texaux)])
         return self.m.down(out, np.float32, (n, 8))
 
+    def gbuffer(self, x0, y0, nx, ny):
+        """IntegratorCommon::gbufferEval for the pixel window: (data1, data2, raw14), each (ny, nx, ...)"""
+        qmc = plane_hammersley(64)
+        n = nx * ny
+        o1, o2, raw = self.m.alloc(n * 16), self.m.alloc(n * 16), self.m.alloc(n * 56)
+        self.m.launch("ref_gbuffer", n, [("p", self.m.up(qmc)), ("i", x0), ("i", y0), ("i", nx), ("i", ny),
+                                         ("p", self.bvh), ("p", self.tris), ("i", self.have_inst), ("p", self.matrices), ("p", self.light_id),
+                                         ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", o1), ("p", o2), ("p", raw),
+                                         ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.texaux)])
+        return self.m.down(o1, np.float32, (ny, nx, 4)), self.m.down(o2, np.float32, (ny, nx, 4)), self.m.down(raw, np.float32, (ny, nx, 14))
+
     def path_trace(self, pos4, dir4, rng2):
         n = len(pos4)
         rng = self.m.up(np.ascontiguousarray(rng2, np.uint32))
@@ -200,3 +211,18 @@ class RefScene:
                                             ("p", self.geom), ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", col), ("i", n),
                                             ("p", self.alpha), ("p", self.bvh1), ("p", self.tris1), ("p", self.alpha1), ("i", self.have_inst1), ("p", self.texaux)])
         return self.m.down(col, np.float32, (n, 4)), self.m.down(rng, np.uint32, (n, 2))
+
+
+def plane_hammersley(n):
+    """PlaneHammersley (hydra_drv/globals_sys.cpp:45-61, host code of the reference: restated, float32 arithmetic): (n, 2)"""
+    out = np.zeros((n, 2), np.float32)
+    for k in range(n):
+        u, p, kk = np.float32(0), np.float32(0.5), k
+        while kk:
+            if kk & 1:
+                u = np.float32(u + p)
+            p = np.float32(p * np.float32(0.5))
+            kk >>= 1
+        out[k, 0] = u
+        out[k, 1] = np.float32(np.float32(k + 0.5) / np.float32(n))
+    return out

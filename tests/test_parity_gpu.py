@@ -994,3 +994,45 @@ def test_full_size_properties_1080p(built, scene, light_max):
     assert b_only.min() >= -1e-3 and b_only[..., :3].max() <= light_max * 1.001
     assert abs(a[..., :3].mean() - b_only[..., :3].mean()) < 0.05 * a[..., :3].mean()      # two independent samples of the same image
     sc.close()
+
+
+@pytest.mark.parametrize("fix,name", [("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_transl", "atrium_transl_small")])
+def test_gbuffer(fix, name, request):
+    """row f4: IHWLayer::EvalGBuffer on the device (64 primary rays per pixel through the path tracer's traversal kernel, one wavefront per pixel
+    for the cluster vote) against the reference's functions (tests/golden/ref_gbuffer_<scene>.npz) and against the oracle"""
+    from test_golden_ref import check_gbuffer, load
+    core, b, orc = request.getfixturevalue(fix)
+    w, h = int(b["width"]), int(b["height"])
+    got = core.eval_gbuffer(w, h, raw=True)
+    g = load("ref_gbuffer_%s.npz" % name)
+    check_gbuffer(got, (g["data1"], g["data2"], g["raw14"]))
+    check_gbuffer(got, orc.gbuffer())
+    # a_instIdByInstId is applied to the instance id of the second layer and to nothing else
+    n_inst = int(got[2][..., 13].view(np.int32).max()) + 1
+    remap = (np.arange(n_inst, dtype=np.int32) * 7 + 3)
+    d1, d2 = core.eval_gbuffer(w, h, inst_remap=remap)
+    inst = got[1][..., 3].view(np.int32)
+    assert (d1.view(np.uint32) == got[0].view(np.uint32)).all() and (d2[..., :3].view(np.uint32) == got[1][..., :3].view(np.uint32)).all()
+    assert (d2[..., 3].view(np.int32) == np.where(inst >= 0, inst * 7 + 3, inst)).all()
+
+
+def test_gbuffer_through_the_ihwlayer_adapter(built):
+    """IHWLayer::EvalGBuffer behind the boundary: the hand-shake over Header()->gbufferIsEmpty, the layers chosen by the shared image's depth
+    (3 -> layers 1, 2; 4 -> layers 2, 3; GPUOCLLayerOther.cpp:725-741), a_instIdByInstId, and the same records as the C-ABI call gives"""
+    from hydracore_amd import HostScene
+    sc = HostScene(scene_path("atrium_small"), 96, 54, trace_depth=5, enable_dof=0, use_hip=True, device=0, seed=777)
+    sc.draw(passes=1, spp=1)                                  # the driver pushes the camera in Draw()
+    d1, d2 = sc.hip().eval_gbuffer(96, 54)
+    l3, st3 = sc.eval_gbuffer(depth=3)
+    assert st3 == 0 and (l3[0] == 0).all()
+    assert (l3[1].view(np.uint32) == d1.view(np.uint32)).all() and (l3[2].view(np.uint32) == d2.view(np.uint32)).all()
+    n_inst = int(d2[..., 3].view(np.int32).max()) + 1
+    l4, st4 = sc.eval_gbuffer(depth=4, inst_remap=np.arange(n_inst, dtype=np.int32)[::-1].copy())
+    assert st4 == 0 and (l4[0] == 0).all() and (l4[1] == 0).all() and (l4[2].view(np.uint32) == d1.view(np.uint32)).all()
+    assert (l4[3][..., 3].view(np.int32) == n_inst - 1 - d2[..., 3].view(np.int32)).all()
+    done, st = sc.eval_gbuffer(depth=3, is_empty=0)           # somebody else has computed it already: nothing is written
+    assert st == 0 and (done == 0).all()
+    with pytest.raises(RuntimeError):
+        sc.eval_gbuffer(depth=2)                              # no G-buffer layers
+    sc.close()
+
