@@ -91,6 +91,13 @@ HK_DEV SegIter segq_iter(const SegQ& q) {
 }
 
 // ================================================================================================ kernels
+// counts of a queue of n items cut into nseg segments of `cap` slots, laid out back to back (item r = slot r % cap of segment r / cap)
+__global__ void k_fill_seg_counts(int n, int cap, int nseg, uint32_t* __restrict__ counts) {
+  const int sg = int(threadIdx.x);
+  if (sg >= nseg) return;
+  const long long left = (long long)n - (long long)sg * cap;
+  counts[sg * HK_CSTRIDE] = uint32_t(left <= 0 ? 0 : (left < cap ? left : cap));
+}
 // P1 -- ray generation: IntegratorCommon::makeEyeRay (Common.cpp:347-359) for every owned pixel
 // Path p of a sub-pass that traces `ns` samples of each of the N owned pixels: stream-major (p = stream * N + pixelIndex, the
 // default) or pixel-major (p = pixelIndex * ns + stream: the 64 lanes of a wave are 64 / ns neighbouring pixels x ns samples;
@@ -1047,6 +1054,7 @@ struct hydra_hip_ctx {
   size_t storageBytes[HYDRA_STORAGE_KINDS] = {0, 0, 0, 0, 0};   // bytes uploaded (a DevBuf may be larger)
   int sortPathsWanted = 1, sortPathsFromDepth = 1;   // options "sort_paths" / "sort_paths_from_bounce": group the paths of a workgroup by shading class in k_bounce
   int sceneTablesInLds = 2;          // option "scene_tables_in_lds"
+  int lastGbufferUs = 0;             // device time of the last hydra_hip_eval_gbuffer (read-only option "last_gbuffer_device_us")
   DevBuf stageImg;                   // the staged scene tables gathered in LDS order (k_build_stage_image), HK_SCENE_LDS_MAX_BYTES
   DevBuf srgbLut;                    // 256 floats, see SceneDev::srgbLut; option "srgb_table" 0 disables it
   int srgbLutWanted = 1;
@@ -2418,6 +2426,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "queue_segments") *value = c->nsegWanted;
   else if (n == "fused_bounce") *value = c->fusedBounce;
   else if (n == "srgb_table") *value = c->srgbLutWanted;
+  else if (n == "last_gbuffer_device_us") *value = c->lastGbufferUs;
   else if (n == "sort_paths") *value = c->sortPathsWanted;
   else if (n == "sort_paths_from_bounce") *value = c->sortPathsFromDepth;
   else if (n == "scene_tables_in_lds") *value = c->sceneTablesInLds;
@@ -2662,10 +2671,16 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
     hipLaunchKernelGGL(k_mmlt_step, dim3(seg_grid(c, q, 256, 64)), dim3(256), 0, c->stream, s, v, k, q, in, b.hits, out, b.counts + size_t(k) * HK_CROW);
   }
   hipLaunchKernelGGL(k_mmlt_connect_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
-  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-  launch_closest(c, s, seg_q(nullptr, n, 1, n), v.eyePos, v.eyeDir, b.eyeHit, nullptr, nullptr, fetch);
-  HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-  launch_shadow(c, s, seg_q(nullptr, n, 1, n), v.shPos, v.shDir, b.shVis, nullptr, fetch);
+  // the two connection rays of every chain, as a segmented queue over the chain order (one fetch counter for all persistent waves
+  // saturates at ~88 fetches per microsecond: 0.19 ms per launch of 1 M rays, more than their traversal takes)
+  const int capC = ((n + b.nseg - 1) / b.nseg + 63) / 64 * 64;
+  uint32_t* connCounts = b.counts + size_t(maxDepth + 1) * HK_CROW;
+  hipLaunchKernelGGL(k_fill_seg_counts, dim3(1), dim3(64), 0, c->stream, n, capC, b.nseg, connCounts);
+  const SegQ qc = seg_q(connCounts, 0, b.nseg, capC);
+  HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
+  launch_closest(c, s, qc, v.eyePos, v.eyeDir, b.eyeHit, nullptr, nullptr, fetch);
+  HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
+  launch_shadow(c, s, qc, v.shPos, v.shDir, b.shVis, nullptr, fetch);
   hipLaunchKernelGGL(k_mmlt_connect_end, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
   HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
@@ -2940,32 +2955,52 @@ int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, const
   int rc = HYDRA_HIP_OK;
   if ((rc = ensure_fetch_counters(c))) return rc;
   const int npix = c->w * c->h;
-  const int pixPerBlock = npix < 65536 ? npix : 65536;   // 4 M rays per block of rows (GPUOCLLayer works in MEGABLOCKSIZE lines the same way, :743-757)
-  const size_t rays = size_t(pixPerBlock) * HK_GBUFFER_SAMPLES;
+  // rays in blocks of pixels (GPUOCLLayer works in MEGABLOCKSIZE lines the same way, :743-757): through the path tracer's own ray and hit
+  // arrays when a render state is allocated (no path is alive between passes), else through 4 M-ray temporaries
   TmpBufs tb;
-  float4* dpos = (float4*)tb.up(c, nullptr, rays * 16, rc);
-  float4* ddir = (float4*)tb.up(c, nullptr, rays * 16, rc);
-  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, nullptr, rays * 16, rc);
+  size_t cap = std::min(std::min(c->sPos.bytes, c->sDir.bytes), c->hits.bytes) / 16 / HK_GBUFFER_SAMPLES;
+  float4* dpos = static_cast<float4*>(c->sPos.p), *ddir = static_cast<float4*>(c->sDir.p);
+  HydraLiteHit* dh = static_cast<HydraLiteHit*>(c->hits.p);
+  if (cap > size_t(1) << 24) cap = size_t(1) << 24;   // n = pixels x 64 stays below 2^31
+  if (cap < 65536 && cap < size_t(npix)) {
+    cap = npix < 65536 ? size_t(npix) : 65536;
+    dpos = (float4*)tb.up(c, nullptr, cap * HK_GBUFFER_SAMPLES * 16, rc);
+    ddir = (float4*)tb.up(c, nullptr, cap * HK_GBUFFER_SAMPLES * 16, rc);
+    dh = (HydraLiteHit*)tb.up(c, nullptr, cap * HK_GBUFFER_SAMPLES * 16, rc);
+  }
+  const int pixPerBlock = size_t(npix) < cap ? npix : int(cap);
   float4* d1 = (float4*)tb.up(c, nullptr, size_t(npix) * 16, rc);
   float4* d2 = (float4*)tb.up(c, nullptr, size_t(npix) * 16, rc);
   float* draw = raw14 ? (float*)tb.up(c, nullptr, size_t(npix) * 14 * 4, rc) : nullptr;
   int* dremap = (inst_remap && inst_remap_size > 0) ? (int*)tb.up(c, inst_remap, size_t(inst_remap_size) * 4, rc) : nullptr;
   if (rc) return rc;
   const SceneDev s = make_scene(c);
+  // the rays go through the traversal kernel as a 32-segment queue like the path tracer's: its persistent waves take their rays through one
+  // counter per segment, and a single counter saturates at ~88 fetches per microsecond (5.6 G rays/s; measured here before the split)
   uint32_t* fetch = static_cast<uint32_t*>(c->fetchCnt.p) + size_t(2 * HK_MAX_DEPTH + 2) * HK_CROW;
+  uint32_t* segCounts = fetch + HK_CROW;
+  const int nsegG = 32;
+  hipEvent_t ev0, ev1;
+  HCHECK(hipEventCreate(&ev0)); HCHECK(hipEventCreate(&ev1));
+  HCHECK(hipEventRecord(ev0, c->stream));
   for (int pix0 = 0; pix0 < npix; pix0 += pixPerBlock) {
     const int nPix = (npix - pix0 < pixPerBlock) ? npix - pix0 : pixPerBlock;
     const int n = nPix * HK_GBUFFER_SAMPLES;
     hipLaunchKernelGGL(k_gbuffer_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, c->w, pix0, nPix, dpos, ddir);
-    HCHECK(hipMemsetAsync(fetch, 0, 4, c->stream));
-    launch_closest(c, s, seg_q(nullptr, n, 1, n), dpos, ddir, dh, nullptr, nullptr, fetch);
+    const int capG = ((n + nsegG - 1) / nsegG + 63) / 64 * 64;
+    HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
+    hipLaunchKernelGGL(k_fill_seg_counts, dim3(1), dim3(64), 0, c->stream, n, capG, nsegG, segCounts);
+    launch_closest(c, s, seg_q(segCounts, 0, nsegG, capG), dpos, ddir, dh, nullptr, nullptr, fetch);
     hipLaunchKernelGGL(k_gbuffer_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, c->w, c->h, pix0, nPix, dpos, ddir, dh, dremap, inst_remap_size, d1, d2, draw);
   }
   HCHECK(hipGetLastError());
+  HCHECK(hipEventRecord(ev1, c->stream));
   HCHECK(hipMemcpyAsync(data1, d1, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
   HCHECK(hipMemcpyAsync(data2, d2, size_t(npix) * 16, hipMemcpyDeviceToHost, c->stream));
   if (raw14) HCHECK(hipMemcpyAsync(raw14, draw, size_t(npix) * 14 * 4, hipMemcpyDeviceToHost, c->stream));
   HCHECK(hipStreamSynchronize(c->stream));
+  { float ms = 0.0f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) c->lastGbufferUs = int(ms * 1000.0f); }   // device time of the rays, the traversal and the vote (option "last_gbuffer_device_us")
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   return HYDRA_HIP_OK;
 }
 

@@ -31,8 +31,9 @@ def main():
     dt = (time.time() - t) / args.iters
     rays = args.width * args.height * 64
     cov = (d1[..., 2].view(np.uint32) >> 24).astype(np.float32) / 255.0
-    print("%s %dx%d: %.1f ms per G-buffer (%d M primary rays, %.0f Mrays/s incl. vote and read-back); mean coverage %.3f, pixels with a hit %.3f"
-          % (args.scene, args.width, args.height, dt * 1e3, rays // 1000000, rays / dt / 1e6, cov.mean(), (d2[..., 2].view(np.int32) >= 0).mean()))
+    dev = core.get_option("last_gbuffer_device_us") * 1e-6
+    print("%s %dx%d: %.1f ms per call, of which %.1f ms on the device (%d M primary rays: %.0f Mrays/s with the vote; the rest is the read-back of 2 x %d MB into pageable host memory); mean coverage %.3f, pixels with a hit %.3f"
+          % (args.scene, args.width, args.height, dt * 1e3, dev * 1e3, rays // 1000000, rays / dev / 1e6, args.width * args.height * 16 // 1000000, cov.mean(), (d2[..., 2].view(np.int32) >= 0).mean()))
 
 
 if __name__ == "__main__":
