@@ -386,7 +386,7 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
-enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ALL = 255,
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_ALL = 511,
        HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent and Blinn nodes */ };
 
 // ================================================================================================ materials
@@ -650,6 +650,225 @@ HK_DEV void BlinnSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_di
     out.color = (color * D) * TorranceSparrowGF1(wo, wi);
     out.pdf = ((exponent + 1.0f) * powf(costheta, exponent)) / fmaxf(HK_TWOPI * 4.0f * dot(wo, wh), HK_DEPSILON);
   }
+  out.direction = newDir;
+  out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
+}
+
+// ---- anisotropic microfacet lobes: Beckmann and Trowbridge-Reitz (GGX) distributions as in PBRT v3 (cmatpbrt.h:105-540) behind the material
+// wrappers of cmaterial.h:1558-1846; both node classes share one layout (BECKMANN_* offsets, :1531-1556): colour 10..12, colour sampler ids
+// 13/14, glossiness 16 with sampler ids 17/18, anisotropy 19, rotation 68, anisotropy sampler ids 69/70, rotation sampler ids 71/72
+HK_DEV float Cos2ThetaPBRT(f3 w) { return w.z * w.z; }
+HK_DEV float AbsCosThetaPBRT(f3 w) { return fabsf(w.z); }
+HK_DEV float Sin2ThetaPBRT(f3 w) { return fmaxf(0.0f, 1.0f - Cos2ThetaPBRT(w)); }
+HK_DEV float SinThetaPBRT(f3 w) { return sqrtf(Sin2ThetaPBRT(w)); }
+HK_DEV float TanThetaPBRT(f3 w) { return (fabsf(w.z) < 1e-6f) ? 0.0f : SinThetaPBRT(w) / w.z; }
+HK_DEV float Tan2ThetaPBRT(f3 w) { return Sin2ThetaPBRT(w) / fmaxf(Cos2ThetaPBRT(w), 1e-6f); }
+HK_DEV float CosPhiPBRT(f3 w) { const float st = SinThetaPBRT(w); return (st == 0.0f) ? 1.0f : clampf(w.x / st, -1.0f, 1.0f); }
+HK_DEV float SinPhiPBRT(f3 w) { const float st = SinThetaPBRT(w); return (st == 0.0f) ? 0.0f : clampf(w.y / st, -1.0f, 1.0f); }
+HK_DEV float Cos2PhiPBRT(f3 w) { return CosPhiPBRT(w) * CosPhiPBRT(w); }
+HK_DEV float Sin2PhiPBRT(f3 w) { return SinPhiPBRT(w) * SinPhiPBRT(w); }
+HK_DEV float ErfPBRT(float x) {   // cmatpbrt.h:139-160
+  const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+  int sign = 1;
+  if (x < 0.0f) sign = -1;
+  x = fabsf(x);
+  const float t = 1.0f / (1.0f + p * x);
+  const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+  return float(sign) * y;
+}
+HK_DEV float ErfInvPBRT(float x) {   // cmatpbrt.h:162-193
+  float w, p;
+  x = clampf(x, -0.99999f, 0.99999f);
+  w = -logf((1.0f - x) * (1.0f + x));
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w; p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+  }
+  return p * x;
+}
+HK_DEV float BeckmannDistributionD(f3 wh, float ax, float ay) {
+  const float tan2Theta = Tan2ThetaPBRT(wh), cos4Theta = Cos2ThetaPBRT(wh) * Cos2ThetaPBRT(wh);
+  return expf((-1.0f) * tan2Theta * (Cos2PhiPBRT(wh) / fmaxf(ax * ax, 1e-6f) + Sin2PhiPBRT(wh) / fmaxf(ay * ay, 1e-6f))) / fmaxf(HK_PI * ax * ay * cos4Theta, 1e-6f);
+}
+HK_DEV float BeckmannDistributionLambda(f3 w, float ax, float ay) {
+  const float absTanTheta = fabsf(TanThetaPBRT(w));
+  if (!isfinite(absTanTheta) || absTanTheta == 0.0f) return 0.0f;
+  const float alpha = sqrtf(fmaxf(Cos2PhiPBRT(w) * ax * ax + Sin2PhiPBRT(w) * ay * ay, 1e-6f));
+  const float a = 1.0f / fmaxf(alpha * absTanTheta, 1e-6f);
+  if (a >= 1.6f) return 0.0f;
+  return (1.0f - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+}
+HK_DEV void BeckmannSample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {   // cmatpbrt.h:219-295
+  if (cosThetaI > 0.9999f) {
+    const float r = sqrtf(logf(1.0f - U1) * (-1.0f));
+    const float sinPhi = sinf(HK_TWOPI * U2), cosPhi = cosf(HK_TWOPI * U2);
+    slope_x = r * cosPhi; slope_y = r * sinPhi;
+    return;
+  }
+  const float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+  const float tanThetaI = sinThetaI / fmaxf(cosThetaI, 1e-6f);
+  const float cotThetaI = 1.0f / fmaxf(tanThetaI, 1e-6f);
+  float a = -1.0f;
+  float c = ErfPBRT(cotThetaI);
+  const float sample_x = fmaxf(U1, 1e-6f);
+  const float thetaI = acosf(cosThetaI);
+  const float fit = 1.0f + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+  float b = c - (1.0f + c) * powf(1.0f - sample_x, fit);
+  const float SQRT_PI_INV = 1.0f / sqrtf(HK_PI);
+  const float normalization = 1.0f / fmaxf(1.0f + c + SQRT_PI_INV * tanThetaI * expf((-1.0f) * cotThetaI * cotThetaI), 1e-6f);
+  int it = 0;
+  while (++it < 10) {
+    if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+    const float invErf = ErfInvPBRT(b);
+    const float value = normalization * (1.0f + b + SQRT_PI_INV * tanThetaI * expf((-1.0f) * invErf * invErf)) - sample_x;
+    const float derivative = normalization * (1.0f - invErf * tanThetaI);
+    if (fabsf(value) < 1e-5f) break;
+    if (value > 0.0f) c = b; else a = b;
+    b -= value / fmaxf(derivative, 1e-6f);
+  }
+  slope_x = ErfInvPBRT(b);
+  slope_y = ErfInvPBRT(2.0f * fmaxf(U2, 1e-6f) - 1.0f);
+}
+HK_DEV void TrowbridgeReitzSample11(float cosTheta, float U1, float U2, float& slope_x, float& slope_y) {   // cmatpbrt.h:397-448
+  if (cosTheta > 0.9999f) {
+    const float r = sqrtf(U1 / fmaxf(1.0f - U1, 1e-6f));
+    const float phi = HK_TWOPI * U2;
+    slope_x = r * cosf(phi); slope_y = r * sinf(phi);
+    return;
+  }
+  const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+  const float tanTheta = sinTheta / cosTheta;
+  const float a = 1.0f / tanTheta;
+  const float G1 = 2.0f / (1.0f + sqrtf(1.0f + 1.0f / (a * a)));
+  const float A = 2.0f * U1 / G1 - 1.0f;
+  float tmp = 1.0f / (A * A - 1.0f);
+  if (tmp > 1e10f) tmp = 1e10f;
+  const float B = tanTheta;
+  const float D = sqrtf(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+  const float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+  slope_x = (A < 0.0f || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+  float S;
+  if (U2 > 0.5f) { S = 1.0f; U2 = 2.0f * (U2 - 0.5f); } else { S = -1.0f; U2 = 2.0f * (0.5f - U2); }
+  const float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+  slope_y = S * z * sqrtf(1.0f + slope_x * slope_x);
+}
+// BeckmannSample / TrowbridgeReitzSample (:297-317, :450-472) and ...DistributionSampleWH (:319-327, :474-482)
+template <bool TR>
+HK_DEV f3 microfacetSampleWH(f3 wo, float u1, float u2, float ax, float ay) {
+  const bool flip = (wo.z < 0.0f);
+  const f3 wi = flip ? wo * (-1.0f) : wo;
+  const f3 wiStretched = normalize(mk3(ax * wi.x, ay * wi.y, wi.z));
+  float slope_x, slope_y;
+  if (TR) TrowbridgeReitzSample11(wiStretched.z, u1, u2, slope_x, slope_y); else BeckmannSample11(wiStretched.z, u1, u2, slope_x, slope_y);
+  const float tmp = CosPhiPBRT(wiStretched) * slope_x - SinPhiPBRT(wiStretched) * slope_y;
+  slope_y = SinPhiPBRT(wiStretched) * slope_x + CosPhiPBRT(wiStretched) * slope_y;
+  slope_x = tmp;
+  slope_x = ax * slope_x;
+  slope_y = ay * slope_y;
+  f3 wh = normalize(mk3(slope_x * (-1.0f), slope_y * (-1.0f), 1.0f));
+  if (flip) wh = wh * (-1.0f);
+  return wh;
+}
+HK_DEV float TrowbridgeReitzDistributionD(f3 wh, float ax, float ay) {
+  const float tan2Theta = Tan2ThetaPBRT(wh);
+  if (!isfinite(tan2Theta)) return 0.0f;
+  const float cos4Theta = Cos2ThetaPBRT(wh) * Cos2ThetaPBRT(wh);
+  const float e = (Cos2PhiPBRT(wh) / (ax * ax) + Sin2PhiPBRT(wh) / (ay * ay)) * tan2Theta;
+  return 1.0f / (HK_PI * ax * ay * cos4Theta * (1.0f + e) * (1.0f + e));
+}
+HK_DEV float TrowbridgeReitzDistributionLambda(f3 w, float ax, float ay) {
+  const float absTanTheta = fabsf(TanThetaPBRT(w));
+  if (!isfinite(absTanTheta)) return 0.0f;
+  const float alpha = sqrtf(Cos2PhiPBRT(w) * ax * ax + Sin2PhiPBRT(w) * ay * ay);
+  const float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+  return (-1.0f + sqrtf(1.0f + alpha2Tan2Theta)) / 2.0f;
+}
+template <bool TR> HK_DEV float microfacetD(f3 wh, float ax, float ay) { return TR ? TrowbridgeReitzDistributionD(wh, ax, ay) : BeckmannDistributionD(wh, ax, ay); }
+template <bool TR> HK_DEV float microfacetLambda(f3 w, float ax, float ay) { return TR ? TrowbridgeReitzDistributionLambda(w, ax, ay) : BeckmannDistributionLambda(w, ax, ay); }
+template <bool TR> HK_DEV float microfacetPdf(f3 wo, f3 wh, float ax, float ay) {   // ...DistributionPdf, :335-338, :490-493
+  return microfacetD<TR>(wh, ax, ay) * (1.0f / (1.0f + microfacetLambda<TR>(wo, ax, ay))) / fmaxf(4.0f * AbsCosThetaPBRT(wo), 1e-6f);
+}
+template <bool TR> HK_DEV float microfacetBRDF_PBRT(f3 wo, f3 wi, float ax, float ay) {   // BeckmannBRDF_PBRT :351-371, TrowbridgeReitzBRDF_PBRT :506-526
+  const float cosThetaO = AbsCosThetaPBRT(wo), cosThetaI = AbsCosThetaPBRT(wi);
+  f3 wh = wi + wo;
+  if (cosThetaI <= 1e-6f || cosThetaO <= 1e-6f) return 0.0f;
+  if (fabsf(wh.x) <= 1e-6f && fabsf(wh.y) <= 1e-6f && fabsf(wh.z) <= 1e-6f) return 0.0f;
+  wh = normalize(wh);
+  const float G = 1.0f / (1.0f + microfacetLambda<TR>(wo, ax, ay) + microfacetLambda<TR>(wi, ax, ay));
+  if (TR) return microfacetD<TR>(wh, ax, ay) * G / fmaxf(4.0f * cosThetaI * cosThetaO, 1e-6f);
+  return microfacetD<TR>(wh, ax, ay) * G * 1.0f / fmaxf(4.0f * cosThetaI * cosThetaO, 1e-6f);   // the Beckmann form carries its F = 1 factor
+}
+HK_DEV float BeckmannRoughnessToAlpha(float roughness) {   // cmatpbrt.h:340-344
+  const float x = logf(fmaxf(roughness, 1.0e-4f));
+  return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+HK_DEV float beckmannGlosiness(const float* m, f2 tc, const SceneDev& s) {   // cmaterial.h:1568-1581 (offsets = phong's)
+  return phongGlosiness(m, tc, s);
+}
+HK_DEV f2 beckmannAlphaXY(const float* m, f2 tc, const SceneDev& s) {   // :1583-1611
+  const float roughness = 0.5f - 0.5f * beckmannGlosiness(m, tc, s);
+  const f3 ac = sample2DExt(as_int(m[HM_BECKMANN_ANISO_TEXMATRIXID]), tc, m, s);
+  const float anisoMult = 1.0f - clampf(m[HM_BECKMANN_ANISOTROPY] * fmaxf(ac.x, fmaxf(ac.y, ac.z)), 0.0f, 1.0f);
+  return mk2(BeckmannRoughnessToAlpha(roughness * roughness), BeckmannRoughnessToAlpha(roughness * roughness * anisoMult * anisoMult));
+}
+HK_DEV void BeckmanTangentSpace(const float* m, f2 alpha, f3 nz, f3 a_tan, f3 a_bitan, f2 tc, const SceneDev& s, f3& nx, f3& ny) {   // :1613-1635
+  if (fabsf(alpha.x - alpha.y) > 1e-5f) {
+    nx = a_bitan; ny = a_tan;
+    const f3 rc = sample2DExt(as_int(m[HM_BECKMANN_ROT_TEXMATRIXID]), tc, m, s);
+    const float rotVal = clampf(m[HM_BECKMANN_ANISO_ROT] * fmaxf(rc.x, fmaxf(rc.y, rc.z)), 0.0f, 1.0f);
+    const float rotAngle = rotVal * HK_TWOPI;
+    const float cos_t = cosf(rotAngle), sin_t = sinf(rotAngle);
+    const f3 v = nz;   // RotateAroundVector4x4, cglobals.h:1122-1150, applied with mul3x3
+    const f3 r0 = mk3((1.0f - cos_t) * v.x * v.x + cos_t, (1.0f - cos_t) * v.x * v.y - sin_t * v.z, (1.0f - cos_t) * v.x * v.z + sin_t * v.y);
+    const f3 r1 = mk3((1.0f - cos_t) * v.y * v.x + sin_t * v.z, (1.0f - cos_t) * v.y * v.y + cos_t, (1.0f - cos_t) * v.y * v.z - sin_t * v.x);
+    const f3 r2 = mk3((1.0f - cos_t) * v.x * v.z - sin_t * v.y, (1.0f - cos_t) * v.z * v.y + sin_t * v.x, (1.0f - cos_t) * v.z * v.z + cos_t);
+    const f3 px = nx, py = ny;
+    nx = mk3(r0.x * px.x + r0.y * px.y + r0.z * px.z, r1.x * px.x + r1.y * px.y + r1.z * px.z, r2.x * px.x + r2.y * px.y + r2.z * px.z);
+    ny = mk3(r0.x * py.x + r0.y * py.y + r0.z * py.z, r1.x * py.x + r1.y * py.y + r1.z * py.z, r2.x * py.x + r2.y * py.y + r2.z * py.z);
+  } else
+    CoordinateSystem(nz, nx, ny);
+  if ((matFlags(m) & HMF_FLIP_TANGENT) != 0) { const f3 t = nx; nx = ny; ny = t; }
+}
+template <bool TR>
+HK_DEV float anisoEvalPDF(const float* m, f3 l, f3 v, f3 n, f3 a_tan, f3 a_bitan, f2 tc, const SceneDev& s) {   // beckmannEvalPDF :1637-1660, trggxEvalPDF :1743-1767
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return 1.0f;
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  f3 nx, ny;
+  BeckmanTangentSpace(m, alpha, n, a_tan, a_bitan, tc, s, nx, ny);
+  const f3 wo = mk3(-dot(v, nx), -dot(v, ny), -dot(v, n));
+  const f3 wh = normalize(l + v);
+  return microfacetPdf<TR>(wo, wh, alpha.x, alpha.y);
+}
+template <bool TR>
+HK_DEV f3 anisoEvalBxDF(const float* m, f3 l, f3 v, f3 n, f3 a_tan, f3 a_bitan, f2 tc, const SceneDev& s) {   // :1662-1687, :1769-1794
+  if (dot(n, v) < 1e-6f || dot(n, l) < 1e-6f) return mk3(0, 0, 0);
+  const f3 color = clamp3(sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s) * matColor(m), 0.0f, 1.0f);
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  f3 nx, ny;
+  BeckmanTangentSpace(m, alpha, n, a_tan, a_bitan, tc, s, nx, ny);
+  const f3 wo = mk3(-dot(v, nx), -dot(v, ny), -dot(v, n)), wi = mk3(-dot(l, nx), -dot(l, ny), -dot(l, n));
+  return color * microfacetBRDF_PBRT<TR>(wo, wi, alpha.x, alpha.y);
+}
+template <bool TR>
+HK_DEV void AnisoSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_dir, f3 a_normal, f2 tc, f3 a_tan, f3 a_bitan, const SceneDev& s, MatSample& out) {   // :1689-1731, :1796-1838
+  const f3 color = clamp3(sample2DExt(as_int(m[HM_TEXMATRIXID]), tc, m, s) * matColor(m), 0.0f, 1.0f);
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  const float gloss = beckmannGlosiness(m, tc, s);
+  f3 nx, ny;
+  const f3 nz = a_normal;
+  BeckmanTangentSpace(m, alpha, nz, a_tan, a_bitan, tc, s, nx, ny);
+  const f3 wo = mk3(-dot(ray_dir, nx), -dot(ray_dir, ny), -dot(ray_dir, nz));
+  const f3 wh = microfacetSampleWH<TR>(wo, r1, r2, alpha.x, alpha.y);
+  const f3 wi = (wh * (2.0f * dot(wo, wh))) - wo;
+  const f3 newDir = normalize(((nx * wi.x) + (ny * wi.y)) + (nz * wi.z));
+  const f3 v = ray_dir * (-1.0f), l = newDir;
+  if (dot(a_normal, v) < 1e-6f || dot(a_normal, l) < 1e-6f) { out.color = mk3(0, 0, 0); out.pdf = 1.0f; }
+  else { out.color = color * microfacetBRDF_PBRT<TR>(wo, wi, alpha.x, alpha.y); out.pdf = microfacetPdf<TR>(wo, wh, alpha.x, alpha.y); }
   out.direction = newDir;
   out.flags = (gloss >= 0.99f) ? HRE_S : HRE_G;
 }
@@ -984,6 +1203,8 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, hitNorm, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
     case HMT_TRANSLUCENT: if (F & HK_FEAT_TRANSLUCENT) TranslucentSampleAndEvalBRDF(node, rands[0], rands[1], hitNorm, sh.texCoord, s, out); break;
     case HMT_BLINN: if (F & HK_FEAT_BLINN) BlinnSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_BECKMANN: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<false>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
+    case HMT_TRGGX: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<true>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
     default: break;
   }
   if (nmap) {   // :2322-2327: the caller multiplies by the cosine to the shading normal
@@ -1064,6 +1285,14 @@ HK_DEV BxDFResult materialEval(const float* a_m, const ShadeContext& sc, const S
         brdf = blinnEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult;
         pf = blinnEvalPDF(m, sc.l, sc.v, n, sc.tc, s);
         pr = blinnEvalPDF(m, sc.v, sc.l, n, sc.tc, s);
+      } else if ((F & HK_FEAT_ANISO) && type == HMT_BECKMANN) {
+        brdf = anisoEvalBxDF<false>(m, sc.l, sc.v, n, sc.tg, sc.bn, sc.tc, s) * cosMult;
+        pf = anisoEvalPDF<false>(m, sc.l, sc.v, n, sc.tg, sc.bn, sc.tc, s);
+        pr = anisoEvalPDF<false>(m, sc.v, sc.l, n, sc.tg, sc.bn, sc.tc, s);
+      } else if ((F & HK_FEAT_ANISO) && type == HMT_TRGGX) {
+        brdf = anisoEvalBxDF<true>(m, sc.l, sc.v, n, sc.tg, sc.bn, sc.tc, s) * cosMult;
+        pf = anisoEvalPDF<true>(m, sc.l, sc.v, n, sc.tg, sc.bn, sc.tc, s);
+        pr = anisoEvalPDF<true>(m, sc.v, sc.l, n, sc.tg, sc.bn, sc.tc, s);
       } else if ((F & HK_FEAT_TRANSLUCENT) && type == HMT_TRANSLUCENT) {
         btdf = translucentEvalBxDF(m, sc.l, sc.v, n, sc.tc, s) * cosMult2;
         pf = translucentEvalPDF(sc.l, sc.v, n);

@@ -362,7 +362,7 @@ HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const Sur
   const f3 surfNormal = surf.normal;
   ShadeContext sc;
   sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = surf.texCoord;
-  if (F & HK_FEAT_NMAP) { sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent; }
+  if (F & (HK_FEAT_NMAP | HK_FEAT_ANISO)) { sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent; }
   const BxDFResult ev = materialEval<F>(mat, sc, s);
   const float cos1 = fmaxf(+dot(shadowRayDir, surfNormal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surfNormal), 0.0f);
   const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
@@ -1285,11 +1285,12 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (type == HMT_GGX) feat |= HK_FEAT_GGX;
       if (type == HMT_TRANSLUCENT) feat |= HK_FEAT_TRANSLUCENT;
       if (type == HMT_BLINN) feat |= HK_FEAT_BLINN;
+      if (type == HMT_BECKMANN || type == HMT_TRGGX) feat |= HK_FEAT_ANISO;
       const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
-                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX || type == HMT_TRANSLUCENT || type == HMT_BLINN);
+                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX || type == HMT_TRANSLUCENT || type == HMT_BLINN || type == HMT_BECKMANN || type == HMT_TRGGX);
       if (!known)
         return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has BxDF class " + std::to_string(type) +
-                                             "; the HIP layer implements phong, Blinn (Torrance-Sparrow), GGX, mirror, thin glass, glass, translucent, lambert, oren-nayar, blend mask and emissive only");
+                                             "; the HIP layer implements phong, Blinn (Torrance-Sparrow), Beckmann, TRGGX, GGX, mirror, thin glass, glass, translucent, lambert, oren-nayar, blend mask and emissive only");
     }
   }
   c->matFeatures = feat;
@@ -1588,7 +1589,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
-  if (!fused && (c->sceneFeatures & (HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN))) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has translucent or Blinn materials, which only the fused bounce kernel contains (fused_bounce = 1)");
+  if (!fused && (c->sceneFeatures & (HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO))) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has translucent, Blinn, Beckmann or TRGGX materials, which only the fused bounce kernel contains (fused_bounce = 1)");
   if (!fused && (c->sceneFeatures & HK_FEAT_NMAP)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the scene has normal-mapped materials; the split bounce form (fused_bounce = 0) carries no tangent frame in its record, use the fused kernel");
   SceneStage stage = scene_stage(c);
   if (stage.matF4 + stage.triBaseF4 > 0) {   // gather the staged tables (the header changes with the camera, so once per pass)
@@ -1625,7 +1626,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
-          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
           else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
           else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
           else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);

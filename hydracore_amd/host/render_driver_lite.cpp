@@ -163,6 +163,25 @@ MatPtr make_blinn(float3 color, int32_t texId, const Sampler& sc, float cosPower
   put_i(p->plain, HM_TYPE, HMT_BLINN);
   return p;
 }
+// BeckmannMaterial / TRGGXMaterial, PlainMaterialConverter.cpp:500-631: one layout (cmaterial.h:1531-1556); the TRGGX constructor does not
+// store the texture ids of its anisotropy and rotation samplers (only their sampler slots), which the shading never reads
+MatPtr make_aniso(bool trggx, float3 color, const Sampler& sc, float cosPower, const Sampler& sg, float gloss, const Sampler& sa, float aniso, const Sampler& sr, float rot, bool flipAxis) {
+  MatPtr p = new_node();
+  float* d = p->plain;
+  d[HM_COLOR] = color.x; d[HM_COLOR + 1] = color.y; d[HM_COLOR + 2] = color.z;
+  d[HM_PHONG_COSPOWER] = cosPower;
+  d[HM_PHONG_GLOSINESS] = gloss;
+  d[HM_BECKMANN_ANISOTROPY] = aniso;
+  d[HM_BECKMANN_ANISO_ROT] = rot;
+  put_sampler_at(d, sc.texId, sc, HM_TEXID, HM_TEXMATRIXID, HM_PHONG_SAMPLER0);
+  put_sampler_at(d, sg.texId, sg, HM_PHONG_GLOSS_TEXID, HM_PHONG_GLOSS_TEXMATRIXID, HM_PHONG_SAMPLER1);
+  put_sampler_at(d, sa.texId, sa, HM_BECKMANN_ANISO_TEXID, HM_BECKMANN_ANISO_TEXMATRIXID, HM_BECKMANN_SAMPLER2);
+  put_sampler_at(d, sr.texId, sr, HM_BECKMANN_ROT_TEXID, HM_BECKMANN_ROT_TEXMATRIXID, HM_BECKMANN_SAMPLER3);
+  if (trggx) { put_i(d, HM_BECKMANN_ANISO_TEXID, 0); put_i(d, HM_BECKMANN_ROT_TEXID, 0); }
+  put_i(d, HM_TYPE, trggx ? HMT_TRGGX : HMT_BECKMANN);
+  put_i(d, HM_FLAGS, HMF_CAST_CAUSTICS | (flipAxis ? HMF_FLIP_TANGENT : 0));
+  return p;
+}
 // GGXMaterial, PlainMaterialConverter.cpp:635-680 (the anisotropy arguments of the constructor are never stored)
 MatPtr make_ggx(float3 color, int32_t texId, const Sampler& sc, float cosPower, int32_t glossTexId, const Sampler& sg, float gloss, float ior) {
   MatPtr p = new_node();
@@ -439,6 +458,14 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     else if (brdf == "torranse_sparrow") {   // sic, PlainMaterialConverter.cpp:1130
       const XmlNode* an = xchild(reflect, "anisotropy");
       pMaterialS = make_blinn(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal, an ? read_value1f(an) : 0.0f);
+    }
+    else if (brdf == "beckmann" || brdf == "trggx" || brdf == "TRGGX") {   // PlainMaterialConverter.cpp:1068-1142
+      const XmlNode* an = xchild(reflect, "anisotropy");
+      Sampler sa, sr;                    // DummySampler: texId = INVALID_TEXTURE
+      if (an && sampler_node(an)) sa = sampler_from_texref(sampler_node(an));
+      if (an && xchild(an, "texture_rot")) sr = sampler_from_texref(xchild(an, "texture_rot"));
+      pMaterialS = make_aniso(brdf != "beckmann", colorS, samplRefl, 0.0f, sg, glossVal, sa, an ? read_value1f(an) : 0.0f, sr,
+                              an ? an->attr_float("rot") : 0.0f, an ? an->attr_int("flip_axis") == 1 : false);
     }
     else if (brdf == "ggx" || brdf == "GGX")
       pMaterialS = make_ggx(colorS, texReflId, samplRefl, 0.0f, texGloss, sg, glossVal, fresnelIOR);

@@ -132,6 +132,8 @@ enum {
   HM_ORENNAYAR_ROUGHNESS = 15, HM_ORENNAYAR_A = 16, HM_ORENNAYAR_B = 17, HM_ORENNAYAR_SAMPLER = 20,   /* cmaterial.h:264-276 */
   HM_PHONG_COSPOWER = 15, HM_PHONG_GLOSINESS = 16, HM_PHONG_GLOSS_TEXID = 17, HM_PHONG_GLOSS_TEXMATRIXID = 18,
   HM_PHONG_SAMPLER0 = 20, HM_PHONG_SAMPLER1 = 32,
+  HM_BECKMANN_ANISOTROPY = 19, HM_BECKMANN_SAMPLER2 = 44, HM_BECKMANN_SAMPLER3 = 56, HM_BECKMANN_ANISO_ROT = 68,   /* Beckmann and TRGGX nodes: cmaterial.h:1531-1556, the rest = phong's offsets */
+  HM_BECKMANN_ANISO_TEXID = 69, HM_BECKMANN_ANISO_TEXMATRIXID = 70, HM_BECKMANN_ROT_TEXID = 71, HM_BECKMANN_ROT_TEXMATRIXID = 72,
   HM_BLINN_ANISOTROPY = 19,   /* BLINN_ANISOTROPY_OFFSET, cmaterial.h:1034; Blinn shares every phong offset */
   HM_MIRROR_SAMPLER = 16,
   HM_GGX_COSPOWER = 15, HM_GGX_GLOSINESS = 16, HM_GGX_GLOSS_TEXID = 17, HM_GGX_GLOSS_TEXMATRIXID = 18, HM_GGX_FRESNEL_IOR = 19,   /* cmaterial.h:1165-1185 */
@@ -154,6 +156,7 @@ enum { /* PLAIN_MAT_FLAGS cglobals.h:2624-2655 */
   HMF_CAST_CAUSTICS = 2, HMF_HAS_DIFFUSE = 4, HMF_HAS_TRANSPARENCY = 8, HMF_FORBID_EMISSIVE_GI = 512,
   HMF_INVERT_NMAP_X = 16, HMF_INVERT_NMAP_Y = 32, HMF_INVERT_SWAP_NMAP_XY = 64, HMF_INVERT_HEIGHT = 128,   /* cglobals.h:2631-2634 */
   HMF_SKIP_SKY_PORTAL = 1024, HMF_HAVE_BTDF = 8192, HMF_CAN_SAMPLE_REFL_ONLY = 32768,
+  HMF_FLIP_TANGENT = 32768 * 128,   /* cglobals.h:2653 */
   HMF_ENERGY_FIX = 32768 * 256
 };
 enum { /* BLEND_MASK_FLAGS cmaterial.h:1975-1979 */

@@ -40,14 +40,14 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_BLINN = 1, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_TRANSLUCENT = 5, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_GGX = 15 };
+enum { MT_PHONG = 0, MT_BLINN = 1, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_TRANSLUCENT = 5, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_BECKMANN = 13, MT_TRGGX = 14, MT_GGX = 15 };
 enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };
 enum { THINGLASS_GLOSINESS = 16, THINGLASS_GLOSINESS_TEXMATRIXID = 18,                  /* cmaterial.h:472-491 */
        GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23,         /* cmaterial.h:566-590 */
        GGX_GLOSINESS = 16, GGX_GLOSINESS_TEXID = 17, GGX_GLOSINESS_TEXMATRIXID = 18 };  /* cmaterial.h:1165-1185 */
 enum { G_ESS_GGX_TABLE = 1268, G_ESS_TRANSP_TABLE = 3316 };   /* EngineGlobals::m_essGgx2017Table / m_essTranspTable in int32 words, cfetch.h:21-81 */   /* cmaterial.h:264-276; colour and sampler offsets equal lambert's */
 enum { MF_CAST_CAUSTICS = 2, MF_FORBID_EMISSIVE_GI = 512, MF_SKIP_SKY_PORTAL = 1024, MF_CAN_SAMPLE_REFL_ONLY = 32768,
-       MF_ENERGY_FIX = 32768 * 256 };
+       MF_FLIP_TANGENT = 32768 * 128, MF_ENERGY_FIX = 32768 * 256 };
 enum { BMF_FRESNEL = 1, BMF_FALOFF = 2, BMF_REFL_WEIGHT_IS_ONE = 4, BMF_EXTRUSION_LUMINANCE = 16 };
 enum { BLEND_SIGMOID = 4, BLEND_INVERT_FALOFF = 1 };
 enum { MIX_TREE_MAX_DEEP = 7, FLOATS_PER_SAMPLE = 3, FLOATS_PER_MLAYER = 7 };
@@ -894,6 +894,216 @@ static void BlinnSampleAndEvalBRDF(const float* m, float r1, float r2, f3 ray_di
   out->direction = newDir;
   out->flags = (gloss >= 0.99f) ? RAY_EVENT_S : RAY_EVENT_G;
 }
+/* ---- anisotropic microfacet lobes: PBRT v3's Beckmann and Trowbridge-Reitz distributions (cmatpbrt.h:105-540) behind the wrappers of
+ * cmaterial.h:1558-1846; one node layout for both classes (BECKMANN_* offsets, :1531-1556) */
+enum { BECKMANN_ANISOTROPY = 19, BECKMANN_ANISO_ROT = 68, BECKMANN_ANISO_TEXMATRIXID = 70, BECKMANN_ROT_TEXMATRIXID = 72 };
+static inline float Cos2ThetaPBRT(f3 w) { return w.z * w.z; }
+static inline float AbsCosThetaPBRT(f3 w) { return fabsf(w.z); }
+static inline float Sin2ThetaPBRT(f3 w) { return fmaxf(0.0f, 1.0f - Cos2ThetaPBRT(w)); }
+static inline float SinThetaPBRT(f3 w) { return sqrtf(Sin2ThetaPBRT(w)); }
+static inline float TanThetaPBRT(f3 w) { return (fabsf(w.z) < 1e-6f) ? 0.0f : SinThetaPBRT(w) / w.z; }
+static inline float Tan2ThetaPBRT(f3 w) { return Sin2ThetaPBRT(w) / fmaxf(Cos2ThetaPBRT(w), 1e-6f); }
+static inline float CosPhiPBRT(f3 w) { const float st = SinThetaPBRT(w); return (st == 0.0f) ? 1.0f : clampf(w.x / st, -1.0f, 1.0f); }
+static inline float SinPhiPBRT(f3 w) { const float st = SinThetaPBRT(w); return (st == 0.0f) ? 0.0f : clampf(w.y / st, -1.0f, 1.0f); }
+static inline float Cos2PhiPBRT(f3 w) { return CosPhiPBRT(w) * CosPhiPBRT(w); }
+static inline float Sin2PhiPBRT(f3 w) { return SinPhiPBRT(w) * SinPhiPBRT(w); }
+static float ErfPBRT(float x) {
+  const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+  int sign = 1;
+  if (x < 0.0f) sign = -1;
+  x = fabsf(x);
+  const float t = 1.0f / (1.0f + p * x);
+  const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+  return sign * y;
+}
+static float ErfInvPBRT(float x) {
+  float w, p;
+  x = clampf(x, -0.99999f, 0.99999f);
+  w = -logf((1.0f - x) * (1.0f + x));
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w; p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+  }
+  return p * x;
+}
+static float BeckmannDistributionD(f3 wh, float ax, float ay) {
+  const float tan2Theta = Tan2ThetaPBRT(wh), cos4Theta = Cos2ThetaPBRT(wh) * Cos2ThetaPBRT(wh);
+  return expf((-1.0f) * tan2Theta * (Cos2PhiPBRT(wh) / fmaxf(ax * ax, 1e-6f) + Sin2PhiPBRT(wh) / fmaxf(ay * ay, 1e-6f))) / fmaxf(M_PI_F * ax * ay * cos4Theta, 1e-6f);
+}
+static float BeckmannDistributionLambda(f3 w, float ax, float ay) {
+  const float absTanTheta = fabsf(TanThetaPBRT(w));
+  if (!isfinite(absTanTheta) || absTanTheta == 0.0f) return 0.0f;
+  const float alpha = sqrtf(fmaxf(Cos2PhiPBRT(w) * ax * ax + Sin2PhiPBRT(w) * ay * ay, 1e-6f));
+  const float a = 1.0f / fmaxf(alpha * absTanTheta, 1e-6f);
+  if (a >= 1.6f) return 0.0f;
+  return (1.0f - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+}
+static void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y) {
+  if (cosThetaI > 0.9999f) {
+    const float r = sqrtf(logf(1.0f - U1) * (-1.0f));
+    const float sinPhi = sinf(M_TWOPI_F * U2), cosPhi = cosf(M_TWOPI_F * U2);
+    *slope_x = r * cosPhi; *slope_y = r * sinPhi;
+    return;
+  }
+  const float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+  const float tanThetaI = sinThetaI / fmaxf(cosThetaI, 1e-6f);
+  const float cotThetaI = 1.0f / fmaxf(tanThetaI, 1e-6f);
+  float a = -1.0f;
+  float c = ErfPBRT(cotThetaI);
+  const float sample_x = fmaxf(U1, 1e-6f);
+  const float thetaI = acosf(cosThetaI);
+  const float fit = 1.0f + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+  float b = c - (1.0f + c) * powf(1.0f - sample_x, fit);
+  const float SQRT_PI_INV = 1.0f / sqrtf(M_PI_F);
+  const float normalization = 1.0f / fmaxf(1.0f + c + SQRT_PI_INV * tanThetaI * expf((-1.0f) * cotThetaI * cotThetaI), 1e-6f);
+  int it = 0;
+  while (++it < 10) {
+    if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+    const float invErf = ErfInvPBRT(b);
+    const float value = normalization * (1.0f + b + SQRT_PI_INV * tanThetaI * expf((-1.0f) * invErf * invErf)) - sample_x;
+    const float derivative = normalization * (1.0f - invErf * tanThetaI);
+    if (fabsf(value) < 1e-5f) break;
+    if (value > 0.0f) c = b; else a = b;
+    b -= value / fmaxf(derivative, 1e-6f);
+  }
+  *slope_x = ErfInvPBRT(b);
+  *slope_y = ErfInvPBRT(2.0f * fmaxf(U2, 1e-6f) - 1.0f);
+}
+static void TrowbridgeReitzSample11(float cosTheta, float U1, float U2, float* slope_x, float* slope_y) {
+  if (cosTheta > 0.9999f) {
+    const float r = sqrtf(U1 / fmaxf(1.0f - U1, 1e-6f));
+    const float phi = M_TWOPI_F * U2;
+    *slope_x = r * cosf(phi); *slope_y = r * sinf(phi);
+    return;
+  }
+  const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+  const float tanTheta = sinTheta / cosTheta;
+  const float a = 1.0f / tanTheta;
+  const float G1 = 2.0f / (1.0f + sqrtf(1.0f + 1.0f / (a * a)));
+  const float A = 2.0f * U1 / G1 - 1.0f;
+  float tmp = 1.0f / (A * A - 1.0f);
+  if (tmp > 1e10f) tmp = 1e10f;
+  const float B = tanTheta;
+  const float D = sqrtf(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+  const float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+  *slope_x = (A < 0.0f || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+  float S;
+  if (U2 > 0.5f) { S = 1.0f; U2 = 2.0f * (U2 - 0.5f); } else { S = -1.0f; U2 = 2.0f * (0.5f - U2); }
+  const float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+  *slope_y = S * z * sqrtf(1.0f + *slope_x * *slope_x);
+}
+static f3 microfacetSampleWH(int TR, f3 wo, float u1, float u2, float ax, float ay) {
+  const int flip = (wo.z < 0.0f);
+  const f3 wi = flip ? scale3(wo, -1.0f) : wo;
+  const f3 wiStretched = normalize3(v3(ax * wi.x, ay * wi.y, wi.z));
+  float slope_x, slope_y;
+  if (TR) TrowbridgeReitzSample11(wiStretched.z, u1, u2, &slope_x, &slope_y); else BeckmannSample11(wiStretched.z, u1, u2, &slope_x, &slope_y);
+  const float tmp = CosPhiPBRT(wiStretched) * slope_x - SinPhiPBRT(wiStretched) * slope_y;
+  slope_y = SinPhiPBRT(wiStretched) * slope_x + CosPhiPBRT(wiStretched) * slope_y;
+  slope_x = tmp;
+  slope_x = ax * slope_x;
+  slope_y = ay * slope_y;
+  f3 wh = normalize3(v3(slope_x * (-1.0f), slope_y * (-1.0f), 1.0f));
+  if (flip) wh = scale3(wh, -1.0f);
+  return wh;
+}
+static float TrowbridgeReitzDistributionD(f3 wh, float ax, float ay) {
+  const float tan2Theta = Tan2ThetaPBRT(wh);
+  if (!isfinite(tan2Theta)) return 0.0f;
+  const float cos4Theta = Cos2ThetaPBRT(wh) * Cos2ThetaPBRT(wh);
+  const float e = (Cos2PhiPBRT(wh) / (ax * ax) + Sin2PhiPBRT(wh) / (ay * ay)) * tan2Theta;
+  return 1.0f / (M_PI_F * ax * ay * cos4Theta * (1.0f + e) * (1.0f + e));
+}
+static float TrowbridgeReitzDistributionLambda(f3 w, float ax, float ay) {
+  const float absTanTheta = fabsf(TanThetaPBRT(w));
+  if (!isfinite(absTanTheta)) return 0.0f;
+  const float alpha = sqrtf(Cos2PhiPBRT(w) * ax * ax + Sin2PhiPBRT(w) * ay * ay);
+  const float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+  return (-1.0f + sqrtf(1.0f + alpha2Tan2Theta)) / 2.0f;
+}
+static float microfacetD(int TR, f3 wh, float ax, float ay) { return TR ? TrowbridgeReitzDistributionD(wh, ax, ay) : BeckmannDistributionD(wh, ax, ay); }
+static float microfacetLambda(int TR, f3 w, float ax, float ay) { return TR ? TrowbridgeReitzDistributionLambda(w, ax, ay) : BeckmannDistributionLambda(w, ax, ay); }
+static float microfacetPdf(int TR, f3 wo, f3 wh, float ax, float ay) {
+  return microfacetD(TR, wh, ax, ay) * (1.0f / (1.0f + microfacetLambda(TR, wo, ax, ay))) / fmaxf(4.0f * AbsCosThetaPBRT(wo), 1e-6f);
+}
+static float microfacetBRDF_PBRT(int TR, f3 wo, f3 wi, float ax, float ay) {
+  const float cosThetaO = AbsCosThetaPBRT(wo), cosThetaI = AbsCosThetaPBRT(wi);
+  f3 wh = add3(wi, wo);
+  if (cosThetaI <= 1e-6f || cosThetaO <= 1e-6f) return 0.0f;
+  if (fabsf(wh.x) <= 1e-6f && fabsf(wh.y) <= 1e-6f && fabsf(wh.z) <= 1e-6f) return 0.0f;
+  wh = normalize3(wh);
+  const float G = 1.0f / (1.0f + microfacetLambda(TR, wo, ax, ay) + microfacetLambda(TR, wi, ax, ay));
+  return microfacetD(TR, wh, ax, ay) * G / fmaxf(4.0f * cosThetaI * cosThetaO, 1e-6f);   /* F = 1 in both forms */
+}
+static float BeckmannRoughnessToAlpha(float roughness) {
+  const float x = logf(fmaxf(roughness, 1.0e-4f));
+  return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+static f2 beckmannAlphaXY(const float* m, f2 tc, const OrcScene* s) {
+  const float roughness = 0.5f - 0.5f * phongGlosiness(m, tc, s);   /* beckmannGlosiness: the phong offsets */
+  const f3 ac = sample2DExt(as_int(m[BECKMANN_ANISO_TEXMATRIXID]), tc, m, s);
+  const float anisoMult = 1.0f - clampf(m[BECKMANN_ANISOTROPY] * fmaxf(ac.x, fmaxf(ac.y, ac.z)), 0.0f, 1.0f);
+  f2 r; r.x = BeckmannRoughnessToAlpha(roughness * roughness); r.y = BeckmannRoughnessToAlpha(roughness * roughness * anisoMult * anisoMult);
+  return r;
+}
+static void BeckmanTangentSpace(const float* m, f2 alpha, f3 nz, f3 a_tan, f3 a_bitan, f2 tc, const OrcScene* s, f3* pNx, f3* pNy) {
+  if (fabsf(alpha.x - alpha.y) > 1e-5f) {
+    *pNx = a_bitan; *pNy = a_tan;
+    const f3 rc = sample2DExt(as_int(m[BECKMANN_ROT_TEXMATRIXID]), tc, m, s);
+    const float rotVal = clampf(m[BECKMANN_ANISO_ROT] * fmaxf(rc.x, fmaxf(rc.y, rc.z)), 0.0f, 1.0f);
+    const float rotAngle = rotVal * M_TWOPI_F;
+    const float cos_t = cosf(rotAngle), sin_t = sinf(rotAngle);
+    const f3 v = nz;   /* RotateAroundVector4x4 (cglobals.h:1122-1150) through mul3x3 (:297-304) */
+    const f3 r0 = v3((1.0f - cos_t) * v.x * v.x + cos_t, (1.0f - cos_t) * v.x * v.y - sin_t * v.z, (1.0f - cos_t) * v.x * v.z + sin_t * v.y);
+    const f3 r1 = v3((1.0f - cos_t) * v.y * v.x + sin_t * v.z, (1.0f - cos_t) * v.y * v.y + cos_t, (1.0f - cos_t) * v.y * v.z - sin_t * v.x);
+    const f3 r2 = v3((1.0f - cos_t) * v.x * v.z - sin_t * v.y, (1.0f - cos_t) * v.z * v.y + sin_t * v.x, (1.0f - cos_t) * v.z * v.z + cos_t);
+    const f3 px = *pNx, py = *pNy;
+    *pNx = v3(px.x * r0.x + px.y * r0.y + px.z * r0.z, px.x * r1.x + px.y * r1.y + px.z * r1.z, px.x * r2.x + px.y * r2.y + px.z * r2.z);
+    *pNy = v3(py.x * r0.x + py.y * r0.y + py.z * r0.z, py.x * r1.x + py.y * r1.y + py.z * r1.z, py.x * r2.x + py.y * r2.y + py.z * r2.z);
+  } else
+    CoordinateSystem(nz, pNx, pNy);
+  if ((matFlags(m) & MF_FLIP_TANGENT) != 0) { const f3 t = *pNx; *pNx = *pNy; *pNy = t; }
+}
+static float anisoEvalPDF(int TR, const float* m, f3 l, f3 v, f3 n, f3 a_tan, f3 a_bitan, f2 tc, const OrcScene* s) {
+  if (dot3(n, v) < 1e-6f || dot3(n, l) < 1e-6f) return 1.0f;
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  f3 nx, ny;
+  BeckmanTangentSpace(m, alpha, n, a_tan, a_bitan, tc, s, &nx, &ny);
+  const f3 wo = v3(-dot3(v, nx), -dot3(v, ny), -dot3(v, n));
+  const f3 wh = normalize3(add3(l, v));
+  return microfacetPdf(TR, wo, wh, alpha.x, alpha.y);
+}
+static f3 anisoEvalBxDF(int TR, const float* m, f3 l, f3 v, f3 n, f3 a_tan, f3 a_bitan, f2 tc, const OrcScene* s) {
+  if (dot3(n, v) < 1e-6f || dot3(n, l) < 1e-6f) return v3(0, 0, 0);
+  const f3 color = clamp3(mul3(sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s), matColor(m)), 0.0f, 1.0f);
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  f3 nx, ny;
+  BeckmanTangentSpace(m, alpha, n, a_tan, a_bitan, tc, s, &nx, &ny);
+  const f3 wo = v3(-dot3(v, nx), -dot3(v, ny), -dot3(v, n)), wi = v3(-dot3(l, nx), -dot3(l, ny), -dot3(l, n));
+  return scale3(color, microfacetBRDF_PBRT(TR, wo, wi, alpha.x, alpha.y));
+}
+static void AnisoSampleAndEvalBRDF(int TR, const float* m, float r1, float r2, f3 ray_dir, f3 a_normal, f2 tc, f3 a_tan, f3 a_bitan, const OrcScene* s, MatSample* out) {
+  const f3 color = clamp3(mul3(sample2DExt(as_int(m[MAT_TEXMATRIXID]), tc, m, s), matColor(m)), 0.0f, 1.0f);
+  const f2 alpha = beckmannAlphaXY(m, tc, s);
+  const float gloss = phongGlosiness(m, tc, s);
+  f3 nx, ny;
+  const f3 nz = a_normal;
+  BeckmanTangentSpace(m, alpha, nz, a_tan, a_bitan, tc, s, &nx, &ny);
+  const f3 wo = v3(-dot3(ray_dir, nx), -dot3(ray_dir, ny), -dot3(ray_dir, nz));
+  const f3 wh = microfacetSampleWH(TR, wo, r1, r2, alpha.x, alpha.y);
+  const f3 wi = sub3(scale3(wh, 2.0f * dot3(wo, wh)), wo);
+  const f3 newDir = normalize3(add3(add3(scale3(nx, wi.x), scale3(ny, wi.y)), scale3(nz, wi.z)));
+  const f3 v = scale3(ray_dir, -1.0f), l = newDir;
+  if (dot3(a_normal, v) < 1e-6f || dot3(a_normal, l) < 1e-6f) { out->color = v3(0, 0, 0); out->pdf = 1.0f; }
+  else { out->color = scale3(color, microfacetBRDF_PBRT(TR, wo, wi, alpha.x, alpha.y)); out->pdf = microfacetPdf(TR, wo, wh, alpha.x, alpha.y); }
+  out->direction = newDir;
+  out->flags = (gloss >= 0.99f) ? RAY_EVENT_S : RAY_EVENT_G;
+}
 /* ---- translucent (diffuse transmission), ref: cmaterial.h:1852-1909; colour and sampler at the lambert offsets */
 static float translucentEvalPDF(f3 l, f3 v, f3 n) {
   const float sign1 = dot3(l, n) > 0 ? 1.0f : -1.0f, sign2 = dot3(v, n) > 0 ? 1.0f : -1.0f;
@@ -1364,6 +1574,8 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_TRANSLUCENT: TranslucentSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
     case MT_BLINN: BlinnSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_BECKMANN: AnisoSampleAndEvalBRDF(0, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
+    case MT_TRGGX: AnisoSampleAndEvalBRDF(1, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */
     default: break;
   }
@@ -1446,6 +1658,14 @@ static BxDFResult materialLeafEval(const float* m, const ShadeContext* sc0, int 
       r.pdfFwd = blinnEvalPDF(m, sc->l, sc->v, sc->n, sc->tc, s);
       r.pdfRev = blinnEvalPDF(m, sc->v, sc->l, sc->n, sc->tc, s);
       break;
+    case MT_BECKMANN:
+    case MT_TRGGX: {
+      const int TR = (matType(m) == MT_TRGGX);
+      r.brdf = scale3(anisoEvalBxDF(TR, m, sc->l, sc->v, sc->n, sc->tg, sc->bn, sc->tc, s), cosMult);
+      r.pdfFwd = anisoEvalPDF(TR, m, sc->l, sc->v, sc->n, sc->tg, sc->bn, sc->tc, s);
+      r.pdfRev = anisoEvalPDF(TR, m, sc->v, sc->l, sc->n, sc->tg, sc->bn, sc->tc, s);
+      break;
+    }
     case MT_TRANSLUCENT:
       r.btdf = scale3(translucentEvalBxDF(m, sc->l, sc->v, sc->n, sc->tc, s), cosMult2);
       r.pdfFwd = translucentEvalPDF(sc->l, sc->v, sc->n);

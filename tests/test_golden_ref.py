@@ -91,7 +91,7 @@ def check_shade_point(out, ref, frac=0.002):
     assert valid.mean() > 0.3
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
@@ -145,7 +145,9 @@ def test_oracle_matches_reference_functions(name, built):
     # path, same ray counts, 0.7 % of the paths off by more than 2e-4, image mean within 1e-4
     # a normal map multiplies a path's sensitivity to its inputs by |dn/duv| at every bounce (measured on this scene's map: a 1e-7 change of the
     # primary direction changes the random-number count of 0.3 % of the paths, none without the map): same draws on > 99.5 %, 0.9 % off by > 2e-4
-    limit = 0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small") else 0.005
+    # BeckmannSample11 (cmatpbrt.h:219-295) inverts a CDF by ten Newton steps that stop at |value| < 1e-5: exp / log / pow of another libm move the
+    # root in the 5th digit, the sampled half vector with it -- same draws on every path, 0.7 % off by more than 2e-4 (0.04 % by more than 1 %), mean within 2e-5
+    limit = 0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small") else 0.005
     assert bad.mean() < limit, bad.mean()
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 
@@ -190,7 +192,7 @@ def test_oracle_matches_reference_bidirectional_blocks(name, built):
     check_bidir(run_bidir(make_oracle(b), g), g)
 
 
-MMLT_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_glass_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small"]
+MMLT_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_glass_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small"]
 
 
 def load_mmlt(name):
@@ -231,7 +233,7 @@ def test_oracle_matches_reference_mmlt_contribution_function(name, built):
     depth, xvec, want = load_mmlt(name)
     r = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(r["width"]), int(r["height"]), int(r["depth"]), int(r["dof"]))
-    check_mmlt_f(make_oracle(b).mmlt_f(depth, xvec), want, small=0.012 if name == "atrium_nmap_small" else 0.006)   # normal maps amplify last-bit differences per bounce
+    check_mmlt_f(make_oracle(b).mmlt_f(depth, xvec), want, small=0.012 if name in ("atrium_nmap_small", "atrium_aniso_small") else 0.006)   # normal maps amplify last-bit differences per bounce
 
 
 GBUFFER_SCENES = ["test_42", "atrium_small", "atrium_cutouts2_small", "atrium_transl_small"]

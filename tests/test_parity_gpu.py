@@ -44,6 +44,16 @@ def gpu_atrium_transl(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_aniso(built):
+    """the hall with anisotropic Beckmann and TRGGX lobes (tangent frame rotated / flipped, glossiness texture) in blends over lambert (cmaterial.h:1558-1846)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_aniso_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_nmap(built):
     """the hall with normal-mapped floor, walls and columns (lambert, textured lambert, lambert + glossy blends; BumpMapping, cmaterial.h:2208-2243)"""
     from hydracore_amd import HipCore
@@ -168,7 +178,7 @@ def test_eye_rays(fix, request):
     np.testing.assert_allclose(dr[:, :3], rdr[:, :3], atol=2e-6)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_closest_hit_bit_exact(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     pos4, dir4 = random_rays(65536, 21) if not fix.startswith("gpu_atrium") else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
@@ -222,7 +232,7 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
         core.set_option("trace_min_active", defaults[1])
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_persistent_counting_kernels_total_what_the_oracle_counts(fix, request):
     """k_trace_dyn<*, true> -- the kernels bench.py prices its roofline bytes with -- against the oracle's per-ray counters
     summed: rays, quads visited, instance quads entered, leaves visited, triangles tested; closest hit and the early-out
@@ -264,7 +274,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -305,14 +315,14 @@ def test_bidirectional_building_blocks(fix, name, request):
 
 
 @pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"),
-                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small")])
+                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small"), ("gpu_atrium_aniso", "atrium_aniso_small")])
 def test_mmlt_contribution_function(fix, name, request):
     """row f3: IntegratorMMLT::F in wavefront form (k_mmlt_* around the traversal kernels) against the oracle's restatement on the same
     primary-sample vectors, and against the reference's functions (tests/golden/ref_mmlt_<scene>.npz)"""
     from test_golden_ref import check_mmlt_f, load_mmlt
     core, b, orc = request.getfixturevalue(fix)
     depth, xvec, want = load_mmlt(name)
-    small = 0.012 if name == "atrium_nmap_small" else 0.006      # normal maps amplify last-bit differences at every bounce (tests/test_golden_ref.py)
+    small = 0.012 if name in ("atrium_nmap_small", "atrium_aniso_small") else 0.006      # normal maps amplify last-bit differences at every bounce (tests/test_golden_ref.py)
     got = core.stage_mmlt_f(depth, xvec)
     check_mmlt_f(got, want, small=small)
     ref = orc.mmlt_f(depth, xvec)
@@ -530,7 +540,7 @@ def test_mmlt_through_the_ihwlayer_adapter(built):
     assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -551,7 +561,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -655,7 +665,7 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""
@@ -677,7 +687,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
         for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
                             ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("scene_tables_in_lds", 1), ("srgb_table", 0)):
             core.set_option(name, value)
-            if name == "fused_bounce" and fix in ("gpu_atrium_nmap", "gpu_atrium_transl"):       # the split form has no tangent frame in its record and no translucent / Blinn lobes: refused, not rendered differently
+            if name == "fused_bounce" and fix in ("gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"):       # the split form has no tangent frame in its record and no translucent / Blinn lobes: refused, not rendered differently
                 with pytest.raises(RuntimeError):
                     render()
                 core.set_option(name, defaults[name])
@@ -726,7 +736,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
 
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
-              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small"}
+              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small"}
 
 
 @pytest.mark.parametrize("fix", list(FIXTURE_OF))
@@ -772,7 +782,7 @@ def test_hip_against_the_reference_fixtures_in_one_hop(fix, request):
     same_draws = (gens == rg).all(axis=1)
     assert same_draws.mean() > 0.995, same_draws.mean()
     bad = (np.abs(col[:, :3] - rc[:, :3]) > 2e-4 * np.maximum(np.abs(rc[:, :3]), 1.0)).any(axis=1)
-    assert bad.mean() < (0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small") else 0.005), bad.mean()   # see tests/test_golden_ref.py for the looser scenes
+    assert bad.mean() < (0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small") else 0.005), bad.mean()   # see tests/test_golden_ref.py for the looser scenes
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 
 
@@ -950,13 +960,13 @@ def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
 
 
 def test_materials_the_layer_does_not_shade_are_refused(gpu224):
-    """a Beckmann reflection node (class 13) or a normal-mapped node would come out black / flat from the device's leaf
-    dispatch: the layer refuses to render instead"""
+    """a shadow-matte node (class 6) or a node whose normal map is not in the aux texture table would come out black / flat from the
+    device's leaf dispatch: the layer refuses to render instead"""
     from hydracore_amd import HipCore, HydraError
     _, b, _ = gpu224
     g = b["globals"]
     root = g[g[219] + 1] * 4                                          # material 1 = blend(phong, lambert): its phong child
-    for word, value, what in ((0, 13, "BxDF class 13"), (83, 1, "normal map")):
+    for word, value, what in ((0, 6, "BxDF class 6"), (83, 1, "normal map")):
         bad = dict(b)
         m = b["materials"].copy().view(np.int32)
         m[root + 192 + word] = value

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -2 $OUT/gpu_tests.log
 timeout -k 10 600 python bench.py --pmc-out $OUT/pmc_live > $OUT/bench_256spp.json.log 2>&1; tail -1 $OUT/bench_256spp.json.log | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 2 --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof_2x64spp.log 2>&1; tail -1 $OUT/bench_under_rocprof_2x64spp.log | cut -c1-160
-for sc in atrium250k atrium250k_sky atrium250k_glass tests/golden/scenes/test_42; do
+for sc in atrium250k atrium250k_sky atrium250k_glass atrium250k_nmap atrium250k_cutouts tests/golden/scenes/test_42; do
   n=$(basename $sc)
   timeout -k 10 600 python bench.py --no-cpu-baseline --scene $sc --pmc-out $OUT/pmc_live_$n > $OUT/bench_${n}_256spp.json.log 2>&1; tail -1 $OUT/bench_${n}_256spp.json.log | cut -c1-200
 done
@@ -19,4 +19,7 @@ timeout -k 10 300 python tools/mmlt_bench.py > $OUT/mmlt_bench_test_42_1080p_1M_
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mmlt -- python3 tools/mmlt_bench.py --passes 8 > $OUT/mmlt_bench_under_rocprof.log 2>&1
 find $OUT/prof_mmlt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_mmlt_8_passes.csv
 rm -rf $OUT/prof_mmlt
+# row f4: IHWLayer::EvalGBuffer at 1080p
+timeout -k 10 200 python tools/gbuffer_bench.py > $OUT/gbuffer_bench_test_224_1080p.log 2>&1; tail -1 $OUT/gbuffer_bench_test_224_1080p.log | cut -c1-200
+timeout -k 10 200 python tools/gbuffer_bench.py --scene atrium250k > $OUT/gbuffer_bench_atrium250k_1080p.log 2>&1; tail -1 $OUT/gbuffer_bench_atrium250k_1080p.log | cut -c1-200
 ls $OUT

@@ -232,6 +232,9 @@ def main():
                     "Blinn/Torrance-Sparrow (cmaterial.h:1020-1168)")
     ap.add_argument("--normal-maps", action="store_true", help="materials 0, 1, 4, 5, 8 and 9 (floor, walls, columns: lambert, textured lambert and lambert + glossy blends) get "
                     "<displacement type='normal_bump'> with a generated 256x256 normal map (smooth round bumps), y inverted on two of them")
+    ap.add_argument("--aniso", action="store_true", help="the reflectivity lobe of material 1 becomes Beckmann (anisotropy 0.7, rotated by 0.15 turns, glossiness "
+                    "from texture 2), that of material 8 TRGGX (anisotropy 0.5, flipped axes), material 9 a Fresnel blend of an isotropic Beckmann lobe "
+                    "over diffuse (cmaterial.h:1558-1846, cmatpbrt.h:105-540)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
@@ -312,6 +315,19 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    if args.aniso:
+        for i, line in enumerate(xml):
+            if line.startswith('  <material id="1" '):
+                xml[i] = ('  <material id="1" name="m1" type="hydra_material"><diffuse brdf_type="lambert"><color val="%.4f %.4f %.4f" /></diffuse>'
+                          '<reflectivity brdf_type="beckmann"><color val="0.35 0.33 0.3" /><glossiness val="0.75"><texture id="2" type="texref" /></glossiness>'
+                          '<anisotropy val="0.7" rot="0.15" flip_axis="0" /></reflectivity></material>' % tuple(cols[1]))
+            if line.startswith('  <material id="8" '):
+                xml[i] = ('  <material id="8" name="m8" type="hydra_material"><diffuse brdf_type="lambert"><color val="%.4f %.4f %.4f" /></diffuse>'
+                          '<reflectivity brdf_type="trggx"><color val="0.4 0.4 0.4" /><glossiness val="0.8" />'
+                          '<anisotropy val="0.5" rot="0.0" flip_axis="1" /></reflectivity></material>' % tuple(cols[8]))
+            if line.startswith('  <material id="9" '):
+                xml[i] = ('  <material id="9" name="m9" type="hydra_material"><diffuse brdf_type="lambert"><color val="%.4f %.4f %.4f" /></diffuse>'
+                          '<reflectivity brdf_type="beckmann"><color val="0.8 0.8 0.8" /><glossiness val="0.6" /><fresnel val="1" /><fresnel_ior val="2.0" /></reflectivity></material>' % tuple(cols[9]))
     if args.translucent:
         for i, line in enumerate(xml):
             if line.startswith('  <material id="6" '):
