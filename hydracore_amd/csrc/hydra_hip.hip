@@ -1626,6 +1626,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           if (f == 0) HK_LAUNCH_BOUNCE(0);
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
+          else if ((f & ~(HK_FEAT_CLASSIC | HK_FEAT_NMAP)) == 0 && (f & HK_FEAT_NMAP)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC | HK_FEAT_NMAP);   // normal maps over the classic set: without the rarer lobes
           else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
           else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
           else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
