@@ -686,19 +686,34 @@ HK_DEV void mmltMutate(const MmltChains& c, int i) {   // xCur -> xNew
   if (selector < plarge) {
     for (int j = 0; j < size; j++) c.xNew[size_t(j) * n + i] = rndFloat1_Pseudo(g);
   } else {
-    for (int j = 0; j < size; j++) c.xNew[size_t(j) * n + i] = c.xCur[size_t(j) * n + i];
+    // every dimension is read from xCur and written to xNew once; the generator is drawn from in the reference's order: light head 4..9, light
+    // bounces, lens 0..3, camera bounces (MutatePrimarySpace, CPUExp_Integrators_MMLT.cpp:540-600).  Dimensions 10 and 11 (light choice, split) only move in a large step
     const int currSplit = mapRndFloatToInt(c.xCur[size_t(11) * n + i], 0, d);
     const int camBegin = mmltStride(currSplit);   // camOffsetInRandArrayMMLT
     const bool lightPart = (plarge < selector && selector <= plarge + plight + pmultiChain);
     const bool cameraPart = !(plarge < selector && selector <= plarge + plight);
-    if (lightPart) {
-      for (int j = 4; j < 10; j++) c.xNew[size_t(j) * n + i] = MutateKelemen(c.xNew[size_t(j) * n + i], rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
-      for (int j = HK_MMLT_HEAD; j < camBegin; j++) c.xNew[size_t(j) * n + i] = MutateKelemen(c.xNew[size_t(j) * n + i], rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
+    for (int j = 4; j < 10; j++) {
+      float v = c.xCur[size_t(j) * n + i];
+      if (lightPart) v = MutateKelemen(v, rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
+      c.xNew[size_t(j) * n + i] = v;
     }
-    if (cameraPart) {
-      for (int j = 0; j < 4; j++) c.xNew[size_t(j) * n + i] = MutateKelemen(c.xNew[size_t(j) * n + i], rndFloat2_Pseudo(g), j < 2 ? HK_MUTATE_COEFF_SCREEN * 1.0f : HK_MUTATE_COEFF_BSDF, 1024.0f);
-      for (int j = camBegin; j < size; j++) c.xNew[size_t(j) * n + i] = MutateKelemen(c.xNew[size_t(j) * n + i], rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
+    for (int j = HK_MMLT_HEAD; j < camBegin; j++) {
+      float v = c.xCur[size_t(j) * n + i];
+      if (lightPart) v = MutateKelemen(v, rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
+      c.xNew[size_t(j) * n + i] = v;
     }
+    for (int j = 0; j < 4; j++) {
+      float v = c.xCur[size_t(j) * n + i];
+      if (cameraPart) v = MutateKelemen(v, rndFloat2_Pseudo(g), j < 2 ? HK_MUTATE_COEFF_SCREEN * 1.0f : HK_MUTATE_COEFF_BSDF, 1024.0f);
+      c.xNew[size_t(j) * n + i] = v;
+    }
+    for (int j = camBegin; j < size; j++) {
+      float v = c.xCur[size_t(j) * n + i];
+      if (cameraPart) v = MutateKelemen(v, rndFloat2_Pseudo(g), HK_MUTATE_COEFF_BSDF, 1024.0f);
+      c.xNew[size_t(j) * n + i] = v;
+    }
+    c.xNew[size_t(10) * n + i] = c.xCur[size_t(10) * n + i];
+    c.xNew[size_t(11) * n + i] = c.xCur[size_t(11) * n + i];
   }
   mchSetGen(c, CH_GEN, i, g);
 }

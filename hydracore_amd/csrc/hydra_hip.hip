@@ -934,7 +934,13 @@ __global__ void __launch_bounds__(256) k_mmlt_begin(SceneDev s, MmltView v, int 
   const int dl = seg * cap + wave_compact_index(la, counter);
   if (la) { out.pos[dl] = lpos; out.dir[dl] = ldir; out.owner[dl] = i * 2 + 1; }
 }
-__global__ void __launch_bounds__(256, 3) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
+#ifndef HK_MMLT_STEP_W
+#define HK_MMLT_STEP_W 3   /* register budget of the MMLT stage kernels in waves per SIMD */
+#endif
+#ifndef HK_MMLT_CONN_W
+#define HK_MMLT_CONN_W 2   /* k_mmlt_connect_end: 256 registers and no spills beat 168 with 69 spilled dwords (533-552 -> 608 M mutations/s, profiles/r02/mmlt_register_budget.log) */
+#endif
+__global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
   const SegIter it = segq_iter(q);
   uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
   for (int idx = it.first; idx - int(__lane_id()) < it.count; idx += it.step) {   // whole waves iterate together: the compaction is a wave ballot
@@ -956,7 +962,7 @@ __global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.n) mmltConnectBegin(s, v, i);
 }
-__global__ void __launch_bounds__(256, 3) k_mmlt_connect_end(SceneDev s, MmltView v) {
+__global__ void __launch_bounds__(256, HK_MMLT_CONN_W) k_mmlt_connect_end(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.n) mmltConnectEnd(s, v, i);
 }
