@@ -1203,6 +1203,9 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, hitNorm, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
     case HMT_TRANSLUCENT: if (F & HK_FEAT_TRANSLUCENT) TranslucentSampleAndEvalBRDF(node, rands[0], rands[1], hitNorm, sh.texCoord, s, out); break;
     case HMT_BLINN: if (F & HK_FEAT_BLINN) BlinnSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
+    case HMT_SHADOW_MATTE:   // ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942, with the shadow value the CPU integrator hands in: (0, 0, 0) (PT_Loop.cpp:240)
+      out.direction = rayDir; out.pdf = 1.0f; out.color = mk3(0, 0, 0) * (1.0f / fmaxf(fabsf(dot(rayDir, hitNorm)), 1e-5f)); out.flags = HRE_S | HRE_T;
+      break;
     case HMT_BECKMANN: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<false>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
     case HMT_TRGGX: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<true>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
     default: break;

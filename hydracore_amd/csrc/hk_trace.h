@@ -280,6 +280,9 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       // reference's IsValidNode term achieves -- 12 VALU instructions less per quad in a loop that is VALU-issue bound
       const bool v0 = true, v1 = true, v2 = true, v3 = true;
 #endif
+#ifdef HK_EXP_SETPRIO   /* timing experiment: the wave that has its quad runs its box tests ahead of the others */
+      __builtin_amdgcn_s_setprio(HK_EXP_SETPRIO);
+#endif
       const float2 t0 = RayBox(t.pos, t.inv, n0a, n0b), t1 = RayBox(t.pos, t.inv, n1a, n1b);
       const float2 t2 = RayBox(t.pos, t.inv, n2a, n2b), t3 = RayBox(t.pos, t.inv, n3a, n3b);
       float k0 = ((t0.x <= t0.y) && (t0.y >= t_rayMin) && (t0.x <= t.hit.t) && v0) ? t0.x : HK_MAXFLOAT;
@@ -307,6 +310,9 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
       else if (t.top >= 0) { t.top--; t.left = stack.get(t.top); }
       t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);
       t.left = t.left & 0x7fffffff;
+#ifdef HK_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (haveInst && t.top < t.instTop && t.instDeep == 1) {
         t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;   // = SafeInverse(t.odir), same bits (ctrace.h:1000-1006)
       }

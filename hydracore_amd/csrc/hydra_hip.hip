@@ -1293,10 +1293,10 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (type == HMT_BLINN) feat |= HK_FEAT_BLINN;
       if (type == HMT_BECKMANN || type == HMT_TRGGX) feat |= HK_FEAT_ANISO;
       const bool known = (type == HMT_PHONG || type == HMT_MIRROR || type == HMT_THIN_GLASS || type == HMT_GLASS || type == HMT_LAMBERT ||
-                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX || type == HMT_TRANSLUCENT || type == HMT_BLINN || type == HMT_BECKMANN || type == HMT_TRGGX);
+                          type == HMT_OREN_NAYAR || type == HMT_EMISSIVE || type == HMT_GGX || type == HMT_TRANSLUCENT || type == HMT_BLINN || type == HMT_BECKMANN || type == HMT_TRGGX || type == HMT_SHADOW_MATTE);
       if (!known)
         return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " has BxDF class " + std::to_string(type) +
-                                             "; the HIP layer implements phong, Blinn (Torrance-Sparrow), Beckmann, TRGGX, GGX, mirror, thin glass, glass, translucent, lambert, oren-nayar, blend mask and emissive only");
+                                             "; the HIP layer implements phong, Blinn (Torrance-Sparrow), Beckmann, TRGGX, GGX, mirror, thin glass, glass, translucent, shadow matte (the CPU integrator's: black), lambert, oren-nayar, blend mask and emissive only");
     }
   }
   c->matFeatures = feat;

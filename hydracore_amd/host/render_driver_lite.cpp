@@ -387,6 +387,16 @@ int32_t RenderDriverLite::AuxNormalMapFor(int32_t texId, int32_t a_matId) {
 // CreateFromHydraMaterialXmlNode + CreateMaterialFromXmlNode, PlainMaterialConverter.cpp:1502-1738
 bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const std::string mtype = a_node->attr("type");
+  if (mtype == "shadow_catcher") {   // ShadowMatteMaterial, PlainMaterialConverter.cpp:77-99, 1638-1660: a bare node of class SHADOW_MATTE; no bump, opacity or emission (:1710).
+    // The CPU integrator hands its sampler a zero shadow value (PT_Loop.cpp:240), so the surface passes rays on with zero throughput; the
+    // back-plate texture of <back> belongs to the OpenCL layer's environmentColorExtended and is not read here
+    MatPtr pMatte = new_node();
+    put_i(pMatte->plain, HM_TYPE, HMT_SHADOW_MATTE);
+    if (a_node->child("back") != nullptr) Unsupported("shadow_catcher <back> plate (material " + std::to_string(a_matId) + "): a feature of the OpenCL layer's environment function");
+    PlainMaterialVec mdata = flatten(pMatte);
+    m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
+    return true;
+  }
   if (mtype != "hydra_material") { Unsupported("material type '" + mtype + "' (id " + std::to_string(a_matId) + ")"); }
 
   const XmlNode* emission = a_node->child("emission");

@@ -40,7 +40,7 @@ enum { MAT_FLOATS = 192, MAT_TYPE = 0, MAT_FLAGS = 1, EMISSIVE_COLOR = 4, EMISSI
        PHONG_GLOSINESS = 16, PHONG_GLOSS_TEXID = 17, PHONG_GLOSS_TEXMATRIXID = 18,
        BLEND_FLAGS_OFFSET = 15, BLEND_MAT1 = 16, BLEND_MAT2 = 17, BLEND_FRESNEL_IOR = 18, BLEND_FALOFF_OFFSET = 19,
        BLEND_FALOFF_SIZE = 20, BLEND_TYPE = 21, BLEND_SIGMOID_EXP = 22, BLEND_FLAGS2 = 23 };
-enum { MT_PHONG = 0, MT_BLINN = 1, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_TRANSLUCENT = 5, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_BECKMANN = 13, MT_TRGGX = 14, MT_GGX = 15 };
+enum { MT_PHONG = 0, MT_BLINN = 1, MT_MIRROR = 2, MT_THIN_GLASS = 3, MT_GLASS = 4, MT_TRANSLUCENT = 5, MT_SHADOW_MATTE = 6, MT_LAMBERT = 7, MT_OREN_NAYAR = 8, MT_BLEND_MASK = 9, MT_EMISSIVE = 10, MT_BECKMANN = 13, MT_TRGGX = 14, MT_GGX = 15 };
 enum { ORENNAYAR_A = 16, ORENNAYAR_B = 17 };
 enum { THINGLASS_GLOSINESS = 16, THINGLASS_GLOSINESS_TEXMATRIXID = 18,                  /* cmaterial.h:472-491 */
        GLASS_IOR = 15, GLASS_GLOSINESS = 21, GLASS_GLOSINESS_TEXMATRIXID = 23,         /* cmaterial.h:566-590 */
@@ -1574,6 +1574,9 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_TRANSLUCENT: TranslucentSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
     case MT_BLINN: BlinnSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
+    case MT_SHADOW_MATTE:   /* ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942; a_shadow = (0,0,0) from kernel_NextBounce, PT_Loop.cpp:240 */
+      out->direction = ray_dir; out->pdf = 1.0f; out->color = scale3(v3(0, 0, 0), 1.0f / fmaxf(fabsf(dot3(ray_dir, n)), 1e-5f)); out->flags = RAY_EVENT_S | RAY_EVENT_T;
+      break;
     case MT_BECKMANN: AnisoSampleAndEvalBRDF(0, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
     case MT_TRGGX: AnisoSampleAndEvalBRDF(1, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */

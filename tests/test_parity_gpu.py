@@ -960,13 +960,13 @@ def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
 
 
 def test_materials_the_layer_does_not_shade_are_refused(gpu224):
-    """a shadow-matte node (class 6) or a node whose normal map is not in the aux texture table would come out black / flat from the
+    """a node of the reference's inactive SSS class (12) or a node whose normal map is not in the aux texture table would come out black / flat from the
     device's leaf dispatch: the layer refuses to render instead"""
     from hydracore_amd import HipCore, HydraError
     _, b, _ = gpu224
     g = b["globals"]
     root = g[g[219] + 1] * 4                                          # material 1 = blend(phong, lambert): its phong child
-    for word, value, what in ((0, 6, "BxDF class 6"), (83, 1, "normal map")):
+    for word, value, what in ((0, 12, "BxDF class 12"), (83, 1, "normal map")):
         bad = dict(b)
         m = b["materials"].copy().view(np.int32)
         m[root + 192 + word] = value

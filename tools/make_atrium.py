@@ -315,7 +315,10 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
-    if args.aniso:
+    if args.aniso:   # ... and the pots (material 3) become shadow catchers: black pass-through surfaces on the CPU integrator's path
+        for i, line in enumerate(xml):
+            if line.startswith('  <material id="3" '):
+                xml[i] = '  <material id="3" name="m3" type="shadow_catcher"></material>'
         for i, line in enumerate(xml):
             if line.startswith('  <material id="1" '):
                 xml[i] = ('  <material id="1" name="m1" type="hydra_material"><diffuse brdf_type="lambert"><color val="%.4f %.4f %.4f" /></diffuse>'
