@@ -97,8 +97,24 @@ HK_DEV void DirectLightSampleForward(const float* L, float4 rands, LightSampleFw
   out.norm = sampleDir;
 }
 // LightSampleForward, clight.h:1064-1110: the light types this layer accepts; the sky dome takes the default branch there too
+HK_DEV void SphereLightSampleForward(const float* L, float4 rands, LightSampleFwd& out) {   // clight.h:720-751
+  const f3 lcenter = lightPos(L);
+  const f3 samplePos = lcenter + (sphereLightUnitSample(rands.x, rands.y) * L[HL_SPHERE_RADIUS]);
+  const f3 lnorm = normalize(samplePos - lcenter);
+  const f3 sampleDir = MapSampleToCosineDistribution(rands.z, rands.w, lnorm, lnorm, 1.0f);
+  const float cosTheta = fmaxf(dot(sampleDir, lnorm), 0.0f);
+  out.isPoint = false;
+  out.pos = samplePos + lnorm * epsilonOfPos(samplePos);
+  out.dir = sampleDir;
+  out.color = lightColor(L) * cosTheta;
+  out.pdfA = 1.0f / L[HL_SURFACE_AREA];
+  out.pdfW = cosTheta * HK_INV_PI;
+  out.cosTheta = cosTheta;
+  out.norm = lnorm;
+}
 HK_DEV void LightSampleForward(const float* L, float4 rands, LightSampleFwd& out) {
   switch (as_int(L[HL_TYPE])) {
+    case HLT_SPHERE: SphereLightSampleForward(L, rands, out); break;
     case HLT_DIRECT: DirectLightSampleForward(L, rands, out); break;
     case HLT_POINT_SPOT: PointSpotSampleForward(L, rands, out); break;
     case HLT_POINT_OMNI: PointLightSampleForward(L, rands, out); break;

@@ -1565,6 +1565,39 @@ HK_DEV void DirectLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out.cosAtLight = 1.0f;
 }
 // LightSampleRev, clight.h:1561-1610: the light types this layer accepts (upload_globals rejects the others)
+// sphere lights, clight.h:1287-1332: uniform points on the sphere, area pdf turned into a solid-angle pdf at the shaded point
+HK_DEV float sphereLightEvalPDF(const float* L, f3 illum, f3 lpos, f3 lnorm) {
+  const float lradius = L[HL_SPHERE_RADIUS];
+  const f3 lcenter = lightPos(L);
+  const f3 dc = lcenter - illum;
+  if (dot(dc, dc) - lradius * lradius <= 0.0f) return 1.0f;
+  const float pdfA = 1.0f / L[HL_SURFACE_AREA];
+  const float dist = length(lpos - illum);
+  const f3 dirToV = normalize(lpos - illum);
+  return PdfAtoW(pdfA, dist, fabsf(dot(dirToV, lnorm)));
+}
+HK_DEV f3 sphereLightUnitSample(float r1, float r2) {   // the direction both samplers build (:1312-1316, :726-730)
+  const float theta = 2.0f * HK_PI * r1;
+  const float phi = acosf(1.0f - 2.0f * r2);
+  return mk3(sinf(phi) * cosf(theta), sinf(phi) * sinf(theta), cosf(phi));
+}
+HK_DEV void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample& out) {
+  const f3 lcenter = lightPos(L);
+  const f3 samplePos = lcenter + (sphereLightUnitSample(rands.x, rands.y) * L[HL_SPHERE_RADIUS]);
+  const f3 lnorm = normalize(samplePos - lcenter);
+  const f3 dirToV = normalize(samplePos - illum);
+  out.isPoint = false;
+  out.pos = samplePos;
+  out.color = lightColor(L);
+  out.pdf = sphereLightEvalPDF(L, illum, samplePos, lnorm);
+  out.maxDist = length(samplePos - illum);
+  out.cosAtLight = fabsf(dot(lnorm, dirToV));
+}
+// lightEvalPDF, clight.h:1613-1633, for the light a path has run into: the types that have a surface (area rectangles / disks and spheres)
+HK_DEV float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
+  if (as_int(L[HL_TYPE]) == HLT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  return areaDiffuseLightEvalPDF(L, rayDir, length(illum - lpos));
+}
 template <int F = HK_FEAT_ALL>
 HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
   const int type = as_int(L[HL_TYPE]);
@@ -1572,6 +1605,7 @@ HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_DIRECT) DirectLightSampleRev(L, rands, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_SPOT) SpotLightSampleRev(L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev(L, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_SPHERE) SphereLightSampleRev(L, rands, illum, out);
   else AreaLightSampleRev(L, rands, illum, out);
 }
 // environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)

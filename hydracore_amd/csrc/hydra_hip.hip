@@ -310,7 +310,7 @@ HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const
     const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
     if (dot(emission, emission) > 1e-3f) {
       if (pLightHit != nullptr) {
-        const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, length(ray_pos - surf.pos));
+        const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
         float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
         if (acc4.w != 0.0f) misWeight = 1.0f;
         currColor = emission * misWeight;
@@ -1807,15 +1807,15 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ) c->skyLightOk = false;
   }
   int lightFeat = (skyId != -1 && lightsNum > 0) ? HK_FEAT_SKY : 0;
-  for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sky-dome, point, spot and directional lights
+  for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sphere, sky-dome, point, spot and directional lights
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
     const int type = blob[at + HL_TYPE];
-    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT);
+    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE);
     if (!known)
-      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sky-dome, point, spot and directional lights only");
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, sky-dome, point, spot and directional lights only");
     if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
-    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT) lightFeat |= HK_FEAT_DELTA_LIGHTS;
+    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
     if (blob[at + HL_FLAGS] & HLF_HAS_IES)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
   }

@@ -748,6 +748,24 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   const std::string ltype = a_node->attr("type"), lshape = a_node->attr("shape"), distr = a_node->attr("distribution");
   if (ltype == "sky") return UpdateSkyLight(a_lightId, a_node);
   if (ltype == "directional" || distr == "directional" || lshape == "point") return UpdateDeltaLight(a_lightId, a_node);   // factory order of PlainLightConverter.cpp:1070-1105
+  if (ltype == "area" && lshape == "sphere") {   // SphereLight, PlainLightConverter.cpp:445-496, CreateSphereLightFromXmlNode :858-865
+    LightProto sp;
+    sp.plain.assign(HL_FLOATS, 0.0f);
+    float* d = sp.plain.data();
+    d[HL_PROB_MULT] = 1.0f;
+    const XmlNode* size = a_node->child("size");
+    const float radius = size ? size->attr_float("radius") : 0.0f;
+    const XmlNode* inten = a_node->child("intensity");
+    const float3 color = read_value3f(xchild(inten, "color")) * read_value1f(xchild(inten, "multiplier"));
+    d[HL_COLOR + 0] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+    d[HL_SPHERE_RADIUS] = radius;
+    d[HL_SURFACE_AREA] = 4.0f * 3.1415926535f * radius * radius;
+    put_i(d, HL_TYPE, HLT_SPHERE);
+    put_i(d, HL_FLAGS, 0);
+    sp.isSphere = true;
+    m_lights[a_lightId] = sp;
+    return true;
+  }
   if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
   if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
   if (xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1) Unsupported("sky portal");
@@ -975,6 +993,18 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
       continue;
     }
     if (it->second.isSky) {                       // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
+      put_i(d, HL_GROUP_ID, a_lightGroupId);
+      d[HL_PICK_PROB_REV] = 1.0f;
+      d[HL_PICK_PROB_FWD] = 1.0f;
+      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
+      continue;
+    }
+    if (it->second.isSphere) {                    // SphereLight::Transform, PlainLightConverter.cpp:466-491
+      const float3 sp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+      d[HL_POS] = sp0.x; d[HL_POS + 1] = sp0.y; d[HL_POS + 2] = sp0.z;
+      const float radius = d[HL_SPHERE_RADIUS] * length(mul_vec(M, normalize(float3(1, 1, 1))));
+      d[HL_SPHERE_RADIUS] = radius;
+      d[HL_SURFACE_AREA] = 4.0f * 3.1415926535f * radius * radius;
       put_i(d, HL_GROUP_ID, a_lightGroupId);
       d[HL_PICK_PROB_REV] = 1.0f;
       d[HL_PICK_PROB_FWD] = 1.0f;

@@ -56,7 +56,8 @@ enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, P
        PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
        AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107,
        PL_COLOR_TEX_MATRIX = 12, SKY_DOME_PDF_TABLE0 = 30, SKY_DOME_SAMPLER0 = 32, SKY_DOME_MATRIX0 = 36, SKY_DOME_INV_MATRIX0 = 56 };   /* clight.h:131-165 */
-enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4 };
+enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4, LT_SPHERE = 5 };
+enum { SPHERE_LIGHT_RADIUS = 14 };   /* clight.h:33 */
 enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADIUS1 = 14, DIRECT_LIGHT_RADIUS2 = 15,
        DIRECT_LIGHT_SSOFTNESS = 16, DIRECT_LIGHT_ALPHA_TAN = 17, DIRECT_LIGHT_ALPHA_COS = 18 };   /* clight.h:118-127 */
 enum { HRT_BSPHERE_RADIUS = 21 };
@@ -1995,8 +1996,42 @@ static void DirectLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out->cosAtLight = 1.0f;
 }
 /* ref: clight.h:1561-1610 LightSampleRev, the types the layer accepts */
+/* ref: clight.h:1287-1332 sphere lights */
+static float sphereLightEvalPDF(const float* L, f3 illum, f3 lpos, f3 lnorm) {
+  const float lradius = L[SPHERE_LIGHT_RADIUS];
+  const f3 lcenter = lightPos(L);
+  const f3 dc = sub3(lcenter, illum);
+  if (dot3(dc, dc) - lradius * lradius <= 0.0f) return 1.0f;
+  const float pdfA = 1.0f / L[PL_SURFACE_AREA];
+  const float dist = length3(sub3(lpos, illum));
+  const f3 dirToV = normalize3(sub3(lpos, illum));
+  return PdfAtoW_full(pdfA, dist, fabsf(dot3(dirToV, lnorm)));
+}
+static f3 sphereLightUnitSample(float r1, float r2) {
+  const float theta = 2.0f * M_PI_F * r1;
+  const float phi = acosf(1.0f - 2.0f * r2);
+  return v3(sinf(phi) * cosf(theta), sinf(phi) * sinf(theta), cosf(phi));
+}
+static void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  const f3 lcenter = lightPos(L);
+  const f3 samplePos = add3(lcenter, scale3(sphereLightUnitSample(rands.x, rands.y), L[SPHERE_LIGHT_RADIUS]));
+  const f3 lnorm = normalize3(sub3(samplePos, lcenter));
+  const f3 dirToV = normalize3(sub3(samplePos, illum));
+  out->isPoint = 0;
+  out->pos = samplePos;
+  out->color = lightColor(L);
+  out->pdf = sphereLightEvalPDF(L, illum, samplePos, lnorm);
+  out->maxDist = length3(sub3(samplePos, illum));
+  out->cosAtLight = fabsf(dot3(lnorm, dirToV));
+}
+/* ref: clight.h:1613-1633 lightEvalPDF for the lights that have a surface in this subset */
+static float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
+  if (as_int(L[PL_TYPE]) == LT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  return areaDiffuseLightEvalPDF(L, rayDir, length3(sub3(illum, lpos)));
+}
 static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
   switch (as_int(L[PL_TYPE])) {
+    case LT_SPHERE: SphereLightSampleRev(L, rands, illum, out); break;
     case LT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
     case LT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
     case LT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
@@ -2015,6 +2050,23 @@ static f3 UniformSampleSphere(float u1, float u2) {
   const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
   const float phi = 2.0f * ORC_PI * u2;
   return v3(r * cosf(phi), r * sinf(phi), z);
+}
+/* ref: clight.h:720-751 SphereLightSampleForward */
+static f3 sphereLightUnitSample(float r1, float r2);
+static void SphereLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+  const f3 lcenter = lightPos(L);
+  const f3 samplePos = add3(lcenter, scale3(sphereLightUnitSample(r[0], r[1]), L[SPHERE_LIGHT_RADIUS]));
+  const f3 lnorm = normalize3(sub3(samplePos, lcenter));
+  const f3 sampleDir = MapSampleToCosineDistribution(r[2], r[3], lnorm, lnorm, 1.0f);
+  const float cosTheta = fmaxf(dot3(sampleDir, lnorm), 0.0f);
+  out->isPoint = 0;
+  out->pos = add3(samplePos, scale3(lnorm, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(lightColor(L), cosTheta);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = cosTheta * INV_PI;
+  out->cosTheta = cosTheta;
+  out->norm = lnorm;
 }
 /* ref: clight.h:654-719 AreaLightSampleForward (no IES, no sky portal in the subset) */
 static void AreaLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
@@ -2109,6 +2161,7 @@ void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds,
     const float* L = lightAt(s, lightIds[i]);
     LightSampleFwd sam;
     switch (as_int(L[PL_TYPE])) {
+      case LT_SPHERE: SphereLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_DIRECT: DirectLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_SPOT: PointSpotSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_OMNI: PointLightSampleForward(L, rands4 + 4 * i, &sam); break;
@@ -2259,8 +2312,7 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
       const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, pLightHit, mat);
       if (dot3(emission, emission) > 1e-3f) {
         if (pLightHit != NULL) {
-          const float hitDist = length3(sub3(ray_pos, surf.pos));   /* lightEvalPDF, clight.h:1613-1633 */
-          const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pLightHit, ray_dir, hitDist);
+          const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
           float misWeight = misWeightHeuristic(misPrev.matSamplePdf, lgtPdf);
           if (misPrev.isSpecular) misWeight = 1.0f;
           currColor = scale3(emission, misWeight);
@@ -2449,6 +2501,7 @@ static int SelectRandomLightFwd(float r, const OrcScene* s, float* pickProb) {
 }
 static void LightSampleForwardAny(const float* L, const float r[4], LightSampleFwd* sam) {
   switch (as_int(L[PL_TYPE])) {
+    case LT_SPHERE: SphereLightSampleForward(L, r, sam); break;
     case LT_DIRECT: DirectLightSampleForward(L, r, sam); break;
     case LT_POINT_SPOT: PointSpotSampleForward(L, r, sam); break;
     case LT_POINT_OMNI: PointLightSampleForward(L, r, sam); break;

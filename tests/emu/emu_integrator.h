@@ -22,7 +22,7 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
       const f3 emission = emissionEval(s, ray_dir, surf, flags, pL, mat);
       if (dot(emission, emission) > 1e-3f) {
         if (pL != nullptr) {
-          const float lgtPdf = pL[HL_PICK_PROB_REV] * areaDiffuseLightEvalPDF(pL, ray_dir, length(ray_pos - surf.pos));
+          const float lgtPdf = pL[HL_PICK_PROB_REV] * lightEvalPDF(pL, ray_pos, ray_dir, surf.pos, surf.normal);
           float w = misWeightHeuristic(misPdf, lgtPdf);
           if (misSpec) w = 1.0f;
           currColor = emission * w;

@@ -13,7 +13,7 @@ EMU = os.path.join(ROOT, "tests", "emu")
 def test_device_code_is_clean_under_asan_ubsan_and_matches_oracle(built):
     so = os.path.join(EMU, "libemu_device_asan.so")
     srcs = [os.path.join(EMU, "emu_device.cpp"), os.path.join(EMU, "emu_integrator.h")] + \
-           [os.path.join(ROOT, "hydracore_amd", "csrc", f) for f in ("hk_common.h", "hk_trace.h", "hk_shading.h", "hk_bidir.h")]
+           [os.path.join(ROOT, "hydracore_amd", "csrc", f) for f in ("hk_common.h", "hk_trace.h", "hk_shading.h", "hk_bidir.h", "hk_gbuffer.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off",
                                "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I/opt/rocm/include",

@@ -132,6 +132,23 @@ def light_quad(hl, hw):
     return m
 
 
+def globe(radius, seg_t=24, seg_p=12, mat=12):
+    """uv sphere around the origin with outward normals: the visible surface of a sphere light"""
+    th = np.linspace(0, 2 * np.pi, seg_t + 1)
+    ph = np.linspace(0, np.pi, seg_p + 1)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    pos = radius * np.stack([np.sin(P) * np.cos(T), np.cos(P), np.sin(P) * np.sin(T)], -1).reshape(-1, 3)
+    uv = np.stack([T / (2 * np.pi), P / np.pi], -1).reshape(-1, 2)
+    tri = grid_indices(seg_t, seg_p)
+    area = np.linalg.norm(np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]]), axis=1)
+    tri = tri[area > 1e-12]                                  # the collapsed triangles at the poles
+    m = finish_mesh(pos, uv, tri, np.full(len(tri), mat))
+    m["norm"][:, :3] = pos / radius
+    if np.dot(np.cross(pos[tri[0, 1]] - pos[tri[0, 0]], pos[tri[0, 2]] - pos[tri[0, 0]]), pos[tri[0]].mean(axis=0)) < 0:
+        m["idx"] = tri[:, ::-1].astype(np.int32).ravel()     # counter-clockwise seen from outside
+    return m
+
+
 def plant(cards=6, height=1.6, width=0.9):
     """crossed vertical cards around the y axis, uv = the whole mask on every card, material 11"""
     pos, uv, tri = [], [], []
@@ -250,6 +267,10 @@ def main():
               ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky or args.delta_lights)), ("light", light_quad(2.0, 0.5))]
     if args.cutouts:
         meshes.append(("plant", plant()))
+    globe_mesh = None
+    if args.delta_lights:      # ... and a sphere light with its visible globe (clight.h:1287-1332)
+        globe_mesh = len(meshes)
+        meshes.append(("globe", globe(0.35)))
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -348,6 +369,8 @@ def main():
     if args.cutouts:   # leaves: textured lambert, the mask's alpha channel is the opacity
         xml.append('  <material id="11" name="leaves" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" /><texture id="%d" type="texref" /></diffuse>'
                    '<opacity smooth="0"><skip_shadow val="0" /><texture id="%d" type="texref" input_alpha="alpha" input_gamma="1" /></opacity></material>' % (mask_tex, mask_tex))
+    if args.delta_lights:
+        xml.append('  <material id="12" name="globe_mat" type="hydra_material" light_id="4" visible="1"><emission><color val="25 22 18" /></emission></material>')
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
@@ -359,7 +382,9 @@ def main():
                   '\n  <light id="2" name="spot" type="point" shape="point" distribution="spot" visible="1"><falloff_angle val="70" /><falloff_angle2 val="40" />'
                   '<intensity><color val="0.7 0.8 1" /><multiplier val="90.0" /></intensity></light>'
                   '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
-                  '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>' if args.delta_lights else '')
+                  '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>'
+                  '\n  <light id="4" name="globe" type="area" shape="sphere" distribution="uniform" visible="1" mat_id="12" mesh_id="%d"><size radius="0.35" />'
+                  '<intensity><color val="1 0.88 0.72" /><multiplier val="25.0" /></intensity></light>' % (globe_mesh or 0) if args.delta_lights else '')
                + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
@@ -408,6 +433,9 @@ def main():
         add(7, mat4(scale=2.2, yaw=np.pi / 2, t=(-9.0, 0.1, 2.5)))       # a big one in the camera's view
     light_m = mat4(t=(2.0, 9.6, 0.0))
     add(6, light_m, ' light_id="0" linst_id="0"')
+    globe_m = mat4(scale=1.4, t=(-6.0, 3.2, 2.0))
+    if args.delta_lights:
+        add(globe_mesh, globe_m, ' light_id="4" linst_id="4"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
     if args.sky:
@@ -416,6 +444,7 @@ def main():
         xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4(t=(-10.0, 5.0, 1.0)))
         xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % mat4(t=(6.0, 7.5, -2.0), rot_x=0.3))
         xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
+        xml.append('    <instance_light id="4" light_id="4" matrix="%s" lgroup_id="-1" />' % globe_m)
     xml += inst
     xml.append("  </scene>\n</scenes>")
     with open(os.path.join(out, "statex_00001.xml"), "w") as f:
