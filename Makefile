@@ -13,7 +13,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -share
 CXXFLAGS := -std=c++17 -O2 -Wall -Wextra -Wno-unused-parameter -fPIC
 HOSTSRC  := $(wildcard hydracore_amd/host/*.cpp)
 HOSTHDR  := $(wildcard hydracore_amd/host/*.h) $(wildcard include/*.h)
-HIPSRC   := hydracore_amd/csrc/hydra_hip.hip hydracore_amd/csrc/hydra_bvh.hip
+HIPSRC   := hydracore_amd/csrc/hydra_hip.hip hydracore_amd/csrc/hydra_bvh.hip hydracore_amd/csrc/hydra_img.hip
 HIPHDR   := $(wildcard hydracore_amd/csrc/*.h) $(wildcard include/*.h)
 
 all: $(LIBDIR)/libhydra_hip.so $(LIBDIR)/libhydra_host.so oracle/liboracle.so

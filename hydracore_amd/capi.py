@@ -52,7 +52,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image",
-    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
 ]
 
 _hip = None
@@ -136,6 +136,8 @@ def load_hip_library():
         "hydra_hip_eval_gbuffer": ([vp, vp, vp, vp, i32, vp], i32),
         "hydra_hip_bvh_build_mesh": ([i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_bvh_last_error": ([], C.c_char_p),
+        "hydra_hip_normal_map_from_displacement": ([i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, vp], i32),
+        "hydra_hip_image_last_error": ([], C.c_char_p),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -237,6 +239,17 @@ def bvh_build_mesh(vert4f, indices, leaf_max=2, device=0):
     if rc != 0:
         raise HydraError("bvh_build_mesh failed (%d): %s" % (rc, lib.hydra_hip_bvh_last_error().decode()))
     return nodes[:nn.value].copy(), order[:npr.value].copy(), ms.value
+
+
+def normal_map_from_displacement(rgba, bump_amt, inv_height, smooth_lvl, device=0):
+    """IHWLayer::NormalMapFromDisplacement on the device: uint8 [h, w, 4] height map -> (uint8 [h, w, 4] normal map, device ms)"""
+    lib = load_hip_library()
+    a = np.ascontiguousarray(rgba, np.uint8)
+    out, ms = np.zeros_like(a), C.c_float(0)
+    rc = lib.hydra_hip_normal_map_from_displacement(device, a.shape[1], a.shape[0], _ptr(a), float(bump_amt), int(bool(inv_height)), float(smooth_lvl), _ptr(out), C.byref(ms))
+    if rc != 0:
+        raise HydraError("normal_map_from_displacement failed (%d): %s" % (rc, lib.hydra_hip_image_last_error().decode()))
+    return out, ms.value
 
 
 class HipCore:

@@ -11,7 +11,7 @@ namespace hydra_host {
 
 class HipHWLayer : public SharedDataLayer {
 public:
-  HipHWLayer(int w, int h, int a_flags, int a_deviceId) : SharedDataLayer(w, h, a_flags), m_h(nullptr) {
+  HipHWLayer(int w, int h, int a_flags, int a_deviceId) : SharedDataLayer(w, h, a_flags), m_h(nullptr), m_deviceId(a_deviceId) {
     const int rc = hydra_hip_create(w, h, a_flags, a_deviceId, &m_h);
     if (rc != HYDRA_HIP_OK) RunTimeError(std::string("CreateHipImpl: ") + hydra_hip_last_error(nullptr));
     hydra_hip_device_name(m_h, m_devName, sizeof(m_devName));
@@ -154,6 +154,14 @@ public:
     m_sppContrib += spp;
   }
   float GetSPPContrib() const override { return m_sppContrib; }
+  // IHWLayer::NormalMapFromDisplacement (:197): the height map of a height_bump material -> its normal map, on the device
+  std::vector<uchar4> NormalMapFromDisplacement(int w, int h, const uchar4* a_data, float bumpAmt, bool invHeight, float smoothLvl) override {
+    std::vector<uchar4> res(size_t(w) * size_t(h));
+    const int rc = hydra_hip_normal_map_from_displacement(m_deviceId, w, h, reinterpret_cast<const uint8_t*>(a_data), bumpAmt, invHeight ? 1 : 0, smoothLvl,
+                                                          reinterpret_cast<uint8_t*>(res.data()), nullptr);
+    if (rc != HYDRA_HIP_OK) RunTimeError(std::string("HipHWLayer::NormalMapFromDisplacement: ") + hydra_hip_image_last_error());
+    return res;
+  }
   // GPUOCLLayer::EvalGBuffer (GPUOCLLayerOther.cpp:694-870): the hand-shake over Header()->gbufferIsEmpty under the image lock, the two
   // layers chosen by the image's depth (:725-741), instance ids mapped through a_instIdByInstId (:846-853); the records themselves come
   // from hydra_hip_eval_gbuffer (IntegratorCommon::gbufferEval, CPUExp_GBuffer.cpp:15-113)
@@ -184,6 +192,7 @@ public:
 
 private:
   hydra_hip_handle m_h;
+  int m_deviceId = 0;
   char m_devName[256] = {0};
   bool m_tablesUploaded = false;
   bool m_mmltRunning = false;

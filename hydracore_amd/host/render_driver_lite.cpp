@@ -363,6 +363,35 @@ bool RenderDriverLite::UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_
 
 // the aux copy of a normal map: one per texture id (the reference keys on texture id + bump parameters, which normal_bump does not have);
 // UpdateImageAux, RenderDriverRTE_AuxTextures.cpp:195-216; ids count up from 0 (AuxNormalTexPerMaterial, PlainMaterialConverter.cpp:1883-1902)
+// GetCachedAuxNormalMatId + GetAuxNormalMapFromDisaplacement for height maps (RenderDriverRTE_AuxTextures.cpp:46-160): the layer turns the 8-bit RGBA
+// height texture into a normal map (IHWLayer::NormalMapFromDisplacement), cached per (texture, amount, smoothing)
+int32_t RenderDriverLite::AuxNormalMapFromHeight(int32_t texId, int32_t a_matId, float bumpAmt, float smoothLvl) {
+  const std::string key = std::to_string(texId) + " " + std::to_string(bumpAmt) + " " + std::to_string(smoothLvl);
+  auto found = m_auxHeightMaps.find(key);
+  if (found != m_auxHeightMaps.end()) return found->second;
+  int32_t auxId = int32_t(HYDRA_INVALID_TEXTURE);
+  const std::vector<int32_t> table = m_pTexStorage->GetTable();
+  if (texId >= 0 && size_t(texId) < table.size() && table[size_t(texId)] >= 0) {
+    const int32_t* header = reinterpret_cast<const int32_t*>(m_pTexStorage->GetBegin()) + size_t(table[size_t(texId)]) * 4;
+    if (header[3] != 4) Unsupported("height map " + std::to_string(texId) + " is not an 8-bit RGBA texture (material " + std::to_string(a_matId) + ")");
+    else {
+      const std::vector<uchar4> normals = m_pHWLayer->NormalMapFromDisplacement(header[0], header[1], reinterpret_cast<const uchar4*>(header + 4), bumpAmt, true /* PLAIN_MATERIAL_INVERT_HEIGHT is set by then, PlainMaterialConverter.cpp:1372 */, smoothLvl);
+      if (normals.size() != size_t(header[0]) * size_t(header[1]))
+        Unsupported("height_bump (material " + std::to_string(a_matId) + "): this layer has no NormalMapFromDisplacement (a device is needed)");
+      else {
+        auxId = m_auxImageNumber++;
+        const size_t inBytes = normals.size() * 4, headerSize = 16, total = ((inBytes + 15) / 16) * 16 + headerSize;
+        const int32_t auxHeader[4] = {header[0], header[1], 4, 4};
+        m_pTexStorageAux->Update(auxId, nullptr, total);
+        m_pTexStorageAux->UpdatePartial(auxId, auxHeader, 0, 16);
+        m_pTexStorageAux->UpdatePartial(auxId, normals.data(), headerSize, inBytes);
+      }
+    }
+  }
+  m_auxHeightMaps[key] = auxId;
+  return auxId;
+}
+
 int32_t RenderDriverLite::AuxNormalMapFor(int32_t texId, int32_t a_matId) {
   auto found = m_auxNormalMaps.find(texId);
   if (found != m_auxNormalMaps.end()) return found->second;
@@ -411,7 +440,7 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const float3 colorSSS = read_value3f(xchild(sss, "color"));
   if (const XmlNode* displ = a_node->child("displacement")) {
     const std::string btype = displ->attr("type");
-    if (btype != "normal_bump") Unsupported("displacement type '" + btype + "' (material " + std::to_string(a_matId) + "): only normal_bump is built (height maps go through IHWLayer::NormalMapFromDisplacement, an OpenCL-layer function)");
+    if (btype != "normal_bump" && btype != "height_bump") Unsupported("displacement type '" + btype + "' (material " + std::to_string(a_matId) + "): normal_bump and height_bump are built");
   }
   m_matOpacity.erase(a_matId);
   if (const XmlNode* op = a_node->child("opacity")) {   // PlainMaterialConverter.cpp:1429-1445: alpha-tested in the traversal, not a BxDF
@@ -568,6 +597,22 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   }
   // RenderDriverRTE::ReadBumpAndOpacity, the normal-map half (PlainMaterialConverter.cpp:1340-1424, 1447-1455), <displacement type="normal_bump">
   if (const XmlNode* displ = a_node->child("displacement")) {
+    const XmlNode* hm = displ->child("height_map");
+    const XmlNode* hTex = hm ? hm->child("texture") : nullptr;
+    if (std::string(displ->attr("type")) == "height_bump" && hTex != nullptr) {   // PlainMaterialConverter.cpp:1357-1378, BumpAmtAndLvl RenderDriverRTE_AuxTextures.cpp:11-31
+      Sampler sm = sampler_from_texref(hTex);
+      sm.gamma = 1.0f;
+      const float bumpAmt = hm->has_attr("amount") ? 0.5f * hm->attr_float("amount") : 0.0f;
+      const float smoothLvl = hm->has_attr("smooth") ? 10.0f * hm->attr_float("smooth") : (hm->has_attr("smooth_lvl") ? 10.0f * hm->attr_float("smooth_lvl") : 0.0f);
+      const int32_t auxId = AuxNormalMapFromHeight(sm.texId, a_matId, bumpAmt, smoothLvl);
+      int flags = HMF_INVERT_HEIGHT;
+      const XmlNode* invert = hm->child("invert");
+      if (invert && invert->attr_int("x") == 1) flags |= HMF_INVERT_NMAP_X;
+      if (invert && invert->attr_int("y") == 1) flags |= HMF_INVERT_NMAP_Y;
+      if (invert && invert->attr_int("swap_xy") == 1) flags |= HMF_INVERT_SWAP_NMAP_XY;
+      put_i(pResult->plain, HM_FLAGS, get_i(pResult->plain, HM_FLAGS) | flags);
+      push_down_normal_map(pResult.get(), auxId, HM_NORMAL_SAMPLER / 4, flags, sm);
+    }
     const XmlNode* nm = displ->child("normal_map");
     const XmlNode* texNode = nm ? nm->child("texture") : nullptr;
     if (std::string(displ->attr("type")) == "normal_bump" && texNode != nullptr) {

@@ -43,6 +43,7 @@ public:
   void AllocAll(int imgNum, int matNum, int lightNum, int meshNum);
   bool UpdateImage(int32_t a_texId, int32_t w, int32_t h, int32_t bpp, int32_t chan, const void* a_data);
   bool UpdateMaterial(int32_t a_matId, const XmlNode* a_materialNode);
+  int32_t AuxNormalMapFromHeight(int32_t a_texId, int32_t a_matId, float bumpAmt, float smoothLvl);   // ... of a height map, through IHWLayer::NormalMapFromDisplacement (GetAuxNormalMapFromDisaplacement, :77-160)
   int32_t AuxNormalMapFor(int32_t a_texId, int32_t a_matId);   // aux-arena copy of a normal map (GetCachedAuxNormalMatId, RenderDriverRTE_AuxTextures.cpp:46-77)
   bool UpdateLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateSkyLight(int32_t a_lightId, const XmlNode* a_lightNode);
@@ -83,6 +84,7 @@ private:
 
   struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false; int kind = 0; };   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
   std::map<int, LightProto> m_lights;
+  std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
 
   std::vector<float4x4> m_instMatricesInv;

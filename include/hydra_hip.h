@@ -223,6 +223,13 @@ typedef struct HydraBuildNode { float boxMin[3]; int32_t first; float boxMax[3];
 int hydra_hip_bvh_build_mesh(int device, const float* vert4f, int num_vert, const int32_t* indices, int num_indices, int leaf_max,
                              HydraBuildNode* nodes_out, int32_t* node_count_out, int32_t* prim_order_out, int32_t* prim_count_out, float* build_ms_out);
 const char* hydra_hip_bvh_last_error(void);
+/* IHWLayer::NormalMapFromDisplacement (hydra_drv/IHWLayer.h:197; host form CPUSharedData::NormalMapFromDisplacement + BilateralFilter,
+ * CPUBilateralFilter2D.cpp:15-246; GPUOCLLayer's kernels GPUOCLData.cpp:549-640): the RGBA8 height map of a <displacement type="height_bump"> becomes
+ * the RGBA8 normal map the shading's BumpMapping reads (xy = 0.5 + 0.5 n, z = n.z, w = height).  bump_amt = 0.5 x the XML amount, smooth_lvl = 10 x the
+ * XML smooth level (RenderDriverRTE_AuxTextures.cpp:11-31); smooth_lvl >= 1 adds the 11 x 11 bilateral filter.  rgba_in / rgba_out: w*h*4 bytes in
+ * host memory.  No layer handle: the driver calls it while it packs materials.  device_ms_out (may be null): device time of the kernels. */
+int hydra_hip_normal_map_from_displacement(int device, int w, int h, const uint8_t* rgba_in, float bump_amt, int inv_height, float smooth_lvl, uint8_t* rgba_out, float* device_ms_out);
+const char* hydra_hip_image_last_error(void);
 /* ---- IntegratorMMLT (row f3; hydra_drv/CPUExp_Integrators_MMLT.cpp): multiplexed MLT over the simplified bidirectional sampler --------------
  * The reference runs 8 chains (one per OpenMP thread, :583-585) of width*height mutations per pass; here every chain is a GPU thread and a
  * pass advances all of them together: mutate (MutatePrimarySpace :93-144), F (:146-315) through the traversal kernels, accept / reject with

@@ -3070,6 +3070,101 @@ void orc_gbuffer(const OrcScene* s, int width, int height, int x0, int y0, int n
   }
 }
 
+/* ------------------------------------------------------------------------------------------------ IHWLayer::NormalMapFromDisplacement */
+/* CPUSharedData::NormalMapFromDisplacement + BilateralFilter, CPUBilateralFilter2D.cpp:15-246.  parity unpinned: the function lives in host C++ that
+ * needs HydraAPI (absent), so no fixture from the reference itself exists; float3 normalize / float4 lerp / dot3f come from HydraAPI's LiteMath and are
+ * taken as u / length(u), u + t (v - u) and x^2 + y^2 + z^2. */
+static inline int clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+static void BilateralFilter(const float* in4, float* out4, int w, int h, int a_windowRadius, float a_smoothLvl) {
+  const float g_NoiseLevel = 1.0f / (a_smoothLvl * a_smoothLvl), g_GaussianSigma = 1.0f / 50.0f, g_WeightThreshold = 0.03f, g_LerpCoefficeint = 0.80f, g_CounterThreshold = 0.05f;
+  const float windowArea = (2.0f * (float)a_windowRadius + 1.0f) * (2.0f * (float)a_windowRadius + 1.0f);
+#pragma omp parallel for
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const int minX = clampi(x - a_windowRadius, 0, w - 1), maxX = clampi(x + a_windowRadius, 0, w - 1);
+      const int minY = clampi(y - a_windowRadius, 0, h - 1), maxY = clampi(y + a_windowRadius, 0, h - 1);
+      const float* c0 = in4 + 4 * ((size_t)y * w + x);
+      int counterPass = 0;
+      float fSum = 0.0f, result[4] = {0, 0, 0, 0};
+      for (int y1 = minY; y1 <= maxY; y1++)
+        for (int x1 = minX; x1 <= maxX; x1++) {
+          const float* c1 = in4 + 4 * ((size_t)y1 * w + x1);
+          const float dx = c1[0] - c0[0], dy = c1[1] - c0[1], dz = c1[2] - c0[2];
+          const int i = x1 - x, j = y1 - y;
+          const float w1 = dx * dx + dy * dy + dz * dz;
+          const float w2 = expf(-(w1 * g_NoiseLevel + (float)(i * i + j * j) * g_GaussianSigma));
+          if (w2 > g_WeightThreshold) counterPass++;
+          fSum += w2;
+          for (int k = 0; k < 4; k++) result[k] += c1[k] * w2;
+        }
+      for (int k = 0; k < 4; k++) result[k] = result[k] * (1.0f / fSum);
+      const float lerpQ = ((float)counterPass > (g_CounterThreshold * windowArea)) ? 1.0f - g_LerpCoefficeint : g_LerpCoefficeint;
+      for (int k = 0; k < 4; k++) out4[4 * ((size_t)y * w + x) + k] = result[k] + lerpQ * (c0[k] - result[k]);
+    }
+}
+void orc_normal_map_from_displacement(int w, int h, const uint8_t* a_data, float bumpAmt, int invHeight, float smoothLvl, uint8_t* out) {
+  float* heightDataf = (float*)malloc(sizeof(float) * (size_t)w * h);
+  float* normals = (float*)malloc(sizeof(float) * 4 * (size_t)w * h);
+  for (size_t i = 0; i < (size_t)w * h; i++)
+    heightDataf[i] = 255.0f - fmaxf((float)a_data[4 * i], fmaxf((float)a_data[4 * i + 1], (float)a_data[4 * i + 2]));
+  const float kScale = 2000.0f / fminf((float)w, (float)h);
+#pragma omp parallel for
+  for (int y = 0; y < h; y++) {
+    const int offsetY = y * w;
+    int offsetYPlusOne = (y + 1) * w, offsetYMinusOne = (y - 1) * w;
+    if (y + 1 >= h) offsetYPlusOne = 0;
+    if (y - 1 <= 0) offsetYMinusOne = (h - 1) * w;
+    for (int x = 0; x < w; x++) {
+      int offsetXPlusOne = x + 1, offsetXMinusOne = x - 1;
+      if (x + 1 >= w) offsetXPlusOne = 0;
+      if (x - 1 <= 0) offsetXMinusOne = w - 1;
+      float diff[8];
+      const float c = heightDataf[offsetY + x];
+      diff[0] = c - heightDataf[offsetYMinusOne + offsetXMinusOne];
+      diff[1] = c - heightDataf[offsetYMinusOne + x];
+      diff[2] = c - heightDataf[offsetYMinusOne + offsetXPlusOne];
+      diff[3] = c - heightDataf[offsetY + offsetXMinusOne];
+      diff[4] = c - heightDataf[offsetY + offsetXPlusOne];
+      diff[5] = c - heightDataf[offsetYPlusOne + offsetXMinusOne];
+      diff[6] = c - heightDataf[offsetYPlusOne + x];
+      diff[7] = c - heightDataf[offsetYPlusOne + offsetXPlusOne];
+      if (!invHeight)
+        for (int i = 0; i < 8; i++) diff[i] *= -1.0f;
+      for (int i = 0; i < 8; i++) diff[i] *= (bumpAmt * bumpAmt);
+      const float scale = kScale;
+      const float vx[8] = {-diff[0], 0.f, diff[2], -diff[3], diff[4], -diff[5], 0.f, diff[7]};
+      const float vy[8] = {-diff[0], -diff[1], -diff[2], 0.f, 0.f, diff[5], diff[6], diff[7]};
+      f3 res = v3(0, 0, 0);
+      for (int i = 0; i < 8; i++) { res.x += vx[i]; res.y += vy[i]; res.z += scale; }
+      res = scale3(res, 1.0f / 8.0f);
+      res.x *= -1.0f;
+      float len = sqrtf(res.x * res.x + res.y * res.y + res.z * res.z);
+      res.x /= len; res.y /= len; res.z /= len;
+      if (res.z < 0.65f) {
+        res.z = 0.65f;
+        len = sqrtf(res.x * res.x + res.y * res.y + res.z * res.z);
+        res.x /= len; res.y /= len; res.z /= len;
+      }
+      float* o = normals + 4 * ((size_t)offsetY + x);
+      o[0] = res.x; o[1] = res.y; o[2] = res.z; o[3] = (255.0f - c) / 255.0f;
+    }
+  }
+  if (smoothLvl >= 1.0f) {
+    const int radius = 5;
+    if (smoothLvl > 10.0f) smoothLvl = 10.0f;
+    float* image2 = (float*)malloc(sizeof(float) * 4 * (size_t)w * h);
+    BilateralFilter(normals, image2, w, h, radius, smoothLvl * 0.1f);
+    free(normals);
+    normals = image2;
+  }
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    float cr[4] = {0.5f * normals[4 * i] + 0.5f, 0.5f * normals[4 * i + 1] + 0.5f, normals[4 * i + 2], normals[4 * i + 3]};
+    for (int k = 0; k < 4; k++) out[4 * i + k] = (uint8_t)fminf(fmaxf(cr[k] * 255.0f, 0.0f), 255.0f);
+  }
+  free(heightDataf);
+  free(normals);
+}
+
 void orc_init_generators(int w, int h, int seed, uint32_t* gens) {
   for (int i = 0; i < w * h; i++) orc_random_init(seed + i, gens + 2 * (size_t)i);
 }

@@ -92,6 +92,8 @@ void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* dept
 void orc_sbdpt_pass(const OrcScene* s, int n, uint32_t* gens4, int maxDepth, int w, float* image4);
 /* IntegratorCommon::gbufferEval (CPUExp_GBuffer.cpp:15-113) for the pixel window [x0, x0+nx) x [y0, y0+ny): packGBuffer1 / packGBuffer2 per pixel (+ the unpacked record) */
 void orc_gbuffer(const OrcScene* s, int width, int height, int x0, int y0, int nx, int ny, float* data1, float* data2, float* raw14);
+/* CPUSharedData::NormalMapFromDisplacement (CPUBilateralFilter2D.cpp:101-246): RGBA8 height map -> RGBA8 normal map; parity unpinned (see the .c file) */
+void orc_normal_map_from_displacement(int w, int h, const uint8_t* rgba_in, float bumpAmt, int invHeight, float smoothLvl, uint8_t* rgba_out);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -55,6 +55,7 @@ def load():
     lib.orc_mmlt_f.argtypes = [sp, i32, vp, vp, i32, vp]
     lib.orc_sbdpt_pass.argtypes = [sp, i32, vp, i32, i32, vp]
     lib.orc_gbuffer.argtypes = [sp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.orc_normal_map_from_displacement.argtypes = [i32, i32, vp, C.c_float, i32, C.c_float, vp]
     lib.orc_mmlt_run.argtypes = [sp, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.orc_init_generators.argtypes = [i32, i32, i32, vp]
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
@@ -279,3 +280,13 @@ class Oracle:
 
     def max_threads(self):
         return self.lib.orc_max_threads()
+
+
+def normal_map_from_displacement(rgba, bump_amt, inv_height, smooth_lvl):
+    """the oracle's CPUSharedData::NormalMapFromDisplacement: uint8 [h, w, 4] -> uint8 [h, w, 4]"""
+    lib = load()
+    a = np.ascontiguousarray(rgba, np.uint8)
+    out = np.zeros_like(a)
+    lib.orc_normal_map_from_displacement(a.shape[1], a.shape[0], _p(a), float(bump_amt), int(bool(inv_height)), float(smooth_lvl), _p(out))
+    return out
+

@@ -194,6 +194,17 @@ def tile_normal_map(n=256, periods=2, amp=0.04):
     return img
 
 
+def tile_height_map(n=256, periods=3):
+    """grey height map of smooth round bumps with a flat rim: what <displacement type="height_bump"> hands to IHWLayer::NormalMapFromDisplacement"""
+    u = (np.arange(n) + 0.5) / n
+    k = 2.0 * np.pi * periods
+    hgt = 0.5 + 0.45 * np.sin(k * u)[None, :] * np.sin(k * u)[:, None]
+    img = np.empty((n, n, 4), np.uint8)
+    img[..., :3] = np.clip(hgt * 255.0 + 0.5, 0, 255).astype(np.uint8)[..., None]
+    img[..., 3] = 255
+    return img
+
+
 def write_vsgf(path, m):
     vn, tn = len(m["pos"]), len(m["idx"]) // 3
     blobs = [m["pos"].tobytes(), m["norm"].tobytes(), m["tan"].tobytes(), m["uv"].tobytes(), m["idx"].tobytes(), m["mat"].tobytes()]
@@ -252,6 +263,8 @@ def main():
     ap.add_argument("--aniso", action="store_true", help="the reflectivity lobe of material 1 becomes Beckmann (anisotropy 0.7, rotated by 0.15 turns, glossiness "
                     "from texture 2), that of material 8 TRGGX (anisotropy 0.5, flipped axes), material 9 a Fresnel blend of an isotropic Beckmann lobe "
                     "over diffuse (cmaterial.h:1558-1846, cmatpbrt.h:105-540)")
+    ap.add_argument("--height-bump", action="store_true", help="materials 0, 4 (floor) and 9 (a wall) get <displacement type='height_bump'> over a generated 256x256 "
+                    "height map (amount 0.8; the wall's copy smoothed, smooth_lvl 0.3): the layer bakes the normal maps (IHWLayer::NormalMapFromDisplacement)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky = args.sky or args.sky_tex
@@ -293,6 +306,10 @@ def main():
     if args.normal_maps:
         nmap_tex = len(texs)
         texs.append((None, tile_normal_map()))
+    hmap_tex = None
+    if args.height_bump:
+        hmap_tex = len(texs)
+        texs.append((None, tile_height_map()))
     xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
     chunk = 0
     for tid, (n, img) in enumerate(texs):
@@ -336,6 +353,13 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    if args.height_bump:
+        for i, line in enumerate(xml):
+            for mid in (0, 4, 9):
+                if line.startswith('  <material id="%d" ' % mid):
+                    bump = ('<displacement type="height_bump"><height_map amount="0.8" smooth_lvl="%s"><texture id="%d" type="texref" '
+                            'matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" /></height_map></displacement>' % ("0.3" if mid == 9 else "0.0", hmap_tex))
+                    xml[i] = line.replace("</material>", bump + "</material>")
     if args.aniso:   # ... and the pots (material 3) become shadow catchers: black pass-through surfaces on the CPU integrator's path
         for i, line in enumerate(xml):
             if line.startswith('  <material id="3" '):
