@@ -1109,3 +1109,28 @@ def test_height_bump_materials_end_to_end(built):
     assert abs(got.mean() - ref.mean()) < 0.03 * ref.mean()
     assert np.corrcoef(down(got).ravel(), down(ref).ravel())[0, 1] > 0.99
 
+
+def test_gbuffer_full_size_1080p(built):
+    """IHWLayer::EvalGBuffer at the BASELINE frame size (1920x1080: 132 M primary rays in four blocks through the segmented queue): two calls give
+    the same bits, the layers are self-consistent, and two 96 x 40 windows (frame centre, and the last rows: the tail block) agree with the oracle's
+    gbufferEval of the same pixels"""
+    from hydracore_amd import HostScene
+    from test_golden_ref import check_gbuffer, unpack_gbuffer1
+    sc = HostScene(scene_path("atrium250k"), 1920, 1080, trace_depth=8, enable_dof=0, use_hip=True, device=0, seed=777)
+    sc.draw(passes=1, spp=1)
+    core = sc.hip()
+    d1, d2, raw = core.eval_gbuffer(1920, 1080, raw=True)
+    e1, e2 = core.eval_gbuffer(1920, 1080)
+    assert (d1.view(np.uint32) == e1.view(np.uint32)).all() and (d2.view(np.uint32) == e2.view(np.uint32)).all()
+    ri = raw.view(np.int32)
+    assert (ri[..., 8] >= 0).mean() > 0.99 and raw[..., 9].min() >= 1.0 / 64 - 1e-6 and raw[..., 9].max() <= 1.0 + 1e-6      # closed hall: nearly every pixel sees a surface; the winner counts itself
+    depth, norm, mat, cov, rgba = unpack_gbuffer1(d1)
+    hit = ri[..., 8] >= 0                                                     # a miss packs matId -1 into 24 bits
+    assert (depth == raw[..., 0]).all() and (mat[hit] == ri[..., 8][hit]).all() and (mat[~hit] == 0xFFFFFF).all() and np.abs(cov - raw[..., 9]).max() <= 1.0 / 255 + 1e-6
+    assert (d2[..., 2].view(np.int32) == ri[..., 12]).all() and (d2[..., 3].view(np.int32) == ri[..., 13]).all()
+    orc = make_oracle(sc.buffers())
+    for x0, y0 in ((912, 520), (1824, 1040)):
+        win = (d1[y0:y0 + 40, x0:x0 + 96], d2[y0:y0 + 40, x0:x0 + 96], raw[y0:y0 + 40, x0:x0 + 96])
+        check_gbuffer(tuple(np.ascontiguousarray(a) for a in win), orc.gbuffer(x0, y0, 96, 40))
+    sc.close()
+
