@@ -340,6 +340,7 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i, float4& cpos,
 
 // one level of CameraPath (:756-929) for the hit of the ray in rayPos[i]; currDepth counts from 1
 // (ray, hit) in, next ray out; returns whether the sub-path goes on
+template <int F = HK_FEAT_ALL>
 HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int currDepth, float4 rayPos4, float4 rayDir4, const HydraLiteHit& hit, float4& npos, float4& ndir) {
   int bits = msti(v, MP_BITS, i);
   mmltDeadRay(npos, ndir);
@@ -395,13 +396,13 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
       float rands[HK_MMLT_PER_BOUNCE];
       mmltRands(v, i, HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * sp + HK_MMLT_PER_BOUNCE * (currDepth - 1), rands);   // camOffsetInRandArrayMMLT(s) + rndMatOffsetMMLT(bounce)
       MatSample ms;
-      MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, uint32_t(currDepth - 1) << 8, s, ms, false);
+      MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, uint32_t(currDepth - 1) << 8, s, ms, false);
       const float cosNext = fabsf(dot(ms.direction, surf.normal));
       if (currDepth == 1) {
         if (isPureSpecular(ms)) mpdfFwd(v, d, i) = 0.0f;
       } else {
         if (!isPureSpecular(ms)) {
-          const float pdfFwdW = materialEval(mat, mmltShadeContext(surf, ray_dir * (-1.0f), ms.direction), s).pdfFwd;
+          const float pdfFwdW = materialEval<F>(mat, mmltShadeContext(surf, ray_dir * (-1.0f), ms.direction), s).pdfFwd;
           mpdfFwd(v, prevVertexId, i) = (pdfFwdW / fmaxf(cosHere, HK_DEPSILON)) * GTerm;
         } else mpdfFwd(v, prevVertexId, i) = -1.0f * GTerm;
         const float pdfCamPrevWP = misPdf / fmaxf(cosPrev, HK_DEPSILON);
@@ -423,6 +424,7 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
 }
 
 // one level of TraceLightPath (:671-754) for the hit of the ray in rayPos[n + i]
+template <int F = HK_FEAT_ALL>
 HK_DEV bool mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currDepth, float4 rayPos4, float4 rayDir4, const HydraLiteHit& hit, float4& npos, float4& ndir) {
   int bits = msti(v, MP_LBITS, i);
   mmltDeadRay(npos, ndir);
@@ -442,7 +444,7 @@ HK_DEV bool mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currD
     float rands[HK_MMLT_PER_BOUNCE];
     mmltRands(v, i, HK_MMLT_HEAD + HK_MMLT_PER_BOUNCE * (currDepth - 1), rands);
     MatSample ms;
-    MaterialSampleAndEvalBxDF(mat, rands, surf, ray_dir, uint32_t(currDepth - 1) << 8, s, ms, true);
+    MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, uint32_t(currDepth - 1) << 8, s, ms, true);
     const float cosNext = fabsf(+dot(ms.direction, surf.normal));
     if (currDepth == lightTraceDepth) {
       mstoreHit(v, MP_LV_HIT, i, surf); mstSet3(v, MP_LV_DIR, i, ray_dir); mstSet3(v, MP_LV_ACC, i, mst3(v, MP_L_COLOR, i));
@@ -450,7 +452,7 @@ HK_DEV bool mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currD
       bits |= MB_LV_VALID;
     } else {
       if (!isPureSpecular(ms)) {
-        const float pdfW = materialEval(mat, mmltShadeContext(surf, ray_dir * (-1.0f), ms.direction * (-1.0f)), s).pdfFwd;
+        const float pdfW = materialEval<F>(mat, mmltShadeContext(surf, ray_dir * (-1.0f), ms.direction * (-1.0f)), s).pdfFwd;
         mpdfRev(v, currDepth, i) = (pdfW / fmaxf(cosCurr, HK_DEPSILON)) * GTermPrev;
       } else mpdfRev(v, currDepth, i) = -1.0f * GTermPrev;
       mstSet3(v, MP_L_COLOR, i, mst3(v, MP_L_COLOR, i) * ((ms.color * cosNext) * (1.0f / fmaxf(ms.pdf, HK_DEPSILON2))));
@@ -466,12 +468,13 @@ HK_DEV bool mmltLightStep(const SceneDev& s, const MmltView& v, int i, int currD
 
 // what mmltConnectBegin and mmltConnectEnd both need of a shadow connection to a sampled light (ConnectShadow :962-990)
 struct MmltLightConn { int lightOffset; float pick; ShadowSample sam; f3 dir, pos; };
+template <int F = HK_FEAT_ALL>
 HK_DEV MmltLightConn mmltLightConnection(const SceneDev& s, const MmltView& v, int i, const SurfaceHit& cvHit) {
   MmltLightConn c;
   c.pick = 1.0f;
   c.lightOffset = SelectRandomLightRev(mx(v, 10, i), s, c.pick);
   if (c.lightOffset >= 0) {
-    LightSampleRev(s, lightAt(s, c.lightOffset), mk3(mx(v, 4, i), mx(v, 5, i), mx(v, 6, i)), cvHit.pos, c.sam);
+    LightSampleRev<F>(s, lightAt(s, c.lightOffset), mk3(mx(v, 4, i), mx(v, 5, i), mx(v, 6, i)), cvHit.pos, c.sam);
     c.dir = normalize(c.sam.pos - cvHit.pos);
     c.pos = OffsRayPos(cvHit.pos, cvHit.normal, c.dir);
   }
@@ -488,6 +491,7 @@ HK_DEV f3 mmltCameraColor(const MmltView& v, int i) {   // the products CameraPa
   return acc;
 }
 
+template <int F = HK_FEAT_ALL>
 HK_DEV void mmltConnectBegin(const SceneDev& s, const MmltView& v, int i) {
   const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i) | msti(v, MP_LBITS, i);
   const int lightTraceDepth = sp - 1, camTraceDepth = d - sp;
@@ -508,7 +512,7 @@ HK_DEV void mmltConnectBegin(const SceneDev& s, const MmltView& v, int i) {
   } else if (lightTraceDepth == 0) {
     if ((bits & MB_CV_VALID) && !(bits & MB_CV_SPEC_ONLY)) {
       const SurfaceHit cv = mloadHit(v, MP_CV_HIT, i);
-      const MmltLightConn c = mmltLightConnection(s, v, i, cv);
+      const MmltLightConn c = mmltLightConnection<F>(s, v, i, cv);
       if (c.lightOffset >= 0) { spos = make_float4(c.pos.x, c.pos.y, c.pos.z, c.sam.maxDist * 0.9995f); sdir = make_float4(c.dir.x, c.dir.y, c.dir.z, 0.0f); }
     }
   } else if ((bits & MB_CV_VALID) && (bits & MB_LV_VALID)) {
@@ -526,6 +530,7 @@ HK_DEV void mmltConnectBegin(const SceneDev& s, const MmltView& v, int i) {
   v.eyePos[i] = epos; v.eyeDir[i] = edir; v.shPos[i] = spos; v.shDir[i] = sdir;
 }
 
+template <int F = HK_FEAT_ALL>
 HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
   const int d = v.depth[i], sp = msti(v, MP_S, i), bits = msti(v, MP_BITS, i) | msti(v, MP_LBITS, i);
   const int t = d - sp, lightTraceDepth = sp - 1, camTraceDepth = t;
@@ -548,7 +553,7 @@ HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
       else {
         const float surfaceToImageFactor = 1.f / imageToSurfaceFactor;
         const float* mat = materialAt(s, lv.matId);
-        const BxDFResult ev = materialEval(mat, mmltShadeContext(lv, camDir, lvDir * (-1.0f)), s, true);
+        const BxDFResult ev = materialEval<F>(mat, mmltShadeContext(lv, camDir, lvDir * (-1.0f)), s, true);
         const f3 colorConnect = ev.brdf + ev.btdf;
         const float pdfRevW = ev.pdfRev;
         const float cosCurr = fabsf(dot(lvDir, lv.normal));
@@ -570,12 +575,12 @@ HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
       f3 explicitColor = mk3(0, 0, 0);
       const SurfaceHit cv = mloadHit(v, MP_CV_HIT, i);
       const f3 cvDir = mst3(v, MP_CV_DIR, i);
-      const MmltLightConn c = mmltLightConnection(s, v, i, cv);
+      const MmltLightConn c = mmltLightConnection<F>(s, v, i, cv);
       const float shadow = v.shVis[i];
       if (c.lightOffset >= 0 && shadow * shadow * 3.0f > 1e-12f) {
         const float* pLight = lightAt(s, c.lightOffset);
         const float* mat = materialAt(s, cv.matId);
-        const BxDFResult ev = materialEval(mat, mmltShadeContext(cv, c.dir, cvDir * (-1.0f)), s);
+        const BxDFResult ev = materialEval<F>(mat, mmltShadeContext(cv, c.dir, cvDir * (-1.0f)), s);
         const float pdfFwdAt1W = ev.pdfRev;
         const float cosThetaOut1 = fmaxf(+dot(c.dir, cv.normal), HK_DEPSILON), cosThetaOut2 = fmaxf(-dot(c.dir, cv.normal), HK_DEPSILON);
         const bool inverseCos = ((matFlags(mat) & HMF_HAVE_BTDF) != 0 && dot(c.dir, cv.normal) < -0.01f);
@@ -613,12 +618,12 @@ HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
       const float GTerm0 = (+dot(lv.normal, lToC)) * (-dot(cv.normal, lToC)) / dist2;
       if (!(GTerm0 < 0.0f) && !(shadow * shadow * 3.0f < 1e-12f)) {
         const float* matL = materialAt(s, lv.matId);
-        const BxDFResult evL = materialEval(matL, mmltShadeContext(lv, lToC, lvDir * (-1.0f)), s, true);
+        const BxDFResult evL = materialEval<F>(matL, mmltShadeContext(lv, lToC, lvDir * (-1.0f)), s, true);
         const f3 lightBRDF = evL.brdf + evL.btdf;
         float signOfNormalL = 1.0f, signOfNormalC = 1.0f;
         if ((matFlags(matL) & HMF_HAVE_BTDF) != 0 && dot(lToC, lv.normal) < -0.01f) signOfNormalL = -1.0f;
         const float* matC = materialAt(s, cv.matId);
-        const BxDFResult evC = materialEval(matC, mmltShadeContext(cv, lToC * (-1.0f), cvDir * (-1.0f)), s);
+        const BxDFResult evC = materialEval<F>(matC, mmltShadeContext(cv, lToC * (-1.0f), cvDir * (-1.0f)), s);
         const f3 camBRDF = evC.brdf + evC.btdf;
         const float camVPdfRevW = evC.pdfFwd, camVPdfFwdW = evC.pdfRev;
         if ((matFlags(matC) & HMF_HAVE_BTDF) != 0 && dot(lToC * (-1.0f), cv.normal) < -0.01f) signOfNormalC = -1.0f;

@@ -940,6 +940,7 @@ __global__ void __launch_bounds__(256) k_mmlt_begin(SceneDev s, MmltView v, int 
 #ifndef HK_MMLT_CONN_W
 #define HK_MMLT_CONN_W 2   /* k_mmlt_connect_end: 256 registers and no spills beat 168 with 69 spilled dwords (533-552 -> 608 M mutations/s, profiles/r02/mmlt_register_budget.log) */
 #endif
+template <int F>
 __global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
   const SegIter it = segq_iter(q);
   uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
@@ -951,20 +952,22 @@ __global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, M
       const int j = it.base + idx;
       owner = in.owner[j];
       const int chain = owner >> 1;
-      alive = (owner & 1) ? mmltLightStep(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir)
-                          : mmltCameraStep(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir);
+      alive = (owner & 1) ? mmltLightStep<F>(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir)
+                          : mmltCameraStep<F>(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir);
     }
     const int dst = it.base + wave_compact_index(alive, counter);
     if (alive) { out.pos[dst] = npos; out.dir[dst] = ndir; out.owner[dst] = owner; }
   }
 }
+template <int F>
 __global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < v.n) mmltConnectBegin(s, v, i);
+  if (i < v.n) mmltConnectBegin<F>(s, v, i);
 }
+template <int F>
 __global__ void __launch_bounds__(256, HK_MMLT_CONN_W) k_mmlt_connect_end(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < v.n) mmltConnectEnd(s, v, i);
+  if (i < v.n) mmltConnectEnd<F>(s, v, i);
 }
 // ---- the Markov chains of IntegratorMMLT (hk_bidir.h): one thread per chain
 __global__ void k_mmlt_init_chains(MmltChains c, int seed) {
@@ -2661,7 +2664,15 @@ static int mmlt_alloc(hydra_hip_ctx* c, TmpBufs& tb, int n, int maxD, MmltBufs& 
   b.v.eyeHit = b.eyeHit; b.v.shVis = b.shVis;
   return rc;
 }
-// F for every chain of the view: v.x, v.depth and v.out8 are set by the caller; maxDepth = the largest d among the chains
+// F for every chain of the view: v.x, v.depth and v.out8 are set by the caller; maxDepth = the largest d among the chains.
+// The stage kernels exist in three feature sets like k_bounce (hk_shading.h, HK_FEAT_*): the sky / delta-light / Oren-Nayar subset, the classic set,
+// everything -- with every BxDF inlined a stage kernel is 47 k vector instructions, most of which a scene like test_42 never runs
+#define HK_MMLT_LAUNCH(K, GRID, ...) do { \
+    const int f_ = c->sceneFeatures; \
+    if ((f_ & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) hipLaunchKernelGGL((K<HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
+    else if ((f_ & ~HK_FEAT_CLASSIC) == 0) hipLaunchKernelGGL((K<HK_FEAT_CLASSIC>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((K<HK_FEAT_ALL>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
+  } while (0)
 static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int maxDepth) {
   const MmltView& v = b.v;
   const int n = v.n;
@@ -2676,9 +2687,9 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
     const SegQ q = seg_q(b.counts + size_t(k - 1) * HK_CROW, 0, b.nseg, b.cap);
     HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
     launch_closest(c, s, q, in.pos, in.dir, b.hits, nullptr, nullptr, fetch);
-    hipLaunchKernelGGL(k_mmlt_step, dim3(seg_grid(c, q, 256, 64)), dim3(256), 0, c->stream, s, v, k, q, in, b.hits, out, b.counts + size_t(k) * HK_CROW);
+    HK_MMLT_LAUNCH(k_mmlt_step, dim3(seg_grid(c, q, 256, 64)), s, v, k, q, in, b.hits, out, b.counts + size_t(k) * HK_CROW);
   }
-  hipLaunchKernelGGL(k_mmlt_connect_begin, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  HK_MMLT_LAUNCH(k_mmlt_connect_begin, dim3((n + 255) / 256), s, v);
   // the two connection rays of every chain, as a segmented queue over the chain order (one fetch counter for all persistent waves
   // saturates at ~88 fetches per microsecond: 0.19 ms per launch of 1 M rays, more than their traversal takes)
   const int capC = ((n + b.nseg - 1) / b.nseg + 63) / 64 * 64;
@@ -2689,7 +2700,7 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
   launch_closest(c, s, qc, v.eyePos, v.eyeDir, b.eyeHit, nullptr, nullptr, fetch);
   HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
   launch_shadow(c, s, qc, v.shPos, v.shDir, b.shVis, nullptr, fetch);
-  hipLaunchKernelGGL(k_mmlt_connect_end, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, v);
+  HK_MMLT_LAUNCH(k_mmlt_connect_end, dim3((n + 255) / 256), s, v);
   HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
 }
