@@ -387,12 +387,12 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
 enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_ALL = 511,
-       HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent and Blinn nodes */ };
+       HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent, Blinn and the anisotropic (Beckmann, TRGGX) nodes */ };   // DELTA_LIGHTS stands for "lights other than area and sky": point, spot, directional, sphere
 
 // ================================================================================================ materials
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
 struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
-struct ShadeContext { f3 l, v, n; f2 tc; f3 fn, tg, bn; };                  // cglobals.h:2282-2301 (fn: light-tracing form of materialEval and normal maps; tg, bn: normal maps)
+struct ShadeContext { f3 l, v, n; f2 tc; f3 fn, tg, bn; };                  // cglobals.h:2282-2301 (fn: light-tracing form of materialEval and normal maps; tg, bn: normal maps and the anisotropic lobes)
 
 // ---- normal maps (cmaterial.h:2208-2243; sample2DAuxExt cfetch.h:795-820 without procedural textures) ----
 HK_DEV bool hasNormalMap(const float* m) { return uint32_t(as_int(m[HM_NORMAL_TEX])) != HYDRA_INVALID_TEXTURE; }
