@@ -112,8 +112,27 @@ HK_DEV void SphereLightSampleForward(const float* L, float4 rands, LightSampleFw
   out.cosTheta = cosTheta;
   out.norm = lnorm;
 }
-HK_DEV void LightSampleForward(const float* L, float4 rands, LightSampleFwd& out) {
+HK_DEV void MeshLightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {   // clight.h:1023-1062
+  f3 samplePos, sampleNorm; float pdfA;
+  MeshLightSamplePos(s, L, mk3(rands.x, rands.y, rands2x), samplePos, sampleNorm, pdfA);
+  samplePos = meshLightMatrixMul(L + HL_MESH_MATRIX, samplePos);
+  sampleNorm = normalize(meshLightMatrixMul(L + HL_MESH_MATRIX, sampleNorm));
+  samplePos = samplePos + lightPos(L);
+  const f3 sampleDir = MapSampleToCosineDistribution(rands.z, rands.w, sampleNorm, sampleNorm, 1.0f);
+  const float cosTheta = fmaxf(dot(sampleDir, sampleNorm), 0.0f);
+  out.isPoint = false;
+  out.pos = samplePos + sampleNorm * epsilonOfPos(samplePos);
+  out.dir = sampleDir;
+  out.color = lightColor(L) * cosTheta;
+  out.pdfA = 1.0f / L[HL_SURFACE_AREA];
+  out.pdfW = cosTheta * HK_INV_PI;
+  out.cosTheta = cosTheta;
+  out.norm = sampleNorm;
+}
+// rands2x: the first of the two extra light dimensions (LightGroup2::group2.x, primary-sample dimension 8), which only mesh lights read
+HK_DEV void LightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {
   switch (as_int(L[HL_TYPE])) {
+    case HLT_MESH: MeshLightSampleForward(s, L, rands, rands2x, out); break;
     case HLT_SPHERE: SphereLightSampleForward(L, rands, out); break;
     case HLT_DIRECT: DirectLightSampleForward(L, rands, out); break;
     case HLT_POINT_SPOT: PointSpotSampleForward(L, rands, out); break;
@@ -326,7 +345,7 @@ HK_DEV void mmltBegin(const SceneDev& s, const MmltView& v, int i, float4& cpos,
     float pick = 1.0f;
     const int lightId = SelectRandomLightFwd(mx(v, 10, i), s, pick);   // RndLightMMLT: group2.z = MMLT_DIM_LGT_N
     LightSampleFwd sam;
-    LightSampleForward(lightAt(s, lightId), make_float4(mx(v, 4, i), mx(v, 5, i), mx(v, 6, i), mx(v, 7, i)), sam);
+    LightSampleForward(s, lightAt(s, lightId), make_float4(mx(v, 4, i), mx(v, 5, i), mx(v, 6, i), mx(v, 7, i)), mx(v, 8, i), sam);
     mpdfFwd(v, 0, i) = sam.pdfA * pick;
     mpdfRev(v, 0, i) = 1.0f;
     mstSet3(v, MP_L_COLOR, i, div3s(sam.color * (1.0f / pick), sam.pdfA * sam.pdfW));

@@ -1593,9 +1593,56 @@ HK_DEV void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out.maxDist = length(samplePos - illum);
   out.cosAtLight = fabsf(dot(lnorm, dirToV));
 }
-// lightEvalPDF, clight.h:1613-1633, for the light a path has run into: the types that have a surface (area rectangles / disks and spheres)
+// mesh lights, clight.h:966-1062, 1513-1546: a copy of the light's mesh and the prefix sums of its triangle areas live in the pdf arena
+// (MeshLight, PlainLightConverter.cpp:724-835); a triangle by area, a point in it by uniform barycentrics; untextured (the front end refuses a texture)
+HK_DEV void MeshLightSamplePos(const SceneDev& s, const float* L, f3 rands, f3& pos, f3& norm, float& pdfA) {
+  const int meshId = as_int(L[HL_MESH_MESH_ID]), pdftId = as_int(L[HL_MESH_TABLE_ID]), triNum = as_int(L[HL_MESH_TRI_NUM]);
+  const int tabOffs = s.hdr[HG_PDF_TABLE_OFFS];
+  const float4* mesh = s.pdfStorage + s.globals[tabOffs + meshId];
+  const float* table = reinterpret_cast<const float*>(s.pdfStorage + s.globals[tabOffs + pdftId]);
+  const HydraPlainMesh* hdr = reinterpret_cast<const HydraPlainMesh*>(mesh);
+  const float4* vpos = mesh + hdr->vPosOffset;
+  const float4* vnorm = mesh + hdr->vNormOffset;
+  const int* indices = reinterpret_cast<const int*>(mesh + hdr->vIndicesOffset);
+  float pickProb = 1.0f;
+  const int triangleId = SelectIndexPropToOpt(rands.z, table, triNum + 1, pickProb);
+  const int iA = indices[triangleId * 3 + 0], iB = indices[triangleId * 3 + 1], iC = indices[triangleId * 3 + 2];
+  const f3 A = xyz(vpos[iA]), B = xyz(vpos[iB]), C = xyz(vpos[iC]);
+  const f3 nA = xyz(vnorm[iA]), nB = xyz(vnorm[iB]), nC = xyz(vnorm[iC]);
+  float u = rands.x, v = rands.y;
+  if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+  const float w = 1.0f - u - v;
+  pos = ((A * u) + (B * v)) + (C * w);
+  norm = ((nA * u) + (nB * v)) + (nC * w);
+  pdfA = 1.0f / L[HL_SURFACE_AREA];
+}
+HK_DEV f3 meshLightMatrixMul(const float* M, f3 v) {   // matrix3x3f_mult_float3, cglobals.h:1091-1098
+  return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
+}
+HK_DEV void MeshLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
+  f3 samplePos, sampleNorm; float pdfA;
+  MeshLightSamplePos(s, L, rands, samplePos, sampleNorm, pdfA);
+  samplePos = meshLightMatrixMul(L + HL_MESH_MATRIX, samplePos);
+  sampleNorm = normalize(meshLightMatrixMul(L + HL_MESH_MATRIX, sampleNorm));
+  samplePos = samplePos + lightPos(L);
+  const f3 rayDir = normalize(samplePos - illum);
+  const float hitDist = length(samplePos - illum);
+  const float cosVal = fmaxf(-dot(rayDir, sampleNorm), 0.0f);
+  out.isPoint = false;
+  out.pos = samplePos + sampleNorm * epsilonOfPos(samplePos);
+  out.color = lightColor(L);          // meshLightGetIntensity without a texture
+  out.pdf = PdfAtoW(pdfA, hitDist, cosVal);
+  out.maxDist = hitDist;
+  out.cosAtLight = cosVal;
+}
+HK_DEV float meshLightEvalPDF(const float* L, f3 rayDir, f3 lnorm, float hitDist) {
+  const float pdfA = 1.0f / fmaxf(L[HL_SURFACE_AREA], HK_DEPSILON);
+  return PdfAtoW(pdfA, hitDist, fmaxf(dot(rayDir, lnorm * (-1.0f)), 0.0f));
+}
+// lightEvalPDF, clight.h:1613-1633, for the light a path has run into: the types that have a surface (area rectangles / disks, spheres, meshes)
 HK_DEV float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
   if (as_int(L[HL_TYPE]) == HLT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  if (as_int(L[HL_TYPE]) == HLT_MESH) return meshLightEvalPDF(L, rayDir, lnorm, length(illum - lpos));
   return areaDiffuseLightEvalPDF(L, rayDir, length(illum - lpos));
 }
 template <int F = HK_FEAT_ALL>
@@ -1606,6 +1653,7 @@ HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_SPOT) SpotLightSampleRev(L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev(L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_SPHERE) SphereLightSampleRev(L, rands, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_MESH) MeshLightSampleRev(s, L, rands, illum, out);
   else AreaLightSampleRev(L, rands, illum, out);
 }
 // environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)

@@ -892,7 +892,7 @@ __global__ void k_stage_light_fwd(SceneDev s, int n, const int* __restrict__ lig
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   LightSampleFwd sam;
-  LightSampleForward(lightAt(s, lightIds[i]), rands4[i], sam);
+  LightSampleForward(s, lightAt(s, lightIds[i]), rands4[i], 0.0f, sam);   // the reference-side fixture hands in rands2 = (0, 0) as well (oracle/ref_driver.cl)
   float* o = out16 + size_t(i) * 16;
   o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
   o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
@@ -1814,11 +1814,11 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
     const int type = blob[at + HL_TYPE];
-    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE);
+    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH);
     if (!known)
-      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, sky-dome, point, spot and directional lights only");
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, mesh, sky-dome, point, spot and directional lights only");
     if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
-    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
+    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
     if (blob[at + HL_FLAGS] & HLF_HAS_IES)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
   }

@@ -793,6 +793,56 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   const std::string ltype = a_node->attr("type"), lshape = a_node->attr("shape"), distr = a_node->attr("distribution");
   if (ltype == "sky") return UpdateSkyLight(a_lightId, a_node);
   if (ltype == "directional" || distr == "directional" || lshape == "point") return UpdateDeltaLight(a_lightId, a_node);   // factory order of PlainLightConverter.cpp:1070-1105
+  if (ltype == "area" && lshape == "mesh") {   // MeshLight, PlainLightConverter.cpp:724-835; RenderDriverRTE::UpdateLight :925-938 hands it the light's mesh
+    const int32_t meshId = a_node->attr_int("mesh_id", -1);
+    const std::vector<int32_t> gtable = m_pGeomStorage->GetTable();
+    if (meshId < 0 || size_t(meshId) >= gtable.size() || gtable[size_t(meshId)] < 0) { Unsupported("mesh light " + std::to_string(a_lightId) + ": its mesh " + std::to_string(meshId) + " is not in the geometry storage yet"); return false; }
+    if (sampler_node(xchild(xchild(a_node, "intensity"), "color"))) Unsupported("textured mesh light " + std::to_string(a_lightId));
+    const char* blob = reinterpret_cast<const char*>(m_pGeomStorage->GetBegin()) + size_t(gtable[size_t(meshId)]) * 16;
+    const HydraPlainMesh* pm = reinterpret_cast<const HydraPlainMesh*>(blob);
+    const float* vpos = reinterpret_cast<const float*>(blob + size_t(pm->vPosOffset) * 16);
+    const int32_t* indices = reinterpret_cast<const int32_t*>(blob + size_t(pm->vIndicesOffset) * 16);
+    LightProto mp;
+    mp.plain.assign(HL_FLOATS, 0.0f);
+    float* d = mp.plain.data();
+    d[HL_PROB_MULT] = 1.0f;
+    const XmlNode* inten = a_node->child("intensity");
+    const float3 color = read_value3f(xchild(inten, "color")) * read_value1f(xchild(inten, "multiplier"));
+    d[HL_COLOR + 0] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+    // CalcTrianglePickProbTable + PrefixSumm, RenderDriverRTE_PdfTables.cpp:650-673, :359-370
+    const int triNum = pm->tIndicesNum / 3;
+    std::vector<float> table(size_t(triNum) + 1);
+    double surfaceAreaTotal = 0.0;
+    float accum = 0.0f;
+    for (int t = 0; t < triNum; t++) {
+      const int iA = indices[3 * t], iB = indices[3 * t + 1], iC = indices[3 * t + 2];
+      const float3 A(vpos[iA * 4], vpos[iA * 4 + 1], vpos[iA * 4 + 2]), B(vpos[iB * 4], vpos[iB * 4 + 1], vpos[iB * 4 + 2]), C(vpos[iC * 4], vpos[iC * 4 + 1], vpos[iC * 4 + 2]);
+      const float triSA = 0.5f * length(cross(B - A, C - A));
+      table[size_t(t)] = accum;
+      accum += triSA;
+      surfaceAreaTotal += double(triSA);
+    }
+    table[size_t(triNum)] = accum;
+    const int32_t meshVerId = m_pPdfStorage->GetMaxObjectId() + 1, meshPdfId = m_pPdfStorage->GetMaxObjectId() + 2;
+    m_pPdfStorage->Update(meshVerId, blob, pm->totalBytesNum);
+    m_pPdfStorage->Update(meshPdfId, table.data(), table.size() * sizeof(float));
+    put_i(d, HL_MESH_MESH_ID, meshVerId);
+    put_i(d, HL_MESH_TABLE_ID, meshPdfId);
+    put_i(d, HL_MESH_TRI_NUM, triNum);
+    d[HL_SURFACE_AREA] = float(surfaceAreaTotal);
+    put_i(d, HL_TYPE, HLT_MESH);
+    put_i(d, HL_FLAGS, 0);
+    put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
+    put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(d + HL_MESH_MATRIX, ident, 36);
+    put_sampler_at(d, int32_t(HYDRA_INVALID_TEXTURE), Sampler(), HL_MESH_TEX_ID, HL_MESH_TEXMATRIX_ID, HL_MESH_TEX_SAMPLER);
+    mp.isMesh = true;
+    mp.meshPos.assign(vpos, vpos + size_t(pm->vPosNum) * 4);
+    mp.meshInd.assign(indices, indices + pm->tIndicesNum);
+    m_lights[a_lightId] = mp;
+    return true;
+  }
   if (ltype == "area" && lshape == "sphere") {   // SphereLight, PlainLightConverter.cpp:445-496, CreateSphereLightFromXmlNode :858-865
     LightProto sp;
     sp.plain.assign(HL_FLOATS, 0.0f);
@@ -1038,6 +1088,27 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
       continue;
     }
     if (it->second.isSky) {                       // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
+      put_i(d, HL_GROUP_ID, a_lightGroupId);
+      d[HL_PICK_PROB_REV] = 1.0f;
+      d[HL_PICK_PROB_FWD] = 1.0f;
+      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
+      continue;
+    }
+    if (it->second.isMesh) {                      // MeshLight::Transform, PlainLightConverter.cpp:795-829: position, the 3x3 part, the area of the transformed triangles
+      const float3 mp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+      d[HL_POS] = mp0.x; d[HL_POS + 1] = mp0.y; d[HL_POS + 2] = mp0.z;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) d[HL_MESH_MATRIX + r * 3 + c] = M.at(r, c);
+      double totalSA = 0.0;
+      const std::vector<float>& P = it->second.meshPos;
+      const std::vector<int32_t>& I = it->second.meshInd;
+      for (size_t k = 0; k + 2 < I.size(); k += 3) {
+        const float3 A = mul_point(M, float3(P[size_t(I[k]) * 4], P[size_t(I[k]) * 4 + 1], P[size_t(I[k]) * 4 + 2]));
+        const float3 B = mul_point(M, float3(P[size_t(I[k + 1]) * 4], P[size_t(I[k + 1]) * 4 + 1], P[size_t(I[k + 1]) * 4 + 2]));
+        const float3 C = mul_point(M, float3(P[size_t(I[k + 2]) * 4], P[size_t(I[k + 2]) * 4 + 1], P[size_t(I[k + 2]) * 4 + 2]));
+        totalSA += double(0.5f * length(cross(B - A, C - A)));
+      }
+      d[HL_SURFACE_AREA] = float(totalSA);
       put_i(d, HL_GROUP_ID, a_lightGroupId);
       d[HL_PICK_PROB_REV] = 1.0f;
       d[HL_PICK_PROB_FWD] = 1.0f;
@@ -1324,9 +1395,6 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
       UpdateImage(t->attr_int("id"), wh[0], wh[1], bpp, 4, d.data() + 8);
     }
   for (auto* m : matLib->children_named("material")) UpdateMaterial(m->attr_int("id"), m);
-  if (lgtLib)
-    for (auto* l : lgtLib->children_named("light")) UpdateLight(l->attr_int("id"), l);
-
   std::set<int> loadedMeshes;
   for (auto* me : geoLib->children_named("mesh")) {
     std::vector<char> d;
@@ -1343,6 +1411,8 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
                (const float*)arr("tangents"), (const float*)arr("texcoords"), (const int*)arr("indices"), (const int*)arr("matindices"));
     loadedMeshes.insert(me->attr_int("id"));
   }
+  if (lgtLib)   // after the meshes: a mesh light copies its mesh out of the geometry storage (RenderDriverRTE::UpdateLight :925-938)
+    for (auto* l : lgtLib->children_named("light")) UpdateLight(l->attr_int("id"), l);
 
   UpdateCamera(camLib ? camLib->child("camera") : nullptr);
   UpdateSettings(settings);

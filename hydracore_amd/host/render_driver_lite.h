@@ -82,7 +82,8 @@ private:
 
   struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0}; } m_camera;
 
-  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false; int kind = 0; };   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
+  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false, isMesh = false; int kind = 0;
+                      std::vector<float> meshPos; std::vector<int32_t> meshInd; };   // meshPos / meshInd: MeshLight::tempPos / tempInd   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance

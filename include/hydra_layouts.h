@@ -174,7 +174,7 @@ enum { HTEX_POINT_SAM = 1, HTEX_ALPHASRC_W = 2, HTEX_CLAMP_U = 4, HTEX_CLAMP_V =
 enum {
   HL_FLOATS = 128,
   HL_TYPE = 0, HL_FLAGS = 1, HL_POS = 2, HL_NORM = 5, HL_COLOR = 8, HL_COLOR_TEX = 11, HL_COLOR_TEX_MATRIX = 12,
-  HL_SURFACE_AREA = 13, HL_SPHERE_RADIUS = 14 /* SPHERE_LIGHT_RADIUS, clight.h:33 */, HL_AREA_SIZE_X = 14, HL_AREA_SIZE_Y = 15, HL_AREA_MATRIX = 16, HL_AREA_IS_DISK = 25,
+  HL_SURFACE_AREA = 13, HL_SPHERE_RADIUS = 14 /* SPHERE_LIGHT_RADIUS, clight.h:33 */, HL_MESH_MESH_ID = 14, HL_MESH_TABLE_ID = 15, HL_MESH_TRI_NUM = 16, HL_MESH_MATRIX = 20, HL_MESH_TEX_ID = 30, HL_MESH_TEXMATRIX_ID = 31, HL_MESH_TEX_SAMPLER = 32 /* MESH_LIGHT_*, clight.h:169-176 */, HL_AREA_SIZE_X = 14, HL_AREA_SIZE_Y = 15, HL_AREA_MATRIX = 16, HL_AREA_IS_DISK = 25,
   HL_AREA_SPOT_DISTR = 26, HL_AREA_SPOT_COS1 = 27, HL_AREA_SPOT_COS2 = 28, HL_AREA_SKY_OFFSET = 29,
   HL_AREA_SKY_SOURCE = 30, HL_AREA_SKYPORTAL_BTEX = 31, HL_AREA_SKYPORTAL_BTEX_MATRIX = 32,
   HL_AREA_SAMPLER0 = 40, HL_AREA_SAMPLER1 = 52,

@@ -56,7 +56,8 @@ enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, P
        PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
        AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107,
        PL_COLOR_TEX_MATRIX = 12, SKY_DOME_PDF_TABLE0 = 30, SKY_DOME_SAMPLER0 = 32, SKY_DOME_MATRIX0 = 36, SKY_DOME_INV_MATRIX0 = 56 };   /* clight.h:131-165 */
-enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4, LT_SPHERE = 5 };
+enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4, LT_SPHERE = 5, LT_MESH = 7 };
+enum { MESH_LIGHT_MESH_OFFSET_ID = 14, MESH_LIGHT_TABLE_OFFSET_ID = 15, MESH_LIGHT_TRI_NUM = 16, MESH_LIGHT_MATRIX_E00 = 20 };   /* clight.h:169-176 */
 enum { SPHERE_LIGHT_RADIUS = 14 };   /* clight.h:33 */
 enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADIUS1 = 14, DIRECT_LIGHT_RADIUS2 = 15,
        DIRECT_LIGHT_SSOFTNESS = 16, DIRECT_LIGHT_ALPHA_TAN = 17, DIRECT_LIGHT_ALPHA_COS = 18 };   /* clight.h:118-127 */
@@ -2024,14 +2025,58 @@ static void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out->maxDist = length3(sub3(samplePos, illum));
   out->cosAtLight = fabsf(dot3(lnorm, dirToV));
 }
+/* ref: clight.h:966-1062, 1513-1546 mesh lights (untextured: meshLightGetIntensity = the base colour) */
+static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, float* pdfA) {
+  const int meshId = as_int(L[MESH_LIGHT_MESH_OFFSET_ID]), pdftId = as_int(L[MESH_LIGHT_TABLE_OFFSET_ID]), triNum = as_int(L[MESH_LIGHT_TRI_NUM]);
+  const float* mesh = pdfTableHeader(s, meshId);
+  const float* table = pdfTableHeader(s, pdftId);
+  const int32_t* hdr = (const int32_t*)mesh;
+  const float* vpos = mesh + (size_t)hdr[0] * 4;
+  const float* vnorm = mesh + (size_t)hdr[1] * 4;
+  const int32_t* indices = (const int32_t*)(mesh + (size_t)hdr[3] * 4);
+  float pickProb = 1.0f;
+  const int triangleId = SelectIndexPropToOpt(rands.z, table, triNum + 1, &pickProb);
+  const int iA = indices[triangleId * 3 + 0], iB = indices[triangleId * 3 + 1], iC = indices[triangleId * 3 + 2];
+  const f3 A = v3(vpos[iA * 4], vpos[iA * 4 + 1], vpos[iA * 4 + 2]), B = v3(vpos[iB * 4], vpos[iB * 4 + 1], vpos[iB * 4 + 2]), C = v3(vpos[iC * 4], vpos[iC * 4 + 1], vpos[iC * 4 + 2]);
+  const f3 nA = v3(vnorm[iA * 4], vnorm[iA * 4 + 1], vnorm[iA * 4 + 2]), nB = v3(vnorm[iB * 4], vnorm[iB * 4 + 1], vnorm[iB * 4 + 2]), nC = v3(vnorm[iC * 4], vnorm[iC * 4 + 1], vnorm[iC * 4 + 2]);
+  float u = rands.x, v = rands.y;
+  if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+  const float w = 1.0f - u - v;
+  *pPos = add3(add3(scale3(A, u), scale3(B, v)), scale3(C, w));
+  *pNorm = add3(add3(scale3(nA, u), scale3(nB, v)), scale3(nC, w));
+  *pdfA = 1.0f / L[PL_SURFACE_AREA];
+}
+static f3 meshLightMatrixMul(const float* M, f3 v) { return v3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
+static void MeshLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  f3 samplePos, sampleNorm; float pdfA;
+  MeshLightSamplePos(s, L, rands, &samplePos, &sampleNorm, &pdfA);
+  samplePos = meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, samplePos);
+  sampleNorm = normalize3(meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, sampleNorm));
+  samplePos = add3(samplePos, lightPos(L));
+  const f3 rayDir = normalize3(sub3(samplePos, illum));
+  const float hitDist = length3(sub3(samplePos, illum));
+  const float cosVal = fmaxf(-dot3(rayDir, sampleNorm), 0.0f);
+  out->isPoint = 0;
+  out->pos = add3(samplePos, scale3(sampleNorm, epsilonOfPos(samplePos)));
+  out->color = lightColor(L);
+  out->pdf = PdfAtoW_full(pdfA, hitDist, cosVal);
+  out->maxDist = hitDist;
+  out->cosAtLight = cosVal;
+}
+static float meshLightEvalPDF(const float* L, f3 rayDir, f3 lnorm, float hitDist) {
+  const float pdfA = 1.0f / fmaxf(L[PL_SURFACE_AREA], DEPSILON);
+  return PdfAtoW_full(pdfA, hitDist, fmaxf(dot3(rayDir, scale3(lnorm, -1.0f)), 0.0f));
+}
 /* ref: clight.h:1613-1633 lightEvalPDF for the lights that have a surface in this subset */
 static float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
   if (as_int(L[PL_TYPE]) == LT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  if (as_int(L[PL_TYPE]) == LT_MESH) return meshLightEvalPDF(L, rayDir, lnorm, length3(sub3(illum, lpos)));
   return areaDiffuseLightEvalPDF(L, rayDir, length3(sub3(illum, lpos)));
 }
 static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
   switch (as_int(L[PL_TYPE])) {
     case LT_SPHERE: SphereLightSampleRev(L, rands, illum, out); break;
+    case LT_MESH: MeshLightSampleRev(s, L, rands, illum, out); break;
     case LT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
     case LT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
     case LT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
@@ -2067,6 +2112,26 @@ static void SphereLightSampleForward(const float* L, const float r[4], LightSamp
   out->pdfW = cosTheta * INV_PI;
   out->cosTheta = cosTheta;
   out->norm = lnorm;
+}
+/* ref: clight.h:1023-1062 MeshLightSampleForward; r2x = rands2.x, the triangle choice */
+static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, float* pdfA);
+static f3 meshLightMatrixMul(const float* M, f3 v);
+static void MeshLightSampleForward(const OrcScene* s, const float* L, const float r[4], float r2x, LightSampleFwd* out) {
+  f3 samplePos, sampleNorm; float pdfA;
+  MeshLightSamplePos(s, L, v3(r[0], r[1], r2x), &samplePos, &sampleNorm, &pdfA);
+  samplePos = meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, samplePos);
+  sampleNorm = normalize3(meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, sampleNorm));
+  samplePos = add3(samplePos, lightPos(L));
+  const f3 sampleDir = MapSampleToCosineDistribution(r[2], r[3], sampleNorm, sampleNorm, 1.0f);
+  const float cosTheta = fmaxf(dot3(sampleDir, sampleNorm), 0.0f);
+  out->isPoint = 0;
+  out->pos = add3(samplePos, scale3(sampleNorm, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(lightColor(L), cosTheta);
+  out->pdfA = 1.0f / L[PL_SURFACE_AREA];
+  out->pdfW = cosTheta * INV_PI;
+  out->cosTheta = cosTheta;
+  out->norm = sampleNorm;
 }
 /* ref: clight.h:654-719 AreaLightSampleForward (no IES, no sky portal in the subset) */
 static void AreaLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
@@ -2161,6 +2226,7 @@ void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds,
     const float* L = lightAt(s, lightIds[i]);
     LightSampleFwd sam;
     switch (as_int(L[PL_TYPE])) {
+      case LT_MESH: MeshLightSampleForward(s, L, rands4 + 4 * i, 0.0f, &sam); break;   /* rands2 = (0, 0), as the reference-side fixture hands in */
       case LT_SPHERE: SphereLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_DIRECT: DirectLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_SPOT: PointSpotSampleForward(L, rands4 + 4 * i, &sam); break;
@@ -2499,8 +2565,9 @@ static int SelectRandomLightFwd(float r, const OrcScene* s, float* pickProb) {
   if (tableSize <= 2) return 0;
   return SelectIndexPropToOpt(r, (const float*)(s->globals + s->globals[G_LSEL_FWD_OFFS]), tableSize, pickProb);
 }
-static void LightSampleForwardAny(const float* L, const float r[4], LightSampleFwd* sam) {
+static void LightSampleForwardAny(const OrcScene* s, const float* L, const float r[4], float r2x, LightSampleFwd* sam) {
   switch (as_int(L[PL_TYPE])) {
+    case LT_MESH: MeshLightSampleForward(s, L, r, r2x, sam); break;
     case LT_SPHERE: SphereLightSampleForward(L, r, sam); break;
     case LT_DIRECT: DirectLightSampleForward(L, r, sam); break;
     case LT_POINT_SPOT: PointSpotSampleForward(L, r, sam); break;
@@ -2645,7 +2712,7 @@ static void mmltF(const OrcScene* s, const float* xVec, int d, float* out8) {
     const int lightId = SelectRandomLightFwd(xVec[MMLT_DIM_LGT_N], s, &lightPickProb);
     const float* pLight = lightAt(s, lightId);
     LightSampleFwd sample;
-    LightSampleForwardAny(pLight, xVec + MMLT_DIM_LGT_X, &sample);
+    LightSampleForwardAny(s, pLight, xVec + MMLT_DIM_LGT_X, xVec[MMLT_DIM_LGT_X + 4], &sample);   /* group1 = dims 4..7, group2.x = dim 8 (RndLightMMLT) */
     pdfArray[0].pdfFwd = sample.pdfA * lightPickProb;
     pdfArray[0].pdfRev = 1.0f;
     f3 color = div3s(scale3(sample.color, 1.0f / lightPickProb), sample.pdfA * sample.pdfW);

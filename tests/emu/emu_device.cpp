@@ -113,7 +113,7 @@ void emu_bidir(const EmuScene* e, int n, const int* lightIds, const float* rands
   const SceneDev s = to_dev(e);
   for (int i = 0; i < n; i++) {
     LightSampleFwd sam;
-    LightSampleForward(lightAt(s, lightIds[i]), make_float4(rands4[4 * i], rands4[4 * i + 1], rands4[4 * i + 2], rands4[4 * i + 3]), sam);
+    LightSampleForward(s, lightAt(s, lightIds[i]), make_float4(rands4[4 * i], rands4[4 * i + 1], rands4[4 * i + 2], rands4[4 * i + 3]), 0.0f, sam);
     float* o = fwd16 + 16 * size_t(i);
     o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
     o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;

@@ -280,10 +280,14 @@ def main():
               ("floor", floor(r(192, 4), r(96, 2))), ("curtain", curtain(r(40, 2), r(64, 2))), ("room", room(open_roof=args.sky or args.delta_lights)), ("light", light_quad(2.0, 0.5))]
     if args.cutouts:
         meshes.append(("plant", plant()))
-    globe_mesh = None
+    globe_mesh = lamp_mesh = None
     if args.delta_lights:      # ... and a sphere light with its visible globe (clight.h:1287-1332)
         globe_mesh = len(meshes)
         meshes.append(("globe", globe(0.35)))
+        lamp_mesh = len(meshes)                 # ... and a mesh light: a coarse, squashed globe (its own triangles are what is sampled, clight.h:966-1062)
+        lamp = globe(0.3, 8, 4, mat=13)
+        lamp["pos"][:, 1] *= 0.6
+        meshes.append(("lamp", lamp))
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -395,6 +399,7 @@ def main():
                    '<opacity smooth="0"><skip_shadow val="0" /><texture id="%d" type="texref" input_alpha="alpha" input_gamma="1" /></opacity></material>' % (mask_tex, mask_tex))
     if args.delta_lights:
         xml.append('  <material id="12" name="globe_mat" type="hydra_material" light_id="4" visible="1"><emission><color val="25 22 18" /></emission></material>')
+        xml.append('  <material id="13" name="lamp_mat" type="hydra_material" light_id="5" visible="1"><emission><color val="18 24 30" /></emission></material>')
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
@@ -408,7 +413,9 @@ def main():
                   '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
                   '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>'
                   '\n  <light id="4" name="globe" type="area" shape="sphere" distribution="uniform" visible="1" mat_id="12" mesh_id="%d"><size radius="0.35" />'
-                  '<intensity><color val="1 0.88 0.72" /><multiplier val="25.0" /></intensity></light>' % (globe_mesh or 0) if args.delta_lights else '')
+                  '<intensity><color val="1 0.88 0.72" /><multiplier val="25.0" /></intensity></light>'
+                  '\n  <light id="5" name="lamp" type="area" shape="mesh" distribution="uniform" visible="1" mat_id="13" mesh_id="%d">'
+                  '<intensity><color val="0.6 0.8 1" /><multiplier val="30.0" /></intensity></light>' % (globe_mesh or 0, lamp_mesh or 0) if args.delta_lights else '')
                + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
@@ -458,8 +465,10 @@ def main():
     light_m = mat4(t=(2.0, 9.6, 0.0))
     add(6, light_m, ' light_id="0" linst_id="0"')
     globe_m = mat4(scale=1.4, t=(-6.0, 3.2, 2.0))
+    lamp_m = mat4(scale=1.8, yaw=0.7, t=(5.0, 2.4, -2.5))
     if args.delta_lights:
         add(globe_mesh, globe_m, ' light_id="4" linst_id="4"')
+        add(lamp_mesh, lamp_m, ' light_id="5" linst_id="5"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
     if args.sky:
@@ -469,6 +478,7 @@ def main():
         xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % mat4(t=(6.0, 7.5, -2.0), rot_x=0.3))
         xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
         xml.append('    <instance_light id="4" light_id="4" matrix="%s" lgroup_id="-1" />' % globe_m)
+        xml.append('    <instance_light id="5" light_id="5" matrix="%s" lgroup_id="-1" />' % lamp_m)
     xml += inst
     xml.append("  </scene>\n</scenes>")
     with open(os.path.join(out, "statex_00001.xml"), "w") as f:
