@@ -455,6 +455,21 @@ HK_DEV int shadeClassOfMaterial(const float* m) {
 HK_DEV int matFlags(const float* m) { return as_int(m[HM_FLAGS]); }
 HK_DEV f3 matColor(const float* m) { return mk3(m[HM_COLOR], m[HM_COLOR + 1], m[HM_COLOR + 2]); }
 
+// the same table as compile-time constants (see cosPowerFromGlosiness)
+HK_DEV constexpr float hk_glosscoeff_row(int r, int c) {
+  constexpr float T[10][4] = {
+    {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
+    {357.142857142857f, -35.7142857142857f, 5.0f, 1.5f},
+    {-2142.85714285714f, 428.571428571429f, 8.57142857142857f, 2.0f},
+    {428.571428571431f, -42.8571428571432f, 30.0f, 5.0f},
+    {2095.23809523810f, -152.380952380952f, 34.2857142857143f, 8.0f},
+    {-4761.90476190476f, 1809.52380952381f, 66.6666666666667f, 12.0f},
+    {9914.71215351811f, 1151.38592750533f, 285.714285714286f, 32.0f},
+    {45037.7068059246f, 9161.90096119855f, 813.432835820895f, 82.0f},
+    {167903.678757035f, 183240.189801913f, 3996.94423223835f, 300.0f},
+    {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
+  return T[r][c];
+}
 __device__ static const float hk_glosscoeff[10][4] = {   // cmaterial.h:435-450
     {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
     {357.142857142857f, -35.7142857142857f, 5.0f, 1.5f},
@@ -477,7 +492,17 @@ HK_DEV float cosPowerFromGlosiness(float x) {   // cmaterial.h:453-466
   const int k = (fabsf(x - 1.0f) < 1e-5f) ? 10 : int(x * 10.0f);
   const float x1 = (x - float(k) * 0.1f);
   if (k == 10 || x >= 0.99f) return 1000000.0f;
-  return hk_glosscoeff[k][3] + hk_glosscoeff[k][2] * x1 + hk_glosscoeff[k][1] * x1 * x1 + hk_glosscoeff[k][0] * x1 * x1 * x1;
+#ifdef HK_HOST_EMU
+  const float c0 = hk_glosscoeff[k][0], c1 = hk_glosscoeff[k][1], c2 = hk_glosscoeff[k][2], c3 = hk_glosscoeff[k][3];
+#else
+  // the row by a chain of selects over literal constants instead of a load from the table in global memory: the lobe functions call this three to
+  // four times per path and bounce, each time in the middle of a dependent chain (a cache hit is still several hundred cycles; 40 selects are not)
+  float c0 = hk_glosscoeff_row(9, 0), c1 = hk_glosscoeff_row(9, 1), c2 = hk_glosscoeff_row(9, 2), c3 = hk_glosscoeff_row(9, 3);
+#pragma unroll
+  for (int r = 8; r >= 0; r--)
+    if (k == r) { c0 = hk_glosscoeff_row(r, 0); c1 = hk_glosscoeff_row(r, 1); c2 = hk_glosscoeff_row(r, 2); c3 = hk_glosscoeff_row(r, 3); }
+#endif
+  return c3 + c2 * x1 + c1 * x1 * x1 + c0 * x1 * x1 * x1;
 }
 
 // ---- lambert, cmaterial.h:219-263
