@@ -386,7 +386,7 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
-enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_ALL = 511,
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_PEREZ = 512, HK_FEAT_ALL = 1023,
        HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent, Blinn and the anisotropic (Beckmann, TRGGX) nodes */ };   // DELTA_LIGHTS stands for "lights other than area and sky": point, spot, directional, sphere
 
 // ================================================================================================ materials
@@ -455,7 +455,7 @@ HK_DEV int shadeClassOfMaterial(const float* m) {
 HK_DEV int matFlags(const float* m) { return as_int(m[HM_FLAGS]); }
 HK_DEV f3 matColor(const float* m) { return mk3(m[HM_COLOR], m[HM_COLOR + 1], m[HM_COLOR + 2]); }
 
-// the same table as compile-time constants (see cosPowerFromGlosiness)
+// cmaterial.h:435-450, as compile-time constants (see cosPowerFromGlosiness)
 HK_DEV constexpr float hk_glosscoeff_row(int r, int c) {
   constexpr float T[10][4] = {
     {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
@@ -470,17 +470,6 @@ HK_DEV constexpr float hk_glosscoeff_row(int r, int c) {
     {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
   return T[r][c];
 }
-__device__ static const float hk_glosscoeff[10][4] = {   // cmaterial.h:435-450
-    {8.88178419700125e-14f, -1.77635683940025e-14f, 5.0f, 1.0f},
-    {357.142857142857f, -35.7142857142857f, 5.0f, 1.5f},
-    {-2142.85714285714f, 428.571428571429f, 8.57142857142857f, 2.0f},
-    {428.571428571431f, -42.8571428571432f, 30.0f, 5.0f},
-    {2095.23809523810f, -152.380952380952f, 34.2857142857143f, 8.0f},
-    {-4761.90476190476f, 1809.52380952381f, 66.6666666666667f, 12.0f},
-    {9914.71215351811f, 1151.38592750533f, 285.714285714286f, 32.0f},
-    {45037.7068059246f, 9161.90096119855f, 813.432835820895f, 82.0f},
-    {167903.678757035f, 183240.189801913f, 3996.94423223835f, 300.0f},
-    {-20281790.7444668f, 6301358.14889336f, 45682.0925553320f, 2700.0f}};
 // translucent (diffuse transmission), cmaterial.h:1852-1909; colour and sampler sit at the lambert offsets
 HK_DEV f3 lambertColorFwd(const float* m, f2 tc, const SceneDev& s);
 HK_DEV float translucentEvalPDF(f3 l, f3 v, f3 n) {
@@ -492,16 +481,12 @@ HK_DEV float cosPowerFromGlosiness(float x) {   // cmaterial.h:453-466
   const int k = (fabsf(x - 1.0f) < 1e-5f) ? 10 : int(x * 10.0f);
   const float x1 = (x - float(k) * 0.1f);
   if (k == 10 || x >= 0.99f) return 1000000.0f;
-#ifdef HK_HOST_EMU
-  const float c0 = hk_glosscoeff[k][0], c1 = hk_glosscoeff[k][1], c2 = hk_glosscoeff[k][2], c3 = hk_glosscoeff[k][3];
-#else
   // the row by a chain of selects over literal constants instead of a load from the table in global memory: the lobe functions call this three to
   // four times per path and bounce, each time in the middle of a dependent chain (a cache hit is still several hundred cycles; 40 selects are not)
   float c0 = hk_glosscoeff_row(9, 0), c1 = hk_glosscoeff_row(9, 1), c2 = hk_glosscoeff_row(9, 2), c3 = hk_glosscoeff_row(9, 3);
 #pragma unroll
   for (int r = 8; r >= 0; r--)
     if (k == r) { c0 = hk_glosscoeff_row(r, 0); c1 = hk_glosscoeff_row(r, 1); c2 = hk_glosscoeff_row(r, 2); c3 = hk_glosscoeff_row(r, 3); }
-#endif
   return c3 + c2 * x1 + c1 * x1 * x1 + c0 * x1 * x1 * x1;
 }
 
@@ -1494,8 +1479,64 @@ HK_DEV float skyLightEvalPDF(const SceneDev& s, const float* L, f3 rayDir) {   /
   const float mapPdf = evalMap2DPdf(tcT, hdr + 4, sizeX, sizeY);
   return (mapPdf * 1.0f) / (2.f * HK_PI * HK_PI * fmaxf(fabsf(sintheta), HK_DEPSILON));
 }
-// skyLightGetIntensityTexturedENV without the Perez model (rejected at upload), clight.h:285-306
+// ---- Perez all-weather sky (Preetham's fit), clight.h:178-282: zenith colour in Yxy, the distribution function, Yxy -> linear RGB,
+// and the sun disc blended in over the last 0.05-0.15 % of the cosine
+HK_DEV f3 perezZenith(float t, float thetaSun) {
+  const float pi = 3.1415926f;   // the reference's own constant here
+  const float t2 = t * t;
+  const float chi = (4.0f / 9.0f - t / 120.0f) * (pi - 2.0f * thetaSun);
+  const float th1 = thetaSun, th2 = thetaSun * thetaSun, th3 = thetaSun * thetaSun * thetaSun;
+  // dot(float4 coefficients, (1, th, th^2, th^3)) in LiteMath's order x*x + y*y + z*z + w*w
+  #define HK_DOT4(a, b, c, d) ((a) * 1.0f + (b) * th1 + (c) * th2 + (d) * th3)
+  const float Y = (4.0453f * t - 4.9710f) * tanf(chi) - 0.2155f * t + 2.4192f;
+  const float x = t2 * HK_DOT4(0.0f, 0.00209f, -0.00375f, 0.00165f) + t * HK_DOT4(0.00394f, -0.03202f, 0.06377f, -0.02903f) + HK_DOT4(0.25886f, 0.06052f, -0.21196f, 0.11693f);
+  const float y = t2 * HK_DOT4(0.0f, 0.00317f, -0.00610f, 0.00275f) + t * HK_DOT4(0.00516f, -0.04153f, 0.08970f, -0.04214f) + HK_DOT4(0.26688f, 0.06670f, -0.26756f, 0.15346f);
+  #undef HK_DOT4
+  return mk3(Y, x, y);
+}
+HK_DEV f3 perezFunc(float t, float cosTheta, float cosGamma) {
+  const float gamma = acosf(cosGamma), cosGammaSq = cosGamma * cosGamma;
+  const float aY = 0.17872f * t - 1.46303f, bY = -0.35540f * t + 0.42749f, cY = -0.02266f * t + 5.32505f, dY = 0.12064f * t - 2.57705f, eY = -0.06696f * t + 0.37027f;
+  const float ax = -0.01925f * t - 0.25922f, bx = -0.06651f * t + 0.00081f, cx = -0.00041f * t + 0.21247f, dx = -0.06409f * t - 0.89887f, ex = -0.00325f * t + 0.04517f;
+  const float ay = -0.01669f * t - 0.26078f, by = -0.09495f * t + 0.00921f, cy = -0.00792f * t + 0.21023f, dy = -0.04405f * t - 1.65369f, ey = -0.01092f * t + 0.05291f;
+  return mk3((1.0f + aY * expf(bY / cosTheta)) * (1.0f + cY * expf(dY * gamma) + eY * cosGammaSq),
+             (1.0f + ax * expf(bx / cosTheta)) * (1.0f + cx * expf(dx * gamma) + ex * cosGammaSq),
+             (1.0f + ay * expf(by / cosTheta)) * (1.0f + cy * expf(dy * gamma) + ey * cosGammaSq));
+}
+HK_DEV f3 perezSky(float turbidity, float cosTheta, float cosGamma, float cosThetaSun) {
+  const f3 a = perezZenith(turbidity, acosf(cosThetaSun)) * perezFunc(turbidity, cosTheta, cosGamma), b = perezFunc(turbidity, 1.0f, cosThetaSun);
+  return mk3(a.x / b.x, a.y / b.y, a.z / b.z);
+}
+HK_DEV f3 perezConvertColor(f3 clrYxy) {   // convertColor, clight.h:235-252
+  clrYxy.x = 1.0f - expf(-clrYxy.x / 20.0f);
+  const float ratio = clrYxy.x / fmaxf(clrYxy.z, 1e-10f);
+  f3 XYZ;
+  XYZ.x = clrYxy.y * ratio;
+  XYZ.y = clrYxy.x;
+  XYZ.z = ratio - XYZ.x - XYZ.y;
+  return clamp3(mk3(dot(mk3(3.240479f, -1.53715f, -0.49853f), XYZ), dot(mk3(-0.969256f, 1.875991f, 0.041556f), XYZ), dot(mk3(0.055684f, -0.204043f, 1.057311f), XYZ)), 0.0f, 1.0f);
+}
+HK_DEV f3 skyLightPerezColor(const float* L, f3 ray_dir) {   // clight.h:255-282
+  const f3 sunDir = mk3(L[HL_SKY_SUN_DIR], L[HL_SKY_SUN_DIR + 1], L[HL_SKY_SUN_DIR + 2]);
+  const float turbidity = L[HL_SKY_TURBIDITY];
+  const f3 colorYxy = perezSky(turbidity, fmaxf(ray_dir.y, 0.0f) + 0.05f, fmaxf(dot(sunDir, ray_dir * (-1.0f)), 0.0f), fmaxf(-sunDir.y, 0.0f));
+  f3 rgb = perezConvertColor(colorYxy);
+  rgb.x = powf(rgb.x, 2.2f); rgb.y = powf(rgb.y, 2.2f); rgb.z = powf(rgb.z, 2.2f);
+  const float tSunAngle = fmaxf(-sunDir.y, 0.0f);
+  const float threshold = 0.9985f + tSunAngle * (0.9995f - 0.9985f);
+  const float tSun = dot(sunDir, ray_dir * (-1.0f));
+  if (tSun >= threshold) {
+    const f3 sunColor = mk3(L[HL_SKY_SUN_COLOR], L[HL_SKY_SUN_COLOR + 1], L[HL_SKY_SUN_COLOR + 2]) * (2.0f + 2.0f * tSunAngle);
+    float tSun2 = (tSun - threshold) / (1.0f - threshold);
+    tSun2 = tSun2 * tSun2;
+    rgb = (sunColor * tSun2) + (rgb * (1.0f - tSun2));
+  }
+  return rgb;
+}
+// skyLightGetIntensityTexturedENV, clight.h:285-306: the lat-long texture is fetched in both branches there, used in one
+template <int F = HK_FEAT_ALL>
 HK_DEV f3 skyLightIntensity(const SceneDev& s, const float* L, f3 dir) {
+  if ((F & HK_FEAT_PEREZ) && (as_int(L[HL_FLAGS]) & HLF_SKY_USE_PEREZ)) return lightColor(L) * skyLightPerezColor(L, dir);
   float sintheta = 0.0f;
   const f2 tc = sphereMapTo2DTexCoord(dir, sintheta);
   return lightColor(L) * sample2DExt(as_int(L[HL_COLOR_TEX_MATRIX]), tc, L + HL_SKY_SAMPLER0, s);
@@ -1688,7 +1729,7 @@ HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool pre
   const int skyId = s.hdr[HG_SKY_LIGHT_ID];
   if (skyId == -1) return mk3(0, 0, 0);
   const float* L = lightAt(s, skyId);
-  f3 envColor = skyLightIntensity(s, L, rayDir);
+  f3 envColor = skyLightIntensity<F>(s, L, rayDir);
   const uint32_t rayBounceNum = (flags >> 8) & 0xFFu;   // unpackBounceNum, cglobals.h:1330-1340
   if (rayBounceNum > 0 && !(uint32_t(s.hdr[HG_FLAGS]) & HF_STUPID_PT_MODE) && !prevSpecular) {
     const float lgtPdf = L[HL_PICK_PROB_REV] * skyLightEvalPDF(s, L, rayDir);

@@ -1086,7 +1086,6 @@ struct hydra_hip_ctx {
   std::vector<int32_t> hostMatTable;
   std::vector<int32_t> hostTexAuxTable;   // aux texture id -> offset in the aux arena (normal maps), for validate_materials
   bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
-  bool skyLightOk = true;            // false when the uploaded sky light needs a model this layer lacks
 
   // render state
   int rank = 0, world = 1, tile = 64;
@@ -1636,7 +1635,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
           else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
           else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
           else if ((f & ~(HK_FEAT_CLASSIC | HK_FEAT_NMAP)) == 0 && (f & HK_FEAT_NMAP)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC | HK_FEAT_NMAP);   // normal maps over the classic set: without the rarer lobes
-          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
+          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
           else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
           else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
           else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);
@@ -1800,14 +1799,12 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     const int64_t to = blob[HG_TEX_TABLE_OFFS], ts = blob[HG_TEX_TABLE_SIZE];
     if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: texture table runs past the blob");
   }
-  // the sky light (if any) must be one this layer implements: constant colour or lat-long texture, no Perez model
-  c->skyLightOk = true;
+  // the sky light (if any) must be well-formed: constant colour, lat-long texture or the Perez model
   const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
   if (skyId != -1 && lightsNum > 0) {   // (before SetAllPODLights the header is still zero-initialised: nothing to check yet)
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(skyId) * HL_FLOATS;
     if (skyId < 0 || skyId >= lightsNum || at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId points outside the lights table");
     if (blob[at + HL_TYPE] != HLT_SKY_DOME) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId does not name a sky light");
-    if (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ) c->skyLightOk = false;
   }
   int lightFeat = (skyId != -1 && lightsNum > 0) ? HK_FEAT_SKY : 0;
   for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sphere, sky-dome, point, spot and directional lights
@@ -1818,6 +1815,7 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (!known)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, mesh, sky-dome, point, spot and directional lights only");
     if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
+    if (type == HLT_SKY_DOME && (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ)) lightFeat |= HK_FEAT_PEREZ;   // only the all-features instantiation carries the model
     if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
     if (blob[at + HL_FLAGS] & HLF_HAS_IES)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
@@ -2269,7 +2267,6 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
   if (c->N == 0) { c->spp += float(spp); return HYDRA_HIP_OK; }
   const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
   if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: HRT_TRACE_DEPTH out of range");
-  if (!c->skyLightOk) return fail(c, HYDRA_HIP_EINVAL, "trace_pass: the scene's sky light uses the Perez model, which the HIP layer does not implement");
 
   const SceneDev s = make_scene(c);
   auto f4 = [](const DevBuf& b) { return static_cast<float4*>(b.p); };
@@ -2594,7 +2591,6 @@ int hydra_hip_stage_shade_point(hydra_hip_handle c, int n, const float* surf24, 
 int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, uint32_t* rng_state2, float* color4) {
   // n caller-provided primary rays + RandomGen states run through the PRODUCTION wavefront kernels (path i plays pixel i)
   STAGE_PROLOG(true);
-  if (!c->skyLightOk) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: the scene's sky light uses the Perez model, which the HIP layer does not implement");
   const int maxDepth = c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
   if (maxDepth < 1 || maxDepth > HK_MAX_DEPTH) return fail(c, HYDRA_HIP_EINVAL, "stage_path_trace: HRT_TRACE_DEPTH out of range");
   float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);

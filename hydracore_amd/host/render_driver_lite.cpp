@@ -687,9 +687,10 @@ bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node
 // (RenderDriverRTE_PdfTables.cpp:479-570).  A sky without texture gets the reference's 2x2 uniform luminance image as its
 // sampling table; an 8-bit lat-long texture gets the table of LuminanceFromUchar4Image (:312-356: halve until <= 256,
 // max(r,g,b)/255, + 0.1 * max(mean, 1)).  Skies with a sampler matrix other than identity, float textures (their table is
-// Gauss-blurred by HydraAPI's HDRImageLite, absent here) and the Perez model are counted as unsupported.
+// Gauss-blurred by HydraAPI's HDRImageLite, absent here) are counted as unsupported.  <perez turbidity sun_id> switches the colour seen by
+// camera and bounce rays to the Perez model (:920-923, 1019-1028); the sun it names is copied in at EndScene.
 bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) {
-  if (a_node->child("perez")) Unsupported("Perez sky model");
+  const XmlNode* perez = a_node->child("perez");
   const XmlNode* inten = a_node->child("intensity");
   const XmlNode* colorNode = xchild(inten, "color");
   const XmlNode* texNode = colorNode ? colorNode->child("texture") : nullptr;
@@ -725,11 +726,11 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   put_i(d, HL_SKY_COLOR_TEX_MATRIX_AUX, texNode ? 0 : int32_t(HYDRA_INVALID_TEXTURE));
   put_i(d, HL_SKY_AUX_TEX_MATRIX_INV, int32_t(HYDRA_INVALID_TEXTURE));
   d[HL_SKY_SUN_DIR] = 0.0f; d[HL_SKY_SUN_DIR + 1] = -1.0f; d[HL_SKY_SUN_DIR + 2] = 0.0f;
-  d[HL_SKY_TURBIDITY] = 0.0f;
+  d[HL_SKY_TURBIDITY] = perez ? perez->attr_float("turbidity") : 0.0f;
   d[HL_SKY_SUN_COLOR] = 1.0f; d[HL_SKY_SUN_COLOR + 1] = 1.0f; d[HL_SKY_SUN_COLOR + 2] = 1.0f;
-  put_i(d, HL_SKY_SUN_DIR_ID, -1);
+  put_i(d, HL_SKY_SUN_DIR_ID, (perez && perez->has_attr("sun_id")) ? perez->attr_int("sun_id") : -1);
   put_i(d, HL_TYPE, HLT_SKY_DOME);
-  put_i(d, HL_FLAGS, 0);
+  put_i(d, HL_FLAGS, perez ? HLF_SKY_USE_PEREZ : 0);
 
   // luminance image the directions are importance-sampled from
   int lw = 2, lh = 2;
@@ -1030,6 +1031,7 @@ bool RenderDriverLite::UpdateSettings(const XmlNode* st) {
 void RenderDriverLite::BeginScene() {
   m_instMatricesInv.clear(); m_instLightInstId.clear(); m_meshIdByInstId.clear(); m_meshRemapListId.clear();
   m_lightsInstanced.clear();
+  m_lightIdByInst.clear();
   m_bvh.ClearScene();
   m_bvhAlpha.ClearScene();
   const int32_t dummyList[2] = {0, 0};
@@ -1069,6 +1071,10 @@ void RenderDriverLite::InstanceMeshes(int32_t a_mesh_id, const float* a_matrices
 void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, const XmlNode** a_lightNodes, int32_t a_instNum, int32_t a_lightGroupId) {
   auto it = m_lights.find(a_lightId);
   if (it == m_lights.end()) { m_log += "InstanceLights: bad light id\n"; return; }
+  struct IdsOnExit {   // m_lightIdByLightInstId of the reference: one entry per record this call appends
+    RenderDriverLite* self; int32_t id;
+    ~IdsOnExit() { self->m_lightIdByInst.resize(self->m_lightsInstanced.size() / HL_FLOATS, id); }
+  } idsOnExit{this, a_lightId};
   for (int i = 0; i < a_instNum; i++) {
     float4x4 M;
     memcpy(M.c, a_matrix + 16 * i, 64);
@@ -1297,6 +1303,18 @@ void RenderDriverLite::EndScene() {
   m_pHWLayer->SetAllFlagsAndVars(vars);
 
   const size_t nl = m_lightsInstanced.size() / HL_FLOATS;
+  // a Perez sky takes direction and colour of its sun from the first instance of light `sun_id`
+  // (RenderDriverRTE::BuildSkyPortalsDependencyDummyInstances, RenderDriverRTE.cpp:1603-1647)
+  for (size_t i = 0; i < nl; i++) {
+    float* sky = &m_lightsInstanced[i * HL_FLOATS];
+    if (get_i(sky, HL_TYPE) != HLT_SKY_DOME || get_i(sky, HL_SKY_SUN_DIR_ID) == -1) continue;
+    for (size_t j = 0; j < nl && j < m_lightIdByInst.size(); j++)
+      if (m_lightIdByInst[j] == get_i(sky, HL_SKY_SUN_DIR_ID)) {
+        const float* sun = &m_lightsInstanced[j * HL_FLOATS];
+        for (int k = 0; k < 3; k++) { sky[HL_SKY_SUN_DIR + k] = sun[HL_NORM + k]; sky[HL_SKY_SUN_COLOR + k] = sun[HL_COLOR + k]; }
+        break;
+      }
+  }
   if (nl > 0) {
     m_pHWLayer->SetAllInstLightInstId(m_instLightInstId.data(), int32_t(m_instLightInstId.size()));
     const std::vector<float> rev = CalcLightPickProbTable(false), fwd = CalcLightPickProbTable(true);

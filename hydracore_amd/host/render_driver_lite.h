@@ -86,6 +86,7 @@ private:
                       std::vector<float> meshPos; std::vector<int32_t> meshInd; };   // meshPos / meshInd: MeshLight::tempPos / tempInd   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
+  std::vector<int32_t> m_lightIdByInst;                                   // light id of every instanced record
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
 
   std::vector<float4x4> m_instMatricesInv;

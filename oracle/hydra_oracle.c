@@ -1844,7 +1844,7 @@ static int SelectRandomLightRev(float r, const OrcScene* s, float* pickProb) {
   return SelectIndexPropToOpt(r, (const float*)(s->globals + s->globals[G_LSEL_REV_OFFS]), tableSize, pickProb);
 }
 
-/* ---- sky dome light (constant colour or lat-long texture; no Perez model) ---- */
+/* ---- sky dome light (constant colour or lat-long texture; the Perez model next to environmentColor) ---- */
 #define ORC_PI 3.14159265358979323846f   /* float: the pinned build of the reference uses -cl-single-precision-constant */
 /* ref: cfetch.h:259-281 sphereMapToPhiTheta + sphereMapTo2DTexCoord */
 static f2 sphereMapTo2DTexCoord(f3 ray_dir, float* pSinTheta) {
@@ -2311,6 +2311,61 @@ void orc_mutate_kelemen(int n, const float* values, const float* rands2, float p
   }
 }
 
+/* ---- Perez all-weather sky, ref: clight.h:178-282 (perezZenith, perezFunc, perezSky, convertColor, skyLightPerezColor) ---- */
+enum { SKY_DOME_SUN_DIR = 23, SKY_DOME_TURBIDITY = 26, SKY_SUN_COLOR = 27, SKY_LIGHT_USE_PEREZ = 4 };   /* clight.h:143-151, cglobals.h:2249 */
+static f3 perezZenith(float t, float thetaSun) {
+  const float pi = 3.1415926f;
+  const float t2 = t * t;
+  const float chi = (4.0f / 9.0f - t / 120.0f) * (pi - 2.0f * thetaSun);
+  const float th[4] = {1.0f, thetaSun, thetaSun * thetaSun, thetaSun * thetaSun * thetaSun};
+  static const float cx1[4] = {0.0f, 0.00209f, -0.00375f, 0.00165f}, cx2[4] = {0.00394f, -0.03202f, 0.06377f, -0.02903f}, cx3[4] = {0.25886f, 0.06052f, -0.21196f, 0.11693f};
+  static const float cy1[4] = {0.0f, 0.00317f, -0.00610f, 0.00275f}, cy2[4] = {0.00516f, -0.04153f, 0.08970f, -0.04214f}, cy3[4] = {0.26688f, 0.06670f, -0.26756f, 0.15346f};
+#define ORC_DOT4(c) ((c)[0] * th[0] + (c)[1] * th[1] + (c)[2] * th[2] + (c)[3] * th[3])
+  const float Y = (4.0453f * t - 4.9710f) * tanf(chi) - 0.2155f * t + 2.4192f;
+  const float x = t2 * ORC_DOT4(cx1) + t * ORC_DOT4(cx2) + ORC_DOT4(cx3);
+  const float y = t2 * ORC_DOT4(cy1) + t * ORC_DOT4(cy2) + ORC_DOT4(cy3);
+#undef ORC_DOT4
+  return v3(Y, x, y);
+}
+static f3 perezFunc(float t, float cosTheta, float cosGamma) {
+  const float gamma = acosf(cosGamma), cosGammaSq = cosGamma * cosGamma;
+  const float aY = 0.17872f * t - 1.46303f, bY = -0.35540f * t + 0.42749f, cY = -0.02266f * t + 5.32505f, dY = 0.12064f * t - 2.57705f, eY = -0.06696f * t + 0.37027f;
+  const float ax = -0.01925f * t - 0.25922f, bx = -0.06651f * t + 0.00081f, cx = -0.00041f * t + 0.21247f, dx = -0.06409f * t - 0.89887f, ex = -0.00325f * t + 0.04517f;
+  const float ay = -0.01669f * t - 0.26078f, by = -0.09495f * t + 0.00921f, cy = -0.00792f * t + 0.21023f, dy = -0.04405f * t - 1.65369f, ey = -0.01092f * t + 0.05291f;
+  return v3((1.0f + aY * expf(bY / cosTheta)) * (1.0f + cY * expf(dY * gamma) + eY * cosGammaSq),
+            (1.0f + ax * expf(bx / cosTheta)) * (1.0f + cx * expf(dx * gamma) + ex * cosGammaSq),
+            (1.0f + ay * expf(by / cosTheta)) * (1.0f + cy * expf(dy * gamma) + ey * cosGammaSq));
+}
+static f3 perezSky(float turbidity, float cosTheta, float cosGamma, float cosThetaSun) {
+  const f3 a = mul3(perezZenith(turbidity, acosf(cosThetaSun)), perezFunc(turbidity, cosTheta, cosGamma)), b = perezFunc(turbidity, 1.0f, cosThetaSun);
+  return v3(a.x / b.x, a.y / b.y, a.z / b.z);
+}
+static f3 perezConvertColor(f3 c) {
+  c.x = 1.0f - expf(-c.x / 20.0f);
+  const float ratio = c.x / fmaxf(c.z, 1e-10f);
+  f3 XYZ;
+  XYZ.x = c.y * ratio;
+  XYZ.y = c.x;
+  XYZ.z = ratio - XYZ.x - XYZ.y;
+  return clamp3(v3(dot3(v3(3.240479f, -1.53715f, -0.49853f), XYZ), dot3(v3(-0.969256f, 1.875991f, 0.041556f), XYZ), dot3(v3(0.055684f, -0.204043f, 1.057311f), XYZ)), 0.0f, 1.0f);
+}
+static f3 skyLightPerezColor(const float* L, f3 ray_dir) {
+  const f3 sunDir = v3(L[SKY_DOME_SUN_DIR], L[SKY_DOME_SUN_DIR + 1], L[SKY_DOME_SUN_DIR + 2]);
+  const float turbidity = L[SKY_DOME_TURBIDITY];
+  const f3 colorYxy = perezSky(turbidity, fmaxf(ray_dir.y, 0.0f) + 0.05f, fmaxf(dot3(sunDir, scale3(ray_dir, -1.0f)), 0.0f), fmaxf(-sunDir.y, 0.0f));
+  f3 rgb = perezConvertColor(colorYxy);
+  rgb.x = powf(rgb.x, 2.2f); rgb.y = powf(rgb.y, 2.2f); rgb.z = powf(rgb.z, 2.2f);
+  const float tSunAngle = fmaxf(-sunDir.y, 0.0f);
+  const float threshold = 0.9985f + tSunAngle * (0.9995f - 0.9985f);
+  const float tSun = dot3(sunDir, scale3(ray_dir, -1.0f));
+  if (tSun >= threshold) {
+    const f3 sunColor = scale3(v3(L[SKY_SUN_COLOR], L[SKY_SUN_COLOR + 1], L[SKY_SUN_COLOR + 2]), 2.0f + 2.0f * tSunAngle);
+    float tSun2 = (tSun - threshold) / (1.0f - threshold);
+    tSun2 = tSun2 * tSun2;
+    rgb = add3(scale3(sunColor, tSun2), scale3(rgb, 1.0f - tSun2));
+  }
+  return rgb;
+}
 /* ref: cbidir.h:492-533 environmentColor; misPrev.prevMaterialOffset is -1 on this path (PT_Loop.cpp:247-249) */
 static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prevSpecular, uint32_t flags) {
   const int skyId = s->globals[G_SKY_LIGHT_ID];
@@ -2319,6 +2374,7 @@ static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prev
   float sintheta = 0.0f;
   const f2 tc = sphereMapTo2DTexCoord(rayDir, &sintheta);   /* skyLightGetIntensityTexturedENV, clight.h:285-306 */
   f3 envColor = mul3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), sample2DExt(as_int(L[PL_COLOR_TEX_MATRIX]), tc, L + SKY_DOME_SAMPLER0, s));
+  if (as_int(L[PL_FLAGS]) & SKY_LIGHT_USE_PEREZ) envColor = mul3(v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]), skyLightPerezColor(L, rayDir));
   const uint32_t rayBounceNum = (flags >> 8) & 0xFFu;
   if (rayBounceNum > 0 && !((uint32_t)s->globals[G_FLAGS] & HRT_STUPID_PT_MODE) && !prevSpecular) {
     const float lgtPdf = L[PL_PICK_PROB_REV] * skyLightEvalPDF(s, L, rayDir);

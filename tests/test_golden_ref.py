@@ -91,7 +91,7 @@ def check_shade_point(out, ref, frac=0.002):
     assert valid.mean() > 0.3
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_perez_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
@@ -147,7 +147,9 @@ def test_oracle_matches_reference_functions(name, built):
     # primary direction changes the random-number count of 0.3 % of the paths, none without the map): same draws on > 99.5 %, 0.9 % off by > 2e-4
     # BeckmannSample11 (cmatpbrt.h:219-295) inverts a CDF by ten Newton steps that stop at |value| < 1e-5: exp / log / pow of another libm move the
     # root in the 5th digit, the sampled half vector with it -- same draws on every path, 0.7 % off by more than 2e-4 (0.04 % by more than 1 %), mean within 2e-5
-    limit = 0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small") else 0.005
+    # the Perez hall has the same directional light (its sun), and the sky colour itself is a chain of tan / acos / exp / pow 2.2 (clight.h:178-282):
+    # 0.5 % of the paths off by more than 2e-4 (median 4e-4 among them), same draws, image mean within 2e-6
+    limit = 0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small", "atrium_perez_small") else 0.005
     assert bad.mean() < limit, bad.mean()
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 

@@ -54,6 +54,16 @@ def gpu_atrium_aniso(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_perez(built):
+    """the hall under a Perez all-weather sky whose sun is the scene's directional light (clight.h:178-282; RenderDriverRTE.cpp:1603-1647)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_perez_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_nmap(built):
     """the hall with normal-mapped floor, walls and columns (lambert, textured lambert, lambert + glossy blends; BumpMapping, cmaterial.h:2208-2243)"""
     from hydracore_amd import HipCore
@@ -274,7 +284,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -540,7 +550,7 @@ def test_mmlt_through_the_ihwlayer_adapter(built):
     assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -561,7 +571,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -736,7 +746,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
 
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
-              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small"}
+              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small"}
 
 
 @pytest.mark.parametrize("fix", list(FIXTURE_OF))
@@ -782,7 +792,7 @@ def test_hip_against_the_reference_fixtures_in_one_hop(fix, request):
     same_draws = (gens == rg).all(axis=1)
     assert same_draws.mean() > 0.995, same_draws.mean()
     bad = (np.abs(col[:, :3] - rc[:, :3]) > 2e-4 * np.maximum(np.abs(rc[:, :3]), 1.0)).any(axis=1)
-    assert bad.mean() < (0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small") else 0.005), bad.mean()   # see tests/test_golden_ref.py for the looser scenes
+    assert bad.mean() < (0.015 if name == "atrium_nmap_small" else 0.01 if name in ("atrium_lights_small", "atrium_ggx_small", "atrium_aniso_small", "atrium_perez_small") else 0.005), bad.mean()   # see tests/test_golden_ref.py for the looser scenes
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 
 

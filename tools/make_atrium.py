@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
     ap.add_argument("--delta-lights", action="store_true", help="open roof, no sky: adds a point, a spot and a directional (soft sun) light to the roof light")
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
+    ap.add_argument("--perez", action="store_true", help="like --sky, but the sky uses the Perez all-weather model (turbidity 2.5) with a directional sun (light id 3) "
+                    "that also lights the hall through the open roof")
     ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
                     "reflection + glass + diffuse, curtains = textured glossy thin glass over diffuse")
     ap.add_argument("--cutouts", action="store_true", help="adds 60 instanced plants made of crossed cards whose material has an <opacity> leaf mask (alpha-tested traversal, "
@@ -267,7 +269,7 @@ def main():
                     "height map (amount 0.8; the wall's copy smoothed, smooth_lvl 0.3): the layer bakes the normal maps (IHWLayer::NormalMapFromDisplacement)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
-    args.sky = args.sky or args.sky_tex
+    args.sky = args.sky or args.sky_tex or args.perez
     refl = "ggx" if args.ggx else "torranse_sparrow" if args.translucent else "phong"   # "torranse_sparrow" (sic) = Blinn in a Torrance-Sparrow model
     s = np.sqrt(args.scale)
     rng = np.random.default_rng(SEED)
@@ -406,6 +408,10 @@ def main():
                + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1">'
                   '<texture id="3" type="texref" input_gamma="2.2" /></color><multiplier val="0.8" /></intensity></light>' if args.sky_tex else
                   '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
+                  '<multiplier val="1.5" /></intensity><perez turbidity="2.5" sun_id="3" /></light>'
+                  '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
+                  '<shadow_softness val="1.0" /><intensity><color val="1 0.92 0.8" /><multiplier val="3.0" /></intensity></light>' if args.perez else
+                  '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
                   '<multiplier val="0.5" /></intensity></light>' if args.sky else
                   '\n  <light id="1" name="bulb" type="point" shape="point" distribution="uniform" visible="1"><intensity><color val="1 0.8 0.6" /><multiplier val="40.0" /></intensity></light>'
                   '\n  <light id="2" name="spot" type="point" shape="point" distribution="spot" visible="1"><falloff_angle val="70" /><falloff_angle2 val="40" />'
@@ -473,6 +479,8 @@ def main():
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
     if args.sky:
         xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4())
+    if args.perez:
+        xml.append('    <instance_light id="2" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.45))
     if args.delta_lights:
         xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4(t=(-10.0, 5.0, 1.0)))
         xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % mat4(t=(6.0, 7.5, -2.0), rot_x=0.3))
