@@ -9,18 +9,30 @@ ARCH     ?= gfx950
 LIBDIR   ?= hydracore_amd/lib
 # EXTRA_DEFS: compile-time tuning (-DHK_LDS_DEPTH=.. -DHK_TRACE_MIN_BLOCKS=..); LIBDIR can point at a variant directory
 EXTRA_DEFS ?=
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -shared $(EXTRA_DEFS)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC $(EXTRA_DEFS)
 CXXFLAGS := -std=c++17 -O2 -Wall -Wextra -Wno-unused-parameter -fPIC
 HOSTSRC  := $(wildcard hydracore_amd/host/*.cpp)
 HOSTHDR  := $(wildcard hydracore_amd/host/*.h) $(wildcard include/*.h)
-HIPSRC   := hydracore_amd/csrc/hydra_hip.hip hydracore_amd/csrc/hydra_bvh.hip hydracore_amd/csrc/hydra_img.hip
+# one object per translation unit, so that `make -j` compiles the device code in parallel (hk_kernels.h says which kernels live where)
+HIPSRC   := $(wildcard hydracore_amd/csrc/*.hip)
 HIPHDR   := $(wildcard hydracore_amd/csrc/*.h) $(wildcard include/*.h)
+OBJDIR   ?= build/obj$(subst /,_,$(LIBDIR))
+HIPOBJ   := $(patsubst hydracore_amd/csrc/%.hip,$(OBJDIR)/%.o,$(HIPSRC))
+MAKEFLAGS += -j8
 
-all: $(LIBDIR)/libhydra_hip.so $(LIBDIR)/libhydra_host.so oracle/liboracle.so
+all: $(LIBDIR)/libhydra_hip.so $(LIBDIR)/libhydra_host.so oracle/liboracle.so oracle/liboracle_fast.so
 
-$(LIBDIR)/libhydra_hip.so: $(HIPSRC) $(HIPHDR)
+# the BVH builder and the image kernels read none of the shading headers: they rebuild only when their own sources do
+$(OBJDIR)/hydra_bvh.o $(OBJDIR)/hydra_img.o: $(OBJDIR)/%.o: hydracore_amd/csrc/%.hip hydracore_amd/csrc/hk_common.h $(wildcard include/*.h)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OBJDIR)/%.o: hydracore_amd/csrc/%.hip $(HIPHDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libhydra_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared $(HIPOBJ) -o $@
 
 $(LIBDIR)/libhydra_host.so: $(HOSTSRC) $(HOSTHDR) $(LIBDIR)/libhydra_hip.so
 	$(CXX) $(CXXFLAGS) -shared $(HOSTSRC) -o $@ -L$(LIBDIR) -lhydra_hip -Wl,-rpath,'$$ORIGIN'
@@ -28,7 +40,12 @@ $(LIBDIR)/libhydra_host.so: $(HOSTSRC) $(HOSTHDR) $(LIBDIR)/libhydra_hip.so
 oracle/liboracle.so: oracle/hydra_oracle.c oracle/hydra_oracle.h
 	$(CC) -std=gnu11 -O2 -Wall -Wextra -fopenmp -ffp-contract=off -fPIC -shared oracle/hydra_oracle.c -o $@ -lm
 
+# the same restatement as bench.py's CPU baseline times it: -O3 and the traversal's visit counters compiled out (never used as the checker)
+oracle/liboracle_fast.so: oracle/hydra_oracle.c oracle/hydra_oracle.h
+	$(CC) -std=gnu11 -O3 -DORC_NO_STATS -Wall -Wextra -fopenmp -ffp-contract=off -fPIC -shared oracle/hydra_oracle.c -o $@ -lm
+
 clean:
-	rm -f $(LIBDIR)/*.so oracle/liboracle.so
+	rm -f $(LIBDIR)/*.so oracle/liboracle.so oracle/liboracle_fast.so
+	rm -rf build/obj*
 
 .PHONY: all clean

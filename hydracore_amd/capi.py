@@ -51,7 +51,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
-    "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image",
+    "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
     "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
 ]
 
@@ -128,12 +128,13 @@ def load_hip_library():
         "hydra_hip_stage_mmlt_f": ([vp, i32, vp, vp, i32, vp], i32),
         "hydra_hip_mmlt_begin": ([vp, i32, i32, i32, i32, i32], i32),
         "hydra_hip_mmlt_pass": ([vp, i32], i32),
-        "hydra_hip_mmlt_get_image": ([vp, vp, vp], i32),
+        "hydra_hip_mmlt_get_image": ([vp, vp, i32, i32, vp], i32),
+        "hydra_hip_mmlt_reset_image": ([vp], i32),
         "hydra_hip_mmlt_get_state": ([vp, vp, vp, vp, vp], i32),
         "hydra_hip_mmlt_end": ([vp], i32),
         "hydra_hip_sbdpt_pass": ([vp, i32], i32),
-        "hydra_hip_sbdpt_get_image": ([vp, vp, vp], i32),
-        "hydra_hip_eval_gbuffer": ([vp, vp, vp, vp, i32, vp], i32),
+        "hydra_hip_sbdpt_get_image": ([vp, vp, i32, i32, vp], i32),
+        "hydra_hip_eval_gbuffer": ([vp, vp, vp, i32, i32, vp, i32, vp], i32),
         "hydra_hip_bvh_build_mesh": ([i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_bvh_last_error": ([], C.c_char_p),
         "hydra_hip_normal_map_from_displacement": ([i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, vp], i32),
@@ -310,6 +311,11 @@ class HipCore:
         self._ck(L.hydra_hip_upload_instances(self.h, _ptr(im), _ptr(il), im.size // 16), "upload_instances")
 
     # ---- rendering
+    def resize(self, width, height):
+        """IHWLayer::ResizeScreen: a new frame size; the render state, a running MMLT run and the exchange's pixel lists restart"""
+        self._ck(self.lib.hydra_hip_resize(self.h, width, height), "resize")
+        self.width, self.height = width, height
+
     def set_tile_partition(self, rank, world, tile=64):
         self._ck(self.lib.hydra_hip_set_tile_partition(self.h, rank, world, tile), "set_tile_partition")
 
@@ -529,14 +535,14 @@ class HipCore:
     def mmlt_image(self, width, height):
         """(kScale x indirect image (h, w, 4), info dict)"""
         img, info = np.zeros((height, width, 4), np.float32), np.zeros(8, np.float32)
-        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, _ptr(img), _ptr(info)), "mmlt_get_image")
+        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, _ptr(img), width, height, _ptr(info)), "mmlt_get_image")
         keys = ("avg_brightness", "k_scale", "acceptance", "mutations", "chains", "first_bounce", "max_depth")
         return img, dict(zip(keys, (float(v) for v in info[:7])))
 
     def mmlt_state(self):
         """chain planes (11, n), d per chain, current x vectors (n, 12 + 10 * max_depth), average brightness per path length"""
         info8 = np.zeros(8, np.float32)
-        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, None, _ptr(info8)), "mmlt_get_image")
+        self._ck(self.lib.hydra_hip_mmlt_get_image(self.h, None, 0, 0, _ptr(info8)), "mmlt_get_image")
         n, max_d = int(info8[4]), int(info8[6])
         ch, depth, x, avg = np.zeros((11, n), np.float32), np.zeros(n, np.int32), np.zeros((n, 12 + 10 * max_d), np.float32), np.zeros(max_d + 1, np.float32)
         self._ck(self.lib.hydra_hip_mmlt_get_state(self.h, _ptr(ch), _ptr(depth), _ptr(x), _ptr(avg)), "mmlt_get_state")
@@ -547,8 +553,11 @@ class HipCore:
 
     def sbdpt_image(self, width, height):
         img, n = np.zeros((height, width, 4), np.float32), C.c_double(0)
-        self._ck(self.lib.hydra_hip_sbdpt_get_image(self.h, _ptr(img), C.byref(n)), "sbdpt_get_image")
+        self._ck(self.lib.hydra_hip_sbdpt_get_image(self.h, _ptr(img), width, height, C.byref(n)), "sbdpt_get_image")
         return img, n.value
+
+    def mmlt_reset_image(self):
+        self._ck(self.lib.hydra_hip_mmlt_reset_image(self.h), "mmlt_reset_image")
 
     def mmlt_end(self):
         self._ck(self.lib.hydra_hip_mmlt_end(self.h), "mmlt_end")
@@ -558,7 +567,7 @@ class HipCore:
         d1, d2 = np.zeros((height, width, 4), np.float32), np.zeros((height, width, 4), np.float32)
         r14 = np.zeros((height, width, 14), np.float32) if raw else None
         rm = np.ascontiguousarray(inst_remap, np.int32) if inst_remap is not None else None
-        self._ck(self.lib.hydra_hip_eval_gbuffer(self.h, _ptr(d1), _ptr(d2), _ptr(rm) if rm is not None else None, 0 if rm is None else rm.size,
+        self._ck(self.lib.hydra_hip_eval_gbuffer(self.h, _ptr(d1), _ptr(d2), width, height, _ptr(rm) if rm is not None else None, 0 if rm is None else rm.size,
                                                  _ptr(r14) if raw else None), "eval_gbuffer")
         return (d1, d2, r14) if raw else (d1, d2)
 

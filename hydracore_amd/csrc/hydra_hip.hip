@@ -24,71 +24,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library itself is dlopen()ed by hydra_hip_comm_init
 #include "../../include/hydra_hip.h"
-#include "hk_common.h"
-#include "hk_trace.h"
-#include "hk_shading.h"
-#include "hk_bidir.h"
+#include "hk_kernels.h"   // the template kernels and their launchers (other translation units hold the instantiations)
 #include "hk_gbuffer.h"
-
-// ================================================================================================ device state
-struct PathState {   // S arrays
-  float4* pos4; float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
-  float4* pend4;      // fused form only: throughput * unoccluded next-event estimate of the previous bounce xyz | unused
-};
-struct MidState {    // M arrays: survivors of K_hit, consumed by shadow + shade
-  float4* dir4; float4* thr4; float4* acc4; uint2* rng2;
-  float4* surfA;      // hit position xyz | matId
-  float4* surfB;      // shading normal xyz | texCoord.x
-  float4* recC;       // direction to the light sample xyz | texCoord.y
-  float4* recD;       // light radiance xyz | light pdf (negative when the sample is a point light)
-  float4* recE;       // light pick prob | lightOffset | gid | hit from inside (0/1)
-  float4* shadowOrg;  // shadow ray origin xyz | t_far
-  float*  vis;        // shadow result
-};
-
-#define HK_MAX_DEPTH 64
-#define HK_TT_ROW 12   // words per bounce in travTotals: 2 kernels x (rays, quads, insts, leaves, tris, out-of-range fetches)
-#ifndef HK_TRACE_MIN_BLOCKS
-#define HK_TRACE_MIN_BLOCKS 1   // resident 128-thread blocks per CU the traversal kernels are register-budgeted for
-#endif
-
-HK_DEV int wave_compact_index(bool alive, uint32_t* counter) {
-  const unsigned long long mask = __ballot(alive);
-  const int lane = int(__lane_id());
-  int base = 0;
-  if (mask != 0ull) {
-    const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = int(atomicAdd(counter, uint32_t(__popcll(mask))));
-    base = __shfl(base, leader);
-  }
-  return base + __popcll(mask & ((1ull << lane) - 1ull));
-}
-
-// Segmented path queues.  One global "next free slot" word saturates at ~88 returning atomics per microsecond on MI355X
-// (MI355X_MICROARCH.md, dequeue row); with one atomic per wave that alone cost k_hit ~1 ms per sample at 1080p.  The
-// path arrays are therefore split into `nseg` segments of `cap` slots, every thread block works on exactly one segment
-// (block b -> segment b % nseg) and appends survivors to the SAME segment of the next queue through that segment's own
-// counter (counters sit HK_CSTRIDE words = 128 B apart).  A segment can never grow, so cap = its initial share is a hard
-// bound and memory use does not change; results are independent of the segmentation because accumulation is keyed by pixel.
-#define HK_CSTRIDE 32
-#define HK_MAX_SEG 64
-#define HK_CROW (HK_MAX_SEG * HK_CSTRIDE)   // words per counter row: one row per bounce, [segment] inside
-struct SegQ {
-  const uint32_t* counts;   // counts[seg * HK_CSTRIDE]; nullptr => countImm items in one segment
-  int countImm, nseg, cap;
-};
-struct SegIter { int seg, base, count, first, step; };
-HK_DEV SegIter segq_iter(const SegQ& q) {
-  SegIter it;
-  const int bps = int(gridDim.x) / q.nseg;            // blocks per segment (grid is a multiple of nseg)
-  it.seg = int(blockIdx.x) % q.nseg;
-  const int bis = int(blockIdx.x) / q.nseg;
-  it.count = (bis < bps) ? (q.counts ? int(q.counts[it.seg * HK_CSTRIDE]) : q.countImm) : 0;
-  it.base = it.seg * q.cap;
-  it.first = bis * int(blockDim.x) + int(threadIdx.x);
-  it.step = (bps > 0 ? bps : 1) * int(blockDim.x);
-  return it;
-}
 
 // ================================================================================================ kernels
 // counts of a queue of n items cut into nseg segments of `cap` slots, laid out back to back (item r = slot r % cap of segment r / cap)
@@ -131,377 +68,6 @@ __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels
   }
 }
 
-// T1 -- closest hit for every live path (kernel_RayTrace).  ALPHA: the tree carries an alpha table (BVH4InstTraverseAlpha,
-// ctrace.h:1297-1520).  carry: this launch walks one of trees 1..3 and starts from the hit the earlier trees left in `hits`
-// (IntegratorCommon::rayTrace loops over the trees with one running Lite_Hit, Common.cpp:128-150; per-ray counters add up).
-template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_trace(SceneDev s, SegQ q,
-                                                           const float4* __restrict__ pos4, const float4* __restrict__ dir4,
-                                                           HydraLiteHit* __restrict__ hits, uint32_t* __restrict__ counters3,
-                                                           unsigned long long* __restrict__ totals5, int carry) {
-  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
-  const SegIter it = segq_iter(q);
-  HkStack st;
-  st.init(ldsStack, threadIdx.x);
-  BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
-  bv.alpha = s.alpha; bv.texTable = s.texTable; bv.texStorage = s.texStorage; bv.srgbLut = s.srgbLut;
-  for (int idx = it.first; idx < it.count; idx += it.step) {
-    const int i = it.base + idx;
-    const f3 pos = xyz(pos4[i]), dir = xyz(dir4[i]);
-    TravCounters c = {0, 0, 0, 0, 0};
-    HydraLiteHit h0 = hk_miss_hit();
-    if (carry) { const float4 p = reinterpret_cast<const float4*>(hits)[i]; h0.t = p.x; h0.primId = as_int(p.y); h0.instId = as_int(p.z); h0.geomId = as_int(p.w); }
-    const HydraLiteHit hit = hk_traverse<false, COUNT, ALPHA>(bv, s.haveInst != 0, pos, dir, 0.0f, h0, st, c);
-    reinterpret_cast<float4*>(hits)[i] = make_float4(hit.t, as_float(hit.primId), as_float(hit.instId), as_float(hit.geomId));
-    if (COUNT && counters3) {
-      if (carry) { counters3[3 * i] += c.quads; counters3[3 * i + 1] += c.insts; counters3[3 * i + 2] += c.tris; }
-      else { counters3[3 * i] = c.quads; counters3[3 * i + 1] = c.insts; counters3[3 * i + 2] = c.tris; }
-    }
-    if (COUNT && totals5) {   // algorithmic-work counters for the roofline byte model
-      if (!carry) atomicAdd(totals5 + 0, 1ull);
-      atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
-      atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
-      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
-    }
-  }
-}
-
-// T2 -- any-hit visibility: origin xyz | t_far, direction xyz (kernel_ShadowTrace)
-template <bool COUNT>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(SceneDev s, SegQ q,
-                                                            const float4* __restrict__ org4, const float4* __restrict__ dir4, float* __restrict__ vis,
-                                                            unsigned long long* __restrict__ totals5) {
-  __shared__ int ldsStack[HK_LDS_DEPTH * HK_TRACE_BLOCK];
-  const SegIter it = segq_iter(q);
-  HkStack st;
-  st.init(ldsStack, threadIdx.x);
-  const BvhView bv = make_bvh_view(s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
-  for (int idx = it.first; idx < it.count; idx += it.step) {
-    const int i = it.base + idx;
-    const float4 o = org4[i];
-    float v = 0.0f;
-    if (o.w >= 0.0f) {   // t_far < 0 marks "no light sample": shadow = 0 (PT_Loop.cpp:175-178)
-      HydraLiteHit h = hk_miss_hit();
-      h.t = o.w;
-      TravCounters c = {0, 0, 0, 0, 0};
-      h = hk_traverse<true, COUNT>(bv, s.haveInst != 0, xyz(o), xyz(dir4[i]), 0.0f, h, st, c);
-      v = (h.primId != -1) ? 0.0f : 1.0f;
-      if (COUNT && totals5) {
-        atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
-        atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
-      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
-      }
-    }
-    vis[i] = v;
-  }
-}
-
-// T1/T2, persistent form: every lane that finishes its ray immediately fetches the next one from a device-side counter
-// (one atomic per wave per refill), and a wave whose active-lane count drops below `minActive` suspends traversal to
-// refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
-// written by ray index, so they are identical to the one-ray-per-lane kernels above.
-template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
-                                                               const float4* __restrict__ a4, const float4* __restrict__ b4,
-                                                               float4* __restrict__ outHits, float* __restrict__ outVis,
-                                                               unsigned long long* __restrict__ totals5, int minActive, int raysPerLane) {
-  constexpr int LDS_DEPTH = (ANYHIT && !COUNT) ? HK_LDS_DEPTH_SHADOW : HK_LDS_DEPTH;
-  __shared__ int ldsStack[LDS_DEPTH * HK_TRACE_BLOCK];
-  __shared__ float4 ldsTop[HK_TOP_QUADS * HK_TOP_STRIDE];
-  __shared__ float4 ldsTri[TOPTRIS ? HK_TOP_TRIS * 3 : 1];   // the LDS-staged triangle packets: the leaves rays visit most (chosen at upload)
-  const SegIter it = segq_iter(q);
-  const int count = it.count, segBase = it.base;
-  // the live count is only known on the device: when it is small, let only the first blocks of the segment take part so
-  // that every lane still gets ~raysPerLane rays to refill from (a thinly spread queue degenerates to one ray per lane)
-  if ((int(blockIdx.x) / q.nseg) * (HK_TRACE_BLOCK * raysPerLane) >= count) return;
-  uint32_t* fetchCounter = fetchCounters + it.seg * HK_CSTRIDE;
-  HkStackT<LDS_DEPTH> st;
-  st.init(ldsStack, threadIdx.x);
-  // the hottest quads of the tree (chosen at upload) go to LDS once per block; the node copy walked here names them by slot
-  const bool useTop = (s.topCount > 0);
-  if (useTop) {
-    for (int i = threadIdx.x; i < s.topCount * 8; i += HK_TRACE_BLOCK) ldsTop[(i >> 3) * HK_TOP_STRIDE + (i & 7)] = s.bvhTop[size_t(s.topQuads[i >> 3]) * 8 + (i & 7)];
-    if (TOPTRIS) for (int i = threadIdx.x; i < s.topTriCount * 3; i += HK_TRACE_BLOCK) ldsTri[i] = s.tris[s.topTriF4[i]];
-    __syncthreads();
-  }
-  BvhView bv = make_bvh_view(useTop ? s.bvhTop : s.bvh, s.bvhBytes, s.tris, s.trisBytes, s.leafEnc != 0);
-  bv.top = (const hk_lds_f4*)ldsTop;
-  bv.topTri = (const hk_lds_f4*)ldsTri;
-  if (ALPHA) { bv.alpha = s.alpha; bv.texTable = s.texTable; bv.texStorage = s.texStorage; bv.srgbLut = s.srgbLut; }
-  const int rootLink = useTop ? (HK_TOP_FLAG | 0) : 1;
-  TravState t;
-  TravCounters c = {0, 0, 0, 0, 0};
-  int rayIdx = -1;
-  bool busy = false, queueEmpty = false;
-  const int lane = int(__lane_id());
-  const bool haveInst = s.haveInst != 0;
-  while (true) {
-    if (!queueEmpty) {
-      const unsigned long long mask = __ballot(!busy);
-      if (mask != 0ull) {
-        const int n = __popcll(mask), leader = __ffsll((long long)mask) - 1;
-        int base = 0;
-        if (lane == leader) base = int(atomicAdd(fetchCounter, uint32_t(n)));
-        base = __shfl(base, leader);
-        if (!busy) {
-          const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-          if (idx < count) {
-            const float4 a = a4[segBase + idx];
-            HydraLiteHit h = hk_miss_hit();
-            bool skip = false;
-            if (ANYHIT) { h.t = a.w; skip = (a.w < 0.0f); }   // t_far < 0: no light sample => shadow = 0
-            if (skip) outVis[segBase + idx] = 0.0f;
-            else {
-              trav_init(t, xyz(a), xyz(b4[segBase + idx]), h, rootLink);
-              if (COUNT) { c.quads = c.insts = c.tris = c.leaves = c.oob = 0; }
-              rayIdx = segBase + idx;
-              busy = true;
-            }
-          }
-        }
-        if (base + n >= count) queueEmpty = true;   // wave-uniform
-      }
-    }
-    if (__ballot(busy) == 0ull) break;
-    if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
-      if (done) {
-        if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
-        else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
-        if (COUNT && totals5) {
-          atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
-          atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
-      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
-        }
-        busy = false;
-      }
-    }
-  }
-}
-
-// ---- per-path phases shared by the split (k_hit + k_shade) and the fused (k_bounce) kernels
-struct LightPick {
-  f3 shadowRayDir, color;
-  float pdfSigned;       // light pdf, negative when the sample is a point light
-  float pickProb;
-  int lightOffset;       // < 0: no light sampled
-  float4 shadowOrg;      // shadow ray origin xyz | t_far (t_far < 0: no shadow ray)
-};
-
-// H1 + E1 + E2 -- surface, environment/emission with MIS, termination (kernel_HitEnvironment, kernel_EvalSurface,
-// kernel_EvalEmission).  Returns true when the path goes on (surf valid); false when it ended with radiance `finalColor`.
-// `td` / `instInv`: the triangle record and the instance matrix of the hit, fetched by the caller (valid when HitSome(hit))
-template <int F = HK_FEAT_ALL>
-HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                               const HydraLiteHit& hit, const TriData& td, const m44& instInv, SurfaceHit& surf, f3& finalColor) {
-  const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
-  const uint32_t flags = uint32_t(as_int(dir4.w));
-  f3 currColor = mk3(0, 0, 0);
-  bool done = false;
-  if (!HitSome(hit)) {              // kernel_HitEnvironment, PT_Loop.cpp:23-33
-    currColor = environmentColor<F>(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
-    done = true;
-  }
-  else {
-    surf = evalSurfaceWith(s, ray_pos, ray_dir, hit, td, instInv);
-    const float* mat = materialAt(s, surf.matId);
-    const int lightOffset0 = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
-    const float* pLightHit = lightAt(s, lightOffset0);
-    const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
-    if (dot(emission, emission) > 1e-3f) {
-      if (pLightHit != nullptr) {
-        const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
-        float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
-        if (acc4.w != 0.0f) misWeight = 1.0f;
-        currColor = emission * misWeight;
-      } else
-        currColor = emission;
-      done = true;
-    } else if (depth >= maxDepth - 1) done = true;
-  }
-  if (done) {
-    finalColor = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
-    return false;
-  }
-  return true;
-}
-
-template <int F = HK_FEAT_ALL>
-HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
-  TriData td;
-  m44 instInv;
-  if (HitSome(hit)) { instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4); td = fetchTri(s, hit); }
-  return surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
-}
-
-// L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample)
-template <int F = HK_FEAT_ALL>
-HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& gen, LightPick& lp) {
-  const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
-  lp.pickProb = 1.0f;
-  lp.lightOffset = SelectRandomLightRev(rl.z, s, lp.pickProb);
-  lp.shadowRayDir = mk3(0, 0, 0);
-  lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
-  ShadowSample sam;
-  sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
-  if (lp.lightOffset >= 0) {
-    LightSampleRev<F>(s, lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // clight.h:1561-1610
-    lp.shadowRayDir = normalize(sam.pos - surf.pos);
-    const f3 shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, lp.shadowRayDir, surf.sRayOff);
-    lp.shadowOrg = mk4(shadowRayPos, length(shadowRayPos - sam.pos) * 0.995f);
-  }
-  lp.color = sam.color;
-  lp.pdfSigned = sam.isPoint ? -sam.pdf : sam.pdf;
-}
-
-// S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
-template <int F = HK_FEAT_ALL>
-HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir,
-                                  const f3 shadowRayDir, const f3 lightColor, const float pdfSigned, const float lightPickProb) {
-  const f3 surfNormal = surf.normal;
-  ShadeContext sc;
-  sc.l = shadowRayDir; sc.v = ray_dir * (-1.0f); sc.n = surfNormal; sc.tc = surf.texCoord;
-  if (F & (HK_FEAT_NMAP | HK_FEAT_ANISO)) { sc.fn = surf.flatNormal; sc.tg = surf.tangent; sc.bn = surf.biTangent; }
-  const BxDFResult ev = materialEval<F>(mat, sc, s);
-  const float cos1 = fmaxf(+dot(shadowRayDir, surfNormal), 0.0f), cos2 = fmaxf(-dot(shadowRayDir, surfNormal), 0.0f);
-  const f3 bxdfVal = (ev.brdf * cos1) + (ev.btdf * cos2);
-  const float samPdf = fabsf(pdfSigned);
-  float misWeight = misWeightHeuristic(samPdf * lightPickProb, ev.pdfFwd);
-  if (pdfSigned < 0.0f) misWeight = 1.0f;
-  const f3 lc = lightColor * (1.0f / fmaxf(samPdf, HK_DEPSILON2));
-  return ((lc * (1.0f / lightPickProb)) * bxdfVal) * misWeight;
-}
-
-// S2 -- BSDF sampling of the next bounce (kernel_NextBounce); `accum` is the radiance carried on
-template <int F = HK_FEAT_ALL>
-HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
-                              const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
-  float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
-  {
-    const float4 r4 = rndFloat4_Pseudo(gen);
-    rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
-    for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
-  }
-  MatSample ms;
-  MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, flags, s, ms);
-  const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
-  const float cosTheta = fabsf(dot(ms.direction, surf.normal));
-  const f3 newPos = OffsRayPos(surf.pos, surf.normal, ms.direction);
-  const bool isSpec = ((ms.flags & HRE_S) != 0 || (ms.flags & HRE_T) != 0);
-  flags = flagsNextBounceLite(flags, ms, s);
-  const f3 thr = xyz(thr4) * (bxdfVal * cosTheta);
-  oPos = mk4(newPos, gidBits);
-  oDir = mk4(ms.direction, as_float(int(flags)));
-  oThr = mk4(thr, ms.pdf);
-  oAcc = mk4(accum, isSpec ? 1.0f : 0.0f);
-}
-
-// Split form, kernel 1 of 2: hit phase, survivors compacted into M
-HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ nextCounts,
-                       uint32_t* __restrict__ shadowCounts, int depth, int maxDepth, const PathState& S,
-                       const HydraLiteHit* __restrict__ hits, const MidState& M,
-                       float4* __restrict__ contrib, uint2* __restrict__ gens) {
-  const SegIter it = segq_iter(q);
-  const int count = it.count;
-  uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
-  int shadowRaysOfWave = 0;   // statistic only: one atomic per wave at the end instead of one per iteration
-  for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {   // idx0 is block-uniform: every wave runs the ballots
-    const int idx = idx0 + int(threadIdx.x);
-    const int i = it.base + idx;
-    bool alive = false;
-    float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
-    RandomGen gen; gen.x = gen.y = 0;
-    SurfaceHit surf;
-    LightPick lp;
-    lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
-    if (idx < count) {
-      pos4 = S.pos4[i]; dir4 = S.dir4[i]; thr4 = S.thr4[i]; acc4 = S.acc4[i];
-      const uint2 g2 = S.rng2[i];
-      gen.x = g2.x; gen.y = g2.y;
-      const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
-      HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
-      f3 finalColor;
-      alive = surface_phase(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
-      if (!alive) {
-        const int gid = as_int(pos4.w);
-        contrib[gid] = mk4(finalColor, 0.0f);
-        gens[gid] = make_uint2(gen.x, gen.y);
-      } else
-        light_phase(s, surf, gen, lp);
-    }
-    const int dst = it.base + wave_compact_index(alive, nextCount);
-    shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
-    if (alive) {
-      M.dir4[dst] = dir4; M.thr4[dst] = thr4; M.acc4[dst] = acc4; M.rng2[dst] = make_uint2(gen.x, gen.y);
-      M.surfA[dst] = mk4(surf.pos, as_float(surf.matId));
-      M.surfB[dst] = mk4(surf.normal, surf.texCoord.x);
-      M.recC[dst] = mk4(lp.shadowRayDir, surf.texCoord.y);
-      M.recD[dst] = mk4(lp.color, lp.pdfSigned);
-      M.recE[dst] = make_float4(lp.pickProb, as_float(lp.lightOffset), pos4.w, surf.hfi ? 1.0f : 0.0f);   // hit-from-inside: the glass BxDF needs it
-      M.shadowOrg[dst] = lp.shadowOrg;
-    }
-  }
-  if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
-}
-
-// W = minimum waves per SIMD the register allocator must leave room for (256-thread blocks): 3 => 152 VGPRs, no spills;
-// 4 => 128 VGPRs with a dozen spilled dwords but a third more waves to hide the dependent gathers (measured in DESIGN.md 6)
-template <int W>
-__global__ void __launch_bounds__(256, W) k_hit(SceneDev s, SegQ q, uint32_t* __restrict__ nextCount,
-                                                 uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
-                                                 const HydraLiteHit* __restrict__ hits, MidState M,
-                                                 float4* __restrict__ contrib, uint2* __restrict__ gens) {
-  k_hit_body(s, q, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
-}
-
-// Split form, kernel 2 of 2 (after the shadow rays): next-event shading and BSDF sampling of the next bounce
-HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, const PathState& S) {
-  const SegIter it = segq_iter(q);
-  for (int idx = it.first; idx < it.count; idx += it.step) {
-    const int i = it.base + idx;
-    const float4 dir4 = M.dir4[i], thr4 = M.thr4[i], acc4 = M.acc4[i];
-    const float4 sa = M.surfA[i], sb = M.surfB[i], rc = M.recC[i], rd = M.recD[i], re = M.recE[i];
-    const uint2 g2 = M.rng2[i];
-    RandomGen gen; gen.x = g2.x; gen.y = g2.y;
-    const f3 ray_dir = xyz(dir4);
-    SurfaceHit surf;
-    surf.pos = xyz(sa); surf.matId = as_int(sa.w); surf.normal = xyz(sb); surf.texCoord = mk2(sb.w, rc.w);
-    surf.hfi = (re.w != 0.0f);
-    surf.flatNormal = surf.normal; surf.tangent = mk3(0, 0, 0); surf.biTangent = mk3(0, 0, 0); surf.t = 0.0f; surf.sRayOff = 0.0f;   // not read after the hit phase
-    const float* mat = materialAt(s, surf.matId);
-    f3 explicitColor = mk3(0, 0, 0);
-    if (as_int(re.y) >= 0) explicitColor = direct_light_unoccluded<HK_FEAT_CLASSIC>(s, mat, surf, ray_dir, xyz(rc), xyz(rd), rd.w, re.x) * M.vis[i];   // the split form carries no tangent frame: scenes with normal maps use the fused kernel
-    const f3 accum = xyz(acc4) + (xyz(thr4) * explicitColor);
-    float4 oPos, oDir, oThr, oAcc;
-    next_bounce_phase<HK_FEAT_CLASSIC>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, accum, re.z, oPos, oDir, oThr, oAcc);
-    S.pos4[i] = oPos; S.dir4[i] = oDir; S.thr4[i] = oThr; S.acc4[i] = oAcc;
-    S.rng2[i] = make_uint2(gen.x, gen.y);
-  }
-}
-
-template <int W>
-__global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M, PathState S) {
-  k_shade_body(s, q, M, S);
-}
-
-// Fused form: one kernel per bounce does hit + light sample + unoccluded next-event estimate + BSDF sampling and writes
-// the next path state straight into the other S buffer.  The light term waits as `pend` = throughput * estimate until
-// the shadow kernel has produced vis; the NEXT k_bounce (which every survivor passes through) adds pend * vis first.
-// vis is 0 or 1, so acc + (thr * X) * vis has the bits of the split form's acc + thr * (X * vis).  Per path-bounce
-// this moves 228 B through HBM instead of 504 B and drops one launch (no M record).
-struct ShadowQ { float4* org4; float4* dir4; float* vis; };
-
-// LDS staging of the scene's small hot tables (SceneDev::matBase ... texTable): sizes in 16-byte units, all zero = leave them in
-// global memory (tables too large for HK_SCENE_LDS_MAX_BYTES per block, or option "scene_tables_in_lds" 0)
-struct SceneStage { int matF4, matTabF4, lightsF4, texTabF4, hdrF4, lselF4, triBaseF4, instLightF4, instMatF4; const float4* img; };
-#define HK_SORT_BINS 16
-#define HK_SCENE_LDS_MAX_BYTES (44 * 1024)   // + 5.3 KB of sort arrays, x 3 resident 256-thread blocks per CU = 148 of the CU's 160 KB
-// STG (compile time): bit 0 = the material group is staged (material arena, material-id table, lights, texture-id table, the scalar
-// header and the light-selection table), bit 1 = the path group (triBase, per-instance light ids and matrices).  The pointers of a
-// staged group are re-pointed UNCONDITIONALLY, so that the compiler sees every access through them start at the LDS array and
-// emits ds_read instead of flat_load: a flat load is routed through the CU's vector-memory address path, the very unit this
-// kernel saturates, and waits on vmcnt and lgkmcnt together, i.e. for every global load in flight as well.
 // The staged tables gathered into one array in the order of the LDS copy (k_build_stage_image, once per pass): a block then fills
 // its LDS from ONE contiguous range with four loads in flight per thread, instead of choosing among nine sources per float4.
 __global__ void k_build_stage_image(SceneDev s, SceneStage st, float4* __restrict__ img) {
@@ -519,207 +85,6 @@ __global__ void k_build_stage_image(SceneDev s, SceneStage st, float4* __restric
     img[i] = v;
   }
 }
-template <int STG>
-HK_DEV void stage_scene_tables(SceneDev& s, const SceneStage st, float4* lds) {
-  if (STG == 0) return;
-  const int n0 = st.matF4, n1 = n0 + st.matTabF4, n2 = n1 + st.lightsF4, n3 = n2 + st.texTabF4, n3a = n3 + st.hdrF4, n3b = n3a + st.lselF4;
-  const int n4 = n3b + st.triBaseF4, n5 = n4 + st.instLightF4, n6 = n5 + st.instMatF4;
-  const float4* __restrict__ img = st.img;
-  const int B = int(blockDim.x);
-  int i = int(threadIdx.x);
-  for (; i + 3 * B < n6; i += 4 * B) {
-    const float4 v0 = img[i], v1 = img[i + B], v2 = img[i + 2 * B], v3 = img[i + 3 * B];
-    lds[i] = v0; lds[i + B] = v1; lds[i + 2 * B] = v2; lds[i + 3 * B] = v3;
-  }
-  for (; i < n6; i += B) lds[i] = img[i];
-  __syncthreads();
-  if (STG & 1) {
-    s.matBase = reinterpret_cast<const float*>(lds);
-    s.matTable = reinterpret_cast<const int*>(lds + n0);
-    s.lightsBase = reinterpret_cast<const float*>(lds + n1);   // lightsF4 == 0: never dereferenced (no light ids exist)
-    s.texTable = reinterpret_cast<const int*>(lds + n2);
-    s.hdr = reinterpret_cast<const int*>(lds + n3);
-    s.lselRev = reinterpret_cast<const float*>(lds + n3a);
-  }
-  if (STG & 2) {
-    s.triBase = reinterpret_cast<const int*>(lds + n3b);
-    s.instLightInstId = reinterpret_cast<const int*>(lds + n4);
-    s.instMatrices = lds + n5;
-  }
-}
-#ifdef HK_EXP_BOUNCE_STAMPS   /* timing experiment (tools/bounce_stamps.py): s_memtime at the phase boundaries of k_bounce, summed per wave */
-__device__ unsigned long long hk_bounce_stamps[16];
-extern "C" int hydra_hip_debug_bounce_stamps(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hk_bounce_stamps), sizeof(hk_bounce_stamps)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hk_bounce_stamps), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#define HK_STAMP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); stampAcc[k] += now_ - stampT; stampT = now_; }
-#else
-#define HK_STAMP(k)
-#endif
-#ifndef HK_BOUNCE_BLOCK
-#define HK_BOUNCE_BLOCK 256   // threads per block of the fused bounce kernel (only wave-level cooperation inside: any multiple of 64 works)
-#endif
-template <int W, int F = HK_FEAT_ALL, int STG = 0>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*); STG: see stage_scene_tables
-__global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, SceneStage stage, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
-                                                    int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
-                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens, int sortPaths) {
-  extern __shared__ float4 hk_scene_lds[];
-  // workgroup-local grouping of the paths by shading class (sortPaths): counts per wave and class, slot offsets, permutation
-  constexpr int NW = HK_BOUNCE_BLOCK / 64;
-  static_assert(NW * HK_SORT_BINS <= 64, "the offset scan of the path grouping runs in one wave");
-  __shared__ int sCnt[NW][HK_SORT_BINS];
-  __shared__ int sOff[HK_SORT_BINS][NW];
-  __shared__ unsigned short sPerm[HK_BOUNCE_BLOCK];
-  __shared__ float4 sHit[HK_BOUNCE_BLOCK];   // the hit records travel with the permutation: no second fetch, and the triangle fetch can leave with the state loads
-  SceneDev s = sArg;
-#ifdef HK_EXP_BOUNCE_STAMPS
-  unsigned long long stampAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stampT = __builtin_readcyclecounter();
-#endif
-  const SegIter it = segq_iter(q);
-  const int count = it.count;
-  if (it.first - int(threadIdx.x) >= count) return;   // block-uniform: nothing in this block's stride (late bounces leave most of the grid idle) -- before the tables are staged
-  stage_scene_tables<STG>(s, stage, hk_scene_lds);
-  uint32_t* nextCount = nextCounts + it.seg * HK_CSTRIDE;
-  int shadowRaysOfWave = 0;
-  HK_STAMP(0)
-  for (int idx0 = it.first - int(threadIdx.x); idx0 < count; idx0 += it.step) {
-    // Which path of this 256-path chunk the thread shades.  Closest hits arrive labelled with the shading class of their
-    // material (hk_trace.h, HK_CLASS_SHIFT): a counting sort of the chunk by class through LDS hands every wave paths that
-    // run the same code (after the first bounce a wave otherwise holds every material of the scene and pays for each of them
-    // in turn).  State is read and survivors are written by path index as before, so nothing but the order inside a chunk changes.
-    int src = int(threadIdx.x);
-    float4 h4 = make_float4(0.0f, as_float(-1), as_float(-1), 0.0f);
-    if (idx0 + src < count) h4 = reinterpret_cast<const float4*>(hits)[it.base + idx0 + src];
-    if (sortPaths) {
-      const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63;
-      int key = HK_SORT_BINS - 1;                             // past the end of the queue
-      if (idx0 + src < count) {
-        const int cls = HK_GEOM_CLASS(as_int(h4.w));
-        key = (as_int(h4.y) == -1) ? 0 : (cls != 0 ? (cls < HK_SORT_BINS - 2 ? cls : HK_SORT_BINS - 2) : HK_SORT_BINS - 2);
-      }
-      int rank = 0;
-      for (int b = 0; b < HK_SORT_BINS; b++) {
-        const unsigned long long m = __ballot(key == b);
-        if (key == b) rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) sCnt[wave][b] = __popcll(m);
-      }
-      __syncthreads();
-      if (wave == 0) {                                         // exclusive scan in class-major, wave-minor order
-        const int b = lane / NW, w = lane % NW;
-        const int v = (lane < NW * HK_SORT_BINS) ? sCnt[w][b] : 0;
-        int incl = v;
-        for (int d = 1; d < 64; d <<= 1) { const int n = __shfl_up(incl, d); if (lane >= d) incl += n; }
-        if (lane < NW * HK_SORT_BINS) sOff[b][w] = incl - v;
-      }
-      __syncthreads();
-      const int slot = sOff[key][wave] + rank;
-      sPerm[slot] = (unsigned short)threadIdx.x;
-      sHit[slot] = h4;
-      __syncthreads();
-      src = int(sPerm[threadIdx.x]);
-      h4 = sHit[threadIdx.x];
-    }
-    HK_STAMP(1)
-    const int idx = idx0 + src;
-    const int i = it.base + idx;
-    bool alive = false;
-    float4 oPos = make_float4(0, 0, 0, 0), oDir = oPos, oThr = oPos, oAcc = oPos, oPend = oPos, oShDir = oPos;
-    RandomGen gen; gen.x = gen.y = 0;
-    LightPick lp;
-    lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
-    float4 pos4 = make_float4(0, 0, 0, 0), dir4 = pos4, thr4 = pos4, acc4 = pos4;
-    SurfaceHit surf;
-    f3 finalColor = mk3(0, 0, 0);
-    if (idx < count) {
-      pos4 = Sin.pos4[i]; dir4 = Sin.dir4[i]; thr4 = Sin.thr4[i]; acc4 = Sin.acc4[i];
-      if (depth > 0) {   // settle the previous bounce's next-event estimate
-        const float4 pend = Sin.pend4[i];
-        const float vis = sh.vis[i];
-        acc4.x = acc4.x + pend.x * vis; acc4.y = acc4.y + pend.y * vis; acc4.z = acc4.z + pend.z * vis;
-      }
-      const uint2 g2 = Sin.rng2[i];
-      gen.x = g2.x; gen.y = g2.y;
-      HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
-      // the triangle record and the instance matrix are requested here, behind the state loads and before anything waits for those:
-      // one round trip to memory for both instead of two in a row
-#ifdef HK_EXP_BOUNCE_PRELOAD
-      TriData td;
-      m44 instInv;
-      if (HitSome(hit)) { instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4); td = fetchTri(s, hit); }
-#endif
-#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 4)   /* timing experiment (profiles/r01/pass_bounce_phase_cost.log): phases left out, results invalid */
-      alive = true; surf.pos = xyz(pos4); surf.normal = mk3(0, 1, 0); surf.flatNormal = surf.normal; surf.tangent = mk3(1, 0, 0); surf.biTangent = mk3(0, 0, 1);
-      surf.texCoord = mk2(0, 0); surf.matId = 0; surf.t = hit.t; surf.sRayOff = 0.0f; surf.hfi = false;
-#else
-#ifdef HK_EXP_BOUNCE_PRELOAD
-      alive = surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
-#else
-      alive = surface_phase<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
-#endif
-#endif
-    }
-    // the slot of the survivor is reserved as soon as survival is known: the returning atomic then overlaps the light and
-    // material fetches below instead of standing alone at the end of the iteration
-    HK_STAMP(2)
-    // issued here, read just before the stores: the atomic's round trip runs under the light and material work
-    const unsigned long long aliveMask = __ballot(alive);
-    const int aliveLeader = aliveMask != 0ull ? __ffsll((long long)aliveMask) - 1 : 0;
-    int slotBase = 0;
-    if (aliveMask != 0ull && int(__lane_id()) == aliveLeader) slotBase = int(atomicAdd(nextCount, uint32_t(__popcll(aliveMask))));
-    HK_STAMP(3)
-    if (idx < count) {
-      if (!alive) {
-        const int gid = as_int(pos4.w);
-        contrib[gid] = mk4(finalColor, 0.0f);
-        gens[gid] = make_uint2(gen.x, gen.y);
-      } else {
-#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 1)
-        lp.lightOffset = -1; lp.shadowRayDir = mk3(0, 1, 0); lp.color = mk3(0, 0, 0); lp.pdfSigned = 1.0f; lp.pickProb = 1.0f;
-#else
-        light_phase<F>(s, surf, gen, lp);
-#endif
-        HK_STAMP(4)
-        const float* mat = materialAt(s, surf.matId);
-        const f3 ray_dir = xyz(dir4);
-        f3 pend = mk3(0, 0, 0);
-        if (lp.lightOffset >= 0)
-          pend = xyz(thr4) * direct_light_unoccluded<F>(s, mat, surf, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb);
-        oPend = mk4(pend, 0.0f);
-        oShDir = mk4(lp.shadowRayDir, 0.0f);
-        HK_STAMP(5)
-#if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
-        oPos = mk4(surf.pos, pos4.w); oDir = dir4; oThr = thr4; oAcc = acc4;
-#else
-        next_bounce_phase<F>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
-#endif
-      }
-    }
-#ifdef HK_EXP_BOUNCE_EXTRA_VALU   /* timing experiment: N dependent multiply-adds per path, result parked in the unused pend4.w */
-    {
-      float x = oThr.x;
-      for (int rep = 0; rep < HK_EXP_BOUNCE_EXTRA_VALU; rep++) { asm volatile("" : "+v"(x)); x = x * 1.0001f + 0.5f; }
-      oPend.w = x;
-    }
-#endif
-    HK_STAMP(6)
-    shadowRaysOfWave += __popcll(__ballot(alive && lp.shadowOrg.w >= 0.0f));
-    const int dst = it.base + __builtin_amdgcn_readlane(slotBase, aliveLeader) + __popcll(aliveMask & ((1ull << __lane_id()) - 1ull));
-    if (alive) {
-      Sout.pos4[dst] = oPos; Sout.dir4[dst] = oDir; Sout.thr4[dst] = oThr; Sout.acc4[dst] = oAcc;
-      Sout.rng2[dst] = make_uint2(gen.x, gen.y);
-      Sout.pend4[dst] = oPend;
-      sh.org4[dst] = lp.shadowOrg; sh.dir4[dst] = oShDir;
-    }
-    HK_STAMP(7)
-  }
-  if (shadowRaysOfWave > 0 && __lane_id() == 0) atomicAdd(shadowCounts + it.seg * HK_CSTRIDE, uint32_t(shadowRaysOfWave));
-#ifdef HK_EXP_BOUNCE_STAMPS
-  if (__lane_id() == 0) { for (int k = 0; k < 8; k++) atomicAdd(&hk_bounce_stamps[k], stampAcc[k]); atomicAdd(&hk_bounce_stamps[8], 1ull); }
-#endif
-}
-
 // F1 -- framebuffer accumulate: sums, mean on readout (SURVEY.md row a/F1; CPU reference keeps a running mean, Common.cpp:283,303)
 // one thread per owned pixel adds the `streams` samples of this sub-pass in stream order, so the sum does not depend on
 // where the paths lived in the queues
@@ -732,6 +97,17 @@ __global__ void k_accumulate(int n, const int* __restrict__ ownedPixels, const f
       a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
     }
     accum[pixel] = a;
+  }
+}
+// P0 readout -- IntegratorCommon::GetImageToLDR (Common.cpp:319-333): mean = sums / spp, ToneMapping4 (clamp to 1, cglobals.h:697-724),
+// linearToSRGB (cglobals.h:3032-3038: the pow in float, the scale and offset in double), RealColorToUint32 (truncation)
+__global__ void k_ldr(int n, const float4* __restrict__ accum, float invSpp, uint32_t* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 a = accum[i];
+    float ch[4] = {fminf(a.x * invSpp, 1.0f), fminf(a.y * invSpp, 1.0f), fminf(a.z * invSpp, 1.0f), fminf(a.w * invSpp, 1.0f)};
+    for (int k = 0; k < 3; k++) ch[k] = (ch[k] <= 0.00313066844250063f) ? ch[k] * 12.92f : float(1.055 * double(powf(ch[k], 1.0f / 2.4f)) - 0.055);
+    const unsigned char r = (unsigned char)(ch[0] * 255.0f), g = (unsigned char)(ch[1] * 255.0f), b = (unsigned char)(ch[2] * 255.0f), al = (unsigned char)(ch[3] * 255.0f);
+    out[i] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | (uint32_t(al) << 24);
   }
 }
 // multi-GPU exchange (hydra_hip_comm_gather_frame): a rank packs the accumulator values of its own pixels, slot order, for the root ...
@@ -918,10 +294,6 @@ __global__ void k_stage_mutate_kelemen(int n, const float* __restrict__ values, 
   if (i >= n) return;
   out[i] = MutateKelemen(values[i], mk2(rands2[i].x, rands2[i].y), p2, p1);
 }
-// ---- IntegratorMMLT::F in wavefront form (hk_bidir.h): one thread per chain between the traversal launches
-// The sub-path rays of a level live in segmented, compacted queues like the path tracer's (SegQ): a ray slot holds origin, direction and its
-// owner (chain * 2 + side, side 1 = light sub-path); a finished sub-path simply appends nothing, so a level traces only the live rays.
-struct MmltRays { float4* pos; float4* dir; int* owner; };
 __global__ void __launch_bounds__(256) k_mmlt_begin(SceneDev s, MmltView v, int nseg, int cap, MmltRays out, uint32_t* __restrict__ outCount) {
   const int seg = int(blockIdx.x) % nseg, bis = int(blockIdx.x) / nseg;
   const int i = (bis * nseg + seg) * int(blockDim.x) + int(threadIdx.x);   // chains are dealt to the segments in chunks of one block
@@ -933,41 +305,6 @@ __global__ void __launch_bounds__(256) k_mmlt_begin(SceneDev s, MmltView v, int 
   if (ca) { out.pos[dc] = cpos; out.dir[dc] = cdir; out.owner[dc] = i * 2; }
   const int dl = seg * cap + wave_compact_index(la, counter);
   if (la) { out.pos[dl] = lpos; out.dir[dl] = ldir; out.owner[dl] = i * 2 + 1; }
-}
-#ifndef HK_MMLT_STEP_W
-#define HK_MMLT_STEP_W 3   /* register budget of the MMLT stage kernels in waves per SIMD */
-#endif
-#ifndef HK_MMLT_CONN_W
-#define HK_MMLT_CONN_W 2   /* k_mmlt_connect_end: 256 registers and no spills beat 168 with 69 spilled dwords (533-552 -> 608 M mutations/s, profiles/r02/mmlt_register_budget.log) */
-#endif
-template <int F>
-__global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
-  const SegIter it = segq_iter(q);
-  uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
-  for (int idx = it.first; idx - int(__lane_id()) < it.count; idx += it.step) {   // whole waves iterate together: the compaction is a wave ballot
-    bool alive = false;
-    float4 npos, ndir;
-    int owner = 0;
-    if (idx < it.count) {
-      const int j = it.base + idx;
-      owner = in.owner[j];
-      const int chain = owner >> 1;
-      alive = (owner & 1) ? mmltLightStep<F>(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir)
-                          : mmltCameraStep<F>(s, v, chain, currDepth, in.pos[j], in.dir[j], hits[j], npos, ndir);
-    }
-    const int dst = it.base + wave_compact_index(alive, counter);
-    if (alive) { out.pos[dst] = npos; out.dir[dst] = ndir; out.owner[dst] = owner; }
-  }
-}
-template <int F>
-__global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < v.n) mmltConnectBegin<F>(s, v, i);
-}
-template <int F>
-__global__ void __launch_bounds__(256, HK_MMLT_CONN_W) k_mmlt_connect_end(SceneDev s, MmltView v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < v.n) mmltConnectEnd<F>(s, v, i);
 }
 // ---- the Markov chains of IntegratorMMLT (hk_bidir.h): one thread per chain
 __global__ void k_mmlt_init_chains(MmltChains c, int seed) {
@@ -1046,6 +383,13 @@ __global__ void k_stage_seed_paths(int n, const float4* __restrict__ pos4, const
   S.rng2[i] = rng2[i];
 }
 
+#ifdef HK_EXP_BOUNCE_STAMPS   /* timing experiment (tools/bounce_stamps.py): the phase stamps of k_bounce, summed over the translation units that instantiate it */
+extern "C" int hydra_hip_debug_bounce_stamps(unsigned long long* out16, int reset) {
+  for (int k = 0; k < 16; k++) out16[k] = 0;
+  return (hk_bounce_stamps_read_lean(out16, reset) || hk_bounce_stamps_read_classic(out16, reset) || hk_bounce_stamps_read_nmap(out16, reset) ||
+          hk_bounce_stamps_read_all(out16, reset) || hk_bounce_stamps_read_all45(out16, reset)) ? -1 : 0;
+}
+#endif
 // ================================================================================================ host side
 struct DevBuf {
   void* p = nullptr;
@@ -1122,6 +466,7 @@ struct hydra_hip_ctx {
   struct MmltRun {
     bool active = false;
     int n = 0, maxD = 0, firstBounce = 0;
+    int w = 0, h = 0;                  // frame the run's images were allocated for (row stride of every splat)
     DevBuf ch, depth, xCur, xNew, out8, image, accum, sum, scaled;
     DevBuf sbDepth, sbImage; unsigned long long sbSamples = 0;   // the SBDPT passes of the same run (hydra_hip_sbdpt_pass)
     DevBuf st, rayPos[2], rayDir[2], rayOwner[2], hits, counts, eyePos, eyeDir, eyeHit, shPos, shDir, shVis;
@@ -1140,6 +485,7 @@ struct hydra_hip_ctx {
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1148,6 +494,8 @@ struct hydra_hip_ctx {
   int commRank = -1, commWorld = 0;
   DevBuf commPacked, commRecv, commPixels;     // this rank's packed pixels; (root) the other ranks' packed pixels and their pixel indices
   std::vector<long long> commCount;            // (root) owned pixels per rank
+  int commW = 0, commH = 0, commTile = 0;      // frame and tile size commCount / commPixels / commRecv were built for
+  DevBuf commMeta;                             // [world][4] ints: what every rank is about to send (comm_agree)
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double tTrace = 0, tHit = 0, tShadow = 0, tShade = 0, tRaygen = 0, tAccum = 0, tPass = 0;
   uint64_t nTrace = 0, nShadow = 0;   // launches folded into tTrace / tShadow
@@ -1505,46 +853,37 @@ static int ensure_fetch_counters(hydra_hip_ctx* c) { return dev_alloc(c, c->fetc
 static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree);
 static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* pos4, const float4* dir4,
                            HydraLiteHit* hits, uint32_t* perRay3, unsigned long long* totals5, uint32_t* fetchCounters) {
-  const bool alpha0 = (s.alpha != nullptr);
+  TraceLaunch a;
+  a.stream = c->stream; a.s = s; a.q = q; a.a4 = pos4; a.b4 = dir4; a.hits = hits; a.vis = nullptr;
+  a.perRay3 = perRay3; a.totals5 = totals5; a.fetchCounters = fetchCounters; a.carry = 0; a.minActive = c->traceMinActive; a.raysPerLane = c->traceRaysPerLane;
+  const bool count = (perRay3 != nullptr || totals5 != nullptr);
   if (c->traceMode == 0 || perRay3 != nullptr || fetchCounters == nullptr) {
-    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-#define HK_LAUNCH_STATIC(CNT, AL, SC, CARRY) hipLaunchKernelGGL((k_trace<CNT, AL>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, SC, q, pos4, dir4, hits, perRay3, totals5, CARRY)
-    if (perRay3 || totals5) { if (alpha0) HK_LAUNCH_STATIC(true, true, s, 0); else HK_LAUNCH_STATIC(true, false, s, 0); }
-    else { if (alpha0) HK_LAUNCH_STATIC(false, true, s, 0); else HK_LAUNCH_STATIC(false, false, s, 0); }
+    a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    hk_launch_trace_static(count, s.alpha != nullptr, a);
   } else {
-    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
-    float4* out = reinterpret_cast<float4*>(hits);
-    float* nov = nullptr;
-#define HK_LAUNCH_DYN(CNT, TT, AL) hipLaunchKernelGGL((k_trace_dyn<false, CNT, TT, AL>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, pos4, dir4, out, nov, totals5, c->traceMinActive, c->traceRaysPerLane)
-    if (alpha0) { if (totals5) HK_LAUNCH_DYN(true, false, true); else HK_LAUNCH_DYN(false, false, true); }
-    else if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true, false); else HK_LAUNCH_DYN(false, true, false); }
-    else { if (totals5) HK_LAUNCH_DYN(true, false, false); else HK_LAUNCH_DYN(false, false, false); }
-#undef HK_LAUNCH_DYN
+    a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+    hk_launch_trace_dyn(false, totals5 != nullptr, s.topTriCount > 0, s.alpha != nullptr, a);
   }
   for (int tree = 1; tree < c->treesNum; tree++) {
     if (!c->bvhNodes[tree].p || !c->bvhTris[tree].p) continue;
-    const SceneDev st = make_scene_tree(c, tree);
-    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-    const bool al = (st.alpha != nullptr);
-    if (perRay3 || totals5) { if (al) HK_LAUNCH_STATIC(true, true, st, 1); else HK_LAUNCH_STATIC(true, false, st, 1); }
-    else { if (al) HK_LAUNCH_STATIC(false, true, st, 1); else HK_LAUNCH_STATIC(false, false, st, 1); }
+    a.s = make_scene_tree(c, tree);
+    a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    a.carry = 1;
+    hk_launch_trace_static(count, a.s.alpha != nullptr, a);
   }
-#undef HK_LAUNCH_STATIC
 }
 static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, const float4* org4, const float4* dir4,
                           float* vis, unsigned long long* totals5, uint32_t* fetchCounters) {
+  TraceLaunch a;
+  a.stream = c->stream; a.s = s; a.q = q; a.a4 = org4; a.b4 = dir4; a.hits = nullptr; a.vis = vis;
+  a.perRay3 = nullptr; a.totals5 = totals5; a.fetchCounters = fetchCounters; a.carry = 0; a.minActive = c->traceMinActive; a.raysPerLane = c->traceRaysPerLane;
   if (c->traceMode == 0 || fetchCounters == nullptr) {
-    const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
-    if (totals5) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, org4, dir4, vis, totals5);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, org4, dir4, vis, totals5);
+    a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
+    hk_launch_shadow_static(totals5 != nullptr, a);
     return;
   }
-  const int g = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
-  float4* noh = nullptr;
-#define HK_LAUNCH_DYN(CNT, TT) hipLaunchKernelGGL((k_trace_dyn<true, CNT, TT>), dim3(g), dim3(HK_TRACE_BLOCK), 0, c->stream, s, q, fetchCounters, org4, dir4, noh, vis, totals5, c->traceMinActive, c->traceRaysPerLane)
-  if (s.topTriCount > 0) { if (totals5) HK_LAUNCH_DYN(true, true); else HK_LAUNCH_DYN(false, true); }
-  else { if (totals5) HK_LAUNCH_DYN(true, false); else HK_LAUNCH_DYN(false, false); }
-#undef HK_LAUNCH_DYN
+  a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->traceBlocksPerCU);
+  hk_launch_trace_dyn(true, totals5 != nullptr, s.topTriCount > 0, false, a);
 }
 
 static hipEvent_t next_event(hydra_hip_ctx* c, size_t& cursor);
@@ -1621,37 +960,30 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     int b = mark();
     if (fused) {
       const int sortPaths = (canSort && depth >= c->sortPathsFromDepth) ? 1 : 0;
-      switch (c->shadeWaves) {
-        case 3: {
-          // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
-          // the first three, 16 spilled for the full one)
-          const int f = c->sceneFeatures;
-#define HK_LAUNCH_BOUNCE_W(W_, F, G) hipLaunchKernelGGL((k_bounce<W_, F, G>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), stageBytes, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths)
-#ifndef HK_BOUNCE_W
-#define HK_BOUNCE_W 3   /* register budget of the default variants in waves per SIMD (an experiment build can ask for 4) */
-#endif
-#define HK_LAUNCH_BOUNCE(F) do { switch (stg) { case 3: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 3); break; case 2: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 2); break; case 1: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 1); break; default: HK_LAUNCH_BOUNCE_W(HK_BOUNCE_W, F, 0); break; } } while (0)
-          if (f == 0) HK_LAUNCH_BOUNCE(0);
-          else if ((f & ~HK_FEAT_SKY) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY);
-          else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) HK_LAUNCH_BOUNCE(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR);
-          else if ((f & ~(HK_FEAT_CLASSIC | HK_FEAT_NMAP)) == 0 && (f & HK_FEAT_NMAP)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC | HK_FEAT_NMAP);   // normal maps over the classic set: without the rarer lobes
-          else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ)) HK_LAUNCH_BOUNCE(HK_FEAT_ALL);
-          else if (!(f & HK_FEAT_GLASS)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GLASS);
-          else if (!(f & HK_FEAT_GGX)) HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC & ~HK_FEAT_GGX);
-          else HK_LAUNCH_BOUNCE(HK_FEAT_CLASSIC);
-          break;
-        }
-        // the 4- and 5-wave register budgets exist as experiment switches only: everything staged, or nothing
-        case 5: if (stg == 3) HK_LAUNCH_BOUNCE_W(5, HK_FEAT_ALL, 3); else hipLaunchKernelGGL((k_bounce<5, HK_FEAT_ALL, 0>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
-        default: if (stg == 3) HK_LAUNCH_BOUNCE_W(4, HK_FEAT_ALL, 3); else hipLaunchKernelGGL((k_bounce<4, HK_FEAT_ALL, 0>), dim3(gBounce), dim3(HK_BOUNCE_BLOCK), 0, c->stream, s, stage, qIn, nextCnt, shCnt, depth, maxDepth, bb.A, bb.B, hits, bb.sh, contrib, gens, sortPaths); break;
-      }
+      // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
+      // the lean sets, 16 spilled for the full one); the 4- and 5-wave register budgets (option shade_waves) exist as experiment
+      // switches only: every feature, and everything staged or nothing
+      const int f = c->sceneFeatures;
+      int W = 3, F = HK_FEAT_CLASSIC, G = stg;
+      if (c->shadeWaves != 3) { W = (c->shadeWaves == 5) ? 5 : 4; F = HK_FEAT_ALL; G = (stg == 3) ? 3 : 0; }
+      else if (f == 0) F = 0;
+      else if ((f & ~HK_FEAT_SKY) == 0) F = HK_FEAT_SKY;
+      else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) F = HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR;
+      else if ((f & ~(HK_FEAT_CLASSIC | HK_FEAT_NMAP)) == 0 && (f & HK_FEAT_NMAP)) F = HK_FEAT_CLASSIC | HK_FEAT_NMAP;   // normal maps over the classic set: without the rarer lobes
+      else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ)) F = HK_FEAT_ALL;
+      else if (!(f & HK_FEAT_GLASS)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GLASS;
+      else if (!(f & HK_FEAT_GGX)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GGX;
+      BounceLaunch bl;
+      bl.grid = gBounce; bl.ldsBytes = (G == 0) ? 0 : stageBytes; bl.stream = c->stream; bl.s = s; bl.stage = stage; bl.qIn = qIn; bl.nextCnt = nextCnt; bl.shCnt = shCnt;
+      bl.depth = depth; bl.maxDepth = maxDepth; bl.A = bb.A; bl.B = bb.B; bl.hits = hits; bl.sh = bb.sh; bl.contrib = contrib; bl.gens = gens; bl.sortPaths = sortPaths;
+      if (!(hk_launch_bounce_lean(W, F, G, bl) || hk_launch_bounce_classic(W, F, G, bl) || hk_launch_bounce_nmap(W, F, G, bl) || hk_launch_bounce_all(W, F, G, bl) || hk_launch_bounce_all45(W, F, G, bl)))
+        return fail(c, HYDRA_HIP_ESTATE, "trace_pass: no k_bounce instantiation for register budget " + std::to_string(W) + ", features " + std::to_string(F) + ", staging " + std::to_string(G));
       std::swap(bb.A, bb.B);
     } else {
-      switch (c->shadeWaves) {
-        case 3: hipLaunchKernelGGL(k_hit<3>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
-        case 5: hipLaunchKernelGGL(k_hit<5>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
-        default: hipLaunchKernelGGL(k_hit<4>, dim3(gWide), dim3(256), 0, c->stream, s, qIn, nextCnt, shCnt, depth, maxDepth, S, hits, bb.M, contrib, gens); break;
-      }
+      SplitLaunch sl;
+      sl.grid = gWide; sl.stream = c->stream; sl.s = s; sl.q = qIn; sl.nextCnt = nextCnt; sl.shCnt = shCnt; sl.depth = depth; sl.maxDepth = maxDepth; sl.S = S;
+      sl.hits = hits; sl.M = bb.M; sl.contrib = contrib; sl.gens = gens;
+      hk_launch_hit(c->shadeWaves, sl);
     }
     int d = mark();
     if (depth + 1 < maxDepth) {
@@ -1660,11 +992,10 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       int e = mark();
       if (timing) c->spans.push_back({d, e, 3, depth});
       if (!fused) {
-        switch (c->shadeWaves) {
-          case 3: hipLaunchKernelGGL(k_shade<3>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
-          case 5: hipLaunchKernelGGL(k_shade<5>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
-          default: hipLaunchKernelGGL(k_shade<4>, dim3(gWide), dim3(256), 0, c->stream, s, qOut, bb.M, S); break;
-        }
+        SplitLaunch sl;
+        sl.grid = gWide; sl.stream = c->stream; sl.s = s; sl.q = qOut; sl.nextCnt = nullptr; sl.shCnt = nullptr; sl.depth = depth; sl.maxDepth = maxDepth; sl.S = S;
+        sl.hits = hits; sl.M = bb.M; sl.contrib = contrib; sl.gens = gens;
+        hk_launch_shade(c->shadeWaves, sl);
         int f = mark();
         if (timing) c->spans.push_back({e, f, 4, depth});
       }
@@ -1739,6 +1070,7 @@ int hydra_hip_destroy(hydra_hip_handle c) {
 }
 
 int hydra_hip_comm_destroy(hydra_hip_handle c);
+int hydra_hip_mmlt_end(hydra_hip_handle c);
 const char* hydra_hip_last_error(hydra_hip_handle c) { return c ? c->err.c_str() : g_createError.c_str(); }
 
 int hydra_hip_device_name(hydra_hip_handle c, char* buf, int n) {
@@ -1753,6 +1085,8 @@ int hydra_hip_resize(hydra_hip_handle c, int width, int height) {
   if (width == c->w && height == c->h && c->stateAllocated) return HYDRA_HIP_OK;
   HCHECK(hipSetDevice(c->device));
   HCHECK(hipDeviceSynchronize());
+  (void)hydra_hip_mmlt_end(c);   // its images and splat stride belong to the old frame
+  c->commCount.clear();          // so do the root's pixel lists of the exchange
   c->w = width; c->h = height;
   dev_free(c->accumInternal);
   c->stateAllocated = false; c->gensReady = false;
@@ -2125,7 +1459,11 @@ int hydra_hip_upload_bvh(hydra_hip_handle c, int tree, const HydraBVHNode* nodes
   HCHECK(hipGetLastError());
   if (tree == 0) {   // the copy the persistent kernels walk (tree 0 only): same nodes, links to the quads kept in LDS tagged with their slot
     std::vector<int> poolF4;
-    const std::vector<TopLeaf> topLeaves = (c->leafEnc[tree] && c->topWanted > 0) ? choose_top_leaves(devNodes, have_inst != 0, tri_f4_num, std::min(c->topTrisWanted, HK_TOP_TRIS), poolF4)
+    // no leaf goes to LDS when the tree has an alpha table: the alpha-tested kernels are instantiated without TOPTRIS (the alpha test
+    // indexes the table with the triangle's address in the list, which a pool index is not), and a tagged link read without TOPTRIS
+    // decodes its LDS flag as part of the list offset
+    const bool treeHasAlpha = (alpha != nullptr && alpha_num > 0);
+    const std::vector<TopLeaf> topLeaves = (c->leafEnc[tree] && c->topWanted > 0 && !treeHasAlpha) ? choose_top_leaves(devNodes, have_inst != 0, tri_f4_num, std::min(c->topTrisWanted, HK_TOP_TRIS), poolF4)
                                                                                    : std::vector<TopLeaf>();
     const std::vector<int> top = choose_and_tag_top_quads(devNodes, have_inst != 0, std::min(c->topWanted, HK_TOP_QUADS));
     c->topCount = int(top.size());
@@ -2185,6 +1523,7 @@ int hydra_hip_set_tile_partition(hydra_hip_handle c, int rank, int world, int ti
   if (rank != c->rank || world != c->world || tile != c->tile) c->gensReady = false;   // generator states are kept per OWNED pixel: a new partition restarts the image
   c->rank = rank; c->world = world; c->tile = tile;
   c->stateAllocated = false;
+  c->commCount.clear();   // the root's pixel lists of the exchange follow the partition
   return HYDRA_HIP_OK;
 }
 int hydra_hip_plan_render_state(int width, int height, int rank, int world, int tile_size, int samples_in_flight, int queue_segments, int fused_bounce,
@@ -2332,23 +1671,22 @@ int hydra_hip_get_hdr_image(hydra_hip_handle c, float* rgba, int width, int heig
   parallel_rows(height, [=](int y0, int y1) { for (size_t i = size_t(y0) * width * 4; i < size_t(y1) * width * 4; i++) rgba[i] *= inv; });
   return HYDRA_HIP_OK;
 }
-// IntegratorCommon::GetImageToLDR (Common.cpp:319-333): clamp to 1, linear -> sRGB, pack RGBA8
+// IntegratorCommon::GetImageToLDR (Common.cpp:319-333) on the device (k_ldr): 4 bytes per pixel cross PCIe instead of 16
 int hydra_hip_get_ldr_image(hydra_hip_handle c, uint32_t* out, int width, int height) {
   if (!c || !out) return HYDRA_HIP_EINVAL;
-  std::vector<float> hdr(size_t(width) * height * 4);
-  const int rc = hydra_hip_get_hdr_image(c, hdr.data(), width, height);
+  if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "get_ldr_image: bad input resolution");
+  if (!c->stateAllocated || c->accum == nullptr) return fail(c, HYDRA_HIP_ESTATE, "get_ldr_image: nothing rendered yet");
+  HCHECK(hipSetDevice(c->device));
+  const int npix = width * height;
+  DevBuf d;
+  const int rc = dev_alloc(c, d, size_t(npix) * 4);
   if (rc) return rc;
-  const float* src = hdr.data();
-  parallel_rows(height, [=](int y0, int y1) {
-    auto toSRGB = [](float l) { return (l <= 0.00313066844250063f) ? l * 12.92f : float(1.055 * double(powf(l, 1.0f / 2.4f)) - 0.055); };
-    for (size_t i = size_t(y0) * width; i < size_t(y1) * width; i++) {
-      float ch[4];
-      for (int k = 0; k < 4; k++) ch[k] = fminf(src[4 * i + k], 1.0f);
-      for (int k = 0; k < 3; k++) ch[k] = toSRGB(ch[k]);
-      const unsigned char r = (unsigned char)(ch[0] * 255.0f), g = (unsigned char)(ch[1] * 255.0f), b = (unsigned char)(ch[2] * 255.0f), a = (unsigned char)(ch[3] * 255.0f);
-      out[i] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | (uint32_t(a) << 24);
-    }
-  });
+  hipLaunchKernelGGL(k_ldr, dim3(grid_for(c, npix, 256, 8)), dim3(256), 0, c->stream, npix, (const float4*)c->accum, c->spp > 0.0f ? 1.0f / c->spp : 0.0f, static_cast<uint32_t*>(d.p));
+  const hipError_t e1 = hipGetLastError();
+  const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(out, d.p, size_t(npix) * 4, hipMemcpyDeviceToHost, c->stream) : e1;
+  const hipError_t e3 = hipStreamSynchronize(c->stream);
+  dev_free(d);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, HYDRA_HIP_EDEVICE, "get_ldr_image: a HIP call failed");
   return HYDRA_HIP_OK;
 }
 
@@ -2663,12 +2001,13 @@ static int mmlt_alloc(hydra_hip_ctx* c, TmpBufs& tb, int n, int maxD, MmltBufs& 
 // F for every chain of the view: v.x, v.depth and v.out8 are set by the caller; maxDepth = the largest d among the chains.
 // The stage kernels exist in three feature sets like k_bounce (hk_shading.h, HK_FEAT_*): the sky / delta-light / Oren-Nayar subset, the classic set,
 // everything -- with every BxDF inlined a stage kernel is 47 k vector instructions, most of which a scene like test_42 never runs
-#define HK_MMLT_LAUNCH(K, GRID, ...) do { \
-    const int f_ = c->sceneFeatures; \
-    if ((f_ & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) hipLaunchKernelGGL((K<HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
-    else if ((f_ & ~HK_FEAT_CLASSIC) == 0) hipLaunchKernelGGL((K<HK_FEAT_CLASSIC>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((K<HK_FEAT_ALL>), GRID, dim3(256), 0, c->stream, __VA_ARGS__); \
-  } while (0)
+static int mmlt_launch(hydra_hip_ctx* c, int kernel, MmltLaunch& a) {   // kernel: 0 = k_mmlt_step, 1 = k_mmlt_connect_begin, 2 = k_mmlt_connect_end
+  const int f_ = c->sceneFeatures;
+  const int F = ((f_ & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) ? (HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR) : (((f_ & ~HK_FEAT_CLASSIC) == 0) ? HK_FEAT_CLASSIC : HK_FEAT_ALL);
+  a.stream = c->stream;
+  if (!(hk_launch_mmlt_lean(kernel, F, a) || hk_launch_mmlt_all(kernel, F, a))) return fail(c, HYDRA_HIP_ESTATE, "mmlt: no stage-kernel instantiation for features " + std::to_string(F));
+  return HYDRA_HIP_OK;
+}
 static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int maxDepth) {
   const MmltView& v = b.v;
   const int n = v.n;
@@ -2678,14 +2017,18 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
   HCHECK(hipMemsetAsync(b.counts, 0, size_t(maxDepth + 2) * HK_CROW * 4, c->stream));
   const int bps = ((n + 255) / 256 + b.nseg - 1) / b.nseg;
   hipLaunchKernelGGL(k_mmlt_begin, dim3(bps * b.nseg), dim3(256), 0, c->stream, s, v, b.nseg, b.cap, b.rays[0], b.counts);
+  MmltLaunch ml;
+  ml.s = s; ml.v = v; ml.currDepth = 0; ml.q = seg_q(nullptr, 0, 1, 0); ml.in = b.rays[0]; ml.hits = b.hits; ml.out = b.rays[1]; ml.outCount = b.counts;
   for (int k = 1; k <= maxDepth; k++) {
     const MmltRays in = b.rays[(k - 1) & 1], out = b.rays[k & 1];
     const SegQ q = seg_q(b.counts + size_t(k - 1) * HK_CROW, 0, b.nseg, b.cap);
     HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
     launch_closest(c, s, q, in.pos, in.dir, b.hits, nullptr, nullptr, fetch);
-    HK_MMLT_LAUNCH(k_mmlt_step, dim3(seg_grid(c, q, 256, 64)), s, v, k, q, in, b.hits, out, b.counts + size_t(k) * HK_CROW);
+    ml.grid = seg_grid(c, q, 256, 64); ml.currDepth = k; ml.q = q; ml.in = in; ml.hits = b.hits; ml.out = out; ml.outCount = b.counts + size_t(k) * HK_CROW;
+    if ((rc = mmlt_launch(c, 0, ml))) return rc;
   }
-  HK_MMLT_LAUNCH(k_mmlt_connect_begin, dim3((n + 255) / 256), s, v);
+  ml.grid = (n + 255) / 256;
+  if ((rc = mmlt_launch(c, 1, ml))) return rc;
   // the two connection rays of every chain, as a segmented queue over the chain order (one fetch counter for all persistent waves
   // saturates at ~88 fetches per microsecond: 0.19 ms per launch of 1 M rays, more than their traversal takes)
   const int capC = ((n + b.nseg - 1) / b.nseg + 63) / 64 * 64;
@@ -2696,7 +2039,7 @@ static int mmlt_eval(hydra_hip_ctx* c, const SceneDev& s, const MmltBufs& b, int
   launch_closest(c, s, qc, v.eyePos, v.eyeDir, b.eyeHit, nullptr, nullptr, fetch);
   HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
   launch_shadow(c, s, qc, v.shPos, v.shDir, b.shVis, nullptr, fetch);
-  HK_MMLT_LAUNCH(k_mmlt_connect_end, dim3((n + 255) / 256), s, v);
+  if ((rc = mmlt_launch(c, 2, ml))) return rc;
   HCHECK(hipGetLastError());
   return HYDRA_HIP_OK;
 }
@@ -2725,13 +2068,24 @@ static bool mmlt_camera_ready(const hydra_hip_ctx* c) {   // F projects light-pa
   memcpy(&wf, &c->hostHeader[HG_VARS_F + HV_F_WIDTH_F], 4); memcpy(&hf, &c->hostHeader[HG_VARS_F + HV_F_HEIGHT_F], 4);
   return wf >= 1.0f && hf >= 1.0f;
 }
+// the on-screen test of a splat uses the header's WIDTH_F x HEIGHT_F, the image it lands in is c->w x c->h: they must be the same frame
+static bool header_frame_matches(const hydra_hip_ctx* c) {
+  float wf, hf;
+  memcpy(&wf, &c->hostHeader[HG_VARS_F + HV_F_WIDTH_F], 4); memcpy(&hf, &c->hostHeader[HG_VARS_F + HV_F_HEIGHT_F], 4);
+  return wf == float(c->w) && hf == float(c->h);
+}
+static int mmlt_frame_check(hydra_hip_ctx* c, const char* who) {
+  if (c->mmlt.w != c->w || c->mmlt.h != c->h) return fail(c, HYDRA_HIP_ESTATE, std::string(who) + ": the frame was resized after mmlt_begin");
+  if (!header_frame_matches(c)) return fail(c, HYDRA_HIP_ESTATE, std::string(who) + ": the globals header's HRT_WIDTH_F x HRT_HEIGHT_F is not the layer's frame");
+  return HYDRA_HIP_OK;
+}
 int hydra_hip_mmlt_end(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   auto& m = c->mmlt;
   dev_free(m.sbDepth); dev_free(m.sbImage); m.sbSamples = 0;
   DevBuf* all[] = {&m.ch, &m.depth, &m.xCur, &m.xNew, &m.out8, &m.image, &m.accum, &m.sum, &m.scaled, &m.st, &m.rayPos[0], &m.rayPos[1], &m.rayDir[0], &m.rayDir[1], &m.rayOwner[0], &m.rayOwner[1], &m.hits, &m.counts, &m.eyePos, &m.eyeDir, &m.eyeHit, &m.shPos, &m.shDir, &m.shVis};
   for (DevBuf* b : all) dev_free(*b);
-  m.active = false; m.n = 0; m.mutations = 0;
+  m.active = false; m.n = 0; m.mutations = 0; m.w = 0; m.h = 0;
   return HYDRA_HIP_OK;
 }
 // DoPassEstimateAvgBrightness (:463-520) + the start of every chain (DoPassIndirectMLT :348-356, :371-377)
@@ -2740,6 +2094,7 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
   STAGE_PROLOG(true);
   if (c->w <= 0 || c->h <= 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: set the image size first");
   if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header holds no camera yet (IHWLayer::SetCamMatrices + PrepareEngineGlobals: the caller's Draw does both)");
+  if (!header_frame_matches(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header's HRT_WIDTH_F x HRT_HEIGHT_F is not the layer's frame (ResizeScreen and the header must agree: splats are tested against one and written into the other)");
   const int maxD = max_depth > 0 ? max_depth : c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
   int first = first_bounce > 0 ? first_bounce : c->hostHeader[HG_VARS_I + HV_I_MMLT_FIRST_BOUNCE];
   if (first > 3) first = 3;   // :481-483
@@ -2748,7 +2103,7 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
   if (estimate_passes <= 0) estimate_passes = 4;
   hydra_hip_mmlt_end(c);
   auto& m = c->mmlt;
-  m.n = n; m.maxD = maxD; m.firstBounce = first;
+  m.n = n; m.maxD = maxD; m.firstBounce = first; m.w = c->w; m.h = c->h;
   const size_t N = size_t(n);
   int qseg = 1, qcap = 0;
   mmlt_queue_shape(n, qseg, qcap);
@@ -2814,6 +2169,7 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
 int hydra_hip_mmlt_pass(hydra_hip_handle c, int mutations) {
   if (!c || mutations <= 0) return HYDRA_HIP_EINVAL;
   if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_pass: call mmlt_begin first");
+  { const int frc = mmlt_frame_check(c, "mmlt_pass"); if (frc) return frc; }
   HCHECK(hipSetDevice(c->device));
   auto& m = c->mmlt;
   const MmltChains ch = mmlt_chains(c);
@@ -2832,9 +2188,10 @@ int hydra_hip_mmlt_pass(hydra_hip_handle c, int mutations) {
 }
 // image4 = kScale x the indirect image (GetImageHDR :616-635 without the direct part; kScale = EstimateScaleCoeff :548-552);
 // info8 = average brightness, kScale, acceptance rate, mutations so far, chains, first bounce, max depth, 0
-int hydra_hip_mmlt_get_image(hydra_hip_handle c, float* image4, float* info8) {
+int hydra_hip_mmlt_get_image(hydra_hip_handle c, float* image4, int width, int height, float* info8) {
   if (!c) return HYDRA_HIP_EINVAL;
   if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_get_image: call mmlt_begin first");
+  if (image4 && (width != c->mmlt.w || height != c->mmlt.h || width != c->w || height != c->h)) return fail(c, HYDRA_HIP_EINVAL, "mmlt_get_image: bad input resolution");
   HCHECK(hipSetDevice(c->device));
   auto& m = c->mmlt;
   const int npix = c->w * c->h;
@@ -2863,11 +2220,21 @@ int hydra_hip_mmlt_get_image(hydra_hip_handle c, float* image4, float* info8) {
   }
   return HYDRA_HIP_OK;
 }
+// the indirect image restarts from zero, the chains go on: what a contribution to a shared accumulation image needs (the reference's
+// ClearAccumulatedColor zeroes the image its MMLT pass splats into and leaves the chain state alone, GPUOCLLayer.cpp:1288-1297)
+int hydra_hip_mmlt_reset_image(hydra_hip_handle c) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "mmlt_reset_image: call mmlt_begin first");
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipMemsetAsync(c->mmlt.image.p, 0, size_t(c->mmlt.w) * c->mmlt.h * 16, c->stream));
+  return HYDRA_HIP_OK;
+}
 // IntegratorSBDPT::DoPass (CPUExp_Integrators_SBDPT.cpp:11-216) on the buffers of the MMLT run: `passes` x chains samples, each a path
 // length drawn uniformly from 2..max_depth, a fresh primary-sample vector, F, a splat weighted by (d + 1)(max_depth - 1)
 int hydra_hip_sbdpt_pass(hydra_hip_handle c, int passes) {
   if (!c || passes <= 0) return HYDRA_HIP_EINVAL;
   if (!c->mmlt.active) return fail(c, HYDRA_HIP_ESTATE, "sbdpt_pass: call mmlt_begin first (it owns the buffers and the generators)");
+  { const int frc = mmlt_frame_check(c, "sbdpt_pass"); if (frc) return frc; }
   HCHECK(hipSetDevice(c->device));
   auto& m = c->mmlt;
   int rc;
@@ -2893,9 +2260,10 @@ int hydra_hip_sbdpt_pass(hydra_hip_handle c, int passes) {
   return HYDRA_HIP_OK;
 }
 // image4 = splats x width*height / samples (the reference's m_hdrData / spp with width*height samples per pass, :18-19, :192); samples so far
-int hydra_hip_sbdpt_get_image(hydra_hip_handle c, float* image4, double* samples) {
+int hydra_hip_sbdpt_get_image(hydra_hip_handle c, float* image4, int width, int height, double* samples) {
   if (!c) return HYDRA_HIP_EINVAL;
   if (!c->mmlt.active || c->mmlt.sbImage.p == nullptr) return fail(c, HYDRA_HIP_ESTATE, "sbdpt_get_image: no SBDPT pass has run");
+  if (image4 && (width != c->mmlt.w || height != c->mmlt.h || width != c->w || height != c->h)) return fail(c, HYDRA_HIP_EINVAL, "sbdpt_get_image: bad input resolution");
   HCHECK(hipSetDevice(c->device));
   auto& m = c->mmlt;
   const int npix = c->w * c->h;
@@ -2959,10 +2327,12 @@ __global__ void __launch_bounds__(256) k_gbuffer_resolve(SceneDev s, int w, int 
     }
   }
 }
-int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, const int32_t* inst_remap, int inst_remap_size, float* raw14) {
+int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, int width, int height, const int32_t* inst_remap, int inst_remap_size, float* raw14) {
   if (!c || !data1 || !data2 || inst_remap_size < 0) return HYDRA_HIP_EINVAL;
+  if (width != c->w || height != c->h) return fail(c, HYDRA_HIP_EINVAL, "eval_gbuffer: bad input resolution");
   if (!scene_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: scene is not uploaded");
   if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: the globals header holds no camera yet (SetCamMatrices + PrepareEngineGlobals)");
+  if (!header_frame_matches(c)) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: the globals header's HRT_WIDTH_F x HRT_HEIGHT_F is not the layer's frame");
   HCHECK(hipSetDevice(c->device));
   { const int prc = prepare_geometry(c); if (prc) return prc; }
   { const int vrc = validate_materials(c); if (vrc) return vrc; }
@@ -3209,7 +2579,7 @@ static bool load_rccl(hydra_hip_ctx* c) {
 #define HK_RCCL_SYM(field, name) c->rccl.field = reinterpret_cast<decltype(c->rccl.field)>(sym(name)); if (!c->rccl.field) return false;
   HK_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") HK_RCCL_SYM(CommInitRank, "ncclCommInitRank") HK_RCCL_SYM(CommDestroy, "ncclCommDestroy")
   HK_RCCL_SYM(Reduce, "ncclReduce") HK_RCCL_SYM(Send, "ncclSend") HK_RCCL_SYM(Recv, "ncclRecv") HK_RCCL_SYM(GroupStart, "ncclGroupStart")
-  HK_RCCL_SYM(GroupEnd, "ncclGroupEnd") HK_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+  HK_RCCL_SYM(GroupEnd, "ncclGroupEnd") HK_RCCL_SYM(GetErrorString, "ncclGetErrorString") HK_RCCL_SYM(AllGather, "ncclAllGather")
 #undef HK_RCCL_SYM
   c->rccl.lib = lib;
   return true;
@@ -3245,16 +2615,19 @@ int hydra_hip_comm_init(hydra_hip_handle c, const char* id128, int rank, int wor
 int hydra_hip_comm_destroy(hydra_hip_handle c) {
   if (!c) return HYDRA_HIP_EINVAL;
   if (c->comm) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
-  dev_free(c->commPacked); dev_free(c->commRecv); dev_free(c->commPixels);
+  dev_free(c->commPacked); dev_free(c->commRecv); dev_free(c->commPixels); dev_free(c->commMeta);
   c->commCount.clear(); c->commRank = -1; c->commWorld = 0;
   return HYDRA_HIP_OK;
 }
-// the staging a gather needs: this rank's packed buffer; on the root also the receive buffer and every other rank's pixel list
+// the staging a gather needs: this rank's packed buffer; on the root also the receive buffer and every other rank's pixel list.
+// The root's lists are a function of (frame, tile size, world): they are rebuilt whenever one of them is not what they were built for
+// (hydra_hip_resize and hydra_hip_set_tile_partition also drop them).
 static int comm_prepare(hydra_hip_ctx* c, int root) {
   if (!c->stateAllocated) { int rc = alloc_render_state(c); if (rc) return rc; }
   int rc;
   if ((rc = dev_alloc(c, c->commPacked, std::max<size_t>(1, size_t(c->N)) * 16)) != 0) return rc;
-  if (c->commRank != root || !c->commCount.empty()) return HYDRA_HIP_OK;
+  if (c->commRank != root) return HYDRA_HIP_OK;
+  if (!c->commCount.empty() && c->commW == c->w && c->commH == c->h && c->commTile == c->tile && int(c->commCount.size()) == c->commWorld) return HYDRA_HIP_OK;
   std::vector<int> all, one;
   c->commCount.assign(size_t(c->commWorld), 0);
   for (int r = 0; r < c->commWorld; r++) {
@@ -3263,17 +2636,44 @@ static int comm_prepare(hydra_hip_ctx* c, int root) {
     c->commCount[size_t(r)] = (long long)one.size();
     all.insert(all.end(), one.begin(), one.end());
   }
-  if ((rc = dev_upload(c, c->commPixels, all.data(), all.size() * 4)) != 0) return rc;
-  return dev_alloc(c, c->commRecv, std::max<size_t>(1, all.size()) * 16);
+  if ((rc = dev_upload(c, c->commPixels, all.data(), all.size() * 4)) != 0) { c->commCount.clear(); return rc; }
+  if ((rc = dev_alloc(c, c->commRecv, std::max<size_t>(1, all.size()) * 16)) != 0) { c->commCount.clear(); return rc; }
+  c->commW = c->w; c->commH = c->h; c->commTile = c->tile;
+  return HYDRA_HIP_OK;
+}
+// Before any rank posts a send or a receive, all of them learn what every other one is about to do: one ncclAllGather of
+// {pixels to send or -1 when this rank could not prepare, width, height, tile}.  A rank that failed, or whose frame or tile size is not
+// the others', makes EVERY rank return an error instead of leaving the root waiting in a receive nobody will match; with equal
+// (frame, tile, world) the per-rank counts are the same function on every rank, so the root's table agrees by construction (checked).
+static int comm_agree(hydra_hip_ctx* c, int root, int prepareRc) {
+  const int W = c->commWorld;
+  int rc;
+  if ((rc = dev_alloc(c, c->commMeta, size_t(W + 1) * 16)) != 0) return rc;   // [0..W) gathered rows, row W = this rank's
+  const int mine[4] = {prepareRc == HYDRA_HIP_OK ? c->N : -1, c->w, c->h, c->tile};
+  int* meta = static_cast<int*>(c->commMeta.p);
+  HCHECK(hipMemcpyAsync(meta + 4 * W, mine, 16, hipMemcpyHostToDevice, c->stream));
+  NCHECK(c->rccl.AllGather(meta + 4 * W, meta, 4, ncclInt32, c->comm, c->stream));
+  std::vector<int> rows(size_t(W) * 4);
+  HCHECK(hipMemcpyAsync(rows.data(), meta, size_t(W) * 16, hipMemcpyDeviceToHost, c->stream));
+  HCHECK(hipStreamSynchronize(c->stream));
+  const std::string keep = c->err;
+  for (int r = 0; r < W; r++) {
+    const int* q = &rows[size_t(r) * 4];
+    if (q[0] < 0) return fail(c, HYDRA_HIP_ESTATE, r == c->commRank ? ("comm_gather_frame: this rank could not prepare the exchange: " + keep) : ("comm_gather_frame: rank " + std::to_string(r) + " could not prepare the exchange"));
+    if (q[1] != c->w || q[2] != c->h || q[3] != c->tile) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: rank " + std::to_string(r) + " renders another frame or tile size than rank " + std::to_string(c->commRank));
+    if (c->commRank == root && r != root && (long long)q[0] != c->commCount[size_t(r)]) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: rank " + std::to_string(r) + " owns another number of pixels than the root's table says");
+  }
+  return HYDRA_HIP_OK;
 }
 int hydra_hip_comm_gather_frame(hydra_hip_handle c, int root) {
   if (!c) return HYDRA_HIP_EINVAL;
-  if (c->world == 1) return HYDRA_HIP_OK;                 // one rank owns the whole frame
+  if (c->world == 1 && !c->comm) return HYDRA_HIP_OK;     // one rank owns the whole frame
   if (!c->comm) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: comm_init first");
   if (root < 0 || root >= c->commWorld) return fail(c, HYDRA_HIP_EINVAL, "comm_gather_frame: bad root");
   if (c->rank != c->commRank || c->world != c->commWorld) return fail(c, HYDRA_HIP_ESTATE, "comm_gather_frame: the tile partition changed after comm_init");
   HCHECK(hipSetDevice(c->device));
-  { int rc = comm_prepare(c, root); if (rc) return rc; }
+  { const int prc = comm_prepare(c, root); const int arc = comm_agree(c, root, prc); if (arc) return arc; if (prc) return prc; }
+  if (c->world == 1) return HYDRA_HIP_OK;                 // a one-rank communicator: the agreement ran, nothing to move
   if (c->commRank != root) {
     if (c->N > 0) {
       hipLaunchKernelGGL(k_pack_owned, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), c->accum, static_cast<float4*>(c->commPacked.p));

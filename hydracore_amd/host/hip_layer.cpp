@@ -72,6 +72,8 @@ public:
   }
 
   void InitPathTracing(int seed, std::vector<int32_t>* = nullptr) override { m_mmltSeed = seed; MLT_Free(); check(hydra_hip_init_path_tracing(m_h, seed), "InitPathTracing"); }
+  // a user-requested clear restarts everything, the Markov chains included (RenderDriverRTE calls this with InitPathTracing when the scene or
+  // the camera changed, RenderDriverRTE.cpp:1738,1776); the per-pass contribution to a shared image clears the sums only (below)
   void ClearAccumulatedColor() override { MLT_Free(); check(hydra_hip_clear_accumulated_color(m_h), "ClearAccumulatedColor"); }
   // HRT_ENABLE_MMLT (cglobals.h:419, set by RenderDriverRTE::UpdateSettings for method_secondary = "mmlt", RenderDriverRTE.cpp:196-202):
   // the pass is the reference layer's DL_Pass + MMLT_Pass (GPUOCLLayer.cpp:1368-1375): the path tracer limited to the paths
@@ -122,7 +124,7 @@ public:
     if (!m_mmltRunning || width != m_width || height != m_height) return;
     std::vector<float> ind(size_t(width) * height * 4);
     float info[8];
-    if (hydra_hip_mmlt_get_image(m_h, ind.data(), info) != HYDRA_HIP_OK) return;
+    if (hydra_hip_mmlt_get_image(m_h, ind.data(), width, height, info) != HYDRA_HIP_OK) return;
     for (size_t i = 0; i < size_t(width) * height; i++) { data[i].x += ind[4 * i]; data[i].y += ind[4 * i + 1]; data[i].z += ind[4 * i + 2]; }
   }
   void GetLDRImage(uint32_t* data, int width, int height) const override { hydra_hip_get_ldr_image(m_h, data, width, height); }
@@ -136,21 +138,33 @@ public:
   // IHWLayer::SetExternalImageAccumulator (:199) keeps the pointer (base class); the contribution itself:
   // GPUOCLLayer::ContribToExternalImageAccumulator (GPUOCLLayerOther.cpp:365-429): internal sums += into the shared image
   // under its lock, spp and the receive counter advance, the internal accumulator restarts.
+  // With MMLT running the reference's layer splats its mutations into the same screen buffer as the direct-light pass (MMLT_Pass,
+  // GPUOCLLayerAdvanced.cpp:395-493), so a contribution carries both parts, and ClearAccumulatedColor (GPUOCLLayer.cpp:1288-1297) zeroes
+  // that buffer without touching the chains.  Here the indirect part is an image of its own: the contribution adds spp x (kScale x indirect
+  // image of the mutations since the last contribution) next to the direct sums -- shared / shared spp is then the spp-weighted mean of
+  // direct + indirect estimates, what GetHDRImage returns for one interval -- and restarts that image; the chains go on.
   void ContribToExternalImageAccumulator(IHRSharedAccumImage* a_pImage) override {
     if (a_pImage == nullptr) return;
     const float spp = hydra_hip_get_spp(m_h);
     if (spp <= 0.0f) return;
     m_sums.resize(size_t(m_width) * m_height * 4);
     check(hydra_hip_get_accumulator(m_h, m_sums.data(), m_width, m_height), "ContribToExternalImageAccumulator");
+    if (m_mmltRunning) {
+      m_indirect.resize(m_sums.size());
+      float info[8];
+      check(hydra_hip_mmlt_get_image(m_h, m_indirect.data(), m_width, m_height, info), "ContribToExternalImageAccumulator(MMLT)");
+    }
     if (!a_pImage->Lock(100)) return;                        // busy: the samples stay in the internal accumulator for the next call
     HRSharedBufferHeader* hdr = a_pImage->Header();
     if (hdr->width != m_width || hdr->height != m_height || hdr->channels != 4) { a_pImage->Unlock(); RunTimeError("HipHWLayer::ContribToExternalImageAccumulator: shared image does not match the frame"); }
     float* out = a_pImage->ImageData(0);
     for (size_t i = 0; i < m_sums.size(); i++) out[i] += m_sums[i];
+    if (m_mmltRunning) for (size_t i = 0; i < m_sums.size(); i++) if ((i & 3) != 3) out[i] += spp * m_indirect[i];
     hdr->counterRcv++;
     hdr->spp += spp;
     a_pImage->Unlock();
-    ClearAccumulatedColor();
+    check(hydra_hip_clear_accumulated_color(m_h), "ContribToExternalImageAccumulator");   // the sums only: not the virtual ClearAccumulatedColor, which ends the MMLT run
+    if (m_mmltRunning) check(hydra_hip_mmlt_reset_image(m_h), "ContribToExternalImageAccumulator(MMLT)");
     m_sppContrib += spp;
   }
   float GetSPPContrib() const override { return m_sppContrib; }
@@ -180,7 +194,7 @@ public:
       a_pAccumImage->Unlock();
       RunTimeError("HipHWLayer::EvalGBuffer: the shared image has no G-buffer layers (depth 3 or 4) of the frame's size");
     }
-    const int rc = hydra_hip_eval_gbuffer(m_h, data1, data2, a_instIdByInstId.empty() ? nullptr : a_instIdByInstId.data(), int(a_instIdByInstId.size()), nullptr);
+    const int rc = hydra_hip_eval_gbuffer(m_h, data1, data2, m_width, m_height, a_instIdByInstId.empty() ? nullptr : a_instIdByInstId.data(), int(a_instIdByInstId.size()), nullptr);
     if (rc != HYDRA_HIP_OK) { a_pAccumImage->Unlock(); check(rc, "EvalGBuffer"); }
     hdr->gbufferIsEmpty = 0;
     a_pAccumImage->Unlock();
@@ -199,7 +213,7 @@ private:
   int m_mmltSeed = 777;
   int m_spp = 1;
   float m_sppContrib = 0.0f;
-  std::vector<float> m_sums;
+  std::vector<float> m_sums, m_indirect;
 
   void check(int rc, const char* where) const {
     if (rc != HYDRA_HIP_OK) RunTimeError(std::string("HipHWLayer::") + where + ": " + hydra_hip_last_error(m_h));

@@ -245,7 +245,10 @@ const char* hydra_hip_image_last_error(void);
  *   12 + 10 * max_depth floats, average brightness per path length [max_depth + 1]; any pointer may be null. */
 int hydra_hip_mmlt_begin(hydra_hip_handle h, int chains, int seed, int first_bounce, int max_depth, int estimate_passes);
 int hydra_hip_mmlt_pass(hydra_hip_handle h, int mutations);
-int hydra_hip_mmlt_get_image(hydra_hip_handle h, float* image4, float* info8);
+int hydra_hip_mmlt_get_image(hydra_hip_handle h, float* image4, int width, int height, float* info8);   /* image4 (may be null) = width*height float4, must be the frame of mmlt_begin */
+/* the indirect image restarts from zero while the chains go on (GPUOCLLayer::ClearAccumulatedColor, GPUOCLLayer.cpp:1288-1297, leaves the MLT state
+ * alone): what a contribution to a shared accumulation image (IHWLayer::ContribToExternalImageAccumulator :201) needs after it has taken the image */
+int hydra_hip_mmlt_reset_image(hydra_hip_handle h);
 int hydra_hip_mmlt_get_state(hydra_hip_handle h, float* chains, int32_t* depth, float* xrows, float* avg_b);
 int hydra_hip_mmlt_end(hydra_hip_handle h);
 /* IntegratorSBDPT::DoPass (hydra_drv/CPUExp_Integrators_SBDPT.cpp:11-216) on the buffers and generators of the MMLT run: `passes` x chains
@@ -254,7 +257,7 @@ int hydra_hip_mmlt_end(hydra_hip_handle h);
  * reference in where the split and the pixel come from (x[MMLT_DIM_SPLIT] and the lens dimensions instead of two rndInt draws, :22, :40-41).
  * sbdpt_get_image: splats x width*height / samples (paths of 2..max_depth segments; directly visible emitters are not part of this pass). */
 int hydra_hip_sbdpt_pass(hydra_hip_handle h, int passes);
-int hydra_hip_sbdpt_get_image(hydra_hip_handle h, float* image4, double* samples);
+int hydra_hip_sbdpt_get_image(hydra_hip_handle h, float* image4, int width, int height, double* samples);
 /* IHWLayer::EvalGBuffer (hydra_drv/IHWLayer.h:136; GPUOCLLayer::EvalGBuffer, GPUOCLLayerOther.cpp:694-870), following the CPU restatement
  * IntegratorCommon::gbufferEval / gbufferSample (hydra_drv/CPUExp_GBuffer.cpp:15-113): per pixel 64 Hammersley-placed primary rays, one
  * surface sample each (depth, normal, diffuse colour, material / object / instance id, texture coordinate), the sample most similar to all
@@ -262,8 +265,9 @@ int hydra_hip_sbdpt_get_image(hydra_hip_handle h, float* image4, double* samples
  * each, the two layers the reference writes into the shared accumulation image (packGBuffer1 / packGBuffer2, cglobals.h:2098-2145);
  * inst_remap (may be null) = a_instIdByInstId, applied to the instance id (:846-853).  raw14 (may be null; tests) = per pixel depth, normal xyz,
  * rgba, matId (int bits), coverage, texCoord xy, objId, instId (int bits).  Alpha is 0 on every hit, as in the CPU form.
- * Needs the camera in the globals header (SetCamMatrices + PrepareEngineGlobals). */
-int hydra_hip_eval_gbuffer(hydra_hip_handle h, float* data1, float* data2, const int32_t* inst_remap, int inst_remap_size, float* raw14);
+ * Needs the camera in the globals header (SetCamMatrices + PrepareEngineGlobals); width x height must be the layer's frame and the header's
+ * HRT_WIDTH_F x HRT_HEIGHT_F (GetHDRImage's size check, CPUExpLayer.cpp:133-147, made loud). */
+int hydra_hip_eval_gbuffer(hydra_hip_handle h, float* data1, float* data2, int width, int height, const int32_t* inst_remap, int inst_remap_size, float* raw14);
 /* IntegratorMMLT::F (hydra_drv/CPUExp_Integrators_MMLT.cpp:146-315; sub-paths :637-929, connections :931-1047 + cbidir.h:190-477): the
  * contribution of n primary-sample vectors.  xvec = n rows of `stride` floats laid out as the reference's PSSampleV (cglobals.h:102-128:
  * lens 0..3, light 4..10, split 11, then 10 floats per bounce, light part first), depth[i] = d (path length in segments, 1..16),

@@ -409,6 +409,9 @@ static inline OrcHit IntersectLeaf(f3 ray_pos, f3 ray_dir, int leaf_offset, floa
  * the walk stops behind the first leaf that produced a hit in (t_rayMin, far) (ref: :1243-1251, `top = 0`). */
 static OrcHit BVH4Traverse_(f3 ray_pos, f3 ray_dir, float t_rayMin, OrcHit hit, const float* bvh, const float* tris, int haveInst, int anyHit, TravStat* st,
                             const OrcScene* s, const uint32_t* alpha) {   /* alpha: BVH4InstTraverseAlpha, ref: ctrace.h:1297-1520 (instanced trees only) */
+#ifdef ORC_NO_STATS   /* liboracle_fast.so, bench.py's cpu_baseline leg only: the visit counters are compiled out of the walk */
+  st = NULL;
+#endif
   f3 invDir = SafeInverse(ray_dir);
   /* the reference declares stackData[80] with stack = stackData + 2 and tests `top < 80` once before up to three pushes
    * (ctrace.h:846-847,964-985): on a tree deeper than the stack it writes stack[78..81], i.e. up to four ints past its

@@ -20,16 +20,18 @@ class OrcScene(C.Structure):
                 ("texAuxStorage", C.c_void_p)]
 
 
-_lib = None
+_lib = {}
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
+def load(fast=False):
+    """liboracle.so (the checker), or with fast=True liboracle_fast.so: the same source at -O3 with the traversal's visit counters compiled
+    out, which only bench.py's cpu_baseline leg times"""
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name in _lib:
+        return _lib[name]
+    path = os.path.join(ROOT, "oracle", name)
     if not os.path.exists(path):
-        subprocess.check_call(["make", "-C", ROOT, "oracle/liboracle.so"])
+        subprocess.check_call(["make", "-C", ROOT, "oracle/" + name])
     lib = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int
     sp = C.POINTER(OrcScene)
@@ -61,7 +63,7 @@ def load():
     lib.orc_collect_rays.argtypes = [sp, i32, i32, i32, i32, i32, vp, vp, vp, C.c_int64]
     lib.orc_collect_rays.restype = C.c_int64
     lib.orc_max_threads.restype = i32
-    _lib = lib
+    _lib[name] = lib
     return lib
 
 
@@ -72,8 +74,8 @@ def _p(a):
 class Oracle:
     """Oracle bound to one set of scene buffers (the dict from HostScene.buffers()); keeps the arrays alive."""
 
-    def __init__(self, buffers):
-        self.lib = load()
+    def __init__(self, buffers, fast=False):
+        self.lib = load(fast)
         self.b = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in buffers.items()}
         b = self.b
         s = OrcScene()

@@ -711,11 +711,13 @@ def test_tuning_options_do_not_change_the_image(fix, request):
             core.set_option(k, v)
 
 
-@pytest.mark.parametrize("name,w,h,depth", [("test_224", 96, 96, 4), ("atrium_small", 96, 54, 5)])
+@pytest.mark.parametrize("name,w,h,depth", [("test_224", 96, 96, 4), ("atrium_small", 96, 54, 5), ("atrium_cutouts_small", 96, 54, 5)])
 def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, name, w, h, depth):
     """the device copies of the node array carry triangle counts in their leaf links and slot numbers in the links to the quads
     kept in LDS (hk_trace.h): hits, per-ray visit counters, shadow answers, the image and the ray counts are bit-identical
-    with the plain copy (instanced and non-instanced tree walk; 0, 5 and 21 cached quads; 0, 5 and 16 triangles of the hottest leaves in LDS)"""
+    with the plain copy (instanced and non-instanced tree walk; 0, 5 and 21 cached quads; 0, 5 and 16 triangles of the hottest leaves in LDS).
+    The cut-out hall has an alpha table on tree 0: its alpha-tested kernels exist without LDS triangles, so the option must not tag any
+    leaf there (a tagged link read by them decodes to an out-of-range offset: no fetch may be out of range)"""
     from hydracore_amd import HipCore
     _, b = host_scene(name, w, h, depth)
     rk = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0) if name.startswith("atrium") else {}
@@ -733,6 +735,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
         bh = core.bench_trace(pos4, dir4, iters=1)                 # the persistent kernels (the ones that use the LDS quads) on the same rays
         tot = core.stage_trace_totals(pos4, dir4)                  # ... and their counting variants: same totals whatever sits in LDS
         stot = core.stage_trace_totals(pos4, dir4, tfar)
+        assert tot[5] == 0 and stot[5] == 0, (links, top, tris, tot, stot)
         core.init_path_tracing(5)
         core.reset_perf_counters()
         core.trace_pass(2)
@@ -915,8 +918,15 @@ def test_native_rccl_entry_points_on_one_rank(gpu224):
     core.init_path_tracing(3)
     core.trace_pass(2)
     before = core.accumulator(w, h)
-    core.comm_gather_frame(0)
+    core.comm_gather_frame(0)                        # one rank: the ranks' agreement (ncclAllGather of count, frame, tile) runs, nothing moves
     core.comm_reduce_frame(0)
+    core.finish()
+    assert (core.accumulator(w, h).view(np.uint32) == before.view(np.uint32)).all()
+    core.resize(w // 2, h // 2)                      # a resize drops what the exchange cached for the old frame; the next gather re-plans
+    core.resize(w, h)
+    core.init_path_tracing(3)
+    core.trace_pass(2)
+    core.comm_gather_frame(0)
     core.finish()
     assert (core.accumulator(w, h).view(np.uint32) == before.view(np.uint32)).all()
     core.comm_destroy()
@@ -958,6 +968,65 @@ def test_shared_accumulation_image_contributions(built):
     sc.close()
 
 
+def test_mmlt_with_a_shared_accumulation_image(built):
+    """MMLT next to IHWLayer::SetExternalImageAccumulator: every pass contributes its direct sums AND spp x the scaled indirect image of
+    the mutations since the last contribution, and clears the sums only -- the chains go on (the reference's ClearAccumulatedColor does
+    not touch its MLT state, GPUOCLLayer.cpp:1288-1297).  The shared image / its spp must be the frame GetHDRImage gives without one."""
+    from hydracore_amd import HostScene
+    w = h = 128
+    ref = HostScene(scene_path("test_42"), w, h, trace_depth=4, enable_dof=0, use_hip=True, device=0, seed=777)
+    ref.set_method("mmlt")
+    ref.draw(passes=12, spp=16)
+    want = ref.hdr_image()[..., :3].copy()
+    ref.close()
+    sc = HostScene(scene_path("test_42"), w, h, trace_depth=4, enable_dof=0, use_hip=True, device=0, seed=777)
+    sc.set_method("mmlt")
+    shared = np.zeros((h, w, 4), np.float32)
+    img = sc.shared_image(shared, attach=True)
+    muts = []
+    for _ in range(3):
+        sc.draw(passes=4, spp=16)
+        muts.append(sc.hip().mmlt_image(w, h)[1]["mutations"])
+    spp, rcv = sc.shared_image_stat(img)
+    sc.shared_image_close(img)
+    sc.close()
+    assert rcv == 12 and spp == 12 * 16.0
+    assert muts[0] > 0 and muts[1] == 2 * muts[0] and muts[2] == 3 * muts[0], muts      # one run of chains: the mutation count keeps growing
+    got = shared[..., :3] / spp
+
+    def down(a, f=8):
+        return a.reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
+    assert abs(got.mean() - want.mean()) < 0.04 * want.mean()
+    assert np.corrcoef(down(got).ravel(), down(want).ravel())[0, 1] > 0.99
+    assert np.abs(down(got) - down(want)).sum() / down(want).sum() < 0.08
+
+
+def test_mmlt_and_gbuffer_refuse_a_frame_that_is_not_the_header_s(gpu42):
+    """splats are tested against the header's HRT_WIDTH_F x HRT_HEIGHT_F and written with the layer's width as row stride: mmlt_begin and
+    eval_gbuffer refuse when the two differ, a resize ends a running MMLT run, and the read-outs check the caller's size"""
+    from hydracore_amd import HydraError
+    core, b, _ = gpu42
+    w, h = b["width"], b["height"]
+    core.mmlt_begin(4096, seed=1, first_bounce=2, max_depth=4)
+    core.mmlt_pass(1)
+    with pytest.raises(HydraError):
+        core.mmlt_image(w + 1, h)
+    with pytest.raises(HydraError):
+        core.eval_gbuffer(w, h + 1)
+    core.resize(w // 2, h // 2)
+    with pytest.raises(HydraError):
+        core.mmlt_pass(1)                            # the run ended with the resize
+    with pytest.raises(HydraError):
+        core.mmlt_begin(4096, seed=1, first_bounce=2, max_depth=4)     # the header still describes the old frame
+    with pytest.raises(HydraError):
+        core.eval_gbuffer(w // 2, h // 2)
+    core.resize(w, h)
+    core.mmlt_begin(4096, seed=1, first_bounce=2, max_depth=4)
+    core.mmlt_pass(1)
+    assert np.isfinite(core.mmlt_image(w, h)[0]).all()
+    core.mmlt_end()
+
+
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     from hydracore_amd import HipCore, HydraError
     core, b, _ = gpu224
@@ -991,7 +1060,7 @@ def test_materials_the_layer_does_not_shade_are_refused(gpu224):
         core.close()
 
 
-@pytest.mark.parametrize("scene,light_max", [("test_224", 160.0), ("atrium250k_sky", 60.0)])
+@pytest.mark.parametrize("scene,light_max", [("test_224", 160.0), ("atrium250k_sky", 60.0), ("atrium250k", 60.0)])
 def test_full_size_properties_1080p(built, scene, light_max):
     """BASELINE configs[1] and configs[2] sizes: 1920x1080, 8 bounces.  Size-independent properties only (the oracle is too
     slow here): ray-count identity, finite non-negative radiance bounded by the brightest emitter, accumulate linearity
@@ -1014,6 +1083,42 @@ def test_full_size_properties_1080p(built, scene, light_max):
     assert b_only.min() >= -1e-3 and b_only[..., :3].max() <= light_max * 1.001
     assert abs(a[..., :3].mean() - b_only[..., :3].mean()) < 0.05 * a[..., :3].mean()      # two independent samples of the same image
     sc.close()
+
+
+def test_mmlt_full_size_properties_1080p(built):
+    """BASELINE configs[4] at its size: MMLT on test_42, 1920x1080, 1 M chains, paths of 3..6 segments.  Size-independent properties (the
+    oracle is far too slow here): every chain keeps mutating (mutation count), the acceptance rate is that of a working Kelemen mutation,
+    the image is finite and non-negative, its brightness is the estimate of mmlt_begin by construction of kScale, and direct (the path
+    tracer limited to 2 segments) + indirect agrees with the path tracer's frame of the same path lengths in brightness and at 40x40-pixel blocks."""
+    from hydracore_amd import HostScene
+    w, h, chains = 1920, 1080, 1 << 20
+    sc = HostScene(scene_path("test_42"), w, h, trace_depth=5, enable_dof=0, use_hip=True, device=0, seed=777)
+    core = sc.hip()
+    core.set_option("samples_in_flight", 8)
+    sc.draw(passes=4, spp=8)                                    # path tracer, paths of up to 6 segments (trace depth 5 + the camera segment's emission)
+    pt = sc.hdr_image()[..., :3].copy()
+    core.set_option("samples_in_flight", 8)
+    core.mmlt_begin(chains, seed=777, first_bounce=3, max_depth=6, estimate_passes=2)
+    core.mmlt_pass(96)
+    ind, info = core.mmlt_image(w, h)
+    assert info["mutations"] == 96.0 * chains and info["chains"] == chains
+    assert 0.3 < info["acceptance"] < 0.98, info
+    assert np.isfinite(ind).all() and ind.min() >= 0.0
+    assert abs(ind[..., :3].mean() - info["avg_brightness"]) < 0.02 * info["avg_brightness"]      # EstimateScaleCoeff: the image's mean IS the estimate
+    core.mmlt_end()
+    sc.close()
+    sc = HostScene(scene_path("test_42"), w, h, trace_depth=1, enable_dof=0, use_hip=True, device=0, seed=777)      # the direct part: paths of fewer than 3 segments
+    sc.hip().set_option("samples_in_flight", 8)
+    sc.draw(passes=4, spp=8)
+    direct = sc.hdr_image()[..., :3].copy()
+    sc.close()
+    mm = direct + ind[..., :3]
+
+    def down(a, f=40):
+        return a.reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
+    assert abs(mm.mean() - pt.mean()) < 0.05 * pt.mean(), (mm.mean(), pt.mean())
+    assert np.corrcoef(down(mm).ravel(), down(pt).ravel())[0, 1] > 0.99
+    assert np.abs(down(mm) - down(pt)).sum() / down(pt).sum() < 0.10
 
 
 @pytest.mark.parametrize("fix,name", [("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_transl", "atrium_transl_small")])

@@ -5,6 +5,7 @@ tools/pmc_passes.sh by hand).  No torch: the scene front end and the HIP layer t
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_child.py --scene <dir> --spp 64
 
 Runs `--steps` passes of `--spp` samples per pixel, all in flight at once -- the launches bench.py times.
+`--mode mmlt`: mmlt_begin + (1 + `--mutations`) mutation steps of `--chains` Markov chains instead (BASELINE configs[4]).
 """
 import argparse
 import os
@@ -26,8 +27,25 @@ def main():
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--mode", default="pt", choices=["pt", "mmlt"])
+    ap.add_argument("--chains", type=int, default=1 << 20)
+    ap.add_argument("--mutations", type=int, default=8)
+    ap.add_argument("--max-depth", type=int, default=6)
+    ap.add_argument("--first-bounce", type=int, default=3)
     args = ap.parse_args()
     from hydracore_amd import HostScene
+    if args.mode == "mmlt":
+        sc = HostScene(args.scene, args.width, args.height, trace_depth=args.depth, enable_dof=0, use_hip=True, device=args.device, seed=777)
+        core = sc.hip()
+        core.set_option("samples_in_flight", 1)
+        sc.draw(passes=1, spp=1)
+        core.mmlt_begin(args.chains, seed=777, first_bounce=args.first_bounce, max_depth=args.max_depth, estimate_passes=1)
+        core.mmlt_pass(1 + args.mutations)
+        core.finish()
+        print("pmc_child: %d chains x %d mutations" % (args.chains, 1 + args.mutations))
+        core.mmlt_end()
+        sc.close()
+        return
     sc = HostScene(args.scene, args.width, args.height, trace_depth=args.depth, enable_dof=0, use_hip=True, device=args.device, seed=777)
     core = sc.hip()
     core.set_tile_partition(args.rank, args.world, args.tile)
