@@ -14,14 +14,16 @@ void hk_launch_shadow_static(bool count, const TraceLaunch& a) {
 }
 void hk_launch_trace_dyn(bool anyhit, bool count, bool toptris, bool alpha, const TraceLaunch& a) {
   float4* out = reinterpret_cast<float4*>(a.hits);
-#define HK_L(AH, CNT, TT, AL) hipLaunchKernelGGL((k_trace_dyn<AH, CNT, TT, AL>), dim3(a.grid), dim3(HK_TRACE_BLOCK), 0, a.stream, a.s, a.q, a.fetchCounters, a.a4, a.b4, out, a.vis, a.totals5, a.minActive, a.raysPerLane)
+#define HK_L(AH, CNT, TT, AL, VT) hipLaunchKernelGGL((k_trace_dyn<AH, CNT, TT, AL, VT>), dim3(a.grid), dim3(HK_TRACE_BLOCK), 0, a.stream, a.s, a.q, a.fetchCounters, a.a4, a.b4, out, a.vis, a.totals5, a.minActive, a.raysPerLane, a.wq, a.wt, a.wi)
+#define HK_LV(AH, CNT, TT, AL) do { if (a.vote) HK_L(AH, CNT, TT, AL, true); else HK_L(AH, CNT, TT, AL, false); } while (0)
   if (!anyhit) {
-    if (alpha) { if (count) HK_L(false, true, false, true); else HK_L(false, false, false, true); }          // the alpha-tested kernels exist without LDS triangles only
-    else if (toptris) { if (count) HK_L(false, true, true, false); else HK_L(false, false, true, false); }
-    else { if (count) HK_L(false, true, false, false); else HK_L(false, false, false, false); }
-  } else {                                                                                                    // shadow rays: tree 0 without the alpha test (Common.cpp:156-180)
-    if (toptris) { if (count) HK_L(true, true, true, false); else HK_L(true, false, true, false); }
-    else { if (count) HK_L(true, true, false, false); else HK_L(true, false, false, false); }
+    if (alpha) { if (count) HK_LV(false, true, false, true); else HK_LV(false, false, false, true); }          // the alpha-tested kernels exist without LDS triangles only
+    else if (toptris) { if (count) HK_LV(false, true, true, false); else HK_LV(false, false, true, false); }
+    else { if (count) HK_LV(false, true, false, false); else HK_LV(false, false, false, false); }
+  } else {                                                                                                     // shadow rays: tree 0 without the alpha test (Common.cpp:156-180)
+    if (toptris) { if (count) HK_LV(true, true, true, false); else HK_LV(true, false, true, false); }
+    else { if (count) HK_LV(true, true, false, false); else HK_LV(true, false, false, false); }
   }
+#undef HK_LV
 #undef HK_L
 }

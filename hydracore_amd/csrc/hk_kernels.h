@@ -147,11 +147,13 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
 // (one atomic per wave per refill), and a wave whose active-lane count drops below `minActive` suspends traversal to
 // refill.  Keeps SIMD lanes busy when path lengths inside a wave diverge (secondary and shadow rays).  Results are
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
-template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false>
+// VOTE: the steps of the wave's rays are scheduled by wave vote (trav_run_vote, hk_trace.h) instead of the reference's loop nest;
+// wq / wt / wi = the weights of the vote.
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false, bool VOTE = false>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
-                                                               unsigned long long* __restrict__ totals5, int minActive, int raysPerLane) {
+                                                               unsigned long long* __restrict__ totals5, int minActive, int raysPerLane, int wq, int wt, int wi) {
   constexpr int LDS_DEPTH = (ANYHIT && !COUNT) ? HK_LDS_DEPTH_SHADOW : HK_LDS_DEPTH;
   __shared__ int ldsStack[LDS_DEPTH * HK_TRACE_BLOCK];
   __shared__ float4 ldsTop[HK_TOP_QUADS * HK_TOP_STRIDE];
@@ -182,16 +184,33 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
   bool busy = false, queueEmpty = false;
   const int lane = int(__lane_id());
   const bool haveInst = s.haveInst != 0;
+  // The wave's own pool of ray indices: it reserves `chunk` consecutive rays of its segment with ONE returning atomic (1.1-1.3 us with
+  // every CU pulling, MI355X_MICROARCH.md "dequeue"; it used to be one per refill) and hands them to its idle lanes with ballot
+  // arithmetic on wave-uniform (scalar) bookkeeping; the next chunk is reserved while up to 64 rays of the current one are unused.
+  // Which wave traces which ray changes; results are written by ray index as before.  Measured (profiles/r03/ab_ray_pool_*.log): -1 %
+  // closest-hit, -5 % shadow traversal.  Two further steps were measured and dropped: touching the next chunk's lines so that the rays'
+  // loads hit L2 (8 more registers: one wave per SIMD less, slower), and loading a finished lane's next ray into its dead state
+  // registers while the wave keeps stepping (slower: what makes frequent refills expensive is not their latency but that lanes which
+  // start at different times want different steps -- see trav_run_vote -- so a wave does best refilling a third of its lanes at once).
+  // chunk: 64..256 rays, at least ~8 chunks per participating wave so that the segment's tail stays balanced
+  const int wavesOfSeg = (int(gridDim.x) / q.nseg) * (HK_TRACE_BLOCK / 64);
+  int chunk = (count / (wavesOfSeg > 0 ? wavesOfSeg * 8 : 8)) & ~63;
+  chunk = chunk < 64 ? 64 : (chunk > 256 ? 256 : chunk);
+  int poolNext = 0, poolEnd = 0, nextBase = -1;   // [poolNext, poolEnd) is reserved and unused; nextBase >= 0: so is [nextBase, nextBase + chunk)
   while (true) {
     if (!queueEmpty) {
       const unsigned long long mask = __ballot(!busy);
       if (mask != 0ull) {
-        const int n = __popcll(mask), leader = __ffsll((long long)mask) - 1;
-        int base = 0;
-        if (lane == leader) base = int(atomicAdd(fetchCounter, uint32_t(n)));
-        base = __shfl(base, leader);
+        const int n = __popcll(mask);
+        const int avail = poolEnd - poolNext;
+        if (nextBase < 0 && avail <= 64) {            // wave-uniform: look one chunk ahead
+          int base = 0;
+          if (lane == 0) base = int(atomicAdd(fetchCounter, uint32_t(chunk)));
+          nextBase = __builtin_amdgcn_readfirstlane(base);
+        }
         if (!busy) {
-          const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+          const int r = __popcll(mask & ((1ull << lane) - 1ull));
+          const int idx = (r < avail) ? poolNext + r : nextBase + (r - avail);
           if (idx < count) {
             const float4 a = a4[segBase + idx];
             HydraLiteHit h = hk_miss_hit();
@@ -206,22 +225,26 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
             }
           }
         }
-        if (base + n >= count) queueEmpty = true;   // wave-uniform
+        if (n >= avail) { poolNext = nextBase + (n - avail); poolEnd = nextBase + chunk; nextBase = -1; }   // (n >= avail implies avail <= 64: the next chunk is reserved)
+        else poolNext += n;
+        if (poolNext >= count) queueEmpty = true;   // wave-uniform: reservations only grow, so nothing this wave can still reserve exists
       }
     }
     if (__ballot(busy) == 0ull) break;
-    if (busy) {
-      const bool done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
-      if (done) {
-        if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
-        else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
-        if (COUNT && totals5) {
-          atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
-          atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
-      if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
-        }
-        busy = false;
+    bool done = false;
+    if (VOTE) {
+      trav_run_vote<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, busy, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive, wq, wt, wi);
+      done = busy && t.top < 0;
+    } else if (busy) done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
+    if (done) {
+      if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;
+      else outHits[rayIdx] = make_float4(t.hit.t, as_float(t.hit.primId), as_float(t.hit.instId), as_float(t.hit.geomId));
+      if (COUNT && totals5) {
+        atomicAdd(totals5 + 0, 1ull); atomicAdd(totals5 + 1, (unsigned long long)c.quads); atomicAdd(totals5 + 2, (unsigned long long)c.insts);
+        atomicAdd(totals5 + 3, (unsigned long long)c.leaves); atomicAdd(totals5 + 4, (unsigned long long)c.tris);
+        if (c.oob) atomicAdd(totals5 + 5, (unsigned long long)c.oob);
       }
+      busy = false;
     }
   }
 }
@@ -699,6 +722,7 @@ struct TraceLaunch {          // one traversal launch: rays a4 (origin | t_far f
   const float4* a4; const float4* b4; HydraLiteHit* hits; float* vis;
   uint32_t* perRay3; unsigned long long* totals5; uint32_t* fetchCounters;
   int carry, minActive, raysPerLane;
+  int vote, wq, wt, wi;       // persistent kernels: schedule by wave vote (trav_run_vote) with these weights, or 0 = the reference's loop nest
 };
 void hk_launch_trace_static(bool count, bool alpha, const TraceLaunch& a);                          // k_trace<COUNT, ALPHA>
 void hk_launch_shadow_static(bool count, const TraceLaunch& a);                                     // k_shadow<COUNT>

@@ -252,8 +252,117 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
   t.searching = true;
 }
 
-// returns true when the ray is finished; false when it was suspended because fewer than minActive lanes were still
-// traversing (minActive <= 0: never suspend).
+// ---- the three kinds of step a ray alternates between.  Each is what BVH4InstTraverse does in one turn of its inner loop
+// (a quad), at a triangle leaf, or at an instance leaf; a ray's sequence of steps -- hence every box test, push, pop and triangle
+// test, and their order -- is the same whatever schedules them (trav_run: the reference's loop nest; trav_run_vote: by wave vote).
+
+// one quad: fetch its 4 child boxes, test, order near -> far, push, descend or pop (ctrace.h:866-1006)
+template <bool COUNT, bool TOPCACHE, class STACK>
+HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst, const float t_rayMin, STACK& stack, TravCounters& cnt) {
+  float4 n0a, n0b, n1a, n1b, n2a, n2b, n3a, n3b;
+  if (TOPCACHE && (t.left & HK_TOP_FLAG)) {   // one of the hottest quads: 8 LDS reads instead of 8 trips through the texture addresser
+    n0a = bv.topPiece(t.left, 0); n0b = bv.topPiece(t.left, 1); n1a = bv.topPiece(t.left, 2); n1b = bv.topPiece(t.left, 3);
+    n2a = bv.topPiece(t.left, 4); n2b = bv.topPiece(t.left, 5); n3a = bv.topPiece(t.left, 6); n3b = bv.topPiece(t.left, 7);
+  } else {
+    n0a = bv.node(t.left, 0); n0b = bv.node(t.left, 1); n1a = bv.node(t.left, 2); n1b = bv.node(t.left, 3);
+    n2a = bv.node(t.left, 4); n2b = bv.node(t.left, 5); n3a = bv.node(t.left, 6); n3b = bv.node(t.left, 7);
+  }
+  if (COUNT) { cnt.quads++; if (!(TOPCACHE && (t.left & HK_TOP_FLAG)) && !bv.nodeInRange(t.left)) cnt.oob++; }
+  int c0 = as_int(n0a.w), c1 = as_int(n1a.w), c2 = as_int(n2a.w), c3 = as_int(n3a.w);
+#ifdef HK_HOST_EMU
+  const bool v0 = !((uint32_t(c0) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n0b.w)) == HYDRA_BVH_INVALID));
+  const bool v1 = !((uint32_t(c1) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n1b.w)) == HYDRA_BVH_INVALID));
+  const bool v2 = !((uint32_t(c2) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n2b.w)) == HYDRA_BVH_INVALID));
+  const bool v3 = !((uint32_t(c3) == HYDRA_BVH_INVALID) && (uint32_t(as_int(n3b.w)) == HYDRA_BVH_INVALID));
+#else
+  // the device copy of the node array has the boxes of invalid children (both link words 0xFFFFFFFF, ctrace.h:889-892)
+  // overwritten with NaN by k_prepare_bvh at upload: every comparison below is then false for them, which is what the
+  // reference's IsValidNode term achieves -- 12 VALU instructions less per quad in a loop that is VALU-issue bound
+  const bool v0 = true, v1 = true, v2 = true, v3 = true;
+#endif
+#ifdef HK_EXP_SETPRIO   /* timing experiment: the wave that has its quad runs its box tests ahead of the others */
+  __builtin_amdgcn_s_setprio(HK_EXP_SETPRIO);
+#endif
+  const float2 t0 = RayBox(t.pos, t.inv, n0a, n0b), t1 = RayBox(t.pos, t.inv, n1a, n1b);
+  const float2 t2 = RayBox(t.pos, t.inv, n2a, n2b), t3 = RayBox(t.pos, t.inv, n3a, n3b);
+  float k0 = ((t0.x <= t0.y) && (t0.y >= t_rayMin) && (t0.x <= t.hit.t) && v0) ? t0.x : HK_MAXFLOAT;
+  float k1 = ((t1.x <= t1.y) && (t1.y >= t_rayMin) && (t1.x <= t.hit.t) && v1) ? t1.x : HK_MAXFLOAT;
+  float k2 = ((t2.x <= t2.y) && (t2.y >= t_rayMin) && (t2.x <= t.hit.t) && v2) ? t2.x : HK_MAXFLOAT;
+  float k3 = ((t3.x <= t3.y) && (t3.y >= t_rayMin) && (t3.x <= t.hit.t) && v3) ? t3.x : HK_MAXFLOAT;
+#define HK_CSWAP(ka, kb, ca, cb) { const bool sw = (kb < ka); const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; const int tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
+  HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
+#ifdef HK_EXP_EXTRA_SORT   /* timing experiment: the network again on sorted keys changes nothing but costs its ~25 VALU instructions */
+  for (int rep = 0; rep < HK_EXP_EXTRA_SORT; rep++) {
+    asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
+    HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
+  }
+#endif
+#undef HK_CSWAP
+  // keys are sorted and misses carry MAXFLOAT, so the children hit are a prefix: nothing is pushed unless k1 is a hit
+  // (same pushes, in the same order, as the three separate tests of ctrace.h:962-975)
+  if (k1 < HK_MAXFLOAT) {
+    const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
+    if (k3 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
+    if (k2 < HK_MAXFLOAT && stackHaveSpace) { stack.put(t.top, c2); t.top++; }
+    if (stackHaveSpace) { stack.put(t.top, c1); t.top++; }
+  }
+  if (k0 < HK_MAXFLOAT) t.left = c0;
+  else if (t.top >= 0) { t.top--; t.left = stack.get(t.top); }
+  t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);
+  t.left = t.left & 0x7fffffff;
+#ifdef HK_EXP_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  if (haveInst && t.top < t.instTop && t.instDeep == 1) {
+    t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;   // = SafeInverse(t.odir), same bits (ctrace.h:1000-1006)
+  }
+}
+// what follows every leaf of either kind (ctrace.h:1043-1056)
+HK_DEV void trav_after_leaf(TravState& t, const bool haveInst) {
+  t.searching = !(t.left & int(HYDRA_BVH_LEAF));
+  t.left = t.left & 0x7fffffff;
+  if (haveInst && t.top < t.instTop && t.instDeep == 1) {
+    t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;
+  }
+}
+// a triangle leaf (of a plain tree, or inside an instance): test its triangles, pop.  Returns true when an any-hit ray is finished by it.
+template <bool ANYHIT, bool COUNT, class STACK, bool TOPTRIS, bool ALPHA>
+HK_DEV bool trav_tri_step(TravState& t, const BvhView& bv, const bool haveInst, const float t_rayMin, STACK& stack, TravCounters& cnt) {
+  if (!haveInst) {
+    if (t.top >= 0) {
+      t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS, false>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, 0, false, cnt);   // BVH4Traverse has no alpha form (Common.cpp:146)
+      if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
+    }
+  } else {
+    t.hit = IntersectLeaf<ANYHIT, COUNT, TOPTRIS, ALPHA>(t.pos, t.dir, t.left, t_rayMin, t.hit, bv, t.instId, true, cnt);
+    if (ANYHIT && t.hit.primId != -1) { t.top = -1; return true; }
+  }
+  t.top--;
+  t.left = stack.get(t.top);
+  trav_after_leaf(t, haveInst);
+  return false;
+}
+// an instance leaf: the ray goes into the object's space and on to the root of its tree (ctrace.h:1023-1041)
+template <bool COUNT>
+HK_DEV void trav_inst_step(TravState& t, const BvhView& bv, TravCounters& cnt) {
+  t.instDeep = 1;
+  t.opos = t.pos; t.odir = t.dir; t.oinv = t.inv;
+  const int nextOffset = as_int(bv.node(t.left, 0).w);
+  m44 matrix;
+  matrix.c[0] = bv.node(t.left, 2); matrix.c[1] = bv.node(t.left, 3); matrix.c[2] = bv.node(t.left, 4); matrix.c[3] = bv.node(t.left, 5);
+  t.instId = as_int(bv.node(t.left, 6).x);
+  if (COUNT) { cnt.insts++; if (!bv.nodeInRange(t.left)) cnt.oob++; }
+  t.pos = mul4x3(matrix, t.pos);
+  t.dir = mul3x3(matrix, t.dir);   // stays un-normalised so t keeps world units
+  t.inv = SafeInverse(t.dir);
+  t.instTop = t.top;
+  t.left = nextOffset;
+  trav_after_leaf(t, true);
+}
+
+// The reference's loop nest, one ray per lane: quads until a leaf, the leaf, again.  Returns true when the ray is finished; false when
+// it was suspended because fewer than minActive lanes were still traversing (minActive <= 0: never suspend).
+// (A/B reference for the vote: the text of the loop nest as it was measured in rounds 1-2, not yet expressed through the step functions)
 template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false>
 HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
                      const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive) {
@@ -351,6 +460,42 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
     if (minActive > 0 && t.top >= 0 && HK_WAVE_ACTIVE_LANES() < minActive) return false;   // let the wave refill
   }
   return true;
+}
+
+// Scheduling by wave vote.  In the loop nest above a wave repeats the quad step until its LAST lane has reached a leaf, then runs the
+// leaf code for whichever lanes hold a triangle leaf and again for those at an instance leaf: with incoherent rays a quarter of the
+// lanes of a VALU instruction do work (measured: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = 0.23 for bounce >= 1 on test_224,
+// profiles/r03).  Here every turn of ONE loop runs the step that the most lanes are waiting for -- quad, triangle leaf or instance
+// entry -- and the others wait that turn out: no lane idles through a phase that only a few stragglers need, and each phase's
+// instructions run with at least a third (typically half or more) of the live lanes.  A lane's own sequence of steps is untouched, so hits, `t` bits and
+// visit counters are those of trav_run (tests: the persistent kernels against the static ones, both against the oracle).
+// Wave-uniform: every lane of the wave (or of the active set) calls it, `busy` says whether the lane holds a ray.  Leaves when no lane
+// is traversing any more, or when fewer than minActive are (minActive <= 0: only when none is) so that the wave can refill.  Refilling a
+// third of the lanes at once beats refilling each lane as it finishes (profiles/r03/vote_minactive_*.log): rays that start together want
+// the same steps at the same time.
+// A finished ray has t.top < 0.  wq / wt / wi: votes count wq x quad lanes against wt x triangle lanes against wi x instance lanes.
+#ifdef HK_HOST_EMU
+#define HK_BALLOT(x) ((x) ? 1ull : 0ull)
+#define HK_POPC(m) __builtin_popcountll(m)
+#else
+#define HK_BALLOT(x) __ballot(x)
+#define HK_POPC(m) __popcll(m)
+#endif
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false>
+HK_DEV void trav_run_vote(TravState& t, const bool busy, const BvhView& bv, const bool haveInst,
+                          const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive, const int wq, const int wt, const int wi) {
+  while (true) {
+    const bool alive = busy && t.top >= 0;
+    const bool atInst = haveInst && t.instDeep == 0;
+    const bool wantQuad = alive && t.searching, wantInst = alive && !t.searching && atInst, wantTri = alive && !t.searching && !atInst;
+    const int nq = HK_POPC(HK_BALLOT(wantQuad)), nt = HK_POPC(HK_BALLOT(wantTri)), ni = haveInst ? HK_POPC(HK_BALLOT(wantInst)) : 0;
+    const int nAlive = nq + nt + ni;
+    if (nAlive == 0 || nAlive < minActive) return;
+    const int vq = nq * wq, vt = nt * wt, vi = ni * wi;
+    if (vq >= vt && vq >= vi) { if (wantQuad) trav_quad_step<COUNT, TOPCACHE, STACK>(t, bv, haveInst, t_rayMin, stack, cnt); }
+    else if (vt >= vi) { if (wantTri) (void)trav_tri_step<ANYHIT, COUNT, STACK, TOPTRIS, ALPHA>(t, bv, haveInst, t_rayMin, stack, cnt); }
+    else { if (wantInst) trav_inst_step<COUNT>(t, bv, cnt); }
+  }
 }
 
 template <bool ANYHIT, bool COUNT, bool ALPHA = false>

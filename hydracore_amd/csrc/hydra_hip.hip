@@ -457,7 +457,9 @@ struct hydra_hip_ctx {
   bool travCounters = false;
   int traceMode = 1;          // 1 = persistent dynamic fetch (k_trace_dyn, default: 8-35 % faster once the refill counters are per segment), 0 = one ray per lane
   int traceRaysPerLane = 1;   // persistent kernels: blocks beyond count / (128 * this) leave at once
-  int traceMinActive = 48;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64)
+  int traceMinActive = 40;    // suspend-and-refill threshold of k_trace_dyn (lanes of 64): the vote's optimum (profiles/r03/vote_minactive_*.log); the loop nest's was 48
+  int traceVote = 1;          // option "trace_vote": the persistent kernels schedule quad / triangle / instance steps by wave vote (hk_trace.h, trav_run_vote); 0 = the reference's loop nest
+  int traceVoteW[3] = {1, 1, 2};   // options "trace_vote_wq / _wt / _wi": weights of the vote
   int shadeWaves = 3;         // launch-bounds variant of k_bounce / k_hit / k_shade (3, 4 or 5 waves per SIMD); 3 = no spills, measured fastest for the fused kernel
   int shadeBlocksPerCU = 256;        // grid cap of the bounce kernels: 16 -> 128..1024 takes 5 % off k_bounce (finer tail, pass_sweep_shade_blocks_final.log)
   int staticBlocksPerCU = 16; // grid cap of the one-ray-per-lane traversal kernels (128-thread blocks per CU)   // grid cap of the 256-thread kernels, in blocks per CU
@@ -856,6 +858,7 @@ static void launch_closest(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, c
   TraceLaunch a;
   a.stream = c->stream; a.s = s; a.q = q; a.a4 = pos4; a.b4 = dir4; a.hits = hits; a.vis = nullptr;
   a.perRay3 = perRay3; a.totals5 = totals5; a.fetchCounters = fetchCounters; a.carry = 0; a.minActive = c->traceMinActive; a.raysPerLane = c->traceRaysPerLane;
+  a.vote = c->traceVote; a.wq = c->traceVoteW[0]; a.wt = c->traceVoteW[1]; a.wi = c->traceVoteW[2];
   const bool count = (perRay3 != nullptr || totals5 != nullptr);
   if (c->traceMode == 0 || perRay3 != nullptr || fetchCounters == nullptr) {
     a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
@@ -877,6 +880,7 @@ static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, co
   TraceLaunch a;
   a.stream = c->stream; a.s = s; a.q = q; a.a4 = org4; a.b4 = dir4; a.hits = nullptr; a.vis = vis;
   a.perRay3 = nullptr; a.totals5 = totals5; a.fetchCounters = fetchCounters; a.carry = 0; a.minActive = c->traceMinActive; a.raysPerLane = c->traceRaysPerLane;
+  a.vote = c->traceVote; a.wq = c->traceVoteW[0]; a.wt = c->traceVoteW[1]; a.wi = c->traceVoteW[2];
   if (c->traceMode == 0 || fetchCounters == nullptr) {
     a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
     hk_launch_shadow_static(totals5 != nullptr, a);
@@ -1731,6 +1735,8 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   const std::string n(name);
   if (n == "trace_mode") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "trace_mode: 0 or 1"); c->traceMode = value; }
   else if (n == "trace_min_active") { if (value < 0 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "trace_min_active: 0..64"); c->traceMinActive = value; }
+  else if (n == "trace_vote") c->traceVote = value ? 1 : 0;
+  else if (n == "trace_vote_wq" || n == "trace_vote_wt" || n == "trace_vote_wi") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, n + ": 1..64"); c->traceVoteW[n == "trace_vote_wq" ? 0 : (n == "trace_vote_wt" ? 1 : 2)] = value; }
   else if (n == "shade_waves") { if (value < 3 || value > 5) return fail(c, HYDRA_HIP_EINVAL, "shade_waves: 3, 4 or 5"); c->shadeWaves = value; }
   else if (n == "shade_blocks_per_cu") { if (value < 1 || value > 4096) return fail(c, HYDRA_HIP_EINVAL, "shade_blocks_per_cu: 1..4096"); c->shadeBlocksPerCU = value; }
   else if (n == "static_blocks_per_cu") { if (value < 1 || value > 64) return fail(c, HYDRA_HIP_EINVAL, "static_blocks_per_cu: 1..64"); c->staticBlocksPerCU = value; }
@@ -1764,6 +1770,10 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   const std::string n(name);
   if (n == "trace_mode") *value = c->traceMode;
   else if (n == "trace_min_active") *value = c->traceMinActive;
+  else if (n == "trace_vote") *value = c->traceVote;
+  else if (n == "trace_vote_wq") *value = c->traceVoteW[0];
+  else if (n == "trace_vote_wt") *value = c->traceVoteW[1];
+  else if (n == "trace_vote_wi") *value = c->traceVoteW[2];
   else if (n == "trace_rays_per_lane") *value = c->traceRaysPerLane;
   else if (n == "shade_waves") *value = c->shadeWaves;
   else if (n == "shade_blocks_per_cu") *value = c->shadeBlocksPerCU;

@@ -223,23 +223,31 @@ def test_shadow_any_hit_equals_closest_hit_rule(gpu224):
 
 
 def test_persistent_traversal_kernels_give_identical_results(gpu224):
-    """trace_mode 1 (dynamic ray fetch, suspend/refill, the default) and 0 (one ray per lane) must agree to the bit"""
+    """trace_mode 1 (dynamic ray fetch, suspend/refill, the default) and 0 (one ray per lane) must agree to the bit, and so must the two
+    ways the persistent kernels schedule a wave's steps: by wave vote (trace_vote 1, with any weights) and in the reference's loop nest (0)"""
     core, b, orc = gpu224
     pos4, dir4 = random_rays(50000, 77)
     tfar = np.random.default_rng(3).uniform(0.2, 25.0, len(pos4)).astype(np.float32)
     ref, refvis = orc.trace(pos4, dir4), orc.shadow_trace(pos4, dir4, tfar)
-    defaults = (core.get_option("trace_mode"), core.get_option("trace_min_active"))   # the shipped defaults, restored below
-    assert defaults == (1, 48)
+    defaults = (core.get_option("trace_mode"), core.get_option("trace_min_active"), core.get_option("trace_vote"))   # the shipped defaults, restored below
+    assert defaults[0] == 1
     try:
-        for mode, min_active in ((0, 40), (1, 0), (1, 40), (1, 48), (1, 64)):
+        for mode, min_active, vote, weights in ((0, 40, 0, (1, 1, 1)), (1, 0, 0, (1, 1, 1)), (1, 40, 0, (1, 1, 1)), (1, 48, 0, (1, 1, 1)), (1, 64, 0, (1, 1, 1)),
+                                                (1, 0, 1, (1, 1, 1)), (1, 48, 1, (1, 1, 1)), (1, 56, 1, (2, 1, 1)), (1, 64, 1, (1, 3, 2)), (1, 32, 1, (1, 1, 64))):
             core.set_option("trace_mode", mode)
             core.set_option("trace_min_active", min_active)
+            core.set_option("trace_vote", vote)
+            for k, v in zip(("trace_vote_wq", "trace_vote_wt", "trace_vote_wi"), weights):
+                core.set_option(k, v)
             hits = core.stage_trace(pos4, dir4)
-            assert (hits == ref).all(), (mode, min_active)
-            assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active)
+            assert (hits == ref).all(), (mode, min_active, vote, weights)
+            assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active, vote, weights)
     finally:
         core.set_option("trace_mode", defaults[0])
         core.set_option("trace_min_active", defaults[1])
+        core.set_option("trace_vote", defaults[2])
+        for k in ("trace_vote_wq", "trace_vote_wt", "trace_vote_wi"):
+            core.set_option(k, {"trace_vote_wq": 1, "trace_vote_wt": 1, "trace_vote_wi": 2}[k])
 
 
 @pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
@@ -681,7 +689,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
     fusion, slot order, register budget, refill threshold"""
     core, b, _ = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
-    defaults = {k: core.get_option(k) for k in ("trace_mode", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
+    defaults = {k: core.get_option(k) for k in ("trace_mode", "trace_vote", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
                                                 "scene_tables_in_lds", "srgb_table")}
     assert (defaults["sort_paths"], defaults["scene_tables_in_lds"], defaults["srgb_table"]) == (1, 2, 1)
 
@@ -694,7 +702,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
         return core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays)
     try:
         base = render()
-        for name, value in (("trace_mode", 0), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
+        for name, value in (("trace_mode", 0), ("trace_vote", 1 - defaults["trace_vote"]), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
                             ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("scene_tables_in_lds", 1), ("srgb_table", 0)):
             core.set_option(name, value)
             if name == "fused_bounce" and fix in ("gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"):       # the split form has no tangent frame in its record and no translucent / Blinn lobes: refused, not rendered differently

@@ -19,11 +19,14 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--sweep", action="append", default=[])
+    ap.add_argument("--in-flight", type=int, default=0, help="samples per pixel in flight (option samples_in_flight; 0 = the layer's default for the resolution)")
     args = ap.parse_args()
     from conftest import scene_path
     from hydracore_amd import HostScene
     sc = HostScene(scene_path(args.scene), args.width, args.height, trace_depth=args.depth, enable_dof=0, use_hip=True)
     core = sc.hip()
+    if args.in_flight > 0:
+        core.set_option("samples_in_flight", args.in_flight)
     sc.draw(1, 1)
     core.enable_stage_timing(True)
     names = [s.split("=")[0] for s in args.sweep]
