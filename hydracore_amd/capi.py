@@ -48,7 +48,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_reset_perf_counters", "hydra_hip_enable_stage_timing", "hydra_hip_get_stage_times_per_bounce", "hydra_hip_set_option", "hydra_hip_get_option", "hydra_hip_enable_traversal_counters",
     "hydra_hip_get_traversal_counters", "hydra_hip_get_traversal_oob", "hydra_hip_stage_trace_totals", "hydra_hip_stage_make_eye_rays",
     "hydra_hip_stage_trace", "hydra_hip_stage_shadow_trace", "hydra_hip_stage_eval_surface",
-    "hydra_hip_stage_shade_point", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
+    "hydra_hip_stage_shade_point", "hydra_hip_stage_bounce", "hydra_hip_stage_path_trace", "hydra_hip_stage_random", "hydra_hip_bench_trace",
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
@@ -112,6 +112,7 @@ def load_hip_library():
         "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_eval_surface": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_shade_point": ([vp, i32, vp, vp, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_bounce": ([vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
         "hydra_hip_stage_path_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_random": ([vp, i32, vp, i32, vp, vp], i32),
         "hydra_hip_bench_trace": ([vp, i32, vp, vp, i32, i32, f32p], i32),
@@ -457,6 +458,16 @@ class HipCore:
         out = np.zeros((n, 28), np.float32)
         self._ck(self.lib.hydra_hip_stage_shade_point(self.h, n, _ptr(surf24), _ptr(dir4), _ptr(flags), _ptr(rnd_light4), _ptr(rands10), _ptr(out)),
                  "stage_shade_point")
+        return out
+
+    def stage_bounce(self, depth, max_depth, pos4, dir4, surf24, in16, rands10):
+        """one bounce of n paths with every input handed in (include/hydra_hip.h, hydra_hip_stage_bounce) -> float32 [n, 40]"""
+        n = len(surf24)
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        surf24, in16, rands10 = np.ascontiguousarray(surf24, np.float32), np.ascontiguousarray(in16, np.float32), np.ascontiguousarray(rands10, np.float32)
+        assert surf24.shape == (n, 24) and in16.shape == (n, 16) and rands10.shape == (n, 10)
+        out = np.zeros((n, 40), np.float32)
+        self._ck(self.lib.hydra_hip_stage_bounce(self.h, n, depth, max_depth, _ptr(pos4), _ptr(dir4), _ptr(surf24), _ptr(in16), _ptr(rands10), _ptr(out)), "stage_bounce")
         return out
 
     def stage_path_trace(self, pos4, dir4, rng2):

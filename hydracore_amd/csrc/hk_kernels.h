@@ -261,6 +261,23 @@ struct LightPick {
 // H1 + E1 + E2 -- surface, environment/emission with MIS, termination (kernel_HitEnvironment, kernel_EvalSurface,
 // kernel_EvalEmission).  Returns true when the path goes on (surf valid); false when it ended with radiance `finalColor`.
 // `td` / `instInv`: the triangle record and the instance matrix of the hit, fetched by the caller (valid when HitSome(hit))
+// E2 -- what a hit surface sends back along the ray, MIS-weighted against the light's pdf when the surface belongs to a light
+// (kernel_EvalEmission, PT_Loop.cpp:86-139).  Returns true when the path ends on an emitter; `currColor` is then its radiance.
+HK_DEV bool emission_phase(const SceneDev& s, const f3 ray_pos, const f3 ray_dir, const uint32_t flags, const float prevPdf, const bool prevSpecular,
+                           const int hitInstId, const SurfaceHit& surf, const float* mat, f3& currColor) {
+  const int lightOffset0 = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hitInstId] : -1;
+  const float* pLightHit = lightAt(s, lightOffset0);
+  const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
+  if (!(dot(emission, emission) > 1e-3f)) return false;
+  if (pLightHit != nullptr) {
+    const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
+    float misWeight = misWeightHeuristic(prevPdf, lgtPdf);
+    if (prevSpecular) misWeight = 1.0f;
+    currColor = emission * misWeight;
+  } else
+    currColor = emission;
+  return true;
+}
 template <int F = HK_FEAT_ALL>
 HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
                                const HydraLiteHit& hit, const TriData& td, const m44& instInv, SurfaceHit& surf, f3& finalColor) {
@@ -274,20 +291,8 @@ HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const
   }
   else {
     surf = evalSurfaceWith(s, ray_pos, ray_dir, hit, td, instInv);
-    const float* mat = materialAt(s, surf.matId);
-    const int lightOffset0 = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
-    const float* pLightHit = lightAt(s, lightOffset0);
-    const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
-    if (dot(emission, emission) > 1e-3f) {
-      if (pLightHit != nullptr) {
-        const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
-        float misWeight = misWeightHeuristic(thr4.w, lgtPdf);
-        if (acc4.w != 0.0f) misWeight = 1.0f;
-        currColor = emission * misWeight;
-      } else
-        currColor = emission;
-      done = true;
-    } else if (depth >= maxDepth - 1) done = true;
+    if (emission_phase(s, ray_pos, ray_dir, flags, thr4.w, acc4.w != 0.0f, hit.instId, surf, materialAt(s, surf.matId), currColor)) done = true;
+    else if (depth >= maxDepth - 1) done = true;
   }
   if (done) {
     finalColor = xyz(acc4) + (xyz(thr4) * currColor);   // kernel_AddLastBouceContrib
@@ -305,15 +310,14 @@ HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const floa
   return surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
 }
 
-// L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample)
+// L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample) with the random numbers handed in: rl = the
+// four numbers of rndLight (crandom.h:404-418), pickRand = the one that picks the light (the CPU path passes rl.z, PT_Loop.cpp:141-151)
 template <int F = HK_FEAT_ALL>
-HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& gen, LightPick& lp) {
-  const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
+HK_DEV void light_phase_with(const SceneDev& s, const SurfaceHit& surf, const float4 rl, const float pickRand, LightPick& lp, ShadowSample& sam) {
   lp.pickProb = 1.0f;
-  lp.lightOffset = SelectRandomLightRev(rl.z, s, lp.pickProb);
+  lp.lightOffset = SelectRandomLightRev(pickRand, s, lp.pickProb);
   lp.shadowRayDir = mk3(0, 0, 0);
   lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
-  ShadowSample sam;
   sam.pos = mk3(0, 0, 0); sam.color = mk3(0, 0, 0); sam.pdf = 0.0f; sam.isPoint = false;
   if (lp.lightOffset >= 0) {
     LightSampleRev<F>(s, lightAt(s, lp.lightOffset), mk3(rl.x, rl.y, rl.z), surf.pos, sam);   // clight.h:1561-1610
@@ -323,6 +327,12 @@ HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& ge
   }
   lp.color = sam.color;
   lp.pdfSigned = sam.isPoint ? -sam.pdf : sam.pdf;
+}
+template <int F = HK_FEAT_ALL>
+HK_DEV void light_phase(const SceneDev& s, const SurfaceHit& surf, RandomGen& gen, LightPick& lp) {
+  const float4 rl = rndFloat4_Pseudo(gen);   // rndLight, crandom.h:404-418
+  ShadowSample sam;
+  light_phase_with<F>(s, surf, rl, rl.z, lp, sam);
 }
 
 // S1 -- next-event estimate before visibility (kernel_Shade): explicitColor of PT_Loop.cpp:190-215 is this value * shadow
@@ -343,16 +353,10 @@ HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const Sur
   return ((lc * (1.0f / lightPickProb)) * bxdfVal) * misWeight;
 }
 
-// S2 -- BSDF sampling of the next bounce (kernel_NextBounce); `accum` is the radiance carried on
+// S2 -- BSDF sampling of the next bounce (kernel_NextBounce) with the ten random numbers of RndMatAll handed in; `accum` is the radiance carried on
 template <int F = HK_FEAT_ALL>
-HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
-                              const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
-  float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
-  {
-    const float4 r4 = rndFloat4_Pseudo(gen);
-    rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
-    for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
-  }
+HK_DEV void next_bounce_with(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, const float* rands,
+                             const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
   MatSample ms;
   MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, flags, s, ms);
   const f3 bxdfVal = ms.color * (1.0f / fmaxf(ms.pdf, 1e-20f));
@@ -365,6 +369,17 @@ HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const Surface
   oDir = mk4(ms.direction, as_float(int(flags)));
   oThr = mk4(thr, ms.pdf);
   oAcc = mk4(accum, isSpec ? 1.0f : 0.0f);
+}
+template <int F = HK_FEAT_ALL>
+HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
+                              const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
+  float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
+  {
+    const float4 r4 = rndFloat4_Pseudo(gen);
+    rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
+    for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
+  }
+  next_bounce_with<F>(s, mat, surf, ray_dir, flags, rands, thr4, accum, gidBits, oPos, oDir, oThr, oAcc);
 }
 
 // Split form, kernel 1 of 2: hit phase, survivors compacted into M

@@ -263,6 +263,60 @@ __global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__
   o[21] = ms.direction.x; o[22] = ms.direction.y; o[23] = ms.direction.z;
   o[24] = as_float(ms.flags); o[25] = as_float(int(flagsNextBounceLite(flags, ms, s)));
 }
+// one bounce of one path with every input handed in -- the phases k_bounce strings together (emission_phase, light_phase_with,
+// direct_light_unoccluded, next_bounce_with, environmentColor), so that each can be checked against the reference's own stage kernel of
+// the same name-sake (HitEnvOrLightKernel, LightSample, Shade, NextBounce; tests/golden/ref_stage_*.npz).  in16 per path: thr xyz, previous
+// BSDF pdf, radiance xyz, previous bounce specular (0/1), the light's four random numbers, the number that picks the light, visibility of
+// the shadow ray, Lite_Hit.instId (int bits), ray flags (int bits).  out40: see include/hydra_hip.h.
+__global__ void k_stage_bounce(SceneDev s, int n, int depth, int maxDepth, const float4* __restrict__ pos4, const float4* __restrict__ dir4, const float* __restrict__ surf24,
+                               const float* __restrict__ in16, const float* __restrict__ rands10, float* __restrict__ out40) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = surf24 + size_t(i) * 24;
+  const float* in = in16 + size_t(i) * 16;
+  float* o = out40 + size_t(i) * 40;
+  for (int k = 0; k < 40; k++) o[k] = 0.0f;
+  const f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
+  const f3 thr = mk3(in[0], in[1], in[2]), acc = mk3(in[4], in[5], in[6]);
+  const float prevPdf = in[3];
+  const bool prevSpec = in[7] != 0.0f;
+  const uint32_t flags = uint32_t(as_int(in[15]));
+  SurfaceHit surf;
+  surf.pos = mk3(r[0], r[1], r[2]); surf.normal = mk3(r[3], r[4], r[5]); surf.flatNormal = mk3(r[6], r[7], r[8]);
+  surf.tangent = mk3(r[9], r[10], r[11]); surf.biTangent = mk3(r[12], r[13], r[14]); surf.texCoord = mk2(r[15], r[16]);
+  surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
+  if (surf.matId < 0) {                                   // the ray left the scene: kernel_HitEnvironment, kernel_AddLastBouceContrib
+    const f3 env = environmentColor(s, ray_dir, prevPdf, prevSpec, flags);
+    const f3 fin = acc + (thr * env);
+    o[0] = env.x; o[1] = env.y; o[2] = env.z; o[3] = as_float(1);
+    o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
+    return;
+  }
+  const float* mat = materialAt(s, surf.matId);
+  f3 currColor = mk3(0, 0, 0);
+  if (emission_phase(s, ray_pos, ray_dir, flags, prevPdf, prevSpec, as_int(in[14]), surf, mat, currColor)) {
+    const f3 fin = acc + (thr * currColor);
+    o[0] = currColor.x; o[1] = currColor.y; o[2] = currColor.z; o[3] = as_float(2);
+    o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
+    return;
+  }
+  if (depth >= maxDepth - 1) { o[3] = as_float(4); o[34] = acc.x; o[35] = acc.y; o[36] = acc.z; return; }
+  LightPick lp;
+  ShadowSample sam;
+  light_phase_with(s, surf, make_float4(in[8], in[9], in[10], in[11]), in[12], lp, sam);
+  o[4] = sam.pos.x; o[5] = sam.pos.y; o[6] = sam.pos.z; o[7] = sam.pdf; o[8] = sam.color.x; o[9] = sam.color.y; o[10] = sam.color.z;
+  o[11] = sam.isPoint ? 1.0f : 0.0f; o[12] = lp.pickProb; o[13] = as_float(lp.lightOffset);
+  o[14] = lp.shadowOrg.x; o[15] = lp.shadowOrg.y; o[16] = lp.shadowOrg.z; o[17] = lp.shadowOrg.w;
+  o[18] = lp.shadowRayDir.x; o[19] = lp.shadowRayDir.y; o[20] = lp.shadowRayDir.z;
+  f3 explicitColor = mk3(0, 0, 0);
+  if (lp.lightOffset >= 0) explicitColor = direct_light_unoccluded(s, mat, surf, ray_dir, lp.shadowRayDir, lp.color, lp.pdfSigned, lp.pickProb) * in[13];
+  o[21] = explicitColor.x; o[22] = explicitColor.y; o[23] = explicitColor.z;
+  const f3 accum = acc + (thr * explicitColor);
+  float4 oPos, oDir, oThr, oAcc;
+  next_bounce_with(s, mat, surf, ray_dir, flags, rands10 + size_t(i) * 10, make_float4(thr.x, thr.y, thr.z, prevPdf), accum, 0.0f, oPos, oDir, oThr, oAcc);
+  o[24] = oPos.x; o[25] = oPos.y; o[26] = oPos.z; o[27] = oDir.x; o[28] = oDir.y; o[29] = oDir.z; o[30] = oDir.w;
+  o[31] = oThr.x; o[32] = oThr.y; o[33] = oThr.z; o[34] = oAcc.x; o[35] = oAcc.y; o[36] = oAcc.z; o[37] = oThr.w; o[38] = oAcc.w;
+}
 // ---- bidirectional building blocks (row f3, first milestone), one call per item with the random numbers handed in
 __global__ void k_stage_light_fwd(SceneDev s, int n, const int* __restrict__ lightIds, const float4* __restrict__ rands4, float* __restrict__ out16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1936,6 +1990,22 @@ int hydra_hip_stage_shade_point(hydra_hip_handle c, int n, const float* surf24, 
   return HYDRA_HIP_OK;
 }
 
+int hydra_hip_stage_bounce(hydra_hip_handle c, int n, int depth, int max_depth, const float* ray_pos4, const float* ray_dir4, const float* surf24, const float* in16,
+                           const float* rands10, float* out40) {
+  STAGE_PROLOG(true);
+  if (!ray_pos4 || !ray_dir4 || !surf24 || !in16 || !rands10 || !out40) return fail(c, HYDRA_HIP_EINVAL, "stage_bounce: null argument");
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  float* dsurf = (float*)tb.up(c, surf24, size_t(n) * 96, rc);
+  float* din = (float*)tb.up(c, in16, size_t(n) * 64, rc);
+  float* dr = (float*)tb.up(c, rands10, size_t(n) * 40, rc);
+  float* dout = (float*)tb.up(c, nullptr, size_t(n) * 160, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_bounce, dim3((n + 127) / 128), dim3(128), 0, c->stream, make_scene(c), n, depth, max_depth, dpos, ddir, dsurf, din, dr, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out40, dout, size_t(n) * 160, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
 int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4, const float* ray_dir4, uint32_t* rng_state2, float* color4) {
   // n caller-provided primary rays + RandomGen states run through the PRODUCTION wavefront kernels (path i plays pixel i)
   STAGE_PROLOG(true);

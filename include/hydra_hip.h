@@ -200,6 +200,21 @@ int hydra_hip_stage_shade_point(hydra_hip_handle h, int n, const float* surf24, 
                                 const float* rnd_light4, const float* rands10, float* out28);
 /* whole paths for n given primary rays with given per-path RandomGen state (2 uint32 each, updated in place), run
  * through the production wavefront kernels: IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb, w = 0 */
+/* One bounce of n paths with every input handed in: the phases of the bounce kernel one after the other -- environment
+ * (kernel_HitEnvironment, hydra_drv/CPUExp_Integrators_PT_Loop.cpp:23-33), emission + MIS (kernel_EvalEmission :86-139), light pick and sample with the
+ * shadow ray (kernel_LightSelect / kernel_LightSample :141-168), next-event shading (kernel_Shade :181-216), BSDF sampling and the path-state
+ * update (kernel_NextBounce :218-256, kernel_AddLastBouceContrib :258-262).  The reference's wavefront layer has a kernel per phase
+ * (shaders/material.cl:301 HitEnvOrLightKernel, :578 Shade, :756 NextBounce; shaders/light.cl:140 LightSample): tests/golden/ref_stage_*.npz
+ * holds their inputs and outputs, which this entry is checked against.
+ * surf24 = the record of hydra_hip_stage_eval_surface (matId < 0: the ray left the scene).  in16 per path: throughput xyz, previous BSDF pdf,
+ * radiance so far xyz, previous bounce was specular (0/1), the light's four random numbers (rndLight), the number that picks the light (the CPU
+ * path uses the third of the four), visibility of the shadow ray, Lite_Hit.instId and the ray flags (int bits).  rands10 = RndMatAll's numbers.
+ * out40: [0..2] environment or emitted radiance after MIS, [3] (int) 1 = left the scene, 2 = ended on an emitter, 4 = ended at the depth limit, 0 = goes on;
+ * [4..6] light sample position, [7] pdf, [8..10] radiance, [11] isPoint, [12] pick probability, [13] (int) light offset, [14..16] shadow ray origin,
+ * [17] its far end, [18..20] its direction; [21..23] next-event contribution (x visibility); [24..26] next ray origin, [27..29] direction, [30] (int) flags,
+ * [31..33] throughput, [34..36] radiance carried on (ended paths: the path's final radiance), [37] BSDF pdf of the sample, [38] sample was specular. */
+int hydra_hip_stage_bounce(hydra_hip_handle h, int n, int depth, int max_depth, const float* ray_pos4, const float* ray_dir4, const float* surf24, const float* in16,
+                           const float* rands10, float* out40);
 int hydra_hip_stage_path_trace(hydra_hip_handle h, int n, const float* ray_pos4, const float* ray_dir4,
                                uint32_t* rng_state2, float* color4);
 /* Row f3 (MMLT / SBDPT, hydra_drv/CPUExp_Integrators_MMLT.cpp), first milestone: the building blocks one call at a time.

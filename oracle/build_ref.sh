@@ -5,6 +5,8 @@
 #   oracle/_ref/ref_driver.hsaco : oracle/ref_driver.cl (our kernel entry points) + the reference inline functions of
 #                                  hydra_drv/c*.h, compiled through their OpenCL branch (-D OCL_COMPILER)
 #   oracle/_ref/trace.hsaco      : the reference's unmodified shaders/trace.cl (BVH4TraversalInstKernel, ComputeHit, ...)
+#   oracle/_ref/material.hsaco, light.hsaco, mlt.hsaco, screen.hsaco : the reference's unmodified stage kernels of its own wavefront
+#                                  layer (HitEnvOrLightKernel, Shade, NextBounce; LightSample; the MMLT kernels; ray generation / clear)
 #
 # Toolchain: the image's clang (ROCm LLVM) + ROCm device bitcode libraries; nothing is stubbed.  Options follow the
 # reference's GetOCLShaderCompilerOptions (hydra_drv/GPUOCLLayer.cpp:877-898) except the three arithmetic relaxations
@@ -25,4 +27,5 @@ FLAGS="-x cl -Xclang -finclude-default-header -cl-std=CL1.2 -target amdgcn-amd-a
  -I $REF -I $REF/shaders -w"
 $CLANG $FLAGS "$HERE/ref_driver.cl" -o "$OUT/ref_driver.hsaco"
 $CLANG $FLAGS "$REF/shaders/trace.cl" -o "$OUT/trace.hsaco"
+for k in material light mlt screen; do $CLANG $FLAGS "$REF/shaders/$k.cl" -o "$OUT/$k.hsaco"; done
 ls -la "$OUT"

@@ -2413,6 +2413,72 @@ typedef struct { uint64_t rays; } PathStat;
 /* optional ray recorder used by orc_collect_rays */
 typedef struct { int bounce, shadow; f3 pos, dir; float tfar; int have; } RayProbe;
 
+/* ---- the stages of IntegratorMISPTLoop2 (ref: CPUExp_Integrators_PT_Loop.cpp:9-262), one function each; PathTrace below strings them
+ * together with the generator, orc_stage_bounce runs them on handed-in inputs (fixtures made by the reference's own stage kernels) */
+
+/* kernel_EvalEmission :86-139.  Returns 1 when the path ends on an emitter (currColor = its radiance after MIS), else 0. */
+static int stage_emission(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceHit* surf, const float* mat, int hitInstId, uint32_t flags, MisData misPrev, f3* currColor) {
+  const int lightOffset0 = (s->globals[G_LIGHTS_NUM] != 0) ? s->instLightInstId[hitInstId] : -1;
+  const float* pLightHit = lightAt(s, lightOffset0);
+  const f3 emission = emissionEval(s, ray_pos, ray_dir, surf, flags, pLightHit, mat);
+  if (!(dot3(emission, emission) > 1e-3f)) return 0;
+  if (pLightHit != NULL) {
+    const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf->pos, surf->normal);
+    float misWeight = misWeightHeuristic(misPrev.matSamplePdf, lgtPdf);
+    if (misPrev.isSpecular) misWeight = 1.0f;
+    *currColor = scale3(emission, misWeight);
+  } else
+    *currColor = emission;
+  return 1;
+}
+/* kernel_LightSelect :141-151 + kernel_LightSample :154-168 + the far end of kernel_ShadowTrace's ray :170-179; rl = rndLight's four numbers,
+ * pickRand = the one that picks the light (the CPU path passes rl[2]) */
+static void stage_light(const OrcScene* s, const SurfaceHit* surf, const float rl[4], float pickRand, float* lightPickProb, int* lightOffset,
+                        ShadowSample* explicitSam, f3* shadowRayPos, f3* shadowRayDir, float* tfar) {
+  *lightPickProb = 1.0f;
+  *lightOffset = SelectRandomLightRev(pickRand, s, lightPickProb);
+  *shadowRayPos = v3(0, 0, 0); *shadowRayDir = v3(0, 0, 0); *tfar = -1.0f;
+  memset(explicitSam, 0, sizeof(*explicitSam));
+  if (*lightOffset >= 0) {
+    const float* pl = lightAt(s, *lightOffset);   /* LightSampleRev, clight.h:1561-1610 */
+    LightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf->pos, explicitSam);
+    *shadowRayDir = normalize3(sub3(explicitSam->pos, surf->pos));
+    *shadowRayPos = OffsShadowRayPos(surf->pos, surf->normal, *shadowRayDir, surf->sRayOff);
+    *tfar = length3(sub3(*shadowRayPos, explicitSam->pos)) * 0.995f;
+  }
+}
+/* kernel_Shade :181-216 */
+static f3 stage_shade(const OrcScene* s, const float* mat, const SurfaceHit* surf, f3 ray_dir, f3 shadowRayDir, const ShadowSample* explicitSam,
+                      float lightPickProb, int lightOffset, float shadow) {
+  if (lightOffset < 0) return v3(0, 0, 0);
+  ShadeContext sc;
+  sc.l = shadowRayDir; sc.v = scale3(ray_dir, -1.0f); sc.n = surf->normal; sc.fn = surf->flatNormal;
+  sc.tg = surf->tangent; sc.bn = surf->biTangent; sc.tc = surf->texCoord;
+  const BxDFResult ev = materialEval(mat, &sc, s);
+  const float cos1 = fmaxf(+dot3(shadowRayDir, surf->normal), 0.0f), cos2 = fmaxf(-dot3(shadowRayDir, surf->normal), 0.0f);
+  const f3 bxdfVal = add3(scale3(ev.brdf, cos1), scale3(ev.btdf, cos2));
+  const float lgtPdf = explicitSam->pdf * lightPickProb;
+  float misWeight = misWeightHeuristic(lgtPdf, ev.pdfFwd);
+  if (explicitSam->isPoint) misWeight = 1.0f;
+  const f3 lc = scale3(explicitSam->color, (1.0f / fmaxf(explicitSam->pdf, DEPSILON2)));
+  return scale3(scale3(mul3(scale3(lc, (1.0f / lightPickProb)), bxdfVal), misWeight), shadow);
+}
+/* kernel_NextBounce :218-256 with RndMatAll's numbers handed in */
+static void stage_next(const OrcScene* s, const float* mat, const SurfaceHit* surf, const float* allRands, f3 explicitColor,
+                       f3* ray_pos, f3* ray_dir, uint32_t* flags, MisData* misPrev, f3* accumColor, f3* thoroughput) {
+  MatSample ms;
+  MaterialSampleAndEvalBxDF(mat, allRands, surf, *ray_dir, *flags, s, &ms);
+  const f3 bxdfVal = scale3(ms.color, (1.0f / fmaxf(ms.pdf, 1e-20f)));
+  const float cosTheta = fabsf(dot3(ms.direction, surf->normal));
+  *ray_dir = ms.direction;
+  *ray_pos = OffsRayPos(surf->pos, surf->normal, ms.direction);
+  misPrev->isSpecular = ((ms.flags & RAY_EVENT_S) != 0 || (ms.flags & RAY_EVENT_T) != 0);
+  misPrev->matSamplePdf = ms.pdf;
+  *flags = flagsNextBounceLite(*flags, &ms, s);
+  *accumColor = add3(*accumColor, mul3(*thoroughput, explicitColor));
+  *thoroughput = mul3(*thoroughput, scale3(bxdfVal, cosTheta));
+}
+
 /* ref: CPUExp_Integrators_PT_Loop.cpp:264-321 IntegratorMISPTLoop2::PathTrace with its kernel_* stages :9-262 */
 static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], PathStat* st, RayProbe* probe) {
   f3 accumColor = v3(0, 0, 0), thoroughput = v3(1, 1, 1), currColor = v3(0, 0, 0);
@@ -2430,61 +2496,24 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     /* kernel_EvalSurface */
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
-    /* kernel_EvalEmission :86-139 */
-    {
-      const int lightOffset0 = (s->globals[G_LIGHTS_NUM] != 0) ? s->instLightInstId[hit.instId] : -1;
-      const float* pLightHit = lightAt(s, lightOffset0);
-      const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, pLightHit, mat);
-      if (dot3(emission, emission) > 1e-3f) {
-        if (pLightHit != NULL) {
-          const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
-          float misWeight = misWeightHeuristic(misPrev.matSamplePdf, lgtPdf);
-          if (misPrev.isSpecular) misWeight = 1.0f;
-          currColor = scale3(emission, misWeight);
-        } else
-          currColor = emission;
-        break;
-      } else if (depth >= maxDepth - 1) { currColor = v3(0, 0, 0); break; }
-    }
-    /* kernel_LightSelect :141-151 */
+    if (stage_emission(s, ray_pos, ray_dir, &surf, mat, hit.instId, flags, misPrev, &currColor)) break;
+    else if (depth >= maxDepth - 1) { currColor = v3(0, 0, 0); break; }
     float rl[4];
     orc_rnd_float4(gen, rl);   /* rndLight, crandom.h:404-418 (pseudo-random branch) */
-    float lightPickProb = 1.0f;
-    const int lightOffset = SelectRandomLightRev(rl[2], s, &lightPickProb);
-    /* kernel_LightSample :154-168 */
-    f3 shadowRayPos = v3(0, 0, 0), shadowRayDir = v3(0, 0, 0);
+    float lightPickProb, tfar;
+    int lightOffset;
+    f3 shadowRayPos, shadowRayDir;
     ShadowSample explicitSam;
-    memset(&explicitSam, 0, sizeof(explicitSam));
-    if (lightOffset >= 0) {
-      const float* pl = lightAt(s, lightOffset);   /* LightSampleRev, clight.h:1561-1610 */
-      LightSampleRev(s, pl, v3(rl[0], rl[1], rl[2]), surf.pos, &explicitSam);
-      shadowRayDir = normalize3(sub3(explicitSam.pos, surf.pos));
-      shadowRayPos = OffsShadowRayPos(surf.pos, surf.normal, shadowRayDir, surf.sRayOff);
-    }
+    stage_light(s, &surf, rl, rl[2], &lightPickProb, &lightOffset, &explicitSam, &shadowRayPos, &shadowRayDir, &tfar);
     /* kernel_ShadowTrace :170-179 */
     float shadow = 0.0f;
     if (lightOffset >= 0) {
-      const float tfar = length3(sub3(shadowRayPos, explicitSam.pos)) * 0.995f;
       if (probe && probe->shadow && probe->bounce == depth) { probe->pos = shadowRayPos; probe->dir = shadowRayDir; probe->tfar = tfar; probe->have = 1; }
       shadow = shadowTrace(s, shadowRayPos, shadowRayDir, tfar);
       st->rays++;
     }
-    /* kernel_Shade :181-216 */
-    f3 explicitColor = v3(0, 0, 0);
-    if (lightOffset >= 0) {
-      ShadeContext sc;
-      sc.l = shadowRayDir; sc.v = scale3(ray_dir, -1.0f); sc.n = surf.normal; sc.fn = surf.flatNormal;
-      sc.tg = surf.tangent; sc.bn = surf.biTangent; sc.tc = surf.texCoord;
-      const BxDFResult ev = materialEval(mat, &sc, s);
-      const float cos1 = fmaxf(+dot3(shadowRayDir, surf.normal), 0.0f), cos2 = fmaxf(-dot3(shadowRayDir, surf.normal), 0.0f);
-      const f3 bxdfVal = add3(scale3(ev.brdf, cos1), scale3(ev.btdf, cos2));
-      const float lgtPdf = explicitSam.pdf * lightPickProb;
-      float misWeight = misWeightHeuristic(lgtPdf, ev.pdfFwd);
-      if (explicitSam.isPoint) misWeight = 1.0f;
-      const f3 lc = scale3(explicitSam.color, (1.0f / fmaxf(explicitSam.pdf, DEPSILON2)));
-      explicitColor = scale3(scale3(mul3(scale3(lc, (1.0f / lightPickProb)), bxdfVal), misWeight), shadow);
-    }
-    /* kernel_NextBounce :218-256; RndMatAll crandom.h:478-494 */
+    const f3 explicitColor = stage_shade(s, mat, &surf, ray_dir, shadowRayDir, &explicitSam, lightPickProb, lightOffset, shadow);
+    /* RndMatAll crandom.h:478-494 */
     float allRands[FLOATS_PER_SAMPLE + FLOATS_PER_MLAYER];
     {
       float r4[4];
@@ -2492,20 +2521,61 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
       allRands[0] = r4[0]; allRands[1] = r4[1]; allRands[2] = r4[2];
       for (int k = 0; k < FLOATS_PER_MLAYER; k++) allRands[FLOATS_PER_SAMPLE + k] = orc_rnd_float1(gen);
     }
-    MatSample ms;
-    MaterialSampleAndEvalBxDF(mat, allRands, &surf, ray_dir, flags, s, &ms);
-    const f3 bxdfVal = scale3(ms.color, (1.0f / fmaxf(ms.pdf, 1e-20f)));
-    const float cosTheta = fabsf(dot3(ms.direction, surf.normal));
-    ray_dir = ms.direction;
-    ray_pos = OffsRayPos(surf.pos, surf.normal, ms.direction);
-    misPrev.isSpecular = ((ms.flags & RAY_EVENT_S) != 0 || (ms.flags & RAY_EVENT_T) != 0);
-    misPrev.matSamplePdf = ms.pdf;
-    flags = flagsNextBounceLite(flags, &ms, s);
-    accumColor = add3(accumColor, mul3(thoroughput, explicitColor));
-    thoroughput = mul3(thoroughput, scale3(bxdfVal, cosTheta));
+    stage_next(s, mat, &surf, allRands, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput);
   }
   accumColor = add3(accumColor, mul3(thoroughput, currColor));   /* kernel_AddLastBouceContrib */
   return accumColor;
+}
+
+/* One bounce of n paths with every input handed in: the stage functions above in PathTrace's order.  Layouts as hydra_hip_stage_bounce
+ * (include/hydra_hip.h): surf24 as written by orc_eval_surface; in16 = throughput xyz, previous BSDF pdf, radiance xyz, previous bounce specular,
+ * rndLight's four numbers, the number that picks the light, shadow visibility, Lite_Hit.instId (int), ray flags (int); out40 there. */
+void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const float* pos4, const float* dir4, const float* surf24, const float* in16,
+                      const float* rands10, float* out40) {
+  for (int i = 0; i < n; i++) {
+    const float* r = surf24 + 24 * (size_t)i;
+    const float* in = in16 + 16 * (size_t)i;
+    float* o = out40 + 40 * (size_t)i;
+    memset(o, 0, 40 * sizeof(float));
+    f3 ray_pos = v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), ray_dir = v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
+    f3 thoroughput = v3(in[0], in[1], in[2]), accumColor = v3(in[4], in[5], in[6]);
+    MisData misPrev = {in[3], in[7] != 0.0f};
+    uint32_t flags = (uint32_t)as_int(in[15]);
+    SurfaceHit surf;
+    memset(&surf, 0, sizeof(surf));
+    surf.pos = v3(r[0], r[1], r[2]); surf.normal = v3(r[3], r[4], r[5]); surf.flatNormal = v3(r[6], r[7], r[8]);
+    surf.tangent = v3(r[9], r[10], r[11]); surf.biTangent = v3(r[12], r[13], r[14]);
+    surf.texCoord.x = r[15]; surf.texCoord.y = r[16];
+    surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
+    f3 currColor = v3(0, 0, 0);
+    if (surf.matId < 0) {
+      currColor = environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags);
+      const f3 fin = add3(accumColor, mul3(thoroughput, currColor));
+      o[0] = currColor.x; o[1] = currColor.y; o[2] = currColor.z; o[3] = as_float(1); o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
+      continue;
+    }
+    const float* mat = materialAt(s, surf.matId);
+    if (stage_emission(s, ray_pos, ray_dir, &surf, mat, as_int(in[14]), flags, misPrev, &currColor)) {
+      const f3 fin = add3(accumColor, mul3(thoroughput, currColor));
+      o[0] = currColor.x; o[1] = currColor.y; o[2] = currColor.z; o[3] = as_float(2); o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
+      continue;
+    }
+    if (depth >= maxDepth - 1) { o[3] = as_float(4); o[34] = accumColor.x; o[35] = accumColor.y; o[36] = accumColor.z; continue; }
+    float lightPickProb, tfar;
+    int lightOffset;
+    f3 shadowRayPos, shadowRayDir;
+    ShadowSample sam;
+    stage_light(s, &surf, in + 8, in[12], &lightPickProb, &lightOffset, &sam, &shadowRayPos, &shadowRayDir, &tfar);
+    o[4] = sam.pos.x; o[5] = sam.pos.y; o[6] = sam.pos.z; o[7] = sam.pdf; o[8] = sam.color.x; o[9] = sam.color.y; o[10] = sam.color.z;
+    o[11] = sam.isPoint ? 1.0f : 0.0f; o[12] = lightPickProb; o[13] = as_float(lightOffset);
+    o[14] = shadowRayPos.x; o[15] = shadowRayPos.y; o[16] = shadowRayPos.z; o[17] = tfar; o[18] = shadowRayDir.x; o[19] = shadowRayDir.y; o[20] = shadowRayDir.z;
+    const f3 explicitColor = stage_shade(s, mat, &surf, ray_dir, shadowRayDir, &sam, lightPickProb, lightOffset, in[13]);
+    o[21] = explicitColor.x; o[22] = explicitColor.y; o[23] = explicitColor.z;
+    stage_next(s, mat, &surf, rands10 + 10 * (size_t)i, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput);
+    o[24] = ray_pos.x; o[25] = ray_pos.y; o[26] = ray_pos.z; o[27] = ray_dir.x; o[28] = ray_dir.y; o[29] = ray_dir.z; o[30] = as_float((int)flags);
+    o[31] = thoroughput.x; o[32] = thoroughput.y; o[33] = thoroughput.z; o[34] = accumColor.x; o[35] = accumColor.y; o[36] = accumColor.z;
+    o[37] = misPrev.matSamplePdf; o[38] = misPrev.isSpecular ? 1.0f : 0.0f;
+  }
 }
 
 /* One shading point: kernel_LightSelect + kernel_LightSample + materialEval towards the sample + the BxDF sampling of

@@ -70,6 +70,9 @@ void orc_eval_surface(const OrcScene* s, int n, const float* pos4, const float* 
 void orc_shade_point(const OrcScene* s, int n, const float* surf24, const float* dir4, const int32_t* flags, const float* rndLight4,
                      const float* rands10, float* out28);
 void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4);
+/* one bounce of n paths with every input handed in: the kernel_* stages of PT_Loop.cpp:9-262 in order (layouts: include/hydra_hip.h, hydra_hip_stage_bounce) */
+void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const float* pos4, const float* dir4, const float* surf24, const float* in16,
+                      const float* rands10, float* out40);
 
 /* P0: one sample for every pixel owned by (rank, world, tile) -- IntegratorCommon::DoPass with per-pixel generators.
  * gens: 2 uint32 per pixel, image: float4 running mean (reference semantics) OR sums when sum_mode != 0.

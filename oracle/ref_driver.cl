@@ -864,3 +864,21 @@ __kernel void ref_gbuffer(__global const float2* qmc, int x0, int y0, int nx, in
   o[8] = as_float(g.data1.matId); o[9] = g.data1.coverage; o[10] = g.data2.texCoord.x; o[11] = g.data2.texCoord.y;
   o[12] = as_float(g.data2.objId); o[13] = as_float(g.data2.instId);
 }
+
+/* The wavefront layer keeps SurfaceHit records in four planes with the flat normal and the tangent frame packed to 2 x 16 bit
+ * (WriteSurfaceHit / ReadSurfaceHit, cglobals.h:2537-2585).  This unpacks a plane set written by the reference's ComputeHit with the
+ * reference's own reader into the 24-float record of ref_eval_surface, so that a test can hand the stage kernels' very inputs to the
+ * build's stage functions. */
+__kernel void ref_read_surface_hit(__global const float4* in_surfaceHit, __global float* out24, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global float* r = out24 + i * 24;
+  for (int k = 0; k < 24; k++) r[k] = 0.0f;
+  SurfaceHit sh;
+  ReadSurfaceHit(in_surfaceHit, i, n, &sh);
+  r[0] = sh.pos.x; r[1] = sh.pos.y; r[2] = sh.pos.z; r[3] = sh.normal.x; r[4] = sh.normal.y; r[5] = sh.normal.z;
+  r[6] = sh.flatNormal.x; r[7] = sh.flatNormal.y; r[8] = sh.flatNormal.z; r[9] = sh.tangent.x; r[10] = sh.tangent.y; r[11] = sh.tangent.z;
+  r[12] = sh.biTangent.x; r[13] = sh.biTangent.y; r[14] = sh.biTangent.z; r[15] = sh.texCoord.x; r[16] = sh.texCoord.y;
+  r[17] = as_float(sh.matId); r[18] = sh.t; r[19] = sh.sRayOff; r[20] = sh.hfi ? 1.0f : 0.0f;
+}

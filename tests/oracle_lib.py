@@ -48,6 +48,7 @@ def load(fast=False):
     lib.orc_eval_surface.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_path_trace.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
+    lib.orc_stage_bounce.argtypes = [sp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.orc_render_pass.restype = C.c_uint64
     lib.orc_light_sample_forward.argtypes = [sp, i32, vp, vp, vp]
@@ -243,6 +244,15 @@ class Oracle:
         d1, d2, raw = np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 14), np.float32)
         self.lib.orc_gbuffer(C.byref(self.s), self.w, self.h, x0, y0, nx, ny, _p(d1), _p(d2), _p(raw))
         return d1, d2, raw
+
+    def stage_bounce(self, depth, max_depth, pos4, dir4, surf24, in16, rands10):
+        """orc_stage_bounce: one bounce of n paths with every input handed in -> float32 [n, 40] (layouts: include/hydra_hip.h, hydra_hip_stage_bounce)"""
+        n = len(surf24)
+        pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)
+        surf24, in16, rands10 = np.ascontiguousarray(surf24, np.float32), np.ascontiguousarray(in16, np.float32), np.ascontiguousarray(rands10, np.float32)
+        out = np.zeros((n, 40), np.float32)
+        self.lib.orc_stage_bounce(C.byref(self.s), n, depth, max_depth, _p(pos4), _p(dir4), _p(surf24), _p(in16), _p(rands10), _p(out))
+        return out
 
     def path_trace(self, pos4, dir4, rng2):
         pos4, dir4 = np.ascontiguousarray(pos4, np.float32), np.ascontiguousarray(dir4, np.float32)

@@ -226,3 +226,118 @@ def plane_hammersley(n):
         out[k, 0] = u
         out[k, 1] = np.float32(np.float32(k + 0.5) / np.float32(n))
     return out
+
+
+class RefWavefront:
+    """The reference's OWN wavefront path-tracing stage kernels (hydra_drv/shaders/trace.cl, material.cl, light.cl: compiled unmodified by
+    oracle/build_ref.sh), launched in the order of its host loop (GPUOCLLayer::trace1D_Rev, GPUOCLLayerCore.cpp:9-130: per bounce
+    traverse -> ComputeHit -> HitEnvOrLightKernel -> LightSample -> shadow traversal -> Shade -> NextBounce) on n rays, every buffer
+    read back after every kernel.  What the kernels draw from their generators is a function of the seed: generator i starts as
+    RandomGenInit(seed + i) (InitRandomGen, trace.cl:6-13)."""
+
+    def __init__(self, b, device=0):
+        self.b = b
+        self.mods = {k: RefModule(k + ".hsaco", device) for k in ("trace", "material", "light", "ref_driver")}
+        self.have_inst = int(b["have_inst"])
+
+    def close(self):
+        for m in self.mods.values():
+            m.close()
+
+    def run(self, pos4, dir4, seed, bounces):
+        b, n = self.b, len(pos4)
+        T, M, L, R = self.mods["trace"], self.mods["material"], self.mods["light"], self.mods["ref_driver"]
+        f32, i32, u32 = np.float32, np.int32, np.uint32
+        zeros4 = np.zeros((n, 4), f32)
+
+        def scene(m):   # every module is its own HIP module: buffers are uploaded per module (small scenes)
+            d = dict(glob=m.up(b["globals"]), mat=m.up(b["materials"]), tex=m.up(b["textures"]), geom=m.up(b["geom"]),
+                     pdf=m.up(b["pdfs"] if b["pdfs"].size else np.zeros(4, f32)), bvh=m.up(b["bvh_nodes"]), tris=m.up(b["bvh_tris"]),
+                     matrices=m.up(b["inst_matrices"]), light_id=m.up(b["inst_light_id"]),
+                     texaux=m.up(b["textures_aux"]) if b.get("textures_aux", np.zeros(0)).size else 0,
+                     remap_lists=m.up(b["remap_lists"] if b["remap_lists"].size else np.zeros(4, i32)),
+                     remap_table=m.up(b["remap_table"] if b["remap_table"].size else np.zeros(4, i32)),
+                     remap_inst=m.up(b["remap_inst"] if b["remap_inst"].size else np.zeros(4, i32)))
+            if not d["texaux"]:
+                d["texaux"] = d["tex"]
+            return d
+        sT, sM, sL = scene(T), scene(M), scene(L)
+        rpos, rdir = np.ascontiguousarray(pos4, f32).copy(), np.ascontiguousarray(dir4, f32).copy()
+        rpos[:, 3] = 0; rdir[:, 3] = 0
+        flags = np.zeros(n, u32)
+        gens = np.zeros((n, 2), u32)
+        g = T.alloc(n * 8)
+        T.launch("InitRandomGen", n, [("p", g), ("i", int(seed)), ("i", n)], block=256)
+        gens = T.down(g, u32, (n, 2))
+        color, thr = zeros4.copy(), np.ones((n, 4), f32)                    # ClearAllInternalTempBuffers (screen.cl:381-406): colour 0, throughput 1
+        mis = np.zeros((n, 4), f32); mis[:, 0] = 1.0; mis[:, 1] = 1.0         # makeInitialMisData: pdf 1, cos 1, no material, isSpecular 1
+        mis.view(i32)[:, 2] = -1; mis.view(i32)[:, 3] = 1
+        fog = zeros4.copy()
+        rec = []
+        n_remap_table = b["remap_table"].size // 2
+        n_inst = b["inst_matrices"].size // 16
+        for depth in range(bounces):
+            st = dict(rpos=rpos.copy(), rdir=rdir.copy(), flags_in=flags.copy(), gens_in=gens.copy(), color_in=color.copy(), thr_in=thr.copy(), mis_in=mis.copy())
+            # ---- closest hit
+            d_flags, d_hits = T.up(flags), T.alloc(n * 16)
+            d_rpos, d_rdir = T.up(rpos), T.up(rdir)
+            T.launch("BVH4TraversalInstKernel" if self.have_inst else "BVH4TraversalKernel", n,
+                     [("p", d_rpos), ("p", d_rdir), ("p", sT["bvh"]), ("p", sT["tris"]), ("p", d_flags), ("p", d_hits), ("i", 0), ("i", n)], block=256)
+            hits = T.down(d_hits, np.dtype([("t", f32), ("primId", i32), ("instId", i32), ("geomId", i32)]), (n,))
+            # ---- ComputeHit
+            d_surf = T.alloc(n * 64)
+            T.launch("ComputeHit", n, [("p", d_rpos), ("p", d_rdir), ("p", d_hits), ("p", sT["matrices"]), ("p", sT["geom"]), ("p", sT["mat"]),
+                                       ("p", sT["remap_lists"]), ("p", sT["remap_table"]), ("p", sT["remap_inst"]), ("p", d_flags), ("p", d_surf),
+                                       ("p", sT["glob"]), ("i", n_remap_table), ("i", n_inst), ("i", n)], block=256)
+            flags = T.down(d_flags, u32, (n,))
+            surf_planes = T.down(d_surf, f32, (4, n, 4))
+            r_surf, r_out = R.up(surf_planes), R.alloc(n * 96)
+            R.launch("ref_read_surface_hit", n, [("p", r_surf), ("p", r_out), ("i", n)])
+            st.update(hits=hits, flags_hit=flags.copy(), surf=R.down(r_out, f32, (n, 24)))
+            # ---- HitEnvOrLightKernel
+            m_flags, m_color, m_thr, m_mis, m_emis = M.up(flags), M.up(color), M.up(thr), M.up(mis), M.alloc(n * 16)
+            m_rpos, m_rdir, m_surf, m_hits = M.up(rpos), M.up(rdir), M.up(surf_planes), M.up(hits)
+            m_xy = M.alloc(n * 4)
+            M.launch("HitEnvOrLightKernel", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_xy), ("p", m_surf), ("p", 0),
+                                                ("p", m_color), ("p", m_thr), ("p", m_mis), ("p", m_emis), ("p", 0), ("p", m_mis), ("p", 0), ("p", 0), ("p", 0),
+                                                ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]),
+                                                ("p", sM["light_id"]), ("p", m_hits), ("f", 1.0), ("i", depth), ("i", 0), ("i", n)], block=256)
+            flags, color, thr = M.down(m_flags, u32, (n,)), M.down(m_color, f32, (n, 4)), M.down(m_thr, f32, (n, 4))
+            emis = M.down(m_emis, f32, (n, 4))
+            st.update(flags_env=flags.copy(), color_env=color.copy(), thr_env=thr.copy(), emission=emis)
+            # ---- LightSample
+            l_gens, l_lrev, l_srpos, l_srdir = L.up(gens), L.alloc(n * 48), L.alloc(n * 16), L.alloc(n * 16)
+            L.launch("LightSample", n, [("p", 0), ("p", 0), ("p", L.up(rpos)), ("p", L.up(rdir)), ("p", L.up(flags)), ("p", L.up(surf_planes)),
+                                        ("p", l_gens), ("p", l_lrev), ("p", l_srpos), ("p", l_srdir), ("p", sL["tex"]), ("p", sL["texaux"]), ("p", sL["pdf"]),
+                                        ("p", sL["glob"]), ("i", n)], block=256)
+            gens_l = L.down(l_gens, u32, (n, 2))
+            lrev, srpos, srdir = L.down(l_lrev, f32, (3, n, 4)), L.down(l_srpos, f32, (n, 4)), L.down(l_srdir, f32, (n, 4))
+            st.update(gens_light=gens_l.copy(), lrev=lrev, srpos=srpos, srdir=srdir)
+            # ---- shadow traversal (the instanced early-out kernel; plain trees: the closest-hit form below maxDist)
+            t_shadow = T.alloc(n * 8)
+            T.launch("BVH4TraversalInstShadowKenrel" if self.have_inst else "BVH4TraversalShadowKenrel", n,
+                     [("p", T.up(flags)), ("p", T.up(srpos)), ("p", T.up(srdir)), ("p", t_shadow), ("p", sT["bvh"]), ("p", sT["tris"]), ("p", sT["glob"]), ("i", 0), ("i", n)], block=256)
+            shadow = T.down(t_shadow, np.uint16, (n, 4))
+            st.update(shadow=shadow)
+            # ---- Shade
+            m_shade, m_shadow, m_lrev = M.alloc(n * 16), M.up(shadow), M.up(lrev)
+            m_flags = M.up(flags)
+            M.launch("Shade", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_surf), ("p", m_shadow), ("p", m_lrev), ("p", 0), ("p", 0), ("p", 0),
+                                  ("p", m_shade), ("p", 0), ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
+            shade = M.down(m_shade, f32, (n, 4))
+            st.update(shade=shade)
+            # ---- NextBounce
+            m_gens, m_fog = M.up(gens_l), M.up(fog)
+            m_color, m_thr, m_mis = M.up(color), M.up(thr), M.up(mis)
+            m_rpos2, m_rdir2 = M.up(rpos), M.up(rdir)
+            M.launch("NextBounce", n, [("p", 0), ("p", 0), ("p", m_rpos2), ("p", m_rdir2), ("p", m_flags), ("p", m_gens), ("p", m_surf), ("p", 0),
+                                       ("p", m_color), ("p", m_thr), ("p", m_mis), ("p", m_shadow), ("p", m_fog), ("p", m_shade), ("p", m_emis), ("p", 0), ("p", 0),
+                                       ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
+            rpos, rdir = M.down(m_rpos2, f32, (n, 4)), M.down(m_rdir2, f32, (n, 4))
+            flags, gens = M.down(m_flags, u32, (n,)), M.down(m_gens, u32, (n, 2))
+            color, thr, mis, fog = M.down(m_color, f32, (n, 4)), M.down(m_thr, f32, (n, 4)), M.down(m_mis, f32, (n, 4)), M.down(m_fog, f32, (n, 4))
+            st.update(rpos_out=rpos.copy(), rdir_out=rdir.copy(), flags_out=flags.copy(), gens_out=gens.copy(), color_out=color.copy(), thr_out=thr.copy(), mis_out=mis.copy())
+            rec.append(st)
+            for m in (T, M, L, R):      # the per-bounce buffers; the scene buffers stay
+                pass
+        return rec

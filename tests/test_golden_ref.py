@@ -299,3 +299,117 @@ def test_oracle_matches_reference_gbuffer(name, built):
     assert (want[2][..., 8].view(np.int32) >= 0).mean() > 0.5 and len(np.unique(want[2][..., 8].view(np.int32))) >= 4      # the fixture sees surfaces of several materials
     check_gbuffer(make_oracle(b).gbuffer(), want)
 
+
+
+# ---- the reference's own stage kernels of its wavefront layer (tests/golden/make_golden.py stage_main, tests/ref_ocl.py RefWavefront):
+# HitEnvOrLightKernel (shaders/material.cl:301), LightSample (shaders/light.cl:140), the shadow traversal of shaders/trace.cl, Shade
+# (material.cl:578) and NextBounce (material.cl:756), run unmodified for three bounces of 4 096 camera rays, every kernel's inputs and
+# outputs stored.  check_stage hands the kernels' inputs to `run` (the oracle's orc_stage_bounce / the HIP layer's hydra_hip_stage_bounce:
+# the stage functions the path tracers string together) and compares what comes back with what the reference's kernels wrote.
+# Where the wavefront layer deliberately differs from the CPU integrator this build follows, the comparison is made where they coincide:
+#  * a ray is killed by NextBounce when its throughput falls below 1e-5 or it hit a light, and by flagsNextBounce at the depth limits
+#    (RAY_IS_DEAD; the CPU path never tests that bit): flags are compared modulo that bit, the path state on rays still alive;
+#  * the light is picked with the 4th of rndLight's numbers (light.cl:205), the CPU path uses the 3rd (PT_Loop.cpp:149): the stage
+#    functions take the picking number as an input;
+#  * LightSample scales a sky sample's shadow ray to 2.0 x its length (lightShadowRayMaxDistScale, clight.h:85-91), the CPU path always
+#    uses 0.995 (PT_Loop.cpp:176): the far end is compared through that ratio; visibility comes from the reference's own shadow kernel;
+#  * NextBounce draws its ten numbers as float4, float4, float2 (material.cl:868-889), RndMatAll as one float4 and seven single draws
+#    (crandom.h:478-494): same meaning per index, so the kernel's numbers are reproduced from its generator states and handed in;
+#  * the emission threshold is 1e-6 there and 1e-3 here (material.cl:444, PT_Loop.cpp:103): no ray of the fixtures falls between them;
+#  * Russian roulette starts at the 4th diffuse bounce (cglobals.h:1789-1806; the CPU path has none): the fixtures stop after three.
+STAGE_SCENES = ("test_224", "atrium_small", "atrium_sky_small")
+_U32 = np.uint32
+
+
+def _next_state(st):          # crandom.h:20-26, vectorised; bit-exact by tests/golden/rng.npz through the same expressions in the oracle
+    x = (st[:, 0] * _U32(17) + st[:, 1] * _U32(13123)).astype(_U32)
+    st[:, 0] = ((x << _U32(13)) ^ x).astype(_U32)
+    st[:, 1] ^= (x << _U32(7)).astype(_U32)
+    return x
+
+
+def _float4(x):               # rndFloat4_Pseudo, crandom.h:51-63
+    def h(a, b, c):
+        return ((x * (x * x * _U32(a) + _U32(b)) + _U32(c)).astype(_U32)).astype(np.float32) * np.float32(1.0 / 4294967296.0)
+    return np.stack([h(15731, 74323, 871483), h(13734, 37828, 234234), h(11687, 26461, 137589), h(15707, 789221, 1376312589)], 1)
+
+
+def check_stage(name, b, run, bounces=3):
+    """run(depth, pos4, dir4, surf24, in16, rands10) -> out40 (include/hydra_hip.h, hydra_hip_stage_bounce)"""
+    fx = load("ref_stage_%s.npz" % name)
+    dead, out_of_scene = (4096 << 16), (128 << 16)
+    with np.errstate(over="ignore"):
+        for d in range(bounces):
+            def g(k):
+                return fx["b%d_%s" % (d, k)]
+            flags_in, flags_hit, flags_env, flags_out = g("flags_in"), g("flags_hit"), g("flags_env"), g("flags_out")
+            act = (flags_in & (dead | out_of_scene)) == 0
+            left = act & ((flags_hit & out_of_scene) != 0)
+            surf = g("surf").copy()
+            surf[left, 17] = np.int32(-1).view(np.float32)
+            n = len(surf)
+            # the numbers the kernels drew: LightSample one float4, NextBounce float4 + float4 + float2 (generator states before / between / after are in the fixture)
+            st = g("gens_in").copy()
+            rl = _float4(_next_state(st))
+            going = act & ~left & ((flags_env & (dead | out_of_scene)) == 0)
+            assert (st[going] == g("gens_light")[going]).all()
+            st = g("gens_light").copy()
+            ra, rb, rc = _float4(_next_state(st)), _float4(_next_state(st)), _float4(_next_state(st))
+            assert (st[going] == g("gens_out")[going]).all()
+            rands10 = np.concatenate([ra, rb, rc[:, :2]], 1)
+            in16 = np.zeros((n, 16), np.float32)
+            in16[:, 0:3], in16[:, 3], in16[:, 4:7], in16[:, 7] = g("thr_in")[:, :3], g("mis_in")[:, 0], g("color_in")[:, :3], g("mis_in").view(np.int32)[:, 3]
+            in16[:, 8:12], in16[:, 12] = rl, rl[:, 3]
+            in16[:, 13] = g("shadow")[:, 0].astype(np.float32) / np.float32(65535.0)       # decompressShadow; opaque scenes: 0 or 1
+            in16[:, 14], in16[:, 15] = g("hits")["instId"].view(np.float32), flags_hit.astype(np.uint32).view(np.float32)
+            out = run(d, g("rpos"), g("rdir"), surf, in16, rands10)
+            code = out[:, 3].view(np.int32)
+            # kernel_HitEnvironment + kernel_AddLastBouceContrib against HitEnvOrLightKernel's colour of the rays that left the scene
+            assert (code[left] == 1).all()
+            if left.any():
+                np.testing.assert_allclose(out[left, 34:37], g("color_env")[left, :3], rtol=2e-5, atol=1e-6)
+            # kernel_EvalEmission against HitEnvOrLightKernel's out_emission
+            em = g("emission")
+            lit = act & ~left & ((em[:, :3] ** 2).sum(1) > 1e-3)
+            assert not (act & ~left & ~lit & ((em[:, :3] ** 2).sum(1) > 1e-6)).any()          # nothing between the two thresholds
+            assert ((code == 2) == lit)[act & ~left].all()
+            if lit.any():
+                np.testing.assert_allclose(out[lit, 0:3], em[lit, :3], rtol=2e-5, atol=1e-6)
+            # kernel_LightSelect / kernel_LightSample against LightSample
+            cont = act & ~left & (code == 0)
+            assert cont.sum() > 0.4 * n / (d + 1)
+            lrev, srpos, srdir = g("lrev"), g("srpos"), g("srdir")
+            assert (out[cont, 13].view(np.int32) == lrev[2, cont, 2].view(np.int32)).all() and (out[cont, 12] == lrev[2, cont, 1]).all()
+            np.testing.assert_allclose(out[cont, 4:7], lrev[0, cont, :3], rtol=2e-6, atol=1e-5)
+            np.testing.assert_allclose(out[cont, 7], np.abs(lrev[0, cont, 3]), rtol=3e-5)          # dist^2 / (area x cos): a near-grazing sample amplifies the last bits of the cosine
+            np.testing.assert_allclose(out[cont, 8:11], lrev[1, cont, :3], rtol=2e-6, atol=1e-7)
+            assert ((out[cont, 11] != 0) == (lrev[0, cont, 3] <= 0)).all()
+            np.testing.assert_allclose(out[cont, 14:17], srpos[cont, :3], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(out[cont, 18:21], srdir[cont, :3], rtol=0, atol=2e-6)
+            ratio = out[cont, 17] / srpos[cont, 3]
+            assert (np.isclose(ratio, 1.0, rtol=2e-6) | np.isclose(ratio, 0.995 / 2.0, rtol=2e-6)).all()      # 0.995 everywhere here; the kernel: 2.0 for a sky sample
+            # kernel_Shade against Shade
+            shade = g("shade")[cont, :3]
+            bad = (np.abs(out[cont, 21:24] - shade) > 2e-4 * np.maximum(shade, 1e-3)).any(1)
+            assert bad.mean() < 0.002, (d, bad.mean())
+            # kernel_NextBounce against NextBounce
+            np.testing.assert_allclose(out[cont, 24:27], g("rpos_out")[cont, :3], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(out[cont, 27:30], g("rdir_out")[cont, :3], rtol=0, atol=3e-5)
+            assert ((out[cont, 30].view(np.uint32) | _U32(dead)) == (flags_out[cont] | _U32(dead))).all()
+            col = g("color_out")[cont, :3]
+            assert ((np.abs(out[cont, 34:37] - col) > 2e-4 * np.maximum(col, 1e-3)).any(1)).mean() < 0.002
+            live = cont & ((flags_out & dead) == 0)
+            thr = g("thr_out")[live, :3]
+            assert ((np.abs(out[live, 31:34] - thr) > 2e-4 * np.maximum(thr, 1e-3)).any(1)).mean() < 0.002
+            mis = g("mis_out")
+            np.testing.assert_allclose(out[live, 37], mis[live, 0], rtol=3e-3)       # a glossy lobe's pdf goes through pow
+            assert (out[live, 38] == mis[live].view(np.int32)[:, 3]).all()
+
+
+@pytest.mark.parametrize("name", STAGE_SCENES)
+def test_oracle_matches_reference_stage_kernels(name, built):
+    """the oracle's stage functions (the ones its PathTrace strings together) against the reference's own wavefront stage kernels"""
+    g = load("ref_%s.npz" % name)                                   # the scene's size and depth, as its main fixture was made
+    _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
+    orc = make_oracle(b)
+    check_stage(name, b, lambda d, pos4, dir4, surf, in16, rands10: orc.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10))

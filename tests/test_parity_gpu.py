@@ -807,6 +807,17 @@ def test_hip_against_the_reference_fixtures_in_one_hop(fix, request):
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 
 
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_sky"])
+def test_hip_against_the_reference_stage_kernels(fix, request):
+    """The phases of the bounce kernel (emission_phase, light_phase_with, direct_light_unoccluded, next_bounce_with, environmentColor: what k_bounce
+    strings together, through hydra_hip_stage_bounce) DIRECTLY against the inputs and outputs of the reference's own wavefront stage kernels --
+    HitEnvOrLightKernel, LightSample, Shade, NextBounce, run unmodified for three bounces (tests/golden/ref_stage_*.npz); no oracle in between.
+    tests/test_golden_ref.py check_stage states the comparison and the places where the wavefront layer deliberately differs from the CPU path."""
+    from test_golden_ref import check_stage
+    core, b, _ = request.getfixturevalue(fix)
+    check_stage(FIXTURE_OF[fix], b, lambda d, pos4, dir4, surf, in16, rands10: core.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10))
+
+
 @pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium"])
 def test_hip_traversal_against_the_reference_on_65536_rays(fix, request):
     """SURVEY.md 8c fixtures 2 + 3 at their stated size, one hop: closest hit and shadow visibility of 65 536 rays against the
