@@ -52,7 +52,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
-    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bake_energy_tables", "hydra_hip_bake_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
 ]
 
 _hip = None
@@ -139,6 +139,8 @@ def load_hip_library():
         "hydra_hip_bvh_build_mesh": ([i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_bvh_last_error": ([], C.c_char_p),
         "hydra_hip_normal_map_from_displacement": ([i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, vp], i32),
+        "hydra_hip_bake_energy_tables": ([i32, vp, vp, vp], i32),
+        "hydra_hip_bake_last_error": ([], C.c_char_p),
         "hydra_hip_image_last_error": ([], C.c_char_p),
     }
     for name, (args, res) in sig.items():
@@ -252,6 +254,17 @@ def normal_map_from_displacement(rgba, bump_amt, inv_height, smooth_lvl, device=
     if rc != 0:
         raise HydraError("normal_map_from_displacement failed (%d): %s" % (rc, lib.hydra_hip_image_last_error().decode()))
     return out, ms.value
+
+
+def bake_energy_tables(device=0):
+    """the two multi-scattering energy tables of the globals header baked on the device (csrc/hydra_bake.hip):
+    (uint16 [64, 64] roughness x dot(N,V), uint16 [64, 64, 64] ior x roughness x dot(N,V), device ms of the bake: 0 when it was cached)"""
+    lib = load_hip_library()
+    ggx, transp, ms = np.zeros((64, 64), np.uint16), np.zeros((64, 64, 64), np.uint16), C.c_float(0)
+    rc = lib.hydra_hip_bake_energy_tables(device, _ptr(ggx), _ptr(transp), C.byref(ms))
+    if rc != 0:
+        raise HydraError("bake_energy_tables failed (%d): %s" % (rc, lib.hydra_hip_bake_last_error().decode()))
+    return ggx, transp, ms.value
 
 
 class HipCore:

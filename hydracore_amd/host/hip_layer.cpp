@@ -15,6 +15,12 @@ public:
     const int rc = hydra_hip_create(w, h, a_flags, a_deviceId, &m_h);
     if (rc != HYDRA_HIP_OK) RunTimeError(std::string("CreateHipImpl: ") + hydra_hip_last_error(nullptr));
     hydra_hip_device_name(m_h, m_devName, sizeof(m_devName));
+    // the reference's layers fill the header's energy tables from baked data in their constructor (IHWLayer.h:101); this one bakes them
+    // on its device (once per process, milliseconds)
+    std::vector<uint16_t> ess(4096 + 262144);
+    if (hydra_hip_bake_energy_tables(a_deviceId, ess.data(), ess.data() + 4096, nullptr) != HYDRA_HIP_OK)
+      RunTimeError(std::string("CreateHipImpl: ") + hydra_hip_bake_last_error());
+    SetEnergyTables(ess.data(), ess.data() + 4096);
   }
   ~HipHWLayer() override { if (m_h) hydra_hip_destroy(m_h); }
 

@@ -1,6 +1,8 @@
 // hw_layer.cpp -- arena, globals-blob assembly and the host-resident SharedDataLayer.
 // Follows hydra_drv/MemoryStorageCPU.cpp:9-127 and hydra_drv/IHWLayerDataAssembler.cpp:66-452.
 #include "hw_layer.h"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cassert>
 #include <cmath>
@@ -76,14 +78,20 @@ size_t CalcConstGlobDataOffsets(int32_t* g) {
 }
 
 IHWLayer::IHWLayer() : m_width(0), m_height(0), m_progressBar(nullptr), m_pExternalImage(nullptr) {
-  // InitEngineGlobals (cfetch.h:83-93): zero, rmQMC = -1, tables-ready flag.  The GGX / transparency energy
-  // tables (bakeBrdfEnergy/) are only read by GGX materials, which are outside this tier: kept zero.
+  // InitEngineGlobals (cfetch.h:83-93): zero, rmQMC = -1, tables-ready flag.  The GGX / transparency energy tables stay zero until a
+  // subclass supplies them (SetEnergyTables): the device layer bakes them, the host-blob layer may read a file.
   m_globsBuffHeader.assign(HG_HEADER_WORDS, 0);
   for (int i = 0; i < 16; i++) m_globsBuffHeader[HG_RM_QMC + i] = -1;
   m_globsBuffHeader[HG_TABLES_READY] = 1;
 }
 
 IHWLayer::~IHWLayer() { m_allMemStorages.clear(); }  // storages are deleted by the driver
+
+void IHWLayer::SetEnergyTables(const uint16_t* a_ggx4096, const uint16_t* a_transp262144) {
+  memcpy(&m_globsBuffHeader[HG_ESS_GGX_TABLE], a_ggx4096, 64 * 64 * sizeof(uint16_t));
+  memcpy(&m_globsBuffHeader[HG_ESS_TRANSP_TABLE], a_transp262144, 64 * 64 * 64 * sizeof(uint16_t));
+  m_haveEnergyTables = true;
+}
 
 void IHWLayer::SetAllFlagsAndVars(const AllRenderVarialbes& a_vars) {
   m_globsBuffHeader[HG_FLAGS] = int32_t(a_vars.m_flags);
@@ -234,6 +242,19 @@ void SharedDataLayer::SetAllInstIdToRemapId(const int* a_allInstId, int a_instNu
   m_remapInst.assign(a_allInstId, a_allInstId + a_instNum);
 }
 
-IHWLayer* CreateHostBlobImpl(int w, int h, int a_flags) { return new SharedDataLayer(w, h, a_flags); }
+// the layer without a device (buffers for the CPU oracle): the energy tables come from a file of a device bake when the environment
+// names one -- 4 096 + 262 144 little-endian u16, GGX table first (tests/conftest.py writes it from tests/golden/energy_tables.npz)
+IHWLayer* CreateHostBlobImpl(int w, int h, int a_flags) {
+  SharedDataLayer* layer = new SharedDataLayer(w, h, a_flags);
+  if (const char* path = getenv("HYDRA_AMD_ENERGY_TABLES")) {
+    std::vector<uint16_t> t(4096 + 262144);
+    if (FILE* f = fopen(path, "rb")) {
+      const size_t got = fread(t.data(), sizeof(uint16_t), t.size(), f);
+      fclose(f);
+      if (got == t.size()) layer->SetEnergyTables(t.data(), t.data() + 4096);
+    }
+  }
+  return layer;
+}
 
 }  // namespace hydra_host

@@ -199,6 +199,13 @@ public:
     return p == m_allMemStorages.end() ? nullptr : p->second;
   }
 
+  // The two multi-scattering energy tables of the header (EngineGlobals::m_essGgx2017Table u16[64 x 64], m_essTranspTable u16[64^3],
+  // cfetch.h:77-79).  The reference's layers copy baked data in when they are constructed (IHWLayer.h:101: InitEngineGlobals with
+  // getGgxTable() / getTranspTable() of bakeBrdfEnergy/); this build's device layer bakes its own on the GPU (hydra_hip_bake_energy_tables)
+  // and the host-blob layer reads a file of such a bake when HYDRA_AMD_ENERGY_TABLES names one.  Not virtual: not part of the boundary.
+  void SetEnergyTables(const uint16_t* a_ggx4096, const uint16_t* a_transp262144);
+  bool HaveEnergyTables() const { return m_haveEnergyTables; }
+
 protected:
   virtual void renderSubPixelData(const char* a_dataName, const std::vector<ushort2>& a_pixels, int spp, float4* a_pixValues, float4* a_subPixValues) {}
 
@@ -212,6 +219,7 @@ protected:
   std::vector<int32_t> m_cdataPrepared;     // [header | tables | lights]
   std::unordered_map<std::string, IMemoryStorage*> m_allMemStorages;
   std::vector<float> m_lightSelectTableRev, m_lightSelectTableFwd;
+  bool m_haveEnergyTables = false;
 };
 
 size_t CalcConstGlobDataOffsets(int32_t* pGlobalsHeader);

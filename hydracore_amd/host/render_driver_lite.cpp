@@ -518,10 +518,10 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     if (!efix) efix = xchild(reflect, "multiscatter");
     if (efix && efix->attr_int("val") == 1) {
       put_i(pMaterialS->plain, HM_FLAGS, get_i(pMaterialS->plain, HM_FLAGS) | HMF_ENERGY_FIX);
-      // on a GGX node the flag makes the shading read EngineGlobals::m_essGgx2017Table; the table data lives in the reference's
-      // bakeBrdfEnergy/MSTables*.cpp, which this front end does not have: the header it assembles carries zeros there
-      if (get_i(pMaterialS->plain, HM_TYPE) == HMT_GGX && length(colorS) > 1e-5f)
-        Unsupported("GGX multi-scattering (material " + std::to_string(a_matId) + "): the energy table is not available to this front end");
+      // on a GGX node the flag makes the shading read EngineGlobals::m_essGgx2017Table, which the layer supplies (IHWLayer::SetEnergyTables:
+      // baked on the device; a layer without a device has it only when it was given a bake)
+      if (get_i(pMaterialS->plain, HM_TYPE) == HMT_GGX && length(colorS) > 1e-5f && !m_pHWLayer->HaveEnergyTables())
+        Unsupported("GGX multi-scattering (material " + std::to_string(a_matId) + "): this layer has no energy tables (no device, and HYDRA_AMD_ENERGY_TABLES names no bake)");
     }
   }
   // TransparentMaterialFromHydraMtl :1151-1199.  The fog (Beer) term the glass node carries is stored as the reference

@@ -243,6 +243,12 @@ const char* hydra_hip_bvh_last_error(void);
  * the RGBA8 normal map the shading's BumpMapping reads (xy = 0.5 + 0.5 n, z = n.z, w = height).  bump_amt = 0.5 x the XML amount, smooth_lvl = 10 x the
  * XML smooth level (RenderDriverRTE_AuxTextures.cpp:11-31); smooth_lvl >= 1 adds the 11 x 11 bilateral filter.  rgba_in / rgba_out: w*h*4 bytes in
  * host memory.  No layer handle: the driver calls it while it packs materials.  device_ms_out (may be null): device time of the kernels. */
+/* The two multi-scattering energy tables of the globals header, baked on the device: ggx4096 = EngineGlobals::m_essGgx2017Table (u16 [64 roughness][64 dot(N,V)]),
+ * transp262144 = m_essTranspTable (u16 [64 ior][64][64]) (hydra_drv/cfetch.h:77-79).  The reference copies offline-baked data into the header when a
+ * layer is constructed (hydra_drv/IHWLayer.h:101, getGgxTable / getTranspTable of bakeBrdfEnergy/MSTables*.cpp, made by bakeBrdfEnergy/bakeBrdf.cpp);
+ * this is the same integrand over the same cells integrated with a fixed point set (csrc/hydra_bake.hip).  No layer handle; baked once per process. */
+int hydra_hip_bake_energy_tables(int device, uint16_t* ggx4096, uint16_t* transp262144, float* device_ms_out);
+const char* hydra_hip_bake_last_error(void);
 int hydra_hip_normal_map_from_displacement(int device, int w, int h, const uint8_t* rgba_in, float bump_amt, int inv_height, float smooth_lvl, uint8_t* rgba_out, float* device_ms_out);
 const char* hydra_hip_image_last_error(void);
 /* ---- IntegratorMMLT (row f3; hydra_drv/CPUExp_Integrators_MMLT.cpp): multiplexed MLT over the simplified bidirectional sampler --------------

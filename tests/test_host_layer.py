@@ -1,4 +1,6 @@
 """CPU: the scene front end packs buffers with the reference's layouts, and the BVH4 builder emits a valid tree."""
+import os
+
 import numpy as np
 
 from conftest import host_scene, make_oracle, random_rays
@@ -259,5 +261,11 @@ def test_ggx_reflection_packs_like_the_reference_converter():
     assert abs(m[gx, 16] - 0.7) < 1e-6 and abs(m[gx, 19] - 2.5) < 1e-6 and m[gx, 15] == 0.0   # gloss, fresnel IOR, cosPower
     assert mi[gx, 13] == -2 and mi[gx, 17] == -2 and mi[gx, 1] == 2                              # no textures, CAST_CAUSTICS
     np.testing.assert_allclose(m[gx, 10:13], 0.8)
-    assert (g[1268:1268 + 2048] == 0).all()                          # the front end has no energy table data: zeros
+    # the header carries the layer's energy tables (here: the bake the host-blob layer reads, conftest.energy_tables_file), and material 8's
+    # GGX lobe asked for the compensation in XML (<multiscatter val="1">: PLAIN_MATERIAL_ENERGY_FIX_OR_MULTISCATTER), material 9's did not
+    import conftest
+    want = np.load(os.path.join(conftest.ROOT, "tests", "golden", "energy_tables.npz"))
+    assert (g.view(np.uint16)[1268 * 2: 1268 * 2 + 4096] == want["ggx"].ravel()).all() and (g.view(np.uint16)[3316 * 2: 3316 * 2 + 64 ** 3] == want["transp"].ravel()).all()
+    n8 = table[8] * 4 // 192
+    assert (mi[n8 + mi[n8, 16], 1] & (32768 * 256)) and not (mi[gx, 1] & (32768 * 256))
     sc.close()

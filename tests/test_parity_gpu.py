@@ -1046,6 +1046,29 @@ def test_mmlt_and_gbuffer_refuse_a_frame_that_is_not_the_header_s(gpu42):
     core.mmlt_end()
 
 
+def test_energy_tables_baked_on_the_device(built):
+    """row f4: the two multi-scattering energy tables of the globals header (cfetch.h:77-79).  The device layer bakes them when it is constructed
+    (hydra_hip_bake_energy_tables; the reference's layers copy offline-baked data in at the same point, IHWLayer.h:101): the bake is the committed
+    tests/golden/energy_tables.npz bit for bit (which tests/test_energy_tables.py holds against the reference's own tables), it lands in the
+    header the front end assembles, and a scene that asks for the compensation in XML is accepted and renders what the oracle renders."""
+    from hydracore_amd import HostScene
+    from hydracore_amd.capi import bake_energy_tables
+    ggx, transp, _ = bake_energy_tables(0)
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "energy_tables.npz"))
+    assert (ggx == want["ggx"]).all() and (transp == want["transp"]).all()
+    sc = HostScene(scene_path("atrium_ggx_small"), 96, 54, trace_depth=8, enable_dof=0, use_hip=True, device=0, seed=777)
+    assert sc.unsupported() == 0, sc.log()
+    g = sc.buffers()["globals"].view(np.uint16)
+    assert (g[1268 * 2: 1268 * 2 + 4096] == ggx.ravel()).all() and (g[3316 * 2: 3316 * 2 + 64 ** 3] == transp.ravel()).all()
+    sc.hip().set_option("samples_in_flight", 4)
+    sc.draw(passes=4, spp=4)
+    img = sc.hdr_image()[..., :3]
+    _, b = host_scene("atrium_ggx_small", 96, 54, 8)        # same scene through the host-blob layer (+ the glass flag of conftest.patch_multiscatter, which the XML cannot set)
+    ref = make_oracle(b).render(16, seed=777, streams=4)[0][..., :3]
+    assert np.isfinite(img).all() and abs(img.mean() - ref.mean()) < 0.03 * ref.mean()
+    sc.close()
+
+
 def test_size_mismatch_and_bad_calls_fail_loudly(gpu224):
     from hydracore_amd import HipCore, HydraError
     core, b, _ = gpu224

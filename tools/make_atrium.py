@@ -346,8 +346,11 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material">%s</material>' % (mid, mid, body))
         elif mid in (1, 8):      # lambert + phong (or GGX) blend
             gloss = 0.5 if mid == 1 else 0.85
+            # with --ggx material 8's lobe asks for the multi-scattering energy compensation (PlainMaterialConverter.cpp:1073-1077, 1145-1146): the
+            # layer's energy tables are read; material 1's lobe stays without it
+            ms = '<multiscatter val="1" />' if (args.ggx and mid == 8) else ''
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
-                       '<reflectivity brdf_type="%s"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" /></reflectivity></material>' % (mid, mid, c, refl, gloss))
+                       '<reflectivity brdf_type="%s"><color val="0.35 0.33 0.3" /><glossiness val="%.2f" />%s</reflectivity></material>' % (mid, mid, c, refl, gloss, ms))
         elif args.ggx and mid == 9:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse>'
                        '<reflectivity brdf_type="ggx"><color val="0.8 0.8 0.8" /><glossiness val="0.7" /><fresnel val="1" /><fresnel_ior val="2.5" /></reflectivity></material>' % (mid, mid, c))
