@@ -686,8 +686,9 @@ bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node
 // SkyDomeLight, hydra_drv/PlainLightConverter.cpp:909-1051 + RenderDriverRTE::UpdatePdfTablesForLight
 // (RenderDriverRTE_PdfTables.cpp:479-570).  A sky without texture gets the reference's 2x2 uniform luminance image as its
 // sampling table; an 8-bit lat-long texture gets the table of LuminanceFromUchar4Image (:312-356: halve until <= 256,
-// max(r,g,b)/255, + 0.1 * max(mean, 1)).  Skies with a sampler matrix other than identity, float textures (their table is
-// Gauss-blurred by HydraAPI's HDRImageLite, absent here) are counted as unsupported.  <perez turbidity sun_id> switches the colour seen by
+// max(r,g,b)/255, + 0.1 * max(mean, 1)); a float (.image4f, e.g. an .hdr environment) texture that of LuminanceFromFloat4Image (:227-266:
+// halve until <= 2048, max(r,g,b), HDRImageLite::gaussBlur(2, 1.5) (:32-111, 151-176), + 0.05 * max(mean, 1)).  The texture's sampler matrix
+// goes into the sampler's rows and, inverted, into the light record (sampling maps table cells back through it).  <perez turbidity sun_id> switches the colour seen by
 // camera and bounce rays to the Perez model (:920-923, 1019-1028); the sun it names is copied in at EndScene.
 bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) {
   const XmlNode* perez = a_node->child("perez");
@@ -696,11 +697,12 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   const XmlNode* texNode = colorNode ? colorNode->child("texture") : nullptr;
   int32_t skyTexId = int32_t(HYDRA_INVALID_TEXTURE);
   float skyGamma = 1.0f;
+  float4x4 samplerMat;          // identity; row-major as HydraXMLHelpers::ReadMatrix4x4 hands it over
   if (texNode) {
     if (texNode->has_attr("matrix")) {
       float m[16];
-      const float ident16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-      if (!parse_floats(texNode->attr("matrix"), m, 16) || memcmp(m, ident16, 64) != 0) Unsupported("sky light texture matrix other than identity");
+      if (!parse_floats(texNode->attr("matrix"), m, 16)) RunTimeError("UpdateLight: sky light texture matrix needs 16 numbers");
+      samplerMat = float4x4::from_row_major(m);
     }
     if (texNode->has_attr("input_gamma")) skyGamma = texNode->attr_float("input_gamma");
     if (texNode->has_attr("id")) skyTexId = texNode->attr_int("id");
@@ -715,12 +717,14 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   d[HL_COLOR] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
   float* sam0 = d + HL_SKY_SAMPLER0;                       // SWTexSampler: flags, gamma, texId, dummy, row0, row1
   put_i(sam0, HS_FLAGS, 0); sam0[HS_GAMMA] = skyGamma; put_i(sam0, HS_TEXID, skyTexId); put_i(sam0, HS_DUMMY, 0);
-  sam0[HS_ROW0] = 1.0f; sam0[HS_ROW1 + 1] = 1.0f;          // identity sampler matrix rows
+  for (int k = 0; k < 4; k++) { sam0[HS_ROW0 + k] = samplerMat.at(0, k); sam0[HS_ROW1 + k] = samplerMat.at(1, k); }   // :986-989
   memcpy(d + HL_SKY_SAMPLER1, sam0, 12 * sizeof(float));
   put_i(d, HL_COLOR_TEX, skyTexId);                                                 // used to build the pdf table
   put_i(d, HL_COLOR_TEX_MATRIX, texNode ? 0 : int32_t(HYDRA_INVALID_TEXTURE));     // 0 = "have sampler and texture" (:976-977)
-  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  memcpy(d + HL_SKY_INV_MATRIX0, ident, 64);               // the reference writes both inverses to slot 0 (:947-948, 999-1000)
+  {
+    const float4x4 inv = inverse4x4(samplerMat);           // the reference writes both inverses to slot 0 (:947-948, 991-992)
+    memcpy(d + HL_SKY_INV_MATRIX0, inv.data(), 64);
+  }
   d[HL_SKY_COLOR_AUX] = color.x; d[HL_SKY_COLOR_AUX + 1] = color.y; d[HL_SKY_COLOR_AUX + 2] = color.z;
   put_i(d, HL_SKY_COLOR_TEX_AUX, skyTexId);
   put_i(d, HL_SKY_COLOR_TEX_MATRIX_AUX, texNode ? 0 : int32_t(HYDRA_INVALID_TEXTURE));
@@ -741,7 +745,47 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
     const int32_t* hdr = reinterpret_cast<const int32_t*>(static_cast<const char*>(m_pTexStorage->GetBegin()) + size_t(table[skyTexId]) * 16);
     int w = hdr[0], h = hdr[1];
     const int bpp = hdr[3];
-    if (bpp != 4) { Unsupported("float sky light texture (its pdf table needs HydraAPI's Gauss blur)"); }
+    if (bpp == 16) {
+      std::vector<float> px(reinterpret_cast<const float*>(hdr + 4), reinterpret_cast<const float*>(hdr + 4) + size_t(w) * h * 4);
+      for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizef4, :186-215
+        if (w <= 2048 && h <= 2048) continue;                      // MAX_ENV_LIGHT_PDF_SIZE, RenderDriverRTE.h:23
+        const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
+        std::vector<float> half(size_t(nw) * nh * 4);
+        for (int y = 0; y < nh; y++)
+          for (int x = 0; x < nw; x++)
+            for (int ch = 0; ch < 4; ch++) {
+              const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
+              half[(size_t(y) * nw + x) * 4 + ch] = 0.25f * (((px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch]) + px[size_t(o2 + 2 * x) * 4 + ch]) + px[size_t(o2 + 2 * x + 1) * 4 + ch]);
+            }
+        px.swap(half); w = nw; h = nh;
+      }
+      lum.assign(size_t(w) * h, 0.0f);
+      float avg = 0.0f;
+      for (size_t i = 0; i < lum.size(); i++) { lum[i] = std::max(px[i * 4], std::max(px[i * 4 + 1], px[i * 4 + 2])); avg += lum[i]; }
+      avg /= float(lum.size());
+      avg = std::max(avg, 1.0f);
+      // HDRImageLite::gaussBlur(2, 1.5), one channel: rows, then columns, windows clipped at the border, weights re-normalised (+ 1e-5)
+      float gk[5], gsum = 0.0f;
+      { const float sg = 2.0f * 1.5f * 1.5f; for (int x = -2; x <= 2; x++) { const float r = sqrtf(float(x * x)); gk[x + 2] = expf(-r / sg) / (3.141592654f * sg); gsum += gk[x + 2]; } for (float& v : gk) v /= gsum; }
+      std::vector<float> tmp(lum.size());
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+          float c = 0.0f, sw = 0.0f;
+          for (int q = std::max(x - 2, 0); q <= std::min(x + 2, w - 1); q++) { c += lum[size_t(y) * w + q] * gk[q + 2 - x]; sw += gk[q + 2 - x]; }
+          tmp[size_t(y) * w + x] = c / (sw + 1e-5f);
+        }
+      if (h == 1) lum = tmp;
+      else
+        for (int x = 0; x < w; x++)
+          for (int y = 0; y < h; y++) {
+            float c = 0.0f, sw = 0.0f;
+            for (int q = std::max(y - 2, 0); q <= std::min(y + 2, h - 1); q++) { c += tmp[size_t(q) * w + x] * gk[q + 2 - y]; sw += gk[q + 2 - y]; }
+            lum[size_t(y) * w + x] = c / (sw + 1e-5f);
+          }
+      for (float& v : lum) v += 0.05f * avg;                        // no pixel with zero pdf
+      lw = w; lh = h;
+    }
+    else if (bpp != 4) Unsupported("sky light texture of " + std::to_string(bpp) + " bytes per texel");
     else {
       std::vector<uint8_t> px(reinterpret_cast<const uint8_t*>(hdr + 4), reinterpret_cast<const uint8_t*>(hdr + 4) + size_t(w) * h * 4);
       for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizeUB4, :268-310
@@ -968,14 +1012,25 @@ bool RenderDriverLite::UpdateMesh(int32_t a_meshId, int vertNum, int triNum, con
 
 bool RenderDriverLite::UpdateCamera(const XmlNode* cam) {
   if (cam == nullptr) return true;
-  if (std::string(cam->attr("type")) == "two_matrices") Unsupported("two_matrices camera");
+  m_camera.useMatrices = false;
+  if (std::string(cam->attr("type")) == "two_matrices") {   // RenderDriverRTE.cpp:1178-1201: both matrices come as text, 16 numbers in row-major order
+    float mWorldView[16], mProj[16];
+    if (!parse_floats(xtext(cam->child("mWorldView")), mWorldView, 16) || !parse_floats(xtext(cam->child("mProj")), mProj, 16))
+      RunTimeError("UpdateCamera: a two_matrices camera needs <mWorldView> and <mProj> with 16 numbers each");
+    m_camera.mProj = float4x4::from_row_major(mProj);
+    m_camera.mWorldView = float4x4::from_row_major(mWorldView);
+    m_camera.useMatrices = true;
+    m_camera.fov = 2.0f * atanf(1.0f / m_camera.mProj.at(1, 1)) * (180.f / 3.14159265358979323846f);   // the field of view back from the projection
+  }
   float v[3];
-  if (cam->child("fov") && !cam->child("fov")->text.empty()) m_camera.fov = strtof(cam->child("fov")->text.c_str(), nullptr);
-  if (cam->child("nearClipPlane")) m_camera.nearPlane = strtof(cam->child("nearClipPlane")->text.c_str(), nullptr);
-  if (cam->child("farClipPlane")) m_camera.farPlane = strtof(cam->child("farClipPlane")->text.c_str(), nullptr);
-  if (cam->child("position") && parse_floats(cam->child("position")->text, v, 3)) m_camera.pos = float3(v[0], v[1], v[2]);
-  if (cam->child("look_at") && parse_floats(cam->child("look_at")->text, v, 3)) m_camera.lookAt = float3(v[0], v[1], v[2]);
-  if (cam->child("up") && parse_floats(cam->child("up")->text, v, 3)) m_camera.up = float3(v[0], v[1], v[2]);
+  if (!m_camera.useMatrices) {
+    if (cam->child("fov") && !cam->child("fov")->text.empty()) m_camera.fov = strtof(cam->child("fov")->text.c_str(), nullptr);
+    if (cam->child("nearClipPlane")) m_camera.nearPlane = strtof(cam->child("nearClipPlane")->text.c_str(), nullptr);
+    if (cam->child("farClipPlane")) m_camera.farPlane = strtof(cam->child("farClipPlane")->text.c_str(), nullptr);
+    if (cam->child("position") && parse_floats(cam->child("position")->text, v, 3)) m_camera.pos = float3(v[0], v[1], v[2]);
+    if (cam->child("look_at") && parse_floats(cam->child("look_at")->text, v, 3)) m_camera.lookAt = float3(v[0], v[1], v[2]);
+    if (cam->child("up") && parse_floats(cam->child("up")->text, v, 3)) m_camera.up = float3(v[0], v[1], v[2]);
+  }
 
   auto vars = m_pHWLayer->GetAllFlagsAndVars();
   vars.m_varsF[HV_F_CAM_FOV] = (3.14159265358979323846f / 180.f) * m_camera.fov;
@@ -1347,8 +1402,9 @@ void RenderDriverLite::EndScene() {
 
 void RenderDriverLite::Draw() {
   const float aspect = float(m_width) / float(m_height);
-  float4x4 proj = perspective_matrix(m_camera.fov, aspect, m_camera.nearPlane, m_camera.farPlane);
-  float4x4 worldView = look_at(m_camera.pos, m_camera.lookAt, m_camera.up);
+  // RenderDriverRTE::CalcCameraMatrices, RenderDriverRTE.cpp:1301-1324
+  float4x4 proj = m_camera.useMatrices ? m_camera.mProj : perspective_matrix(m_camera.fov, aspect, m_camera.nearPlane, m_camera.farPlane);
+  float4x4 worldView = m_camera.useMatrices ? m_camera.mWorldView : look_at(m_camera.pos, m_camera.lookAt, m_camera.up);
   float4x4 projInv = inverse4x4(proj), mvInv = inverse4x4(worldView);
   m_pHWLayer->SetCamMatrices(&projInv.c[0][0], &mvInv.c[0][0], &proj.c[0][0], &worldView.c[0][0], aspect,
                              (3.14159265358979323846f / 180.f) * m_camera.fov, m_camera.lookAt);

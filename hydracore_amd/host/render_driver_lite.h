@@ -80,7 +80,8 @@ private:
   bool MeshHasOpacity(int32_t a_meshId) const;
   void CreateAlphaTestTable(ConvertionResult& cr);
 
-  struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0}; } m_camera;
+  struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0};
+                  bool useMatrices = false; float4x4 mProj, mWorldView; } m_camera;   // useMatrices: a "two_matrices" camera (RenderDriverRTE.cpp:1178-1201)
 
   struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false, isMesh = false; int kind = 0;
                       std::vector<float> meshPos; std::vector<int32_t> meshInd; };   // meshPos / meshInd: MeshLight::tempPos / tempInd   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)

@@ -91,7 +91,7 @@ def check_shade_point(out, ref, frac=0.002):
     assert valid.mean() > 0.3
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_perez_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_skyhdr_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_perez_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))

@@ -94,6 +94,17 @@ def gpu_atrium_sky(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_skyhdr(built):
+    """the open hall under a FLOAT lat-long environment texture (sun 25 x the sky) sampled through a sampler matrix that turns it by a quarter of the
+    horizon: the blurred table of LuminanceFromFloat4Image (RenderDriverRTE_PdfTables.cpp:227-266) and the inverse-matrix path of SkyLightSampleRev"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_skyhdr_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_skytex(built):
     """open roof and a lat-long environment texture as the sky light (512x256, importance table 256x128)"""
     from hydracore_amd import HipCore
@@ -292,7 +303,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -558,7 +569,7 @@ def test_mmlt_through_the_ihwlayer_adapter(built):
     assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -579,7 +590,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -755,7 +766,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
         assert (outs[0][3].view(np.uint32) == o[3].view(np.uint32)).all() and outs[0][4:] == o[4:]
 
 
-FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small",
+FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small", "gpu_atrium_skyhdr": "atrium_skyhdr_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
               "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small"}
 

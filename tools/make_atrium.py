@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sky", action="store_true", help="open roof + constant sky light (1,1,1) x 0.5 next to the roof light (SURVEY 8d, S2)")
     ap.add_argument("--delta-lights", action="store_true", help="open roof, no sky: adds a point, a spot and a directional (soft sun) light to the roof light")
+    ap.add_argument("--sky-hdr", action="store_true", help="like --sky-tex, but the environment map is a float texture (.image4f, sun at 25x the sky) sampled through a sampler matrix "
+                    "that turns it by a quarter of the horizon: the table of LuminanceFromFloat4Image and the inverse-matrix path of SkyLightSampleRev")
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     ap.add_argument("--perez", action="store_true", help="like --sky, but the sky uses the Perez all-weather model (turbidity 2.5) with a directional sun (light id 3) "
                     "that also lights the hall through the open roof")
@@ -269,6 +271,7 @@ def main():
                     "height map (amount 0.8; the wall's copy smoothed, smooth_lvl 0.3): the layer bakes the normal maps (IHWLayer::NormalMapFromDisplacement)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
+    args.sky_tex = args.sky_tex or args.sky_hdr
     args.sky = args.sky or args.sky_tex or args.perez
     refl = "ggx" if args.ggx else "torranse_sparrow" if args.translucent else "phong"   # "torranse_sparrow" (sic) = Blinn in a Torrance-Sparrow model
     s = np.sqrt(args.scale)
@@ -301,9 +304,14 @@ def main():
         env[..., 0] = 0.35 + 0.25 * (1 - up); env[..., 1] = 0.45 + 0.25 * (1 - up); env[..., 2] = 0.75 - 0.15 * (1 - up)
         env[v < 0.5] = [0.12, 0.11, 0.10, 0]                          # ground half
         sun = np.exp(-(((u - 0.62) * 2.0) ** 2 + (v - 0.80) ** 2) / (2 * 0.02 ** 2))
-        env[..., :3] = np.clip(env[..., :3] + sun[..., None] * np.array([1.0, 0.95, 0.8]), 0, 1)
-        env[..., 3] = 1.0
-        texs.append((None, (env * 255.0 + 0.5).astype(np.uint8)))
+        if args.sky_hdr:
+            env[..., :3] = env[..., :3] + sun[..., None] * np.array([25.0, 23.0, 18.0])
+            env[..., 3] = 1.0
+            texs.append((None, env.astype(np.float32)))
+        else:
+            env[..., :3] = np.clip(env[..., :3] + sun[..., None] * np.array([1.0, 0.95, 0.8]), 0, 1)
+            env[..., 3] = 1.0
+            texs.append((None, (env * 255.0 + 0.5).astype(np.uint8)))
     mask_tex = None
     if args.cutouts:
         mask_tex = len(texs)
@@ -319,12 +327,12 @@ def main():
     xml = ['<?xml version="1.0"?>', '<textures_lib total_chunks="%d">' % (len(texs) + len(meshes))]
     chunk = 0
     for tid, (n, img) in enumerate(texs):
-        name = "data/chunk_%05d.image4ub" % chunk
+        name = "data/chunk_%05d.%s" % (chunk, "image4f" if img.dtype == np.float32 else "image4ub")
         th, tw = img.shape[0], img.shape[1]
         with open(os.path.join(out, name), "wb") as f:
             f.write(struct.pack("<II", tw, th))
             f.write(img.tobytes())
-        xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, tw * th * 4, tw, th))
+        xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, tw * th * img.dtype.itemsize * 4, tw, th))
         chunk += 1
     xml.append("</textures_lib>")
 
@@ -409,6 +417,8 @@ def main():
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
                + ('\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1">'
+                  '<texture id="3" type="texref" matrix="1 0 0 -0.25 0 1 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></color><multiplier val="0.8" /></intensity></light>' if args.sky_hdr else
+                  '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1">'
                   '<texture id="3" type="texref" input_gamma="2.2" /></color><multiplier val="0.8" /></intensity></light>' if args.sky_tex else
                   '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
                   '<multiplier val="1.5" /></intensity><perez turbidity="2.5" sun_id="3" /></light>'

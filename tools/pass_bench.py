@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--sweep", action="append", default=[])
+    ap.add_argument("--per-bounce", action="store_true", help="also print the bounce kernel's time per bounce (ms)")
     ap.add_argument("--in-flight", type=int, default=0, help="samples per pixel in flight (option samples_in_flight; 0 = the layer's default for the resolution)")
     args = ap.parse_args()
     from conftest import scene_path
@@ -43,6 +44,9 @@ def main():
         rays = st.extensionRays + st.shadowRays
         print("%-40s %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f %9.0f" % (" ".join("%s=%d" % (n, v) for n, v in zip(names, combo)), st.traversalTimeMs, st.evalHitMs,
                                                                  st.shadowTimeMs, st.shadeTimeMs, other, st.passTimeMs, rays / st.passTimeMs / 1e3), flush=True)
+        if args.per_bounce:
+            pb = core.stage_times_per_bounce(args.depth + 1)
+            print("    bounce kernel per bounce (ms): " + " ".join("%.2f" % x for x in pb[:, 1]) + "   closest: " + " ".join("%.2f" % x for x in pb[:, 0]), flush=True)
 
 
 if __name__ == "__main__":
