@@ -18,8 +18,8 @@ HK_DEV f3 UniformSampleSphere(float u1, float u2) {   // cglobals.h:1160-1168
 HK_DEV f3 lightMatrixMul(const float* M, f3 v) {   // matrix3x3f_mult_float3, row-major 3x3
   return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
 }
-// clight.h:654-719 (no IES, no sky portal: both are refused at upload)
-HK_DEV void AreaLightSampleForward(const float* L, float4 rands, LightSampleFwd& out) {
+// clight.h:654-719 (no IES: refused at upload)
+HK_DEV void AreaLightSampleForward(const SceneDev& s, const float* L, float4 rands, LightSampleFwd& out) {
   const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
   f3 samplePos = mk3(offsetX * L[HL_AREA_SIZE_X], 0.0f, offsetY * L[HL_AREA_SIZE_Y]);
   if (as_int(L[HL_AREA_IS_DISK]) != 0) {
@@ -37,7 +37,7 @@ HK_DEV void AreaLightSampleForward(const float* L, float4 rands, LightSampleFwd&
     pdfW = 1.0f / (2.0f * HK_PI * (1.0f - cos2));
   }
   cosTheta = fmaxf(dot(sampleDir, lnorm), 0.0f);
-  const f3 color = areaDiffuseLightGetIntensity(L, sampleDir * (-1.0f), false);
+  const f3 color = (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL) ? areaLightSkyPortalCustomColor<HK_FEAT_ALL>(s, L, sampleDir * (-1.0f)) : areaDiffuseLightGetIntensity(L, sampleDir * (-1.0f), false);
   out.isPoint = false;
   out.pos = samplePos + lnorm * epsilonOfPos(samplePos);
   out.dir = sampleDir;
@@ -113,8 +113,8 @@ HK_DEV void SphereLightSampleForward(const float* L, float4 rands, LightSampleFw
   out.norm = lnorm;
 }
 HK_DEV void MeshLightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {   // clight.h:1023-1062
-  f3 samplePos, sampleNorm; float pdfA;
-  MeshLightSamplePos(s, L, mk3(rands.x, rands.y, rands2x), samplePos, sampleNorm, pdfA);
+  f3 samplePos, sampleNorm; f2 tc; float pdfA;
+  MeshLightSamplePos(s, L, mk3(rands.x, rands.y, rands2x), samplePos, sampleNorm, tc, pdfA);
   samplePos = meshLightMatrixMul(L + HL_MESH_MATRIX, samplePos);
   sampleNorm = normalize(meshLightMatrixMul(L + HL_MESH_MATRIX, sampleNorm));
   samplePos = samplePos + lightPos(L);
@@ -123,21 +123,36 @@ HK_DEV void MeshLightSampleForward(const SceneDev& s, const float* L, float4 ran
   out.isPoint = false;
   out.pos = samplePos + sampleNorm * epsilonOfPos(samplePos);
   out.dir = sampleDir;
-  out.color = lightColor(L) * cosTheta;
+  out.color = meshLightGetIntensity(s, L, tc) * cosTheta;
   out.pdfA = 1.0f / L[HL_SURFACE_AREA];
   out.pdfW = cosTheta * HK_INV_PI;
   out.cosTheta = cosTheta;
   out.norm = sampleNorm;
 }
-// rands2x: the first of the two extra light dimensions (LightGroup2::group2.x, primary-sample dimension 8), which only mesh lights read
+HK_DEV void CylinderLightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {   // clight.h:813-835
+  f3 samplePos, lnorm; f2 tc; float pdfA;
+  CylinderLightSamplePos(s, L, mk3(rands.x, rands.y, rands2x), samplePos, lnorm, tc, pdfA);
+  const f3 sampleDir = MapSampleToCosineDistribution(rands.z, rands.w, lnorm, lnorm, 1.0f);
+  const float cosTheta = fmaxf(dot(sampleDir, lnorm), 0.0f);
+  out.isPoint = false;
+  out.pos = samplePos + lnorm * epsilonOfPos(samplePos);
+  out.dir = sampleDir;
+  out.color = cylinderLightGetIntensity(s, L, tc) * cosTheta;
+  out.pdfA = pdfA;
+  out.pdfW = cosTheta * HK_INV_PI;
+  out.cosTheta = cosTheta;
+  out.norm = lnorm;
+}
+// rands2x: the first of the two extra light dimensions (LightGroup2::group2.x, primary-sample dimension 8), which only mesh and cylinder lights read
 HK_DEV void LightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {
   switch (as_int(L[HL_TYPE])) {
     case HLT_MESH: MeshLightSampleForward(s, L, rands, rands2x, out); break;
+    case HLT_CYLINDER: CylinderLightSampleForward(s, L, rands, rands2x, out); break;
     case HLT_SPHERE: SphereLightSampleForward(L, rands, out); break;
     case HLT_DIRECT: DirectLightSampleForward(L, rands, out); break;
     case HLT_POINT_SPOT: PointSpotSampleForward(L, rands, out); break;
     case HLT_POINT_OMNI: PointLightSampleForward(L, rands, out); break;
-    default: AreaLightSampleForward(L, rands, out); break;
+    default: AreaLightSampleForward(s, L, rands, out); break;
   }
 }
 // lightPdfFwd, clight.h:1117-1175 (no IES)
@@ -388,7 +403,7 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
     const float* mat = materialAt(s, surf.matId);
     const int lightOffset = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
     const float* pLight = lightAt(s, lightOffset);
-    const f3 emission = emissionEval(s, ray_dir, surf, flags, pLight, mat);
+    const f3 emission = emissionEval<F>(s, ray_pos, ray_dir, surf, flags, misSpec, pLight, mat);
     const bool splitDL = g_varsI(s)[HV_I_MMLT_FIRST_BOUNCE] > 3;   // m_splitDLByGrammar, Common.cpp:28
     if (dot(emission, emission) > 1e-6f) {
       if (currDepth == camTraceDepth && haveToHitLight && pLight != nullptr) {

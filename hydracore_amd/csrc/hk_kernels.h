@@ -263,14 +263,15 @@ struct LightPick {
 // `td` / `instInv`: the triangle record and the instance matrix of the hit, fetched by the caller (valid when HitSome(hit))
 // E2 -- what a hit surface sends back along the ray, MIS-weighted against the light's pdf when the surface belongs to a light
 // (kernel_EvalEmission, PT_Loop.cpp:86-139).  Returns true when the path ends on an emitter; `currColor` is then its radiance.
+template <int F = HK_FEAT_ALL>
 HK_DEV bool emission_phase(const SceneDev& s, const f3 ray_pos, const f3 ray_dir, const uint32_t flags, const float prevPdf, const bool prevSpecular,
                            const int hitInstId, const SurfaceHit& surf, const float* mat, f3& currColor) {
   const int lightOffset0 = (s.hdr[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hitInstId] : -1;
   const float* pLightHit = lightAt(s, lightOffset0);
-  const f3 emission = emissionEval(s, ray_dir, surf, flags, pLightHit, mat);
+  const f3 emission = emissionEval<F>(s, ray_pos, ray_dir, surf, flags, prevSpecular, pLightHit, mat);
   if (!(dot(emission, emission) > 1e-3f)) return false;
   if (pLightHit != nullptr) {
-    const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf.pos, surf.normal);
+    const float lgtPdf = pLightHit[HL_PICK_PROB_REV] * lightEvalPDF<F>(s, pLightHit, ray_pos, ray_dir, surf.pos, surf.normal, surf.texCoord);
     float misWeight = misWeightHeuristic(prevPdf, lgtPdf);
     if (prevSpecular) misWeight = 1.0f;
     currColor = emission * misWeight;
@@ -291,7 +292,7 @@ HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const
   }
   else {
     surf = evalSurfaceWith(s, ray_pos, ray_dir, hit, td, instInv);
-    if (emission_phase(s, ray_pos, ray_dir, flags, thr4.w, acc4.w != 0.0f, hit.instId, surf, materialAt(s, surf.matId), currColor)) done = true;
+    if (emission_phase<F>(s, ray_pos, ray_dir, flags, thr4.w, acc4.w != 0.0f, hit.instId, surf, materialAt(s, surf.matId), currColor)) done = true;
     else if (depth >= maxDepth - 1) done = true;
   }
   if (done) {

@@ -386,7 +386,7 @@ HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const S
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
-enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_PEREZ = 512, HK_FEAT_ALL = 1023,
+enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_PEREZ = 512, HK_FEAT_RARE_LIGHTS = 1024 /* sky portals, cylinder lights, textured mesh lights */, HK_FEAT_ALL = 2047,
        HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent, Blinn and the anisotropic (Beckmann, TRGGX) nodes */ };   // DELTA_LIGHTS stands for "lights other than area and sky": point, spot, directional, sphere
 
 // ================================================================================================ materials
@@ -1384,7 +1384,10 @@ HK_DEV f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, bool eyeRay) {
   return color;
 }
 struct ShadowSample { f3 pos, color; float pdf, maxDist, cosAtLight; bool isPoint; };   // cglobals.h:2448-2456
-HK_DEV void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:1180-1229
+// sky portals (AREA_LIGHT_SKY_PORTAL): an area light whose colour is multiplied by what the sky light it names shows in the ray's direction; defined below, after the sky
+template <int F> HK_DEV f3 areaLightSkyPortalCustomColor(const SceneDev& s, const float* L, f3 rayDir);
+template <int F>
+HK_DEV void AreaLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:1180-1229
   const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
   f3 sp = mk3(offsetX * L[HL_AREA_SIZE_X], 0.0f, offsetY * L[HL_AREA_SIZE_Y]);
   if (as_int(L[HL_AREA_IS_DISK]) != 0) {
@@ -1399,7 +1402,8 @@ HK_DEV void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample&
   const f3 ln = lightNorm(L);
   out.isPoint = false;
   out.pos = sp + ln * epsilonOfPos(sp);
-  out.color = areaDiffuseLightGetIntensity(L, rayDir, false);
+  if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL)) out.color = areaLightSkyPortalCustomColor<F>(s, L, rayDir);
+  else out.color = areaDiffuseLightGetIntensity(L, rayDir, false);
   out.pdf = areaDiffuseLightEvalPDF(L, rayDir, hitDist);
   out.maxDist = hitDist;
   out.cosAtLight = -dot(rayDir, ln);
@@ -1541,6 +1545,16 @@ HK_DEV f3 skyLightIntensity(const SceneDev& s, const float* L, f3 dir) {
   const f2 tc = sphereMapTo2DTexCoord(dir, sintheta);
   return lightColor(L) * sample2DExt(as_int(L[HL_COLOR_TEX_MATRIX]), tc, L + HL_SKY_SAMPLER0, s);
 }
+// areaLightSkyPortalCustomColor, clight.h:614-629, and the tail of areaDiffuseLightGetIntensity (:590-607): the sky record sits AREA_LIGHT_SKY_OFFSET records
+// away from the portal's (RenderDriverRTE.cpp:1670-1682); a Perez sky counts half
+template <int F>
+HK_DEV f3 portalSkyColor(const SceneDev& s, const float* L, f3 rayDir) {
+  const float* sky = L + ptrdiff_t(as_int(L[HL_AREA_SKY_OFFSET])) * HL_FLOATS;
+  if ((F & HK_FEAT_PEREZ) && (as_int(sky[HL_FLAGS]) & HLF_SKY_USE_PEREZ)) return skyLightPerezColor(sky, rayDir) * 0.5f;
+  return skyLightIntensity<F & ~HK_FEAT_PEREZ>(s, sky, rayDir);
+}
+template <int F>
+HK_DEV f3 areaLightSkyPortalCustomColor(const SceneDev& s, const float* L, f3 rayDir) { return lightColor(L) * portalSkyColor<F>(s, L, rayDir); }
 HK_DEV void SkyLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:427-462
   const float* hdr = pdfTableHeader(s, as_int(L[HL_SKY_PDF_TABLE0]));
   const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
@@ -1660,8 +1674,9 @@ HK_DEV void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out.cosAtLight = fabsf(dot(lnorm, dirToV));
 }
 // mesh lights, clight.h:966-1062, 1513-1546: a copy of the light's mesh and the prefix sums of its triangle areas live in the pdf arena
-// (MeshLight, PlainLightConverter.cpp:724-835); a triangle by area, a point in it by uniform barycentrics; untextured (the front end refuses a texture)
-HK_DEV void MeshLightSamplePos(const SceneDev& s, const float* L, f3 rands, f3& pos, f3& norm, float& pdfA) {
+// (MeshLight, PlainLightConverter.cpp:724-835); a triangle by area, a point in it by uniform barycentrics; the colour texture (meshLightGetIntensity, :957-963) is looked up at the
+// texture coordinates interpolated the same way
+HK_DEV void MeshLightSamplePos(const SceneDev& s, const float* L, f3 rands, f3& pos, f3& norm, f2& texCoord, float& pdfA) {
   const int meshId = as_int(L[HL_MESH_MESH_ID]), pdftId = as_int(L[HL_MESH_TABLE_ID]), triNum = as_int(L[HL_MESH_TRI_NUM]);
   const int tabOffs = s.hdr[HG_PDF_TABLE_OFFS];
   const float4* mesh = s.pdfStorage + s.globals[tabOffs + meshId];
@@ -1673,21 +1688,25 @@ HK_DEV void MeshLightSamplePos(const SceneDev& s, const float* L, f3 rands, f3& 
   float pickProb = 1.0f;
   const int triangleId = SelectIndexPropToOpt(rands.z, table, triNum + 1, pickProb);
   const int iA = indices[triangleId * 3 + 0], iB = indices[triangleId * 3 + 1], iC = indices[triangleId * 3 + 2];
-  const f3 A = xyz(vpos[iA]), B = xyz(vpos[iB]), C = xyz(vpos[iC]);
-  const f3 nA = xyz(vnorm[iA]), nB = xyz(vnorm[iB]), nC = xyz(vnorm[iC]);
+  const float4 dA = vpos[iA], dB = vpos[iB], dC = vpos[iC], dnA = vnorm[iA], dnB = vnorm[iB], dnC = vnorm[iC];
+  const f3 A = xyz(dA), B = xyz(dB), C = xyz(dC);
+  const f3 nA = xyz(dnA), nB = xyz(dnB), nC = xyz(dnC);
   float u = rands.x, v = rands.y;
   if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
   const float w = 1.0f - u - v;
   pos = ((A * u) + (B * v)) + (C * w);
   norm = ((nA * u) + (nB * v)) + (nC * w);
+  texCoord = mk2((dA.w * u + dB.w * v) + dC.w * w, (dnA.w * u + dnB.w * v) + dnC.w * w);   // u rides in pos.w, v in norm.w (:1003-1005)
   pdfA = 1.0f / L[HL_SURFACE_AREA];
 }
 HK_DEV f3 meshLightMatrixMul(const float* M, f3 v) {   // matrix3x3f_mult_float3, cglobals.h:1091-1098
   return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
 }
+HK_DEV f3 meshLightGetIntensity(const SceneDev& s, const float* L, f2 tc) { return sample2DExt(as_int(L[HL_MESH_TEXMATRIX_ID]), tc, L, s) * lightColor(L); }
+template <int F = HK_FEAT_ALL>
 HK_DEV void MeshLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
-  f3 samplePos, sampleNorm; float pdfA;
-  MeshLightSamplePos(s, L, rands, samplePos, sampleNorm, pdfA);
+  f3 samplePos, sampleNorm; f2 tc; float pdfA;
+  MeshLightSamplePos(s, L, rands, samplePos, sampleNorm, tc, pdfA);
   samplePos = meshLightMatrixMul(L + HL_MESH_MATRIX, samplePos);
   sampleNorm = normalize(meshLightMatrixMul(L + HL_MESH_MATRIX, sampleNorm));
   samplePos = samplePos + lightPos(L);
@@ -1696,7 +1715,7 @@ HK_DEV void MeshLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 i
   const float cosVal = fmaxf(-dot(rayDir, sampleNorm), 0.0f);
   out.isPoint = false;
   out.pos = samplePos + sampleNorm * epsilonOfPos(samplePos);
-  out.color = lightColor(L);          // meshLightGetIntensity without a texture
+  out.color = (F & HK_FEAT_RARE_LIGHTS) ? meshLightGetIntensity(s, L, tc) : lightColor(L);   // an untextured light's sampler returns white
   out.pdf = PdfAtoW(pdfA, hitDist, cosVal);
   out.maxDist = hitDist;
   out.cosAtLight = cosVal;
@@ -1705,9 +1724,76 @@ HK_DEV float meshLightEvalPDF(const float* L, f3 rayDir, f3 lnorm, float hitDist
   const float pdfA = 1.0f / fmaxf(L[HL_SURFACE_AREA], HK_DEPSILON);
   return PdfAtoW(pdfA, hitDist, fmaxf(dot(rayDir, lnorm * (-1.0f)), 0.0f));
 }
+// cylinder lights, clight.h:753-830, 1338-1385: (z, phi) over the 2-D table the front end makes from the colour texture (2 x 2 uniform without one), mapped onto the
+// open cylinder of the light's local frame; the area pdf carries the table's density
+struct Map2DSample { f2 texCoord; float mapPdf; };
+HK_DEV Map2DSample sampleMap2D(f3 rands, const float* intervals, const int sizeX, const int sizeY) {   // clight.h:378-403
+  const float fw = float(sizeX), fh = float(sizeY);
+  float pdf = 1.0f;
+  int pixelOffset = SelectIndexPropToOpt(rands.z, intervals, sizeX * sizeY + 1, pdf);
+  if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+  const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+  Map2DSample r;
+  r.texCoord = mk2((1.0f / fw) * ((float(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f), (1.0f / fh) * ((float(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f));
+  r.mapPdf = pdf * (fw * fh);
+  return r;
+}
+HK_DEV f3 cylinderLightGetIntensity(const SceneDev& s, const float* L, f2 tc) { return sample2DExt(as_int(L[HL_CYL_TEXMATRIX_ID]), tc, L, s) * lightColor(L); }
+HK_DEV void CylinderLightSamplePos(const SceneDev& s, const float* L, f3 rands, f3& pos, f3& norm, f2& texCoord, float& pdfA) {
+  Map2DSample sample;
+  sample.texCoord = mk2(rands.x, rands.y);
+  sample.mapPdf = 1.0f;
+  const int texId = as_int(L[HL_CYL_PDF_TABLE_ID]);
+  if (texId > 0) {
+    const float* hdr = pdfTableHeader(s, texId);
+    sample = sampleMap2D(rands, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+  }
+  pdfA = sample.mapPdf / L[HL_SURFACE_AREA];
+  const float zMin = L[HL_CYL_ZMIN], zMax = L[HL_CYL_ZMAX], radius = L[HL_CYL_RADIUS], phiMax = L[HL_CYL_PHIMAX];
+  const float z = zMin + sample.texCoord.x * (zMax - zMin);
+  const float phi = sample.texCoord.y * phiMax;
+  const float sinPhi = sinf(phi), cosPhi = cosf(phi);
+  f3 pObj = mk3(radius * cosPhi, radius * sinPhi, z);
+  f3 n = normalize(mk3(pObj.x, pObj.y, 0.0f));
+  const float hitRad = sqrtf(pObj.x * pObj.x + pObj.y * pObj.y);
+  pObj.x *= radius / hitRad;
+  pObj.y *= radius / hitRad;
+  n = normalize(meshLightMatrixMul(L + HL_CYL_MATRIX, n));
+  const f3 center = lightPos(L);
+  pos = (center + meshLightMatrixMul(L + HL_CYL_MATRIX, pObj)) + (n * epsilonOfPos(center));
+  norm = n;
+  texCoord = sample.texCoord;
+}
+HK_DEV float cylinderLightEvalPDF(const SceneDev& s, const float* L, f3 illum, f3 lpos, f3 lnorm, f2 texCoord) {
+  float mapPdf = 1.0f;
+  const int texId = as_int(L[HL_CYL_PDF_TABLE_ID]);
+  if (texId != 0) {
+    const float* hdr = pdfTableHeader(s, texId);
+    mapPdf = evalMap2DPdf(texCoord, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+  }
+  const float hitDist = length(lpos - illum);
+  const f3 rayDir = normalize(lpos - illum);
+  const float pdfA = mapPdf / fmaxf(L[HL_SURFACE_AREA], HK_DEPSILON);
+  return PdfAtoW(pdfA, hitDist, fmaxf(dot(rayDir, lnorm * (-1.0f)), 0.0f));
+}
+HK_DEV void CylinderLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {
+  f3 samplePos, n; f2 tc; float pdfA;
+  CylinderLightSamplePos(s, L, rands, samplePos, n, tc, pdfA);
+  const float hitDist = length(samplePos - illum);
+  const f3 rayDir = normalize(samplePos - illum);
+  const float cosVal = fmaxf(dot(rayDir, n * (-1.0f)), 0.0f);
+  out.isPoint = false;
+  out.pos = samplePos;
+  out.color = cylinderLightGetIntensity(s, L, tc);
+  out.pdf = PdfAtoW(pdfA, hitDist, cosVal);
+  out.maxDist = hitDist;
+  out.cosAtLight = cosVal;
+}
 // lightEvalPDF, clight.h:1613-1633, for the light a path has run into: the types that have a surface (area rectangles / disks, spheres, meshes)
-HK_DEV float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
+template <int F = HK_FEAT_ALL>
+HK_DEV float lightEvalPDF(const SceneDev& s, const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm, f2 texCoord) {
   if (as_int(L[HL_TYPE]) == HLT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  if ((F & HK_FEAT_RARE_LIGHTS) && as_int(L[HL_TYPE]) == HLT_CYLINDER) return cylinderLightEvalPDF(s, L, illum, lpos, lnorm, texCoord);
   if (as_int(L[HL_TYPE]) == HLT_MESH) return meshLightEvalPDF(L, rayDir, lnorm, length(illum - lpos));
   return areaDiffuseLightEvalPDF(L, rayDir, length(illum - lpos));
 }
@@ -1719,8 +1805,9 @@ HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_SPOT) SpotLightSampleRev(L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev(L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_SPHERE) SphereLightSampleRev(L, rands, illum, out);
-  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_MESH) MeshLightSampleRev(s, L, rands, illum, out);
-  else AreaLightSampleRev(L, rands, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_MESH) MeshLightSampleRev<F>(s, L, rands, illum, out);
+  else if ((F & HK_FEAT_RARE_LIGHTS) && type == HLT_CYLINDER) CylinderLightSampleRev(s, L, rands, illum, out);
+  else AreaLightSampleRev<F>(s, L, rands, illum, out);
 }
 // environmentColor, cbidir.h:492-533 (misPrev.prevMaterialOffset stays -1 on this path: PT_Loop.cpp:247-249)
 template <int F = HK_FEAT_ALL>
@@ -1738,8 +1825,63 @@ HK_DEV f3 environmentColor(const SceneDev& s, f3 rayDir, float prevPdf, bool pre
   return envColor;
 }
 
-// emissionEval, cbidir.h:653-678 (+ lightGetIntensity clight.h:1661-1706 for area lights)
-HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_dir, const SurfaceHit& sh, uint32_t flags, const float* pLight, const float* mat) {
+// hitDirectLight, clight.h:1636-1657: the first sun of the header whose cone holds the ray
+HK_DEV int hitDirectLight(const SceneDev& s, f3 ray_dir) {
+  const float* gf = reinterpret_cast<const float*>(s.globals);
+  const int sunNumber = s.globals[HG_SUN_NUMBER];   // beyond the words a kernel may hold staged in LDS (HK_HDR_WORDS): read from the buffer itself
+  for (int sunId = 0; sunId < sunNumber; sunId++) {
+    const float* sun = gf + HG_SUNS + sunId * HL_FLOATS;
+    if (-dot(ray_dir, lightNorm(sun)) > sun[HL_DIRECT_ALPHA_COS]) return sunId;
+  }
+  return -1;
+}
+HK_DEV float directLightAttenuation(const float* L, f3 illum) {   // clight.h:892-912
+  const f3 lpos = lightPos(L);
+  const float cos_alpha = dot(normalize(illum - lpos), lightNorm(L));
+  if (cos_alpha > 0.0f) {
+    const float sinAlpha = sqrtf(1.0f - cos_alpha * cos_alpha);
+    const float d = length(illum - lpos) * sinAlpha;
+    const float r1 = L[HL_DIRECT_RADIUS1], r2 = L[HL_DIRECT_RADIUS2];
+    return mylocalsmoothstep(fmaxf(r2, r1), fminf(r2, r1), d);
+  }
+  return 0.0f;
+}
+HK_DEV float directLightEvalPDF(const float* L, f3 ray_dir) {   // clight.h:1462-1476
+  if (L[HL_DIRECT_SSOFTNESS] > 1e-5f) {
+    const float tanAlpha = L[HL_DIRECT_ALPHA_TAN], cosTheta = -dot(ray_dir, lightNorm(L));
+    return HK_PI * (tanAlpha * tanAlpha) * (cosTheta * cosTheta * cosTheta);
+  }
+  return 1.0f;
+}
+// lightGetIntensity, clight.h:1661-1706: what the light a path has run into sends back along the ray
+template <int F = HK_FEAT_ALL>
+HK_DEV f3 lightGetIntensity(const SceneDev& s, const float* L, f3 ray_pos, f3 ray_dir, f2 texCoord, uint32_t flags, bool wasSpecular) {
+  const int type = as_int(L[HL_TYPE]);
+  if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL) && (flags & 0xFFu) > 0) {
+    const int hitId = hitDirectLight(s, ray_dir);
+    if (hitId >= 0) {   // the ray looks into a sun through the portal
+      const float* sun = reinterpret_cast<const float*>(s.globals) + HG_SUNS + hitId * HL_FLOATS;
+      f3 sunColor = lightColor(sun) * directLightAttenuation(sun, ray_pos);
+      const float pdfW = directLightEvalPDF(sun, ray_dir);
+      const uint32_t gflags = uint32_t(s.hdr[HG_FLAGS]);
+      if (((flags >> 8) & 0xFFu) > 0 && !(gflags & HF_STUPID_PT_MODE) && !wasSpecular) sunColor = mk3(0, 0, 0);
+      else if ((wasSpecular && (gflags & HF_ENABLE_PT_CAUSTICS)) || (gflags & HF_STUPID_PT_MODE)) sunColor = sunColor * (1.0f / pdfW);
+      return sunColor;
+    }
+    return areaLightSkyPortalCustomColor<F>(s, L, ray_dir);
+  }
+  if (type == HLT_AREA) {
+    f3 color = areaDiffuseLightGetIntensity(L, ray_dir, (flags & 0xFFu) == 0);
+    if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL)) color = color * portalSkyColor<F>(s, L, ray_dir);
+    return color;
+  }
+  if ((F & HK_FEAT_RARE_LIGHTS) && type == HLT_CYLINDER) return cylinderLightGetIntensity(s, L, texCoord);
+  if ((F & HK_FEAT_RARE_LIGHTS) && type == HLT_MESH) return meshLightGetIntensity(s, L, texCoord);
+  return lightColor(L);
+}
+// emissionEval, cbidir.h:653-678
+template <int F = HK_FEAT_ALL>
+HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_pos, f3 ray_dir, const SurfaceHit& sh, uint32_t flags, bool wasSpecular, const float* pLight, const float* mat) {
   const f3 normal = sh.hfi ? sh.normal * (-1.0f) : sh.normal;
   const int lightsNum = s.hdr[HG_LIGHTS_NUM];
   bool hasIES = false;
@@ -1747,9 +1889,6 @@ HK_DEV f3 emissionEval(const SceneDev& s, f3 ray_dir, const SurfaceHit& sh, uint
   if (dot(ray_dir, normal) >= 0.0f && !hasIES) return mk3(0, 0, 0);
   f3 out = materialEvalEmission(mat, ray_dir, normal, sh.texCoord, s);
   if ((matFlags(mat) & HMF_FORBID_EMISSIVE_GI) && (flags & 0xFFu) > 0) out = mk3(0, 0, 0);
-  if (lightsNum > 0 && pLight != nullptr) {
-    if (as_int(pLight[HL_TYPE]) == HLT_AREA) out = areaDiffuseLightGetIntensity(pLight, ray_dir, (flags & 0xFFu) == 0);
-    else out = lightColor(pLight);
-  }
+  if (lightsNum > 0 && pLight != nullptr) out = lightGetIntensity<F>(s, pLight, ray_pos, ray_dir, sh.texCoord, flags, wasSpecular);
   return out;
 }

@@ -1028,7 +1028,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       else if ((f & ~HK_FEAT_SKY) == 0) F = HK_FEAT_SKY;
       else if ((f & ~(HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR)) == 0) F = HK_FEAT_SKY | HK_FEAT_DELTA_LIGHTS | HK_FEAT_OREN_NAYAR;
       else if ((f & ~(HK_FEAT_CLASSIC | HK_FEAT_NMAP)) == 0 && (f & HK_FEAT_NMAP)) F = HK_FEAT_CLASSIC | HK_FEAT_NMAP;   // normal maps over the classic set: without the rarer lobes
-      else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ)) F = HK_FEAT_ALL;
+      else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ | HK_FEAT_RARE_LIGHTS)) F = HK_FEAT_ALL;
       else if (!(f & HK_FEAT_GLASS)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GLASS;
       else if (!(f & HK_FEAT_GGX)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GGX;
       BounceLaunch bl;
@@ -1203,15 +1203,30 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
     const int type = blob[at + HL_TYPE];
-    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH);
+    const bool known = (type == HLT_AREA || type == HLT_SKY_DOME || type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH || type == HLT_CYLINDER);
     if (!known)
-      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, mesh, sky-dome, point, spot and directional lights only");
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has type " + std::to_string(type) + "; the HIP layer implements area, sphere, cylinder, mesh, sky-dome, point, spot and directional lights only");
+    if (type == HLT_AREA && uint32_t(blob[at + HL_COLOR_TEX]) != HYDRA_INVALID_TEXTURE)   // the reference's converter never makes one either (PlainLightConverter.cpp:206-207)
+      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " is a textured area light, which the HIP layer does not implement");
+    if (type == HLT_AREA && (blob[at + HL_FLAGS] & HLF_SKY_PORTAL)) {   // a portal names its sky by a record offset (RenderDriverRTE.cpp:1670-1682)
+      const int64_t sky = int64_t(i) + blob[at + HL_AREA_SKY_OFFSET];
+      if (sky < 0 || sky >= blob[HG_LIGHTS_NUM] || blob[size_t(blob[HG_LIGHTS_OFFS]) + size_t(sky) * HL_FLOATS + HL_TYPE] != HLT_SKY_DOME)
+        return fail(c, HYDRA_HIP_EINVAL, "upload_globals: sky portal " + std::to_string(i) + " does not name a sky light of the table");
+    }
+    if (type == HLT_CYLINDER || (type == HLT_AREA && (blob[at + HL_FLAGS] & HLF_SKY_PORTAL)) || (type == HLT_MESH && uint32_t(blob[at + HL_MESH_TEXMATRIX_ID]) != HYDRA_INVALID_TEXTURE))
+      lightFeat |= HK_FEAT_RARE_LIGHTS;   // only the all-features instantiations carry them
+    if (type == HLT_CYLINDER) {
+      const int tab = blob[at + HL_CYL_PDF_TABLE_ID];
+      if (tab < 0 || tab >= blob[HG_PDF_TABLE_SIZE])
+        return fail(c, HYDRA_HIP_EINVAL, "upload_globals: cylinder light " + std::to_string(i) + " has no sampling table (RenderDriverRTE::UpdateLight always makes one)");
+    }
     if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
     if (type == HLT_SKY_DOME && (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ)) lightFeat |= HK_FEAT_PEREZ;   // only the all-features instantiation carries the model
-    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
+    if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH || type == HLT_CYLINDER) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
     if (blob[at + HL_FLAGS] & HLF_HAS_IES)
       return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
   }
+  if (blob[HG_SUN_NUMBER] < 0 || blob[HG_SUN_NUMBER] > 8) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: sunNumber outside 0..8 (MAX_SUN_NUM, cfetch.h:18)");
   c->lightFeatures = lightFeat;
   c->sceneFeatures = c->matFeatures | c->lightFeatures;
   c->matDirty = true;   // (re)derives sceneFeatures together with the material walk

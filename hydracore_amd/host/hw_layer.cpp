@@ -182,10 +182,23 @@ void IHWLayer::SetAllPODLights(PlainLight* a_lights, size_t a_number) {
     memcpy(&type, a_lights + i * HL_FLOATS + HL_TYPE, 4);
     if (type == HLT_SKY_DOME) { skyLightOffset = int(i); break; }
   }
-  // suns (direct lights with soft shadows) are outside this tier's light set; sunNumber stays 0
+  // suns: directional lights with a soft shadow, which a path that leaves through a sky portal may look into (lightGetIntensity, clight.h:1670-1690).
+  // sic: every slot finds the same first such light again, so a scene with one has MAX_SUN_NUM copies of it (Assembler.cpp:422-443)
+  int sunNumber = 0;
+  for (int sunId = 0; sunId < 8 /*MAX_SUN_NUM, cfetch.h:18*/; sunId++) {
+    int sunCurrOffset = -1;
+    for (size_t i = 0; i < a_number; i++) {
+      int32_t type;
+      memcpy(&type, a_lights + i * HL_FLOATS + HL_TYPE, 4);
+      if (type == HLT_DIRECT && a_lights[i * HL_FLOATS + HL_DIRECT_SSOFTNESS] > 1e-6f) { sunCurrOffset = int(i); break; }
+    }
+    if (sunCurrOffset < 0) break;
+    memcpy(m_globsBuffHeader.data() + HG_SUNS + sunId * HL_FLOATS, a_lights + size_t(sunCurrOffset) * HL_FLOATS, sizeof(float) * HL_FLOATS);
+    sunNumber++;
+  }
   m_globsBuffHeader[HG_SKY_LIGHT_ID] = skyLightOffset;
   m_globsBuffHeader[HG_LIGHTS_NUM] = int(a_number);
-  m_globsBuffHeader[HG_SUN_NUMBER] = 0;
+  m_globsBuffHeader[HG_SUN_NUMBER] = sunNumber;
 }
 
 // ------------------------------------------------------------------------------------------ SharedDataLayer

@@ -426,6 +426,26 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
     return true;
   }
+  if (mtype == "sky_portal_mtl") {   // SkyPortalMaterial + CreateSkyPortalMaterial, PlainMaterialConverter.cpp:304-350, 1604-1614: a thin glass no shadow ray stops at;
+    // the emission block of CreateMaterialFromXmlNode (:1716) skips materials with this flag, ReadBumpAndOpacity finds nothing to read on one
+    const XmlNode* em = a_node->child("emission");
+    const float mult = xchild(em, "multiplier") ? xchild(em, "multiplier")->attr_float("val") : 1.0f;
+    float c3[3] = {0, 0, 0};
+    if (xchild(em, "color")) parse_floats(xchild(em, "color")->attr("val"), c3, 3);
+    MatPtr pPortal = make_thinglass(float3(c3[0], c3[1], c3[2]) * mult, int32_t(HYDRA_INVALID_TEXTURE), Sampler(), 1000000.0f, 1.0f, int32_t(HYDRA_INVALID_TEXTURE), Sampler());
+    put_i(pPortal->plain, HM_FLAGS, HMF_HAS_TRANSPARENCY | HMF_SKIP_SHADOW | HMF_SKIP_SKY_PORTAL | ((a_node->attr_int("visible") == 1) ? 0 : HMF_INVIS_LIGHT));
+    Opacity o;
+    o.texId = int32_t(HYDRA_INVALID_TEXTURE);
+    float raw[12];
+    put_sampler_raw(raw, 0, Sampler());
+    memcpy(o.sampler, raw, sizeof(raw));
+    o.smooth = false;
+    o.skipShadow = true;
+    m_matOpacity[a_matId] = o;
+    PlainMaterialVec mdata = flatten(pPortal);
+    m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
+    return true;
+  }
   if (mtype != "hydra_material") { Unsupported("material type '" + mtype + "' (id " + std::to_string(a_matId) + ")"); }
 
   const XmlNode* emission = a_node->child("emission");
@@ -578,7 +598,16 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   // emission header copied into the root when the material is not emissive-only (:1716-1728)
   if (length(colorE) > 1e-5f && pResult != pMaterialE) {
     const bool visible = (a_node->attr_int("visible") == 1);
-    if (!visible && a_node->has_attr("light_id")) Unsupported("invisible light material " + std::to_string(a_matId));
+    if (!visible && a_node->has_attr("light_id")) {   // an invisible light: a clear thin glass that shadow rays pass (:1719-1724)
+      pResult = make_thinglass(float3(1, 1, 1), int32_t(HYDRA_INVALID_TEXTURE), Sampler(), 1e6f, 1.0f, int32_t(HYDRA_INVALID_TEXTURE), Sampler());
+      add_flags(pResult, HMF_INVIS_LIGHT);
+      Opacity o;
+      auto had = m_matOpacity.find(a_matId);
+      if (had != m_matOpacity.end()) o = had->second;
+      else { o.texId = int32_t(HYDRA_INVALID_TEXTURE); float raw[12]; put_sampler_raw(raw, 0, Sampler()); memcpy(o.sampler, raw, sizeof(raw)); o.smooth = false; }
+      o.skipShadow = true;
+      m_matOpacity[a_matId] = o;
+    }
     float* dst = pResult->plain;
     const float* src = pMaterialE->plain;
     memcpy(dst + HM_EMISSIVE_COLOR, src + HM_EMISSIVE_COLOR, 12);
@@ -683,6 +712,97 @@ bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node
   return true;
 }
 
+// The luminance image a light's 2-D sampling table is made of (RenderDriverRTE::UpdatePdfTablesForLight, RenderDriverRTE_PdfTables.cpp:512-533): sky domes
+// and cylinder lights share it
+void RenderDriverLite::LuminanceImageOf(int32_t texId, std::vector<float>& lum, int& lw, int& lh) {
+  const std::vector<int32_t> table = m_pTexStorage->GetTable();
+  if (texId < 0 || texId >= int32_t(table.size()) || table[texId] < 0) RunTimeError("UpdateLight: light texture " + std::to_string(texId) + " is not loaded");
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(static_cast<const char*>(m_pTexStorage->GetBegin()) + size_t(table[texId]) * 16);
+  int w = hdr[0], h = hdr[1];
+  const int bpp = hdr[3];
+  if (bpp == 16) {
+    std::vector<float> px(reinterpret_cast<const float*>(hdr + 4), reinterpret_cast<const float*>(hdr + 4) + size_t(w) * h * 4);
+    for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizef4, :186-215
+      if (w <= 2048 && h <= 2048) continue;                      // MAX_ENV_LIGHT_PDF_SIZE, RenderDriverRTE.h:23
+      const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
+      std::vector<float> half(size_t(nw) * nh * 4);
+      for (int y = 0; y < nh; y++)
+        for (int x = 0; x < nw; x++)
+          for (int ch = 0; ch < 4; ch++) {
+            const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
+            half[(size_t(y) * nw + x) * 4 + ch] = 0.25f * (((px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch]) + px[size_t(o2 + 2 * x) * 4 + ch]) + px[size_t(o2 + 2 * x + 1) * 4 + ch]);
+          }
+      px.swap(half); w = nw; h = nh;
+    }
+    lum.assign(size_t(w) * h, 0.0f);
+    float avg = 0.0f;
+    for (size_t i = 0; i < lum.size(); i++) { lum[i] = std::max(px[i * 4], std::max(px[i * 4 + 1], px[i * 4 + 2])); avg += lum[i]; }
+    avg /= float(lum.size());
+    avg = std::max(avg, 1.0f);
+    // HDRImageLite::gaussBlur(2, 1.5), one channel: rows, then columns, windows clipped at the border, weights re-normalised (+ 1e-5)
+    float gk[5], gsum = 0.0f;
+    { const float sg = 2.0f * 1.5f * 1.5f; for (int x = -2; x <= 2; x++) { const float r = sqrtf(float(x * x)); gk[x + 2] = expf(-r / sg) / (3.141592654f * sg); gsum += gk[x + 2]; } for (float& v : gk) v /= gsum; }
+    std::vector<float> tmp(lum.size());
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        float c = 0.0f, sw = 0.0f;
+        for (int q = std::max(x - 2, 0); q <= std::min(x + 2, w - 1); q++) { c += lum[size_t(y) * w + q] * gk[q + 2 - x]; sw += gk[q + 2 - x]; }
+        tmp[size_t(y) * w + x] = c / (sw + 1e-5f);
+      }
+    if (h == 1) lum = tmp;
+    else
+      for (int x = 0; x < w; x++)
+        for (int y = 0; y < h; y++) {
+          float c = 0.0f, sw = 0.0f;
+          for (int q = std::max(y - 2, 0); q <= std::min(y + 2, h - 1); q++) { c += tmp[size_t(q) * w + x] * gk[q + 2 - y]; sw += gk[q + 2 - y]; }
+          lum[size_t(y) * w + x] = c / (sw + 1e-5f);
+        }
+    for (float& v : lum) v += 0.05f * avg;                        // no pixel with zero pdf
+    lw = w; lh = h;
+  }
+  else if (bpp != 4) Unsupported("light texture of " + std::to_string(bpp) + " bytes per texel");
+  else {
+    std::vector<uint8_t> px(reinterpret_cast<const uint8_t*>(hdr + 4), reinterpret_cast<const uint8_t*>(hdr + 4) + size_t(w) * h * 4);
+    for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizeUB4, :268-310
+      if (w <= 256 && h <= 256) continue;
+      const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
+      std::vector<uint8_t> half(size_t(nw) * nh * 4);
+      for (int y = 0; y < nh; y++)
+        for (int x = 0; x < nw; x++)
+          for (int ch = 0; ch < 4; ch++) {
+            const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
+            const int sum = px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch] + px[size_t(o2 + 2 * x) * 4 + ch] + px[size_t(o2 + 2 * x + 1) * 4 + ch];
+            half[(size_t(y) * nw + x) * 4 + ch] = uint8_t(std::min(sum >> 2, 255));
+          }
+      px.swap(half); w = nw; h = nh;
+    }
+    lum.assign(size_t(w) * h, 0.0f);
+    float avg = 0.0f;
+    for (size_t i = 0; i < lum.size(); i++) {
+      const float r = px[i * 4] * (1.0f / 255.0f), g = px[i * 4 + 1] * (1.0f / 255.0f), b = px[i * 4 + 2] * (1.0f / 255.0f);
+      lum[i] = std::max(r, std::max(g, b));
+      avg += lum[i];
+    }
+    avg /= float(lum.size());
+    avg = std::max(avg, 1.0f);
+    for (float& v : lum) v += 0.1f * avg;                         // no pixel with zero pdf
+    lw = w; lh = h;
+  }
+}
+// header {w, h, 1, n + 1} + prefix sums of the luminance image + a trailing 1.0 (:546-566); returns the id the table got
+int32_t RenderDriverLite::PutPdfTable2D(const std::vector<float>& lum, int lw, int lh) {
+  const int32_t tabId = m_pPdfStorage->GetMaxObjectId() + 1;
+  const size_t n = lum.size() + 1;                                // PrefixSumm: n + 1 entries
+  std::vector<float> data(4 + n + 1);
+  put_i(data.data(), 0, lw); put_i(data.data(), 1, lh); put_i(data.data(), 2, 1); put_i(data.data(), 3, int32_t(n + 1));
+  float acc = 0.0f;
+  for (size_t i = 0; i < lum.size(); i++) { data[4 + i] = acc; acc += lum[i]; }
+  data[4 + lum.size()] = acc;
+  data[4 + n] = 1.0f;
+  m_pPdfStorage->Update(tabId, data.data(), data.size() * sizeof(float));
+  return tabId;
+}
+
 // SkyDomeLight, hydra_drv/PlainLightConverter.cpp:909-1051 + RenderDriverRTE::UpdatePdfTablesForLight
 // (RenderDriverRTE_PdfTables.cpp:479-570).  A sky without texture gets the reference's 2x2 uniform luminance image as its
 // sampling table; an 8-bit lat-long texture gets the table of LuminanceFromUchar4Image (:312-356: halve until <= 256,
@@ -739,94 +859,8 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   // luminance image the directions are importance-sampled from
   int lw = 2, lh = 2;
   std::vector<float> lum(4, 0.25f);
-  if (skyTexId != int32_t(HYDRA_INVALID_TEXTURE)) {
-    const std::vector<int32_t> table = m_pTexStorage->GetTable();
-    if (skyTexId < 0 || skyTexId >= int32_t(table.size()) || table[skyTexId] < 0) RunTimeError("UpdateLight: sky light texture " + std::to_string(skyTexId) + " is not loaded");
-    const int32_t* hdr = reinterpret_cast<const int32_t*>(static_cast<const char*>(m_pTexStorage->GetBegin()) + size_t(table[skyTexId]) * 16);
-    int w = hdr[0], h = hdr[1];
-    const int bpp = hdr[3];
-    if (bpp == 16) {
-      std::vector<float> px(reinterpret_cast<const float*>(hdr + 4), reinterpret_cast<const float*>(hdr + 4) + size_t(w) * h * 4);
-      for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizef4, :186-215
-        if (w <= 2048 && h <= 2048) continue;                      // MAX_ENV_LIGHT_PDF_SIZE, RenderDriverRTE.h:23
-        const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
-        std::vector<float> half(size_t(nw) * nh * 4);
-        for (int y = 0; y < nh; y++)
-          for (int x = 0; x < nw; x++)
-            for (int ch = 0; ch < 4; ch++) {
-              const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
-              half[(size_t(y) * nw + x) * 4 + ch] = 0.25f * (((px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch]) + px[size_t(o2 + 2 * x) * 4 + ch]) + px[size_t(o2 + 2 * x + 1) * 4 + ch]);
-            }
-        px.swap(half); w = nw; h = nh;
-      }
-      lum.assign(size_t(w) * h, 0.0f);
-      float avg = 0.0f;
-      for (size_t i = 0; i < lum.size(); i++) { lum[i] = std::max(px[i * 4], std::max(px[i * 4 + 1], px[i * 4 + 2])); avg += lum[i]; }
-      avg /= float(lum.size());
-      avg = std::max(avg, 1.0f);
-      // HDRImageLite::gaussBlur(2, 1.5), one channel: rows, then columns, windows clipped at the border, weights re-normalised (+ 1e-5)
-      float gk[5], gsum = 0.0f;
-      { const float sg = 2.0f * 1.5f * 1.5f; for (int x = -2; x <= 2; x++) { const float r = sqrtf(float(x * x)); gk[x + 2] = expf(-r / sg) / (3.141592654f * sg); gsum += gk[x + 2]; } for (float& v : gk) v /= gsum; }
-      std::vector<float> tmp(lum.size());
-      for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-          float c = 0.0f, sw = 0.0f;
-          for (int q = std::max(x - 2, 0); q <= std::min(x + 2, w - 1); q++) { c += lum[size_t(y) * w + q] * gk[q + 2 - x]; sw += gk[q + 2 - x]; }
-          tmp[size_t(y) * w + x] = c / (sw + 1e-5f);
-        }
-      if (h == 1) lum = tmp;
-      else
-        for (int x = 0; x < w; x++)
-          for (int y = 0; y < h; y++) {
-            float c = 0.0f, sw = 0.0f;
-            for (int q = std::max(y - 2, 0); q <= std::min(y + 2, h - 1); q++) { c += tmp[size_t(q) * w + x] * gk[q + 2 - y]; sw += gk[q + 2 - y]; }
-            lum[size_t(y) * w + x] = c / (sw + 1e-5f);
-          }
-      for (float& v : lum) v += 0.05f * avg;                        // no pixel with zero pdf
-      lw = w; lh = h;
-    }
-    else if (bpp != 4) Unsupported("sky light texture of " + std::to_string(bpp) + " bytes per texel");
-    else {
-      std::vector<uint8_t> px(reinterpret_cast<const uint8_t*>(hdr + 4), reinterpret_cast<const uint8_t*>(hdr + 4) + size_t(w) * h * 4);
-      for (int pass = 0; pass < 4; pass++) {                       // resizeToHalfSizeUB4, :268-310
-        if (w <= 256 && h <= 256) continue;
-        const int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
-        std::vector<uint8_t> half(size_t(nw) * nh * 4);
-        for (int y = 0; y < nh; y++)
-          for (int x = 0; x < nw; x++)
-            for (int ch = 0; ch < 4; ch++) {
-              const int o1 = (2 * y + 0) * 2 * nw, o2 = (2 * y + 1) * 2 * nw;
-              const int sum = px[size_t(o1 + 2 * x) * 4 + ch] + px[size_t(o1 + 2 * x + 1) * 4 + ch] + px[size_t(o2 + 2 * x) * 4 + ch] + px[size_t(o2 + 2 * x + 1) * 4 + ch];
-              half[(size_t(y) * nw + x) * 4 + ch] = uint8_t(std::min(sum >> 2, 255));
-            }
-        px.swap(half); w = nw; h = nh;
-      }
-      lum.assign(size_t(w) * h, 0.0f);
-      float avg = 0.0f;
-      for (size_t i = 0; i < lum.size(); i++) {
-        const float r = px[i * 4] * (1.0f / 255.0f), g = px[i * 4 + 1] * (1.0f / 255.0f), b = px[i * 4 + 2] * (1.0f / 255.0f);
-        lum[i] = std::max(r, std::max(g, b));
-        avg += lum[i];
-      }
-      avg /= float(lum.size());
-      avg = std::max(avg, 1.0f);
-      for (float& v : lum) v += 0.1f * avg;                         // no pixel with zero pdf
-      lw = w; lh = h;
-    }
-  }
-  // pdf tables 0 and 1: header {w, h, 1, n + 1} + prefix sums of the luminance image + a trailing 1.0 (:546-566)
-  for (int t = 0; t < 2; t++) {
-    const int32_t tabId = m_pPdfStorage->GetMaxObjectId() + 1;
-    const size_t n = lum.size() + 1;                                // PrefixSumm: n + 1 entries
-    std::vector<float> data(4 + n + 1);
-    put_i(data.data(), 0, lw); put_i(data.data(), 1, lh); put_i(data.data(), 2, 1); put_i(data.data(), 3, int32_t(n + 1));
-    float acc = 0.0f;
-    for (size_t i = 0; i < lum.size(); i++) { data[4 + i] = acc; acc += lum[i]; }
-    data[4 + lum.size()] = acc;
-    data[4 + n] = 1.0f;
-    m_pPdfStorage->Update(tabId, data.data(), data.size() * sizeof(float));
-    put_i(d, HL_SKY_PDF_TABLE0 + t, tabId);
-  }
+  if (skyTexId != int32_t(HYDRA_INVALID_TEXTURE)) LuminanceImageOf(skyTexId, lum, lw, lh);
+  for (int t = 0; t < 2; t++) put_i(d, HL_SKY_PDF_TABLE0 + t, PutPdfTable2D(lum, lw, lh));   // pdf tables 0 and 1
   lp.isDisk = false;
   lp.isSky = true;
   m_lights[a_lightId] = lp;
@@ -842,7 +876,6 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
     const int32_t meshId = a_node->attr_int("mesh_id", -1);
     const std::vector<int32_t> gtable = m_pGeomStorage->GetTable();
     if (meshId < 0 || size_t(meshId) >= gtable.size() || gtable[size_t(meshId)] < 0) { Unsupported("mesh light " + std::to_string(a_lightId) + ": its mesh " + std::to_string(meshId) + " is not in the geometry storage yet"); return false; }
-    if (sampler_node(xchild(xchild(a_node, "intensity"), "color"))) Unsupported("textured mesh light " + std::to_string(a_lightId));
     const char* blob = reinterpret_cast<const char*>(m_pGeomStorage->GetBegin()) + size_t(gtable[size_t(meshId)]) * 16;
     const HydraPlainMesh* pm = reinterpret_cast<const HydraPlainMesh*>(blob);
     const float* vpos = reinterpret_cast<const float*>(blob + size_t(pm->vPosOffset) * 16);
@@ -881,11 +914,44 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
     put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     memcpy(d + HL_MESH_MATRIX, ident, 36);
-    put_sampler_at(d, int32_t(HYDRA_INVALID_TEXTURE), Sampler(), HL_MESH_TEX_ID, HL_MESH_TEXMATRIX_ID, HL_MESH_TEX_SAMPLER);
+    {   // the colour texture, CreateMeshLightFromXmlNode (PlainLightConverter.cpp:837-...): looked up at the mesh's own texture coordinates
+      Sampler sc; int32_t texIdColor = int32_t(HYDRA_INVALID_TEXTURE);
+      if (const XmlNode* tx = sampler_node(xchild(inten, "color"))) { sc = sampler_from_texref(tx); texIdColor = sc.texId; }
+      put_sampler_at(d, texIdColor, sc, HL_MESH_TEX_ID, HL_MESH_TEXMATRIX_ID, HL_MESH_TEX_SAMPLER);
+    }
     mp.isMesh = true;
     mp.meshPos.assign(vpos, vpos + size_t(pm->vPosNum) * 4);
     mp.meshInd.assign(indices, indices + pm->tIndicesNum);
     m_lights[a_lightId] = mp;
+    return true;
+  }
+  if (ltype == "area" && lshape == "cylinder") {   // CylinderLight, PlainLightConverter.cpp:354-443, CreateCylinderLightFromXmlNode :867-893
+    LightProto cp;
+    cp.plain.assign(HL_FLOATS, 0.0f);
+    float* d = cp.plain.data();
+    d[HL_PROB_MULT] = 1.0f;
+    const XmlNode* size = a_node->child("size");
+    const float radius = size ? size->attr_float("radius") : 0.0f, height = size ? size->attr_float("height") : 0.0f, angle = size ? size->attr_float("angle") : 0.0f;
+    const float zMin = -0.5f * height, zMax = +0.5f * height, phiMax = (3.14159265358979323846f / 180.f) * angle;
+    const XmlNode* inten = a_node->child("intensity");
+    const float3 color = read_value3f(xchild(inten, "color")) * read_value1f(xchild(inten, "multiplier"));
+    d[HL_COLOR + 0] = color.x; d[HL_COLOR + 1] = color.y; d[HL_COLOR + 2] = color.z;
+    d[HL_CYL_RADIUS] = radius; d[HL_CYL_ZMIN] = zMin; d[HL_CYL_ZMAX] = zMax; d[HL_CYL_PHIMAX] = phiMax;
+    d[HL_SURFACE_AREA] = (zMax - zMin) * radius * phiMax;
+    Sampler sc; int32_t texIdColor = int32_t(HYDRA_INVALID_TEXTURE);
+    if (const XmlNode* tx = sampler_node(xchild(inten, "color"))) { sc = sampler_from_texref(tx); texIdColor = sc.texId; }
+    sc.row0[0] = 1; sc.row0[1] = 0; sc.row0[2] = 0; sc.row0[3] = 0;   // no texture matrices on cylinder lights (:888-889)
+    sc.row1[0] = 0; sc.row1[1] = 1; sc.row1[2] = 0; sc.row1[3] = 0;
+    put_sampler_at(d, texIdColor, sc, HL_CYL_TEX_ID, HL_CYL_TEXMATRIX_ID, HL_CYL_TEX_SAMPLER);
+    put_i(d, HL_TYPE, HLT_CYLINDER);
+    put_i(d, HL_FLAGS, 0);
+    // the (z, phi) sampling table, RenderDriverRTE::UpdateLight :940-941 -> UpdatePdfTablesForLight: the luminance image of the colour texture, 2 x 2 uniform without one
+    int lw = 2, lh = 2;
+    std::vector<float> lum(4, 0.25f);
+    if (texIdColor != int32_t(HYDRA_INVALID_TEXTURE)) LuminanceImageOf(texIdColor, lum, lw, lh);
+    put_i(d, HL_CYL_PDF_TABLE_ID, PutPdfTable2D(lum, lw, lh));
+    cp.isCylinder = true;
+    m_lights[a_lightId] = cp;
     return true;
   }
   if (ltype == "area" && lshape == "sphere") {   // SphereLight, PlainLightConverter.cpp:445-496, CreateSphereLightFromXmlNode :858-865
@@ -908,7 +974,7 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   }
   if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
   if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
-  if (xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1) Unsupported("sky portal");
+  const bool isSkyPortal = xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1;   // :197-204; OLD_PHOTOMETRIC_SCALE is 1
 
   LightProto lp;
   lp.plain.assign(HL_FLOATS, 0.0f);
@@ -941,9 +1007,10 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   d[HL_AREA_SPOT_COS2] = cosf(0.5f * DEG2RAD * angle1);
   put_i(d, HL_AREA_IS_DISK, int(isDisk));
   put_i(d, HL_AREA_SPOT_DISTR, int(isSpot));
-  put_i(d, HL_AREA_SKY_SOURCE, 0);
+  put_i(d, HL_AREA_SKY_SOURCE, isSkyPortal ? xchild(a_node, "sky_portal")->attr_int("source_id") : 0);
   put_i(d, HL_TYPE, HLT_AREA);
-  put_i(d, HL_FLAGS, 0);
+  put_i(d, HL_FLAGS, isSkyPortal ? HLF_SKY_PORTAL : 0);
+  if (isSkyPortal) { put_i(d, HL_AREA_SKYPORTAL_BTEX, int32_t(HYDRA_INVALID_TEXTURE)); put_i(d, HL_AREA_SKYPORTAL_BTEX_MATRIX, int32_t(HYDRA_INVALID_TEXTURE)); }
   put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
   put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
   // IES matrix: identity rotated 90 degrees about Y (ROTATE_IES_90_DEG, PlainLightConverter.cpp:14,170-174); unused without IES
@@ -1087,6 +1154,7 @@ void RenderDriverLite::BeginScene() {
   m_instMatricesInv.clear(); m_instLightInstId.clear(); m_meshIdByInstId.clear(); m_meshRemapListId.clear();
   m_lightsInstanced.clear();
   m_lightIdByInst.clear();
+  m_sceneHaveSkyPortals = false;
   m_bvh.ClearScene();
   m_bvhAlpha.ClearScene();
   const int32_t dummyList[2] = {0, 0};
@@ -1142,20 +1210,8 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
         const float3 ln0 = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
         d[HL_NORM] = ln0.x; d[HL_NORM + 1] = ln0.y; d[HL_NORM + 2] = ln0.z;
       }
-      put_i(d, HL_GROUP_ID, a_lightGroupId);
-      d[HL_PICK_PROB_REV] = 1.0f;
-      d[HL_PICK_PROB_FWD] = 1.0f;
-      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
-      continue;
-    }
-    if (it->second.isSky) {                       // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
-      put_i(d, HL_GROUP_ID, a_lightGroupId);
-      d[HL_PICK_PROB_REV] = 1.0f;
-      d[HL_PICK_PROB_FWD] = 1.0f;
-      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
-      continue;
-    }
-    if (it->second.isMesh) {                      // MeshLight::Transform, PlainLightConverter.cpp:795-829: position, the 3x3 part, the area of the transformed triangles
+    } else if (it->second.isSky) {                // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
+    } else if (it->second.isMesh) {               // MeshLight::Transform, PlainLightConverter.cpp:795-829: position, the 3x3 part, the area of the transformed triangles
       const float3 mp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
       d[HL_POS] = mp0.x; d[HL_POS + 1] = mp0.y; d[HL_POS + 2] = mp0.z;
       for (int r = 0; r < 3; r++)
@@ -1170,39 +1226,39 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
         totalSA += double(0.5f * length(cross(B - A, C - A)));
       }
       d[HL_SURFACE_AREA] = float(totalSA);
-      put_i(d, HL_GROUP_ID, a_lightGroupId);
-      d[HL_PICK_PROB_REV] = 1.0f;
-      d[HL_PICK_PROB_FWD] = 1.0f;
-      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
-      continue;
-    }
-    if (it->second.isSphere) {                    // SphereLight::Transform, PlainLightConverter.cpp:466-491
+    } else if (it->second.isSphere) {             // SphereLight::Transform, PlainLightConverter.cpp:466-491
       const float3 sp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
       d[HL_POS] = sp0.x; d[HL_POS + 1] = sp0.y; d[HL_POS + 2] = sp0.z;
       const float radius = d[HL_SPHERE_RADIUS] * length(mul_vec(M, normalize(float3(1, 1, 1))));
       d[HL_SPHERE_RADIUS] = radius;
       d[HL_SURFACE_AREA] = 4.0f * 3.1415926535f * radius * radius;
-      put_i(d, HL_GROUP_ID, a_lightGroupId);
-      d[HL_PICK_PROB_REV] = 1.0f;
-      d[HL_PICK_PROB_FWD] = 1.0f;
-      m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
-      continue;
+    } else if (it->second.isCylinder) {           // CylinderLight::Transform, PlainLightConverter.cpp:382-413: the radius field stays, the area takes the scale twice
+      const float3 cp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+      d[HL_POS] = cp0.x; d[HL_POS + 1] = cp0.y; d[HL_POS + 2] = cp0.z;
+      const float mult = length(mul_vec(M, normalize(float3(1, 1, 1))));
+      const float newRadius = d[HL_CYL_RADIUS] * mult;
+      d[HL_SURFACE_AREA] = (d[HL_CYL_ZMAX] - d[HL_CYL_ZMIN]) * mult * newRadius * d[HL_CYL_PHIMAX];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) d[HL_CYL_MATRIX + r * 3 + c] = M.at(r, c);
+    } else {                                      // AreaDiffuseLight::Transform, :281-352
+      const float3 lpos = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
+      d[HL_POS] = lpos.x; d[HL_POS + 1] = lpos.y; d[HL_POS + 2] = lpos.z;
+      const float3 ln = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
+      d[HL_NORM] = ln.x; d[HL_NORM + 1] = ln.y; d[HL_NORM + 2] = ln.z;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) d[HL_AREA_MATRIX + r * 3 + c] = M.at(r, c);
+      if (it->second.isDisk) {
+        const float3 vert = mul_vec(M, normalize(float3(1, 1, 1)));
+        const float radius = d[HL_AREA_SIZE_X] * length(vert);
+        d[HL_SURFACE_AREA] = 3.1415926535f * radius * radius;
+      } else {
+        const float sx = d[HL_AREA_SIZE_X], sy = d[HL_AREA_SIZE_Y];
+        const float3 v0 = mul_point(M, float3(-sx, 0, -sy)), v1 = mul_point(M, float3(-sx, 0, sy)), v2 = mul_point(M, float3(sx, 0, sy));
+        d[HL_SURFACE_AREA] = length(v1 - v0) * length(v1 - v2);
+      }
     }
-    const float3 lpos = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
-    d[HL_POS] = lpos.x; d[HL_POS + 1] = lpos.y; d[HL_POS + 2] = lpos.z;
-    const float3 ln = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
-    d[HL_NORM] = ln.x; d[HL_NORM + 1] = ln.y; d[HL_NORM + 2] = ln.z;
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) d[HL_AREA_MATRIX + r * 3 + c] = M.at(r, c);
-    if (it->second.isDisk) {
-      const float3 vert = mul_vec(M, normalize(float3(1, 1, 1)));
-      const float radius = d[HL_AREA_SIZE_X] * length(vert);
-      d[HL_SURFACE_AREA] = 3.1415926535f * radius * radius;
-    } else {
-      const float sx = d[HL_AREA_SIZE_X], sy = d[HL_AREA_SIZE_Y];
-      const float3 v0 = mul_point(M, float3(-sx, 0, -sy)), v1 = mul_point(M, float3(-sx, 0, sy)), v2 = mul_point(M, float3(sx, 0, sy));
-      d[HL_SURFACE_AREA] = length(v1 - v0) * length(v1 - v2);
-    }
+    // the instance node's own attributes, every light type alike (RenderDriverRTE.cpp:2032-2066)
+    bool doNotSampleMe = false;
     if (a_lightNodes && a_lightNodes[i]) {
       const XmlNode* n = a_lightNodes[i];
       if (n->has_attr("color_mult")) {
@@ -1210,13 +1266,16 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
         parse_floats(n->attr("color_mult"), cm, 3);
         d[HL_COLOR] *= cm[0]; d[HL_COLOR + 1] *= cm[1]; d[HL_COLOR + 2] *= cm[2];
       }
+      if (n->has_attr("do_not_sample_me")) { const std::string v = n->attr("do_not_sample_me"); doNotSampleMe = !v.empty() && (v[0] == '1' || v[0] == 't' || v[0] == 'T' || v[0] == 'y' || v[0] == 'Y'); }   // pugi as_bool
       if (n->has_attr("prob_mult")) d[HL_PROB_MULT] = n->attr_float("prob_mult");
     }
     put_i(d, HL_GROUP_ID, a_lightGroupId);
     d[HL_PICK_PROB_REV] = 1.0f;
     d[HL_PICK_PROB_FWD] = 1.0f;
+    if (doNotSampleMe) put_i(d, HL_FLAGS, get_i(d, HL_FLAGS) | HLF_DO_NOT_SAMPLE_ME);
     m_lightsInstanced.insert(m_lightsInstanced.end(), copy.begin(), copy.end());
   }
+  if (get_i(it->second.plain.data(), HL_FLAGS) & HLF_SKY_PORTAL) m_sceneHaveSkyPortals = true;   // :2069-2070
 }
 
 // RenderDriverRTE_PdfTables.cpp:575-647
@@ -1224,10 +1283,13 @@ std::vector<float> RenderDriverLite::CalcLightPickProbTable(bool a_fwd) {
   const size_t n = m_lightsInstanced.size() / HL_FLOATS;
   std::vector<float> pick(n);
   std::map<int, int> groups;
+  std::set<int> disableSky;
   int noGroups = 0;
   for (size_t i = 0; i < n; i++) {
     const int g = get_i(&m_lightsInstanced[i * HL_FLOATS], HL_GROUP_ID);
     if (g == -1) noGroups++; else groups[g]++;
+    // sic: the reference collects light ids here and looks them up by position in the instanced array below (:598-602, 631-635)
+    if (get_i(&m_lightsInstanced[i * HL_FLOATS], HL_FLAGS) & HLF_SKY_PORTAL) disableSky.insert(get_i(&m_lightsInstanced[i * HL_FLOATS], HL_AREA_SKY_SOURCE));
   }
   noGroups += int(groups.size());
   const float pickGroupProb = 1.0f / float(noGroups);
@@ -1235,7 +1297,8 @@ std::vector<float> RenderDriverLite::CalcLightPickProbTable(bool a_fwd) {
     float* d = &m_lightsInstanced[i * HL_FLOATS];
     const int g = get_i(d, HL_GROUP_ID);
     float pp = (g == -1) ? pickGroupProb : pickGroupProb / float(groups[g]);
-    if (get_i(d, HL_TYPE) == HLT_SKY_DOME && a_fwd) pp = 0.0f;
+    if (get_i(d, HL_FLAGS) & HLF_DO_NOT_SAMPLE_ME) pp = 0.0f;
+    if (get_i(d, HL_TYPE) == HLT_SKY_DOME && (a_fwd || disableSky.count(int(i)))) pp = 0.0f;
     if (length(float3(d[HL_COLOR], d[HL_COLOR + 1], d[HL_COLOR + 2])) < 0.01f) pp = 0.0f;
     if (d[HL_PROB_MULT] > 0.0f) pp *= d[HL_PROB_MULT];
     d[a_fwd ? HL_PICK_PROB_FWD : HL_PICK_PROB_REV] = pp;
@@ -1357,7 +1420,7 @@ void RenderDriverLite::EndScene() {
   vars.m_varsF[36 /*HRT_BACK_TEXINPUT_GAMMA*/] = 2.2f;
   m_pHWLayer->SetAllFlagsAndVars(vars);
 
-  const size_t nl = m_lightsInstanced.size() / HL_FLOATS;
+  size_t nl = m_lightsInstanced.size() / HL_FLOATS;
   // a Perez sky takes direction and colour of its sun from the first instance of light `sun_id`
   // (RenderDriverRTE::BuildSkyPortalsDependencyDummyInstances, RenderDriverRTE.cpp:1603-1647)
   for (size_t i = 0; i < nl; i++) {
@@ -1369,6 +1432,31 @@ void RenderDriverLite::EndScene() {
         for (int k = 0; k < 3; k++) { sky[HL_SKY_SUN_DIR + k] = sun[HL_NORM + k]; sky[HL_SKY_SUN_COLOR + k] = sun[HL_COLOR + k]; }
         break;
       }
+  }
+  {   // (1) of the same function: the layer is told whether portals exist
+    auto v26 = m_pHWLayer->GetAllFlagsAndVars();
+    v26.m_varsI[26 /*HRT_HRT_SCENE_HAVE_PORTALS*/] = m_sceneHaveSkyPortals ? 1 : 0;
+    m_pHWLayer->SetAllFlagsAndVars(v26);
+  }
+  if (m_sceneHaveSkyPortals) {   // (3) sky lights no instance names get a record all the same, (4) every portal learns how far away its sky's record is (:1653-1684)
+    std::map<int32_t, int32_t> alreadyInstanced;
+    for (size_t i = 0; i < nl && i < m_lightIdByInst.size(); i++)
+      if (get_i(&m_lightsInstanced[i * HL_FLOATS], HL_TYPE) == HLT_SKY_DOME) alreadyInstanced[m_lightIdByInst[i]] = int32_t(i);
+    for (const auto& kv : m_lights) {
+      if (!kv.second.isSky || alreadyInstanced.count(kv.first)) continue;
+      m_lightsInstanced.insert(m_lightsInstanced.end(), kv.second.plain.begin(), kv.second.plain.end());
+      m_lightIdByInst.push_back(kv.first);
+      alreadyInstanced[kv.first] = int32_t(m_lightsInstanced.size() / HL_FLOATS - 1);
+    }
+    nl = m_lightsInstanced.size() / HL_FLOATS;
+    for (size_t i = 0; i < nl; i++) {
+      float* d = &m_lightsInstanced[i * HL_FLOATS];
+      if (!(get_i(d, HL_FLAGS) & HLF_SKY_PORTAL)) continue;
+      const auto sky = alreadyInstanced.find(get_i(d, HL_AREA_SKY_SOURCE));
+      if (sky == alreadyInstanced.end()) RunTimeError("EndScene: sky portal names light " + std::to_string(get_i(d, HL_AREA_SKY_SOURCE)) + ", which is not a sky light");   // the reference's map would hand out record 0 here
+      put_i(d, HL_AREA_SKY_OFFSET, sky->second - int32_t(i));
+    }
+    m_sceneHaveSkyPortals = false;
   }
   if (nl > 0) {
     m_pHWLayer->SetAllInstLightInstId(m_instLightInstId.data(), int32_t(m_instLightInstId.size()));

@@ -153,7 +153,7 @@ enum { /* PLAIN_MAT_TYPES cglobals.h:2604-2621 */
   HMT_BECKMANN = 13, HMT_TRGGX = 14, HMT_GGX = 15
 };
 enum { /* PLAIN_MAT_FLAGS cglobals.h:2624-2655 */
-  HMF_CAST_CAUSTICS = 2, HMF_HAS_DIFFUSE = 4, HMF_HAS_TRANSPARENCY = 8, HMF_FORBID_EMISSIVE_GI = 512,
+  HMF_CAST_CAUSTICS = 2, HMF_HAS_DIFFUSE = 4, HMF_HAS_TRANSPARENCY = 8, HMF_SKIP_SHADOW = 256, HMF_FORBID_EMISSIVE_GI = 512, HMF_INVIS_LIGHT = 16384,
   HMF_INVERT_NMAP_X = 16, HMF_INVERT_NMAP_Y = 32, HMF_INVERT_SWAP_NMAP_XY = 64, HMF_INVERT_HEIGHT = 128,   /* cglobals.h:2631-2634 */
   HMF_SKIP_SKY_PORTAL = 1024, HMF_HAVE_BTDF = 8192, HMF_CAN_SAMPLE_REFL_ONLY = 32768,
   HMF_FLIP_TANGENT = 32768 * 128,   /* cglobals.h:2653 */
@@ -175,6 +175,7 @@ enum {
   HL_FLOATS = 128,
   HL_TYPE = 0, HL_FLAGS = 1, HL_POS = 2, HL_NORM = 5, HL_COLOR = 8, HL_COLOR_TEX = 11, HL_COLOR_TEX_MATRIX = 12,
   HL_SURFACE_AREA = 13, HL_SPHERE_RADIUS = 14 /* SPHERE_LIGHT_RADIUS, clight.h:33 */, HL_MESH_MESH_ID = 14, HL_MESH_TABLE_ID = 15, HL_MESH_TRI_NUM = 16, HL_MESH_MATRIX = 20, HL_MESH_TEX_ID = 30, HL_MESH_TEXMATRIX_ID = 31, HL_MESH_TEX_SAMPLER = 32 /* MESH_LIGHT_*, clight.h:169-176 */, HL_AREA_SIZE_X = 14, HL_AREA_SIZE_Y = 15, HL_AREA_MATRIX = 16, HL_AREA_IS_DISK = 25,
+  HL_CYL_MATRIX = 16, HL_CYL_RADIUS = 25, HL_CYL_ZMIN = 26, HL_CYL_ZMAX = 27, HL_CYL_PHIMAX = 28, HL_CYL_TEX_ID = 29, HL_CYL_TEXMATRIX_ID = 30, HL_CYL_PDF_TABLE_ID = 31, HL_CYL_TEX_SAMPLER = 32 /* CYLINDER_*, clight.h:96-114 */,
   HL_AREA_SPOT_DISTR = 26, HL_AREA_SPOT_COS1 = 27, HL_AREA_SPOT_COS2 = 28, HL_AREA_SKY_OFFSET = 29,
   HL_AREA_SKY_SOURCE = 30, HL_AREA_SKYPORTAL_BTEX = 31, HL_AREA_SKYPORTAL_BTEX_MATRIX = 32,
   HL_AREA_SAMPLER0 = 40, HL_AREA_SAMPLER1 = 52,

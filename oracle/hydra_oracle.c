@@ -56,7 +56,10 @@ enum { LIGHT_FLOATS = 128, PL_TYPE = 0, PL_FLAGS = 1, PL_POS = 2, PL_NORM = 5, P
        PL_SURFACE_AREA = 13, AL_SIZE_X = 14, AL_SIZE_Y = 15, AL_MATRIX = 16, AL_IS_DISK = 25, AL_SPOT_DISTR = 26,
        AL_SPOT_COS1 = 27, AL_SPOT_COS2 = 28, PL_PICK_PROB_REV = 107,
        PL_COLOR_TEX_MATRIX = 12, SKY_DOME_PDF_TABLE0 = 30, SKY_DOME_SAMPLER0 = 32, SKY_DOME_MATRIX0 = 36, SKY_DOME_INV_MATRIX0 = 56 };   /* clight.h:131-165 */
-enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4, LT_SPHERE = 5, LT_MESH = 7 };
+enum { LT_POINT_OMNI = 0, LT_POINT_SPOT = 1, LT_DIRECT = 2, LT_SKY_DOME = 3, LT_AREA = 4, LT_SPHERE = 5, LT_CYLINDER = 6, LT_MESH = 7 };
+enum { CYLINDER_LIGHT_MATRIX_E00 = 16, CYLINDER_LIGHT_RADIUS = 25, CYLINDER_LIGHT_ZMIN = 26, CYLINDER_LIGHT_ZMAX = 27, CYLINDER_LIGHT_PHIMAX = 28,
+       CYLINDER_TEXMATRIX_ID = 30, CYLINDER_PDF_TABLE_ID = 31 };   /* clight.h:96-114 */
+enum { AREA_LIGHT_SKY_OFFSET = 29, MESH_LIGHT_TEXMATRIX_ID = 31, G_SUN_NUMBER = 242, G_SUNS = 243 };   /* clight.h:57, 174; cfetch.h:74-75 in int32 words */
 enum { MESH_LIGHT_MESH_OFFSET_ID = 14, MESH_LIGHT_TABLE_OFFSET_ID = 15, MESH_LIGHT_TRI_NUM = 16, MESH_LIGHT_MATRIX_E00 = 20 };   /* clight.h:169-176 */
 enum { SPHERE_LIGHT_RADIUS = 14 };   /* clight.h:33 */
 enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADIUS1 = 14, DIRECT_LIGHT_RADIUS2 = 15,
@@ -1791,9 +1794,11 @@ static f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, int eyeRay) {
   }
   return color;
 }
+/* ref: clight.h:614-629 areaLightSkyPortalCustomColor and the tail of areaDiffuseLightGetIntensity :590-607 (defined after the sky) */
+static f3 portalSkyColor(const OrcScene* s, const float* L, f3 rayDir);
 /* ref: clight.h:1180-1229 AreaLightSampleRev */
 typedef struct { f3 pos, color; float pdf, maxDist, cosAtLight; int isPoint; } ShadowSample;
-static void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample* out) {
+static void AreaLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
   const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
   f3 sp = v3(offsetX * L[AL_SIZE_X], 0.0f, offsetY * L[AL_SIZE_Y]);
   if (as_int(L[AL_IS_DISK]) != 0) {
@@ -1806,7 +1811,7 @@ static void AreaLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSample*
   sp = add3(sp, lightPos(L));
   const f3 rayDir = normalize3(sub3(sp, illum));
   const float hitDist = length3(sub3(sp, illum));
-  const f3 color = areaDiffuseLightGetIntensity(L, rayDir, 0);
+  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, rayDir)) : areaDiffuseLightGetIntensity(L, rayDir, 0);
   const f3 ln = lightNorm(L);
   out->isPoint = 0;
   out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
@@ -2028,8 +2033,9 @@ static void SphereLightSampleRev(const float* L, f3 rands, f3 illum, ShadowSampl
   out->maxDist = length3(sub3(samplePos, illum));
   out->cosAtLight = fabsf(dot3(lnorm, dirToV));
 }
-/* ref: clight.h:966-1062, 1513-1546 mesh lights (untextured: meshLightGetIntensity = the base colour) */
-static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, float* pdfA) {
+/* ref: clight.h:957-1062, 1513-1546 mesh lights */
+static f3 meshLightGetIntensity(const OrcScene* s, const float* L, f2 tc) { return mul3(sample2DExt(as_int(L[MESH_LIGHT_TEXMATRIX_ID]), tc, L, s), lightColor(L)); }
+static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, f2* pTexCoord, float* pdfA) {
   const int meshId = as_int(L[MESH_LIGHT_MESH_OFFSET_ID]), pdftId = as_int(L[MESH_LIGHT_TABLE_OFFSET_ID]), triNum = as_int(L[MESH_LIGHT_TRI_NUM]);
   const float* mesh = pdfTableHeader(s, meshId);
   const float* table = pdfTableHeader(s, pdftId);
@@ -2047,12 +2053,14 @@ static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* 
   const float w = 1.0f - u - v;
   *pPos = add3(add3(scale3(A, u), scale3(B, v)), scale3(C, w));
   *pNorm = add3(add3(scale3(nA, u), scale3(nB, v)), scale3(nC, w));
+  pTexCoord->x = (vpos[iA * 4 + 3] * u + vpos[iB * 4 + 3] * v) + vpos[iC * 4 + 3] * w;   /* tA = (pos.w, norm.w), :1003-1005 */
+  pTexCoord->y = (vnorm[iA * 4 + 3] * u + vnorm[iB * 4 + 3] * v) + vnorm[iC * 4 + 3] * w;
   *pdfA = 1.0f / L[PL_SURFACE_AREA];
 }
 static f3 meshLightMatrixMul(const float* M, f3 v) { return v3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
 static void MeshLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
-  f3 samplePos, sampleNorm; float pdfA;
-  MeshLightSamplePos(s, L, rands, &samplePos, &sampleNorm, &pdfA);
+  f3 samplePos, sampleNorm; f2 tc; float pdfA;
+  MeshLightSamplePos(s, L, rands, &samplePos, &sampleNorm, &tc, &pdfA);
   samplePos = meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, samplePos);
   sampleNorm = normalize3(meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, sampleNorm));
   samplePos = add3(samplePos, lightPos(L));
@@ -2061,7 +2069,7 @@ static void MeshLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 i
   const float cosVal = fmaxf(-dot3(rayDir, sampleNorm), 0.0f);
   out->isPoint = 0;
   out->pos = add3(samplePos, scale3(sampleNorm, epsilonOfPos(samplePos)));
-  out->color = lightColor(L);
+  out->color = meshLightGetIntensity(s, L, tc);
   out->pdf = PdfAtoW_full(pdfA, hitDist, cosVal);
   out->maxDist = hitDist;
   out->cosAtLight = cosVal;
@@ -2070,9 +2078,69 @@ static float meshLightEvalPDF(const float* L, f3 rayDir, f3 lnorm, float hitDist
   const float pdfA = 1.0f / fmaxf(L[PL_SURFACE_AREA], DEPSILON);
   return PdfAtoW_full(pdfA, hitDist, fmaxf(dot3(rayDir, scale3(lnorm, -1.0f)), 0.0f));
 }
+/* ref: clight.h:753-830, 1338-1385 cylinder lights; sampleMap2D :378-403 */
+static f3 cylinderLightGetIntensity(const OrcScene* s, const float* L, f2 tc) { return mul3(sample2DExt(as_int(L[CYLINDER_TEXMATRIX_ID]), tc, L, s), lightColor(L)); }
+static void CylinderLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNormal, f2* pTexCoord, float* pPdfA) {
+  f2 tc = {rands.x, rands.y};
+  float mapPdf = 1.0f;
+  const int texId = as_int(L[CYLINDER_PDF_TABLE_ID]);
+  if (texId > 0) {
+    const float* hdr = pdfTableHeader(s, texId);
+    const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+    const float fw = (float)sizeX, fh = (float)sizeY;
+    float pdf = 1.0f;
+    int pixelOffset = SelectIndexPropToOpt(rands.z, hdr + 4, sizeX * sizeY + 1, &pdf);
+    if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+    const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+    tc.x = (1.0f / fw) * (((float)(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+    tc.y = (1.0f / fh) * (((float)(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+    mapPdf = pdf * (fw * fh);
+  }
+  *pPdfA = mapPdf / L[PL_SURFACE_AREA];
+  const float zMin = L[CYLINDER_LIGHT_ZMIN], zMax = L[CYLINDER_LIGHT_ZMAX], radius = L[CYLINDER_LIGHT_RADIUS], phiMax = L[CYLINDER_LIGHT_PHIMAX];
+  const float z = zMin + tc.x * (zMax - zMin);
+  const float phi = tc.y * phiMax;
+  const float sinPhi = sinf(phi), cosPhi = cosf(phi);   /* sincos2f, cglobals.h:338-341 */
+  f3 pObj = v3(radius * cosPhi, radius * sinPhi, z);
+  f3 n = normalize3(v3(pObj.x, pObj.y, 0.0f));
+  const float hitRad = sqrtf(pObj.x * pObj.x + pObj.y * pObj.y);
+  pObj.x *= radius / hitRad;
+  pObj.y *= radius / hitRad;
+  n = normalize3(meshLightMatrixMul(L + CYLINDER_LIGHT_MATRIX_E00, n));
+  const f3 center = lightPos(L);
+  *pPos = add3(add3(center, meshLightMatrixMul(L + CYLINDER_LIGHT_MATRIX_E00, pObj)), scale3(n, epsilonOfPos(center)));
+  *pNormal = n;
+  *pTexCoord = tc;
+}
+static float cylinderLightEvalPDF(const OrcScene* s, const float* L, f3 illum, f3 lpos, f3 lnorm, f2 texCoord) {
+  float mapPdf = 1.0f;
+  const int texId = as_int(L[CYLINDER_PDF_TABLE_ID]);
+  if (texId) {
+    const float* hdr = pdfTableHeader(s, texId);
+    mapPdf = evalMap2DPdf(texCoord, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+  }
+  const float hitDist = length3(sub3(lpos, illum));
+  const f3 rayDir = normalize3(sub3(lpos, illum));
+  const float pdfA = mapPdf / fmaxf(L[PL_SURFACE_AREA], DEPSILON);
+  return PdfAtoW_full(pdfA, hitDist, fmaxf(dot3(rayDir, scale3(lnorm, -1.0f)), 0.0f));
+}
+static void CylinderLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
+  f3 samplePos, n; f2 tc; float pdfA;
+  CylinderLightSamplePos(s, L, rands, &samplePos, &n, &tc, &pdfA);
+  const float hitDist = length3(sub3(samplePos, illum));
+  const f3 rayDir = normalize3(sub3(samplePos, illum));
+  const float cosVal = fmaxf(dot3(rayDir, scale3(n, -1.0f)), 0.0f);
+  out->isPoint = 0;
+  out->pos = samplePos;
+  out->color = cylinderLightGetIntensity(s, L, tc);
+  out->pdf = PdfAtoW_full(pdfA, hitDist, cosVal);
+  out->maxDist = hitDist;
+  out->cosAtLight = cosVal;
+}
 /* ref: clight.h:1613-1633 lightEvalPDF for the lights that have a surface in this subset */
-static float lightEvalPDF(const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm) {
+static float lightEvalPDF(const OrcScene* s, const float* L, f3 illum, f3 rayDir, f3 lpos, f3 lnorm, f2 texCoord) {
   if (as_int(L[PL_TYPE]) == LT_SPHERE) return sphereLightEvalPDF(L, illum, lpos, lnorm);
+  if (as_int(L[PL_TYPE]) == LT_CYLINDER) return cylinderLightEvalPDF(s, L, illum, lpos, lnorm, texCoord);
   if (as_int(L[PL_TYPE]) == LT_MESH) return meshLightEvalPDF(L, rayDir, lnorm, length3(sub3(illum, lpos)));
   return areaDiffuseLightEvalPDF(L, rayDir, length3(sub3(illum, lpos)));
 }
@@ -2084,7 +2152,8 @@ static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum
     case LT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
     case LT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
     case LT_POINT_OMNI: PointLightSampleRev(L, illum, out); break;
-    default: AreaLightSampleRev(L, rands, illum, out); break;
+    case LT_CYLINDER: CylinderLightSampleRev(s, L, rands, illum, out); break;
+    default: AreaLightSampleRev(s, L, rands, illum, out); break;
   }
 }
 
@@ -2117,11 +2186,12 @@ static void SphereLightSampleForward(const float* L, const float r[4], LightSamp
   out->norm = lnorm;
 }
 /* ref: clight.h:1023-1062 MeshLightSampleForward; r2x = rands2.x, the triangle choice */
-static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, float* pdfA);
+static void MeshLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNorm, f2* pTexCoord, float* pdfA);
+static f3 meshLightGetIntensity(const OrcScene* s, const float* L, f2 tc);
 static f3 meshLightMatrixMul(const float* M, f3 v);
 static void MeshLightSampleForward(const OrcScene* s, const float* L, const float r[4], float r2x, LightSampleFwd* out) {
-  f3 samplePos, sampleNorm; float pdfA;
-  MeshLightSamplePos(s, L, v3(r[0], r[1], r2x), &samplePos, &sampleNorm, &pdfA);
+  f3 samplePos, sampleNorm; f2 tc; float pdfA;
+  MeshLightSamplePos(s, L, v3(r[0], r[1], r2x), &samplePos, &sampleNorm, &tc, &pdfA);
   samplePos = meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, samplePos);
   sampleNorm = normalize3(meshLightMatrixMul(L + MESH_LIGHT_MATRIX_E00, sampleNorm));
   samplePos = add3(samplePos, lightPos(L));
@@ -2130,14 +2200,31 @@ static void MeshLightSampleForward(const OrcScene* s, const float* L, const floa
   out->isPoint = 0;
   out->pos = add3(samplePos, scale3(sampleNorm, epsilonOfPos(samplePos)));
   out->dir = sampleDir;
-  out->color = scale3(lightColor(L), cosTheta);
+  out->color = scale3(meshLightGetIntensity(s, L, tc), cosTheta);
   out->pdfA = 1.0f / L[PL_SURFACE_AREA];
   out->pdfW = cosTheta * INV_PI;
   out->cosTheta = cosTheta;
   out->norm = sampleNorm;
 }
-/* ref: clight.h:654-719 AreaLightSampleForward (no IES, no sky portal in the subset) */
-static void AreaLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
+/* ref: clight.h:813-835 CylinderLightSampleForward */
+static void CylinderLightSamplePos(const OrcScene* s, const float* L, f3 rands, f3* pPos, f3* pNormal, f2* pTexCoord, float* pPdfA);
+static f3 cylinderLightGetIntensity(const OrcScene* s, const float* L, f2 tc);
+static void CylinderLightSampleForward(const OrcScene* s, const float* L, const float r[4], float r2x, LightSampleFwd* out) {
+  f3 samplePos, ln; f2 tc; float pdfA;
+  CylinderLightSamplePos(s, L, v3(r[0], r[1], r2x), &samplePos, &ln, &tc, &pdfA);
+  const f3 sampleDir = MapSampleToCosineDistribution(r[2], r[3], ln, ln, 1.0f);
+  const float cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
+  out->isPoint = 0;
+  out->pos = add3(samplePos, scale3(ln, epsilonOfPos(samplePos)));
+  out->dir = sampleDir;
+  out->color = scale3(cylinderLightGetIntensity(s, L, tc), cosTheta);
+  out->pdfA = pdfA;
+  out->pdfW = cosTheta * INV_PI;
+  out->cosTheta = cosTheta;
+  out->norm = ln;
+}
+/* ref: clight.h:654-719 AreaLightSampleForward (no IES in the subset) */
+static void AreaLightSampleForward(const OrcScene* s, const float* L, const float r[4], LightSampleFwd* out) {
   const float offsetX = r[0] * 2.0f - 1.0f, offsetY = r[1] * 2.0f - 1.0f;
   f3 sp = v3(offsetX * L[AL_SIZE_X], 0.0f, offsetY * L[AL_SIZE_Y]);
   if (as_int(L[AL_IS_DISK]) != 0) {
@@ -2159,7 +2246,7 @@ static void AreaLightSampleForward(const float* L, const float r[4], LightSample
     pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
   }
   cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
-  const f3 color = areaDiffuseLightGetIntensity(L, scale3(sampleDir, -1.0f), 0);
+  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, scale3(sampleDir, -1.0f))) : areaDiffuseLightGetIntensity(L, scale3(sampleDir, -1.0f), 0);
   out->isPoint = 0;
   out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
   out->dir = sampleDir;
@@ -2234,7 +2321,8 @@ void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds,
       case LT_DIRECT: DirectLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_SPOT: PointSpotSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_OMNI: PointLightSampleForward(L, rands4 + 4 * i, &sam); break;
-      default: AreaLightSampleForward(L, rands4 + 4 * i, &sam); break;
+      case LT_CYLINDER: CylinderLightSampleForward(s, L, rands4 + 4 * i, 0.0f, &sam); break;
+      default: AreaLightSampleForward(s, L, rands4 + 4 * i, &sam); break;
     }
     float* o = out16 + 16 * (size_t)i;
     o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
@@ -2389,8 +2477,68 @@ static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prev
 /* ------------------------------------------------------------------------------------------------ path tracer */
 typedef struct { float matSamplePdf; int isSpecular; } MisData;   /* ref: cglobals.h:1382-1400 (fields the PT path reads) */
 
+/* the sky a portal names sits AREA_LIGHT_SKY_OFFSET records away (RenderDriverRTE.cpp:1670-1682); a Perez sky counts half (clight.h:598-601, 622-625) */
+static f3 portalSkyColor(const OrcScene* s, const float* L, f3 rayDir) {
+  const float* sky = L + (ptrdiff_t)as_int(L[AREA_LIGHT_SKY_OFFSET]) * LIGHT_FLOATS;
+  if (as_int(sky[PL_FLAGS]) & SKY_LIGHT_USE_PEREZ) return scale3(skyLightPerezColor(sky, rayDir), 0.5f);
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(rayDir, &sintheta);   /* skyLightGetIntensityTexturedENV, clight.h:285-306 */
+  return mul3(lightColor(sky), sample2DExt(as_int(sky[PL_COLOR_TEX_MATRIX]), tc, sky + SKY_DOME_SAMPLER0, s));
+}
+/* ref: clight.h:1636-1657 hitDirectLight, :892-912 directLightAttenuation, :1462-1476 directLightEvalPDF */
+static int hitDirectLight(const OrcScene* s, f3 ray_dir) {
+  for (int sunId = 0; sunId < s->globals[G_SUN_NUMBER]; sunId++) {
+    const float* sun = (const float*)(s->globals + G_SUNS) + (size_t)sunId * LIGHT_FLOATS;
+    if (-dot3(ray_dir, lightNorm(sun)) > sun[DIRECT_LIGHT_ALPHA_COS]) return sunId;
+  }
+  return -1;
+}
+static float directLightAttenuation(const float* L, f3 illum) {
+  const f3 lpos = lightPos(L);
+  const float cos_alpha = dot3(normalize3(sub3(illum, lpos)), lightNorm(L));
+  if (cos_alpha > 0.0f) {
+    const float sinAlpha = sqrtf(1.0f - cos_alpha * cos_alpha);
+    const float d = length3(sub3(illum, lpos)) * sinAlpha;
+    const float r1 = L[DIRECT_LIGHT_RADIUS1], r2 = L[DIRECT_LIGHT_RADIUS2];
+    return mylocalsmoothstep(fmaxf(r2, r1), fminf(r2, r1), d);
+  }
+  return 0.0f;
+}
+static float directLightEvalPDF(const float* L, f3 ray_dir) {
+  if (L[DIRECT_LIGHT_SSOFTNESS] > 1e-5f) {
+    const float tanAlpha = L[DIRECT_LIGHT_ALPHA_TAN], cosTheta = -dot3(ray_dir, lightNorm(L));
+    return ORC_PI * (tanAlpha * tanAlpha) * (cosTheta * cosTheta * cosTheta);
+  }
+  return 1.0f;
+}
+/* ref: clight.h:1661-1706 lightGetIntensity */
+static f3 lightGetIntensity(const OrcScene* s, const float* L, f3 ray_pos, f3 ray_dir, f2 texCoord, uint32_t flags, int wasSpecular) {
+  const int eyeRay = ((flags & 0xFFu) == 0);
+  const int type = as_int(L[PL_TYPE]);
+  if ((as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) && (flags & 0xFFu) > 0) {
+    const int hitId = hitDirectLight(s, ray_dir);
+    if (hitId >= 0) {
+      const float* sun = (const float*)(s->globals + G_SUNS) + (size_t)hitId * LIGHT_FLOATS;
+      f3 sunColor = scale3(lightColor(sun), directLightAttenuation(sun, ray_pos));
+      const float pdfW = directLightEvalPDF(sun, ray_dir);
+      const uint32_t gflags = (uint32_t)s->globals[G_FLAGS];
+      if (((flags >> 8) & 0xFFu) > 0 && !(gflags & HRT_STUPID_PT_MODE) && !wasSpecular) sunColor = v3(0, 0, 0);
+      else if ((wasSpecular && (gflags & HRT_ENABLE_PT_CAUSTICS)) || (gflags & HRT_STUPID_PT_MODE)) sunColor = scale3(sunColor, 1.0f / pdfW);
+      return sunColor;
+    }
+    return mul3(lightColor(L), portalSkyColor(s, L, ray_dir));
+  }
+  if (type == LT_AREA) {
+    f3 color = areaDiffuseLightGetIntensity(L, ray_dir, eyeRay);
+    if (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) color = mul3(color, portalSkyColor(s, L, ray_dir));
+    return color;
+  }
+  if (type == LT_CYLINDER) return cylinderLightGetIntensity(s, L, texCoord);
+  if (type == LT_MESH) return meshLightGetIntensity(s, L, texCoord);
+  return lightColor(L);
+}
 /* ref: cbidir.h:653-678 emissionEval + CPUExp_Integrators_Common.cpp:516-527 */
-static f3 emissionEval(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceHit* sh, uint32_t flags, const float* pLight, const float* mat) {
+static f3 emissionEval(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceHit* sh, uint32_t flags, int wasSpecular, const float* pLight, const float* mat) {
   const f3 normal = sh->hfi ? scale3(sh->normal, -1.0f) : sh->normal;
   int hasIES = 0;
   const int lightsNum = s->globals[G_LIGHTS_NUM];
@@ -2398,13 +2546,7 @@ static f3 emissionEval(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceH
   if (dot3(ray_dir, normal) >= 0.0f && !hasIES) return v3(0, 0, 0);
   f3 out = materialEvalEmission(mat, ray_dir, normal, sh->texCoord, s);
   if ((matFlags(mat) & MF_FORBID_EMISSIVE_GI) && (flags & 0xFFu) > 0) out = v3(0, 0, 0);
-  if (lightsNum > 0 && pLight != NULL) {
-    /* lightGetIntensity, clight.h:1661-1706: area lights only in the subset */
-    const int eyeRay = ((flags & 0xFFu) == 0);
-    if (as_int(pLight[PL_TYPE]) == LT_AREA) out = areaDiffuseLightGetIntensity(pLight, ray_dir, eyeRay);
-    else out = lightColor(pLight);
-  }
-  (void)ray_pos;
+  if (lightsNum > 0 && pLight != NULL) out = lightGetIntensity(s, pLight, ray_pos, ray_dir, sh->texCoord, flags, wasSpecular);
   return out;
 }
 
@@ -2420,10 +2562,10 @@ typedef struct { int bounce, shadow; f3 pos, dir; float tfar; int have; } RayPro
 static int stage_emission(const OrcScene* s, f3 ray_pos, f3 ray_dir, const SurfaceHit* surf, const float* mat, int hitInstId, uint32_t flags, MisData misPrev, f3* currColor) {
   const int lightOffset0 = (s->globals[G_LIGHTS_NUM] != 0) ? s->instLightInstId[hitInstId] : -1;
   const float* pLightHit = lightAt(s, lightOffset0);
-  const f3 emission = emissionEval(s, ray_pos, ray_dir, surf, flags, pLightHit, mat);
+  const f3 emission = emissionEval(s, ray_pos, ray_dir, surf, flags, misPrev.isSpecular == 1, pLightHit, mat);
   if (!(dot3(emission, emission) > 1e-3f)) return 0;
   if (pLightHit != NULL) {
-    const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * lightEvalPDF(pLightHit, ray_pos, ray_dir, surf->pos, surf->normal);
+    const float lgtPdf = pLightHit[PL_PICK_PROB_REV] * lightEvalPDF(s, pLightHit, ray_pos, ray_dir, surf->pos, surf->normal, surf->texCoord);
     float misWeight = misWeightHeuristic(misPrev.matSamplePdf, lgtPdf);
     if (misPrev.isSpecular) misWeight = 1.0f;
     *currColor = scale3(emission, misWeight);
@@ -2701,7 +2843,8 @@ static void LightSampleForwardAny(const OrcScene* s, const float* L, const float
     case LT_DIRECT: DirectLightSampleForward(L, r, sam); break;
     case LT_POINT_SPOT: PointSpotSampleForward(L, r, sam); break;
     case LT_POINT_OMNI: PointLightSampleForward(L, r, sam); break;
-    default: AreaLightSampleForward(L, r, sam); break;
+    case LT_CYLINDER: CylinderLightSampleForward(s, L, r, r2x, sam); break;
+    default: AreaLightSampleForward(s, L, r, sam); break;
   }
 }
 static void lightPdfFwdOne(const float* L, float ct, float* pdfA, float* pdfW) {
@@ -2775,7 +2918,7 @@ static void mmltF(const OrcScene* s, const float* xVec, int d, float* out8) {
       }
       const float* mat = materialAt(s, surf.matId);
       const float* pLight = lightAt(s, s->instLightInstId[hit.instId]);
-      const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, pLight, mat);
+      const f3 emission = emissionEval(s, ray_pos, ray_dir, &surf, flags, misPrev.isSpecular == 1, pLight, mat);
       if (dot3(emission, emission) > 1e-6f) {
         if (currDepth == camTraceDepth && haveToHitLight) {
           float pdfA, pdfW;

@@ -19,10 +19,10 @@ HK_DEV f3 hk_path_trace_one(const SceneDev& s, HkStack& st, f3 ray_pos, f3 ray_d
     {
       const int lo0 = (s.globals[HG_LIGHTS_NUM] != 0) ? s.instLightInstId[hit.instId] : -1;
       const float* pL = lightAt(s, lo0);
-      const f3 emission = emissionEval(s, ray_dir, surf, flags, pL, mat);
+      const f3 emission = emissionEval(s, ray_pos, ray_dir, surf, flags, misSpec, pL, mat);
       if (dot(emission, emission) > 1e-3f) {
         if (pL != nullptr) {
-          const float lgtPdf = pL[HL_PICK_PROB_REV] * lightEvalPDF(pL, ray_pos, ray_dir, surf.pos, surf.normal);
+          const float lgtPdf = pL[HL_PICK_PROB_REV] * lightEvalPDF(s, pL, ray_pos, ray_dir, surf.pos, surf.normal, surf.texCoord);
           float w = misWeightHeuristic(misPdf, lgtPdf);
           if (misSpec) w = 1.0f;
           currColor = emission * w;

@@ -325,3 +325,70 @@ def test_two_matrices_camera(tmp_path):
     np.testing.assert_allclose(gb[0:64].view(np.float32), ga[0:64].view(np.float32), rtol=2e-5, atol=2e-6)
     fa, fb = ga[G_VARS_F:G_VARS_F + 64].view(np.float32), gb[G_VARS_F:G_VARS_F + 64].view(np.float32)
     np.testing.assert_allclose(fb[14], fa[14], rtol=1e-5)          # varsF[HRT_CAM_FOV]
+
+
+def test_cylinder_and_textured_mesh_lights_pack_like_the_reference_converter():
+    """CylinderLight + CreateCylinderLightFromXmlNode (PlainLightConverter.cpp:354-443, 867-893), its 2-D table (RenderDriverRTE.cpp:940-941 ->
+    UpdatePdfTablesForLight, RenderDriverRTE_PdfTables.cpp:479-570) and the colour texture of a MeshLight (:770-782)"""
+    _, b = host_scene("atrium_tubes_small", 96, 54, 5)
+    g = b["globals"]
+    gf = g.view(np.float32)
+    n = g[G_LIGHTS_NUM]
+    L = gf[g[G_LIGHTS_OFFS]:g[G_LIGHTS_OFFS] + n * 128].reshape(n, 128)
+    Li = L.view(np.int32)
+    assert list(Li[:, 0]) == [4, 6, 6, 7]                                            # area, cylinder, cylinder, mesh
+    tube, half = L[1], L[2]
+    np.testing.assert_allclose(tube[25:29], [0.15, -3.0, 3.0, 2 * np.pi], rtol=1e-6)  # radius, zMin, zMax, phiMax
+    np.testing.assert_allclose(tube[13], 6.0 * 0.15 * 2 * np.pi, rtol=1e-6)           # (zMax - zMin) * radius * phiMax under a rigid instance matrix
+    np.testing.assert_allclose(half[25:29], [0.3, -1.5, 1.5, np.pi], rtol=1e-6)       # the radius field keeps the light's own value ...
+    np.testing.assert_allclose(half[13], 3.0 * 1.3 * (0.3 * 1.3) * np.pi, rtol=1e-5)  # ... the area takes the instance scale twice (:399-408)
+    np.testing.assert_allclose(tube[8:11], 30.0)
+    m = tube[16:25].reshape(3, 3)
+    np.testing.assert_allclose(m @ m.T, np.eye(3), atol=1e-6)                         # the instance's rotation
+    np.testing.assert_allclose(np.linalg.norm(half[16:25].reshape(3, 3), axis=0), 1.3, rtol=1e-5)
+    # the colour texture: id 1 behind an identity sampler at int4 offset 8 of the record; none on the half tube
+    assert Li[1, 29] == 1 and Li[1, 30] == 8 and Li[1, 32 + 2] == 1
+    np.testing.assert_allclose(tube[32 + 4:32 + 12], [1, 0, 0, 0, 0, 1, 0, 0])
+    assert np.uint32(Li[2, 29]) == 0xFFFFFFFE and np.uint32(Li[2, 30]) == 0xFFFFFFFE
+    # the (z, phi) tables: luminance of the 256^2 checker / the 2 x 2 uniform image, as prefix sums behind {w, h, 1, n + 1}
+    pdf = b["pdfs"] if "pdfs" in b else None
+    tab = g[g[220]:g[220] + g[225]]                                                   # pdf table offsets (float4 units)
+    for rec, (w, h) in ((Li[1], (256, 256)), (Li[2], (2, 2))):
+        tid = rec[31]
+        assert 0 <= tid < len(tab)
+        if pdf is not None:
+            t = pdf.reshape(-1)[tab[tid] * 4:]
+            assert tuple(t[:4].view(np.int32)) == (w, h, 1, w * h + 2)
+            acc = t[4:4 + w * h + 1]
+            assert acc[0] == 0 and (np.diff(acc) > 0).all() and t[4 + w * h + 1] == 1.0
+    # mesh light: colour texture 2 at the record's own sampler slot (MESH_LIGHT_TEX_ID / _TEXMATRIX_ID / _TEX_SAMPLER = 30 / 31 / 32)
+    assert Li[3, 30] == 2 and Li[3, 31] == 8 and Li[3, 32 + 2] == 2
+    np.testing.assert_allclose(L[:, 107], 0.25)
+
+
+def test_sky_portal_packs_like_the_reference_converter():
+    """AreaDiffuseLight with <sky_portal> (PlainLightConverter.cpp:197-258), SkyPortalMaterial (PlainMaterialConverter.cpp:304-350), the offsets
+    RenderDriverRTE::BuildSkyPortalsDependencyDummyInstances writes (RenderDriverRTE.cpp:1653-1684), the pick table that leaves the portal's sky
+    out (RenderDriverRTE_PdfTables.cpp:598-602, 631-635) and the header's sun table (IHWLayerDataAssembler.cpp:422-449)"""
+    _, b = host_scene("atrium_portal_small", 96, 54, 5)
+    g = b["globals"]
+    gf = g.view(np.float32)
+    n = g[G_LIGHTS_NUM]
+    L = gf[g[G_LIGHTS_OFFS]:g[G_LIGHTS_OFFS] + n * 128].reshape(n, 128)
+    Li = L.view(np.int32)
+    assert list(Li[:, 0]) == [4, 3, 4, 2] and g[G_SKY] == 1                           # roof light, sky, portal, sun
+    assert Li[2, 1] == 8 and Li[2, 30] == 1 and Li[2, 29] == -1                      # AREA_LIGHT_SKY_PORTAL, source light id, record offset to the sky
+    assert np.uint32(Li[2, 11]) == 0xFFFFFFFE and np.uint32(Li[2, 31]) == 0xFFFFFFFE  # no texture of its own, no blurred texture
+    np.testing.assert_allclose(L[2, 13], 16.0 * 8.0)
+    np.testing.assert_allclose(L[:, 107], [1 / 3, 0.0, 1 / 3, 1 / 3], rtol=1e-6)      # the sky is never picked: the portal stands in for it
+    np.testing.assert_allclose(L[:, 106], [1 / 3, 0.0, 1 / 3, 1 / 3], rtol=1e-6)
+    assert g[G_VARS_I + 26] == 1                                                     # HRT_HRT_SCENE_HAVE_PORTALS
+    assert g[242] == 8                                                               # sic: MAX_SUN_NUM copies of the one soft sun
+    suns = gf[243:243 + 8 * 128].reshape(8, 128)
+    assert (suns.view(np.int32) == Li[3]).all()
+    # the portal's material: clear thin glass, PLAIN_MATERIAL_HAS_TRANSPARENCY | SKIP_SHADOW | SKIP_SKY_PORTAL, no emission of its own
+    m = b["materials"].reshape(-1, 192)
+    mi = m.view(np.int32)
+    at = g[g[G_MAT_TABLE] + 12] * 4 // 192
+    assert mi[at, 0] == 3 and mi[at, 1] == (8 | 256 | 1024)
+    np.testing.assert_allclose(m[at, 10:13], 1.0)

@@ -64,6 +64,26 @@ def gpu_atrium_perez(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_tubes(built):
+    """the closed hall with a textured cylinder light, an untextured half cylinder on a scaled instance and a textured mesh light (clight.h:753-830, 957-1062, 1338-1385)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_tubes_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
+def gpu_atrium_portal(built):
+    """the open hall whose sky (lat-long texture) is sampled through a sky portal in the roof; a soft sun fills the header's sun table (clight.h:590-629, 1636-1695)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_portal_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_nmap(built):
     """the hall with normal-mapped floor, walls and columns (lambert, textured lambert, lambert + glossy blends; BumpMapping, cmaterial.h:2208-2243)"""
     from hydracore_amd import HipCore
@@ -199,7 +219,7 @@ def test_eye_rays(fix, request):
     np.testing.assert_allclose(dr[:, :3], rdr[:, :3], atol=2e-6)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_closest_hit_bit_exact(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     pos4, dir4 = random_rays(65536, 21) if not fix.startswith("gpu_atrium") else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
@@ -261,7 +281,7 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
             core.set_option(k, {"trace_vote_wq": 1, "trace_vote_wt": 1, "trace_vote_wi": 2}[k])
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_persistent_counting_kernels_total_what_the_oracle_counts(fix, request):
     """k_trace_dyn<*, true> -- the kernels bench.py prices its roofline bytes with -- against the oracle's per-ray counters
     summed: rays, quads visited, instance quads entered, leaves visited, triangles tested; closest hit and the early-out
@@ -303,7 +323,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -326,7 +346,7 @@ class _HipBidir:
         self.camera_connect, self.mutate_kelemen = core.stage_camera_connect, core.stage_mutate_kelemen
 
 
-@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small")])
+@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small")])
 def test_bidirectional_building_blocks(fix, name, request):
     """row f3, first milestone: LightSampleForward, lightPdfFwd, CameraImageToSurfaceFactor + worldPosToScreenSpace and
     MutateKelemen on the device, against the oracle (same inputs, float-exact up to exp/log/sin/cos) and against the
@@ -344,7 +364,7 @@ def test_bidirectional_building_blocks(fix, name, request):
 
 
 @pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"),
-                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small"), ("gpu_atrium_aniso", "atrium_aniso_small")])
+                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small"), ("gpu_atrium_aniso", "atrium_aniso_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small")])
 def test_mmlt_contribution_function(fix, name, request):
     """row f3: IntegratorMMLT::F in wavefront form (k_mmlt_* around the traversal kernels) against the oracle's restatement on the same
     primary-sample vectors, and against the reference's functions (tests/golden/ref_mmlt_<scene>.npz)"""
@@ -569,7 +589,7 @@ def test_mmlt_through_the_ihwlayer_adapter(built):
     assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -590,7 +610,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -694,7 +714,7 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""
@@ -768,7 +788,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
 
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small", "gpu_atrium_skyhdr": "atrium_skyhdr_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
-              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small"}
+              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small", "gpu_atrium_tubes": "atrium_tubes_small", "gpu_atrium_portal": "atrium_portal_small"}
 
 
 @pytest.mark.parametrize("fix", list(FIXTURE_OF))

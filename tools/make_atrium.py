@@ -149,6 +149,24 @@ def globe(radius, seg_t=24, seg_p=12, mat=12):
     return m
 
 
+def tube(radius, height, angle_deg, seg_p=32, seg_z=8, mat=12):
+    """open cylinder around the local z axis, the visible surface of a cylinder light: the point (z, phi) of CylinderLightSamplePos (clight.h:785-798)
+    carries the texture coordinate ((z - zMin) / height, phi / phiMax), so that a hit looks up the same texel and table cell a sample of that point does"""
+    ph = np.linspace(0, np.radians(angle_deg), seg_p + 1)
+    zz = np.linspace(-0.5 * height, 0.5 * height, seg_z + 1)
+    P, Z = np.meshgrid(ph, zz, indexing="ij")
+    pos = np.stack([radius * np.cos(P), radius * np.sin(P), Z], -1).reshape(-1, 3)
+    uv = np.stack([(Z + 0.5 * height) / height, P / np.radians(angle_deg)], -1).reshape(-1, 2)
+    tri = grid_indices(seg_p, seg_z)
+    m = finish_mesh(pos, uv, tri, np.full(len(tri), mat))
+    nrm = pos.copy(); nrm[:, 2] = 0; nrm /= radius
+    m["norm"][:, :3] = nrm
+    c = pos[tri[0]].mean(axis=0); c[2] = 0
+    if np.dot(np.cross(pos[tri[0, 1]] - pos[tri[0, 0]], pos[tri[0, 2]] - pos[tri[0, 0]]), c) < 0:
+        m["idx"] = tri[:, ::-1].astype(np.int32).ravel()     # counter-clockwise seen from outside
+    return m
+
+
 def plant(cards=6, height=1.6, width=0.9):
     """crossed vertical cards around the y axis, uv = the whole mask on every card, material 11"""
     pos, uv, tri = [], [], []
@@ -253,6 +271,10 @@ def main():
     ap.add_argument("--sky-tex", action="store_true", help="like --sky, but the sky is a 512x256 lat-long texture (horizon gradient + sun) x 0.8")
     ap.add_argument("--perez", action="store_true", help="like --sky, but the sky uses the Perez all-weather model (turbidity 2.5) with a directional sun (light id 3) "
                     "that also lights the hall through the open roof")
+    ap.add_argument("--tube-lights", action="store_true", help="closed hall; adds a cylinder light textured with the 256^2 checker, an untextured half cylinder and a mesh light "
+                    "textured with the 128^2 checker (clight.h:753-830, 957-1062), each with its visible surface")
+    ap.add_argument("--portal", action="store_true", help="like --sky-tex plus a soft sun; a 16 x 8 sky portal (area light with <sky_portal>, material sky_portal_mtl) lies in the "
+                    "open roof and stands in for the sky light, which is then never sampled (clight.h:590-629, 1670-1695)")
     ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
                     "reflection + glass + diffuse, curtains = textured glossy thin glass over diffuse")
     ap.add_argument("--cutouts", action="store_true", help="adds 60 instanced plants made of crossed cards whose material has an <opacity> leaf mask (alpha-tested traversal, "
@@ -271,7 +293,7 @@ def main():
                     "height map (amount 0.8; the wall's copy smoothed, smooth_lvl 0.3): the layer bakes the normal maps (IHWLayer::NormalMapFromDisplacement)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
-    args.sky_tex = args.sky_tex or args.sky_hdr
+    args.sky_tex = args.sky_tex or args.sky_hdr or args.portal
     args.sky = args.sky or args.sky_tex or args.perez
     refl = "ggx" if args.ggx else "torranse_sparrow" if args.translucent else "phong"   # "torranse_sparrow" (sic) = Blinn in a Torrance-Sparrow model
     s = np.sqrt(args.scale)
@@ -293,6 +315,22 @@ def main():
         lamp = globe(0.3, 8, 4, mat=13)
         lamp["pos"][:, 1] *= 0.6
         meshes.append(("lamp", lamp))
+
+    tube_mesh = half_tube_mesh = tlamp_mesh = portal_mesh = None
+    if args.tube_lights:
+        tube_mesh = len(meshes)
+        meshes.append(("tube", tube(0.15, 6.0, 360.0)))
+        half_tube_mesh = len(meshes)
+        meshes.append(("half_tube", tube(0.3, 3.0, 180.0, 16, 4, mat=13)))
+        tlamp_mesh = len(meshes)
+        tl = globe(0.3, 8, 4, mat=14)
+        tl["pos"][:, 1] *= 0.6
+        meshes.append(("tlamp", tl))
+    if args.portal:
+        portal_mesh = len(meshes)
+        pm = light_quad(8.0, 4.0)
+        pm["mat"][:] = 12
+        meshes.append(("portal", pm))
 
     # textures: id 0 = white dummy (as in the reference fixtures), 1..2 = checkers
     texs = [(2, np.full((2, 2, 4), 255, np.uint8)), (256, checker(256, (200, 170, 120), (120, 90, 60))), (128, checker(128, (90, 110, 160), (210, 210, 220), 4))]
@@ -413,6 +451,12 @@ def main():
     if args.delta_lights:
         xml.append('  <material id="12" name="globe_mat" type="hydra_material" light_id="4" visible="1"><emission><color val="25 22 18" /></emission></material>')
         xml.append('  <material id="13" name="lamp_mat" type="hydra_material" light_id="5" visible="1"><emission><color val="18 24 30" /></emission></material>')
+    if args.tube_lights:
+        xml.append('  <material id="12" name="tube_mat" type="hydra_material" light_id="1" visible="1"><emission><color val="30 30 30" /></emission></material>')
+        xml.append('  <material id="13" name="half_tube_mat" type="hydra_material" light_id="2" visible="1"><emission><color val="20 14 8" /></emission></material>')
+        xml.append('  <material id="14" name="tlamp_mat" type="hydra_material" light_id="3" visible="1"><emission><color val="18 24 30" /></emission></material>')
+    if args.portal:
+        xml.append('  <material id="12" name="portal_mat" type="sky_portal_mtl" light_id="2" visible="1"><emission><color val="1 1 1" /><multiplier val="1.0" /></emission></material>')
     xml.append("</materials_lib>")
     xml.append('<lights_lib>\n  <light id="0" name="roof_light" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="10" mesh_id="6">'
                '<size half_length="2.0" half_width="0.5" /><intensity><color val="1 0.933 0.833" /><multiplier val="60.0" /></intensity></light>'
@@ -426,6 +470,12 @@ def main():
                   '<shadow_softness val="1.0" /><intensity><color val="1 0.92 0.8" /><multiplier val="3.0" /></intensity></light>' if args.perez else
                   '\n  <light id="1" name="sky" type="sky" shape="point" distribution="uniform" visible="1"><intensity><color val="1 1 1" />'
                   '<multiplier val="0.5" /></intensity></light>' if args.sky else
+                  '\n  <light id="1" name="tube" type="area" shape="cylinder" distribution="uniform" visible="1" mat_id="12" mesh_id="%d"><size radius="0.15" height="6" angle="360" />'
+                  '<intensity><color val="1 1 1"><texture id="1" type="texref" /></color><multiplier val="30.0" /></intensity></light>'
+                  '\n  <light id="2" name="half_tube" type="area" shape="cylinder" distribution="uniform" visible="1" mat_id="13" mesh_id="%d"><size radius="0.3" height="3" angle="180" />'
+                  '<intensity><color val="1 0.7 0.4" /><multiplier val="20.0" /></intensity></light>'
+                  '\n  <light id="3" name="tlamp" type="area" shape="mesh" distribution="uniform" visible="1" mat_id="14" mesh_id="%d">'
+                  '<intensity><color val="0.6 0.8 1"><texture id="2" type="texref" /></color><multiplier val="30.0" /></intensity></light>' % (tube_mesh, half_tube_mesh, tlamp_mesh) if args.tube_lights else
                   '\n  <light id="1" name="bulb" type="point" shape="point" distribution="uniform" visible="1"><intensity><color val="1 0.8 0.6" /><multiplier val="40.0" /></intensity></light>'
                   '\n  <light id="2" name="spot" type="point" shape="point" distribution="spot" visible="1"><falloff_angle val="70" /><falloff_angle2 val="40" />'
                   '<intensity><color val="0.7 0.8 1" /><multiplier val="90.0" /></intensity></light>'
@@ -435,6 +485,10 @@ def main():
                   '<intensity><color val="1 0.88 0.72" /><multiplier val="25.0" /></intensity></light>'
                   '\n  <light id="5" name="lamp" type="area" shape="mesh" distribution="uniform" visible="1" mat_id="13" mesh_id="%d">'
                   '<intensity><color val="0.6 0.8 1" /><multiplier val="30.0" /></intensity></light>' % (globe_mesh or 0, lamp_mesh or 0) if args.delta_lights else '')
+               + ('\n  <light id="2" name="portal" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="12" mesh_id="%d"><size half_length="8.0" half_width="4.0" />'
+                  '<intensity><color val="1 1 1" /><multiplier val="1.0" /></intensity><sky_portal val="1" source_id="1" /></light>'
+                  '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
+                  '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>' % portal_mesh if args.portal else '')
                + '\n</lights_lib>')
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
@@ -488,6 +542,15 @@ def main():
     if args.delta_lights:
         add(globe_mesh, globe_m, ' light_id="4" linst_id="4"')
         add(lamp_mesh, lamp_m, ' light_id="5" linst_id="5"')
+    tube_m = mat4(yaw=0.6, t=(-6.0, 6.5, 1.0), rot_x=0.2)
+    half_tube_m = mat4(scale=1.3, yaw=-0.4, t=(7.0, 1.2, -3.0), rot_x=1.2)
+    portal_m = mat4(t=(0.0, 10.0, 0.0))
+    if args.tube_lights:
+        add(tube_mesh, tube_m, ' light_id="1" linst_id="1"')
+        add(half_tube_mesh, half_tube_m, ' light_id="2" linst_id="2"')
+        add(tlamp_mesh, lamp_m, ' light_id="3" linst_id="3"')
+    if args.portal:
+        add(portal_mesh, portal_m, ' light_id="2" linst_id="2"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
     xml.append('    <instance_light id="0" light_id="0" matrix="%s" lgroup_id="-1" />' % light_m)
     if args.sky:
@@ -500,6 +563,13 @@ def main():
         xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
         xml.append('    <instance_light id="4" light_id="4" matrix="%s" lgroup_id="-1" />' % globe_m)
         xml.append('    <instance_light id="5" light_id="5" matrix="%s" lgroup_id="-1" />' % lamp_m)
+    if args.tube_lights:
+        xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % tube_m)
+        xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % half_tube_m)
+        xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % lamp_m)
+    if args.portal:
+        xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % portal_m)
+        xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
     xml += inst
     xml.append("  </scene>\n</scenes>")
     with open(os.path.join(out, "statex_00001.xml"), "w") as f:
