@@ -52,7 +52,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_comm_unique_id", "hydra_hip_comm_init", "hydra_hip_comm_gather_frame", "hydra_hip_comm_reduce_frame", "hydra_hip_comm_destroy",
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
-    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bake_energy_tables", "hydra_hip_bake_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_last_error",
+    "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bake_energy_tables", "hydra_hip_bake_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_build_mesh_ex", "hydra_hip_bvh_last_error",
 ]
 
 _hip = None
@@ -137,6 +137,7 @@ def load_hip_library():
         "hydra_hip_sbdpt_get_image": ([vp, vp, i32, i32, vp], i32),
         "hydra_hip_eval_gbuffer": ([vp, vp, vp, i32, i32, vp, i32, vp], i32),
         "hydra_hip_bvh_build_mesh": ([i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+        "hydra_hip_bvh_build_mesh_ex": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_bvh_last_error": ([], C.c_char_p),
         "hydra_hip_normal_map_from_displacement": ([i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, vp], i32),
         "hydra_hip_bake_energy_tables": ([i32, vp, vp, vp], i32),
@@ -232,14 +233,14 @@ def _f4(a, n):
 BUILD_NODE_DTYPE = np.dtype([("boxMin", np.float32, 3), ("first", np.int32), ("boxMax", np.float32, 3), ("count", np.int32), ("child", np.int32, 4)])
 
 
-def bvh_build_mesh(vert4f, indices, leaf_max=2, device=0):
-    """GPU LBVH build of one mesh (hydra_hip_bvh_build_mesh): -> (nodes (BUILD_NODE_DTYPE), triangle order, device ms)"""
+def bvh_build_mesh(vert4f, indices, leaf_max=2, device=0, method="ploc", radius=128):
+    """GPU build of one mesh (hydra_hip_bvh_build_mesh_ex; method "ploc" or "lbvh"): -> (nodes (BUILD_NODE_DTYPE), triangle order, device ms)"""
     lib = load_hip_library()
     v, idx = np.ascontiguousarray(vert4f, np.float32).reshape(-1, 4), np.ascontiguousarray(indices, np.int32).ravel()
     tri = idx.size // 3
     nodes, order = np.zeros(2 * tri, BUILD_NODE_DTYPE), np.zeros(tri, np.int32)
     nn, npr, ms = C.c_int32(0), C.c_int32(0), C.c_float(0)
-    rc = lib.hydra_hip_bvh_build_mesh(device, _ptr(v), len(v), _ptr(idx), idx.size, leaf_max, _ptr(nodes), C.byref(nn), _ptr(order), C.byref(npr), C.byref(ms))
+    rc = lib.hydra_hip_bvh_build_mesh_ex(device, _ptr(v), len(v), _ptr(idx), idx.size, leaf_max, {"lbvh": 0, "ploc": 1}[method], radius, _ptr(nodes), C.byref(nn), _ptr(order), C.byref(npr), C.byref(ms))
     if rc != 0:
         raise HydraError("bvh_build_mesh failed (%d): %s" % (rc, lib.hydra_hip_bvh_last_error().decode()))
     return nodes[:nn.value].copy(), order[:npr.value].copy(), ms.value

@@ -196,8 +196,11 @@ void BVH4Builder::CommitScene() {
       std::vector<int32_t> order(static_cast<size_t>(triNum));
       int32_t nodeCount = 0, primCount = 0;
       float ms = 0.0f;
-      const int rc = hydra_hip_bvh_build_mesh(gpuBuildDevice, mesh.vert4f.data(), int(mesh.vert4f.size() / 4), mesh.indices.data(), int(mesh.indices.size()), leafMax,
-                                              gn.data(), &nodeCount, order.data(), &primCount, &ms);
+      int method = HYDRA_BVH_PLOC, radius = 128;                                     // A/B switches: HYDRA_GPU_BVH_METHOD=lbvh|ploc, HYDRA_GPU_BVH_RADIUS=1..128
+      if (const char* e = getenv("HYDRA_GPU_BVH_METHOD")) method = (std::string(e) == "lbvh") ? HYDRA_BVH_LBVH : HYDRA_BVH_PLOC;
+      if (const char* e = getenv("HYDRA_GPU_BVH_RADIUS")) radius = std::max(1, std::min(128, atoi(e)));
+      const int rc = hydra_hip_bvh_build_mesh_ex(gpuBuildDevice, mesh.vert4f.data(), int(mesh.vert4f.size() / 4), mesh.indices.data(), int(mesh.indices.size()), leafMax, method, radius,
+                                                 gn.data(), &nodeCount, order.data(), &primCount, &ms);
       if (rc != HYDRA_HIP_OK) RunTimeError(std::string("BVH4Builder::CommitScene: GPU build failed: ") + hydra_hip_bvh_last_error());
       statGpuBuildMs += ms;
       const int nodeBase = int(m_nodes.size()), primBase = int(m_primIds.size());

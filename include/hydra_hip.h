@@ -229,7 +229,7 @@ int hydra_hip_stage_camera_connect(hydra_hip_handle h, int n, const float* pos4,
 int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* values, const float* rands2, float p2, float p1, float* out);
 /* ---- GPU-side BVH build (row f2).  The reference builds through IBVHBuilder2 (hydra_drv/IBVHBuilderAPI.h:35-68: InstanceTriangleMeshes /
  * CommitScene / ConvertMap, Embree 2.17 behind it); this entry builds the tree of ONE mesh on the device -- Morton codes, a hand-written stable
- * radix sort, the binary radix tree of Karras 2012, bottom-up boxes, level-synchronous collapse to 4-wide nodes with leaves of <= leaf_max
+ * radix sort, a binary tree over the sorted triangles (see hydra_hip_bvh_build_mesh_ex), level-synchronous collapse to 4-wide nodes with leaves of <= leaf_max
  * triangles -- and returns it in build form: node 0 is the root; an inner node has count == 0 and up to four children (-1 = none), a leaf owns
  * prim_order[first .. first + count).  Degenerate triangles are dropped (bvh_access_dll2.cpp:354-355).  Emission into the reference's quad /
  * triangle-list layout (ConvertMap, bvh_access_dll2.cpp:604-717) is the host builder's (hydracore_amd/host/bvh4_builder.cpp), which its own
@@ -237,6 +237,13 @@ int hydra_hip_stage_mutate_kelemen(hydra_hip_handle h, int n, const float* value
 typedef struct HydraBuildNode { float boxMin[3]; int32_t first; float boxMax[3]; int32_t count; int32_t child[4]; } HydraBuildNode;
 int hydra_hip_bvh_build_mesh(int device, const float* vert4f, int num_vert, const int32_t* indices, int num_indices, int leaf_max,
                              HydraBuildNode* nodes_out, int32_t* node_count_out, int32_t* prim_order_out, int32_t* prim_count_out, float* build_ms_out);
+/* The same with the way the binary tree under the collapse is made chosen: HYDRA_BVH_LBVH = the binary radix tree of the Morton codes alone (Karras
+ * 2012); HYDRA_BVH_PLOC (what hydra_hip_bvh_build_mesh uses, radius 128) = parallel locally-ordered clustering over the Morton order (Meister & Bittner
+ * 2018): every round each cluster merges with the neighbour within `radius` places whose union with it has the smallest surface area, if that neighbour
+ * chose it too.  radius 1..128 (larger: better trees, slower build). */
+enum { HYDRA_BVH_LBVH = 0, HYDRA_BVH_PLOC = 1 };
+int hydra_hip_bvh_build_mesh_ex(int device, const float* vert4f, int num_vert, const int32_t* indices, int num_indices, int leaf_max, int method, int radius,
+                                HydraBuildNode* nodes_out, int32_t* node_count_out, int32_t* prim_order_out, int32_t* prim_count_out, float* build_ms_out);
 const char* hydra_hip_bvh_last_error(void);
 /* IHWLayer::NormalMapFromDisplacement (hydra_drv/IHWLayer.h:197; host form CPUSharedData::NormalMapFromDisplacement + BilateralFilter,
  * CPUBilateralFilter2D.cpp:15-246; GPUOCLLayer's kernels GPUOCLData.cpp:549-640): the RGBA8 height map of a <displacement type="height_bump"> becomes

@@ -506,7 +506,7 @@ def _check_build_tree(nodes, order, verts, idx, leaf_max):
 
 
 def test_gpu_bvh_builder_structure(built):
-    """row f2: hydra_hip_bvh_build_mesh (Morton codes, radix sort, Karras hierarchy, refit, collapse to 4-wide) on synthetic meshes with
+    """row f2: hydra_hip_bvh_build_mesh_ex (Morton codes, radix sort, PLOC clustering or the Karras hierarchy, collapse to 4-wide) on synthetic meshes with
     duplicated centroids, degenerate triangles, one and two triangles, and a 200 k-triangle height field"""
     from hydracore_amd.capi import bvh_build_mesh
     rng = np.random.default_rng(3)
@@ -517,12 +517,14 @@ def test_gpu_bvh_builder_structure(built):
     idx[100:200] = idx[0:100]                                                    # duplicates: equal Morton codes, the index tie-break of the hierarchy
     idx[300:320, 2] = idx[300:320, 1]                                            # degenerate: dropped
     for leaf_max in (1, 2, 4):
-        nodes, order, ms = bvh_build_mesh(verts, idx, leaf_max)
-        _check_build_tree(nodes, order, verts, idx.ravel(), leaf_max)
+        for method, radius in (("ploc", 100), ("ploc", 1), ("ploc", 128), ("lbvh", 16)):
+            nodes, order, ms = bvh_build_mesh(verts, idx, leaf_max, method=method, radius=radius)
+            _check_build_tree(nodes, order, verts, idx.ravel(), leaf_max)
     # (b) one triangle, two triangles
-    for t in (1, 2):
-        nodes, order, ms = bvh_build_mesh(verts, idx[:t], 2)
-        _check_build_tree(nodes, order, verts, idx[:t].ravel(), 2)
+    for t in (1, 2, 3):
+        for method in ("ploc", "lbvh"):
+            nodes, order, ms = bvh_build_mesh(verts, idx[:t], 2, method=method)
+            _check_build_tree(nodes, order, verts, idx[:t].ravel(), 2)
     # (c) a regular grid (many equal coordinates) of 200 k triangles: timing is printed for the log
     n = 317
     gx, gz = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32))
@@ -530,9 +532,15 @@ def test_gpu_bvh_builder_structure(built):
     gv[:, 0], gv[:, 2], gv[:, 1] = gx.ravel(), gz.ravel(), np.sin(gx.ravel() * 0.1) * np.cos(gz.ravel() * 0.07)
     q = (np.arange(n - 1)[:, None] * n + np.arange(n - 1)[None, :]).ravel()
     gi = np.concatenate([np.stack([q, q + 1, q + n], 1), np.stack([q + 1, q + n + 1, q + n], 1)]).astype(np.int32)
-    nodes, order, ms = bvh_build_mesh(gv, gi, 2)
-    _check_build_tree(nodes, order, gv, gi.ravel(), 2)
-    print("GPU LBVH: %d triangles in %.3f ms of device time (%.1f Mtris/s), %d nodes" % (len(gi), ms, len(gi) / ms / 1e3, len(nodes)))
+    for method in ("lbvh", "ploc"):
+        bvh_build_mesh(gv, gi, 2, method=method)                                  # first call: code load
+        nodes, order, ms = bvh_build_mesh(gv, gi, 2, method=method)
+        _check_build_tree(nodes, order, gv, gi.ravel(), 2)
+        inner = nodes["count"] == 0
+        ext = nodes["boxMax"] - nodes["boxMin"]
+        area = 2 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0])
+        sah = (area[inner].sum() * 1.0 + (area[~inner] * nodes["count"][~inner]).sum()) / area[0]   # expected quad visits + triangle tests of a random ray
+        print("GPU %s: %d triangles in %.3f ms of device time (%.1f Mtris/s), %d nodes, SAH cost %.1f" % (method, len(gi), ms, len(gi) / ms / 1e3, len(nodes), sah))
     with pytest.raises(RuntimeError):
         bvh_build_mesh(verts, np.array([[0, 1, 3000]], np.int32), 2)             # vertex index out of range
 
