@@ -18,8 +18,17 @@ HK_DEV f3 UniformSampleSphere(float u1, float u2) {   // cglobals.h:1160-1168
 HK_DEV f3 lightMatrixMul(const float* M, f3 v) {   // matrix3x3f_mult_float3, row-major 3x3
   return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
 }
-// clight.h:654-719 (no IES: refused at upload)
-HK_DEV void AreaLightSampleForward(const SceneDev& s, const float* L, float4 rands, LightSampleFwd& out) {
+// LightSampleIESSphere, clight.h:411-426: a direction drawn from the photometric web's 2-D table, turned into world space by the inverse IES matrix
+HK_DEV void LightSampleIESSphere(const SceneDev& s, const float* L, f3 rands, f3& outDir, float& outPdfW) {
+  const float* hdr = pdfTableHeader(s, as_int(L[HL_IES_SPHERE_PDF_ID]));
+  const Map2DSample sample = sampleMap2D(rands, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+  float sinTheta = 0.0f;
+  const f3 lsDir = texCoord2DToSphereMap(sample.texCoord, sinTheta);
+  outDir = normalize(lightMatrixMul3(L + HL_IES_INV_MATRIX, lsDir));
+  outPdfW = HK_INV_PI * HK_INV_PI * 0.5f * (sample.mapPdf / fmaxf(fabsf(sinTheta), HK_DEPSILON2));
+}
+// clight.h:654-719
+HK_DEV void AreaLightSampleForward(const SceneDev& s, const float* L, float4 rands, float rands2x, LightSampleFwd& out) {
   const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
   f3 samplePos = mk3(offsetX * L[HL_AREA_SIZE_X], 0.0f, offsetY * L[HL_AREA_SIZE_Y]);
   if (as_int(L[HL_AREA_IS_DISK]) != 0) {
@@ -27,17 +36,21 @@ HK_DEV void AreaLightSampleForward(const SceneDev& s, const float* L, float4 ran
     samplePos = mk3(d.x * L[HL_AREA_SIZE_X], 0.0f, d.y * L[HL_AREA_SIZE_X]);
   }
   samplePos = lightMatrixMul(L + HL_AREA_MATRIX, samplePos) + lightPos(L);
-  const f3 lnorm = lightNorm(L);
+  if (as_int(L[HL_FLAGS]) & HLF_IES_POINT_AREA) samplePos = lightPos(L);
+  f3 lnorm = lightNorm(L);
   f3 sampleDir = MapSampleToCosineDistribution(rands.z, rands.w, lnorm, lnorm, 1.0f);
   float cosTheta = fmaxf(dot(sampleDir, lnorm), 0.0f);
   float pdfW = cosTheta * HK_INV_PI;
-  if (as_int(L[HL_AREA_SPOT_DISTR]) != 0) {
+  if (as_int(L[HL_FLAGS]) & HLF_HAS_IES) {
+    LightSampleIESSphere(s, L, mk3(rands.z, rands.w, rands2x), sampleDir, pdfW);
+    lnorm = dot(lnorm, sampleDir) > 0.0f ? lnorm : lnorm * (-1.0f);
+  } else if (as_int(L[HL_AREA_SPOT_DISTR]) != 0) {
     const float cos2 = L[HL_AREA_SPOT_COS2];
     sampleDir = MapSamplesToCone(cos2, mk2(rands.z, rands.w), lnorm);
     pdfW = 1.0f / (2.0f * HK_PI * (1.0f - cos2));
   }
   cosTheta = fmaxf(dot(sampleDir, lnorm), 0.0f);
-  const f3 color = (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL) ? areaLightSkyPortalCustomColor<HK_FEAT_ALL>(s, L, sampleDir * (-1.0f)) : areaDiffuseLightGetIntensity(L, sampleDir * (-1.0f), false);
+  const f3 color = (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL) ? areaLightSkyPortalCustomColor<HK_FEAT_ALL>(s, L, sampleDir * (-1.0f)) : areaLightIntensity<HK_FEAT_ALL>(s, L, sampleDir * (-1.0f), false);
   out.isPoint = false;
   out.pos = samplePos + lnorm * epsilonOfPos(samplePos);
   out.dir = sampleDir;
@@ -47,15 +60,19 @@ HK_DEV void AreaLightSampleForward(const SceneDev& s, const float* L, float4 ran
   out.cosTheta = cosTheta;
   out.norm = lnorm;
 }
-HK_DEV void PointLightSampleForward(const float* L, float4 rands, LightSampleFwd& out) {   // clight.h:838-862, no IES
-  const f3 sampleDir = UniformSampleSphere(rands.x, rands.y);
+HK_DEV void PointLightSampleForward(const SceneDev& s, const float* L, float4 rands, LightSampleFwd& out) {   // clight.h:838-862
+  float pdfW = HK_INV_PI * 0.25f;
+  f3 sampleDir = UniformSampleSphere(rands.x, rands.y);
+  const bool ies = (as_int(L[HL_FLAGS]) & HLF_HAS_IES) != 0;
+  if (ies) LightSampleIESSphere(s, L, mk3(rands.x, rands.y, rands.z), sampleDir, pdfW);
   const f3 samplePos = lightPos(L);
+  const float mask = ies ? lightDistributionMask(s, L, sampleDir * (-1.0f)) : 1.0f;
   out.isPoint = true;
   out.pos = samplePos + sampleDir * epsilonOfPos(samplePos);
   out.dir = sampleDir;
-  out.color = lightColor(L) * (1.0f / L[HL_SURFACE_AREA]);   // pointLightGetIntensity without IES = the base colour
+  out.color = (mk3(mask, mask, mask) * lightColor(L)) * (1.0f / L[HL_SURFACE_AREA]);   // pointLightGetIntensity: the base colour without IES
   out.pdfA = 1.0f / L[HL_SURFACE_AREA];
-  out.pdfW = HK_INV_PI * 0.25f;
+  out.pdfW = pdfW;
   out.cosTheta = 1.0f;
   out.norm = sampleDir;
 }
@@ -151,12 +168,12 @@ HK_DEV void LightSampleForward(const SceneDev& s, const float* L, float4 rands, 
     case HLT_SPHERE: SphereLightSampleForward(L, rands, out); break;
     case HLT_DIRECT: DirectLightSampleForward(L, rands, out); break;
     case HLT_POINT_SPOT: PointSpotSampleForward(L, rands, out); break;
-    case HLT_POINT_OMNI: PointLightSampleForward(L, rands, out); break;
-    default: AreaLightSampleForward(s, L, rands, out); break;
+    case HLT_POINT_OMNI: PointLightSampleForward(s, L, rands, out); break;
+    default: AreaLightSampleForward(s, L, rands, rands2x, out); break;
   }
 }
-// lightPdfFwd, clight.h:1117-1175 (no IES)
-HK_DEV LightPdfFwd lightPdfFwd(const float* L, float cosTheta) {
+// lightPdfFwd, clight.h:1117-1175
+HK_DEV LightPdfFwd lightPdfFwd(const SceneDev& s, const float* L, f3 ray_dir, float cosTheta) {
   LightPdfFwd res;
   res.pdfA = 1.0f / L[HL_SURFACE_AREA];
   res.pdfW = fmaxf(cosTheta * HK_INV_PI, 0.0f);
@@ -172,7 +189,14 @@ HK_DEV LightPdfFwd lightPdfFwd(const float* L, float cosTheta) {
     res.pdfA = 1.0f / (HK_PI * radius2 * radius2);
     res.pdfW = 0.0f;
   }
-  if (ltype == HLT_AREA && as_int(L[HL_AREA_SPOT_DISTR]) != 0) {
+  if (as_int(L[HL_FLAGS]) & HLF_HAS_IES) {
+    const f3 rayDir = lightMatrixMul3(L + HL_IES_LIGHT_MATRIX, ray_dir);
+    const float* hdr = pdfTableHeader(s, as_int(L[HL_IES_SPHERE_PDF_ID]));
+    float sintheta = 0.0f;
+    const f2 tc = sphereMapTo2DTexCoord(rayDir * (-1.0f), sintheta);
+    const float mapPdf = evalMap2DPdf(tc, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+    res.pdfW = mapPdf / (2.f * HK_PI * HK_PI * fmaxf(sintheta, HK_DEPSILON2));
+  } else if (ltype == HLT_AREA && as_int(L[HL_AREA_SPOT_DISTR]) != 0) {
     const float cos2 = L[HL_AREA_SPOT_COS2];
     res.pdfW = 1.0f / (2.0f * HK_PI * (1.0f - cos2));
     if (cosTheta < cos2) res.pdfW = 0.0f;
@@ -407,7 +431,7 @@ HK_DEV bool mmltCameraStep(const SceneDev& s, const MmltView& v, int i, int curr
     const bool splitDL = g_varsI(s)[HV_I_MMLT_FIRST_BOUNCE] > 3;   // m_splitDLByGrammar, Common.cpp:28
     if (dot(emission, emission) > 1e-6f) {
       if (currDepth == camTraceDepth && haveToHitLight && pLight != nullptr) {
-        const LightPdfFwd lp = lightPdfFwd(pLight, cosHere);
+        const LightPdfFwd lp = lightPdfFwd(s, pLight, ray_dir, cosHere);
         const float pdfLightWP = lp.pdfW / fmaxf(cosHere, HK_DEPSILON);
         const float pdfMatRevWP = misPdf / fmaxf(cosPrev, HK_DEPSILON);
         mpdfFwd(v, 0, i) = lp.pdfA / float(s.hdr[HG_LIGHTS_NUM]);
@@ -625,7 +649,7 @@ HK_DEV void mmltConnectEnd(const SceneDev& s, const MmltView& v, int i) {
         const float pdfRevWP = ev.pdfFwd / fmaxf(cosThetaOut, HK_DEPSILON);
         const float shadowDist = length(cv.pos - c.sam.pos);
         const float GTerm = cosThetaOut * cosAtLight / fmaxf(shadowDist * shadowDist, HK_DEPSILON2);
-        const LightPdfFwd lp = lightPdfFwd(pLight, cosAtLight);
+        const LightPdfFwd lp = lightPdfFwd(s, pLight, c.dir, cosAtLight);
         mpdfFwd(v, 0, i) = lp.pdfA * c.pick;
         mpdfRev(v, 0, i) = 1.0f;
         mpdfFwd(v, 1, i) = (lp.pdfW / cosAtLight) * GTerm;

@@ -1386,6 +1386,8 @@ HK_DEV f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, bool eyeRay) {
 struct ShadowSample { f3 pos, color; float pdf, maxDist, cosAtLight; bool isPoint; };   // cglobals.h:2448-2456
 // sky portals (AREA_LIGHT_SKY_PORTAL): an area light whose colour is multiplied by what the sky light it names shows in the ray's direction; defined below, after the sky
 template <int F> HK_DEV f3 areaLightSkyPortalCustomColor(const SceneDev& s, const float* L, f3 rayDir);
+// an area light with an IES distribution (LIGHT_HAS_IES): the colour is scaled by the photometric table in the ray's direction; defined below, after the table helpers
+template <int F> HK_DEV f3 areaLightIntensity(const SceneDev& s, const float* L, f3 rayDir, bool eyeRay);
 template <int F>
 HK_DEV void AreaLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum, ShadowSample& out) {   // clight.h:1180-1229
   const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
@@ -1403,7 +1405,8 @@ HK_DEV void AreaLightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 i
   out.isPoint = false;
   out.pos = sp + ln * epsilonOfPos(sp);
   if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL)) out.color = areaLightSkyPortalCustomColor<F>(s, L, rayDir);
-  else out.color = areaDiffuseLightGetIntensity(L, rayDir, false);
+  else if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_IES_POINT_AREA)) out.color = areaLightIntensity<F>(s, L, normalize(lightPos(L) - illum), false);   // the table is read from the light's centre (:1215-1217)
+  else out.color = areaLightIntensity<F>(s, L, rayDir, false);
   out.pdf = areaDiffuseLightEvalPDF(L, rayDir, hitDist);
   out.maxDist = hitDist;
   out.cosAtLight = -dot(rayDir, ln);
@@ -1482,6 +1485,43 @@ HK_DEV float skyLightEvalPDF(const SceneDev& s, const float* L, f3 rayDir) {   /
   const f2 tcT = mk2(r0[0] * tc.x + r0[1] * tc.y + r0[3], r0[4] * tc.x + r0[5] * tc.y + r0[7]);   // mul2x4, cfetch.h:642-648
   const float mapPdf = evalMap2DPdf(tcT, hdr + 4, sizeX, sizeY);
   return (mapPdf * 1.0f) / (2.f * HK_PI * HK_PI * fmaxf(fabsf(sintheta), HK_DEPSILON));
+}
+// ---- IES distributions (clight.h:405-426, 465-495; cfetch.h:364-462): the photometric web as a one-channel float lat-long image in the pdf arena
+// ({w, h, 1, 4} + w * h floats, RenderDriverRTE_PdfTables.cpp:385-478) and a 2-D sampling table over the same pixels
+HK_DEV float read_imagef_sw1(const float4* tex, f2 tc, int flags) {   // the float (bpp == 4) branch; IES images are never 8-bit
+  const int4 header = *reinterpret_cast<const int4*>(tex);
+  const int w = header.x, h = header.y;
+  float ffx = tc.x * float(w) - 0.5f, ffy = tc.y * float(h) - 0.5f;
+  if ((flags & HTEX_CLAMP_U) != 0 && ffx < 0) ffx = 0.0f;
+  if ((flags & HTEX_CLAMP_V) != 0 && ffy < 0) ffy = 0.0f;
+  const float* fdata = reinterpret_cast<const float*>(tex + 1);
+  const int px = int(ffx), py = int(ffy);
+  const float fx = fabsf(ffx - float(px)), fy = fabsf(ffy - float(py));
+  const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+  const float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+  const int4 offs = bilinearOffsets(ffx, ffy, flags, w, h);
+  return ((fdata[offs.x] * w1 + fdata[offs.y] * w2) + fdata[offs.z] * w3) + fdata[offs.w] * w4;
+}
+HK_DEV f3 lightMatrixMul3(const float* M, f3 v) {   // matrix3x3f_mult_float3, cglobals.h:1091-1098
+  return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
+}
+HK_DEV float lightDistributionMask(const SceneDev& s, const float* L, f3 rayDir) {   // clight.h:465-484, for a light that has the table (1 otherwise)
+  rayDir = normalize(lightMatrixMul3(L + HL_IES_LIGHT_MATRIX, rayDir));
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(rayDir * (-1.0f), sintheta);
+  const float4* tex = s.pdfStorage + s.globals[s.hdr[HG_PDF_TABLE_OFFS] + as_int(L[HL_IES_SPHERE_TEX_ID])];
+  return read_imagef_sw1(tex, tc, HTEX_CLAMP_U | HTEX_CLAMP_V);
+}
+template <int F>
+HK_DEV f3 areaLightIntensity(const SceneDev& s, const float* L, f3 rayDir, bool eyeRay) {   // areaDiffuseLightGetIntensity with its IES branch (clight.h:563-577)
+  if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_HAS_IES)) {
+    f3 color = lightColor(L);
+    const float atten = lightDistributionMask(s, L, rayDir);
+    if (!eyeRay) color = color * atten;
+    else color = color * (1.0f / fmaxf(color.x, fmaxf(color.y, color.z)));
+    return color;
+  }
+  return areaDiffuseLightGetIntensity(L, rayDir, eyeRay);
 }
 // ---- Perez all-weather sky (Preetham's fit), clight.h:178-282: zenith colour in Yxy, the distribution function, Yxy -> linear RGB,
 // and the sun disc blended in over the last 0.05-0.15 % of the cosine
@@ -1586,12 +1626,15 @@ HK_DEV float mylocalsmoothstep(float edge0, float edge1, float x) {   // clight.
   return t * t * (3.0f - 2.0f * t);
 }
 HK_DEV float PdfAtoW(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / fmaxf(aCosThere, HK_DEPSILON2); }   // cglobals.h:1754-1757
-HK_DEV void PointLightSampleRev(const float* L, f3 illum, ShadowSample& out) {   // clight.h:1394-1407; lightDistributionMask = 1 without IES (:465-484)
+template <int F = HK_FEAT_ALL>
+HK_DEV void PointLightSampleRev(const SceneDev& s, const float* L, f3 illum, ShadowSample& out) {   // clight.h:1394-1407; lightDistributionMask = 1 without IES (:465-484)
   const f3 samplePos = lightPos(L);
   const float hitDist = length(samplePos - illum);
   out.isPoint = true;
   out.pos = samplePos;
-  out.color = mk3(1.0f, 1.0f, 1.0f) * lightColor(L);
+  float mask = 1.0f;
+  if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_HAS_IES)) mask = lightDistributionMask(s, L, normalize(samplePos - illum));
+  out.color = mk3(mask, mask, mask) * lightColor(L);
   out.pdf = PdfAtoW(1.0f, hitDist, 1.0f);
   out.maxDist = hitDist;
   out.cosAtLight = 1.0f;
@@ -1803,7 +1846,7 @@ HK_DEV void LightSampleRev(const SceneDev& s, const float* L, f3 rands, f3 illum
   if ((F & HK_FEAT_SKY) && type == HLT_SKY_DOME) SkyLightSampleRev(s, L, rands, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_DIRECT) DirectLightSampleRev(L, rands, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_SPOT) SpotLightSampleRev(L, illum, out);
-  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev(L, illum, out);
+  else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_POINT_OMNI) PointLightSampleRev<F>(s, L, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_SPHERE) SphereLightSampleRev(L, rands, illum, out);
   else if ((F & HK_FEAT_DELTA_LIGHTS) && type == HLT_MESH) MeshLightSampleRev<F>(s, L, rands, illum, out);
   else if ((F & HK_FEAT_RARE_LIGHTS) && type == HLT_CYLINDER) CylinderLightSampleRev(s, L, rands, illum, out);
@@ -1871,7 +1914,9 @@ HK_DEV f3 lightGetIntensity(const SceneDev& s, const float* L, f3 ray_pos, f3 ra
     return areaLightSkyPortalCustomColor<F>(s, L, ray_dir);
   }
   if (type == HLT_AREA) {
-    f3 color = areaDiffuseLightGetIntensity(L, ray_dir, (flags & 0xFFu) == 0);
+    f3 customDir = ray_dir;
+    if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_IES_POINT_AREA)) customDir = normalize(lightPos(L) - ray_pos);
+    f3 color = areaLightIntensity<F>(s, L, customDir, (flags & 0xFFu) == 0);
     if ((F & HK_FEAT_RARE_LIGHTS) && (as_int(L[HL_FLAGS]) & HLF_SKY_PORTAL)) color = color * portalSkyColor<F>(s, L, ray_dir);
     return color;
   }

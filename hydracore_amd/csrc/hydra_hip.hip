@@ -331,7 +331,7 @@ __global__ void k_stage_light_fwd(SceneDev s, int n, const int* __restrict__ lig
 __global__ void k_stage_light_pdf_fwd(SceneDev s, int n, const int* __restrict__ lightIds, const float* __restrict__ cosTheta, float4* __restrict__ out4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const LightPdfFwd p = lightPdfFwd(lightAt(s, lightIds[i]), cosTheta[i]);
+  const LightPdfFwd p = lightPdfFwd(s, lightAt(s, lightIds[i]), mk3(0.0f, 0.0f, 1.0f), cosTheta[i]);   // the direction the reference-side fixture hands in
   out4[i] = make_float4(p.pdfA, p.pdfW, p.pickProb, 0.0f);
 }
 __global__ void k_stage_camera_connect(SceneDev s, int n, const float4* __restrict__ pos4, const float4* __restrict__ norm4, const float2* __restrict__ disk2, float* __restrict__ out8) {
@@ -1223,8 +1223,14 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (type == HLT_SKY_DOME) lightFeat |= HK_FEAT_SKY;
     if (type == HLT_SKY_DOME && (blob[at + HL_FLAGS] & HLF_SKY_USE_PEREZ)) lightFeat |= HK_FEAT_PEREZ;   // only the all-features instantiation carries the model
     if (type == HLT_POINT_OMNI || type == HLT_POINT_SPOT || type == HLT_DIRECT || type == HLT_SPHERE || type == HLT_MESH || type == HLT_CYLINDER) lightFeat |= HK_FEAT_DELTA_LIGHTS;   // the bit stands for "lights other than area and sky"
-    if (blob[at + HL_FLAGS] & HLF_HAS_IES)
-      return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution, which the HIP layer does not implement");
+    if (blob[at + HL_FLAGS] & HLF_HAS_IES) {   // point and area lights carry a photometric web: an image and a sampling table in the pdf arena
+      if (type != HLT_POINT_OMNI && type != HLT_AREA)
+        return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " has an IES distribution on a light type that has none in the reference");
+      const int tex = blob[at + HL_IES_SPHERE_TEX_ID], tab = blob[at + HL_IES_SPHERE_PDF_ID];
+      if (tex < 0 || tex >= blob[HG_PDF_TABLE_SIZE] || tab < 0 || tab >= blob[HG_PDF_TABLE_SIZE])
+        return fail(c, HYDRA_HIP_EINVAL, "upload_globals: IES light " + std::to_string(i) + " names tables outside the pdf-table table");
+      lightFeat |= HK_FEAT_RARE_LIGHTS;
+    }
   }
   if (blob[HG_SUN_NUMBER] < 0 || blob[HG_SUN_NUMBER] > 8) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: sunNumber outside 0..8 (MAX_SUN_NUM, cfetch.h:18)");
   c->lightFeatures = lightFeat;

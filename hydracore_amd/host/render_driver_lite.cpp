@@ -663,11 +663,176 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   return true;
 }
 
+// ---- IES photometric webs.  The reference reads the file through Ian Ashdown's IESNA.C (hydra_drv/utils/ies_parser/IESNA.H, IESRender.cpp:19-36), which is not
+// part of the reference tree; what follows reads the published IESNA LM-63 (1986/1991/1995) layout directly: label / keyword lines up to "TILT=", an optional
+// TILT=INCLUDE block, then free-format numbers -- lamps, lumens, candela multiplier, number of vertical and horizontal angles, photometric type, units,
+// width, length, height; ballast factor, ballast-lamp factor, input watts; the vertical angles; the horizontal angles; per horizontal angle the candela
+// values over the vertical angles (pcandela[horz][vert] in IESNA.C, raw as in the file).  Parity of the reader is unpinned: the reference tree holds no .ies file.
+struct IesData { std::vector<float> vert, horz; std::vector<std::vector<float>> candela; };
+static bool read_ies_file(const std::string& path, IesData& out) {
+  std::vector<char> raw;
+  if (!read_file(path, raw)) return false;
+  const std::string text(raw.begin(), raw.end());
+  size_t at = text.find("TILT=");
+  if (at == std::string::npos) return false;
+  const size_t eol = text.find('\n', at);
+  const std::string tilt = text.substr(at + 5, (eol == std::string::npos ? text.size() : eol) - at - 5);
+  std::vector<double> num;
+  {
+    std::string rest = (eol == std::string::npos) ? std::string() : text.substr(eol + 1);
+    for (char& ch : rest) if (ch == ',') ch = ' ';
+    std::istringstream is(rest);
+    double v;
+    while (is >> v) num.push_back(v);
+  }
+  size_t k = 0;
+  if (tilt.find("INCLUDE") != std::string::npos) {   // lamp-to-luminaire geometry, number of pairs, angles, multiplying factors: not used by the renderer
+    if (num.size() < 2) return false;
+    const size_t pairs = size_t(num[1]);
+    k = 2 + 2 * pairs;
+  }
+  if (num.size() < k + 13) return false;
+  const int nV = int(num[k + 3]), nH = int(num[k + 4]);
+  k += 13;
+  if (nV <= 0 || nH <= 0 || num.size() < k + size_t(nV) + size_t(nH) + size_t(nV) * size_t(nH)) return false;
+  out.vert.assign(num.begin() + k, num.begin() + k + nV); k += size_t(nV);
+  out.horz.assign(num.begin() + k, num.begin() + k + nH); k += size_t(nH);
+  out.candela.assign(size_t(nH), std::vector<float>(size_t(nV)));
+  for (int h = 0; h < nH; h++)
+    for (int v = 0; v < nV; v++) out.candela[size_t(h)][size_t(v)] = float(num[k++]);
+  return true;
+}
+// CreateSphericalTextureFromIES, hydra_drv/IESRender.cpp:29-200: the web as a lat-long image (x: phi 0..360, y: theta 0..180), mirrored into the quadrants the file leaves out
+static std::vector<float> spherical_texture_from_ies(const IesData& ies, int& w, int& h) {
+  const float PI = 3.14159265358979323846f, INV_PI_F = 1.0f / PI, D2R = PI / 180.0f;
+  const int nV = int(ies.vert.size()), nH = int(ies.horz.size());
+  const float verticalStart = ies.vert[0], verticalEnd = ies.vert[size_t(nV) - 1];
+  const float horizontStart = ies.horz[0];
+  float horizontEnd = ies.horz[size_t(nH) - 1];
+  const float eps = 1e-5f;
+  if (fabsf(verticalStart) < eps && fabsf(verticalEnd - 90.0f) < eps) h = nV * 2;
+  else if (fabsf(verticalStart - 90.0f) < eps && fabsf(verticalEnd - 180.0f) < eps) h = nV * 2;
+  else h = nV;
+  enum { REFLECT4, REFLECT2, REFLECT0 } reflectType = REFLECT0;
+  if (fabsf(horizontStart) < eps && fabsf(horizontEnd) < eps) w = 1;
+  else if (fabsf(horizontStart) < eps && fabsf(horizontEnd - 90.0f) < eps) { w = nH * 4; reflectType = REFLECT4; }
+  else if (fabsf(horizontStart) < eps && fabsf(horizontEnd - 180.0f) < eps) { w = nH * 4; reflectType = REFLECT4; }   // sic: treated like the quadrant case (:79-83)
+  else if (fabsf(horizontStart - 90.0f) < eps && fabsf(horizontEnd - 180.0f) < eps) { w = nH * 2; reflectType = REFLECT2; }
+  else w = nH;
+  if (horizontEnd > 180.0f && horizontEnd < 360.0f) horizontEnd = 360.0f;
+  std::vector<float> res(size_t(w) * size_t(h), 0.0f);
+  const float stepTheta = (verticalEnd - verticalStart) / float(nV);
+  float stepPhi = (horizontEnd - horizontStart) / float(nH);
+  if (fabsf(stepPhi) < eps) stepPhi = 360.0f;
+  auto row = [&](float thetaGrad) { int iY = int(((D2R * thetaGrad) * INV_PI_F) * float(h) + 0.5f); return iY >= h ? h - 1 : iY; };
+  auto col = [&](float phiGrad) { int iX = int(((D2R * phiGrad) * 0.5f * INV_PI_F) * float(w) + 0.5f); return iX >= w ? w - 1 : iX; };
+  int thetaIndex = 0;
+  for (float thetaGrad = verticalStart; thetaIndex < nV; thetaGrad += stepTheta, thetaIndex++) {
+    const int iY = row(thetaGrad);
+    int phiIndex = 0;
+    for (float phiGrad = horizontStart; phiIndex < nH; phiGrad += stepPhi, phiIndex++) res[size_t(iY) * w + col(phiGrad)] = ies.candela[size_t(phiIndex)][size_t(thetaIndex)];
+  }
+  if (reflectType == REFLECT4) {
+    for (float thetaGrad = verticalStart; thetaGrad <= verticalEnd; thetaGrad += stepTheta) {
+      const int iY = row(thetaGrad);
+      for (float phiGrad = 0.0f; phiGrad <= 90.0f; phiGrad += stepPhi) {
+        const int iX1 = col(phiGrad), iX2 = col(180.0f - phiGrad - stepPhi), iX3 = col(180.0f + phiGrad), iX4 = col(360.0f - phiGrad - stepPhi);
+        res[size_t(iY) * w + iX2] = res[size_t(iY) * w + iX1];
+        res[size_t(iY) * w + iX3] = res[size_t(iY) * w + iX1];
+        res[size_t(iY) * w + iX4] = res[size_t(iY) * w + iX1];
+      }
+    }
+  } else if (reflectType == REFLECT2) {
+    for (float thetaGrad = verticalStart; thetaGrad <= verticalEnd; thetaGrad += stepTheta) {
+      const int iY = row(thetaGrad);
+      for (float phiGrad = 0.0f; phiGrad <= 180.0f; phiGrad += stepPhi) res[size_t(iY) * w + col(360.0f - phiGrad - stepPhi)] = res[size_t(iY) * w + col(phiGrad)];
+    }
+  }
+  return res;
+}
+// HDRImageLite::gaussBlur(2, 1.5) on one channel (RenderDriverRTE_PdfTables.cpp:32-111, 151-176): rows, then columns, windows clipped at the border, weights re-normalised (+ 1e-5)
+static void gauss_blur_1ch(std::vector<float>& lum, int w, int h) {
+  float gk[5], gsum = 0.0f;
+  { const float sg = 2.0f * 1.5f * 1.5f; for (int x = -2; x <= 2; x++) { const float r = sqrtf(float(x * x)); gk[x + 2] = expf(-r / sg) / (3.141592654f * sg); gsum += gk[x + 2]; } for (float& v : gk) v /= gsum; }
+  std::vector<float> tmp(lum.size());
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float c = 0.0f, sw = 0.0f;
+      for (int q = std::max(x - 2, 0); q <= std::min(x + 2, w - 1); q++) { c += lum[size_t(y) * w + q] * gk[q + 2 - x]; sw += gk[q + 2 - x]; }
+      tmp[size_t(y) * w + x] = c / (sw + 1e-5f);
+    }
+  if (h == 1) { lum = tmp; return; }
+  for (int x = 0; x < w; x++)
+    for (int y = 0; y < h; y++) {
+      float c = 0.0f, sw = 0.0f;
+      for (int q = std::max(y - 2, 0); q <= std::min(y + 2, h - 1); q++) { c += tmp[size_t(q) * w + x] * gk[q + 2 - y]; sw += gk[q + 2 - y]; }
+      lum[size_t(y) * w + x] = c / (sw + 1e-5f);
+    }
+}
+// AddIesTexTableToStorage, RenderDriverRTE_PdfTables.cpp:385-478: {w, h, 1, 4} + the web scaled to a maximum of 1 (+ one spare float) as the image, {w, h, 1, 4} + prefix
+// sums of the blurred web + 0.05 x mean as the sampling table; both in the pdf arena, cached per file.  Returns {-1, -1} for a file that cannot be used.
+std::pair<int32_t, int32_t> RenderDriverLite::AddIesTexTable(const std::string& loc) {
+  auto p = m_iesCache.find(loc);
+  if (p != m_iesCache.end()) return p->second;
+  IesData ies;
+  if (!read_ies_file(m_libPath + "/" + loc, ies) || ies.vert.empty()) { m_log += "oldies::IE_ReadFile error: " + loc + "\n"; return {-1, -1}; }
+  int w = 0, h = 0;
+  std::vector<float> tex = spherical_texture_from_ies(ies, w, h);
+  const int32_t iesTexId = m_pPdfStorage->GetMaxObjectId() + 1;
+  float maxVal = 0.0f;
+  for (float v : tex) maxVal = fmaxf(maxVal, v);
+  if (tex.size() == 1 || maxVal == 0.0f) { m_log += "[ERROR]: broken IES file (maxVal = 0.0): " + loc + "\n"; return {-1, -1}; }
+  const float invMax = 1.0f / maxVal;
+  for (float& v : tex) v = invMax * v;
+  std::vector<float> data2(tex.size() + 5, 0.0f);
+  put_i(data2.data(), 0, w); put_i(data2.data(), 1, h); put_i(data2.data(), 2, 1); put_i(data2.data(), 3, 4);
+  double avgVal = 0.0;
+  for (size_t i = 0; i < tex.size(); i++) { avgVal += double(tex[i]); data2[i + 4] = tex[i]; }
+  avgVal /= double(tex.size());
+  m_pPdfStorage->Update(iesTexId, data2.data(), data2.size() * sizeof(float));
+  gauss_blur_1ch(tex, w, h);
+  for (float& v : tex) v = v + 0.05f * float(avgVal);          // no pixel with zero pdf
+  std::vector<float> data3(4 + tex.size() + 1);
+  put_i(data3.data(), 0, w); put_i(data3.data(), 1, h); put_i(data3.data(), 2, 1); put_i(data3.data(), 3, 4);
+  float acc = 0.0f;
+  for (size_t i = 0; i < tex.size(); i++) { data3[4 + i] = acc; acc += tex[i]; }
+  data3[4 + tex.size()] = acc;
+  const int32_t iesPdfId = m_pPdfStorage->GetMaxObjectId() + 1;
+  m_pPdfStorage->Update(iesPdfId, data3.data(), data3.size() * sizeof(float));
+  m_iesCache[loc] = {iesTexId, iesPdfId};
+  return {iesTexId, iesPdfId};
+}
+// the IES frame of a light record: iesMatrix (optionally turned 90 degrees about Y first, ROTATE_IES_90_DEG, PlainLightConverter.cpp:14, 170-174, 645-649) in the light-matrix slot
+static void put_ies_matrix(float* d, const XmlNode* iesNode, bool rotate90) {
+  float4x4 iesMatrix;
+  if (iesNode && iesNode->has_attr("matrix")) {
+    float m[16];
+    if (parse_floats(iesNode->attr("matrix"), m, 16)) iesMatrix = float4x4::from_row_major(m);
+  }
+  if (rotate90) {
+    float4x4 mrot;                                            // LiteMath::rotate4x4Y(90 degrees): (0,2) = +sin, (2,0) = -sin (HydraAPI's LiteMath is not part of the reference tree)
+    mrot.at(0, 0) = 0.0f; mrot.at(0, 2) = 1.0f; mrot.at(2, 0) = -1.0f; mrot.at(2, 2) = 0.0f;
+    iesMatrix = mul(mrot, iesMatrix);
+  }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) d[HL_IES_LIGHT_MATRIX + r * 3 + c] = iesMatrix.at(r, c);
+}
+// ILight::TransformIESMatrix, PlainLightConverter.cpp:113-124
+static void transform_ies_matrix(const float* proto, const float4x4& M, float* copy) {
+  float4x4 mrot = M;
+  mrot.c[3][0] = 0.0f; mrot.c[3][1] = 0.0f; mrot.c[3][2] = 0.0f; mrot.c[3][3] = 1.0f;
+  float4x4 sub;                                               // transpose(GetSubMatrix3x3(m_plain, IES_LIGHT_MATRIX_E00))
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) sub.at(c, r) = proto[HL_IES_LIGHT_MATRIX + r * 3 + c];
+  const float4x4 ies = mul(mrot, sub), inv = inverse4x4(ies);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) { copy[HL_IES_LIGHT_MATRIX + r * 3 + c] = ies.at(c, r); copy[HL_IES_INV_MATRIX + r * 3 + c] = inv.at(c, r); }   // PutSubMatrix3x3Transp
+}
+
 // DirectLight (:500-566, CreateDirectLightFromXmlNode :840-855), SpotLight (:568-626, CreatePointSpotLightFromXmlNode :894-906)
 // and PointLight without IES (:628-700); OLD_PHOTOMETRIC_SCALE is 1 (:15)
 bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node) {
   const std::string ltype = a_node->attr("type"), distr = a_node->attr("distribution");
-  if (distr == "ies" || a_node->child("ies") || a_node->child("honio")) Unsupported("IES / honio light distribution");
   const XmlNode* inten = a_node->child("intensity");
   const float3 color = read_value3f(xchild(inten, "color")) * read_value1f(xchild(inten, "multiplier"));
   const float DEG2RAD = 3.14159265358979323846f / 180.f;
@@ -705,6 +870,18 @@ bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node
     put_i(d, HL_TYPE, HLT_POINT_OMNI);
     put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
     put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
+    const XmlNode* iesNode = a_node->child("ies");             // PointLight with a photometric web, PlainLightConverter.cpp:640-697
+    if (a_node->child("honio")) Unsupported("honio light distribution (light " + std::to_string(a_lightId) + ")");
+    if (iesNode && iesNode->has_attr("loc") && distr == "ies") {
+      const auto ids = AddIesTexTable(iesNode->attr("loc"));
+      if (ids.first >= 0 && ids.second >= 0) {
+        put_i(d, HL_IES_SPHERE_TEX_ID, ids.first);
+        put_i(d, HL_IES_SPHERE_PDF_ID, ids.second);
+        put_i(d, HL_FLAGS, HLF_HAS_IES);
+        put_ies_matrix(d, iesNode, true);
+        lp.hasIes = true;
+      }
+    }
     lp.kind = 0;
   }
   lp.isDelta = true;
@@ -739,24 +916,7 @@ void RenderDriverLite::LuminanceImageOf(int32_t texId, std::vector<float>& lum, 
     for (size_t i = 0; i < lum.size(); i++) { lum[i] = std::max(px[i * 4], std::max(px[i * 4 + 1], px[i * 4 + 2])); avg += lum[i]; }
     avg /= float(lum.size());
     avg = std::max(avg, 1.0f);
-    // HDRImageLite::gaussBlur(2, 1.5), one channel: rows, then columns, windows clipped at the border, weights re-normalised (+ 1e-5)
-    float gk[5], gsum = 0.0f;
-    { const float sg = 2.0f * 1.5f * 1.5f; for (int x = -2; x <= 2; x++) { const float r = sqrtf(float(x * x)); gk[x + 2] = expf(-r / sg) / (3.141592654f * sg); gsum += gk[x + 2]; } for (float& v : gk) v /= gsum; }
-    std::vector<float> tmp(lum.size());
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) {
-        float c = 0.0f, sw = 0.0f;
-        for (int q = std::max(x - 2, 0); q <= std::min(x + 2, w - 1); q++) { c += lum[size_t(y) * w + q] * gk[q + 2 - x]; sw += gk[q + 2 - x]; }
-        tmp[size_t(y) * w + x] = c / (sw + 1e-5f);
-      }
-    if (h == 1) lum = tmp;
-    else
-      for (int x = 0; x < w; x++)
-        for (int y = 0; y < h; y++) {
-          float c = 0.0f, sw = 0.0f;
-          for (int q = std::max(y - 2, 0); q <= std::min(y + 2, h - 1); q++) { c += tmp[size_t(q) * w + x] * gk[q + 2 - y]; sw += gk[q + 2 - y]; }
-          lum[size_t(y) * w + x] = c / (sw + 1e-5f);
-        }
+    gauss_blur_1ch(lum, w, h);                                    // HDRImageLite::gaussBlur(2, 1.5), one channel
     for (float& v : lum) v += 0.05f * avg;                        // no pixel with zero pdf
     lw = w; lh = h;
   }
@@ -973,7 +1133,6 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
     return true;
   }
   if (ltype != "area" || (lshape != "rect" && lshape != "disk")) { Unsupported("light type '" + ltype + "/" + lshape + "'"); }
-  if (distr == "ies" || a_node->child("ies")) Unsupported("IES light distribution");
   const bool isSkyPortal = xchild(a_node, "sky_portal") && xchild(a_node, "sky_portal")->attr_int("val") == 1;   // :197-204; OLD_PHOTOMETRIC_SCALE is 1
 
   LightProto lp;
@@ -1013,9 +1172,18 @@ bool RenderDriverLite::UpdateLight(int32_t a_lightId, const XmlNode* a_node) {
   if (isSkyPortal) { put_i(d, HL_AREA_SKYPORTAL_BTEX, int32_t(HYDRA_INVALID_TEXTURE)); put_i(d, HL_AREA_SKYPORTAL_BTEX_MATRIX, int32_t(HYDRA_INVALID_TEXTURE)); }
   put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
   put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
-  // IES matrix: identity rotated 90 degrees about Y (ROTATE_IES_90_DEG, PlainLightConverter.cpp:14,170-174); unused without IES
-  const float iesM[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};
-  memcpy(d + HL_IES_LIGHT_MATRIX, iesM, 36);
+  // IES matrix: the <ies matrix> (identity without one) turned 90 degrees about Y (ROTATE_IES_90_DEG, PlainLightConverter.cpp:14, 162-174); read only with a web
+  const XmlNode* iesNode = a_node->child("ies");
+  put_ies_matrix(d, (iesNode && iesNode->has_attr("matrix")) ? iesNode : nullptr, true);
+  if (iesNode && iesNode->has_attr("loc") && distr == "ies") {   // :176-187, 259-266
+    const auto ids = AddIesTexTable(iesNode->attr("loc"));
+    if (ids.first >= 0 && ids.second >= 0) {
+      put_i(d, HL_FLAGS, get_i(d, HL_FLAGS) | HLF_HAS_IES | ((iesNode->attr_int("point_area") == 1) ? HLF_IES_POINT_AREA : 0));
+      put_i(d, HL_IES_SPHERE_TEX_ID, ids.first);
+      put_i(d, HL_IES_SPHERE_PDF_ID, ids.second);
+    }
+  }
+  lp.hasIes = true;                                           // AreaDiffuseLight::Transform turns the IES frame with or without a web (:304)
   lp.isDisk = isDisk;
   m_lights[a_lightId] = lp;
   return true;
@@ -1210,6 +1378,7 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
         const float3 ln0 = mul_vec(M, float3(d[HL_NORM], d[HL_NORM + 1], d[HL_NORM + 2]));
         d[HL_NORM] = ln0.x; d[HL_NORM + 1] = ln0.y; d[HL_NORM + 2] = ln0.z;
       }
+      if (it->second.hasIes) transform_ies_matrix(it->second.plain.data(), M, d);   // PointLight::Transform :700-715 (a light without a web keeps its zeros: the reference inverts a zero matrix there)
     } else if (it->second.isSky) {                // SkyDomeLight::Transform returns the light unchanged (:1024-1027)
     } else if (it->second.isMesh) {               // MeshLight::Transform, PlainLightConverter.cpp:795-829: position, the 3x3 part, the area of the transformed triangles
       const float3 mp0 = mul_point(M, float3(d[HL_POS], d[HL_POS + 1], d[HL_POS + 2]));
@@ -1247,6 +1416,7 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
       d[HL_NORM] = ln.x; d[HL_NORM + 1] = ln.y; d[HL_NORM + 2] = ln.z;
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) d[HL_AREA_MATRIX + r * 3 + c] = M.at(r, c);
+      if (it->second.hasIes) transform_ies_matrix(it->second.plain.data(), M, d);
       if (it->second.isDisk) {
         const float3 vert = mul_vec(M, normalize(float3(1, 1, 1)));
         const float radius = d[HL_AREA_SIZE_X] * length(vert);
@@ -1507,6 +1677,7 @@ void RenderDriverLite::Draw() {
 // ------------------------------------------------------------------------------------------------ HydraAPI's part
 void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width, int a_height, int a_traceDepth, int a_enableDof) {
   std::vector<char> xmlData;
+  m_libPath = libPath;
   std::string xmlPath = libPath + "/statex_00001.xml";
   if (!read_file(xmlPath, xmlData)) RunTimeError("LoadSceneLibrary: can't open " + xmlPath);
   const std::string src(xmlData.begin(), xmlData.end());

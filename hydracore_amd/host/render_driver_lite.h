@@ -49,6 +49,9 @@ public:
   bool UpdateSkyLight(int32_t a_lightId, const XmlNode* a_lightNode);
   void LuminanceImageOf(int32_t texId, std::vector<float>& lum, int& lw, int& lh);
   int32_t PutPdfTable2D(const std::vector<float>& lum, int lw, int lh);
+  std::pair<int32_t, int32_t> AddIesTexTable(const std::string& loc);
+  std::map<std::string, std::pair<int32_t, int32_t>> m_iesCache;
+  std::string m_libPath;
   bool UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_lightNode);
   bool UpdateMesh(int32_t a_meshId, int vertNum, int triNum, const float* pos4f, const float* norm4f, const float* tan4f,
                   const float* texcoord2f, const int* indices, const int* triMatIndices);
@@ -85,7 +88,7 @@ private:
   struct Camera { float fov = 45.0f, nearPlane = 0.1f, farPlane = 1000.0f; float3 pos{0, 0, 0}, lookAt{0, 0, -1}, up{0, 1, 0};
                   bool useMatrices = false; float4x4 mProj, mWorldView; } m_camera;   // useMatrices: a "two_matrices" camera (RenderDriverRTE.cpp:1178-1201)
 
-  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false, isMesh = false, isCylinder = false; int kind = 0;
+  struct LightProto { std::vector<float> plain; bool isDisk = false, isSky = false, isDelta = false, isSphere = false, isMesh = false, isCylinder = false, hasIes = false; int kind = 0;
                       std::vector<float> meshPos; std::vector<int32_t> meshInd; };   // meshPos / meshInd: MeshLight::tempPos / tempInd   // kind: 0 point, 1 spot, 2 directional   // un-instanced PlainLight (128 floats)
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id

@@ -65,7 +65,8 @@ enum { SPHERE_LIGHT_RADIUS = 14 };   /* clight.h:33 */
 enum { POINT_LIGHT_SPOT_COS1 = 14, POINT_LIGHT_SPOT_COS2 = 15, DIRECT_LIGHT_RADIUS1 = 14, DIRECT_LIGHT_RADIUS2 = 15,
        DIRECT_LIGHT_SSOFTNESS = 16, DIRECT_LIGHT_ALPHA_TAN = 17, DIRECT_LIGHT_ALPHA_COS = 18 };   /* clight.h:118-127 */
 enum { HRT_BSPHERE_RADIUS = 21 };
-enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16 };
+enum { LF_SKY_PORTAL = 8, LF_HAS_IES = 16, LF_IES_POINT_AREA = 32 };
+enum { IES_INV_MATRIX_E00 = 108, IES_LIGHT_MATRIX_E00 = 117, IES_SPHERE_PDF_ID = 126, IES_SPHERE_TEX_ID = 127 };   /* clight.h:40-62 */
 /* ray flags, ref: cglobals.h:1330-1376 */
 enum { RAY_EVENT_S = 1, RAY_EVENT_D = 2, RAY_EVENT_G = 4, RAY_EVENT_T = 8, RAY_EVENT_TNINGLASS = 64 };
 enum { RAY_GRAMMAR_DIRECT_LIGHT = 64, RAY_IS_DEAD = 4096 };
@@ -1796,6 +1797,8 @@ static f3 areaDiffuseLightGetIntensity(const float* L, f3 rayDir, int eyeRay) {
 }
 /* ref: clight.h:614-629 areaLightSkyPortalCustomColor and the tail of areaDiffuseLightGetIntensity :590-607 (defined after the sky) */
 static f3 portalSkyColor(const OrcScene* s, const float* L, f3 rayDir);
+static f3 areaLightIntensity(const OrcScene* s, const float* L, f3 rayDir, int eyeRay);
+static float lightDistributionMask(const OrcScene* s, const float* L, f3 rayDir);
 /* ref: clight.h:1180-1229 AreaLightSampleRev */
 typedef struct { f3 pos, color; float pdf, maxDist, cosAtLight; int isPoint; } ShadowSample;
 static void AreaLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
@@ -1811,7 +1814,9 @@ static void AreaLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 i
   sp = add3(sp, lightPos(L));
   const f3 rayDir = normalize3(sub3(sp, illum));
   const float hitDist = length3(sub3(sp, illum));
-  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, rayDir)) : areaDiffuseLightGetIntensity(L, rayDir, 0);
+  f3 customRayDir = rayDir;
+  if (as_int(L[PL_FLAGS]) & LF_IES_POINT_AREA) customRayDir = normalize3(sub3(lightPos(L), illum));
+  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, rayDir)) : areaLightIntensity(s, L, customRayDir, 0);
   const f3 ln = lightNorm(L);
   out->isPoint = 0;
   out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
@@ -1908,6 +1913,68 @@ static float skyLightEvalPDF(const OrcScene* s, const float* L, f3 rayDir) {
   const float mapPdf = evalMap2DPdf(tcT, hdr + 4, sizeX, sizeY);
   return (mapPdf * 1.0f) / (2.f * ORC_PI * ORC_PI * fmaxf(fabsf(sintheta), DEPSILON));
 }
+/* ---- IES distributions.  ref: cfetch.h:364-462 read_imagef_sw1 (the float branch: IES images are {w, h, 1, 4} + w * h floats, RenderDriverRTE_PdfTables.cpp:425-441) */
+static float read_imagef_sw1(const int32_t* tex, f2 tc, int flags) {
+  const int w = tex[0], h = tex[1];
+  float ffx = tc.x * (float)w - 0.5f, ffy = tc.y * (float)h - 0.5f;
+  if ((flags & TEX_CLAMP_U) != 0 && ffx < 0) ffx = 0.0f;
+  if ((flags & TEX_CLAMP_V) != 0 && ffy < 0) ffy = 0.0f;
+  const float* fdata = (const float*)(tex + 4);
+  const int px = (int)(ffx), py = (int)(ffy);
+  const float fx = fabsf(ffx - (float)px), fy = fabsf(ffy - (float)py);
+  const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+  const float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+  int offs[4];
+  bilinearOffsets(ffx, ffy, flags, w, h, offs);
+  return ((fdata[offs[0]] * w1 + fdata[offs[1]] * w2) + fdata[offs[2]] * w3) + fdata[offs[3]] * w4;
+}
+static f3 lightMatrixMul3(const float* M, f3 v) { return v3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
+/* ref: clight.h:465-484 lightDistributionMask for a light with LIGHT_HAS_IES (1 otherwise) */
+static float lightDistributionMask(const OrcScene* s, const float* L, f3 rayDir) {
+  rayDir = normalize3(lightMatrixMul3(L + IES_LIGHT_MATRIX_E00, rayDir));
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(scale3(rayDir, -1.0f), &sintheta);
+  return read_imagef_sw1((const int32_t*)pdfTableHeader(s, as_int(L[IES_SPHERE_TEX_ID])), tc, TEX_CLAMP_U | TEX_CLAMP_V);
+}
+/* areaDiffuseLightGetIntensity with its IES branch, ref: clight.h:563-577 */
+static f3 areaLightIntensity(const OrcScene* s, const float* L, f3 rayDir, int eyeRay) {
+  if (as_int(L[PL_FLAGS]) & LF_HAS_IES) {
+    f3 color = lightColor(L);
+    const float atten = lightDistributionMask(s, L, rayDir);
+    if (!eyeRay) color = scale3(color, atten);
+    else color = scale3(color, 1.0f / fmaxf(color.x, fmaxf(color.y, color.z)));
+    return color;
+  }
+  return areaDiffuseLightGetIntensity(L, rayDir, eyeRay);
+}
+/* ref: clight.h:411-426 LightSampleIESSphere */
+static f3 texCoord2DToSphereMap(f2 tc, float* pSinTheta);
+static void LightSampleIESSphere(const OrcScene* s, const float* L, f3 rands, f3* outDir, float* outPdfW) {
+  const float* hdr = pdfTableHeader(s, as_int(L[IES_SPHERE_PDF_ID]));
+  const int sizeX = as_int(hdr[0]), sizeY = as_int(hdr[1]);
+  const float fw = (float)sizeX, fh = (float)sizeY;
+  float pdf = 1.0f;
+  int pixelOffset = SelectIndexPropToOpt(rands.z, hdr + 4, sizeX * sizeY + 1, &pdf);
+  if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+  const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+  f2 tc;
+  tc.x = (1.0f / fw) * (((float)(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+  tc.y = (1.0f / fh) * (((float)(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+  const float mapPdf = pdf * (fw * fh);
+  float sinTheta = 0.0f;
+  const f3 lsDir = texCoord2DToSphereMap(tc, &sinTheta);
+  *outDir = normalize3(lightMatrixMul3(L + IES_INV_MATRIX_E00, lsDir));
+  *outPdfW = INV_PI * INV_PI * 0.5f * (mapPdf / fmaxf(fabsf(sinTheta), DEPSILON2));
+}
+/* the IES branch of lightPdfFwd, ref: clight.h:1152-1164 */
+static float lightPdfFwdIES(const OrcScene* s, const float* L, f3 ray_dir) {
+  const f3 rayDir = lightMatrixMul3(L + IES_LIGHT_MATRIX_E00, ray_dir);
+  const float* hdr = pdfTableHeader(s, as_int(L[IES_SPHERE_PDF_ID]));
+  float sintheta = 0.0f;
+  const f2 tc = sphereMapTo2DTexCoord(scale3(rayDir, -1.0f), &sintheta);
+  const float mapPdf = evalMap2DPdf(tc, hdr + 4, as_int(hdr[0]), as_int(hdr[1]));
+  return mapPdf / (2.f * ORC_PI * ORC_PI * fmaxf(sintheta, DEPSILON2));
+}
 /* ref: clight.h:427-462 SkyLightSampleRev, :378-403 sampleMap2D */
 static void SkyLightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum, ShadowSample* out) {
   const float* hdr = pdfTableHeader(s, as_int(L[SKY_DOME_PDF_TABLE0]));
@@ -1945,12 +2012,13 @@ static float mylocalsmoothstep(float edge0, float edge1, float x) {
 /* ref: cglobals.h:1754-1757 PdfAtoW */
 static float PdfAtoW_full(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / fmaxf(aCosThere, DEPSILON2); }
 /* ref: clight.h:1394-1407 PointLightSampleRev; lightDistributionMask (:465-484) is (1,1,1) without IES */
-static void PointLightSampleRev(const float* L, f3 illum, ShadowSample* out) {
+static void PointLightSampleRev(const OrcScene* s, const float* L, f3 illum, ShadowSample* out) {
   const f3 samplePos = v3(L[PL_POS], L[PL_POS + 1], L[PL_POS + 2]);
   const float hitDist = length3(sub3(samplePos, illum));
   out->isPoint = 1;
   out->pos = samplePos;
-  out->color = mul3(v3(1.0f, 1.0f, 1.0f), v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]));
+  const float mask = (as_int(L[PL_FLAGS]) & LF_HAS_IES) ? lightDistributionMask(s, L, normalize3(sub3(samplePos, illum))) : 1.0f;
+  out->color = mul3(v3(mask, mask, mask), v3(L[PL_COLOR], L[PL_COLOR + 1], L[PL_COLOR + 2]));
   out->pdf = PdfAtoW_full(1.0f, hitDist, 1.0f);
   out->maxDist = hitDist;
   out->cosAtLight = 1.0f;
@@ -2151,7 +2219,7 @@ static void LightSampleRev(const OrcScene* s, const float* L, f3 rands, f3 illum
     case LT_SKY_DOME: SkyLightSampleRev(s, L, rands, illum, out); break;
     case LT_DIRECT: DirectLightSampleRev(L, rands, illum, out); break;
     case LT_POINT_SPOT: SpotLightSampleRev(L, illum, out); break;
-    case LT_POINT_OMNI: PointLightSampleRev(L, illum, out); break;
+    case LT_POINT_OMNI: PointLightSampleRev(s, L, illum, out); break;
     case LT_CYLINDER: CylinderLightSampleRev(s, L, rands, illum, out); break;
     default: AreaLightSampleRev(s, L, rands, illum, out); break;
   }
@@ -2223,8 +2291,8 @@ static void CylinderLightSampleForward(const OrcScene* s, const float* L, const 
   out->cosTheta = cosTheta;
   out->norm = ln;
 }
-/* ref: clight.h:654-719 AreaLightSampleForward (no IES in the subset) */
-static void AreaLightSampleForward(const OrcScene* s, const float* L, const float r[4], LightSampleFwd* out) {
+/* ref: clight.h:654-719 AreaLightSampleForward; r2x = rands2.x, the third number of the IES table sample */
+static void AreaLightSampleForward(const OrcScene* s, const float* L, const float r[4], float r2x, LightSampleFwd* out) {
   const float offsetX = r[0] * 2.0f - 1.0f, offsetY = r[1] * 2.0f - 1.0f;
   f3 sp = v3(offsetX * L[AL_SIZE_X], 0.0f, offsetY * L[AL_SIZE_Y]);
   if (as_int(L[AL_IS_DISK]) != 0) {
@@ -2235,18 +2303,22 @@ static void AreaLightSampleForward(const OrcScene* s, const float* L, const floa
   const float* M = L + AL_MATRIX;
   sp = v3(M[0] * sp.x + M[1] * sp.y + M[2] * sp.z, M[3] * sp.x + M[4] * sp.y + M[5] * sp.z, M[6] * sp.x + M[7] * sp.y + M[8] * sp.z);
   sp = add3(sp, lightPos(L));
-  const f3 ln = lightNorm(L);
+  if (as_int(L[PL_FLAGS]) & LF_IES_POINT_AREA) sp = lightPos(L);
+  f3 ln = lightNorm(L);
   f3 sampleDir = MapSampleToCosineDistribution(r[2], r[3], ln, ln, 1.0f);
   float cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
   float pdfW = cosTheta * INV_PI;
-  if (as_int(L[AL_SPOT_DISTR]) != 0) {
+  if (as_int(L[PL_FLAGS]) & LF_HAS_IES) {
+    LightSampleIESSphere(s, L, v3(r[2], r[3], r2x), &sampleDir, &pdfW);
+    ln = dot3(ln, sampleDir) > 0.0f ? ln : scale3(ln, -1.0f);
+  } else if (as_int(L[AL_SPOT_DISTR]) != 0) {
     const float cos2 = L[AL_SPOT_COS2];
     f2 sm = {r[2], r[3]};
     sampleDir = MapSamplesToCone(cos2, sm, ln);
     pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
   }
   cosTheta = fmaxf(dot3(sampleDir, ln), 0.0f);
-  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, scale3(sampleDir, -1.0f))) : areaDiffuseLightGetIntensity(L, scale3(sampleDir, -1.0f), 0);
+  const f3 color = (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) ? mul3(lightColor(L), portalSkyColor(s, L, scale3(sampleDir, -1.0f))) : areaLightIntensity(s, L, scale3(sampleDir, -1.0f), 0);
   out->isPoint = 0;
   out->pos = add3(sp, scale3(ln, epsilonOfPos(sp)));
   out->dir = sampleDir;
@@ -2257,15 +2329,19 @@ static void AreaLightSampleForward(const OrcScene* s, const float* L, const floa
   out->norm = ln;
 }
 /* ref: clight.h:838-862 PointLightSampleForward (pointLightGetIntensity :486-495 is the base colour without IES) */
-static void PointLightSampleForward(const float* L, const float r[4], LightSampleFwd* out) {
-  const f3 sampleDir = UniformSampleSphere(r[0], r[1]);
+static void PointLightSampleForward(const OrcScene* s, const float* L, const float r[4], LightSampleFwd* out) {
+  float pdfW = INV_PI * 0.25f;
+  f3 sampleDir = UniformSampleSphere(r[0], r[1]);
+  const int ies = (as_int(L[PL_FLAGS]) & LF_HAS_IES) != 0;
+  if (ies) LightSampleIESSphere(s, L, v3(r[0], r[1], r[2]), &sampleDir, &pdfW);
   const f3 samplePos = lightPos(L);
+  const float mask = ies ? lightDistributionMask(s, L, scale3(sampleDir, -1.0f)) : 1.0f;
   out->isPoint = 1;
   out->pos = add3(samplePos, scale3(sampleDir, epsilonOfPos(samplePos)));
   out->dir = sampleDir;
-  out->color = scale3(lightColor(L), 1.0f / L[PL_SURFACE_AREA]);
+  out->color = scale3(mul3(v3(mask, mask, mask), lightColor(L)), 1.0f / L[PL_SURFACE_AREA]);
   out->pdfA = 1.0f / L[PL_SURFACE_AREA];
-  out->pdfW = INV_PI * 0.25f;
+  out->pdfW = pdfW;
   out->cosTheta = 1.0f;
   out->norm = sampleDir;
 }
@@ -2320,9 +2396,9 @@ void orc_light_sample_forward(const OrcScene* s, int n, const int32_t* lightIds,
       case LT_SPHERE: SphereLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_DIRECT: DirectLightSampleForward(L, rands4 + 4 * i, &sam); break;
       case LT_POINT_SPOT: PointSpotSampleForward(L, rands4 + 4 * i, &sam); break;
-      case LT_POINT_OMNI: PointLightSampleForward(L, rands4 + 4 * i, &sam); break;
+      case LT_POINT_OMNI: PointLightSampleForward(s, L, rands4 + 4 * i, &sam); break;
       case LT_CYLINDER: CylinderLightSampleForward(s, L, rands4 + 4 * i, 0.0f, &sam); break;
-      default: AreaLightSampleForward(s, L, rands4 + 4 * i, &sam); break;
+      default: AreaLightSampleForward(s, L, rands4 + 4 * i, 0.0f, &sam); break;
     }
     float* o = out16 + 16 * (size_t)i;
     o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
@@ -2347,7 +2423,8 @@ void orc_light_pdf_fwd(const OrcScene* s, int n, const int32_t* lightIds, const 
       pdfA = 1.0f / (ORC_PI * radius2 * radius2);
       pdfW = 0.0f;
     }
-    if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) {
+    if (as_int(L[PL_FLAGS]) & LF_HAS_IES) pdfW = lightPdfFwdIES(s, L, v3(0.0f, 0.0f, 1.0f));   /* the direction the reference-side fixture hands in */
+    else if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) {
       const float cos2 = L[AL_SPOT_COS2];
       pdfW = 1.0f / (2.0f * ORC_PI * (1.0f - cos2));
       if (ct < cos2) pdfW = 0.0f;
@@ -2529,7 +2606,9 @@ static f3 lightGetIntensity(const OrcScene* s, const float* L, f3 ray_pos, f3 ra
     return mul3(lightColor(L), portalSkyColor(s, L, ray_dir));
   }
   if (type == LT_AREA) {
-    f3 color = areaDiffuseLightGetIntensity(L, ray_dir, eyeRay);
+    f3 customDir = ray_dir;
+    if (as_int(L[PL_FLAGS]) & LF_IES_POINT_AREA) customDir = normalize3(sub3(lightPos(L), ray_pos));
+    f3 color = areaLightIntensity(s, L, customDir, eyeRay);
     if (as_int(L[PL_FLAGS]) & LF_SKY_PORTAL) color = mul3(color, portalSkyColor(s, L, ray_dir));
     return color;
   }
@@ -2842,19 +2921,20 @@ static void LightSampleForwardAny(const OrcScene* s, const float* L, const float
     case LT_SPHERE: SphereLightSampleForward(L, r, sam); break;
     case LT_DIRECT: DirectLightSampleForward(L, r, sam); break;
     case LT_POINT_SPOT: PointSpotSampleForward(L, r, sam); break;
-    case LT_POINT_OMNI: PointLightSampleForward(L, r, sam); break;
+    case LT_POINT_OMNI: PointLightSampleForward(s, L, r, sam); break;
     case LT_CYLINDER: CylinderLightSampleForward(s, L, r, r2x, sam); break;
-    default: AreaLightSampleForward(s, L, r, sam); break;
+    default: AreaLightSampleForward(s, L, r, r2x, sam); break;
   }
 }
-static void lightPdfFwdOne(const float* L, float ct, float* pdfA, float* pdfW) {
+static void lightPdfFwdOne(const OrcScene* s, const float* L, f3 ray_dir, float ct, float* pdfA, float* pdfW) {
   float out4[4];
   const int ltype = as_int(L[PL_TYPE]);
   out4[0] = 1.0f / L[PL_SURFACE_AREA]; out4[1] = fmaxf(ct * INV_PI, 0.0f);
   if (ltype == LT_POINT_OMNI) out4[1] = INV_PI * 0.25f;
   else if (ltype == LT_POINT_SPOT) { const float cos2 = L[POINT_LIGHT_SPOT_COS2]; out4[1] = 1.0f / (2.0f * ORC_PI * (1.0f - cos2)); if (ct < cos2) out4[1] = 0.0f; }
   else if (ltype == LT_DIRECT) { const float r2 = L[DIRECT_LIGHT_RADIUS2]; out4[0] = 1.0f / (ORC_PI * r2 * r2); out4[1] = 0.0f; }
-  if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) { const float cos2 = L[AL_SPOT_COS2]; out4[1] = 1.0f / (2.0f * ORC_PI * (1.0f - cos2)); if (ct < cos2) out4[1] = 0.0f; }
+  if (as_int(L[PL_FLAGS]) & LF_HAS_IES) out4[1] = lightPdfFwdIES(s, L, ray_dir);
+  else if (ltype == LT_AREA && as_int(L[AL_SPOT_DISTR]) != 0) { const float cos2 = L[AL_SPOT_COS2]; out4[1] = 1.0f / (2.0f * ORC_PI * (1.0f - cos2)); if (ct < cos2) out4[1] = 0.0f; }
   *pdfA = out4[0]; *pdfW = out4[1];
 }
 static ShadeContext makeShadeContext(const SurfaceHit* h, f3 l, f3 v) {
@@ -2922,7 +3002,7 @@ static void mmltF(const OrcScene* s, const float* xVec, int d, float* out8) {
       if (dot3(emission, emission) > 1e-6f) {
         if (currDepth == camTraceDepth && haveToHitLight) {
           float pdfA, pdfW;
-          lightPdfFwdOne(pLight, cosHere, &pdfA, &pdfW);
+          lightPdfFwdOne(s, pLight, ray_dir, cosHere, &pdfA, &pdfW);
           const float pdfLightWP = pdfW / fmaxf(cosHere, DEPSILON);
           const float pdfMatRevWP = misPrev.matSamplePdf / fmaxf(cosPrev, DEPSILON);
           pdfArray[0].pdfFwd = pdfA / (float)s->globals[G_LIGHTS_NUM];
@@ -3077,7 +3157,7 @@ static void mmltF(const OrcScene* s, const float* xVec, int d, float* out8) {
           const float shadowDist = length3(sub3(cv.hit.pos, explicitSam.pos));
           const float GTerm = cosThetaOut * cosAtLight / fmaxf(shadowDist * shadowDist, DEPSILON2);
           float pdfA, pdfW;
-          lightPdfFwdOne(pLight, cosAtLight, &pdfA, &pdfW);
+          lightPdfFwdOne(s, pLight, shadowRayDir, cosAtLight, &pdfA, &pdfW);
           pdfArray[0].pdfFwd = pdfA * lightPickProb;
           pdfArray[0].pdfRev = 1.0f;
           pdfArray[1].pdfFwd = (pdfW / cosAtLight) * GTerm;

@@ -118,7 +118,7 @@ void emu_bidir(const EmuScene* e, int n, const int* lightIds, const float* rands
     o[0] = sam.pos.x; o[1] = sam.pos.y; o[2] = sam.pos.z; o[3] = sam.dir.x; o[4] = sam.dir.y; o[5] = sam.dir.z;
     o[6] = sam.norm.x; o[7] = sam.norm.y; o[8] = sam.norm.z; o[9] = sam.color.x; o[10] = sam.color.y; o[11] = sam.color.z;
     o[12] = sam.pdfA; o[13] = sam.pdfW; o[14] = sam.cosTheta; o[15] = sam.isPoint ? 1.0f : 0.0f;
-    const LightPdfFwd p = lightPdfFwd(lightAt(s, lightIds[i]), cosTheta[i]);
+    const LightPdfFwd p = lightPdfFwd(s, lightAt(s, lightIds[i]), mk3(0.0f, 0.0f, 1.0f), cosTheta[i]);
     pdf4[4 * i] = p.pdfA; pdf4[4 * i + 1] = p.pdfW; pdf4[4 * i + 2] = p.pickProb; pdf4[4 * i + 3] = 0.0f;
     f3 camDir; float zDepth;
     const f3 hp = mk3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]);

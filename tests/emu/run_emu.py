@@ -78,7 +78,7 @@ def main():
         return a.ctypes.data_as(C.c_void_p)
     worst = 0.0
     hall = dict(center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
-    for name, ww, hh, depth, dof, rk in (("test_224", 96, 96, 4, 0, {}), ("test_42", 96, 96, 4, 1, {}), ("atrium_sky_small", 96, 54, 5, 0, hall), ("atrium_skytex_small", 96, 54, 5, 0, hall), ("atrium_lights_small", 96, 54, 5, 0, hall), ("atrium_glass_small", 96, 54, 8, 0, hall), ("atrium_ggx_small", 96, 54, 8, 0, hall), ("atrium_nmap_small", 96, 54, 5, 0, hall), ("atrium_transl_small", 96, 54, 5, 0, hall), ("atrium_aniso_small", 96, 54, 5, 0, hall), ("atrium_tubes_small", 96, 54, 5, 0, hall), ("atrium_portal_small", 96, 54, 5, 0, hall)):
+    for name, ww, hh, depth, dof, rk in (("test_224", 96, 96, 4, 0, {}), ("test_42", 96, 96, 4, 1, {}), ("atrium_sky_small", 96, 54, 5, 0, hall), ("atrium_skytex_small", 96, 54, 5, 0, hall), ("atrium_lights_small", 96, 54, 5, 0, hall), ("atrium_glass_small", 96, 54, 8, 0, hall), ("atrium_ggx_small", 96, 54, 8, 0, hall), ("atrium_nmap_small", 96, 54, 5, 0, hall), ("atrium_transl_small", 96, 54, 5, 0, hall), ("atrium_aniso_small", 96, 54, 5, 0, hall), ("atrium_tubes_small", 96, 54, 5, 0, hall), ("atrium_portal_small", 96, 54, 5, 0, hall), ("atrium_ies_small", 96, 54, 5, 0, hall)):
         if os.environ.get("EMU_ONLY") and name not in os.environ["EMU_ONLY"].split(","):
             continue
         _, b = host_scene(name, ww, hh, depth, dof)

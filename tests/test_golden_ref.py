@@ -91,7 +91,7 @@ def check_shade_point(out, ref, frac=0.002):
     assert valid.mean() > 0.3
 
 
-@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_skyhdr_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_perez_small", "atrium_tubes_small", "atrium_portal_small"])
+@pytest.mark.parametrize("name", ["test_224", "test_42", "atrium_small", "atrium_sky_small", "atrium_skytex_small", "atrium_skyhdr_small", "atrium_lights_small", "atrium_glass_small", "atrium_ggx_small", "atrium_cutouts_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_perez_small", "atrium_tubes_small", "atrium_portal_small", "atrium_ies_small"])
 def test_oracle_matches_reference_functions(name, built):
     g = load("ref_%s.npz" % name)
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
@@ -154,7 +154,7 @@ def test_oracle_matches_reference_functions(name, built):
     assert abs(col[:, :3].mean() - rc[:, :3].mean()) < 2e-3 * rc[:, :3].mean()
 
 
-BIDIR_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_tubes_small", "atrium_portal_small"]
+BIDIR_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_tubes_small", "atrium_portal_small", "atrium_ies_small"]
 
 
 def check_bidir(got, g, exact_pdf=True):
@@ -194,7 +194,7 @@ def test_oracle_matches_reference_bidirectional_blocks(name, built):
     check_bidir(run_bidir(make_oracle(b), g), g)
 
 
-MMLT_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_glass_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_tubes_small", "atrium_portal_small"]
+MMLT_SCENES = ["test_224", "test_42", "atrium_small", "atrium_lights_small", "atrium_glass_small", "atrium_cutouts2_small", "atrium_nmap_small", "atrium_transl_small", "atrium_aniso_small", "atrium_tubes_small", "atrium_portal_small", "atrium_ies_small"]
 
 
 def load_mmlt(name):

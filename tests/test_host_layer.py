@@ -392,3 +392,41 @@ def test_sky_portal_packs_like_the_reference_converter():
     at = g[g[G_MAT_TABLE] + 12] * 4 // 192
     assert mi[at, 0] == 3 and mi[at, 1] == (8 | 256 | 1024)
     np.testing.assert_allclose(m[at, 10:13], 1.0)
+
+
+def test_ies_lights_pack_like_the_reference_converter():
+    """PointLight / AreaDiffuseLight with distribution="ies" (PlainLightConverter.cpp:162-266, 632-697), the lat-long image of the web (IESRender.cpp:29-200) and
+    its two tables (AddIesTexTableToStorage, RenderDriverRTE_PdfTables.cpp:385-478), the IES frame carried through the instance matrix (TransformIESMatrix :113-124).
+    The LM-63 reader itself is unpinned (the reference's parser and any .ies file are absent from its tree): the check here is against the generator's own function"""
+    _, b = host_scene("atrium_ies_small", 96, 54, 5)
+    g = b["globals"]
+    gf = g.view(np.float32)
+    n = g[G_LIGHTS_NUM]
+    L = gf[g[G_LIGHTS_OFFS]:g[G_LIGHTS_OFFS] + n * 128].reshape(n, 128)
+    Li = L.view(np.int32)
+    assert list(Li[:, 0]) == [4, 0, 4, 4] and list(Li[:, 1]) == [0, 16, 16, 16 | 32]     # LIGHT_HAS_IES, + LIGHT_IES_POINT_AREA on the last
+    assert Li[1, 127] == Li[3, 127] and Li[1, 126] == Li[3, 126] and Li[2, 127] != Li[1, 127]   # one image + table per file (the cache), ids TEX = 127, PDF = 126
+    pdf, tab = b["pdfs"], g[g[220]:g[220] + g[225]]
+    # file 1: the whole sphere, 19 x 9 angles -> a 9 x 19 image; pixel (phi index, theta index) holds the candela value, scaled to a maximum of 1
+    t = pdf[tab[Li[1, 127]] * 4:]
+    assert tuple(t[:4].view(np.int32)) == (9, 19, 1, 4)
+    img = t[4:4 + 9 * 19].reshape(19, 9)
+    fn = lambda th, ph: 800.0 * max(np.cos(th), 0.0) ** 2 * (1.0 + 0.6 * np.cos(ph - 1.05)) + 150.0 * max(-np.cos(th), 0.0) + 20.0
+    want = np.array([[float("%.4f" % fn(np.radians(10.0 * iy), np.radians(45.0 * ix))) for ix in range(9)] for iy in range(19)])
+    # the reference's own placement rule rounds theta / 180 * h and phi / 360 * w with steps of span / count: columns and rows land where the loop of IESRender.cpp:105-124 puts them
+    assert np.isclose(img.max(), 1.0) and (img > 0).all()
+    np.testing.assert_allclose(img[0, 0], want[0, 0] / want.max(), rtol=1e-5)
+    s = pdf[tab[Li[1, 126]] * 4:]
+    assert tuple(s[:4].view(np.int32)) == (9, 19, 1, 4)
+    acc = s[4:4 + 9 * 19 + 1]
+    assert acc[0] == 0 and (np.diff(acc) > 0).all()                                 # blurred web + 0.05 x mean: no cell without probability
+    # file 2: a quadrant of the lower hemisphere (13 x 5 angles) -> 20 x 26, mirrored into the four quadrants, upper hemisphere dark
+    t2 = pdf[tab[Li[2, 127]] * 4:]
+    assert tuple(t2[:4].view(np.int32)) == (20, 26, 1, 4)
+    img2 = t2[4:4 + 20 * 26].reshape(26, 20)
+    assert (img2[14:] == 0).all() and (img2[:13].max(axis=0) > 0).sum() >= 16
+    # the IES frame: rotation, its inverse in the second slot
+    for k in (1, 2, 3):
+        m, inv = L[k, 117:126].reshape(3, 3), L[k, 108:117].reshape(3, 3)
+        np.testing.assert_allclose(m @ inv, np.eye(3) * (m @ inv)[0, 0], atol=1e-5)
+        np.testing.assert_allclose(m @ inv, np.eye(3), atol=1e-5)

@@ -74,6 +74,16 @@ def gpu_atrium_tubes(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_ies(built):
+    """the closed hall lit through photometric webs: a point light and two rectangular area lights (one evaluated from its centre) with generated LM-63 files (clight.h:405-426, 465-495)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_ies_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_portal(built):
     """the open hall whose sky (lat-long texture) is sampled through a sky portal in the roof; a soft sun fills the header's sun table (clight.h:590-629, 1636-1695)"""
     from hydracore_amd import HipCore
@@ -219,7 +229,7 @@ def test_eye_rays(fix, request):
     np.testing.assert_allclose(dr[:, :3], rdr[:, :3], atol=2e-6)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_closest_hit_bit_exact(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     pos4, dir4 = random_rays(65536, 21) if not fix.startswith("gpu_atrium") else random_rays(65536, 21, center=(0.0, 4.0, 0.0), radius=3.0, spread=9.0)
@@ -281,7 +291,7 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
             core.set_option(k, {"trace_vote_wq": 1, "trace_vote_wt": 1, "trace_vote_wi": 2}[k])
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_persistent_counting_kernels_total_what_the_oracle_counts(fix, request):
     """k_trace_dyn<*, true> -- the kernels bench.py prices its roofline bytes with -- against the oracle's per-ray counters
     summed: rays, quads visited, instance quads entered, leaves visited, triangles tested; closest hit and the early-out
@@ -323,7 +333,7 @@ def test_surface_reconstruction(gpu224):
     np.testing.assert_allclose(surf[:, 18:20], ref[:, 18:20], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_light_and_material_functions_at_shading_points(fix, request):
     """rows a/L1, L2, S1, S2 one function at a time: light pick + LightSampleRev, materialEval, MaterialSampleAndEvalBxDF and
     flagsNextBounceLite on the device against the oracle, same surface points, same random numbers"""
@@ -346,7 +356,7 @@ class _HipBidir:
         self.camera_connect, self.mutate_kelemen = core.stage_camera_connect, core.stage_mutate_kelemen
 
 
-@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small")])
+@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small"), ("gpu_atrium_ies", "atrium_ies_small")])
 def test_bidirectional_building_blocks(fix, name, request):
     """row f3, first milestone: LightSampleForward, lightPdfFwd, CameraImageToSurfaceFactor + worldPosToScreenSpace and
     MutateKelemen on the device, against the oracle (same inputs, float-exact up to exp/log/sin/cos) and against the
@@ -364,7 +374,7 @@ def test_bidirectional_building_blocks(fix, name, request):
 
 
 @pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu42", "test_42"), ("gpu_atrium", "atrium_small"), ("gpu_atrium_lights", "atrium_lights_small"),
-                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small"), ("gpu_atrium_aniso", "atrium_aniso_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small")])
+                                      ("gpu_atrium_glass", "atrium_glass_small"), ("gpu_atrium_cutouts2", "atrium_cutouts2_small"), ("gpu_atrium_nmap", "atrium_nmap_small"), ("gpu_atrium_transl", "atrium_transl_small"), ("gpu_atrium_aniso", "atrium_aniso_small"), ("gpu_atrium_tubes", "atrium_tubes_small"), ("gpu_atrium_portal", "atrium_portal_small"), ("gpu_atrium_ies", "atrium_ies_small")])
 def test_mmlt_contribution_function(fix, name, request):
     """row f3: IntegratorMMLT::F in wavefront form (k_mmlt_* around the traversal kernels) against the oracle's restatement on the same
     primary-sample vectors, and against the reference's functions (tests/golden/ref_mmlt_<scene>.npz)"""
@@ -597,7 +607,7 @@ def test_mmlt_through_the_ihwlayer_adapter(built):
     assert abs(again.mean() - pt.mean()) < 0.15 * pt.mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_whole_paths(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -618,7 +628,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -722,7 +732,7 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""
@@ -796,7 +806,7 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
 
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small", "gpu_atrium_skyhdr": "atrium_skyhdr_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
-              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small", "gpu_atrium_tubes": "atrium_tubes_small", "gpu_atrium_portal": "atrium_portal_small"}
+              "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small", "gpu_atrium_tubes": "atrium_tubes_small", "gpu_atrium_portal": "atrium_portal_small", "gpu_atrium_ies": "atrium_ies_small"}
 
 
 @pytest.mark.parametrize("fix", list(FIXTURE_OF))

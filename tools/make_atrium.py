@@ -273,6 +273,9 @@ def main():
                     "that also lights the hall through the open roof")
     ap.add_argument("--tube-lights", action="store_true", help="closed hall; adds a cylinder light textured with the 256^2 checker, an untextured half cylinder and a mesh light "
                     "textured with the 128^2 checker (clight.h:753-830, 957-1062), each with its visible surface")
+    ap.add_argument("--ies", action="store_true", help="closed hall; adds a point light and two rectangular area lights (one evaluated from its centre, point_area) whose "
+                    "distribution is a photometric web: two generated IESNA LM-63 files, one covering the whole sphere without symmetry, one a quadrant of the lower hemisphere "
+                    "(clight.h:405-426, 465-495; IESRender.cpp)")
     ap.add_argument("--portal", action="store_true", help="like --sky-tex plus a soft sun; a 16 x 8 sky portal (area light with <sky_portal>, material sky_portal_mtl) lies in the "
                     "open roof and stands in for the sky light, which is then never sampled (clight.h:590-629, 1670-1695)")
     ap.add_argument("--glass", action="store_true", help="closed hall; pots = clear glass + Fresnel mirror, arches = rough (GGX) glass, column bands = "
@@ -326,6 +329,30 @@ def main():
         tl = globe(0.3, 8, 4, mat=14)
         tl["pos"][:, 1] *= 0.6
         meshes.append(("tlamp", tl))
+    ies_quad1 = ies_quad2 = None
+    if args.ies:
+        ies_quad1 = len(meshes)
+        q1 = light_quad(0.6, 0.3)
+        q1["mat"][:] = 12
+        meshes.append(("ies_panel", q1))
+        ies_quad2 = len(meshes)
+        q2 = light_quad(0.4, 0.4)
+        q2["mat"][:] = 13
+        meshes.append(("ies_panel2", q2))
+
+        def write_ies(path, vert, horz, fn):
+            with open(path, "w") as f:
+                f.write("IESNA:LM-63-1995\n[TEST] generated by tools/make_atrium.py\n[MANUFAC] none\nTILT=NONE\n")
+                f.write("1 1000 1 %d %d 1 2 0 0 0\n1 1 50\n" % (len(vert), len(horz)))
+                f.write(" ".join("%g" % v for v in vert) + "\n" + " ".join("%g" % v for v in horz) + "\n")
+                for hz in horz:
+                    f.write(" ".join("%.4f" % fn(np.radians(v), np.radians(hz)) for v in vert) + "\n")
+        # the whole sphere, no lateral symmetry: a downward lobe that leans towards phi = 60 degrees, a weaker upward one
+        write_ies(os.path.join(out, "data", "web_00001.ies"), np.arange(0, 181, 10), np.arange(0, 361, 45),
+                  lambda t, p: 800.0 * max(np.cos(t), 0.0) ** 2 * (1.0 + 0.6 * np.cos(p - 1.05)) + 150.0 * max(-np.cos(t), 0.0) + 20.0)
+        # a quadrant (0..90 degrees both ways) of the lower hemisphere: the file leaves the mirroring to the reader
+        write_ies(os.path.join(out, "data", "web_00002.ies"), np.arange(0, 91, 7.5), np.arange(0, 91, 22.5),
+                  lambda t, p: 600.0 * np.cos(t) ** 4 * (1.0 + 0.5 * np.cos(2 * p)) + 10.0)
     if args.portal:
         portal_mesh = len(meshes)
         pm = light_quad(8.0, 4.0)
@@ -455,6 +482,9 @@ def main():
         xml.append('  <material id="12" name="tube_mat" type="hydra_material" light_id="1" visible="1"><emission><color val="30 30 30" /></emission></material>')
         xml.append('  <material id="13" name="half_tube_mat" type="hydra_material" light_id="2" visible="1"><emission><color val="20 14 8" /></emission></material>')
         xml.append('  <material id="14" name="tlamp_mat" type="hydra_material" light_id="3" visible="1"><emission><color val="18 24 30" /></emission></material>')
+    if args.ies:
+        xml.append('  <material id="12" name="ies_panel_mat" type="hydra_material" light_id="2" visible="1"><emission><color val="20 20 18" /></emission></material>')
+        xml.append('  <material id="13" name="ies_panel2_mat" type="hydra_material" light_id="3" visible="1"><emission><color val="14 16 20" /></emission></material>')
     if args.portal:
         xml.append('  <material id="12" name="portal_mat" type="sky_portal_mtl" light_id="2" visible="1"><emission><color val="1 1 1" /><multiplier val="1.0" /></emission></material>')
     xml.append("</materials_lib>")
@@ -476,6 +506,12 @@ def main():
                   '<intensity><color val="1 0.7 0.4" /><multiplier val="20.0" /></intensity></light>'
                   '\n  <light id="3" name="tlamp" type="area" shape="mesh" distribution="uniform" visible="1" mat_id="14" mesh_id="%d">'
                   '<intensity><color val="0.6 0.8 1"><texture id="2" type="texref" /></color><multiplier val="30.0" /></intensity></light>' % (tube_mesh, half_tube_mesh, tlamp_mesh) if args.tube_lights else
+                  '\n  <light id="1" name="web_bulb" type="point" shape="point" distribution="ies" visible="1"><ies data="web_00001.ies" loc="data/web_00001.ies" matrix="0.8 0 0.6 0 0 1 0 0 -0.6 0 0.8 0 0 0 0 1" />'
+                  '<intensity><color val="1 0.9 0.7" /><multiplier val="120.0" /></intensity></light>'
+                  '\n  <light id="2" name="web_panel" type="area" shape="rect" distribution="ies" visible="1" mat_id="12" mesh_id="%d"><size half_length="0.6" half_width="0.3" />'
+                  '<ies data="web_00002.ies" loc="data/web_00002.ies" point_area="0" /><intensity><color val="1 1 0.9" /><multiplier val="60.0" /></intensity></light>'
+                  '\n  <light id="3" name="web_panel2" type="area" shape="rect" distribution="ies" visible="1" mat_id="13" mesh_id="%d"><size half_length="0.4" half_width="0.4" />'
+                  '<ies data="web_00001.ies" loc="data/web_00001.ies" point_area="1" matrix="1 0 0 0 0 0.8 -0.6 0 0 0.6 0.8 0 0 0 0 1" /><intensity><color val="0.7 0.8 1" /><multiplier val="80.0" /></intensity></light>' % (ies_quad1, ies_quad2) if args.ies else
                   '\n  <light id="1" name="bulb" type="point" shape="point" distribution="uniform" visible="1"><intensity><color val="1 0.8 0.6" /><multiplier val="40.0" /></intensity></light>'
                   '\n  <light id="2" name="spot" type="point" shape="point" distribution="spot" visible="1"><falloff_angle val="70" /><falloff_angle2 val="40" />'
                   '<intensity><color val="0.7 0.8 1" /><multiplier val="90.0" /></intensity></light>'
@@ -549,6 +585,11 @@ def main():
         add(tube_mesh, tube_m, ' light_id="1" linst_id="1"')
         add(half_tube_mesh, half_tube_m, ' light_id="2" linst_id="2"')
         add(tlamp_mesh, lamp_m, ' light_id="3" linst_id="3"')
+    ies_panel_m = mat4(yaw=0.5, t=(-7.0, 6.0, -2.0), rot_x=0.25)
+    ies_panel2_m = mat4(scale=1.2, yaw=-0.8, t=(8.0, 5.0, 2.5), rot_x=-0.3)
+    if args.ies:
+        add(ies_quad1, ies_panel_m, ' light_id="2" linst_id="2"')
+        add(ies_quad2, ies_panel2_m, ' light_id="3" linst_id="3"')
     if args.portal:
         add(portal_mesh, portal_m, ' light_id="2" linst_id="2"')
     xml.append('<scenes>\n  <scene id="0" name="atrium250k" discard="1" bbox="-20 20 0 10 -10 10">')
@@ -567,6 +608,10 @@ def main():
         xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % tube_m)
         xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % half_tube_m)
         xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % lamp_m)
+    if args.ies:
+        xml.append('    <instance_light id="1" light_id="1" matrix="%s" lgroup_id="-1" />' % mat4(yaw=0.9, t=(-1.0, 5.5, 1.5), rot_x=0.4))
+        xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % ies_panel_m)
+        xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % ies_panel2_m)
     if args.portal:
         xml.append('    <instance_light id="2" light_id="2" matrix="%s" lgroup_id="-1" />' % portal_m)
         xml.append('    <instance_light id="3" light_id="3" matrix="%s" lgroup_id="-1" />' % mat4(t=(0.0, 30.0, 0.0), rot_x=-0.35))
