@@ -305,6 +305,11 @@ class HipCore:
         return buf.value.decode()
 
     # ---- scene upload from host buffers (dict produced by HostScene.buffers())
+    def upload_globals(self, g):
+        """the [EngineGlobals | tables | lights] blob alone (the storages stay)"""
+        g = np.ascontiguousarray(g, dtype=np.int32)
+        self._ck(self.lib.hydra_hip_upload_globals(self.h, _ptr(g), g.size), "upload_globals")
+
     def upload_scene(self, b):
         L = self.lib
         g = np.ascontiguousarray(b["globals"], dtype=np.int32)

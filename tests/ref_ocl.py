@@ -341,3 +341,149 @@ class RefWavefront:
             for m in (T, M, L, R):      # the per-bounce buffers; the scene buffers stay
                 pass
         return rec
+
+
+class RefMmltWavefront:
+    """The reference's OWN MMLT stage kernels (hydra_drv/shaders/mlt.cl, compiled unmodified by oracle/build_ref.sh) launched in the order of its host
+    loop GPUOCLLayer::EvalSBDPT (GPUOCLLayerAdvanced.cpp:949-1024): MMLTMakeEyeRays -> MMLTInitCameraPath -> [traverse -> ComputeHit ->
+    MMLTCameraPathBounce] x maxBounce -> MMLTLightSampleForward -> [traverse -> ComputeHit -> MMLTLightPathBounce] x (maxBounce - 1) ->
+    MMLTMakeShadowRay -> shadow traversal -> MMLTConnect, for n primary-sample vectors with their (d, s) handed in.
+
+    The OpenCL layer keeps a vector transposed (number k of state i at [k * n + i]) and stores the ten numbers of a bounce as six packed words (four 24-bit
+    and six 16-bit integers, crandom.h:262-345, mlt.cl:637-660): `slots` holds those integers; float value = integer x (1 / 16777215) resp. x (1 / 65535), which is what
+    the CPU side (IntegratorMMLT, the oracle) is handed as its unpacked vector -- see unpacked()."""
+
+    def __init__(self, b, device=0):
+        self.b = b
+        self.mods = {k: RefModule(k + ".hsaco", device) for k in ("trace", "mlt")}
+        self.have_inst = int(b["have_inst"])
+
+    def close(self):
+        for m in self.mods.values():
+            m.close()
+
+    @staticmethod
+    def pack(slots):
+        """[n, nslots, 10] integers (0..3: 24-bit, 4..9: 16-bit) -> [n, nslots, 6] uint32 words (packBounceGroup / packBounceGroup2)"""
+        s = np.asarray(slots, np.uint32)
+        ix0, ix1, ix2, ix3, iy0, iy1 = (s[..., k] for k in range(6))
+        w = np.empty(s.shape[:-1] + (6,), np.uint32)
+        w[..., 0] = (ix0 & 0x00FFFFFF) | ((ix1 & 0x00FF0000) << 8)
+        w[..., 1] = (ix1 & 0x0000FFFF) | ((iy0 & 0x0000FFFF) << 16)
+        w[..., 2] = (ix2 & 0x00FFFFFF) | ((ix3 & 0x00FF0000) << 8)
+        w[..., 3] = (ix3 & 0x0000FFFF) | ((iy1 & 0x0000FFFF) << 16)
+        w[..., 4] = s[..., 6] | (s[..., 7] << 16)
+        w[..., 5] = s[..., 8] | (s[..., 9] << 16)
+        return w
+
+    @staticmethod
+    def unpacked(head, slots):
+        """the vector as the CPU integrator reads it: 12 head numbers + 10 floats per bounce slot (unpackBounceGroup's arithmetic)"""
+        s = np.asarray(slots, np.uint32).astype(np.float32)
+        f = np.empty(s.shape, np.float32)
+        f[..., :4] = s[..., :4] * np.float32(1.0 / 16777215.0)
+        f[..., 4:] = s[..., 4:] * np.float32(1.0 / 65535.0)
+        return np.concatenate([np.asarray(head, np.float32), f.reshape(len(head), -1)], axis=1)
+
+    def run(self, depth, split, head, slots):
+        b, n = self.b, len(depth)
+        T, M = self.mods["trace"], self.mods["mlt"]
+        f32, i32, u32 = np.float32, np.int32, np.uint32
+        max_d = int(np.max(depth))
+
+        def scene(m):
+            d = dict(glob=m.up(b["globals"]), mat=m.up(b["materials"]), tex=m.up(b["textures"]), geom=m.up(b["geom"]),
+                     pdf=m.up(b["pdfs"] if b["pdfs"].size else np.zeros(4, f32)), bvh=m.up(b["bvh_nodes"]), tris=m.up(b["bvh_tris"]),
+                     matrices=m.up(b["inst_matrices"]), light_id=m.up(b["inst_light_id"]),
+                     texaux=m.up(b["textures_aux"]) if b.get("textures_aux", np.zeros(0)).size else 0,
+                     remap_lists=m.up(b["remap_lists"] if b["remap_lists"].size else np.zeros(4, i32)),
+                     remap_table=m.up(b["remap_table"] if b["remap_table"].size else np.zeros(4, i32)),
+                     remap_inst=m.up(b["remap_inst"] if b["remap_inst"].size else np.zeros(4, i32)))
+            if not d["texaux"]:
+                d["texaux"] = d["tex"]
+            return d
+        sT, sM = scene(T), scene(M)
+        n_remap_table = b["remap_table"].size // 2
+        n_inst = b["inst_matrices"].size // 16
+        width, height = int(b["width"]), int(b["height"])
+        lsc = float(width * height)
+        # the vector, transposed: 12 head numbers, then 6 words per slot
+        words = self.pack(slots)
+        nslots = words.shape[1]
+        vec = np.empty((12 + 6 * nslots, n), f32)
+        vec[:12] = np.asarray(head, f32).T
+        vec[12:] = words.reshape(n, nslots * 6).T.view(f32)
+        morton = np.array([sum(((i >> k) & 1) << (2 * k) for k in range(8)) for i in range(256)], np.uint16)
+        m_vec, m_morton = M.up(vec), M.up(morton)
+        m_split = M.up(np.stack([depth, split], 1).astype(i32))
+        m_rpos, m_rdir, m_zind = M.alloc(n * 16), M.alloc(n * 16), M.alloc(n * 8)
+        m_flags, m_color = M.alloc(n * 4), M.alloc(n * 16)
+        m_cvsup, m_lvsup = M.alloc(n * 32), M.alloc(n * 32)
+        m_pdf = M.up(np.ones((max_d + 2, n, 2), f32))
+        m_gens = M.up(np.zeros((n, 2), u32))
+        mis0 = np.zeros((n, 4), f32); mis0[:, 0] = 1.0; mis0[:, 1] = 1.0          # makeInitialMisData (ClearAllInternalTempBuffers, screen.cl:381-406)
+        mis0.view(i32)[:, 2] = -1; mis0.view(i32)[:, 3] = 1
+        m_mis, m_fog = M.up(mis0), M.up(np.zeros((n, 4), f32))
+        M.launch("MMLTMakeEyeRays", n, [("p", m_vec), ("p", m_rpos), ("p", m_rdir), ("p", m_zind), ("p", m_morton), ("p", sM["glob"]), ("i", n)], block=256)
+        M.launch("MMLTInitCameraPath", n, [("p", m_flags), ("p", m_color), ("p", m_split), ("p", m_cvsup), ("p", m_pdf), ("i", n)], block=256)
+        hit_dt = np.dtype([("t", f32), ("primId", i32), ("instId", i32), ("geomId", i32)])
+
+        def trace_and_hit():
+            rpos, rdir, flags = M.down(m_rpos, f32, (n, 4)), M.down(m_rdir, f32, (n, 4)), M.down(m_flags, u32, (n,))
+            d_rpos, d_rdir, d_flags, d_hits, d_surf = T.up(rpos), T.up(rdir), T.up(flags), T.alloc(n * 16), T.alloc(n * 64)
+            T.launch("BVH4TraversalInstKernel" if self.have_inst else "BVH4TraversalKernel", n,
+                     [("p", d_rpos), ("p", d_rdir), ("p", sT["bvh"]), ("p", sT["tris"]), ("p", d_flags), ("p", d_hits), ("i", 0), ("i", n)], block=256)
+            T.launch("ComputeHit", n, [("p", d_rpos), ("p", d_rdir), ("p", d_hits), ("p", sT["matrices"]), ("p", sT["geom"]), ("p", sT["mat"]),
+                                       ("p", sT["remap_lists"]), ("p", sT["remap_table"]), ("p", sT["remap_inst"]), ("p", d_flags), ("p", d_surf),
+                                       ("p", sT["glob"]), ("i", n_remap_table), ("i", n_inst), ("i", n)], block=256)
+            hits, surf, flags = T.down(d_hits, hit_dt, (n,)), T.down(d_surf, f32, (4, n, 4)), T.down(d_flags, u32, (n,))
+            return hits, surf, flags
+        # (1) camera pass
+        cv_surf = np.zeros((4, n, 4), f32)
+        m_cvhit = M.up(cv_surf)
+        for bounce in range(1, max_d + 1):
+            hits, surf, flags = trace_and_hit()
+            # the layer's ComputeHit writes into cameraVertexHit for the threads still running; a finished thread keeps the vertex it ended on
+            act = ((flags >> 16) & (4096 | 128)) == 0
+            prev = M.down(m_cvhit, f32, (4, n, 4))
+            prev[:, act] = surf[:, act]
+            m_cvhit = M.up(prev)
+            m_hits, m_fl = M.up(hits), M.up(flags)
+            m_flags = m_fl
+            M.launch("MMLTCameraPathBounce", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_gens), ("p", m_vec), ("p", m_split), ("p", m_hits), ("p", sM["light_id"]),
+                                                 ("p", m_cvhit), ("p", 0), ("p", m_color), ("p", m_mis), ("p", m_fog), ("p", m_pdf), ("p", m_cvsup),
+                                                 ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n), ("f", lsc)], block=256)
+        cv_sup = M.down(m_cvsup, f32, (2, n, 4))
+        # (2) light pass
+        M.launch("MMLTLightSampleForward", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_gens), ("p", m_vec), ("p", m_color), ("p", m_pdf), ("p", m_lvsup), ("p", m_mis),
+                                               ("p", sM["tex"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
+        m_lvhit = M.up(np.zeros((4, n, 4), f32))
+        for bounce in range(1, max_d):
+            hits, surf, flags = trace_and_hit()
+            act = ((flags >> 16) & (4096 | 128)) == 0
+            prev = M.down(m_lvhit, f32, (4, n, 4))
+            prev[:, act] = surf[:, act]
+            m_lvhit = M.up(prev)
+            m_flags = M.up(flags)
+            M.launch("MMLTLightPathBounce", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_gens), ("p", m_vec), ("p", m_split), ("p", m_lvhit), ("p", 0),
+                                                ("p", m_color), ("p", m_mis), ("p", m_fog), ("p", m_pdf), ("p", m_lvsup),
+                                                ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
+        lv_sup = M.down(m_lvsup, f32, (2, n, 4))
+        # (3) connection
+        m_srpos, m_srdir, m_srflags, m_lssam = M.alloc(n * 16), M.alloc(n * 16), M.alloc(n * 4), M.up(np.zeros((3, n, 4), f32))
+        M.launch("MMLTMakeShadowRay", n, [("p", m_split), ("p", m_lvhit), ("p", m_lvsup), ("p", m_cvhit), ("p", m_cvsup), ("p", m_srpos), ("p", m_srdir), ("p", m_srflags), ("p", m_lssam),
+                                          ("p", m_gens), ("p", m_vec), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["tex"]), ("p", sM["glob"]), ("i", n)], block=256)
+        srpos, srdir, srflags = M.down(m_srpos, f32, (n, 4)), M.down(m_srdir, f32, (n, 4)), M.down(m_srflags, u32, (n,))
+        t_shadow = T.alloc(n * 8)
+        T.launch("BVH4TraversalInstShadowKenrel" if self.have_inst else "BVH4TraversalShadowKenrel", n,
+                 [("p", T.up(srflags)), ("p", T.up(srpos)), ("p", T.up(srdir)), ("p", t_shadow), ("p", sT["bvh"]), ("p", sT["tris"]), ("p", sT["glob"]), ("i", 0), ("i", n)], block=256)
+        shadow = T.down(t_shadow, np.uint16, (n, 4))
+        m_out = M.alloc(n * 16)
+        m_scale = M.up(np.ones(max_d + 2, f32))
+        M.launch("MMLTConnect", n, [("p", m_split), ("p", m_lvhit), ("p", m_lvsup), ("p", m_cvhit), ("p", m_cvsup), ("p", 0), ("p", M.up(shadow)), ("p", m_lssam), ("p", m_pdf),
+                                    ("p", m_out), ("p", m_zind), ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("p", m_scale), ("p", m_morton),
+                                    ("i", n), ("f", lsc), ("i", n)], block=256)
+        out = M.down(m_out, f32, (n, 4))
+        xy = out[:, 3].view(u32)
+        return dict(color=out[:, :3].copy(), x=(xy & 0xFFFF).astype(i32), y=(xy >> 16).astype(i32), cv_sup=cv_sup, lv_sup=lv_sup, shadow=shadow,
+                    pdf=M.down(m_pdf, f32, (max_d + 2, n, 2)), srpos=srpos, srdir=srdir)

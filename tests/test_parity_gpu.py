@@ -804,6 +804,22 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
         assert (outs[0][3].view(np.uint32) == o[3].view(np.uint32)).all() and outs[0][4:] == o[4:]
 
 
+@pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu_atrium", "atrium_small")])
+def test_hip_against_the_reference_mmlt_stage_kernels(fix, name, request):
+    """IntegratorMMLT::F on the device (the wavefront k_mmlt_* kernels, hydra_hip_stage_mmlt_f) DIRECTLY against the reference's own MMLT stage kernels (shaders/mlt.cl, unmodified,
+    launched in the order of GPUOCLLayer::EvalSBDPT; tests/golden/ref_mmlt_stage_<scene>.npz) -- no oracle in between.  The listed deliberate differences of the OpenCL layer and the
+    bar that follows from them: tests/test_golden_ref.py check_mmlt_stage"""
+    from test_golden_ref import check_mmlt_stage
+    core, b, orc = request.getfixturevalue(fix)
+    g = b["globals"].copy()
+    g[64 + 34] = 4                                                                       # HRT_MMLT_FIRST_BOUNCE: m_splitDLByGrammar on, as the OpenCL layer's compile-time SPLIT_DL_BY_GRAMMAR
+    core.upload_globals(g)
+    try:
+        check_mmlt_stage(name, core.stage_mmlt_f, int(b["width"]), int(b["height"]))
+    finally:
+        core.upload_globals(b["globals"])
+
+
 FIXTURE_OF = {"gpu224": "test_224", "gpu42": "test_42", "gpu_atrium": "atrium_small", "gpu_atrium_sky": "atrium_sky_small", "gpu_atrium_skytex": "atrium_skytex_small", "gpu_atrium_skyhdr": "atrium_skyhdr_small",
               "gpu_atrium_lights": "atrium_lights_small", "gpu_atrium_glass": "atrium_glass_small", "gpu_atrium_ggx": "atrium_ggx_small",
               "gpu_atrium_cutouts": "atrium_cutouts_small", "gpu_atrium_cutouts2": "atrium_cutouts2_small", "gpu_atrium_nmap": "atrium_nmap_small", "gpu_atrium_transl": "atrium_transl_small", "gpu_atrium_aniso": "atrium_aniso_small", "gpu_atrium_perez": "atrium_perez_small", "gpu_atrium_tubes": "atrium_tubes_small", "gpu_atrium_portal": "atrium_portal_small", "gpu_atrium_ies": "atrium_ies_small"}
