@@ -487,3 +487,40 @@ class RefMmltWavefront:
         xy = out[:, 3].view(u32)
         return dict(color=out[:, :3].copy(), x=(xy & 0xFFFF).astype(i32), y=(xy >> 16).astype(i32), cv_sup=cv_sup, lv_sup=lv_sup, shadow=shadow,
                     pdf=M.down(m_pdf, f32, (max_d + 2, n, 2)), srpos=srpos, srdir=srdir)
+
+
+class RefGBufferKernels:
+    """The reference's OWN G-buffer kernels in the order of GPUOCLLayer::EvalGBuffer (GPUOCLLayerOther.cpp:742-765): MakeEyeRaysSPP (screen.cl:35, GBUFFER_SAMPLES = 64 plane
+    Hammersley samples per pixel) -> traversal -> ComputeHit -> GetGBufferSample (material.cl:1347, one work-group of 64 per pixel), compiled unmodified.  Returns the two packed
+    float4 layers.  (The layer's further steps -- transparent bounces and PutAlphaToGBuffer for the alpha channel -- have no counterpart in CPUExp_GBuffer.cpp and are not run.)"""
+
+    def __init__(self, b, device=0):
+        self.b = b
+        self.mods = {k: RefModule(k + ".hsaco", device) for k in ("trace", "material", "screen")}
+        self.have_inst = int(b["have_inst"])
+
+    def close(self):
+        for m in self.mods.values():
+            m.close()
+
+    def run(self):
+        b = self.b
+        T, M, S = self.mods["trace"], self.mods["material"], self.mods["screen"]
+        f32, i32, u32 = np.float32, np.int32, np.uint32
+        w, h = int(b["width"]), int(b["height"])
+        n = w * h * 64
+        glob, mat, tex = T.up(b["globals"]), T.up(b["materials"]), T.up(b["textures"])     # one device, one context: pointers are good in every module
+        texaux = T.up(b["textures_aux"]) if b.get("textures_aux", np.zeros(0)).size else tex
+        geom, bvh, tris, matrices = T.up(b["geom"]), T.up(b["bvh_nodes"]), T.up(b["bvh_tris"]), T.up(b["inst_matrices"])
+        remap_lists = T.up(b["remap_lists"] if b["remap_lists"].size else np.zeros(4, i32))
+        remap_table = T.up(b["remap_table"] if b["remap_table"].size else np.zeros(4, i32))
+        remap_inst = T.up(b["remap_inst"] if b["remap_inst"].size else np.zeros(4, i32))
+        rpos, rdir, flags, hits, surf = T.alloc(n * 16), T.alloc(n * 16), T.alloc(n * 4), T.alloc(n * 16), T.alloc(n * 64)
+        S.launch("MakeEyeRaysSPP", n, [("p", rpos), ("p", rdir), ("i", w), ("i", h), ("i", 64), ("i", 0), ("p", T.up(plane_hammersley(64))), ("p", glob)], block=256)
+        T.launch("BVH4TraversalInstKernel" if self.have_inst else "BVH4TraversalKernel", n,
+                 [("p", rpos), ("p", rdir), ("p", bvh), ("p", tris), ("p", flags), ("p", hits), ("i", 0), ("i", n)], block=256)
+        T.launch("ComputeHit", n, [("p", rpos), ("p", rdir), ("p", hits), ("p", matrices), ("p", geom), ("p", mat), ("p", remap_lists), ("p", remap_table), ("p", remap_inst),
+                                   ("p", flags), ("p", surf), ("p", glob), ("i", b["remap_table"].size // 2), ("i", b["inst_matrices"].size // 16), ("i", n)], block=256)
+        g1, g2 = T.alloc(w * h * 16), T.alloc(w * h * 16)
+        M.launch("GetGBufferSample", n, [("p", rdir), ("p", hits), ("p", flags), ("p", surf), ("p", 0), ("p", g1), ("p", g2), ("p", mat), ("p", tex), ("p", texaux), ("p", glob), ("i", n)], block=64)
+        return T.down(g1, f32, (h, w, 4)), T.down(g2, f32, (h, w, 4))

@@ -804,6 +804,21 @@ def test_leaf_count_links_and_lds_quads_do_not_change_hits_or_counters(built, na
         assert (outs[0][3].view(np.uint32) == o[3].view(np.uint32)).all() and outs[0][4:] == o[4:]
 
 
+@pytest.mark.parametrize("name,depth,dof", [("test_42", 4, 1), ("atrium_small", 5, 0), ("atrium_transl_small", 5, 0)])
+def test_hip_against_the_reference_gbuffer_stage_kernels(name, depth, dof, built):
+    """IHWLayer::EvalGBuffer on the device DIRECTLY against the reference's own G-buffer kernels (MakeEyeRaysSPP, traversal, ComputeHit, GetGBufferSample, unmodified;
+    tests/golden/ref_gbuffer_stage_<scene>.npz): which sample wins, the ids and the coverage; the colour / normal averaging of the OpenCL kernel is its own (check_gbuffer_stage)"""
+    from test_golden_ref import check_gbuffer_stage
+    from hydracore_amd import HipCore
+    _, b = host_scene(name, 96, 96, depth, dof)                                            # a square frame: see check_gbuffer_stage
+    core = HipCore(96, 96, device=0)
+    core.upload_scene(b)
+    try:
+        check_gbuffer_stage(name, core.eval_gbuffer(96, 96))
+    finally:
+        core.close()
+
+
 @pytest.mark.parametrize("fix,name", [("gpu224", "test_224"), ("gpu_atrium", "atrium_small")])
 def test_hip_against_the_reference_mmlt_stage_kernels(fix, name, request):
     """IntegratorMMLT::F on the device (the wavefront k_mmlt_* kernels, hydra_hip_stage_mmlt_f) DIRECTLY against the reference's own MMLT stage kernels (shaders/mlt.cl, unmodified,
