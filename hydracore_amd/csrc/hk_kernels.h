@@ -402,7 +402,9 @@ HK_DEV void k_hit_body(const SceneDev& s, const SegQ& q, uint32_t* __restrict__ 
     LightPick lp;
     lp.shadowOrg = make_float4(0, 0, 0, -1.0f);
     if (idx < count) {
-      pos4 = S.pos4[i]; dir4 = S.dir4[i]; thr4 = S.thr4[i]; acc4 = S.acc4[i];
+      pos4 = S.pos4[i]; dir4 = S.dir4[i];
+      if (depth > 0) { thr4 = S.thr4[i]; acc4 = S.acc4[i]; }
+      else { thr4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f); acc4 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); }   // what every path starts with: not stored by k_raygen, see there
       const uint2 g2 = S.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
       const float4 h4 = reinterpret_cast<const float4*>(hits)[i];
@@ -605,8 +607,12 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
     SurfaceHit surf;
     f3 finalColor = mk3(0, 0, 0);
     if (idx < count) {
-      pos4 = Sin.pos4[i]; dir4 = Sin.dir4[i]; thr4 = Sin.thr4[i]; acc4 = Sin.acc4[i];
+      pos4 = Sin.pos4[i]; dir4 = Sin.dir4[i];
+      // a path starts with throughput 1, MIS pdf 1, no radiance, "previous bounce specular" (kernel_InitAccumData + makeInitialMisData): constants, so k_raygen
+      // does not write them and the first bounce does not read them (64 B less per path and sample through HBM)
+      thr4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f); acc4 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
       if (depth > 0) {   // settle the previous bounce's next-event estimate
+        thr4 = Sin.thr4[i]; acc4 = Sin.acc4[i];
         const float4 pend = Sin.pend4[i];
         const float vis = sh.vis[i];
         acc4.x = acc4.x + pend.x * vis; acc4.y = acc4.y + pend.y * vis; acc4.z = acc4.z + pend.z * vis;

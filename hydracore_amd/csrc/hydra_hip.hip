@@ -62,8 +62,8 @@ __global__ void k_raygen(SceneDev s, SegQ q, const int* __restrict__ ownedPixels
     MakeRandEyeRay(pixel % w, pixel / w, w, h, offs, s, pos, dir);
     S.pos4[i] = mk4(pos, as_float(gid));
     S.dir4[i] = mk4(dir, as_float(0));
-    S.thr4[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // kernel_InitAccumData + makeInitialMisData (pdf = 1)
-    S.acc4[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // isSpecular = 1
+    // thr4 = (1, 1, 1 | MIS pdf 1) and acc4 = (0, 0, 0 | isSpecular 1) (kernel_InitAccumData + makeInitialMisData) are the same for every path: the bounce
+    // kernels put them in at depth 0 instead of reading them, so they are not written here
     S.rng2[i] = make_uint2(gen.x, gen.y);
   }
 }
