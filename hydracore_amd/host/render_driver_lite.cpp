@@ -416,6 +416,14 @@ int32_t RenderDriverLite::AuxNormalMapFor(int32_t texId, int32_t a_matId) {
 // CreateFromHydraMaterialXmlNode + CreateMaterialFromXmlNode, PlainMaterialConverter.cpp:1502-1738
 bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const std::string mtype = a_node->attr("type");
+  if (!m_procTexIds.empty()) {   // a texture slot bound to a procedural texture (<texture type="proc">: user code the OpenCL layer compiles into its kernels, shaders/texproc.cl)
+    std::function<void(const XmlNode*)> scan = [&](const XmlNode* n) {
+      if (n->name == "texture" && n->has_attr("id") && m_procTexIds.count(n->attr_int("id")))
+        Unsupported("material " + std::to_string(a_matId) + " binds procedural texture " + std::to_string(n->attr_int("id")) + " (DESIGN.md 8.7)");
+      for (const auto& ch : n->children) scan(ch.get());
+    };
+    scan(a_node);
+  }
   if (mtype == "shadow_catcher") {   // ShadowMatteMaterial, PlainMaterialConverter.cpp:77-99, 1638-1660: a bare node of class SHADOW_MATTE; no bump, opacity or emission (:1710).
     // The CPU integrator hands its sampler a zero shadow value (PT_Loop.cpp:240), so the surface passes rays on with zero throughput; the
     // back-plate texture of <back> belongs to the OpenCL layer's environmentColorExtended and is not read here
@@ -1717,6 +1725,7 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
 
   if (texLib)
     for (auto* t : texLib->children_named("texture")) {
+      if (std::string(t->attr("type")) == "proc") { m_procTexIds.insert(t->attr_int("id")); continue; }   // declared only: refused when a material binds it (UpdateMaterial)
       if (!t->has_attr("loc")) continue;                       // delayed-load textures without data (dl="1")
       std::vector<char> d;
       if (!read_file(libPath + "/" + t->attr("loc"), d) || d.size() < 8) { m_log += std::string("missing texture chunk ") + t->attr("loc") + "\n"; continue; }

@@ -12,6 +12,7 @@
 #include <vector>
 #include <memory>
 #include <map>
+#include <set>
 #include "hw_layer.h"
 #include "bvh4_builder.h"
 #include "xml_mini.h"
@@ -93,6 +94,7 @@ private:
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
   bool m_sceneHaveSkyPortals = false;
+  std::set<int32_t> m_procTexIds;                                         // ids of <texture type="proc"> declarations
   std::vector<int32_t> m_lightIdByInst;                                   // light id of every instanced record
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
 
