@@ -1199,6 +1199,8 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     if (blob[at + HL_TYPE] != HLT_SKY_DOME) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: skyLightId does not name a sky light");
   }
   int lightFeat = (skyId != -1 && lightsNum > 0) ? HK_FEAT_SKY : 0;
+  if (lightsNum < 0 || (lightsNum > 0 && (blob[HG_LIGHTS_OFFS] < 0 || size_t(blob[HG_LIGHTS_OFFS]) + size_t(lightsNum) * HL_FLOATS > words)))
+    return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");   // checked as a whole first: a portal's record offset names another record of it
   for (int i = 0; i < blob[HG_LIGHTS_NUM]; i++) {   // LightSampleRev knows area (rect/disk/spot cone), sphere, sky-dome, point, spot and directional lights
     const size_t at = size_t(blob[HG_LIGHTS_OFFS]) + size_t(i) * HL_FLOATS;
     if (at + HL_FLOATS > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: lights table runs past the blob");
@@ -1215,6 +1217,11 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
     }
     if (type == HLT_CYLINDER || (type == HLT_AREA && (blob[at + HL_FLAGS] & HLF_SKY_PORTAL)) || (type == HLT_MESH && uint32_t(blob[at + HL_MESH_TEXMATRIX_ID]) != HYDRA_INVALID_TEXTURE))
       lightFeat |= HK_FEAT_RARE_LIGHTS;   // only the all-features instantiations carry them
+    if (type == HLT_CYLINDER || type == HLT_MESH) {   // the colour sampler sits inside the record, addressed in float4 units
+      const uint32_t so = uint32_t(blob[at + (type == HLT_CYLINDER ? HL_CYL_TEXMATRIX_ID : HL_MESH_TEXMATRIX_ID)]);
+      if (so != HYDRA_INVALID_TEXTURE && (so * 4u + 12u > uint32_t(HL_FLOATS)))
+        return fail(c, HYDRA_HIP_EINVAL, "upload_globals: light " + std::to_string(i) + " places its colour sampler outside its own record");
+    }
     if (type == HLT_CYLINDER) {
       const int tab = blob[at + HL_CYL_PDF_TABLE_ID];
       if (tab < 0 || tab >= blob[HG_PDF_TABLE_SIZE])

@@ -1182,6 +1182,33 @@ def test_materials_the_layer_does_not_shade_are_refused(gpu224):
         core.close()
 
 
+def test_light_records_the_layer_cannot_follow_are_refused(built):
+    """upload_globals checks what the device code will dereference in the new light records: a portal's record offset must lead to a sky dome of the table, a cylinder
+    light needs its 2-D table, an IES light its image and table in the pdf-table table, a colour sampler must lie inside its own record, the sun count must be 0..8"""
+    from hydracore_amd import HipCore, HydraError
+    cases = [("atrium_portal_small", 2, 29, 5, "sky portal"), ("atrium_tubes_small", 1, 31, -1, "cylinder light"), ("atrium_tubes_small", 1, 30, 40, "colour sampler"),
+             ("atrium_tubes_small", 3, 31, 33, "colour sampler"), ("atrium_ies_small", 1, 127, 100000, "IES light"), ("atrium_ies_small", 2, 126, -7, "IES light")]
+    for name, light, word, value, what in cases:
+        _, b = host_scene(name, 96, 54, 5)
+        g = b["globals"].copy()
+        g[g[236] + light * 128 + word] = value
+        core = HipCore(32, 32, device=0)
+        with pytest.raises(HydraError, match=what):
+            core.upload_globals(g)
+        core.close()
+    _, b = host_scene("atrium_portal_small", 96, 54, 5)
+    g = b["globals"].copy()
+    g[242] = 9
+    core = HipCore(32, 32, device=0)
+    with pytest.raises(HydraError, match="sunNumber"):
+        core.upload_globals(g)
+    g[242] = 8
+    g[238] = 1 << 20                                                                     # a lights table longer than the blob
+    with pytest.raises(HydraError, match="lights table"):
+        core.upload_globals(g)
+    core.close()
+
+
 @pytest.mark.parametrize("scene,light_max", [("test_224", 160.0), ("atrium250k_sky", 60.0), ("atrium250k", 60.0)])
 def test_full_size_properties_1080p(built, scene, light_max):
     """BASELINE configs[1] and configs[2] sizes: 1920x1080, 8 bounces.  Size-independent properties only (the oracle is too
