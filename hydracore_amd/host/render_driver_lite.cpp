@@ -879,14 +879,17 @@ bool RenderDriverLite::UpdateDeltaLight(int32_t a_lightId, const XmlNode* a_node
     put_i(d, HL_IES_SPHERE_TEX_ID, int32_t(HYDRA_INVALID_TEXTURE));
     put_i(d, HL_IES_SPHERE_PDF_ID, int32_t(HYDRA_INVALID_TEXTURE));
     const XmlNode* iesNode = a_node->child("ies");             // PointLight with a photometric web, PlainLightConverter.cpp:640-697
-    if (a_node->child("honio")) Unsupported("honio light distribution (light " + std::to_string(a_lightId) + ")");
     if (iesNode && iesNode->has_attr("loc") && distr == "ies") {
       const auto ids = AddIesTexTable(iesNode->attr("loc"));
       if (ids.first >= 0 && ids.second >= 0) {
         put_i(d, HL_IES_SPHERE_TEX_ID, ids.first);
         put_i(d, HL_IES_SPHERE_PDF_ID, ids.second);
         put_i(d, HL_FLAGS, HLF_HAS_IES);
-        put_ies_matrix(d, iesNode, true);
+        // the frame of the web: <ies matrix> turned 90 degrees about Y, else a <honio matrix> as it is, else identity (:640-656)
+        const XmlNode* honio = a_node->child("honio");
+        if (iesNode->has_attr("matrix")) put_ies_matrix(d, iesNode, true);
+        else if (honio && honio->has_attr("matrix")) put_ies_matrix(d, honio, false);
+        else put_ies_matrix(d, nullptr, false);
         lp.hasIes = true;
       }
     }
