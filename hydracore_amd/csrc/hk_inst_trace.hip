@@ -22,7 +22,10 @@ void hk_launch_trace_dyn(bool anyhit, bool count, bool toptris, bool alpha, cons
     else { if (count) HK_LV(false, true, false, false); else HK_LV(false, false, false, false); }
   } else {                                                                                                     // shadow rays: tree 0 without the alpha test (Common.cpp:156-180)
     if (toptris) { if (count) HK_LV(true, true, true, false); else HK_LV(true, false, true, false); }
-    else { if (count) HK_LV(true, true, false, false); else HK_LV(true, false, false, false); }
+    else if (count) HK_LV(true, true, false, false);
+    else if (a.vote && a.unordered)
+      hipLaunchKernelGGL((k_trace_dyn<true, false, false, false, true, true>), dim3(a.grid), dim3(HK_TRACE_BLOCK), 0, a.stream, a.s, a.q, a.fetchCounters, a.a4, a.b4, out, a.vis, a.totals5, a.minActive, a.raysPerLane, a.wq, a.wt, a.wi);
+    else HK_LV(true, false, false, false);
   }
 #undef HK_LV
 #undef HK_L

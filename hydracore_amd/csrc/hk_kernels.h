@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, HK_TRACE_MIN_BLOCKS) k_shadow(
 // written by ray index, so they are identical to the one-ray-per-lane kernels above.
 // VOTE: the steps of the wave's rays are scheduled by wave vote (trav_run_vote, hk_trace.h) instead of the reference's loop nest;
 // wq / wt / wi = the weights of the vote.
-template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false, bool VOTE = false>
+template <bool ANYHIT, bool COUNT, bool TOPTRIS = false, bool ALPHA = false, bool VOTE = false, bool UNORD = false>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_MIN_WAVES_SHADOW : HK_TRACE_MIN_BLOCKS) k_trace_dyn(SceneDev s, SegQ q, uint32_t* __restrict__ fetchCounters,
                                                                const float4* __restrict__ a4, const float4* __restrict__ b4,
                                                                float4* __restrict__ outHits, float* __restrict__ outVis,
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
     if (__ballot(busy) == 0ull) break;
     bool done = false;
     if (VOTE) {
-      trav_run_vote<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, busy, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive, wq, wt, wi);
+      trav_run_vote<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA, UNORD>(t, busy, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive, wq, wt, wi);
       done = busy && t.top < 0;
     } else if (busy) done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
     if (done) {
@@ -745,6 +745,7 @@ struct TraceLaunch {          // one traversal launch: rays a4 (origin | t_far f
   uint32_t* perRay3; unsigned long long* totals5; uint32_t* fetchCounters;
   int carry, minActive, raysPerLane;
   int vote, wq, wt, wi;       // persistent kernels: schedule by wave vote (trav_run_vote) with these weights, or 0 = the reference's loop nest
+  int unordered = 0;          // shadow rays under the vote: children of a quad in stored order (k_trace_dyn<..., UNORD>)
 };
 void hk_launch_trace_static(bool count, bool alpha, const TraceLaunch& a);                          // k_trace<COUNT, ALPHA>
 void hk_launch_shadow_static(bool count, const TraceLaunch& a);                                     // k_shadow<COUNT>

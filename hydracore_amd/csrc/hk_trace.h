@@ -257,7 +257,7 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
 // test, and their order -- is the same whatever schedules them (trav_run: the reference's loop nest; trav_run_vote: by wave vote).
 
 // one quad: fetch its 4 child boxes, test, order near -> far, push, descend or pop (ctrace.h:866-1006)
-template <bool COUNT, bool TOPCACHE, class STACK>
+template <bool COUNT, bool TOPCACHE, class STACK, bool SORTED = true>
 HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst, const float t_rayMin, STACK& stack, TravCounters& cnt) {
   float4 n0a, n0b, n1a, n1b, n2a, n2b, n3a, n3b;
   if (TOPCACHE && (t.left & HK_TOP_FLAG)) {   // one of the hottest quads: 8 LDS reads instead of 8 trips through the texture addresser
@@ -289,6 +289,19 @@ HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst,
   float k1 = ((t1.x <= t1.y) && (t1.y >= t_rayMin) && (t1.x <= t.hit.t) && v1) ? t1.x : HK_MAXFLOAT;
   float k2 = ((t2.x <= t2.y) && (t2.y >= t_rayMin) && (t2.x <= t.hit.t) && v2) ? t2.x : HK_MAXFLOAT;
   float k3 = ((t3.x <= t3.y) && (t3.y >= t_rayMin) && (t3.x <= t.hit.t) && v3) ? t3.x : HK_MAXFLOAT;
+  if (!SORTED) {   // any-hit rays only (the answer -- is anything in the way -- does not depend on the order): the children that were hit in stored order, no sorting network
+    const bool h0 = k0 < HK_MAXFLOAT, h1 = k1 < HK_MAXFLOAT, h2 = k2 < HK_MAXFLOAT, h3 = k3 < HK_MAXFLOAT;
+    const bool stackHaveSpace = (t.top < HK_STACK_SIZE);
+    if (h3 && (h0 || h1 || h2) && stackHaveSpace) { stack.put(t.top, c3); t.top++; }
+    if (h2 && (h0 || h1) && stackHaveSpace) { stack.put(t.top, c2); t.top++; }
+    if (h1 && h0 && stackHaveSpace) { stack.put(t.top, c1); t.top++; }
+    if (h0 || h1 || h2 || h3) t.left = h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3));
+    else if (t.top >= 0) { t.top--; t.left = stack.get(t.top); }
+    t.searching = !(t.left & int(HYDRA_BVH_LEAF)) && (t.top >= 0);
+    t.left = t.left & 0x7fffffff;
+    if (haveInst && t.top < t.instTop && t.instDeep == 1) { t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0; }
+    return;
+  }
 #define HK_CSWAP(ka, kb, ca, cb) { const bool sw = (kb < ka); const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; const int tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
   HK_CSWAP(k0, k1, c0, c1) HK_CSWAP(k2, k3, c2, c3) HK_CSWAP(k0, k2, c0, c2) HK_CSWAP(k1, k3, c1, c3) HK_CSWAP(k1, k2, c1, c2)
 #ifdef HK_EXP_EXTRA_SORT   /* timing experiment: the network again on sorted keys changes nothing but costs its ~25 VALU instructions */
@@ -481,9 +494,12 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
 #define HK_BALLOT(x) __ballot(x)
 #define HK_POPC(m) __popcll(m)
 #endif
-template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false>
+// UNORD (any-hit, non-counting kernels only; option shadow_unordered): a quad's children are taken in stored order instead of near to far; closest-hit rays and the
+// counting kernels always walk near to far, as BVH4InstTraverse / BVH4InstTraverseShadow do
+template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false, bool UNORD = false>
 HK_DEV void trav_run_vote(TravState& t, const bool busy, const BvhView& bv, const bool haveInst,
                           const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive, const int wq, const int wt, const int wi) {
+  static_assert(!UNORD || (ANYHIT && !COUNT), "only an any-hit query is independent of the order");
   while (true) {
     const bool alive = busy && t.top >= 0;
     const bool atInst = haveInst && t.instDeep == 0;
@@ -492,7 +508,7 @@ HK_DEV void trav_run_vote(TravState& t, const bool busy, const BvhView& bv, cons
     const int nAlive = nq + nt + ni;
     if (nAlive == 0 || nAlive < minActive) return;
     const int vq = nq * wq, vt = nt * wt, vi = ni * wi;
-    if (vq >= vt && vq >= vi) { if (wantQuad) trav_quad_step<COUNT, TOPCACHE, STACK>(t, bv, haveInst, t_rayMin, stack, cnt); }
+    if (vq >= vt && vq >= vi) { if (wantQuad) trav_quad_step<COUNT, TOPCACHE, STACK, !UNORD>(t, bv, haveInst, t_rayMin, stack, cnt); }
     else if (vt >= vi) { if (wantTri) (void)trav_tri_step<ANYHIT, COUNT, STACK, TOPTRIS, ALPHA>(t, bv, haveInst, t_rayMin, stack, cnt); }
     else { if (wantInst) trav_inst_step<COUNT>(t, bv, cnt); }
   }

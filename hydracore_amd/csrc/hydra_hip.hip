@@ -468,6 +468,7 @@ struct hydra_hip_ctx {
   DevBuf leafHeaders[4]; int leafHeadersNum[4] = {0, 0, 0, 0}; bool classDirty = true;   // triangle-leaf headers per tree; the class labels in the device triangle lists must be (re)written
   DevBuf bvhNodesTop, topQuads;      // node copy with tagged links to the cached quads + their indices (tree 0, persistent kernels)
   DevBuf topTriF4; int topTriCount = 0, topTrisWanted = 0;   // option "top_tris_in_lds" (0..HK_TOP_TRIS), read by the next upload_bvh
+  int shadowUnordered = 1;           // option "shadow_unordered": any-hit rays take a quad's children in stored order (hk_trace.h, trav_run_vote)
   int topCount = 0, topWanted = HK_TOP_QUADS;   // option "top_quads_in_lds" (0..HK_TOP_QUADS), read by the next upload_bvh
   DevBuf bvhAlpha[4];                // alpha tables of the trees that have one (uint2 per float4 of the triangle list + the opacity samplers)
   DevBuf globals, storage[HYDRA_STORAGE_KINDS], bvhNodes[4], bvhTris[4], instMat, instLight, triRec, triTan, triBase, remapLists, remapTable, remapInst;
@@ -934,7 +935,7 @@ static void launch_shadow(hydra_hip_ctx* c, const SceneDev& s, const SegQ& q, co
   TraceLaunch a;
   a.stream = c->stream; a.s = s; a.q = q; a.a4 = org4; a.b4 = dir4; a.hits = nullptr; a.vis = vis;
   a.perRay3 = nullptr; a.totals5 = totals5; a.fetchCounters = fetchCounters; a.carry = 0; a.minActive = c->traceMinActive; a.raysPerLane = c->traceRaysPerLane;
-  a.vote = c->traceVote; a.wq = c->traceVoteW[0]; a.wt = c->traceVoteW[1]; a.wi = c->traceVoteW[2];
+  a.vote = c->traceVote; a.wq = c->traceVoteW[0]; a.wt = c->traceVoteW[1]; a.wi = c->traceVoteW[2]; a.unordered = c->shadowUnordered;
   if (c->traceMode == 0 || fetchCounters == nullptr) {
     a.grid = seg_grid(c, q, HK_TRACE_BLOCK, c->staticBlocksPerCU);
     hk_launch_shadow_static(totals5 != nullptr, a);
@@ -1827,6 +1828,7 @@ int hydra_hip_set_option(hydra_hip_handle c, const char* name, int value) {
   else if (n == "path_order") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "path_order: 0 or 1"); c->streamMajor = value; }
   else if (n == "leaf_count_links") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "leaf_count_links: 0 or 1"); c->leafEncWanted = value; }
   else if (n == "top_tris_in_lds") { if (value < 0 || value > HK_TOP_TRIS) return fail(c, HYDRA_HIP_EINVAL, "top_tris_in_lds: 0.." + std::to_string(HK_TOP_TRIS)); c->topTrisWanted = value; }
+  else if (n == "shadow_unordered") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "shadow_unordered: 0 or 1"); c->shadowUnordered = value; }
   else if (n == "top_quads_in_lds") { if (value < 0 || value > HK_TOP_QUADS) return fail(c, HYDRA_HIP_EINVAL, "top_quads_in_lds: 0.." + std::to_string(HK_TOP_QUADS)); c->topWanted = value; }
   else if (n == "scene_tables_in_lds") { if (value < 0 || value > 2) return fail(c, HYDRA_HIP_EINVAL, "scene_tables_in_lds: 0, 1 or 2"); c->sceneTablesInLds = value; }
   else if (n == "sort_paths") { if (value < 0 || value > 1) return fail(c, HYDRA_HIP_EINVAL, "sort_paths: 0 or 1"); c->sortPathsWanted = value; }
@@ -1856,6 +1858,7 @@ int hydra_hip_get_option(hydra_hip_handle c, const char* name, int* value) {
   else if (n == "trace_vote_wq") *value = c->traceVoteW[0];
   else if (n == "trace_vote_wt") *value = c->traceVoteW[1];
   else if (n == "trace_vote_wi") *value = c->traceVoteW[2];
+  else if (n == "shadow_unordered") *value = c->shadowUnordered;
   else if (n == "trace_rays_per_lane") *value = c->traceRaysPerLane;
   else if (n == "shade_waves") *value = c->shadeWaves;
   else if (n == "shade_blocks_per_cu") *value = c->shadeBlocksPerCU;

@@ -123,7 +123,8 @@ int hydra_hip_get_stage_times_per_bounce(hydra_hip_handle h, float* out, int max
  * Tuning knobs that never change results: "trace_mode" 1 = persistent traversal kernels with dynamic ray fetch (default),
  * 0 = one ray per lane; "trace_min_active" = refill threshold in lanes (default 48); "trace_blocks_per_cu" (default 12);
  * "shade_waves" 3|4|5 = register budget variant of the bounce kernels (default 3);
- * "shade_blocks_per_cu" (default 256), "static_blocks_per_cu" = grid caps; "queue_segments" 1..64 = independent path sub-queues
+ * "shade_blocks_per_cu" (default 256), "static_blocks_per_cu" = grid caps; "shadow_unordered" (default 1): shadow (any-hit) rays take the children of a quad in stored order instead of near to far -- the answer of an any-hit query does not
+ * depend on the order (trees deeper than the 80-entry stack aside, where the entries dropped differ), the sorting network is saved; 0 = the order of BVH4InstTraverseShadow; "queue_segments" 1..64 = independent path sub-queues
  * (default 32); "fused_bounce" 1 = one kernel per bounce (default), 0 = hit and shade kernels with an intermediate record;
  * "path_order" 1 = stream-major slots (default), 0 = pixel-major; "leaf_count_links" 1 = the device copy of the node array carries
  * triangle counts in its leaf links (default; read by the next upload_bvh, HYDRA_HIP_LEAF_COUNT_LINKS presets it).

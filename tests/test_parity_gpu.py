@@ -282,8 +282,11 @@ def test_persistent_traversal_kernels_give_identical_results(gpu224):
                 core.set_option(k, v)
             hits = core.stage_trace(pos4, dir4)
             assert (hits == ref).all(), (mode, min_active, vote, weights)
-            assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active, vote, weights)
+            for unordered in (1, 0):       # any-hit rays: a quad's children in stored order (default) or near to far like the reference: the same answer
+                core.set_option("shadow_unordered", unordered)
+                assert (core.stage_shadow_trace(pos4, dir4, tfar) == refvis).all(), (mode, min_active, vote, weights, unordered)
     finally:
+        core.set_option("shadow_unordered", 1)
         core.set_option("trace_mode", defaults[0])
         core.set_option("trace_min_active", defaults[1])
         core.set_option("trace_vote", defaults[2])
@@ -738,7 +741,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
     fusion, slot order, register budget, refill threshold"""
     core, b, _ = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
-    defaults = {k: core.get_option(k) for k in ("trace_mode", "trace_vote", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
+    defaults = {k: core.get_option(k) for k in ("trace_mode", "trace_vote", "shadow_unordered", "fused_bounce", "path_order", "shade_waves", "trace_min_active", "sort_paths", "sort_paths_from_bounce",
                                                 "scene_tables_in_lds", "srgb_table")}
     assert (defaults["sort_paths"], defaults["scene_tables_in_lds"], defaults["srgb_table"]) == (1, 2, 1)
 
@@ -751,7 +754,7 @@ def test_tuning_options_do_not_change_the_image(fix, request):
         return core.hdr_image(w, h).copy(), int(st.extensionRays), int(st.shadowRays)
     try:
         base = render()
-        for name, value in (("trace_mode", 0), ("trace_vote", 1 - defaults["trace_vote"]), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
+        for name, value in (("trace_mode", 0), ("trace_vote", 1 - defaults["trace_vote"]), ("shadow_unordered", 1 - defaults["shadow_unordered"]), ("fused_bounce", 0), ("path_order", 0), ("shade_waves", 4), ("trace_min_active", 8), ("sort_paths", 0),
                             ("sort_paths_from_bounce", 0), ("scene_tables_in_lds", 0), ("scene_tables_in_lds", 1), ("srgb_table", 0)):
             core.set_option(name, value)
             if name == "fused_bounce" and fix in ("gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso"):       # the split form has no tangent frame in its record and no translucent / Blinn lobes: refused, not rendered differently
