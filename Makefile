@@ -26,13 +26,26 @@ all: $(LIBDIR)/libhydra_hip.so $(LIBDIR)/libhydra_host.so oracle/liboracle.so or
 $(OBJDIR)/hydra_bvh.o $(OBJDIR)/hydra_img.o: $(OBJDIR)/%.o: hydracore_amd/csrc/%.hip hydracore_amd/csrc/hk_common.h $(wildcard include/*.h)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+# procedural textures: the device headers the run-time compiled kernel is built against, embedded as one text (hydra_proctex.hip hands it to hiprtc).
+# Local #include lines are dropped (the files follow each other in dependency order); hiprtc supplies the HIP runtime declarations itself.
+AMALGAM_SRC := include/hydra_layouts.h hydracore_amd/csrc/hk_common.h hydracore_amd/csrc/hk_trace.h hydracore_amd/csrc/hk_shading.h hydracore_amd/csrc/hk_proctex_rt.h
+$(OBJDIR)/hk_proctex_amalgam.inc: $(AMALGAM_SRC)
+	@mkdir -p $(OBJDIR)
+	( echo 'R"HKAMALGAM(' ; \
+	  echo 'typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t; typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;' ; \
+	  echo '#define FLT_MAX 3.402823466e+38F' ; \
+	  sed -e '/^[[:space:]]*#[[:space:]]*include/d' -e '/^#pragma once/d' $(AMALGAM_SRC) ; \
+	  echo ')HKAMALGAM"' ) > $@
+$(OBJDIR)/hydra_proctex.o: hydracore_amd/csrc/hydra_proctex.hip $(OBJDIR)/hk_proctex_amalgam.inc $(HIPHDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -I$(OBJDIR) -c $< -o $@
 $(OBJDIR)/%.o: hydracore_amd/csrc/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libhydra_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared $(HIPOBJ) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared $(HIPOBJ) -o $@ -lhiprtc
 
 $(LIBDIR)/libhydra_host.so: $(HOSTSRC) $(HOSTHDR) $(LIBDIR)/libhydra_hip.so
 	$(CXX) $(CXXFLAGS) -shared $(HOSTSRC) -o $@ -L$(LIBDIR) -lhydra_hip -Wl,-rpath,'$$ORIGIN'

@@ -53,6 +53,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
     "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bake_energy_tables", "hydra_hip_bake_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_build_mesh_ex", "hydra_hip_bvh_last_error",
+    "hydra_hip_proctex_compile", "hydra_hip_proctex_check", "hydra_hip_stage_proctex", "hydra_hip_stage_set_proctex",
 ]
 
 _hip = None
@@ -112,6 +113,10 @@ def load_hip_library():
         "hydra_hip_stage_shadow_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_eval_surface": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_shade_point": ([vp, i32, vp, vp, vp, vp, vp, vp], i32),
+        "hydra_hip_proctex_compile": ([vp, C.c_char_p, C.c_size_t], i32),
+        "hydra_hip_proctex_check": ([C.c_char_p, C.c_size_t], i32),
+        "hydra_hip_stage_proctex": ([vp, i32, i32, vp, vp, vp, vp, vp], i32),
+        "hydra_hip_stage_set_proctex": ([vp, i32, i32, vp, vp], i32),
         "hydra_hip_stage_bounce": ([vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
         "hydra_hip_stage_path_trace": ([vp, i32, vp, vp, vp, vp], i32),
         "hydra_hip_stage_random": ([vp, i32, vp, i32, vp, vp], i32),
@@ -191,7 +196,7 @@ def load_host_library():
     for n in ("hydra_host_width", "hydra_host_height", "hydra_host_unsupported", "hydra_host_have_inst", "hydra_host_trees_num"):
         getattr(lib, n).argtypes = [vp]
         getattr(lib, n).restype = i32
-    for n in ("hydra_host_log", "hydra_host_last_error"):
+    for n in ("hydra_host_log", "hydra_host_last_error", "hydra_host_proctex_program"):
         getattr(lib, n).argtypes = [vp]
         getattr(lib, n).restype = C.c_char_p
     lib.hydra_host_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -255,6 +260,17 @@ def normal_map_from_displacement(rgba, bump_amt, inv_height, smooth_lvl, device=
     if rc != 0:
         raise HydraError("normal_map_from_displacement failed (%d): %s" % (rc, lib.hydra_hip_image_last_error().decode()))
     return out, ms.value
+
+
+def proctex_check(text):
+    """does this procedural-texture program build for gfx950?  (hydra_hip_proctex_check: hiprtc only, no device) -> the build log; raises HydraError with the compiler's messages"""
+    lib = load_hip_library()
+    b = text.encode() if isinstance(text, str) else bytes(text)
+    rc = lib.hydra_hip_proctex_check(b, len(b))
+    msg = lib.hydra_hip_last_error(None).decode()
+    if rc != 0:
+        raise HydraError(msg)
+    return msg
 
 
 def bake_energy_tables(device=0):
@@ -479,6 +495,31 @@ class HipCore:
                  "stage_shade_point")
         return out
 
+    def proctex_compile(self, text):
+        """IHWLayer::RecompileProcTexShaders: build the scene's procedural textures from the program text ('' drops the program)"""
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        self._ck(self.lib.hydra_hip_proctex_compile(self.h, b if b else None, len(b)), "proctex_compile")
+
+    def stage_proctex(self, pos4, dir4, hits, max_num=16):
+        """the compiled program on n hits -> (ids int32 [max_num, n], colours float32 [max_num, n, 4] decoded from the halfs the layer stores)"""
+        n = len(hits)
+        pos4, dir4 = _f4(pos4, n), _f4(dir4, n)
+        hits = np.ascontiguousarray(hits, dtype=LITE_HIT_DTYPE)
+        ids = np.zeros((max_num, n), np.int32)
+        halfs = np.zeros((max_num, n, 4), np.float16)
+        self._ck(self.lib.hydra_hip_stage_proctex(self.h, n, max_num, _ptr(pos4), _ptr(dir4), _ptr(hits), _ptr(ids), _ptr(halfs)), "stage_proctex")
+        return ids, halfs.astype(np.float32)
+
+    def stage_set_proctex(self, ids=None, colours=None):
+        """the per-point lists the next stage_shade_point / stage_bounce calls of the same n consult: ids [max_num, n], colours [max_num, n, 4] (stored as halfs); None drops them"""
+        if ids is None:
+            self._ck(self.lib.hydra_hip_stage_set_proctex(self.h, 0, 0, None, None), "stage_set_proctex")
+            return
+        ids = np.ascontiguousarray(ids, np.int32)
+        halfs = np.ascontiguousarray(colours, np.float16)
+        assert ids.ndim == 2 and halfs.shape == ids.shape + (4,)
+        self._ck(self.lib.hydra_hip_stage_set_proctex(self.h, ids.shape[1], ids.shape[0], _ptr(ids), _ptr(halfs)), "stage_set_proctex")
+
     def stage_bounce(self, depth, max_depth, pos4, dir4, surf24, in16, rands10):
         """one bounce of n paths with every input handed in (include/hydra_hip.h, hydra_hip_stage_bounce) -> float32 [n, 40]"""
         n = len(surf24)
@@ -651,6 +692,10 @@ class HostScene:
 
     def log(self):
         return self.lib.hydra_host_log(self.p).decode()
+
+    def proctex_program(self):
+        """the text the front end handed to IHWLayer::RecompileProcTexShaders ('' = the scene declares no procedural textures)"""
+        return self.lib.hydra_host_proctex_program(self.p).decode()
 
     def buffers(self):
         """numpy COPIES of every buffer the kernels read (same bytes the HIP layer gets)."""

@@ -153,7 +153,44 @@ struct SceneDev {
   // reverse light-selection table (clight.h:1774-1793), by their own pointers for the same reason: every shaded path reads them
   const int*    hdr;
   const float*  lselRev;
+  // Procedural textures (hk_proctex_rt.h): what the run-time compiled kernel k_proctex left for every path of the bounce -- the ids of
+  // the procedural textures of the hit material (plane k of ptlIds: slot + k * ptlStride, the list ends at HYDRA_INVALID_TEXTURE or after
+  // ptlMax planes) and their colours as four halfs each (ptlVals, same addressing), the precision the reference's layer hands them
+  // on with (WriteProcTextureList, cglobals.h:2327-2359).  ptlSlot is PER LANE: the path slot whose list the texture fetches of this lane
+  // consult (sample2DExt), -1 = none.  Only kernels instantiated with HK_FEAT_PROCTEX set it; everywhere else it is the constant -1 and
+  // the look-up folds away.
+  const int*    ptlIds;
+  const uint2*  ptlVals;
+  int           ptlStride, ptlMax;
+  int           ptlSlot;
 };
+#ifndef HK_HOST_EMU
+// Segmented path queues.  One global "next free slot" word saturates at ~88 returning atomics per microsecond on MI355X
+// (MI355X_MICROARCH.md, dequeue row); with one atomic per wave that alone cost k_hit ~1 ms per sample at 1080p.  The
+// path arrays are therefore split into `nseg` segments of `cap` slots, every thread block works on exactly one segment
+// (block b -> segment b % nseg) and appends survivors to the SAME segment of the next queue through that segment's own
+// counter (counters sit HK_CSTRIDE words = 128 B apart).  A segment can never grow, so cap = its initial share is a hard
+// bound and memory use does not change; results are independent of the segmentation because accumulation is keyed by pixel.
+#define HK_CSTRIDE 32
+#define HK_MAX_SEG 64
+#define HK_CROW (HK_MAX_SEG * HK_CSTRIDE)   // words per counter row: one row per bounce, [segment] inside
+struct SegQ {
+  const uint32_t* counts;   // counts[seg * HK_CSTRIDE]; nullptr => countImm items in one segment
+  int countImm, nseg, cap;
+};
+struct SegIter { int seg, base, count, first, step; };
+HK_DEV SegIter segq_iter(const SegQ& q) {
+  SegIter it;
+  const int bps = int(gridDim.x) / q.nseg;            // blocks per segment (grid is a multiple of nseg)
+  it.seg = int(blockIdx.x) % q.nseg;
+  const int bis = int(blockIdx.x) / q.nseg;
+  it.count = (bis < bps) ? (q.counts ? int(q.counts[it.seg * HK_CSTRIDE]) : q.countImm) : 0;
+  it.base = it.seg * q.cap;
+  it.first = bis * int(blockDim.x) + int(threadIdx.x);
+  it.step = (bps > 0 ? bps : 1) * int(blockDim.x);
+  return it;
+}
+#endif
 #define HK_HDR_WORDS 240   /* HG_MPROJ .. HG_DUMMY1, include/hydra_layouts.h */
 
 HK_DEV const float* g_varsF(const SceneDev& s) { return reinterpret_cast<const float*>(s.hdr + HG_VARS_F); }

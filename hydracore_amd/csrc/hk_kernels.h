@@ -10,6 +10,8 @@
 // A kernel template is instantiated only in the TU whose launcher names it; hydra_hip.hip calls the launchers declared at the end of
 // this file (plain functions taking one argument record), so no TU ever launches a kernel another TU holds.
 #pragma once
+#include <string>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "../../include/hydra_hip.h"
@@ -52,32 +54,7 @@ HK_DEV int wave_compact_index(bool alive, uint32_t* counter) {
   return base + __popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Segmented path queues.  One global "next free slot" word saturates at ~88 returning atomics per microsecond on MI355X
-// (MI355X_MICROARCH.md, dequeue row); with one atomic per wave that alone cost k_hit ~1 ms per sample at 1080p.  The
-// path arrays are therefore split into `nseg` segments of `cap` slots, every thread block works on exactly one segment
-// (block b -> segment b % nseg) and appends survivors to the SAME segment of the next queue through that segment's own
-// counter (counters sit HK_CSTRIDE words = 128 B apart).  A segment can never grow, so cap = its initial share is a hard
-// bound and memory use does not change; results are independent of the segmentation because accumulation is keyed by pixel.
-#define HK_CSTRIDE 32
-#define HK_MAX_SEG 64
-#define HK_CROW (HK_MAX_SEG * HK_CSTRIDE)   // words per counter row: one row per bounce, [segment] inside
-struct SegQ {
-  const uint32_t* counts;   // counts[seg * HK_CSTRIDE]; nullptr => countImm items in one segment
-  int countImm, nseg, cap;
-};
-struct SegIter { int seg, base, count, first, step; };
-HK_DEV SegIter segq_iter(const SegQ& q) {
-  SegIter it;
-  const int bps = int(gridDim.x) / q.nseg;            // blocks per segment (grid is a multiple of nseg)
-  it.seg = int(blockIdx.x) % q.nseg;
-  const int bis = int(blockIdx.x) / q.nseg;
-  it.count = (bis < bps) ? (q.counts ? int(q.counts[it.seg * HK_CSTRIDE]) : q.countImm) : 0;
-  it.base = it.seg * q.cap;
-  it.first = bis * int(blockDim.x) + int(threadIdx.x);
-  it.step = (bps > 0 ? bps : 1) * int(blockDim.x);
-  return it;
-}
-
+// SegQ / segq_iter (the segmented path queues): hk_common.h
 // T1 -- closest hit for every live path (kernel_RayTrace).  ALPHA: the tree carries an alpha table (BVH4InstTraverseAlpha,
 // ctrace.h:1297-1520).  carry: this launch walks one of trees 1..3 and starts from the hit the earlier trees left in `hits`
 // (IntegratorCommon::rayTrace loops over the trees with one running Lite_Hit, Common.cpp:128-150; per-ray counters add up).
@@ -440,6 +417,7 @@ __global__ void __launch_bounds__(256, W) k_hit(SceneDev s, SegQ q, uint32_t* __
                                                  uint32_t* __restrict__ shadowCount, int depth, int maxDepth, PathState S,
                                                  const HydraLiteHit* __restrict__ hits, MidState M,
                                                  float4* __restrict__ contrib, uint2* __restrict__ gens) {
+  s.ptlSlot = -1;
   k_hit_body(s, q, nextCount, shadowCount, depth, maxDepth, S, hits, M, contrib, gens);
 }
 
@@ -470,6 +448,7 @@ HK_DEV void k_shade_body(const SceneDev& s, const SegQ& q, const MidState& M, co
 
 template <int W>
 __global__ void __launch_bounds__(256, W) k_shade(SceneDev s, SegQ q, MidState M, PathState S) {
+  s.ptlSlot = -1;
   k_shade_body(s, q, M, S);
 }
 
@@ -548,6 +527,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
   __shared__ unsigned short sPerm[HK_BOUNCE_BLOCK];
   __shared__ float4 sHit[HK_BOUNCE_BLOCK];   // the hit records travel with the permutation: no second fetch, and the triangle fetch can leave with the state loads
   SceneDev s = sArg;
+  if constexpr ((F & HK_FEAT_PROCTEX) == 0) s.ptlSlot = -1;   // a constant: the procedural-texture look-up of sample2DExt folds away
 #ifdef HK_EXP_BOUNCE_STAMPS
   unsigned long long stampAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stampT = __builtin_readcyclecounter();
 #endif
@@ -620,6 +600,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
       const uint2 g2 = Sin.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
       HydraLiteHit hit; hit.t = h4.x; hit.primId = as_int(h4.y); hit.instId = as_int(h4.z); hit.geomId = as_int(h4.w);
+      if constexpr ((F & HK_FEAT_PROCTEX) != 0) s.ptlSlot = (uint32_t(s.ptlIds[i]) != HYDRA_INVALID_TEXTURE) ? i : -1;   // what k_proctex left for this path (hk_proctex_rt.h)
       // the triangle record and the instance matrix are requested here, behind the state loads and before anything waits for those:
       // one round trip to memory for both instead of two in a row
 #ifdef HK_EXP_BOUNCE_PRELOAD
@@ -710,6 +691,7 @@ struct MmltRays { float4* pos; float4* dir; int* owner; };
 #endif
 template <int F>
 __global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, MmltView v, int currDepth, SegQ q, MmltRays in, const HydraLiteHit* __restrict__ hits, MmltRays out, uint32_t* __restrict__ outCount) {
+  s.ptlSlot = -1;   // MMLT does not run procedural textures (hydra_hip_mmlt_begin refuses such a scene)
   const SegIter it = segq_iter(q);
   uint32_t* counter = outCount + it.seg * HK_CSTRIDE;
   for (int idx = it.first; idx - int(__lane_id()) < it.count; idx += it.step) {   // whole waves iterate together: the compaction is a wave ballot
@@ -730,11 +712,13 @@ __global__ void __launch_bounds__(256, HK_MMLT_STEP_W) k_mmlt_step(SceneDev s, M
 template <int F>
 __global__ void k_mmlt_connect_begin(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  s.ptlSlot = -1;
   if (i < v.n) mmltConnectBegin<F>(s, v, i);
 }
 template <int F>
 __global__ void __launch_bounds__(256, HK_MMLT_CONN_W) k_mmlt_connect_end(SceneDev s, MmltView v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  s.ptlSlot = -1;
   if (i < v.n) mmltConnectEnd<F>(s, v, i);
 }
 
@@ -766,6 +750,18 @@ bool hk_launch_bounce_all45(int W, int F, int STG, const BounceLaunch& a);     /
 int hk_bounce_stamps_read_lean(unsigned long long*, int); int hk_bounce_stamps_read_classic(unsigned long long*, int); int hk_bounce_stamps_read_nmap(unsigned long long*, int);
 int hk_bounce_stamps_read_all(unsigned long long*, int); int hk_bounce_stamps_read_all45(unsigned long long*, int);
 #endif
+
+bool hk_launch_bounce_proctex(int W, int F, int STG, const BounceLaunch& a);   // W 3; F = ALL | PROCTEX (scenes whose materials bind procedural textures)
+
+// procedural textures (hydra_proctex.hip): the scene's own texture functions, compiled at load time into k_proctex (hk_proctex_rt.h)
+struct HkProcTexProgram;
+bool hk_proctex_compile(const char* source, size_t len, std::vector<char>& code, std::string& log, std::string& err);   // text -> gfx950 code object; needs no device
+HkProcTexProgram* hk_proctex_build(const char* source, size_t len, std::string& err);   // nullptr + err (with the compiler's log) on failure
+void hk_proctex_free(HkProcTexProgram* p);
+hipError_t hk_proctex_launch(HkProcTexProgram* p, int grid, hipStream_t stream, const SceneDev& s, const SegQ& q, const float4* pos4, const float4* dir4, const HydraLiteHit* hits,
+                             int* ids, uint2* vals, int stride, int maxNum);
+hipError_t hk_proctex_launch_points(HkProcTexProgram* p, hipStream_t stream, const SceneDev& s, int n, const float4* pos4, const float4* dir4, const HydraLiteHit* hits,
+                                    int* ids, uint2* vals, int stride, int maxNum);
 
 struct SplitLaunch {          // the split form: k_hit<W> / k_shade<W>
   int grid; hipStream_t stream; SceneDev s; SegQ q; uint32_t* nextCnt; uint32_t* shCnt; int depth, maxDepth; PathState S;

@@ -379,14 +379,61 @@ HK_DEV_CALL f3 sample2DExtCall(int samplerOffset, f2 texCoord, const float* blob
   if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return mk3(c.x, c.y, c.z);
 }
+// ---- procedural textures: readProcTex (cglobals.h:2402-2441) over the per-path list the run-time compiled kernel wrote (SceneDev::ptl*, hk_proctex_rt.h).
+// Returns w = -1 when the path's list does not hold the id (the reference's "not found" marker), else the colour with w = 0.
+#ifdef HK_HOST_EMU
+HK_DEV float hk_half_to_float(unsigned h) {
+  const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+  if (e == 0) return as_float(int(sign)) * 0.0f + (sign ? -1.0f : 1.0f) * float(m) * 5.9604644775390625e-08f;   // zero and subnormals: m * 2^-24
+  if (e == 31) return as_float(int(sign | 0x7f800000u | (m << 13)));
+  return as_float(int(sign | ((e + 112u) << 23) | (m << 13)));
+}
+#else
+HK_DEV float hk_half_to_float(unsigned h) { return float(__builtin_bit_cast(_Float16, (unsigned short)h)); }
+#endif
+HK_DEV float4 readProcTexAt(int texId, const int* ids, const uint2* vals, int stride, int maxNum) {   // ids / vals: already offset to the path's slot
+  float4 r = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+  for (int k = 0; k < maxNum; k++) {
+    const int id = ids[size_t(k) * stride];
+    if (uint32_t(id) == HYDRA_INVALID_TEXTURE) break;
+    if (id == texId) {
+      const uint2 v = vals[size_t(k) * stride];
+      r = make_float4(hk_half_to_float(v.x & 0xffffu), hk_half_to_float(v.x >> 16), hk_half_to_float(v.y & 0xffffu), 0.0f);
+      break;
+    }
+  }
+  return r;
+}
+HK_DEV float4 readProcTex(int texId, const SceneDev& s) { return readProcTexAt(texId, s.ptlIds + s.ptlSlot, s.ptlVals + s.ptlSlot, s.ptlStride, s.ptlMax); }
+// sample2DExt with the path's procedural textures (cfetch.h:677-709 as written): the stored texture is fetched when the id has one, the procedural colour wins.
+// A real call like sample2DExtCall, so everything by value (a reference to the scene view would force the caller's copy of it into memory).
+HK_DEV_CALL f3 sample2DExtProc(int samplerOffset, f2 texCoord, const float* blob, const int* texTable, const int4* texStorage, const float* srgbLut,
+                               const int* ids, const uint2* vals, int stride, int maxNum) {
+  const float* sm = blob + size_t(samplerOffset) * 4;
+  const int flags = as_int(sm[HS_FLAGS]);
+  const int texId = as_int(sm[HS_TEXID]);
+  if (texId <= 0) return mk3(1, 1, 1);
+  const f2 tct = mk2(sm[HS_ROW0] * texCoord.x + sm[HS_ROW0 + 1] * texCoord.y + sm[HS_ROW0 + 3],
+                     sm[HS_ROW1] * texCoord.x + sm[HS_ROW1 + 1] * texCoord.y + sm[HS_ROW1 + 3]);
+  float4 c = readProcTexAt(texId, ids, vals, stride, maxNum);
+  if (fabsf(c.w + 1.0f) < 1e-5f) {
+    const int offset = texTable[texId];
+    c = make_float4(1, 1, 1, 1);
+    if (offset >= 0) c = read_imagef_sw4(texStorage + offset, tct, flags, (sm[HS_GAMMA] != 1.0f), srgbLut);
+  }
+  if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
+  return mk3(c.x, c.y, c.z);
+}
 HK_DEV f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const SceneDev& s) {
   if (uint32_t(samplerOffset) == HYDRA_INVALID_TEXTURE || samplerOffset < 0) return mk3(1, 1, 1);   // the common untextured node: no call
+  if (s.ptlSlot >= 0) return sample2DExtProc(samplerOffset, texCoord, blob, s.texTable, s.texStorage, s.srgbLut, s.ptlIds + s.ptlSlot, s.ptlVals + s.ptlSlot, s.ptlStride, s.ptlMax);   // only in kernels that set a slot (HK_FEAT_PROCTEX); the constant -1 elsewhere
   return sample2DExtCall(samplerOffset, texCoord, blob, s.texTable, s.texStorage, s.srgbLut);
 }
 
 // Compile-time feature sets of the shading code.  A kernel instantiated with a subset does not contain (nor keep registers for)
 // the rest; the host picks the instantiation from the material classes and light types the uploaded scene really has.
 enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEAT_GLASS = 8, HK_FEAT_GGX = 16, HK_FEAT_NMAP = 32, HK_FEAT_TRANSLUCENT = 64, HK_FEAT_BLINN = 128, HK_FEAT_ANISO = 256, HK_FEAT_PEREZ = 512, HK_FEAT_RARE_LIGHTS = 1024 /* sky portals, cylinder lights, textured mesh lights */, HK_FEAT_ALL = 2047,
+       HK_FEAT_PROCTEX = 2048 /* the kernel reads the per-path procedural texture lists (SceneDev::ptl*); NOT part of HK_FEAT_ALL: one more instantiation on top of it */,
        HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent, Blinn and the anisotropic (Beckmann, TRGGX) nodes */ };   // DELTA_LIGHTS stands for "lights other than area and sky": point, spot, directional, sphere
 
 // ================================================================================================ materials
@@ -403,8 +450,9 @@ HK_DEV f3 sample2DAuxExt(int auxTexId, int samplerOffset, f2 texCoord, const flo
   const f2 tct = mk2(sm[HS_ROW0] * texCoord.x + sm[HS_ROW0 + 1] * texCoord.y + sm[HS_ROW0 + 3],
                      sm[HS_ROW1] * texCoord.x + sm[HS_ROW1 + 1] * texCoord.y + sm[HS_ROW1 + 3]);
   if (as_int(sm[HS_TEXID]) == 0) return mk3(1, 1, 1);
-  const int offset = s.texAuxTable[auxTexId];
-  float4 c = read_imagef_sw4(s.texAuxStorage + offset, tct, flags, (sm[HS_GAMMA] != 1.0f), s.srgbLut);
+  float4 c = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+  if (s.ptlSlot >= 0) c = readProcTex(as_int(sm[HS_TEXID]), s);   // a procedural normal map: its slot holds the texture id, not an aux id (PlainMaterialConverter.cpp:1396-1399) -- the aux arena is not read for it
+  if (fabsf(c.w + 1.0f) < 1e-5f) c = read_imagef_sw4(s.texAuxStorage + s.texAuxTable[auxTexId], tct, flags, (sm[HS_GAMMA] != 1.0f), s.srgbLut);
   if (flags & HTEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return mk3(c.x, c.y, c.z);
 }

@@ -227,6 +227,7 @@ __global__ void k_stage_shade_point(SceneDev s, int n, const float* __restrict__
                                     const float4* __restrict__ rndLight4, const float* __restrict__ rands10, float* __restrict__ out28) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  s.ptlSlot = (s.ptlIds != nullptr && uint32_t(s.ptlIds[i]) != HYDRA_INVALID_TEXTURE) ? i : -1;   // procedural texture lists handed in (hydra_hip_stage_set_proctex)
   const float* r = surf24 + size_t(i) * 24;
   float* o = out28 + size_t(i) * 28;
   for (int k = 0; k < 28; k++) o[k] = 0.0f;
@@ -272,6 +273,7 @@ __global__ void k_stage_bounce(SceneDev s, int n, int depth, int maxDepth, const
                                const float* __restrict__ in16, const float* __restrict__ rands10, float* __restrict__ out40) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  s.ptlSlot = (s.ptlIds != nullptr && uint32_t(s.ptlIds[i]) != HYDRA_INVALID_TEXTURE) ? i : -1;
   const float* r = surf24 + size_t(i) * 24;
   const float* in = in16 + size_t(i) * 16;
   float* o = out40 + size_t(i) * 40;
@@ -485,6 +487,12 @@ struct hydra_hip_ctx {
   std::vector<int32_t> hostMatTable;
   std::vector<int32_t> hostTexAuxTable;   // aux texture id -> offset in the aux arena (normal maps), for validate_materials
   bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
+  // procedural textures: the scene's compiled program (hydra_hip_proctex_compile), how many a material head lists at most (validate_materials), the per-path lists
+  // of the bounce in flight (ids: int[ptlMax][slots], colours: uint2[ptlMax][slots]) and the lists handed to the stage entries (hydra_hip_stage_set_proctex)
+  HkProcTexProgram* procTex = nullptr;
+  int ptlMax = 0;
+  DevBuf ptlIds, ptlVals;
+  DevBuf stagePtlIds, stagePtlVals; int stagePtlN = 0, stagePtlMax = 0;
 
   // render state
   int rank = 0, world = 1, tile = 64;
@@ -637,6 +645,7 @@ static SceneDev make_scene_tree(const hydra_hip_ctx* c, int tree) {
   s.texAuxTable = hdr ? s.globals + c->hostHeader[HG_TEXAUX_TABLE_OFFS] : nullptr;
   s.hdr = s.globals;
   s.lselRev = hdr ? reinterpret_cast<const float*>(s.globals + c->hostHeader[HG_LSEL_REV_OFFS]) : nullptr;
+  s.ptlIds = nullptr; s.ptlVals = nullptr; s.ptlStride = 0; s.ptlMax = 0; s.ptlSlot = -1;   // procedural textures: set by the callers that run them (trace_pass, the stage entries)
   return s;
 }
 static bool scene_ready(const hydra_hip_ctx* c) {
@@ -665,13 +674,34 @@ static int validate_materials(hydra_hip_ctx* c) {
   if (!c->matDirty) return HYDRA_HIP_OK;
   const size_t floats = c->hostMaterials.size();
   auto word = [](const float* m, int i) { int32_t v; memcpy(&v, m + i, 4); return v; };
-  int feat = 0;
+  int feat = 0, ptlMax = 0;
   for (size_t id = 0; id < c->hostMatTable.size(); id++) {
     const int32_t offs = c->hostMatTable[id];
     if (offs < 0) continue;
     size_t stack[2 * 8];
-    int top = 0, visited = 0;
+    int top = 0, visited = 0, procIds = 0;
+    const float* headOfTree = c->hostMaterials.data() + size_t(offs) * 4;
     stack[top++] = size_t(offs) * 4;
+    if (size_t(offs) * 4 + HM_NODE_FLOATS <= floats && (word(c->hostMaterials.data() + size_t(offs) * 4, HM_FLAGS) & HMF_HAVE_PROC_TEXTURES) != 0) {
+      // the head lists the ids (cglobals.h:2732-2753) and points at its argument table, one node of (id, offset) pairs whose last word is the count, followed by
+      // the argument words (RenderDriverRTE_ProcTex.cpp:191-252, PlainMaterialConverter.cpp:1865-1874): all of it must lie inside the arena
+      const float* head = c->hostMaterials.data() + size_t(offs) * 4;
+      const std::string who = "material " + std::to_string(id);
+      int n = 0;
+      while (n < 16 && uint32_t(word(head, HM_PROC_TEX_IDS + n)) != HYDRA_INVALID_TEXTURE) n++;
+      if (n == 0) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + " is flagged as having procedural textures but its head lists none");
+      const long long tab = word(head, HM_PROC_TEX_TABLE);
+      if (tab <= 0 || size_t(offs) * 4 + size_t(tab) + HM_NODE_FLOATS > floats) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": procedural texture argument table outside the material arena");
+      const float* table = head + tab;
+      const int entries = word(table, HM_NODE_FLOATS - 1);
+      if (entries < 0 || entries > (HM_NODE_FLOATS - 1) / 2) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": bad procedural texture argument table");
+      for (int e = 0; e < entries; e++) {
+        const int o = word(table, 2 * e + 1);
+        if (o < -1 || size_t(offs) * 4 + size_t(tab) + HM_NODE_FLOATS + size_t(o < 0 ? 0 : o) > floats) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": procedural texture arguments outside the material arena");
+      }
+      ptlMax = std::max(ptlMax, n);
+      procIds = n;
+    }
     while (top > 0) {
       const size_t at = stack[--top];
       const std::string who = "material " + std::to_string(id) + " (node at float " + std::to_string(at) + ")";
@@ -679,7 +709,14 @@ static int validate_materials(hydra_hip_ctx* c) {
       if (++visited > 64) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": blend tree with more than 64 nodes (cycle?)");
       const float* m = c->hostMaterials.data() + at;
       const int type = word(m, HM_TYPE);
-      if (type != HMT_BLEND_MASK && uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) {   // normal-mapped leaf (a blend node may carry the ids too: never read)
+      bool procNormal = false;   // a procedural normal map: the slot holds the texture id and the value comes from the path's list (PlainMaterialConverter.cpp:1396-1399)
+      if (type != HMT_BLEND_MASK && uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE && procIds > 0) {
+        const int so = word(m, HM_NORMAL_TEX_MATRIX);
+        if (so > 0 && so * 4 + HS_TEXID < HM_NODE_FLOATS)
+          for (int k = 0; k < procIds; k++) procNormal = procNormal || (word(headOfTree, HM_PROC_TEX_IDS + k) == word(m, so * 4 + HS_TEXID));
+        if (procNormal) feat |= HK_FEAT_NMAP;
+      }
+      if (!procNormal && type != HMT_BLEND_MASK && uint32_t(word(m, HM_NORMAL_TEX)) != HYDRA_INVALID_TEXTURE) {   // normal-mapped leaf (a blend node may carry the ids too: never read)
         const int auxId = word(m, HM_NORMAL_TEX);
         if (auxId < 0 || size_t(auxId) >= c->hostTexAuxTable.size()) return fail(c, HYDRA_HIP_EINVAL, "materials: " + who + ": normal-map id outside the aux texture table");
         const int offs = c->hostTexAuxTable[size_t(auxId)];
@@ -707,6 +744,7 @@ static int validate_materials(hydra_hip_ctx* c) {
     }
   }
   c->matFeatures = feat;
+  c->ptlMax = ptlMax;
   c->sceneFeatures = c->matFeatures | c->lightFeatures;
   c->matDirty = false;
   return HYDRA_HIP_OK;
@@ -1004,6 +1042,16 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     const int nF4 = stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.hdrF4 + stage.lselF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4;
     hipLaunchKernelGGL(k_build_stage_image, dim3((nF4 + 255) / 256), dim3(256), 0, c->stream, s, stage, static_cast<float4*>(c->stageImg.p));
   }
+  // procedural textures: k_proctex (the scene's program) runs between the traversal and the bounce kernel and leaves every path its list
+  SceneDev sPtl = s;
+  if (c->ptlMax > 0) {
+    if (c->procTex == nullptr) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: materials of the scene bind procedural textures, but no program was compiled for them (hydra_hip_proctex_compile / IHWLayer::RecompileProcTexShaders)");
+    if (!fused || c->shadeWaves != 3) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: procedural textures exist in the fused bounce kernel at its default register budget only (fused_bounce = 1, shade_waves = 3)");
+    const size_t slots = size_t(nseg) * size_t(segCap);
+    int rc = dev_alloc(c, c->ptlIds, slots * size_t(c->ptlMax) * 4); if (rc != 0) return rc;
+    rc = dev_alloc(c, c->ptlVals, slots * size_t(c->ptlMax) * 8); if (rc != 0) return rc;
+    sPtl.ptlIds = static_cast<const int*>(c->ptlIds.p); sPtl.ptlVals = static_cast<const uint2*>(c->ptlVals.p); sPtl.ptlStride = int(slots); sPtl.ptlMax = c->ptlMax;
+  }
   const bool canSort = (c->sortPathsWanted != 0) && (HK_BOUNCE_BLOCK / 64) * HK_SORT_BINS <= 64;
   const size_t stageBytes = size_t(stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.hdrF4 + stage.lselF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4) * 16;
   const int stg = (stage.matF4 > 0 ? 1 : 0) | (stage.triBaseF4 > 0 ? 2 : 0);
@@ -1017,6 +1065,9 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     const PathState S = bb.A;
     launch_closest(c, s, qIn, S.pos4, S.dir4, hits, nullptr, tt, fetch ? fetch + size_t(2 * depth) * HK_CROW : nullptr);
     int b = mark();
+    if (c->ptlMax > 0)   // timed with the bounce kernel: it is shading work
+      HCHECK(hk_proctex_launch(c->procTex, seg_grid(c, qIn, 256, c->shadeBlocksPerCU), c->stream, s, qIn, S.pos4, S.dir4, hits,
+                               static_cast<int*>(c->ptlIds.p), static_cast<uint2*>(c->ptlVals.p), sPtl.ptlStride, c->ptlMax));
     if (fused) {
       const int sortPaths = (canSort && depth >= c->sortPathsFromDepth) ? 1 : 0;
       // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
@@ -1032,10 +1083,11 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       else if (f & (HK_FEAT_NMAP | HK_FEAT_TRANSLUCENT | HK_FEAT_BLINN | HK_FEAT_ANISO | HK_FEAT_PEREZ | HK_FEAT_RARE_LIGHTS)) F = HK_FEAT_ALL;
       else if (!(f & HK_FEAT_GLASS)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GLASS;
       else if (!(f & HK_FEAT_GGX)) F = HK_FEAT_CLASSIC & ~HK_FEAT_GGX;
+      if (c->ptlMax > 0) F = HK_FEAT_ALL | HK_FEAT_PROCTEX;
       BounceLaunch bl;
-      bl.grid = gBounce; bl.ldsBytes = (G == 0) ? 0 : stageBytes; bl.stream = c->stream; bl.s = s; bl.stage = stage; bl.qIn = qIn; bl.nextCnt = nextCnt; bl.shCnt = shCnt;
+      bl.grid = gBounce; bl.ldsBytes = (G == 0) ? 0 : stageBytes; bl.stream = c->stream; bl.s = sPtl; bl.stage = stage; bl.qIn = qIn; bl.nextCnt = nextCnt; bl.shCnt = shCnt;
       bl.depth = depth; bl.maxDepth = maxDepth; bl.A = bb.A; bl.B = bb.B; bl.hits = hits; bl.sh = bb.sh; bl.contrib = contrib; bl.gens = gens; bl.sortPaths = sortPaths;
-      if (!(hk_launch_bounce_lean(W, F, G, bl) || hk_launch_bounce_classic(W, F, G, bl) || hk_launch_bounce_nmap(W, F, G, bl) || hk_launch_bounce_all(W, F, G, bl) || hk_launch_bounce_all45(W, F, G, bl)))
+      if (!(hk_launch_bounce_lean(W, F, G, bl) || hk_launch_bounce_classic(W, F, G, bl) || hk_launch_bounce_nmap(W, F, G, bl) || hk_launch_bounce_all(W, F, G, bl) || hk_launch_bounce_all45(W, F, G, bl) || hk_launch_bounce_proctex(W, F, G, bl)))
         return fail(c, HYDRA_HIP_ESTATE, "trace_pass: no k_bounce instantiation for register budget " + std::to_string(W) + ", features " + std::to_string(F) + ", staging " + std::to_string(G));
       std::swap(bb.A, bb.B);
     } else {
@@ -1123,6 +1175,8 @@ int hydra_hip_destroy(hydra_hip_handle c) {
   dev_free(c->bvhNodesTop); dev_free(c->topQuads); for (auto& b : c->leafHeaders) dev_free(b); dev_free(c->topTriF4);
   for (auto& b : c->bvhTris) dev_free(b);
   for (auto& b : c->bvhAlpha) dev_free(b);
+  dev_free(c->ptlIds); dev_free(c->ptlVals); dev_free(c->stagePtlIds); dev_free(c->stagePtlVals);
+  hk_proctex_free(c->procTex); c->procTex = nullptr;
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   delete c;
   return HYDRA_HIP_OK;
@@ -1935,6 +1989,63 @@ struct TmpBufs {
   HCHECK(hipGetLastError());                                                                            \
   HCHECK(hipStreamSynchronize(c->stream));
 
+// ---- procedural textures (hydra_proctex.hip, hk_proctex_rt.h)
+int hydra_hip_proctex_compile(hydra_hip_handle c, const char* source, size_t length) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->stream));
+  hk_proctex_free(c->procTex); c->procTex = nullptr;
+  if (source == nullptr || length == 0) return HYDRA_HIP_OK;   // no procedural textures: the program is dropped
+  std::string err;
+  c->procTex = hk_proctex_build(source, length, err);
+  if (c->procTex == nullptr) return fail(c, HYDRA_HIP_EINVAL, err);
+  return HYDRA_HIP_OK;
+}
+// the same compilation without a device or a context: does this text build?  (the build log, or the error, through hydra_hip_last_error(NULL))
+int hydra_hip_proctex_check(const char* source, size_t length) {
+  if (source == nullptr || length == 0) return fail(nullptr, HYDRA_HIP_EINVAL, "proctex_check: no text");
+  std::vector<char> code;
+  std::string log, err;
+  if (!hk_proctex_compile(source, length, code, log, err)) return fail(nullptr, HYDRA_HIP_EINVAL, err);
+  g_createError = log;
+  return HYDRA_HIP_OK;
+}
+// the lists the next stage_shade_point / stage_bounce calls of the same n consult: ids[max_num][n], colours as halfs [max_num][n][4]; n = 0 drops them
+int hydra_hip_stage_set_proctex(hydra_hip_handle c, int n, int max_num, const int32_t* ids, const uint16_t* halfs4) {
+  if (!c) return HYDRA_HIP_EINVAL;
+  HCHECK(hipSetDevice(c->device));
+  c->stagePtlN = 0; c->stagePtlMax = 0;
+  if (n <= 0) return HYDRA_HIP_OK;
+  if (max_num < 1 || max_num > 16 || !ids || !halfs4) return fail(c, HYDRA_HIP_EINVAL, "stage_set_proctex: bad arguments");
+  int rc = dev_upload(c, c->stagePtlIds, ids, size_t(n) * size_t(max_num) * 4); if (rc) return rc;
+  rc = dev_upload(c, c->stagePtlVals, halfs4, size_t(n) * size_t(max_num) * 8); if (rc) return rc;
+  c->stagePtlN = n; c->stagePtlMax = max_num;
+  return HYDRA_HIP_OK;
+}
+static void stage_proctex_lists(hydra_hip_ctx* c, int n, SceneDev& s) {
+  if (c->stagePtlN != n || c->stagePtlMax <= 0) return;
+  s.ptlIds = static_cast<const int*>(c->stagePtlIds.p); s.ptlVals = static_cast<const uint2*>(c->stagePtlVals.p); s.ptlStride = n; s.ptlMax = c->stagePtlMax;
+}
+// the compiled program on n hits handed in: ids[max_num][n] (HYDRA_INVALID_TEXTURE ends a point's list), colours as halfs [max_num][n][4]
+int hydra_hip_stage_proctex(hydra_hip_handle c, int n, int max_num, const float* ray_pos4, const float* ray_dir4, const HydraLiteHit* hits, int32_t* ids, uint16_t* halfs4) {
+  STAGE_PROLOG(true);
+  if (!ray_pos4 || !ray_dir4 || !hits || !ids || !halfs4 || max_num < 1 || max_num > 16) return fail(c, HYDRA_HIP_EINVAL, "stage_proctex: bad arguments");
+  if (c->procTex == nullptr) return fail(c, HYDRA_HIP_ESTATE, "stage_proctex: no program compiled (hydra_hip_proctex_compile)");
+  float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  HydraLiteHit* dh = (HydraLiteHit*)tb.up(c, hits, size_t(n) * 16, rc);
+  int* dids = (int*)tb.up(c, nullptr, size_t(n) * size_t(max_num) * 4, rc);
+  uint2* dvals = (uint2*)tb.up(c, nullptr, size_t(n) * size_t(max_num) * 8, rc);
+  if (rc) return rc;
+  HCHECK(hipMemsetAsync(dids, 0xff, size_t(n) * size_t(max_num) * 4, c->stream));
+  HCHECK(hipMemsetAsync(dvals, 0, size_t(n) * size_t(max_num) * 8, c->stream));
+  HCHECK(hk_proctex_launch_points(c->procTex, c->stream, make_scene(c), n, dpos, ddir, dh, dids, dvals, n, max_num));
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(ids, dids, size_t(n) * size_t(max_num) * 4, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(halfs4, dvals, size_t(n) * size_t(max_num) * 8, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
 int hydra_hip_stage_make_eye_rays(hydra_hip_handle c, int n, const int32_t* xy, const float* offs4, float* ray_pos4, float* ray_dir4) {
   if (!c || n <= 0 || !c->globals.p) return fail(c, HYDRA_HIP_ESTATE, "stage_make_eye_rays: globals are not uploaded");
   HCHECK(hipSetDevice(c->device));
@@ -2015,6 +2126,7 @@ int hydra_hip_stage_shade_point(hydra_hip_handle c, int n, const float* surf24, 
   float* dout = (float*)tb.up(c, nullptr, size_t(n) * 112, rc);
   if (rc) return rc;
   SceneDev s = make_scene(c);
+  stage_proctex_lists(c, n, s);
   hipLaunchKernelGGL(k_stage_shade_point, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, n, dsurf, ddir, dfl, drl, drn, dout);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(out28, dout, size_t(n) * 112, hipMemcpyDeviceToHost));
@@ -2032,7 +2144,9 @@ int hydra_hip_stage_bounce(hydra_hip_handle c, int n, int depth, int max_depth, 
   float* dr = (float*)tb.up(c, rands10, size_t(n) * 40, rc);
   float* dout = (float*)tb.up(c, nullptr, size_t(n) * 160, rc);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_stage_bounce, dim3((n + 127) / 128), dim3(128), 0, c->stream, make_scene(c), n, depth, max_depth, dpos, ddir, dsurf, din, dr, dout);
+  SceneDev s = make_scene(c);
+  stage_proctex_lists(c, n, s);
+  hipLaunchKernelGGL(k_stage_bounce, dim3((n + 127) / 128), dim3(128), 0, c->stream, s, n, depth, max_depth, dpos, ddir, dsurf, din, dr, dout);
   STAGE_EPILOG();
   HCHECK(hipMemcpy(out40, dout, size_t(n) * 160, hipMemcpyDeviceToHost));
   return HYDRA_HIP_OK;
@@ -2204,6 +2318,7 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
   int n = chains;
   STAGE_PROLOG(true);
   if (c->w <= 0 || c->h <= 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: set the image size first");
+  if (c->ptlMax > 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: materials of the scene bind procedural textures; this layer runs them in the path tracer only (trace_pass)");
   if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header holds no camera yet (IHWLayer::SetCamMatrices + PrepareEngineGlobals: the caller's Draw does both)");
   if (!header_frame_matches(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header's HRT_WIDTH_F x HRT_HEIGHT_F is not the layer's frame (ResizeScreen and the header must agree: splats are tested against one and written into the other)");
   const int maxD = max_depth > 0 ? max_depth : c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];
@@ -2447,6 +2562,7 @@ int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, int w
   HCHECK(hipSetDevice(c->device));
   { const int prc = prepare_geometry(c); if (prc) return prc; }
   { const int vrc = validate_materials(c); if (vrc) return vrc; }
+  if (c->ptlMax > 0) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: materials of the scene bind procedural textures; this layer runs them in the path tracer only (trace_pass)");
   { const int crc = prepare_classes(c); if (crc) return crc; }
   int rc = HYDRA_HIP_OK;
   if ((rc = ensure_fetch_counters(c))) return rc;

@@ -112,6 +112,10 @@ public:
   // with a shared accumulation image attached, every pass ends by adding its samples to it (the reference's layers do
   // this inside their per-pass contribution, GPUOCLLayerOther.cpp:259-283)
   void EndTracingPass() override { if (m_pExternalImage != nullptr) ContribToExternalImageAccumulator(m_pExternalImage); }
+  // IHWLayer.h:205 with RECOMPILE_PROCTEX_FROM_STRING (IHWLayer.h:341): the argument is the program text RenderDriverRTE::EndTexturesUpdate assembled
+  // from shaders/texproc.cl and the scene's data/proctex_*.c; GPUOCLLayer rebuilds its OpenCL program from it (GPUOCLLayer.cpp:788-810), this layer cuts
+  // the scene's functions and the generated calls out of it and builds them for gfx950 (hydra_hip_proctex_compile).  A text that does not compile throws with the compiler's log.
+  void RecompileProcTexShaders(const std::string& a_shaderText) override { check(hydra_hip_proctex_compile(m_h, a_shaderText.c_str(), a_shaderText.size()), "RecompileProcTexShaders"); }
   void FinishAll() override { check(hydra_hip_finish(m_h), "FinishAll"); }
   void SetRaysPerPixel(int a_num) override { m_spp = a_num > 0 ? a_num : 1; }
   int  GetRaysPerPixel() const override { return m_spp; }

@@ -66,6 +66,7 @@ int hydra_host_width(void* p) { return static_cast<HostScene*>(p)->drv->Width();
 int hydra_host_height(void* p) { return static_cast<HostScene*>(p)->drv->Height(); }
 int hydra_host_unsupported(void* p) { return static_cast<HostScene*>(p)->drv->UnsupportedFeatures(); }
 const char* hydra_host_log(void* p) { return static_cast<HostScene*>(p)->drv->Log().c_str(); }
+const char* hydra_host_proctex_program(void* p) { return static_cast<HostScene*>(p)->drv->ProcTexProgram().c_str(); }
 const char* hydra_host_last_error(void* p) { return static_cast<HostScene*>(p)->err.c_str(); }
 
 // what: 0 globals blob, 1 textures, 2 textures_aux, 3 geom, 4 materials, 5 pdfs, 6 bvh nodes (tree 0), 7 triangle float4 list

@@ -416,14 +416,6 @@ int32_t RenderDriverLite::AuxNormalMapFor(int32_t texId, int32_t a_matId) {
 // CreateFromHydraMaterialXmlNode + CreateMaterialFromXmlNode, PlainMaterialConverter.cpp:1502-1738
 bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   const std::string mtype = a_node->attr("type");
-  if (!m_procTexIds.empty()) {   // a texture slot bound to a procedural texture (<texture type="proc">: user code the OpenCL layer compiles into its kernels, shaders/texproc.cl)
-    std::function<void(const XmlNode*)> scan = [&](const XmlNode* n) {
-      if (n->name == "texture" && n->has_attr("id") && m_procTexIds.count(n->attr_int("id")))
-        Unsupported("material " + std::to_string(a_matId) + " binds procedural texture " + std::to_string(n->attr_int("id")) + " (DESIGN.md 8.7)");
-      for (const auto& ch : n->children) scan(ch.get());
-    };
-    scan(a_node);
-  }
   if (mtype == "shadow_catcher") {   // ShadowMatteMaterial, PlainMaterialConverter.cpp:77-99, 1638-1660: a bare node of class SHADOW_MATTE; no bump, opacity or emission (:1710).
     // The CPU integrator hands its sampler a zero shadow value (PT_Loop.cpp:240), so the surface passes rays on with zero throughput; the
     // back-plate texture of <back> belongs to the OpenCL layer's environmentColorExtended and is not read here
@@ -655,7 +647,8 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     if (std::string(displ->attr("type")) == "normal_bump" && texNode != nullptr) {
       Sampler sm = sampler_from_texref(texNode);
       if (!texNode->has_attr("input_gamma")) sm.gamma = 1.0f;
-      const int32_t auxId = AuxNormalMapFor(sm.texId, a_matId);
+      // a procedural normal map keeps its texture id in the slot (PlainMaterialConverter.cpp:1396-1399): the value comes from the path's list, not from the aux arena
+      const int32_t auxId = m_procTextures.count(sm.texId) ? sm.texId : AuxNormalMapFor(sm.texId, a_matId);
       int flags = 0;
       const XmlNode* invert = nm->child("invert");
       if (invert && invert->attr_int("x") == 1) flags |= HMF_INVERT_NMAP_X;
@@ -667,8 +660,117 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   }
   // PutAbstractMaterialToStorage :1848-1881
   PlainMaterialVec mdata = flatten(pResult);
+  AppendProcTexTail(a_node, a_matId, mdata);
   m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
   return true;
+}
+
+// ---- procedural textures.  The scene library declares them as <texture type="proc"> with the text of their functions in a data/proctex_*.c file and one
+// generated call; a material binds one with <texture type="texref_proc" id=...> and its arguments.  The reference splices the functions and the calls into
+// shaders/texproc.cl and has the layer rebuild that program (RenderDriverRTE_ProcTex.cpp); the material head lists the ids and is followed by an (id, offset)
+// table and the argument words the calls read as `stack[...]`.
+static const char* const kProcTexTailTag = "_PROCTEXTAILTAG_";
+static std::string replace_all(std::string s, const std::string& what, const std::string& with) {
+  for (size_t at = s.find(what); at != std::string::npos; at = s.find(what, at + with.size())) s.replace(at, what.size(), with);
+  return s;
+}
+bool RenderDriverLite::UpdateImageProc(int32_t a_texId, const XmlNode* a_texNode) {
+  const XmlNode* code = a_texNode->child("code");
+  const XmlNode* gen = xchild(code, "generated");
+  if (!code || !gen || !gen->child("call")) { Unsupported("procedural texture " + std::to_string(a_texId) + " without <code><generated><call>"); return false; }
+  if (const XmlNode* ao = a_texNode->child("ao"))   // ReadAOFromNode :272-302: ambient-occlusion rays feed readAttr_AO; this layer does not trace them
+    if (std::string(ao->attr("hemisphere")) != "") Unsupported("procedural texture " + std::to_string(a_texId) + " asks for ambient occlusion (<ao>)");
+  ProcTex pt;
+  pt.retT = (std::string(xattr(gen->child("return"), "type")) == "float4") ? 4 : 1;
+  pt.call = replace_all(gen->child("call")->text, kProcTexTailTag, "in_texStorage1, in_globals, hr_viewVectorHack");
+  std::vector<char> d;
+  if (!read_file(m_libPath + "/" + code->attr("loc"), d)) {   // the reference goes on without the functions (UpdateImageProc :603-615): fatal only once a material binds the texture
+    m_log += "procedural texture " + std::to_string(a_texId) + ": code file '" + code->attr("loc") + "' is missing from the scene library\n";
+    m_procTexMissing.insert(a_texId);
+    return false;
+  }
+  pt.code = replace_all(std::string(d.begin(), d.end()), kProcTexTailTag, " __global const float4* restrict in_texStorage1, __global const EngineGlobals* restrict in_globals, const float3 hr_viewVectorHack");
+  m_procTextures[a_texId] = pt;
+  return true;
+}
+std::string RenderDriverLite::ProcTexProgramText() const {
+  // the two regions of shaders/texproc.cl by their marker lines; every region ends at this layer's own end mark (include/hydra_hip.h, hydra_hip_proctex_compile)
+  std::string t = "// procedural textures of " + m_libPath + "\n//#PUT_YOUR_PROCEDURAL_TEXTURES_HERE:\n\n";
+  for (const auto& pt : m_procTextures) t += pt.second.code + "\n";
+  t += "//#HK_END_OF_PROCEDURAL_TEXTURES\n//#PUT_YOUR_PROCEDURAL_TEXTURES_EVAL_HERE:\n\n    int counter = 0;\n";
+  for (const auto& pt : m_procTextures) {
+    const std::string id = std::to_string(pt.first);
+    t += "    if(materialHeadHaveTargetProcTex(pHitMaterial," + id + ") && counter < MAXPROCTEX)\n    {\n";
+    t += "      __global const float* stack = fdata + findArgDataOffsetInTable(" + id + ", table);\n";
+    t += "      ptl.fdata4[counter] = to_float3(" + pt.second.call + ");\n";
+    t += "      ptl.id_f4 [counter] = " + id + ";\n      counter++;\n    }\n\n";
+  }
+  t += "    ptl.currMaxProcTex = counter;\n//#HK_END_OF_PROCEDURAL_TEXTURES_EVAL\n";
+  return t;
+}
+void RenderDriverLite::AppendProcTexTail(const XmlNode* a_materialNode, int32_t a_matId, std::vector<float>& mdata) {
+  if (m_procTextures.empty() && m_procTexMissing.empty()) return;
+  // FindAllProcTextures :57-87: the bound ids in document order; ReadAllProcTexArgsFromMaterialNode :90-193: the <arg> words of every texref_proc node
+  std::vector<int32_t> ids;
+  std::map<int32_t, std::vector<float>> args;
+  std::function<void(const XmlNode*)> scan = [&](const XmlNode* n) {
+    if (n->name == "texture" && n->has_attr("id") && m_procTextures.count(n->attr_int("id"))) {
+      const int32_t id = n->attr_int("id");
+      ids.push_back(id);
+      if (std::string(n->attr("type")) == "texref_proc") {
+        std::vector<float> datav;
+        for (const XmlNode* arg : n->children_named("arg")) {
+          const std::string type = arg->attr("type");
+          const int size = arg->attr_int("size");
+          std::istringstream in(arg->attr("val"));
+          int comps = 0;
+          if (type == "sampler2D" || type == "int") { for (int i = 0; i < size; i++) { int x = 0; in >> x; float f; memcpy(&f, &x, 4); datav.push_back(f); } }
+          else if (type == "unsigned") { for (int i = 0; i < size; i++) { unsigned x = 0; in >> x; float f; memcpy(&f, &x, 4); datav.push_back(f); } }
+          else if (type == "float") comps = 1;
+          else if (type == "float2") comps = 2;
+          else if (type == "float3") comps = 3;
+          else if (type == "float4") comps = 4;
+          for (int i = 0; i < comps * size; i++) { float x = 0; in >> x; datav.push_back(x); }
+        }
+        args[id] = datav;
+      }
+    }
+    for (const auto& ch : n->children) scan(ch.get());
+  };
+  if (!m_procTexMissing.empty()) {
+    std::function<void(const XmlNode*)> scanMissing = [&](const XmlNode* n) {
+      if (n->name == "texture" && n->has_attr("id") && m_procTexMissing.count(n->attr_int("id")))
+        Unsupported("material " + std::to_string(a_matId) + " binds procedural texture " + std::to_string(n->attr_int("id")) + " whose code file is missing from the scene library");
+      for (const auto& ch : n->children) scanMissing(ch.get());
+    };
+    scanMissing(a_materialNode);
+  }
+  scan(a_materialNode);
+  if (ids.empty()) return;
+  if (mdata.size() < size_t(HM_NODE_FLOATS)) return;
+  float* head = mdata.data();
+  put_i(head, HM_FLAGS, get_i(head, HM_FLAGS) | HMF_HAVE_PROC_TEXTURES);
+  // MakePTListFromTupleArray :255-277 + PutProcTexturesIdListToMaterialHead (cglobals.h:2732-2739): at most 16, the rest of the slots invalid
+  if (ids.size() > 16) { Unsupported("material " + std::to_string(a_matId) + " binds more than 16 procedural textures"); ids.resize(16); }
+  for (int i = 0; i < 16; i++) put_i(head, HM_PROC_TEX_IDS + i, i < int(ids.size()) ? ids[size_t(i)] : int32_t(HYDRA_INVALID_TEXTURE));
+  // PutTexParamsToMaterialWithDamnTable :196-252: one node of (id, offset) pairs over ALL procedural textures of the scene (offset -1: not bound here), its last
+  // word their number; then the argument words in pages of one node
+  std::vector<float> table(HM_NODE_FLOATS, 0.0f), data;
+  int counter = 0;
+  for (const auto& pt : m_procTextures) {
+    if (counter >= HM_NODE_FLOATS / 2) break;
+    const auto p = args.find(pt.first);
+    put_i(table.data(), counter * 2 + 0, pt.first);
+    put_i(table.data(), counter * 2 + 1, p != args.end() ? int32_t(data.size()) : -1);
+    if (p != args.end()) data.insert(data.end(), p->second.begin(), p->second.end());
+    counter++;
+  }
+  put_i(table.data(), HM_NODE_FLOATS - 1, counter);
+  data.resize((data.size() / HM_NODE_FLOATS + 1) * HM_NODE_FLOATS, 0.0f);
+  const int32_t tableOffset = int32_t(mdata.size());   // in floats from the head (PROC_TEX_TABLE_OFFSET = oldSize * PLAIN_MATERIAL_DATA_SIZE)
+  mdata.insert(mdata.end(), table.begin(), table.end());
+  mdata.insert(mdata.end(), data.begin(), data.end());
+  put_i(mdata.data(), HM_PROC_TEX_TABLE, tableOffset);
 }
 
 // ---- IES photometric webs.  The reference reads the file through Ian Ashdown's IESNA.C (hydra_drv/utils/ies_parser/IESNA.H, IESRender.cpp:19-36), which is not
@@ -1728,7 +1830,7 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
 
   if (texLib)
     for (auto* t : texLib->children_named("texture")) {
-      if (std::string(t->attr("type")) == "proc") { m_procTexIds.insert(t->attr_int("id")); continue; }   // declared only: refused when a material binds it (UpdateMaterial)
+      if (std::string(t->attr("type")) == "proc") { UpdateImageProc(t->attr_int("id"), t); continue; }
       if (!t->has_attr("loc")) continue;                       // delayed-load textures without data (dl="1")
       std::vector<char> d;
       if (!read_file(libPath + "/" + t->attr("loc"), d) || d.size() < 8) { m_log += std::string("missing texture chunk ") + t->attr("loc") + "\n"; continue; }
@@ -1739,6 +1841,9 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
       if (bpp != 4 && bpp != 16) { Unsupported("texture bpp " + std::to_string(bpp)); continue; }
       UpdateImage(t->attr_int("id"), wh[0], wh[1], bpp, 4, d.data() + 8);
     }
+  // EndTexturesUpdate :485-574: the layer builds the scene's procedural textures (nothing to do without any: the layer keeps no program)
+  m_procTexProgram = m_procTextures.empty() ? std::string() : ProcTexProgramText();
+  m_pHWLayer->RecompileProcTexShaders(m_procTexProgram);
   for (auto* m : matLib->children_named("material")) UpdateMaterial(m->attr_int("id"), m);
   std::set<int> loadedMeshes;
   for (auto* me : geoLib->children_named("mesh")) {

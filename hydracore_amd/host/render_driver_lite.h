@@ -37,6 +37,7 @@ public:
   int Height() const { return m_height; }
   int UnsupportedFeatures() const { return m_unsupported; }
   const std::string& Log() const { return m_log; }
+  const std::string& ProcTexProgram() const { return m_procTexProgram; }   // what RecompileProcTexShaders was handed (empty: no procedural textures)
   BVH4Builder& Builder() { return m_bvh; }
   void SetSeed(int s) { m_seed = s; m_ptInitDone = false; }
 
@@ -94,7 +95,14 @@ private:
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
   bool m_sceneHaveSkyPortals = false;
-  std::set<int32_t> m_procTexIds;                                         // ids of <texture type="proc"> declarations
+  // procedural textures (RenderDriverRTE_ProcTex.cpp): what <texture type="proc"> declares -- the generated call, the functions' text, the return width
+  struct ProcTex { std::string call, code; int retT = 4; };
+  std::map<int32_t, ProcTex> m_procTextures;
+  std::string m_procTexProgram;
+  std::set<int32_t> m_procTexMissing;                                     // declared, but the code file is not in the library
+  bool UpdateImageProc(int32_t a_texId, const XmlNode* a_texNode);        // RenderDriverRTE::UpdateImageProc :576-629
+  std::string ProcTexProgramText() const;                                  // the text EndTexturesUpdate hands to IHWLayer::RecompileProcTexShaders :485-574
+  void AppendProcTexTail(const XmlNode* a_materialNode, int32_t a_matId, std::vector<float>& mdata);   // UpdateMaterial :875-899 + PutAbstractMaterialToStorage :1865-1874
   std::vector<int32_t> m_lightIdByInst;                                   // light id of every instanced record
   std::vector<float> m_lightsInstanced;                                   // 128 floats per light instance
 

@@ -175,6 +175,24 @@ int hydra_hip_comm_destroy(hydra_hip_handle h);
 /* test entry point: the pack and unpack kernels of comm_gather_frame applied to this rank's own pixels into a zeroed frame */
 int hydra_hip_stage_pack_unpack(hydra_hip_handle h, float* rgba_frame, int width, int height);
 
+/* ---- procedural textures.
+ * Replaces IHWLayer::RecompileProcTexShaders (hydra_drv/IHWLayer.h:205; with RECOMPILE_PROCTEX_FROM_STRING, IHWLayer.h:341, its argument is the program text) as
+ * GPUOCLLayer implements it (GPUOCLLayer.cpp:788-810: rebuild the texproc program, size the per-ray result buffer).  `source` is that text: shaders/texproc.cl
+ * with the scene's functions after its '#PUT_YOUR_PROCEDURAL_TEXTURES_HERE:' line and one generated call per texture after '#PUT_YOUR_PROCEDURAL_TEXTURES_EVAL_HERE:'
+ * (RenderDriverRTE_ProcTex.cpp:446-629).  The two regions are cut out (they end at the reference file's next own line, or at '#HK_END_OF_PROCEDURAL_TEXTURES' /
+ * '#HK_END_OF_PROCEDURAL_TEXTURES_EVAL'), compiled for gfx950 with hiprtc inside this library's frame (hydracore_amd/csrc/hk_proctex_rt.h) and run between the
+ * closest-hit traversal and the bounce kernel of every bounce (where GPUOCLLayer::runKernel_ComputeHit runs ProcTexExec, GPUOCLKernels.cpp:662-690); results reach the
+ * shading code as four halfs per texture, as in the reference (WriteProcTextureList, cglobals.h:2327-2359).  HYDRA_HIP_EINVAL with the compiler's log in
+ * hydra_hip_last_error when the text does not compile.  source = NULL or length 0 drops the program.  A scene whose materials carry PLAIN_MATERIAL_HAVE_PROC_TEXTURES
+ * cannot be traced without one (trace_pass fails), and runs in the path tracer only (mmlt_begin / eval_gbuffer refuse it).  Ambient-occlusion inputs (readAttr_AO) are 1. */
+int hydra_hip_proctex_compile(hydra_hip_handle h, const char* source, size_t length);
+/* the same compilation without a device or a context (hiprtc builds for gfx950 wherever it runs): HYDRA_HIP_OK, or HYDRA_HIP_EINVAL with the log in hydra_hip_last_error(NULL) */
+int hydra_hip_proctex_check(const char* source, size_t length);
+/* test entries: the compiled program on n hits handed in -- ids[max_num][n] (HYDRA_INVALID_TEXTURE ends a point's list; what follows it is undefined) and the
+ * colours as halfs [max_num][n][4]; and the lists the following stage_shade_point / stage_bounce calls OF THE SAME n consult (n = 0 drops them) */
+int hydra_hip_stage_proctex(hydra_hip_handle h, int n, int max_num, const float* ray_pos4, const float* ray_dir4, const HydraLiteHit* hits, int32_t* ids, uint16_t* halfs4);
+int hydra_hip_stage_set_proctex(hydra_hip_handle h, int n, int max_num, const int32_t* ids, const uint16_t* halfs4);
+
 /* ---------------------------------------------------------------- stage entry points
  * One call = one wavefront kernel over n host-provided items; used by the parity tests and by the
  * traversal roofline bench.  All pointers are HOST pointers; float4 arrays are n*4 floats.           */

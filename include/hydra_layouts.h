@@ -156,6 +156,7 @@ enum { /* PLAIN_MAT_FLAGS cglobals.h:2624-2655 */
   HMF_CAST_CAUSTICS = 2, HMF_HAS_DIFFUSE = 4, HMF_HAS_TRANSPARENCY = 8, HMF_SKIP_SHADOW = 256, HMF_FORBID_EMISSIVE_GI = 512, HMF_INVIS_LIGHT = 16384,
   HMF_INVERT_NMAP_X = 16, HMF_INVERT_NMAP_Y = 32, HMF_INVERT_SWAP_NMAP_XY = 64, HMF_INVERT_HEIGHT = 128,   /* cglobals.h:2631-2634 */
   HMF_SKIP_SKY_PORTAL = 1024, HMF_HAVE_BTDF = 8192, HMF_CAN_SAMPLE_REFL_ONLY = 32768,
+  HMF_HAVE_PROC_TEXTURES = 65536,   /* PLAIN_MATERIAL_HAVE_PROC_TEXTURES, cglobals.h:2647: the head lists procedural texture ids (HM_PROC_TEX_IDS) and is followed by their argument table (HM_PROC_TEX_TABLE) */
   HMF_FLIP_TANGENT = 32768 * 128,   /* cglobals.h:2653 */
   HMF_ENERGY_FIX = 32768 * 256
 };
@@ -168,7 +169,7 @@ enum { /* BLEND_MASK_FLAGS cmaterial.h:1975-1979 */
 /* texture sampler embedded in a material / light blob, 12 words (cfetch.h:108-131) */
 enum { HS_FLAGS = 0, HS_GAMMA = 1, HS_TEXID = 2, HS_DUMMY = 3, HS_ROW0 = 4, HS_ROW1 = 8 };
 enum { HTEX_POINT_SAM = 1, HTEX_ALPHASRC_W = 2, HTEX_CLAMP_U = 4, HTEX_CLAMP_V = 8,
-       HTEX_COORD_SECOND = 16, HTEX_COORD_CAM_PROJ = 32 };
+       HTEX_COORD_SECOND = 16, HTEX_COORD_CAM_PROJ = 32, HTEX_DATA_HDR = 64 /* cglobals.h:18-24 */ };
 
 /* ---- lights: 128 floats each (clight.h:14-62, 493-521) ---- */
 enum {

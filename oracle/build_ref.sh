@@ -25,6 +25,18 @@ FLAGS="-x cl -Xclang -finclude-default-header -cl-std=CL1.2 -target amdgcn-amd-a
  -mllvm -force-attribute=MapSamplesToDisc:noinline -mllvm -force-attribute=MapSamplesToDisc:optnone \
  -cl-single-precision-constant -cl-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -D OCL_COMPILER -D SHADOW_TRACE_COLORED_SHADOWS -D ENABLE_OPACITY_TEX -D ENABLE_BLINN \
  -I $REF -I $REF/shaders -w"
+if [ "${1:-}" = texproc ]; then
+  # build_ref.sh texproc <scene library> <name>: the reference's procedural-texture program of one scene library (shaders/texproc.cl + the library's functions, put
+  # together by oracle/splice_texproc.py as RenderDriverRTE does at scene load) -> oracle/_ref/texproc_<name>.hsaco.  The spliced text lives in a scratch directory only.
+  # -Wno-error=incompatible-pointer-types: texproc.cl:27 hands a float4 pointer to a parameter declared int4*, which this clang rejects by default (a diagnostic
+  # level, the source is untouched).
+  TMPD=$(mktemp -d)
+  python3 "$HERE/splice_texproc.py" "$2" "$TMPD/texproc_generated.cl"
+  $CLANG $FLAGS -Wno-error=incompatible-pointer-types "$TMPD/texproc_generated.cl" -o "$OUT/texproc_$3.hsaco"
+  rm -rf "$TMPD"
+  ls -la "$OUT/texproc_$3.hsaco"
+  exit 0
+fi
 $CLANG $FLAGS "$HERE/ref_driver.cl" -o "$OUT/ref_driver.hsaco"
 $CLANG $FLAGS "$REF/shaders/trace.cl" -o "$OUT/trace.hsaco"
 for k in material light mlt screen; do $CLANG $FLAGS "$REF/shaders/$k.cl" -o "$OUT/$k.hsaco"; done

@@ -721,7 +721,55 @@ static f4 read_imagef_sw4(const int32_t* tex, f2 tc, int flags, int srgb) {
   res.w = f[0].w * w1 + f[1].w * w2 + f[2].w * w3 + f[3].w * w4;
   return res;
 }
-/* ref: cfetch.h:677-709 sample2DExt (no procedural textures: readProcTex returns w = -1, cglobals.h:2402-2440).
+/* ---- procedural textures.  The CPU integrator evaluates none (IntegratorCommon hands materialEval a dummy list, CPUExp_Integrators_Common.cpp:91-93); the OpenCL
+ * layer runs the scene's own functions in ProcTexExec (shaders/texproc.cl) and hands every ray a ProcTextureList (cglobals.h:2312-2318) whose colours went through
+ * half precision (WriteProcTextureList / ReadProcTextureList, :2327-2396).  The oracle restates the CONSUMER: readProcTex (:2402-2441) inside sample2DExt /
+ * sample2DAuxExt, over the list of the point being shaded -- handed in by the test (orc_stage_set_proctex: the lists the reference's ProcTexExec wrote) -- kept in a
+ * thread-local pointer because the reference threads it through every material function as an argument. */
+typedef struct { int n; int ids[16]; float vals[16][3]; } OrcPtl;
+static _Thread_local const OrcPtl* g_ptl = NULL;
+static inline f4 readProcTex(int texId) {
+  f4 r = {1.0f, 1.0f, 1.0f, -1.0f};
+  if (g_ptl == NULL) return r;
+  for (int k = 0; k < g_ptl->n && k < 16; k++)
+    if (g_ptl->ids[k] == texId) { r.x = g_ptl->vals[k][0]; r.y = g_ptl->vals[k][1]; r.z = g_ptl->vals[k][2]; r.w = 0.0f; break; }   /* ids are unique in a list: first = only match */
+  return r;
+}
+static float half_bits_to_float(unsigned h) {
+  const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+  uint32_t bits;
+  if (e == 0) { const float v = (float)m * 5.9604644775390625e-08f; return sign ? -v : v; }
+  if (e == 31) bits = sign | 0x7f800000u | (m << 13); else bits = sign | ((e + 112u) << 23) | (m << 13);
+  float f; memcpy(&f, &bits, 4); return f;
+}
+static int g_stagePtlN = 0, g_stagePtlMax = 0;
+static int* g_stagePtlIds = NULL;
+static uint16_t* g_stagePtlHalfs = NULL;
+/* the lists the following orc_stage_bounce / orc_stage_shade_point calls of the same n consult: ids[max_num][n], halfs[max_num][n][4]; n = 0 drops them */
+void orc_stage_set_proctex(int n, int max_num, const int* ids, const uint16_t* halfs4) {
+  free(g_stagePtlIds); free(g_stagePtlHalfs); g_stagePtlIds = NULL; g_stagePtlHalfs = NULL; g_stagePtlN = 0; g_stagePtlMax = 0;
+  if (n <= 0 || max_num <= 0 || !ids || !halfs4) return;
+  g_stagePtlIds = (int*)malloc(sizeof(int) * (size_t)n * (size_t)max_num);
+  g_stagePtlHalfs = (uint16_t*)malloc(sizeof(uint16_t) * 4 * (size_t)n * (size_t)max_num);
+  memcpy(g_stagePtlIds, ids, sizeof(int) * (size_t)n * (size_t)max_num);
+  memcpy(g_stagePtlHalfs, halfs4, sizeof(uint16_t) * 4 * (size_t)n * (size_t)max_num);
+  g_stagePtlN = n; g_stagePtlMax = max_num > 16 ? 16 : max_num;
+}
+/* ReadProcTextureList for point i of a stage call over n points: NULL when no lists were handed in for this n */
+static const OrcPtl* stage_ptl(int n, int i, OrcPtl* tmp) {
+  if (g_stagePtlN != n || g_stagePtlIds == NULL) return NULL;
+  tmp->n = 0;
+  for (int k = 0; k < g_stagePtlMax; k++) {
+    const int id = g_stagePtlIds[(size_t)k * n + i];
+    if ((uint32_t)id == INVALID_TEXTURE) break;
+    const uint16_t* h = g_stagePtlHalfs + ((size_t)k * n + i) * 4;
+    tmp->ids[k] = id; tmp->vals[k][0] = half_bits_to_float(h[0]); tmp->vals[k][1] = half_bits_to_float(h[1]); tmp->vals[k][2] = half_bits_to_float(h[2]);
+    tmp->n = k + 1;
+  }
+  return tmp;
+}
+
+/* ref: cfetch.h:677-709 sample2DExt.
  * blob = the material / light the sampler is embedded in, addressed in int4 units. */
 static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const OrcScene* s) {
   if ((uint32_t)samplerOffset == INVALID_TEXTURE || samplerOffset < 0) return v3(1, 1, 1);
@@ -735,6 +783,8 @@ static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const O
   f4 c;
   if (offset >= 0) c = read_imagef_sw4(s->texStorage + (size_t)offset * 4, tct, flags, (gamma != 1.0f));
   else { c.x = c.y = c.z = c.w = 1.0f; }
+  const f4 c1 = readProcTex(texId);
+  if (!(fabsf(c1.w + 1.0f) < 1e-5f)) c = c1;
   if (flags & TEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return v3(c.x, c.y, c.z);
 }
@@ -750,8 +800,11 @@ static f3 sample2DAuxExt(int auxTexId, int samplerOffset, f2 texCoord, const flo
   tct.x = sm[4] * texCoord.x + sm[5] * texCoord.y + sm[7];
   tct.y = sm[8] * texCoord.x + sm[9] * texCoord.y + sm[11];
   if (texId == 0) return v3(1, 1, 1);
-  const int offset = s->globals[s->globals[G_TEXAUX_TABLE] + auxTexId];
-  f4 c = read_imagef_sw4(s->texAuxStorage + (size_t)offset * 4, tct, flags, (gamma != 1.0f));
+  f4 c = readProcTex(texId);   /* a procedural normal map keeps its texture id in the aux slot (PlainMaterialConverter.cpp:1396-1399): the aux arena holds nothing for it and is not read */
+  if (fabsf(c.w + 1.0f) < 1e-5f) {
+    const int offset = s->globals[s->globals[G_TEXAUX_TABLE] + auxTexId];
+    c = read_imagef_sw4(s->texAuxStorage + (size_t)offset * 4, tct, flags, (gamma != 1.0f));
+  }
   if (flags & TEX_ALPHASRC_W) { c.x = c.w; c.y = c.w; c.z = c.w; }
   return v3(c.x, c.y, c.z);
 }
@@ -2758,6 +2811,8 @@ void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const f
     const float* in = in16 + 16 * (size_t)i;
     float* o = out40 + 40 * (size_t)i;
     memset(o, 0, 40 * sizeof(float));
+    OrcPtl ptlTmp;
+    g_ptl = stage_ptl(n, i, &ptlTmp);
     f3 ray_pos = v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), ray_dir = v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
     f3 thoroughput = v3(in[0], in[1], in[2]), accumColor = v3(in[4], in[5], in[6]);
     MisData misPrev = {in[3], in[7] != 0.0f};
@@ -2797,6 +2852,7 @@ void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const f
     o[31] = thoroughput.x; o[32] = thoroughput.y; o[33] = thoroughput.z; o[34] = accumColor.x; o[35] = accumColor.y; o[36] = accumColor.z;
     o[37] = misPrev.matSamplePdf; o[38] = misPrev.isSpecular ? 1.0f : 0.0f;
   }
+  g_ptl = NULL;
 }
 
 /* One shading point: kernel_LightSelect + kernel_LightSample + materialEval towards the sample + the BxDF sampling of

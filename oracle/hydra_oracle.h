@@ -71,6 +71,9 @@ void orc_shade_point(const OrcScene* s, int n, const float* surf24, const float*
                      const float* rands10, float* out28);
 void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* dir4, uint32_t* rng2, float* color4);
 /* one bounce of n paths with every input handed in: the kernel_* stages of PT_Loop.cpp:9-262 in order (layouts: include/hydra_hip.h, hydra_hip_stage_bounce) */
+/* procedural textures: the per-point lists (ids[max_num][n], colours as halfs [max_num][n][4]; HYDRA's INVALID_TEXTURE ends a list) the following orc_stage_bounce
+ * calls OF THE SAME n consult -- the oracle restates the consumer of the lists (readProcTex in sample2DExt), not the scene's functions; n = 0 drops them */
+void orc_stage_set_proctex(int n, int max_num, const int* ids, const uint16_t* halfs4);
 void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const float* pos4, const float* dir4, const float* surf24, const float* in16,
                       const float* rands10, float* out40);
 

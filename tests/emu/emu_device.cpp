@@ -37,6 +37,7 @@ static SceneDev to_dev(const EmuScene* e) {
   s.remapLists = e->remapListsSize > 0 ? e->remapLists : nullptr; s.remapListsSize = e->remapListsSize;
   s.remapTable = e->remapTableSize > 0 ? e->remapTable : nullptr; s.remapTableSize = e->remapTableSize;
   s.remapInst = e->remapInstSize > 0 ? e->remapInst : nullptr;    s.remapInstSize = e->remapInstSize;
+  s.ptlIds = nullptr; s.ptlVals = nullptr; s.ptlStride = 0; s.ptlMax = 0; s.ptlSlot = -1;   // no procedural texture lists in the emulation
   s.srgbLut = nullptr;
   s.alpha = reinterpret_cast<const uint2*>(e->alpha[0]);
   s.matBase = e->matStorage;

@@ -49,6 +49,8 @@ def load(fast=False):
     lib.orc_path_trace.argtypes = [sp, i32, vp, vp, vp, vp]
     lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_stage_bounce.argtypes = [sp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.orc_stage_set_proctex.argtypes = [i32, i32, vp, vp]
+    lib.orc_stage_set_proctex.restype = None
     lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.orc_render_pass.restype = C.c_uint64
     lib.orc_light_sample_forward.argtypes = [sp, i32, vp, vp, vp]
@@ -244,6 +246,14 @@ class Oracle:
         d1, d2, raw = np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 14), np.float32)
         self.lib.orc_gbuffer(C.byref(self.s), self.w, self.h, x0, y0, nx, ny, _p(d1), _p(d2), _p(raw))
         return d1, d2, raw
+
+    def stage_set_proctex(self, ids=None, colours=None):
+        """orc_stage_set_proctex: the per-point procedural texture lists (ids [max_num, n], colours [max_num, n, 4], stored as halfs) for the following stage_bounce calls of the same n"""
+        if ids is None:
+            self.lib.orc_stage_set_proctex(0, 0, None, None)
+            return
+        ids, halfs = np.ascontiguousarray(ids, np.int32), np.ascontiguousarray(colours, np.float16)
+        self.lib.orc_stage_set_proctex(ids.shape[1], ids.shape[0], _p(ids), _p(halfs))
 
     def stage_bounce(self, depth, max_depth, pos4, dir4, surf24, in16, rands10):
         """orc_stage_bounce: one bounce of n paths with every input handed in -> float32 [n, 40] (layouts: include/hydra_hip.h, hydra_hip_stage_bounce)"""

@@ -235,14 +235,20 @@ class RefWavefront:
     read back after every kernel.  What the kernels draw from their generators is a function of the seed: generator i starts as
     RandomGenInit(seed + i) (InitRandomGen, trace.cl:6-13)."""
 
-    def __init__(self, b, device=0):
+    def __init__(self, b, device=0, texproc=None):
+        """texproc: name of the scene's procedural-texture program in oracle/_ref (oracle/build_ref.sh texproc: the reference's texproc.cl with the scene's functions
+        spliced in as RenderDriverRTE does); ProcTexExec then runs after ComputeHit, as in GPUOCLLayer::runKernel_ComputeHit (GPUOCLKernels.cpp:662-690), and its
+        per-ray lists reach HitEnvOrLightKernel, Shade and NextBounce."""
         self.b = b
         self.mods = {k: RefModule(k + ".hsaco", device) for k in ("trace", "material", "light", "ref_driver")}
+        self.texproc = RefModule(texproc, device) if texproc else None
         self.have_inst = int(b["have_inst"])
 
     def close(self):
         for m in self.mods.values():
             m.close()
+        if self.texproc:
+            self.texproc.close()
 
     def run(self, pos4, dir4, seed, bounces):
         b, n = self.b, len(pos4)
@@ -294,11 +300,23 @@ class RefWavefront:
             r_surf, r_out = R.up(surf_planes), R.alloc(n * 96)
             R.launch("ref_read_surface_hit", n, [("p", r_surf), ("p", r_out), ("i", n)])
             st.update(hits=hits, flags_hit=flags.copy(), surf=R.down(r_out, f32, (n, 24)))
+            # ---- ProcTexExec (texproc.cl:94-192): F4_PROCTEX_SIZE = 12 float4 planes per ray -- 16 int planes of ids, then two textures per float4 as halfs
+            m_ptl = 0
+            if self.texproc is not None:
+                P = self.texproc
+                if depth == 0:
+                    sP = dict(tex=P.up(b["textures"]), mat=P.up(b["materials"]), glob=P.up(b["globals"]), matrices=P.up(b["inst_matrices"]))
+                p_out = P.up(np.zeros((12, n, 4), f32))
+                P.launch("ProcTexExec", n, [("p", P.up(flags)), ("p", P.up(rdir)), ("p", P.up(surf_planes)), ("p", 0), ("p", 0), ("p", P.up(hits)), ("p", sP["matrices"]),
+                                            ("p", p_out), ("p", sP["tex"]), ("p", sP["mat"]), ("p", sP["glob"]), ("i", n)], block=256)
+                ptl = P.down(p_out, f32, (12, n, 4))
+                st.update(proctex=ptl)
+                m_ptl = M.up(ptl)
             # ---- HitEnvOrLightKernel
             m_flags, m_color, m_thr, m_mis, m_emis = M.up(flags), M.up(color), M.up(thr), M.up(mis), M.alloc(n * 16)
             m_rpos, m_rdir, m_surf, m_hits = M.up(rpos), M.up(rdir), M.up(surf_planes), M.up(hits)
             m_xy = M.alloc(n * 4)
-            M.launch("HitEnvOrLightKernel", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_xy), ("p", m_surf), ("p", 0),
+            M.launch("HitEnvOrLightKernel", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_xy), ("p", m_surf), ("p", m_ptl),
                                                 ("p", m_color), ("p", m_thr), ("p", m_mis), ("p", m_emis), ("p", 0), ("p", m_mis), ("p", 0), ("p", 0), ("p", 0),
                                                 ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]),
                                                 ("p", sM["light_id"]), ("p", m_hits), ("f", 1.0), ("i", depth), ("i", 0), ("i", n)], block=256)
@@ -322,7 +340,7 @@ class RefWavefront:
             # ---- Shade
             m_shade, m_shadow, m_lrev = M.alloc(n * 16), M.up(shadow), M.up(lrev)
             m_flags = M.up(flags)
-            M.launch("Shade", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_surf), ("p", m_shadow), ("p", m_lrev), ("p", 0), ("p", 0), ("p", 0),
+            M.launch("Shade", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_surf), ("p", m_shadow), ("p", m_lrev), ("p", m_ptl), ("p", 0), ("p", 0),
                                   ("p", m_shade), ("p", 0), ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
             shade = M.down(m_shade, f32, (n, 4))
             st.update(shade=shade)
@@ -330,7 +348,7 @@ class RefWavefront:
             m_gens, m_fog = M.up(gens_l), M.up(fog)
             m_color, m_thr, m_mis = M.up(color), M.up(thr), M.up(mis)
             m_rpos2, m_rdir2 = M.up(rpos), M.up(rdir)
-            M.launch("NextBounce", n, [("p", 0), ("p", 0), ("p", m_rpos2), ("p", m_rdir2), ("p", m_flags), ("p", m_gens), ("p", m_surf), ("p", 0),
+            M.launch("NextBounce", n, [("p", 0), ("p", 0), ("p", m_rpos2), ("p", m_rdir2), ("p", m_flags), ("p", m_gens), ("p", m_surf), ("p", m_ptl),
                                        ("p", m_color), ("p", m_thr), ("p", m_mis), ("p", m_shadow), ("p", m_fog), ("p", m_shade), ("p", m_emis), ("p", 0), ("p", 0),
                                        ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]), ("i", n)], block=256)
             rpos, rdir = M.down(m_rpos2, f32, (n, 4)), M.down(m_rdir2, f32, (n, 4))

@@ -334,8 +334,19 @@ def _float4(x):               # rndFloat4_Pseudo, crandom.h:51-63
     return np.stack([h(15731, 74323, 871483), h(13734, 37828, 234234), h(11687, 26461, 137589), h(15707, 789221, 1376312589)], 1)
 
 
-def check_stage(name, b, run, bounces=3):
-    """run(depth, pos4, dir4, surf24, in16, rands10) -> out40 (include/hydra_hip.h, hydra_hip_stage_bounce)"""
+def proctex_lists(planes):
+    """the per-ray procedural texture lists as the reference's ProcTexExec stores them (WriteProcTextureList, cglobals.h:2327-2359: F4_PROCTEX_SIZE = 12 float4 planes --
+    16 int planes of ids, then two textures per float4 as four halfs each) -> ids int32 [16, n], colours float32 [16, n, 4]"""
+    n = planes.shape[1]
+    ids = planes.reshape(-1).view(np.int32)[:16 * n].reshape(16, n).copy()
+    halfs = planes[4:12].reshape(8, n, 4).view(np.float16).reshape(8, n, 2, 4)
+    vals = halfs.transpose(0, 2, 1, 3).reshape(16, n, 4).astype(np.float32)
+    return ids, vals
+
+
+def check_stage(name, b, run, bounces=3, set_lists=None):
+    """run(depth, pos4, dir4, surf24, in16, rands10) -> out40 (include/hydra_hip.h, hydra_hip_stage_bounce); set_lists(ids, colours): scenes with procedural textures --
+    hands the lists the reference's ProcTexExec wrote for this bounce to the implementation under test before run is called"""
     fx = load("ref_stage_%s.npz" % name)
     dead, out_of_scene = (4096 << 16), (128 << 16)
     with np.errstate(over="ignore"):
@@ -362,6 +373,10 @@ def check_stage(name, b, run, bounces=3):
             in16[:, 8:12], in16[:, 12] = rl, rl[:, 3]
             in16[:, 13] = g("shadow")[:, 0].astype(np.float32) / np.float32(65535.0)       # decompressShadow; opaque scenes: 0 or 1
             in16[:, 14], in16[:, 15] = g("hits")["instId"].view(np.float32), flags_hit.astype(np.uint32).view(np.float32)
+            if set_lists is not None:
+                ids, vals = proctex_lists(g("proctex"))
+                ids[:, ~(act & ~left)] = _U32(0xFFFFFFFE).view(np.int32)       # ProcTexExec leaves the rows of inactive rays untouched
+                set_lists(ids, vals)
             out = run(d, g("rpos"), g("rdir"), surf, in16, rands10)
             code = out[:, 3].view(np.int32)
             # kernel_HitEnvironment + kernel_AddLastBouceContrib against HitEnvOrLightKernel's colour of the rays that left the scene
@@ -413,6 +428,64 @@ def test_oracle_matches_reference_stage_kernels(name, built):
     _, b = host_scene(name, int(g["width"]), int(g["height"]), int(g["depth"]), int(g["dof"]))
     orc = make_oracle(b)
     check_stage(name, b, lambda d, pos4, dir4, surf, in16, rands10: orc.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10))
+
+
+def test_oracle_matches_reference_stage_kernels_with_procedural_textures(built):
+    """the same on the procedural-texture scene (tools/make_atrium.py --proctex): the oracle's sample2DExt / sample2DAuxExt consult the lists the reference's own
+    ProcTexExec (shaders/texproc.cl + the scene's functions, oracle/build_ref.sh texproc) wrote for every ray; HitEnvOrLightKernel, Shade and NextBounce read the same lists"""
+    _, b = host_scene("atrium_proctex_small", 96, 54, 5)
+    orc = make_oracle(b)
+    try:
+        check_stage("atrium_proctex_small", b, lambda d, pos4, dir4, surf, in16, rands10: orc.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10), set_lists=orc.stage_set_proctex)
+    finally:
+        orc.stage_set_proctex(None)
+    fx = load("ref_stage_atrium_proctex_small.npz")      # the fixture does exercise the lists: all four textures, the two-texture material included
+    ids, vals = proctex_lists(fx["b1_proctex"])
+    assert {3, 4, 5, 6} <= set(np.unique(ids[:2]).tolist()) and ((ids[1] >= 3) & (ids[1] <= 6)).sum() > 50 and np.isfinite(vals[:2]).all()
+
+
+def test_the_scene_library_of_procedural_textures_is_packed_and_compiles(built):
+    """Front end + run-time compiler without a device: the program text the front end hands to IHWLayer::RecompileProcTexShaders has the two regions of shaders/texproc.cl
+    and builds for gfx950 (hydra_hip_proctex_check: hiprtc needs no GPU); a broken function comes back with the compiler's message; material heads carry the flag, the id
+    list, the (id, offset) table over ALL procedural textures of the scene and the argument words (RenderDriverRTE_ProcTex.cpp:196-252, PlainMaterialConverter.cpp:1865-1874)"""
+    from hydracore_amd import HydraError
+    from hydracore_amd.capi import proctex_check
+    sc, b = host_scene("atrium_proctex_small", 96, 54, 5)
+    text = sc.proctex_program()
+    assert "#PUT_YOUR_PROCEDURAL_TEXTURES_HERE:" in text and "#PUT_YOUR_PROCEDURAL_TEXTURES_EVAL_HERE:" in text and "_PROCTEXTAILTAG_" not in text
+    proctex_check(text)
+    with pytest.raises(HydraError, match="prtex4_mix"):
+        proctex_check(text.replace("return x*(1.0f - a) + y*a;", "return x*(1.0f - a) + y*a + prtex4_mix;"))
+    with pytest.raises(HydraError, match="PUT_YOUR_PROCEDURAL_TEXTURES_HERE"):
+        proctex_check("float4 f() { return make_float4(0, 0, 0, 0); }")
+    g, mats = b["globals"], b["materials"].reshape(-1)
+    table = g[g[219]:g[219] + g[224]]                      # materials table (HG_MAT_TABLE_OFFS, HG_MAT_TABLE_SIZE): id -> offset in float4 (cfetch.h:192-197)
+    mi = mats.view(np.int32)
+    inv = np.uint32(0xFFFFFFFE).view(np.int32)
+
+    def head(mid):
+        o = int(table[mid]) * 4
+        return mats[o:], mi[o:]
+    expect = {0: [5], 4: [5], 1: [3, 4], 3: [4], 9: [6]}
+    for mid in range(10):
+        hf, hi = head(mid)
+        ids = [int(x) for x in hi[163:179] if x != inv]
+        assert ids == expect.get(mid, []), (mid, ids)
+        assert bool(hi[1] & 65536) == (mid in expect)
+        if mid not in expect:
+            continue
+        tab = hi[int(hi[129]):]
+        assert int(tab[191]) == 4 and [int(tab[2 * k]) for k in range(4)] == [3, 4, 5, 6]
+        offs = {int(tab[2 * k]): int(tab[2 * k + 1]) for k in range(4)}
+        assert all((offs[t] >= 0) == (t in expect[mid]) for t in offs)
+        args = hf[int(hi[129]) + 192:]
+        if mid == 1:       # checker3d(colorA, colorB, cells) then falloff(color1, color2)
+            np.testing.assert_allclose(args[offs[3]:offs[3] + 7], [0.85, 0.8, 0.7, 0.25, 0.2, 0.3, 2.5], rtol=1e-6)
+            np.testing.assert_allclose(args[offs[4]:offs[4] + 6], [0.9, 0.2, 0.1, 0.1, 0.3, 0.9], rtol=1e-6)
+        if mid == 0:       # triplanar(sampler2D 1, sampler2D 2, 4, 3.0): samplers travel as int bits
+            assert args[offs[5]:offs[5] + 2].view(np.int32).tolist() == [1, 2] and args[offs[5] + 2:offs[5] + 4].tolist() == [4.0, 3.0]
+        if mid == 9:       # the procedural normal map keeps its texture id in the normal-map slot
+            assert int(hi[83]) == 6
 
 
 # ---- the reference's own MMLT stage kernels (shaders/mlt.cl: MMLTMakeEyeRays, MMLTInitCameraPath, MMLTCameraPathBounce, MMLTLightSampleForward, MMLTLightPathBounce,

@@ -1401,3 +1401,111 @@ def test_gbuffer_full_size_1080p(built):
         check_gbuffer(tuple(np.ascontiguousarray(a) for a in win), orc.gbuffer(x0, y0, 96, 40))
     sc.close()
 
+
+
+# ---- procedural textures (hydra_hip_proctex_compile, hk_proctex_rt.h): the scene's own texture functions, compiled at load time
+def _proctex_core(name, w=96, h=54, depth=5):
+    from hydracore_amd import HipCore
+    sc, b = host_scene(name, w, h, depth)
+    core = HipCore(w, h, device=0)
+    core.upload_scene(b)
+    core.proctex_compile(sc.proctex_program())
+    return core, b, sc
+
+
+@pytest.fixture(scope="module")
+def gpu_atrium_proctex(built):
+    """the closed hall with four procedural textures (tools/make_atrium.py --proctex): 3-D checker, view falloff, tri-planar texture2D blend, procedural normal map"""
+    return _proctex_core("atrium_proctex_small")
+
+
+def test_procedural_textures_against_the_reference_program(gpu_atrium_proctex):
+    """The lists k_proctex writes, against the reference's own ProcTexExec (shaders/texproc.cl with this scene's functions spliced in the reference's way, compiled by
+    oracle/build_ref.sh texproc) on the rays of ref_stage_atrium_proctex_small.npz: same ids in the same order, colours equal as halfs except where the last bit of an
+    intermediate differs (the OpenCL layer hands ProcTexExec tangent frames it stores as 16-bit normals; nothing here reads them except through the normal)."""
+    from test_golden_ref import load, proctex_lists
+    core, b, _ = gpu_atrium_proctex
+    fx = load("ref_stage_atrium_proctex_small.npz")
+    inv = np.uint32(0xFFFFFFFE).view(np.int32)
+    seen = set()
+    for d in range(3):
+        ids_ref, vals_ref = proctex_lists(fx["b%d_proctex" % d])
+        flags_in, flags_hit = fx["b%d_flags_in" % d], fx["b%d_flags_hit" % d]
+        act = ((flags_in | flags_hit) & ((4096 | 128) << 16)) == 0
+        ids, vals = core.stage_proctex(fx["b%d_rpos" % d], fx["b%d_rdir" % d], fx["b%d_hits" % d])
+        have = act & (ids[0] != inv)
+        assert have.sum() > 0.2 * act.sum()
+        assert (ids_ref[0][act & ~have] == 0).all()                 # materials without procedural textures: the reference leaves the row as it was (zeros here)
+        length, length_ref = (ids != inv).cumprod(axis=0).sum(axis=0), (ids_ref != inv).cumprod(axis=0).sum(axis=0)
+        assert (length[have] == length_ref[have]).all() and length[have].max() == 2
+        for k in range(int(length[have].max())):
+            row = have & (length > k)
+            assert (ids[k][row] == ids_ref[k][row]).all()
+            seen.update(np.unique(ids[k][row]).tolist())
+            a, r = vals[k][row, :3], vals_ref[k][row, :3]
+            assert (a == r).all(axis=1).mean() > 0.97, (d, k, (a == r).all(axis=1).mean())
+            np.testing.assert_allclose(a, r, rtol=4e-3, atol=2e-3)    # two half ulps
+    assert seen == {3, 4, 5, 6}, seen                               # every texture of the scene was hit, the two-texture material included
+
+
+def test_hip_against_the_reference_stage_kernels_with_procedural_textures(gpu_atrium_proctex):
+    """test_hip_against_the_reference_stage_kernels on the procedural-texture scene: HitEnvOrLightKernel, Shade and NextBounce read the lists the reference's ProcTexExec
+    wrote; the bounce kernel's phases get the same lists (hydra_hip_stage_set_proctex) -- sample2DExt's procedural branch, the two-texture material, the procedural normal map"""
+    from test_golden_ref import check_stage
+    core, b, _ = gpu_atrium_proctex
+    try:
+        check_stage("atrium_proctex_small", b, lambda d, pos4, dir4, surf, in16, rands10: core.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10), set_lists=core.stage_set_proctex)
+    finally:
+        core.stage_set_proctex(None)
+
+
+def _render(core, w, h, spp=16, seed=99):
+    core.set_tile_partition(0, 1, 64)
+    core.init_path_tracing(seed)
+    core.reset_perf_counters()
+    core.trace_pass(spp)
+    return core.hdr_image(w, h), core.rays_stat()
+
+
+def test_flat_procedural_textures_render_the_plain_scene_bit_for_bit(built):
+    """End to end through the production kernels (k_proctex -> k_bounce<ALL | PROCTEX>): a 3-D checker and a falloff whose two colours are equal and exactly representable
+    as halfs, over white materials, against the same hall with those colours as the materials' own.  Same paths, same random numbers: the images are identical, and so
+    are the ray counts."""
+    flat, bf, _ = _proctex_core("atrium_proctexflat_small")
+    from hydracore_amd import HipCore
+    _, bp = host_scene("atrium_proctexplain_small", 96, 54, 5)
+    plain = HipCore(96, 54, device=0)
+    plain.upload_scene(bp)
+    img_f, st_f = _render(flat, 96, 54)
+    img_p, st_p = _render(plain, 96, 54)
+    assert np.isfinite(img_f).all() and img_f[..., :3].mean() > 0.01
+    assert (st_f.extensionRays, st_f.shadowRays, st_f.samples) == (st_p.extensionRays, st_p.shadowRays, st_p.samples)
+    assert (img_f.view(np.uint32) == img_p.view(np.uint32)).all()
+    flat.close(); plain.close()
+
+
+def test_procedural_texture_scene_renders_and_refuses_what_it_cannot_run(gpu_atrium_proctex):
+    """the full scene through the production kernels: finite, lit, tuning knobs leave it bit-identical; without a compiled program the pass fails loudly, MMLT and the
+    G-buffer refuse the scene, a text that does not compile comes back with the compiler's message"""
+    from hydracore_amd import HydraError
+    core, b, sc = gpu_atrium_proctex
+    img, st = _render(core, 96, 54)
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01 and st.samples == 16 * 96 * 54
+    for name, value in (("sort_paths", 0), ("scene_tables_in_lds", 0), ("trace_mode", 0), ("path_order", 0)):
+        old = core.get_option(name)
+        core.set_option(name, value)
+        img2, st2 = _render(core, 96, 54)
+        core.set_option(name, old)
+        assert (img2.view(np.uint32) == img.view(np.uint32)).all(), name
+        assert (st2.extensionRays, st2.shadowRays) == (st.extensionRays, st.shadowRays)
+    with pytest.raises(HydraError, match="procedural"):
+        core.mmlt_begin(1024, 1, 3, 5)
+    core.proctex_compile("")
+    with pytest.raises(HydraError, match="procedural textures"):
+        core.trace_pass(1)
+    bad = sc.proctex_program().replace("prtex3_cell(p.x, cells)", "prtex3_cell(p.x, cells, 1)")
+    with pytest.raises(HydraError, match="prtex3_cell"):
+        core.proctex_compile(bad)
+    core.proctex_compile(sc.proctex_program())
+    img3, _ = _render(core, 96, 54)
+    assert (img3.view(np.uint32) == img.view(np.uint32)).all()

@@ -294,6 +294,12 @@ def main():
                     "over diffuse (cmaterial.h:1558-1846, cmatpbrt.h:105-540)")
     ap.add_argument("--height-bump", action="store_true", help="materials 0, 4 (floor) and 9 (a wall) get <displacement type='height_bump'> over a generated 256x256 "
                     "height map (amount 0.8; the wall's copy smoothed, smooth_lvl 0.3): the layer bakes the normal maps (IHWLayer::NormalMapFromDisplacement)")
+    ap.add_argument("--proctex", nargs="?", const="full", default=None, choices=("full", "flat", "plain"), help="closed hall; declares four procedural textures (<texture type='proc'> + data/proctex_*.c in the dialect HydraAPI "
+                    "generates: a 3-D checker over the local position, a view falloff over hr_viewVectorHack, a tri-planar blend of the two stored checkers through "
+                    "texture2D, a rippled normal through StoreNormal) and binds them: floor = tri-planar diffuse, columns = checker diffuse + falloff reflection "
+                    "(two textures in one material), pots = falloff diffuse, a wall = the procedural normal map.  'flat': the checker and the falloff with both colours "
+                    "equal (exactly representable in half precision) on materials 0, 1, 3, 4 over white; 'plain': no procedural textures, those colours as the materials' own -- "
+                    "the two must render the same image bit for bit")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky_tex = args.sky_tex or args.sky_hdr or args.portal
@@ -399,6 +405,92 @@ def main():
             f.write(img.tobytes())
         xml.append('  <texture id="%d" name="tex%d" loc="%s" offset="8" bytesize="%d" width="%d" height="%d" dl="0" />' % (tid, tid, name, tw * th * img.dtype.itemsize * 4, tw, th))
         chunk += 1
+    proc_ids = {}
+    if args.proctex in ("full", "flat"):   # procedural textures: functions in the scene library, one generated call each (the layout of HydraAPI's HRTextureNodeProc export)
+        procs = [
+            ("checker3d", """float prtex%(n)d_cell(float x, float s)
+{
+  return floor(x*s);
+}
+
+float4 prtex%(n)d_main(const SurfaceInfo* sHit, float3 colorA, float3 colorB, float cells, _PROCTEXTAILTAG_)
+{
+  const float3 p = readAttr_LocalPos(sHit);
+  const float k = prtex%(n)d_cell(p.x, cells) + prtex%(n)d_cell(p.y, cells) + prtex%(n)d_cell(p.z, cells);
+  const float odd = fabs(fmod(k, 2.0f));
+  const float3 c = (odd > 0.5f) ? colorA : colorB;
+  return make_float4(c.x, c.y, c.z, 0.0f);
+}
+""", [("float3", "colorA", 3), ("float3", "colorB", 3), ("float", "cells", 1)]),
+            ("falloff", """float3 prtex%(n)d_mix(float3 x, float3 y, float a)
+{
+  return x*(1.0f - a) + y*a;
+}
+
+float4 prtex%(n)d_main(const SurfaceInfo* sHit, float3 color1, float3 color2, _PROCTEXTAILTAG_)
+{
+  const float3 norm   = readAttr_ShadeNorm(sHit);
+  const float3 rayDir = hr_viewVectorHack;
+  const float cosAlpha = fabs(dot(norm, rayDir));
+  return to_float4(prtex%(n)d_mix(color1, color2, cosAlpha), 0.0f);
+}
+""", [("float3", "color1", 3), ("float3", "color2", 3)]),
+            ("triplanar", """float3 prtex%(n)d_weights(float3 n, float sharp)
+{
+  float3 w = make_float3(pow(fabs(n.x), sharp), pow(fabs(n.y), sharp), pow(fabs(n.z), sharp));
+  w = max(w, 0.00001f);
+  const float b = w.x + w.y + w.z;
+  return w / b;
+}
+
+float4 prtex%(n)d_main(const SurfaceInfo* sHit, sampler2D texSide, sampler2D texTop, float sharp, float mapScale, _PROCTEXTAILTAG_)
+{
+  const float3 norm = readAttr_ShadeNorm(sHit);
+  const float3 pos  = readAttr_WorldPos(sHit);
+  const float3 w    = prtex%(n)d_weights(norm, sharp);
+  const float2 x_uv = make_float2(pos.z / mapScale, pos.y / mapScale);
+  const float2 y_uv = make_float2(pos.x / mapScale, pos.z / mapScale);
+  const float2 z_uv = make_float2(pos.x / mapScale, pos.y / mapScale);
+  const float4 cx = texture2D(texSide, x_uv, 0);
+  const float4 cy = texture2D(texTop,  y_uv, TEX_CLAMP_U);
+  const float4 cz = texture2D(texSide, z_uv, TEX_POINT_SAM);
+  return cx * w.x + cy * w.y + cz * w.z;
+}
+""", [("sampler2D", "texSide", 1), ("sampler2D", "texTop", 1), ("float", "sharp", 1), ("float", "mapScale", 1)]),
+            ("ripples", """float4 prtex%(n)d_main(const SurfaceInfo* sHit, float freq, float amp, _PROCTEXTAILTAG_)
+{
+  const float2 tc = readAttr_TexCoord0(sHit);
+  const float dx = amp * cos(freq * tc.x) ;
+  const float dy = amp * sin(freq * tc.y + 0.5f * tc.x);
+  return StoreNormal(make_float3(-dx, -dy, 1.0f), NORMAL_IN_TANGENT_SPACE);
+}
+""", [("float", "freq", 1), ("float", "amp", 1)]),
+        ]
+        for k, (pname, code, pargs) in enumerate(procs):
+            tid = len(texs) + k
+            proc_ids[pname] = tid
+            fname = "data/proctex_%05d.c" % tid
+            with open(os.path.join(out, fname), "w") as f:
+                f.write(code % {"n": tid})
+            call, arg_xml, wo = [], [], 0
+            for ai, (atype, aname, words) in enumerate(pargs):
+                arg_xml.append('        <arg id="%d" type="%s" name="%s" size="1" wsize="%d" woffset="%d" />' % (ai, atype, aname, words, wo))
+                if atype == "float3":
+                    call.append("make_float3(stack[%d], stack[%d], stack[%d])" % (wo, wo + 1, wo + 2))
+                elif atype == "sampler2D":
+                    call.append("as_int(stack[%d])" % wo)
+                else:
+                    call.append("stack[%d]" % wo)
+                wo += words
+            xml.append('  <texture id="%d" name="%s" type="proc">' % (tid, pname))
+            xml.append('    <code file="%s.c" main="main" loc="%s">' % (pname, fname))
+            xml.append('      <generated>')
+            xml.extend(arg_xml)
+            xml.append('        <return type="float4" />')
+            xml.append('        <call>prtex%d_main(sHit, %s, _PROCTEXTAILTAG_)</call>' % (tid, ", ".join(call)))
+            xml.append('      </generated>')
+            xml.append('    </code>')
+            xml.append('  </texture>')
     xml.append("</textures_lib>")
 
     cols = rng.uniform(0.2, 0.8, (10, 3))
@@ -435,6 +527,44 @@ def main():
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="orennayar"><color val="%s" /><roughness val="%.2f" /></diffuse></material>' % (mid, mid, c, 0.4 if mid == 2 else 0.9))
         else:
             xml.append('  <material id="%d" name="m%d" type="hydra_material"><diffuse brdf_type="lambert"><color val="%s" /></diffuse></material>' % (mid, mid, c))
+    if args.proctex:
+        def texref_proc(name, vals):   # a bound procedural texture: <arg> values in the order of the declaration
+            a = "".join('<arg id="%d" type="%s" size="1" val="%s" />' % (i, t, v) for i, (t, v) in enumerate(vals))
+            return '<texture id="%d" type="texref_proc">%s</texture>' % (proc_ids[name], a)
+        checker_args = [("float3", "0.85 0.8 0.7"), ("float3", "0.25 0.2 0.3"), ("float", "2.5")]
+        falloff_args = [("float3", "0.9 0.2 0.1"), ("float3", "0.1 0.3 0.9")]
+        new_mats = {} if args.proctex != "full" else {
+            0: '<diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" />%s</diffuse>' % texref_proc("triplanar", [("sampler2D", "1"), ("sampler2D", "2"), ("float", "4"), ("float", "3.0")]),
+            4: '<diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" />%s</diffuse>' % texref_proc("triplanar", [("sampler2D", "2"), ("sampler2D", "1"), ("float", "2"), ("float", "1.5")]),
+            1: '<diffuse brdf_type="lambert"><color val="0.8 0.8 0.8" />%s</diffuse><reflectivity brdf_type="%s"><color val="0.5 0.5 0.5">%s</color><glossiness val="0.6" /></reflectivity>'
+               % (texref_proc("checker3d", checker_args), refl, texref_proc("falloff", falloff_args)),
+            3: '<diffuse brdf_type="lambert"><color val="1 1 1" />%s</diffuse>' % texref_proc("falloff", [("float3", "0.9 0.9 0.2"), ("float3", "0.2 0.7 0.3")]),
+            9: '<diffuse brdf_type="lambert"><color val="%.4f %.4f %.4f" /></diffuse><displacement type="normal_bump"><normal_map><invert x="0" y="0" swap_xy="0" />%s</normal_map></displacement>'
+               % (tuple(cols[9]) + (texref_proc("ripples", [("float", "40.0"), ("float", "0.35")]),)),
+        }
+        flat_a, flat_b = "0.5 0.25 0.75", "0.75 0.5 0.25"
+        if args.proctex == "flat":
+            fa = [("float3", flat_a), ("float3", flat_a), ("float", "2.5")]
+            fb = [("float3", flat_b), ("float3", flat_b)]
+            new_mats = {
+                0: '<diffuse brdf_type="lambert"><color val="1 1 1" />%s</diffuse>' % texref_proc("checker3d", fa),
+                4: '<diffuse brdf_type="lambert"><color val="1 1 1" />%s</diffuse>' % texref_proc("falloff", fb),
+                # the reflectivity colour also sets the blend weight on the host (PlainMaterialConverter.cpp:1541-1591): it stays as in 'plain', under a white falloff
+                1: '<diffuse brdf_type="lambert"><color val="1 1 1" />%s</diffuse><reflectivity brdf_type="%s"><color val="%s">%s</color><glossiness val="0.6" /></reflectivity>'
+                   % (texref_proc("checker3d", fa), refl, flat_b, texref_proc("falloff", [("float3", "1 1 1"), ("float3", "1 1 1")])),
+                3: '<diffuse brdf_type="lambert"><color val="1 1 1" />%s</diffuse>' % texref_proc("falloff", fb),
+            }
+        elif args.proctex == "plain":
+            new_mats = {
+                0: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>' % flat_a,
+                4: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>' % flat_b,
+                1: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse><reflectivity brdf_type="%s"><color val="%s" /><glossiness val="0.6" /></reflectivity>' % (flat_a, refl, flat_b),
+                3: '<diffuse brdf_type="lambert"><color val="%s" /></diffuse>' % flat_b,
+            }
+        for i, line in enumerate(xml):
+            for mid, body in new_mats.items():
+                if line.startswith('  <material id="%d" ' % mid):
+                    xml[i] = '  <material id="%d" name="m%d" type="hydra_material">%s</material>' % (mid, mid, body)
     if args.height_bump:
         for i, line in enumerate(xml):
             for mid in (0, 4, 9):
