@@ -31,7 +31,14 @@ typedef ::SceneDev EngineGlobals;   // what `in_globals` points at: the tail arg
 #define __private
 #define __constant const
 #define restrict __restrict__
+#ifdef HK_HOST_EMU   /* the same frame built for the host (tests/proctex_host.py: the scene's functions feeding the CPU oracle); never in the product */
+#define HKU static inline
+#define __float_as_int(x) ::as_int(x)
+#define __int_as_float(x) ::as_float(x)
+#define __float_as_uint(x) ((unsigned)::as_int(x))
+#else
 #define HKU __device__ __forceinline__
+#endif
 
 HKU float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
 HKU float3 make_float3(float x, float y, float z) { float3 r = {x, y, z}; return r; }
@@ -51,7 +58,7 @@ HKU uint  as_uint(float x) { return __float_as_uint(x); }
   HKU float2 name(float2 v) { return make_float2(name(v.x), name(v.y)); } \
   HKU float3 name(float3 v) { return make_float3(name(v.x), name(v.y), name(v.z)); } \
   HKU float4 name(float4 v) { return make_float4(name(v.x), name(v.y), name(v.z), name(v.w)); }
-HKU_UNARY(fabs, ::fabsf(x))   HKU_UNARY(floor, ::floorf(x)) HKU_UNARY(ceil, ::ceilf(x))   HKU_UNARY(sqrt, ::sqrtf(x))  HKU_UNARY(rsqrt, ::rsqrtf(x))
+HKU_UNARY(fabs, ::fabsf(x))   HKU_UNARY(floor, ::floorf(x)) HKU_UNARY(ceil, ::ceilf(x))   HKU_UNARY(sqrt, ::sqrtf(x))  HKU_UNARY(rsqrt, 1.0f / ::sqrtf(x))
 HKU_UNARY(sin, ::sinf(x))     HKU_UNARY(cos, ::cosf(x))     HKU_UNARY(tan, ::tanf(x))     HKU_UNARY(asin, ::asinf(x))  HKU_UNARY(acos, ::acosf(x))
 HKU_UNARY(atan, ::atanf(x))   HKU_UNARY(exp, ::expf(x))     HKU_UNARY(exp2, ::exp2f(x))   HKU_UNARY(log, ::logf(x))    HKU_UNARY(log2, ::log2f(x))
 HKU_UNARY(trunc, ::truncf(x)) HKU_UNARY(round, ::roundf(x)) HKU_UNARY(sign, (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f))
@@ -160,6 +167,7 @@ HKU void evalAll(const PlainMaterial* pHitMaterial, const SurfaceInfo* sHit, con
 
 }   // namespace hk_user
 
+#ifndef HK_HOST_EMU
 // K_proctex: one thread per path of the bounce, between the closest-hit traversal and k_bounce (GPUOCLLayer::runKernel_ComputeHit runs ProcTexExec in the
 // same place, GPUOCLKernels.cpp:662-690).  Writes the path's list: ids[k * stride + slot] (HYDRA_INVALID_TEXTURE ends it), vals likewise as four halfs.
 __device__ __forceinline__ unsigned hk_float_to_half_bits(float f) { return unsigned(__builtin_bit_cast(unsigned short, _Float16(f))); }   // round to nearest even, as vstore_half does
@@ -171,11 +179,13 @@ __device__ __forceinline__ void proctex_one_path(const SceneDev& s, const int i,
   hk_user::ProcTextureList ptl;
   ptl.currMaxProcTex = 0;
   if (HitSome(hit)) {
-    const f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
-    const m44 worldToObject = load_m44(s.instMatrices + size_t(hit.instId) * 4);
-    const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
-    const float* head = materialAt(s, surf.matId);
-    if (head != nullptr && (as_int(head[HM_FLAGS]) & HMF_HAVE_PROC_TEXTURES) != 0) {
+    // the material first (triangle record -> remap lists -> head): most paths of most scenes end here, before the surface is worth evaluating
+    const TriData td = fetchTri(s, hit);
+    const float* head = materialAt(s, remapMaterialId(td.matId, hit.instId, s));
+    if ((as_int(head[HM_FLAGS]) & HMF_HAVE_PROC_TEXTURES) != 0) {
+      const f3 ray_pos = xyz(pos4[i]), ray_dir = xyz(dir4[i]);
+      const m44 worldToObject = load_m44(s.instMatrices + size_t(hit.instId) * 4);
+      const SurfaceHit surf = evalSurfaceWith(s, ray_pos, ray_dir, hit, td, worldToObject);
       hk_user::SurfaceInfo si;
       si.wp = hk_user::make_float3(surf.pos.x, surf.pos.y, surf.pos.z);
       const f3 lp = mul4x3(worldToObject, surf.pos);
@@ -209,3 +219,4 @@ extern "C" __global__ void __launch_bounds__(256) k_proctex_points(SceneDev s, i
   s.ptlSlot = -1;
   if (i < nPoints) proctex_one_path(s, i, pos4, dir4, hits, ids, vals, stride, maxNum);
 }
+#endif   // HK_HOST_EMU

@@ -769,6 +769,37 @@ static const OrcPtl* stage_ptl(int n, int i, OrcPtl* tmp) {
   return tmp;
 }
 
+/* The scene's own texture functions are user code, not reference code: for whole-frame comparisons the test builds them for the host (tests/proctex_host.py) and
+ * hands the oracle the entry; PathTrace then does what ProcTexExec does for a hit whose material head carries PLAIN_MATERIAL_HAVE_PROC_TEXTURES (texproc.cl:127-190):
+ * world and local position, frame, texture coordinate, AO inputs = 1, the ray direction as `hr_viewVectorHack`; colours go through half precision as in
+ * WriteProcTextureList / ReadProcTextureList. */
+typedef void (*orc_proctex_fn)(void* user, const float* surf19, const float* head, const float* view3, int* count, int* ids16, float* vals48);
+static orc_proctex_fn g_proctexFn = NULL;
+static void* g_proctexUser = NULL;
+void orc_set_proctex_eval(void* fn, void* user) { g_proctexFn = (orc_proctex_fn)fn; g_proctexUser = user; }
+static unsigned float_to_half_bits(float f) {   /* round to nearest even (vstore_half) */
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((x >> 23) & 0xffu) - 127 + 15;
+  uint32_t m = x & 0x7fffffu;
+  if (((x >> 23) & 0xffu) == 0xffu) return sign | 0x7c00u | (m ? 0x200u : 0u);
+  if (e >= 31) return sign | 0x7c00u;
+  if (e <= 0) {
+    if (e < -10) return sign;
+    m |= 0x800000u;
+    const int shift = 14 - e;
+    uint32_t h = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1u))) h++;
+    return sign | h;
+  }
+  uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+  return sign | h;
+}
+enum { MF_HAVE_PROC_TEXTURES = 65536 };   /* cglobals.h:2647 */
+
 /* ref: cfetch.h:677-709 sample2DExt.
  * blob = the material / light the sampler is embedded in, addressed in int4 units. */
 static f3 sample2DExt(int samplerOffset, f2 texCoord, const float* blob, const OrcScene* s) {
@@ -2770,6 +2801,21 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     /* kernel_EvalSurface */
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
+    OrcPtl ptlOfHit;
+    g_ptl = NULL;
+    if (g_proctexFn != NULL && (as_int(mat[1]) & MF_HAVE_PROC_TEXTURES)) {   /* ProcTexExec, shaders/texproc.cl:127-190 */
+      const m44 worldToObject = load_m44(s->instMatrices + (size_t)hit.instId * 16);
+      const f3 lp = mul4x3(worldToObject, surf.pos);
+      const float surf19[19] = {surf.pos.x, surf.pos.y, surf.pos.z, lp.x, lp.y, lp.z, surf.normal.x, surf.normal.y, surf.normal.z, surf.tangent.x, surf.tangent.y, surf.tangent.z,
+                                surf.biTangent.x, surf.biTangent.y, surf.biTangent.z, surf.texCoord.x, surf.texCoord.y, 1.0f, 1.0f};
+      const float view3[3] = {ray_dir.x, ray_dir.y, ray_dir.z};
+      int count = 0;
+      float vals48[48];
+      g_proctexFn(g_proctexUser, surf19, mat, view3, &count, ptlOfHit.ids, vals48);
+      ptlOfHit.n = count < 16 ? count : 16;
+      for (int k = 0; k < ptlOfHit.n; k++) for (int c = 0; c < 3; c++) ptlOfHit.vals[k][c] = half_bits_to_float(float_to_half_bits(vals48[3 * k + c]));
+      g_ptl = &ptlOfHit;
+    }
     if (stage_emission(s, ray_pos, ray_dir, &surf, mat, hit.instId, flags, misPrev, &currColor)) break;
     else if (depth >= maxDepth - 1) { currColor = v3(0, 0, 0); break; }
     float rl[4];
@@ -2797,6 +2843,7 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     }
     stage_next(s, mat, &surf, allRands, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput);
   }
+  g_ptl = NULL;
   accumColor = add3(accumColor, mul3(thoroughput, currColor));   /* kernel_AddLastBouceContrib */
   return accumColor;
 }

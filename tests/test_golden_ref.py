@@ -591,3 +591,51 @@ def test_oracle_matches_reference_gbuffer_stage_kernels(name, built):
     r = load("ref_%s.npz" % name)
     _, b = host_scene(name, 96, 96, int(r["depth"]), int(r["dof"]))
     check_gbuffer_stage(name, make_oracle(b).gbuffer())
+
+
+def test_oracle_runs_the_scene_functions_built_for_the_host(built):
+    """tests/proctex_host.py: the scene's procedural texture functions compiled for x86 inside the frame the device build uses, called by the oracle's PathTrace per hit.
+    Checked here without a GPU against the reference: on the rays of ref_stage_atrium_proctex_small.npz the host-built functions give the lists the reference's own
+    ProcTexExec wrote (same ids; colours equal as halfs on >= 97 % and within two half-ulps elsewhere: glibc's pow / cos / sin / fmod against the device's), and a frame
+    renders through them."""
+    import ctypes as C
+    import proctex_host
+    sc, b = host_scene("atrium_proctex_small", 96, 54, 5)
+    orc = make_oracle(b)
+    lib = C.CDLL(proctex_host.build(sc.proctex_program()))
+    user = proctex_host.HostUser(b["globals"].ctypes.data, b["textures"].ctypes.data)
+    fx = load("ref_stage_atrium_proctex_small.npz")
+    ids_ref, vals_ref = proctex_lists(fx["b1_proctex"])
+    surf, rdir, hits = fx["b1_surf"], fx["b1_rdir"], fx["b1_hits"]
+    act = ((fx["b1_flags_in"] | fx["b1_flags_hit"]) & ((4096 | 128) << 16)) == 0
+    g, mats = b["globals"], b["materials"].reshape(-1)
+    table = g[g[219]:g[219] + g[224]]
+    inst = b["inst_matrices"].reshape(-1, 4, 4)
+    lib.proctex_eval.argtypes = [C.c_void_p] * 7
+    checked = same = 0
+    for i in np.nonzero(act)[0][:1500]:
+        mid = int(surf[i, 17].view(np.int32))
+        head = mats[int(table[mid]) * 4:]
+        if not (int(head[1].view(np.int32)) & 65536):
+            assert ids_ref[0, i] == 0
+            continue
+        m = inst[hits["instId"][i]]                                  # four columns, world -> object
+        wp = surf[i, 0:3]
+        lp = m[0, :3] * wp[0] + m[1, :3] * wp[1] + m[2, :3] * wp[2] + m[3, :3]
+        s19 = np.concatenate([wp, lp, surf[i, 3:6], surf[i, 9:12], surf[i, 12:15], surf[i, 15:17], [1.0, 1.0]]).astype(np.float32)
+        view = np.ascontiguousarray(rdir[i, :3], np.float32)
+        count, ids, vals = C.c_int(0), np.zeros(16, np.int32), np.zeros(48, np.float32)
+        lib.proctex_eval(C.addressof(user), s19.ctypes.data, head.ctypes.data, view.ctypes.data, C.addressof(count), ids.ctypes.data, vals.ctypes.data)
+        n = count.value
+        assert n >= 1 and (ids[:n] == ids_ref[:n, i]).all() and (n == 16 or ids_ref[n, i] == np.uint32(0xFFFFFFFE).view(np.int32))
+        mine = vals[:3 * n].reshape(n, 3).astype(np.float16).astype(np.float32)
+        np.testing.assert_allclose(mine, vals_ref[:n, i, :3], rtol=4e-3, atol=2e-3)
+        checked += n
+        same += int((mine == vals_ref[:n, i, :3]).all(axis=1).sum())
+    assert checked > 400 and same >= 0.97 * checked, (checked, same)
+    proctex_host.attach(orc, sc.proctex_program(), b)
+    try:
+        with_tex, _, _ = orc.render(1, seed=5, sum_mode=False, streams=1)
+    finally:
+        proctex_host.detach(orc)
+    assert np.isfinite(with_tex).all() and with_tex[..., :3].mean() > 0.01      # (without the lists the scene cannot be rendered at all: its procedural normal map has no stored texture)

@@ -1509,3 +1509,29 @@ def test_procedural_texture_scene_renders_and_refuses_what_it_cannot_run(gpu_atr
     core.proctex_compile(sc.proctex_program())
     img3, _ = _render(core, 96, 54)
     assert (img3.view(np.uint32) == img.view(np.uint32)).all()
+
+
+def test_procedural_texture_scene_matches_the_oracle_image(gpu_atrium_proctex):
+    """Whole frames: the production kernels (k_proctex -> k_bounce<ALL | PROCTEX>) against the CPU oracle, whose PathTrace gets the lists from the SAME scene functions built
+    for the host (tests/proctex_host.py: the frame of hk_proctex_rt.h under HK_HOST_EMU, clang for x86) and rounds the colours through half precision as the reference's
+    layer does.  Device pow / cos / sin / fmod against glibc's can move a colour by one half-ulp (1e-3 relative), hence the looser per-pixel tolerance than
+    test_wavefront_pass_matches_oracle_image."""
+    import proctex_host
+    core, b, sc = gpu_atrium_proctex
+    orc = make_oracle(b)
+    proctex_host.attach(orc, sc.proctex_program(), b)
+    try:
+        w, h = b["width"], b["height"]
+        core.set_tile_partition(0, 1, 64)
+        core.init_path_tracing(777)
+        core.reset_perf_counters()
+        core.trace_pass(3)
+        img, st = core.hdr_image(w, h), core.rays_stat()
+        ref, rays, _ = orc.render(3, seed=777, sum_mode=False, streams=core.samples_in_flight())
+        assert abs(int(st.extensionRays + st.shadowRays) - rays) <= 0.002 * rays
+        err = np.abs(img[..., :3] - ref[..., :3])
+        bad = (err > 2e-3 * np.maximum(np.abs(ref[..., :3]), 1.0)).any(axis=2)
+        assert bad.mean() < 0.01, bad.mean()
+        assert abs(img[..., :3].mean() - ref[..., :3].mean()) < 2e-3 * ref[..., :3].mean()
+    finally:
+        proctex_host.detach(orc)
