@@ -256,15 +256,28 @@ HK_DEV bool emission_phase(const SceneDev& s, const f3 ray_pos, const f3 ray_dir
     currColor = emission;
   return true;
 }
+// back-plate scenes (hk_shading.h, environmentColorExtended): the pixel a path was generated for, from the path's id (k_raygen: gid = stream * nOwned + index of the pixel
+// in this rank's list); ownedPixels == nullptr: path i plays pixel i (hydra_hip_stage_path_trace)
+struct ScreenOfPath { const int* ownedPixels; int nOwned, width; };
+HK_DEV void screen_of_path(const ScreenOfPath& sp, int gid, int& x, int& y) {
+  const int pixel = (sp.ownedPixels != nullptr && sp.nOwned > 0) ? sp.ownedPixels[gid % sp.nOwned] : gid;
+  const int w = sp.width > 0 ? sp.width : 1;
+  x = pixel % w; y = pixel / w;
+}
 template <int F = HK_FEAT_ALL>
 HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                               const HydraLiteHit& hit, const TriData& td, const m44& instInv, SurfaceHit& surf, f3& finalColor) {
+                               const HydraLiteHit& hit, const TriData& td, const m44& instInv, SurfaceHit& surf, f3& finalColor, const ScreenOfPath sp = {nullptr, 0, 0}) {
   const f3 ray_pos = xyz(pos4), ray_dir = xyz(dir4);
   const uint32_t flags = uint32_t(as_int(dir4.w));
   f3 currColor = mk3(0, 0, 0);
   bool done = false;
   if (!HitSome(hit)) {              // kernel_HitEnvironment, PT_Loop.cpp:23-33
-    currColor = environmentColor<F>(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
+    if ((F & HK_FEAT_RARE_LIGHTS) && haveBackPlate(s)) {
+      int sx, sy;
+      screen_of_path(sp, as_int(pos4.w), sx, sy);
+      currColor = environmentColorExtended<F>(s, ray_pos, ray_dir, thr4.w, acc4.w != 0.0f, flags, sx, sy);
+    } else
+      currColor = environmentColor<F>(s, ray_dir, thr4.w, acc4.w != 0.0f, flags);
     done = true;
   }
   else {
@@ -281,11 +294,11 @@ HK_DEV bool surface_phase_with(const SceneDev& s, int depth, int maxDepth, const
 
 template <int F = HK_FEAT_ALL>
 HK_DEV bool surface_phase(const SceneDev& s, int depth, int maxDepth, const float4& pos4, const float4& dir4, const float4& thr4, const float4& acc4,
-                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor) {
+                          const HydraLiteHit& hit, SurfaceHit& surf, f3& finalColor, const ScreenOfPath sp = {nullptr, 0, 0}) {
   TriData td;
   m44 instInv;
   if (HitSome(hit)) { instInv = load_m44(s.instMatrices + size_t(hit.instId) * 4); td = fetchTri(s, hit); }
-  return surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
+  return surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor, sp);
 }
 
 // L1 + L2 -- light pick + sample, shadow ray (kernel_LightSelect, kernel_LightSample) with the random numbers handed in: rl = the
@@ -517,7 +530,7 @@ static inline int hk_bounce_stamps_read(unsigned long long* acc16, int reset) {
 template <int W, int F = HK_FEAT_ALL, int STG = 0>   // F: the shading features this instantiation contains (hk_shading.h, HK_FEAT_*); STG: see stage_scene_tables
 __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, SceneStage stage, SegQ q, uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ shadowCounts,
                                                     int depth, int maxDepth, PathState Sin, PathState Sout, const HydraLiteHit* __restrict__ hits,
-                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens, int sortPaths) {
+                                                    ShadowQ sh, float4* __restrict__ contrib, uint2* __restrict__ gens, int sortPaths, ScreenOfPath screen) {
   extern __shared__ float4 hk_scene_lds[];
   // workgroup-local grouping of the paths by shading class (sortPaths): counts per wave and class, slot offsets, permutation
   constexpr int NW = HK_BOUNCE_BLOCK / 64;
@@ -613,9 +626,9 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
       surf.texCoord = mk2(0, 0); surf.matId = 0; surf.t = hit.t; surf.sRayOff = 0.0f; surf.hfi = false;
 #else
 #ifdef HK_EXP_BOUNCE_PRELOAD
-      alive = surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor);
+      alive = surface_phase_with<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, td, instInv, surf, finalColor, screen);
 #else
-      alive = surface_phase<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor);
+      alive = surface_phase<F>(s, depth, maxDepth, pos4, dir4, thr4, acc4, hit, surf, finalColor, screen);
 #endif
 #endif
     }
@@ -739,6 +752,7 @@ struct BounceLaunch {         // one launch of the fused bounce kernel
   int grid; size_t ldsBytes; hipStream_t stream; SceneDev s; SceneStage stage; SegQ qIn;
   uint32_t* nextCnt; uint32_t* shCnt; int depth, maxDepth; PathState A, B; const HydraLiteHit* hits; ShadowQ sh;
   float4* contrib; uint2* gens; int sortPaths;
+  ScreenOfPath screen;   // back-plate scenes: which pixel a path belongs to
 };
 // each returns false when (W, F, STG) is not one of its instantiations; hk_launch_bounce tries them in turn
 bool hk_launch_bounce_lean(int W, int F, int STG, const BounceLaunch& a);      // W 3; F = 0, SKY, SKY | DELTA_LIGHTS | OREN_NAYAR

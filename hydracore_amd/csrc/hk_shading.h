@@ -1944,6 +1944,42 @@ HK_DEV float directLightEvalPDF(const float* L, f3 ray_dir) {   // clight.h:1462
   }
   return 1.0f;
 }
+// ---- the back-plate: what the CAMERA sees where a ray leaves the scene, when the scene names one (a sky light's or a shadow catcher's <back>: HRT_SHADOW_MATTE_BACK).
+// environmentColorExtended, cbidir.h:593-629, the OpenCL layer's form of the miss shader (HitEnvOrLightKernel, material.cl:354): a ray into a sun of the header's table
+// returns that sun; any other ray the environment as before, replaced by backColorOfSecondEnv (:543-573) for camera rays and for rays that only passed through
+// transparent surfaces.  The CPU integrator has no such branch (kernel_HitEnvironment calls environmentColor, PT_Loop.cpp:28); this layer takes it when, and only when,
+// the header names a back texture, so every scene without one keeps the CPU path's values.
+HK_DEV bool haveBackPlate(const SceneDev& s) { return uint32_t(g_varsI(s)[HV_I_SHADOW_MATTE_BACK]) != HYDRA_INVALID_TEXTURE; }
+HK_DEV f3 backColorOfSecondEnv(const SceneDev& s, f3 ray_dir, float screenX, float screenY) {
+  const float* vf = g_varsF(s);
+  const int offset = s.texTable[g_varsI(s)[HV_I_SHADOW_MATTE_BACK]];
+  const f3 mult = mk3(vf[HV_F_SHADOW_MATTE_BACK_COLOR_X], vf[HV_F_SHADOW_MATTE_BACK_COLOR_X + 1], vf[HV_F_SHADOW_MATTE_BACK_COLOR_X + 2]);
+  f2 tc = mk2(screenX / vf[HV_F_WIDTH_F], screenY / vf[HV_F_HEIGHT_F]);
+  if (g_varsI(s)[HV_I_SHADOW_MATTE_BACK_MODE] == 1) { float sintheta = 0.0f; tc = sphereMapTo2DTexCoord(ray_dir, sintheta); }
+  const float4 c = read_imagef_sw4(s.texStorage + offset, tc, HTEX_CLAMP_U | HTEX_CLAMP_V, true, s.srgbLut);
+  f3 env = mult * mk3(c.x, c.y, c.z);
+  if (vf[HV_F_BACK_TEXINPUT_GAMMA] != 1.0f) env = mk3(sRGBToLinear(env.x), sRGBToLinear(env.y), sRGBToLinear(env.z));   // on top of the fetch's own decode, as the reference has it
+  return env;
+}
+template <int F = HK_FEAT_ALL>
+HK_DEV f3 environmentColorExtended(const SceneDev& s, f3 ray_pos, f3 ray_dir, float prevPdf, bool prevSpecular, uint32_t flags, int screenX, int screenY) {
+  const int hitId = hitDirectLight(s, ray_dir);
+  if (hitId >= 0) {
+    const float* sun = reinterpret_cast<const float*>(s.globals) + HG_SUNS + hitId * HL_FLOATS;
+    f3 envColor = lightColor(sun) * directLightAttenuation(sun, ray_pos);
+    const float pdfW = directLightEvalPDF(sun, ray_dir);
+    const uint32_t gflags = uint32_t(s.hdr[HG_FLAGS]);
+    if (((flags >> 8) & 0xFFu) > 0 && !(gflags & HF_STUPID_PT_MODE) && !prevSpecular) envColor = mk3(0, 0, 0);
+    else if ((prevSpecular && (gflags & HF_ENABLE_PT_CAUSTICS)) || (gflags & HF_STUPID_PT_MODE)) envColor = envColor * (1.0f / pdfW);
+    if (gflags & HF_3WAY_MIS_WEIGHTS) envColor = mk3(0, 0, 0);
+    return envColor;
+  }
+  f3 envColor = environmentColor<F>(s, ray_dir, prevPdf, prevSpecular, flags);
+  const uint32_t rayBounce = (flags >> 8) & 0xFFu, other = flags >> 16;
+  const bool transparent = (other & 8u) != 0 && (other & 2u) == 0 && (other & 4u) == 0;   // RAY_EVENT_T without _D and _G, cglobals.h:1333-1336
+  if (rayBounce == 0 || transparent) envColor = backColorOfSecondEnv(s, ray_dir, float(screenX) + 0.5f, float(screenY) + 0.5f);
+  return envColor;
+}
 // lightGetIntensity, clight.h:1661-1706: what the light a path has run into sends back along the ray
 template <int F = HK_FEAT_ALL>
 HK_DEV f3 lightGetIntensity(const SceneDev& s, const float* L, f3 ray_pos, f3 ray_dir, f2 texCoord, uint32_t flags, bool wasSpecular) {

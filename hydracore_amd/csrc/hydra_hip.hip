@@ -199,6 +199,18 @@ __global__ void k_init_gens(int nOwned, int streams, const int* __restrict__ own
   }
 }
 
+// the miss shader of a scene with a back-plate on rays handed in (hydra_hip_stage_environment)
+__global__ void k_stage_environment(SceneDev s, int n, const float4* __restrict__ dir4, const float* __restrict__ in8, float4* __restrict__ out4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  s.ptlSlot = -1;
+  const float* in = in8 + size_t(i) * 8;
+  const f3 c = haveBackPlate(s) ? environmentColorExtended(s, mk3(in[0], in[1], in[2]), xyz(dir4[i]), in[3], in[4] != 0.0f, uint32_t(as_int(in[5])), as_int(in[6]), as_int(in[7]))
+                                : environmentColor(s, xyz(dir4[i]), in[3], in[4] != 0.0f, uint32_t(as_int(in[5])));
+  out4[i] = mk4(c, 0.0f);
+}
+
+
 // ---------------------------------------------------------------------------------------- stage kernels (tests)
 __global__ void k_stage_eye(SceneDev s, int n, int w, int h, const int* xy, const float4* offs, float4* pos4, float4* dir4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,6 +498,7 @@ struct hydra_hip_ctx {
   std::vector<float> hostMaterials;  // host copy of the material arena and table, for validate_materials only
   std::vector<int32_t> hostMatTable;
   std::vector<int32_t> hostTexAuxTable;   // aux texture id -> offset in the aux arena (normal maps), for validate_materials
+  std::vector<int32_t> hostTexTable;      // texture id -> offset in the texture arena, for the back-plate check of run_bounces
   bool geomDirty = true;             // triRec/triTan/triBase must be rebuilt (geometry arena or geometry table changed)
   // procedural textures: the scene's compiled program (hydra_hip_proctex_compile), how many a material head lists at most (validate_materials), the per-path lists
   // of the bounce in flight (ids: int[ptlMax][slots], colours: uint2[ptlMax][slots]) and the lists handed to the stage entries (hydra_hip_stage_set_proctex)
@@ -1029,7 +1042,7 @@ struct BounceBufs {
 // split: trace -> k_hit (+compaction) -> shadow -> k_shade.
 // counters: live / shadowCnt / fetch are arrays of counter rows (HK_CROW words), row = bounce (fetch: 2*bounce + shadow)
 static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap, int maxDepth, BounceBufs bb, uint32_t* live, uint32_t* shadowCnt,
-                       float4* contrib, uint2* gens, uint32_t* fetch, bool timing) {
+                       float4* contrib, uint2* gens, uint32_t* fetch, bool timing, const ScreenOfPath& screen) {
   const int gWide = seg_grid(c, seg_q(live, 0, nseg, segCap), 256, c->shadeBlocksPerCU);
   const int gBounce = seg_grid(c, seg_q(live, 0, nseg, segCap), HK_BOUNCE_BLOCK, c->shadeBlocksPerCU * 256 / HK_BOUNCE_BLOCK);
   const bool fused = c->fusedBounce != 0;
@@ -1041,6 +1054,17 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
     stage.img = static_cast<const float4*>(c->stageImg.p);
     const int nF4 = stage.matF4 + stage.matTabF4 + stage.lightsF4 + stage.texTabF4 + stage.hdrF4 + stage.lselF4 + stage.triBaseF4 + stage.instLightF4 + stage.instMatF4;
     hipLaunchKernelGGL(k_build_stage_image, dim3((nF4 + 255) / 256), dim3(256), 0, c->stream, s, stage, static_cast<float4*>(c->stageImg.p));
+  }
+  // the back-plate (hk_shading.h, environmentColorExtended): named by the header's variables, which arrive with every PrepareEngineGlobals -- checked per pass
+  bool backPlate = false;
+  if (c->hostHeader.size() > size_t(HG_VARS_I + HV_I_SHADOW_MATTE_BACK_MODE)) {
+    const int32_t backId = c->hostHeader[HG_VARS_I + HV_I_SHADOW_MATTE_BACK];
+    if (uint32_t(backId) != HYDRA_INVALID_TEXTURE) {
+      if (backId <= 0 || size_t(backId) >= c->hostTexTable.size() || c->hostTexTable[size_t(backId)] < 0)
+        return fail(c, HYDRA_HIP_EINVAL, "trace_pass: HRT_SHADOW_MATTE_BACK names texture " + std::to_string(backId) + ", which is not in the texture arena");
+      if (!fused || c->shadeWaves != 3) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the back-plate exists in the fused bounce kernel at its default register budget only (fused_bounce = 1, shade_waves = 3)");
+      backPlate = true;
+    }
   }
   // procedural textures: k_proctex (the scene's program) runs between the traversal and the bounce kernel and leaves every path its list
   SceneDev sPtl = s;
@@ -1073,7 +1097,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       // the leanest instantiation that contains everything the scene uses (register need without spills: 167-168 VGPRs for
       // the lean sets, 16 spilled for the full one); the 4- and 5-wave register budgets (option shade_waves) exist as experiment
       // switches only: every feature, and everything staged or nothing
-      const int f = c->sceneFeatures;
+      const int f = c->sceneFeatures | (backPlate ? HK_FEAT_RARE_LIGHTS : 0);
       int W = 3, F = HK_FEAT_CLASSIC, G = stg;
       if (c->shadeWaves != 3) { W = (c->shadeWaves == 5) ? 5 : 4; F = HK_FEAT_ALL; G = (stg == 3) ? 3 : 0; }
       else if (f == 0) F = 0;
@@ -1086,7 +1110,7 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
       if (c->ptlMax > 0) F = HK_FEAT_ALL | HK_FEAT_PROCTEX;
       BounceLaunch bl;
       bl.grid = gBounce; bl.ldsBytes = (G == 0) ? 0 : stageBytes; bl.stream = c->stream; bl.s = sPtl; bl.stage = stage; bl.qIn = qIn; bl.nextCnt = nextCnt; bl.shCnt = shCnt;
-      bl.depth = depth; bl.maxDepth = maxDepth; bl.A = bb.A; bl.B = bb.B; bl.hits = hits; bl.sh = bb.sh; bl.contrib = contrib; bl.gens = gens; bl.sortPaths = sortPaths;
+      bl.depth = depth; bl.maxDepth = maxDepth; bl.A = bb.A; bl.B = bb.B; bl.hits = hits; bl.sh = bb.sh; bl.contrib = contrib; bl.gens = gens; bl.sortPaths = sortPaths; bl.screen = screen;
       if (!(hk_launch_bounce_lean(W, F, G, bl) || hk_launch_bounce_classic(W, F, G, bl) || hk_launch_bounce_nmap(W, F, G, bl) || hk_launch_bounce_all(W, F, G, bl) || hk_launch_bounce_all45(W, F, G, bl) || hk_launch_bounce_proctex(W, F, G, bl)))
         return fail(c, HYDRA_HIP_ESTATE, "trace_pass: no k_bounce instantiation for register budget " + std::to_string(W) + ", features " + std::to_string(F) + ", staging " + std::to_string(G));
       std::swap(bb.A, bb.B);
@@ -1245,6 +1269,7 @@ int hydra_hip_upload_globals(hydra_hip_handle c, const int32_t* blob, size_t wor
   {
     const int64_t to = blob[HG_TEX_TABLE_OFFS], ts = blob[HG_TEX_TABLE_SIZE];
     if (to < 0 || ts < 0 || size_t(to + ts) > words) return fail(c, HYDRA_HIP_EINVAL, "upload_globals: texture table runs past the blob");
+    c->hostTexTable.assign(blob + to, blob + to + ts);
   }
   // the sky light (if any) must be well-formed: constant colour, lat-long texture or the Perez model
   const int skyId = blob[HG_SKY_LIGHT_ID], lightsNum = blob[HG_LIGHTS_NUM];
@@ -1777,7 +1802,7 @@ int hydra_hip_trace_pass(hydra_hip_handle c, int spp) {
     int e1 = mark();
     if (timing) c->spans.push_back({e0, e1, 0, -1});
     { int rc = run_bounces(c, s, c->nseg, c->segCap, maxDepth, bb, live, shadowCnt, static_cast<float4*>(c->contrib.p), static_cast<uint2*>(c->gens.p),
-                           static_cast<uint32_t*>(c->fetchCnt.p), timing); if (rc) return rc; }
+                           static_cast<uint32_t*>(c->fetchCnt.p), timing, ScreenOfPath{static_cast<const int*>(c->ownedPixels.p), c->N, c->w}); if (rc) return rc; }
     int g0 = mark();
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->N, 256, 8)), dim3(256), 0, c->stream, c->N, static_cast<const int*>(c->ownedPixels.p), static_cast<const float4*>(c->contrib.p), c->accum, ns);
     hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, live, shadowCnt, maxDepth, c->nseg, static_cast<unsigned long long*>(c->totals.p));
@@ -1989,6 +2014,21 @@ struct TmpBufs {
   HCHECK(hipGetLastError());                                                                            \
   HCHECK(hipStreamSynchronize(c->stream));
 
+// the miss shader with a back-plate: environmentColorExtended (hk_shading.h) for n rays that left the scene; in8 = ray origin xyz, previous BSDF pdf, previous bounce
+// specular (0/1), ray flags (int bits), pixel x, y (int bits)
+int hydra_hip_stage_environment(hydra_hip_handle c, int n, const float* ray_dir4, const float* in8, float* out4) {
+  STAGE_PROLOG(true);
+  if (!ray_dir4 || !in8 || !out4) return fail(c, HYDRA_HIP_EINVAL, "stage_environment: null argument");
+  float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
+  float* din = (float*)tb.up(c, in8, size_t(n) * 32, rc);
+  float4* dout = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_environment, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_scene(c), n, ddir, din, dout);
+  STAGE_EPILOG();
+  HCHECK(hipMemcpy(out4, dout, size_t(n) * 16, hipMemcpyDeviceToHost));
+  return HYDRA_HIP_OK;
+}
+
 // ---- procedural textures (hydra_proctex.hip, hk_proctex_rt.h)
 int hydra_hip_proctex_compile(hydra_hip_handle c, const char* source, size_t length) {
   if (!c) return HYDRA_HIP_EINVAL;
@@ -2183,7 +2223,7 @@ int hydra_hip_stage_path_trace(hydra_hip_handle c, int n, const float* ray_pos4,
   HCHECK(hipMemsetAsync(contrib, 0, size_t(n) * 16, c->stream));
   SceneDev s = make_scene(c);
   hipLaunchKernelGGL(k_stage_seed_paths, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dpos, ddir, drng, S);
-  rc = run_bounces(c, s, 1, n, maxDepth, bb, live, shadowCnt, contrib, gensOut, fetch, false);
+  rc = run_bounces(c, s, 1, n, maxDepth, bb, live, shadowCnt, contrib, gensOut, fetch, false, ScreenOfPath{nullptr, 0, c->w});   // path i plays pixel i
   if (rc) return rc;
   STAGE_EPILOG();
   HCHECK(hipMemcpy(color4, contrib, size_t(n) * 16, hipMemcpyDeviceToHost));

@@ -421,7 +421,16 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     // back-plate texture of <back> belongs to the OpenCL layer's environmentColorExtended and is not read here
     MatPtr pMatte = new_node();
     put_i(pMatte->plain, HM_TYPE, HMT_SHADOW_MATTE);
-    if (a_node->child("back") != nullptr) Unsupported("shadow_catcher <back> plate (material " + std::to_string(a_matId) + "): a feature of the OpenCL layer's environment function");
+    if (const XmlNode* back = a_node->child("back")) {   // PlainMaterialConverter.cpp:1642-1668.  Always camera-projected: the reference compares the mode string by pointer (:1655)
+      m_shadowMatteBackTexId = xchild(back, "texture") ? xchild(back, "texture")->attr_int("id") : 0;
+      m_shadowMatteBackColor = float3(1, 1, 1);
+      if (back->has_attr("multcolor")) { float v[3] = {1, 1, 1}; parse_floats(back->attr("multcolor"), v, 3); m_shadowMatteBackColor = float3(v[0], v[1], v[2]); }
+      if (m_shadowMatteBackTexId == 0) m_shadowMatteBackTexId = int32_t(HYDRA_INVALID_TEXTURE);
+      m_shadowMatteBackMode = 0;
+      if (xhas(xchild(back, "texture"), "input_gamma")) m_shadowMatteBackGamma = xchild(back, "texture")->attr_float("input_gamma");
+      if (back->attr_int("reflection") == 1 || back->attr_int("fix_black_triangles") == 1)
+        Unsupported("shadow_catcher <back reflection / fix_black_triangles> (material " + std::to_string(a_matId) + "): camera-mapped reflections of the OpenCL layer's catcher");
+    } else { m_shadowMatteBackTexId = int32_t(HYDRA_INVALID_TEXTURE); m_shadowMatteBackColor = float3(1, 1, 1); }
     PlainMaterialVec mdata = flatten(pMatte);
     m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
     return true;
@@ -1137,6 +1146,14 @@ bool RenderDriverLite::UpdateSkyLight(int32_t a_lightId, const XmlNode* a_node) 
   lp.isDisk = false;
   lp.isSky = true;
   m_lights[a_lightId] = lp;
+  SkyBack sb;   // RenderDriverRTE::UpdateLight :946-967
+  if (const XmlNode* back = a_node->child("back")) {
+    sb.texId = xchild(back, "texture") ? xchild(back, "texture")->attr_int("id") : 0;
+    if (xhas(xchild(back, "texture"), "input_gamma")) sb.gamma = xchild(back, "texture")->attr_float("input_gamma");
+    if (back->has_attr("multcolor")) { float v[3] = {1, 1, 1}; parse_floats(back->attr("multcolor"), v, 3); sb.color = float3(v[0], v[1], v[2]); }
+    sb.mode = (std::string(back->attr("mode")) == "spherical") ? 1 : 0;
+  }
+  m_skyBack[a_lightId] = sb;
   return true;
 }
 
@@ -1479,6 +1496,10 @@ void RenderDriverLite::InstanceLights(int32_t a_lightId, const float* a_matrix, 
     RenderDriverLite* self; int32_t id;
     ~IdsOnExit() { self->m_lightIdByInst.resize(self->m_lightsInstanced.size() / HL_FLOATS, id); }
   } idsOnExit{this, a_lightId};
+  if (it->second.isSky) {   // :2072-2078: an instanced sky light decides about the back-plate, with or without a <back> node of its own
+    const SkyBack sb = m_skyBack.count(a_lightId) ? m_skyBack[a_lightId] : SkyBack();
+    m_shadowMatteBackTexId = sb.texId; m_shadowMatteBackGamma = sb.gamma; m_shadowMatteBackMode = sb.mode; m_shadowMatteBackColor = sb.color;
+  }
   for (int i = 0; i < a_instNum; i++) {
     float4x4 M;
     memcpy(M.c, a_matrix + 16 * i, 64);
@@ -1699,8 +1720,12 @@ void RenderDriverLite::EndScene() {
   vars.m_varsF[HV_F_BSPHERE_CENTER_X + 1] = center.y;
   vars.m_varsF[HV_F_BSPHERE_CENTER_X + 2] = center.z;
   vars.m_varsF[HV_F_BSPHERE_RADIUS] = length(half);
-  vars.m_varsI[35 /*HRT_SHADOW_MATTE_BACK*/] = int32_t(HYDRA_INVALID_TEXTURE);
-  vars.m_varsF[36 /*HRT_BACK_TEXINPUT_GAMMA*/] = 2.2f;
+  vars.m_varsI[HV_I_SHADOW_MATTE_BACK] = m_shadowMatteBackTexId;            // RenderDriverRTE.cpp:1487-1492
+  vars.m_varsF[HV_F_BACK_TEXINPUT_GAMMA] = m_shadowMatteBackGamma;
+  vars.m_varsI[HV_I_SHADOW_MATTE_BACK_MODE] = m_shadowMatteBackMode;
+  vars.m_varsF[HV_F_SHADOW_MATTE_BACK_COLOR_X] = m_shadowMatteBackColor.x;
+  vars.m_varsF[HV_F_SHADOW_MATTE_BACK_COLOR_X + 1] = m_shadowMatteBackColor.y;
+  vars.m_varsF[HV_F_SHADOW_MATTE_BACK_COLOR_X + 2] = m_shadowMatteBackColor.z;
   m_pHWLayer->SetAllFlagsAndVars(vars);
 
   size_t nl = m_lightsInstanced.size() / HL_FLOATS;

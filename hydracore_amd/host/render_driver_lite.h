@@ -95,6 +95,11 @@ private:
   std::map<int, LightProto> m_lights;
   std::map<std::string, int32_t> m_auxHeightMaps;   // m_texturesProcessedNM: texture id + bump parameters -> aux id
   bool m_sceneHaveSkyPortals = false;
+  // the back-plate (RenderDriverRTE.h:128-131): set by a shadow_catcher's <back> (PlainMaterialConverter.cpp:1642-1674), then overwritten by every instanced sky light with
+  // ITS <back> -- or with "none" when it has no such node (RenderDriverRTE.cpp:2072-2078); EndScene hands it to the layer's variables (:1487-1492)
+  int32_t m_shadowMatteBackTexId = int32_t(HYDRA_INVALID_TEXTURE); int m_shadowMatteBackMode = 0; float m_shadowMatteBackGamma = 2.2f; float3 m_shadowMatteBackColor{1, 1, 1};
+  struct SkyBack { int32_t texId = int32_t(HYDRA_INVALID_TEXTURE); int mode = 0; float gamma = 2.2f; float3 color{1, 1, 1}; };
+  std::map<int, SkyBack> m_skyBack;   // ILight::tmpSkyLightBack*, AbstractMaterial.h:152-155
   // procedural textures (RenderDriverRTE_ProcTex.cpp): what <texture type="proc"> declares -- the generated call, the functions' text, the return width
   struct ProcTex { std::string call, code; int retT = 4; };
   std::map<int32_t, ProcTex> m_procTextures;

@@ -219,6 +219,13 @@ int hydra_hip_stage_shade_point(hydra_hip_handle h, int n, const float* surf24, 
                                 const float* rnd_light4, const float* rands10, float* out28);
 /* whole paths for n given primary rays with given per-path RandomGen state (2 uint32 each, updated in place), run
  * through the production wavefront kernels: IntegratorMISPTLoop2::PathTrace (PT_Loop.cpp:264-321) -> rgb, w = 0 */
+/* test entry: the miss shader -- what a ray that leaves the scene brings back -- for n rays handed in.  With a back-plate named by the header (HRT_SHADOW_MATTE_BACK: a sky
+ * light's or a shadow catcher's <back> texture) this is the OpenCL layer's environmentColorExtended (hydra_drv/cbidir.h:593-629, called by HitEnvOrLightKernel,
+ * shaders/material.cl:354): suns of the header's table first, else environmentColor, replaced by the back texture (camera-projected by pixel, or spherical) for camera rays
+ * and rays that only crossed transparent surfaces; without one, environmentColor (cbidir.h:492-533) as the CPU integrator calls it (CPUExp_Integrators_PT_Loop.cpp:28).
+ * in8 per ray: origin xyz, previous BSDF pdf, previous bounce specular (0/1), ray flags, pixel x, pixel y (the last three as int bits).  out4: colour | 0. */
+int hydra_hip_stage_environment(hydra_hip_handle h, int n, const float* ray_dir4, const float* in8, float* out4);
+
 /* One bounce of n paths with every input handed in: the phases of the bounce kernel one after the other -- environment
  * (kernel_HitEnvironment, hydra_drv/CPUExp_Integrators_PT_Loop.cpp:23-33), emission + MIS (kernel_EvalEmission :86-139), light pick and sample with the
  * shadow ray (kernel_LightSelect / kernel_LightSample :141-168), next-event shading (kernel_Shade :181-216), BSDF sampling and the path-state

@@ -65,7 +65,9 @@ enum {
   HV_I_ENABLE_DOF          = 0,
   HV_I_TRACE_DEPTH         = 9,
   HV_I_DIFFUSE_TRACE_DEPTH = 13,
-  HV_I_MMLT_FIRST_BOUNCE   = 34
+  HV_I_MMLT_FIRST_BOUNCE   = 34,
+  HV_I_SHADOW_MATTE_BACK      = 35,   /* texture id of the back-plate the camera sees where a ray leaves the scene (HYDRA_INVALID_TEXTURE: none), cglobals.h:475 */
+  HV_I_SHADOW_MATTE_BACK_MODE = 41    /* 0 = camera projected, 1 = spherical (BACK_MODE, cglobals.h:436) */
 };
 enum {
   HV_F_DOF_LENS_RADIUS      = 0,
@@ -80,7 +82,9 @@ enum {
   HV_F_FOV_X                = 23,
   HV_F_FOV_Y                = 24,
   HV_F_WIDTH_F              = 25,
-  HV_F_HEIGHT_F             = 26
+  HV_F_HEIGHT_F             = 26,
+  HV_F_BACK_TEXINPUT_GAMMA  = 36,   /* cglobals.h:537 */
+  HV_F_SHADOW_MATTE_BACK_COLOR_X = 42   /* .. Z = 44: the back-plate's colour multiplier, read from varsF by index (cbidir.h:549-551) */
 };
 /* g_flags bits (cglobals.h:405-434) */
 enum {
@@ -88,6 +92,7 @@ enum {
   HF_USE_MIS            = 32,
   HF_ENABLE_MMLT        = 16384,        /* HRT_ENABLE_MMLT, cglobals.h:419 */
   HF_STUPID_PT_MODE     = 65536 * 8,
+  HF_3WAY_MIS_WEIGHTS   = 1024,           /* HRT_3WAY_MIS_WEIGHTS, cglobals.h:416 */
   HF_ENABLE_PT_CAUSTICS = 65536 * 2048
 };
 

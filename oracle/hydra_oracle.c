@@ -2673,6 +2673,52 @@ static float directLightEvalPDF(const float* L, f3 ray_dir) {
   return 1.0f;
 }
 /* ref: clight.h:1661-1706 lightGetIntensity */
+/* ---- the back-plate.  ref: cbidir.h:543-573 backColorOfSecondEnv, :593-629 environmentColorExtended -- the miss shader of the OpenCL layer (HitEnvOrLightKernel,
+ * shaders/material.cl:354).  The CPU integrator calls plain environmentColor (PT_Loop.cpp:28) and knows no back-plate; PathTrace takes the extended form when, and only
+ * when, the header names a back texture (HRT_SHADOW_MATTE_BACK), like the HIP layer does.  The pixel of the path comes from the caller (thread-local). */
+enum { HRT_SHADOW_MATTE_BACK = 35, HRT_SHADOW_MATTE_BACK_MODE = 41, HRT_SHADOW_MATTE_BACK_COLOR_X = 42, HRT_BACK_TEXINPUT_GAMMA = 36, HRT_3WAY_MIS_WEIGHTS = 1024 };   /* cglobals.h:416, 475-484, 537 */
+static _Thread_local int g_screenX = 0, g_screenY = 0;
+static inline int haveBackPlate(const OrcScene* s) { return (uint32_t)g_varsI(s)[HRT_SHADOW_MATTE_BACK] != INVALID_TEXTURE; }
+static f3 backColorOfSecondEnv(const OrcScene* s, f3 ray_dir, float screenX, float screenY) {
+  const float* vf = g_varsF(s);
+  const int offset = s->globals[s->globals[G_TEX_TABLE] + g_varsI(s)[HRT_SHADOW_MATTE_BACK]];
+  const f3 mult = v3(vf[HRT_SHADOW_MATTE_BACK_COLOR_X], vf[HRT_SHADOW_MATTE_BACK_COLOR_X + 1], vf[HRT_SHADOW_MATTE_BACK_COLOR_X + 2]);
+  f2 tc = {screenX / vf[HRT_WIDTH_F], screenY / vf[HRT_HEIGHT_F]};
+  if (g_varsI(s)[HRT_SHADOW_MATTE_BACK_MODE] == 1) { float sintheta = 0.0f; tc = sphereMapTo2DTexCoord(ray_dir, &sintheta); }
+  const f4 c = read_imagef_sw4(s->texStorage + (size_t)offset * 4, tc, TEX_CLAMP_U | TEX_CLAMP_V, 1);
+  f3 env = mul3(mult, v3(c.x, c.y, c.z));
+  if (vf[HRT_BACK_TEXINPUT_GAMMA] != 1.0f) env = v3(sRGBToLinear(env.x), sRGBToLinear(env.y), sRGBToLinear(env.z));
+  return env;
+}
+static f3 environmentColor(const OrcScene* s, f3 rayDir, float prevPdf, int prevSpecular, uint32_t flags);
+static f3 environmentColorExtended(const OrcScene* s, f3 ray_pos, f3 ray_dir, float prevPdf, int prevSpecular, uint32_t flags, int screenX, int screenY) {
+  const int hitId = hitDirectLight(s, ray_dir);
+  if (hitId >= 0) {
+    const float* sun = (const float*)(s->globals + G_SUNS) + (size_t)hitId * LIGHT_FLOATS;
+    f3 envColor = scale3(lightColor(sun), directLightAttenuation(sun, ray_pos));
+    const float pdfW = directLightEvalPDF(sun, ray_dir);
+    const uint32_t gflags = (uint32_t)s->globals[G_FLAGS];
+    if (((flags >> 8) & 0xFFu) > 0 && !(gflags & HRT_STUPID_PT_MODE) && !prevSpecular) envColor = v3(0, 0, 0);
+    else if ((prevSpecular && (gflags & HRT_ENABLE_PT_CAUSTICS)) || (gflags & HRT_STUPID_PT_MODE)) envColor = scale3(envColor, 1.0f / pdfW);
+    if (gflags & HRT_3WAY_MIS_WEIGHTS) envColor = v3(0, 0, 0);
+    return envColor;
+  }
+  f3 envColor = environmentColor(s, ray_dir, prevPdf, prevSpecular, flags);
+  const uint32_t rayBounce = (flags >> 8) & 0xFFu, other = flags >> 16;
+  const int transparent = (other & 8u) != 0 && (other & 2u) == 0 && (other & 4u) == 0;   /* RAY_EVENT_T without _D and _G */
+  if (rayBounce == 0 || transparent) envColor = backColorOfSecondEnv(s, ray_dir, (float)screenX + 0.5f, (float)screenY + 0.5f);
+  return envColor;
+}
+/* the miss shader on rays handed in (layout: include/hydra_hip.h, hydra_hip_stage_environment) */
+void orc_stage_environment(const OrcScene* s, int n, const float* dir4, const float* in8, float* out4) {
+  for (int i = 0; i < n; i++) {
+    const float* in = in8 + 8 * (size_t)i;
+    const f3 d = v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]);
+    const f3 c = haveBackPlate(s) ? environmentColorExtended(s, v3(in[0], in[1], in[2]), d, in[3], in[4] != 0.0f, (uint32_t)as_int(in[5]), as_int(in[6]), as_int(in[7]))
+                                  : environmentColor(s, d, in[3], in[4] != 0.0f, (uint32_t)as_int(in[5]));
+    out4[4 * i] = c.x; out4[4 * i + 1] = c.y; out4[4 * i + 2] = c.z; out4[4 * i + 3] = 0.0f;
+  }
+}
 static f3 lightGetIntensity(const OrcScene* s, const float* L, f3 ray_pos, f3 ray_dir, f2 texCoord, uint32_t flags, int wasSpecular) {
   const int eyeRay = ((flags & 0xFFu) == 0);
   const int type = as_int(L[PL_TYPE]);
@@ -2797,7 +2843,11 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
     const OrcHit hit = rayTrace(s, ray_pos, ray_dir, NULL);
     st->rays++;
     /* kernel_HitEnvironment :23-33 */
-    if (!HitSome(hit)) { currColor = environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags); break; }
+    if (!HitSome(hit)) {
+      currColor = haveBackPlate(s) ? environmentColorExtended(s, ray_pos, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags, g_screenX, g_screenY)
+                                   : environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags);
+      break;
+    }
     /* kernel_EvalSurface */
     const SurfaceHit surf = evalSurface(s, ray_pos, ray_dir, hit);
     const float* mat = materialAt(s, surf.matId);
@@ -2954,6 +3004,7 @@ void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* di
 #pragma omp parallel for schedule(dynamic, 64)
   for (int i = 0; i < n; i++) {
     PathStat st = {0};
+    { const int wdt = (int)g_varsF(s)[HRT_WIDTH_F]; g_screenX = wdt > 0 ? i % wdt : 0; g_screenY = wdt > 0 ? i / wdt : 0; }   /* path i plays pixel i (back-plate scenes) */
     const f3 c = PathTrace(s, v3(pos4[4 * i], pos4[4 * i + 1], pos4[4 * i + 2]), v3(dir4[4 * i], dir4[4 * i + 1], dir4[4 * i + 2]), rng2 + 2 * (size_t)i, &st, NULL);
     color4[4 * i] = c.x; color4[4 * i + 1] = c.y; color4[4 * i + 2] = c.z; color4[4 * i + 3] = (float)st.rays;
   }
@@ -3735,6 +3786,7 @@ uint64_t orc_render_pass(const OrcScene* s, int w, int h, uint32_t* gens, float*
       f3 ray_pos, ray_dir;
       MakeRandEyeRay(x, y, w, h, offs, s, &ray_pos, &ray_dir);
       PathStat st = {0};
+      g_screenX = x; g_screenY = y;
       const f3 color = PathTrace(s, ray_pos, ray_dir, gen, &st, NULL);
       totalRays += st.rays;
       float* px = image4 + 4 * ((size_t)y * w + x);

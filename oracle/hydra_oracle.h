@@ -73,6 +73,9 @@ void orc_path_trace(const OrcScene* s, int n, const float* pos4, const float* di
 /* one bounce of n paths with every input handed in: the kernel_* stages of PT_Loop.cpp:9-262 in order (layouts: include/hydra_hip.h, hydra_hip_stage_bounce) */
 /* procedural textures: the per-point lists (ids[max_num][n], colours as halfs [max_num][n][4]; HYDRA's INVALID_TEXTURE ends a list) the following orc_stage_bounce
  * calls OF THE SAME n consult -- the oracle restates the consumer of the lists (readProcTex in sample2DExt), not the scene's functions; n = 0 drops them */
+/* the miss shader for n rays handed in (include/hydra_hip.h, hydra_hip_stage_environment): with a back-plate in the header the OpenCL layer's environmentColorExtended
+ * (cbidir.h:593-629), else environmentColor */
+void orc_stage_environment(const OrcScene* s, int n, const float* dir4, const float* in8, float* out4);
 /* whole frames: the scene's functions built for the host by the test (tests/proctex_host.py), called by PathTrace for every hit on a material with procedural textures:
  * fn(user, surf19 = wp lp n tg bn tc0 ao ao2, material head, ray direction, &count, ids[16], colours[48]); NULL = none (the lists stay empty) */
 void orc_set_proctex_eval(void* fn, void* user);

@@ -413,6 +413,22 @@ __kernel void ref_camera_connect(__global const float4* pos4, __global const flo
   o[0] = f; o[1] = camDir.x; o[2] = camDir.y; o[3] = camDir.z; o[4] = zDepth; o[5] = scr.x; o[6] = scr.y; o[7] = 0.0f;
 }
 
+/* The miss shader of the reference's wavefront layer as HitEnvOrLightKernel calls it (shaders/material.cl:354): environmentColorExtended, cbidir.h:593-629 -- suns of the
+   header's table, the environment, the back-plate for camera rays and rays that only crossed transparent surfaces.  in8 per ray: origin xyz, previous BSDF pdf, previous
+   bounce specular (0/1), ray flags, pixel x, pixel y (the last three as int bits); prevMaterialOffset = -1 as the path tracer leaves it (CPUExp_Integrators_PT_Loop.cpp:247-249). */
+__kernel void ref_environment_extended(__global const float4* dir4, __global const float* in8, __global const float4* in_mtlStorage, __global const int4* in_texStorage,
+                                       __global const float4* in_pdfStorage, __global const EngineGlobals* a_globals, __global float4* out4, int n)
+{
+  const int i = get_global_id(0);
+  if (i >= n) return;
+  __global const float* in = in8 + i * 8;
+  MisData misPrev;
+  misPrev.matSamplePdf = in[3]; misPrev.cosThetaPrev = 1.0f; misPrev.prevMaterialOffset = -1; misPrev.isSpecular = (in[4] != 0.0f) ? 1 : 0;
+  const float3 c = environmentColorExtended(make_float3(in[0], in[1], in[2]), to_float3(dir4[i]), misPrev, (uint)as_int(in[5]), as_int(in[6]), as_int(in[7]),
+                                            a_globals, in_mtlStorage, in_pdfStorage, in_texStorage);
+  out4[i] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
 __kernel void ref_mutate_kelemen(__global const float* values, __global const float2* rands2, float p2, float p1, __global float* out, int n)
 {
   const int i = get_global_id(0);

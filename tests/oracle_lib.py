@@ -50,6 +50,8 @@ def load(fast=False):
     lib.orc_shade_point.argtypes = [sp, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_stage_bounce.argtypes = [sp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.orc_stage_set_proctex.argtypes = [i32, i32, vp, vp]
+    lib.orc_stage_environment.argtypes = [sp, i32, vp, vp, vp]
+    lib.orc_stage_environment.restype = None
     lib.orc_stage_set_proctex.restype = None
     lib.orc_render_pass.argtypes = [sp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.orc_render_pass.restype = C.c_uint64
@@ -246,6 +248,14 @@ class Oracle:
         d1, d2, raw = np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 4), np.float32), np.zeros((ny, nx, 14), np.float32)
         self.lib.orc_gbuffer(C.byref(self.s), self.w, self.h, x0, y0, nx, ny, _p(d1), _p(d2), _p(raw))
         return d1, d2, raw
+
+    def stage_environment(self, dir4, in8):
+        """orc_stage_environment -> float32 [n, 4]"""
+        n = len(in8)
+        dir4, in8 = np.ascontiguousarray(dir4, np.float32), np.ascontiguousarray(in8, np.float32)
+        out = np.zeros((n, 4), np.float32)
+        self.lib.orc_stage_environment(C.byref(self.s), n, _p(dir4), _p(in8), _p(out))
+        return out
 
     def stage_set_proctex(self, ids=None, colours=None):
         """orc_stage_set_proctex: the per-point procedural texture lists (ids [max_num, n], colours [max_num, n, 4], stored as halfs) for the following stage_bounce calls of the same n"""

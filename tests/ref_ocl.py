@@ -174,6 +174,14 @@ class RefScene:
                                                 ("p", self.m.up(np.ascontiguousarray(disk2, np.float32))), ("p", self.globals), ("p", out), ("i", n)])
         return self.m.down(out, np.float32, (n, 8))
 
+    def environment_extended(self, dir4, in8):
+        """environmentColorExtended (cbidir.h:593-629) for n rays that left the scene: in8 = origin xyz, previous pdf, previous specular, flags, pixel x, y (int bits) -> [n, 4]"""
+        n = len(in8)
+        out = self.m.alloc(n * 16)
+        self.m.launch("ref_environment_extended", n, [("p", self.m.up(np.ascontiguousarray(dir4, np.float32))), ("p", self.m.up(np.ascontiguousarray(in8, np.float32))),
+                                                      ("p", self.mat), ("p", self.tex), ("p", self.pdf), ("p", self.globals), ("p", out), ("i", n)])
+        return self.m.down(out, np.float32, (n, 4))
+
     def mutate_kelemen(self, values, rands2, p2, p1):
         n = len(values)
         out = self.m.alloc(n * 4)

@@ -639,3 +639,44 @@ def test_oracle_runs_the_scene_functions_built_for_the_host(built):
     finally:
         proctex_host.detach(orc)
     assert np.isfinite(with_tex).all() and with_tex[..., :3].mean() > 0.01      # (without the lists the scene cannot be rendered at all: its procedural normal map has no stored texture)
+
+
+# ---- the back-plate: environmentColorExtended (cbidir.h:593-629), the OpenCL layer's miss shader, against the reference's own function on seeded rays
+BACKPLATE_SCENES = ("atrium_back_small", "atrium_backsph_small", "atrium_portal_small")
+
+
+def check_backplate(name, b, run):
+    """run(dir4, in8) -> [n, 4].  atrium_back_small / atrium_backsph_small: a sky light whose <back> texture the camera sees, projected by pixel / as a sphere map;
+    atrium_portal_small: no back-plate in the header -- the entry then is plain environmentColor, which the reference's extended form also reduces to wherever no sun of
+    the header's table is hit (its sun branch is compared on the two back-plate scenes' absent suns trivially, and on this scene's two suns where the header has no
+    back-plate: left out there, the layers differ by design)"""
+    fx = load("ref_backplate_%s.npz" % name)
+    out = run(fx["dir4"], fx["in8"])
+    ref = fx["out"]
+    g = b["globals"]
+    have_back = np.uint32(g[64 + 35]) != np.uint32(0xFFFFFFFE)
+    keep = np.ones(len(ref), bool)
+    if not have_back and g[242] > 0:        # portal scene: rays inside a sun's cone take the sun branch in the reference's extended function only
+        for k in range(int(g[242])):
+            sun = g[243 + 128 * k: 243 + 128 * (k + 1)].view(np.float32)
+            keep &= ~(-(fx["dir4"][:, :3] * sun[5:8]).sum(1) > sun[18] - 1e-4)      # PLIGHT_NORM, DIRECT_LIGHT_ALPHA_COS (clight.h)
+        assert 0.3 < keep.mean() < 1.0
+    np.testing.assert_allclose(out[keep, :3], ref[keep, :3], rtol=1e-4, atol=2e-6)      # sRGB decode of the back texture: powf on both sides
+    if have_back:
+        flags = fx["in8"][:, 5].view(np.uint32)
+        cam = ((flags >> 8) & 0xFF) == 0
+        assert np.abs(ref[cam, :3] - ref[~cam, :3].mean(0)).mean() > 0.01          # the back-plate does change what camera rays see
+
+
+@pytest.mark.parametrize("name", BACKPLATE_SCENES)
+def test_oracle_matches_reference_environment_extended(name, built):
+    _, b = host_scene(name, 96, 54, 5)
+    orc = make_oracle(b)
+    check_backplate(name, b, orc.stage_environment)
+    # the front end's variables (RenderDriverRTE.cpp:946-967, 1487-1492, 2072-2078): texture 1 x (0.9, 1.0, 0.8), gamma 2.2, camera-projected / spherical; none in the portal hall
+    g = b["globals"]
+    vi, vf = g[64:128], g[128:192].view(np.float32)
+    if name == "atrium_portal_small":
+        assert np.uint32(vi[35]) == np.uint32(0xFFFFFFFE)
+    else:
+        assert vi[35] == 1 and vi[41] == (1 if name == "atrium_backsph_small" else 0) and np.allclose(vf[42:45], [0.9, 1.0, 0.8]) and np.isclose(vf[36], 2.2)

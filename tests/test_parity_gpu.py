@@ -1535,3 +1535,45 @@ def test_procedural_texture_scene_matches_the_oracle_image(gpu_atrium_proctex):
         assert abs(img[..., :3].mean() - ref[..., :3].mean()) < 2e-3 * ref[..., :3].mean()
     finally:
         proctex_host.detach(orc)
+
+
+# ---- the back-plate (environmentColorExtended, hk_shading.h): a sky light's <back> texture is what the camera sees where a ray leaves the scene
+@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_backsph_small", "atrium_portal_small"])
+def test_hip_matches_reference_environment_extended(name, built):
+    """the miss shader against the reference's own environmentColorExtended (ref_backplate_*.npz), one hop"""
+    from hydracore_amd import HipCore
+    from test_golden_ref import check_backplate
+    _, b = host_scene(name, 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    check_backplate(name, b, core.stage_environment)
+    core.close()
+
+
+@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_backsph_small"])
+def test_back_plate_scene_matches_the_oracle_image(name, built):
+    """whole frames through the production kernels (k_bounce<ALL> reads the pixel of every path that leaves the scene) against the oracle; the same hall without the <back>
+    node differs exactly where the camera looks out of the open roof"""
+    from hydracore_amd import HipCore
+    _, b = host_scene(name, 96, 54, 5)
+    orc = make_oracle(b)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    img, st = _render(core, 96, 54, spp=3, seed=777)
+    ref, rays, _ = orc.render(3, seed=777, sum_mode=False, streams=core.samples_in_flight())
+    assert abs(int(st.extensionRays + st.shadowRays) - rays) <= 0.002 * rays
+    bad = (np.abs(img[..., :3] - ref[..., :3]) > 2e-4 * np.maximum(np.abs(ref[..., :3]), 1.0)).any(axis=2)
+    assert bad.mean() < 0.01, bad.mean()
+    for opt, val in (("sort_paths", 0), ("scene_tables_in_lds", 0), ("path_order", 0)):
+        old = core.get_option(opt)
+        core.set_option(opt, val)
+        img2, _ = _render(core, 96, 54, spp=3, seed=777)
+        core.set_option(opt, old)
+        assert (img2.view(np.uint32) == img.view(np.uint32)).all(), opt
+    _, bs = host_scene("atrium_skytex_small", 96, 54, 5)
+    plain = HipCore(96, 54, device=0)
+    plain.upload_scene(bs)
+    img_s, _ = _render(plain, 96, 54, spp=3, seed=777)
+    differs = (np.abs(img_s[..., :3] - img[..., :3]) > 1e-3).any(axis=2)
+    assert 0.005 < differs.mean() < 0.6, differs.mean()
+    core.close(); plain.close()

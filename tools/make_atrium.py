@@ -300,9 +300,12 @@ def main():
                     "(two textures in one material), pots = falloff diffuse, a wall = the procedural normal map.  'flat': the checker and the falloff with both colours "
                     "equal (exactly representable in half precision) on materials 0, 1, 3, 4 over white; 'plain': no procedural textures, those colours as the materials' own -- "
                     "the two must render the same image bit for bit")
+    ap.add_argument("--back", nargs="?", const="camera", default=None, choices=("camera", "spherical"), help="like --sky-tex, and the sky light carries a <back> node: the 256^2 "
+                    "checker (texture 1) x (0.9, 1.0, 0.8) is what the camera sees where a ray leaves the hall -- projected by pixel, or as a sphere map -- while the light of the "
+                    "sky stays the environment texture (the OpenCL layer's environmentColorExtended, cbidir.h:593-629)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
-    args.sky_tex = args.sky_tex or args.sky_hdr or args.portal
+    args.sky_tex = args.sky_tex or args.sky_hdr or args.portal or (args.back is not None)
     args.sky = args.sky or args.sky_tex or args.perez
     refl = "ggx" if args.ggx else "torranse_sparrow" if args.translucent else "phong"   # "torranse_sparrow" (sic) = Blinn in a Torrance-Sparrow model
     s = np.sqrt(args.scale)
@@ -656,6 +659,11 @@ float4 prtex%(n)d_main(const SurfaceInfo* sHit, sampler2D texSide, sampler2D tex
                   '\n  <light id="3" name="sun" type="directional" shape="point" distribution="directional" visible="1"><size inner_radius="30" outer_radius="40" />'
                   '<shadow_softness val="2.0" /><intensity><color val="1 0.95 0.85" /><multiplier val="2.5" /></intensity></light>' % portal_mesh if args.portal else '')
                + '\n</lights_lib>')
+    if args.back:   # the sky light's <back>: what the camera sees instead of the environment (RenderDriverRTE.cpp:946-967)
+        lights = xml[-1]
+        at = lights.index('name="sky"')
+        end = lights.index("</light>", at)
+        xml[-1] = lights[:end] + '<back mode="%s" multcolor="0.9 1.0 0.8"><texture id="1" type="texref" input_gamma="2.2" /></back>' % args.back + lights[end:]
     xml.append('<cam_lib>\n  <camera id="0" name="cam" type="uvn"><fov>60</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>200.0</farClipPlane>'
                '<up>0 1 0</up><position>-17 2.2 0.6</position><look_at>10 2.6 -0.4</look_at></camera>\n</cam_lib>')
 
