@@ -455,7 +455,8 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
     m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
     return true;
   }
-  if (mtype != "hydra_material") { Unsupported("material type '" + mtype + "' (id " + std::to_string(a_matId) + ")"); }
+  const bool isBlendOfTwo = (mtype == "hydra_blend");   // two materials of the library under a mask (CreateBlendDefferedProxyFromXmlNode, PlainMaterialConverter.cpp:1457-1500)
+  if (mtype != "hydra_material" && !isBlendOfTwo) { Unsupported("material type '" + mtype + "' (id " + std::to_string(a_matId) + ")"); }
 
   const XmlNode* emission = a_node->child("emission");
   const XmlNode* diffuse = a_node->child("diffuse");
@@ -585,7 +586,25 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
   MatPtr pResult;
   const bool haveT = length(colorT) > 1e-5f, haveS = length(colorS) > 1e-5f, haveD = length(colorD) > 1e-5f;
   auto add_flags = [](const MatPtr& m, int f) { put_i(m->plain, HM_FLAGS, get_i(m->plain, HM_FLAGS) | f); };
-  if (haveT && haveS && haveD) {          // :1541-1553
+  if (isBlendOfTwo) {
+    // The reference defers these to EndMaterialUpdate and resolves node_top / node_bottom against the materials updated so far, in id order (:1787-1842); LoadSceneLibrary
+    // calls this function for the blends last and in id order.  Mask: a plain texture value, or Fresnel of the blend's own IOR; the colour factor is white; the
+    // extrusion is read from the MATERIAL node (ReadExtrusionType(a_node), :1481), the IOR from its <blend> child.
+    const XmlNode* blend = a_node->child("blend");
+    const bool fresnelBlend = std::string(xattr(blend, "type")) == "fresnel_blend";
+    Sampler sm;
+    int32_t maskTex = int32_t(HYDRA_INVALID_TEXTURE);
+    if (const XmlNode* tx = xchild(xchild(blend, "mask"), "texture")) { sm = sampler_from_texref(tx); maskTex = sm.texId; }
+    auto sub = [&](const char* attr) -> MatPtr {
+      const auto it = a_node->has_attr(attr) ? m_materialTrees.find(a_node->attr_int(attr)) : m_materialTrees.end();
+      if (it == m_materialTrees.end() || !it->second) {
+        Unsupported("hydra_blend " + std::to_string(a_matId) + ": '" + attr + "' names no material of the library that was converted before it");
+        return make_lambert(float3(1, 1, 1), int32_t(HYDRA_INVALID_TEXTURE), Sampler());
+      }
+      return std::static_pointer_cast<MatTree>(it->second);
+    };
+    pResult = make_blend(sub("node_top"), sub("node_bottom"), float3(1, 1, 1), maskTex, sm, fresnelBlend, false, read_extrusion(a_node), read_fresnel_ior(blend));
+  } else if (haveT && haveS && haveD) {          // :1541-1553
     MatPtr pST = make_blend(pMaterialS, pMaterialT, colorS, texReflId, samplRefl, haveFresnelRefl, true, reflExtrusion, fresnelIOR);
     pResult = make_blend(pST, pMaterialD, colorT, texTranspId, samplTransp, false, true, reflExtrusion, fresnelIOR);
     add_flags(pST, HMF_HAS_TRANSPARENCY | HMF_CAN_SAMPLE_REFL_ONLY);
@@ -667,6 +686,8 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
       push_down_normal_map(pResult.get(), auxId, HM_NORMAL_SAMPLER / 4, flags, sm);
     }
   }
+  m_materialTrees[a_matId] = pResult;   // m_materialUpdated: what a later hydra_blend composes
+  m_materialNodes[a_matId] = a_node;
   // PutAbstractMaterialToStorage :1848-1881
   PlainMaterialVec mdata = flatten(pResult);
   AppendProcTexTail(a_node, a_matId, mdata);
@@ -723,6 +744,11 @@ void RenderDriverLite::AppendProcTexTail(const XmlNode* a_materialNode, int32_t 
   std::vector<int32_t> ids;
   std::map<int32_t, std::vector<float>> args;
   std::function<void(const XmlNode*)> scan = [&](const XmlNode* n) {
+    if (n->name == "material" && std::string(n->attr("type")) == "hydra_blend")   // the blended materials' bindings count for the blend (:63-75, 99-110): top, then bottom
+      for (const char* a : {"node_top", "node_bottom"}) {
+        const auto sub = m_materialNodes.find(n->attr_int(a));
+        if (sub != m_materialNodes.end()) scan(sub->second);
+      }
     if (n->name == "texture" && n->has_attr("id") && m_procTextures.count(n->attr_int("id"))) {
       const int32_t id = n->attr_int("id");
       ids.push_back(id);
@@ -1869,7 +1895,15 @@ void RenderDriverLite::LoadSceneLibrary(const std::string& libPath, int a_width,
   // EndTexturesUpdate :485-574: the layer builds the scene's procedural textures (nothing to do without any: the layer keeps no program)
   m_procTexProgram = m_procTextures.empty() ? std::string() : ProcTexProgramText();
   m_pHWLayer->RecompileProcTexShaders(m_procTexProgram);
-  for (auto* m : matLib->children_named("material")) UpdateMaterial(m->attr_int("id"), m);
+  {   // BeginMaterialUpdate ... EndMaterialUpdate (:1749-1843): everything but the blends of two materials first, then those in id order
+    std::map<int, const XmlNode*> blends;
+    for (auto* m : matLib->children_named("material")) {
+      if (std::string(m->attr("type")) == "hydra_blend") blends[m->attr_int("id")] = m;
+      else UpdateMaterial(m->attr_int("id"), m);
+    }
+    for (const auto& bl : blends) UpdateMaterial(bl.first, bl.second);
+    m_materialNodes.clear();   // they point into this function's document
+  }
   std::set<int> loadedMeshes;
   for (auto* me : geoLib->children_named("mesh")) {
     std::vector<char> d;

@@ -102,6 +102,8 @@ private:
   std::map<int, SkyBack> m_skyBack;   // ILight::tmpSkyLightBack*, AbstractMaterial.h:152-155
   // procedural textures (RenderDriverRTE_ProcTex.cpp): what <texture type="proc"> declares -- the generated call, the functions' text, the return width
   struct ProcTex { std::string call, code; int retT = 4; };
+  std::map<int32_t, std::shared_ptr<void>> m_materialTrees;   // RenderDriverRTE::m_materialUpdated: the converted tree (MatTree, render_driver_lite.cpp) of every material, for hydra_blend
+  std::map<int32_t, const XmlNode*> m_materialNodes;          // RenderDriverRTE::m_materialNodes: valid while LoadSceneLibrary's document lives (the blends are converted inside it)
   std::map<int32_t, ProcTex> m_procTextures;
   std::string m_procTexProgram;
   std::set<int32_t> m_procTexMissing;                                     // declared, but the code file is not in the library

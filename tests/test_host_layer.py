@@ -444,3 +444,35 @@ def test_ies_lights_pack_like_the_reference_converter():
         m, inv = L[k, 117:126].reshape(3, 3), L[k, 108:117].reshape(3, 3)
         np.testing.assert_allclose(m @ inv, np.eye(3) * (m @ inv)[0, 0], atol=1e-5)
         np.testing.assert_allclose(m @ inv, np.eye(3), atol=1e-5)
+
+
+def test_hydra_blend_materials_compose_materials_of_the_library(built):
+    """hydra_blend (CreateBlendDefferedProxyFromXmlNode + EndMaterialUpdate, PlainMaterialConverter.cpp:1457-1500, 1787-1842): a blend-mask node over the converted trees of
+    node_top / node_bottom, resolved after all other materials and in id order -- children with higher ids than the blend, and a blend of a blend, both work; mask texture
+    and sampler matrix, Fresnel flag with the blend's own IOR, the extrusion read from the material node, white colour factor"""
+    from conftest import host_scene
+    sc, b = host_scene("atrium_blend_small", 96, 54, 5)
+    assert sc.unsupported() == 0, sc.log()
+    g, mats = b["globals"], b["materials"].reshape(-1)
+    mi = mats.view(np.int32)
+    table = g[g[219]:g[219] + g[224]]
+
+    def node(mid, k=0):
+        o = int(table[mid]) * 4 + 192 * k
+        return mats[o:o + 192], mi[o:o + 192]
+    f1, i1 = node(1)
+    f12, i12 = node(12)
+    assert i1[0] == 9 and (i1[16], i1[17]) == (1, 1 + 3)                     # [blend][material 12: blend + 2 leaves][material 13]
+    assert (node(1, 1)[1] == i12).all() and (node(1, 4)[1] == node(13)[1]).all()               # compared as words: invalid ids are NaN patterns
+    HM_COLOR, HM_TEXID, HM_TEXMATRIXID = 10, 13, 14                          # include/hydra_layouts.h
+    sampler = i1[HM_TEXMATRIXID] * 4                                         # the embedded sampler: texture 2, matrix scale 3
+    assert i1[HM_TEXID] == 2 and i1[sampler + 2] == 2 and f1[sampler + 4] == 3.0 and f1[sampler + 9] == 3.0
+    assert (i1[15] & 1) == 0 and tuple(f1[HM_COLOR:HM_COLOR + 3]) == (1.0, 1.0, 1.0)   # BLEND_MASK_FLAGS: a plain mask; white colour factor
+    f3, i3 = node(3)
+    assert i3[0] == 9 and (i3[15] & 1) == 1 and (i3[15] & 16) == 16 and np.isclose(f3[18], 1.8)   # Fresnel blend, luminance extrusion, its IOR (BLEND_MASK_FRESNEL_IOR)
+    assert (node(3, 1)[1] == node(14)[1]).all() and (node(3, 2)[1] == node(15)[1]).all()
+    f5, i5 = node(5)
+    assert i5[0] == 9 and (i5[16], i5[17]) == (1, 6)                          # blend over [material 1's five nodes][material 13]
+    for k in range(5):
+        assert (node(5, 1 + k)[1] == node(1, k)[1]).all()
+    assert (node(5, 6)[1] == node(13)[1]).all()

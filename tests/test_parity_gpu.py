@@ -84,6 +84,16 @@ def gpu_atrium_ies(built):
 
 
 @pytest.fixture(scope="module")
+def gpu_atrium_blend(built):
+    """the closed hall whose materials 1, 3 and 5 are hydra_blend materials: two materials of the library under a texture mask / Fresnel mask / a blend of a blend (PlainMaterialConverter.cpp:1457-1500, 1787-1842)"""
+    from hydracore_amd import HipCore
+    sc, b = host_scene("atrium_blend_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    return core, b, make_oracle(b)
+
+
+@pytest.fixture(scope="module")
 def gpu_atrium_portal(built):
     """the open hall whose sky (lat-long texture) is sampled through a sky portal in the roof; a soft sun fills the header's sun table (clight.h:590-629, 1636-1695)"""
     from hydracore_amd import HipCore
@@ -631,7 +641,7 @@ def test_whole_paths(fix, request):
     assert abs(col[:, :3].mean() - ref[:, :3].mean()) < 1e-3 * ref[:, :3].mean()
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu42", "gpu_atrium", "gpu_atrium_sky", "gpu_atrium_skytex", "gpu_atrium_skyhdr", "gpu_atrium_perez", "gpu_atrium_lights", "gpu_atrium_glass", "gpu_atrium_ggx", "gpu_atrium_cutouts", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies", "gpu_atrium_blend"])
 def test_wavefront_pass_matches_oracle_image(fix, request):
     core, b, orc = request.getfixturevalue(fix)
     w, h = b["width"], b["height"]
@@ -735,7 +745,7 @@ def test_queue_segmentation_does_not_change_the_image(fix, request):
         core.set_option("queue_segments", 65)
 
 
-@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies"])
+@pytest.mark.parametrize("fix", ["gpu224", "gpu_atrium_sky", "gpu_atrium_glass", "gpu_atrium_cutouts2", "gpu_atrium_nmap", "gpu_atrium_transl", "gpu_atrium_aniso", "gpu_atrium_tubes", "gpu_atrium_portal", "gpu_atrium_ies", "gpu_atrium_blend"])
 def test_tuning_options_do_not_change_the_image(fix, request):
     """every knob hydra_hip.h calls a tuning knob leaves the image and the ray counts bit-identical: traversal form, kernel
     fusion, slot order, register budget, refill threshold"""

@@ -303,6 +303,9 @@ def main():
     ap.add_argument("--back", nargs="?", const="camera", default=None, choices=("camera", "spherical"), help="like --sky-tex, and the sky light carries a <back> node: the 256^2 "
                     "checker (texture 1) x (0.9, 1.0, 0.8) is what the camera sees where a ray leaves the hall -- projected by pixel, or as a sphere map -- while the light of the "
                     "sky stays the environment texture (the OpenCL layer's environmentColorExtended, cbidir.h:593-629)")
+    ap.add_argument("--blend", action="store_true", help="closed hall; materials 1, 3 and 5 become hydra_blend materials -- two materials of the library under a mask: "
+                    "1 = its former self (now id 12) over a red lambert (13) through the 128^2 checker, 3 = a glossy lobe (14) over a lambert (15) by Fresnel (IOR 1.8, "
+                    "luminance extrusion), 5 = blend 1 over material 13 under a constant 0.5 grey texture-less mask: a blend of a blend, and children with higher ids than the blend")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky_tex = args.sky_tex or args.sky_hdr or args.portal or (args.back is not None)
@@ -568,6 +571,21 @@ float4 prtex%(n)d_main(const SurfaceInfo* sHit, sampler2D texSide, sampler2D tex
             for mid, body in new_mats.items():
                 if line.startswith('  <material id="%d" ' % mid):
                     xml[i] = '  <material id="%d" name="m%d" type="hydra_material">%s</material>' % (mid, mid, body)
+    if args.blend:
+        for i, line in enumerate(xml):
+            if line.startswith('  <material id="1" '):
+                moved = line.replace('<material id="1" name="m1"', '<material id="12" name="m12"')
+                xml[i] = ('  <material id="1" name="m1" type="hydra_blend" node_top="12" node_bottom="13"><blend type="mask_blend"><mask val="1.0">'
+                          '<texture id="2" type="texref" matrix="3 0 0 0 0 3 0 0 0 0 1 0 0 0 0 1" /></mask></blend></material>')
+            if line.startswith('  <material id="3" '):
+                xml[i] = ('  <material id="3" name="m3" type="hydra_blend" node_top="14" node_bottom="15"><blend type="fresnel_blend"><fresnel_ior val="1.8" /></blend>'
+                          '<extrusion val="luminance" /></material>')
+            if line.startswith('  <material id="5" '):
+                xml[i] = '  <material id="5" name="m5" type="hydra_blend" node_top="1" node_bottom="13"><blend type="mask_blend"><mask val="1.0" /></blend></material>'
+        blend_children = [moved,
+                          '  <material id="13" name="m13" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.7 0.15 0.1" /></diffuse></material>',
+                          '  <material id="14" name="m14" type="hydra_material"><reflectivity brdf_type="%s"><color val="0.9 0.9 0.9" /><glossiness val="0.9" /></reflectivity></material>' % refl,
+                          '  <material id="15" name="m15" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.2 0.4 0.7" /></diffuse></material>']
     if args.height_bump:
         for i, line in enumerate(xml):
             for mid in (0, 4, 9):
@@ -605,6 +623,8 @@ float4 prtex%(n)d_main(const SurfaceInfo* sHit, sampler2D texSide, sampler2D tex
                             'matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" /></normal_map></displacement>' % (1 if mid in (4, 9) else 0, nmap_tex))
                     xml[i] = line.replace("</material>", bump + "</material>")
     xml.append('  <material id="10" name="light_mat" type="hydra_material" light_id="0" visible="1"><emission><color val="60 56 50" /></emission></material>')
+    if args.blend:
+        xml.extend(blend_children)
     if args.cutouts:   # leaves: textured lambert, the mask's alpha channel is the opacity
         xml.append('  <material id="11" name="leaves" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.9 0.9 0.9" /><texture id="%d" type="texref" /></diffuse>'
                    '<opacity smooth="0"><skip_shadow val="0" /><texture id="%d" type="texref" input_alpha="alpha" input_gamma="1" /></opacity></material>' % (mask_tex, mask_tex))
