@@ -30,3 +30,9 @@ rm -rf $OUT/prof_extra
 # device tree builders A/B
 timeout -k 10 400 bash tools/bvh_ab.sh atrium250k 16 2>&1 | grep -v "^make\|^atrium" > $OUT/bvh_ab_atrium250k.log; tail -2 $OUT/bvh_ab_atrium250k.log
 ls $OUT
+# row f4: procedural textures at BASELINE configs[2]'s size (k_proctex next to k_bounce<ALL | PROCTEX>)
+timeout -k 10 300 python tools/pass_bench.py --scene atrium250k_proctex --spp 64 --in-flight 64 > $OUT/pass_atrium250k_proctex.log 2>&1; tail -1 $OUT/pass_atrium250k_proctex.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_pt -- python3 tools/pass_bench.py --scene atrium250k_proctex --spp 64 --in-flight 64 > $OUT/pass_atrium250k_proctex_under_rocprof.log 2>&1
+find $OUT/prof_pt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_atrium250k_proctex.csv
+rm -rf $OUT/prof_pt
+ls $OUT
