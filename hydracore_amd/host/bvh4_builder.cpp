@@ -155,6 +155,20 @@ int BVH4Builder::BuildRecursive(std::vector<PrimRef>& prims, int begin, int end,
     r[pick] = left;
     r[nr++] = right;
   }
+  // Order of the children inside the quad.  Closest-hit rays sort them by distance anyway; any-hit (shadow) rays take them as stored (hk_trace.h, UNORD), so the
+  // order decides how soon an occluder is found.  HYDRA_BVH_CHILD_ORDER = area: largest box first; count: most triangles first; unset: the split order.
+  static const char* const orderEnv = getenv("HYDRA_BVH_CHILD_ORDER");
+  if (orderEnv != nullptr && (orderEnv[0] == 'a' || orderEnv[0] == 'c')) {
+    float key[4];
+    for (int i = 0; i < nr; i++) {
+      if (orderEnv[0] == 'c') { key[i] = float(r[i].e - r[i].b); continue; }
+      float3 mn, mx; box_reset(mn, mx);
+      for (int k = r[i].b; k < r[i].e; k++) { mn = vmin(mn, prims[k].box.mn); mx = vmax(mx, prims[k].box.mx); }
+      key[i] = box_area(mn, mx);
+    }
+    for (int i = 1; i < nr; i++)
+      for (int j = i; j > 0 && key[j] > key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(r[j], r[j - 1]); }
+  }
   for (int i = 0; i < nr; i++) {
     const int c = BuildRecursive(prims, r[i].b, r[i].e, leafMax);
     m_nodes[idx].child[i] = c;
