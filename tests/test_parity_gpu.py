@@ -1587,3 +1587,34 @@ def test_back_plate_scene_matches_the_oracle_image(name, built):
     differs = (np.abs(img_s[..., :3] - img[..., :3]) > 1e-3).any(axis=2)
     assert 0.005 < differs.mean() < 0.6, differs.mean()
     core.close(); plain.close()
+
+
+@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_proctex_small"])
+def test_tile_partition_is_exact_with_back_plate_and_procedural_textures(name, built):
+    """row e for the round's late features: the pixel a path belongs to is recovered from its id and this rank's pixel list (back-plate, ScreenOfPath), and the procedural
+    texture lists are indexed by queue slot -- both must give the frame of one rank when the frame is dealt to three (disjoint supports, bit-identical sum), with 4 samples
+    per pixel in flight so that a rank's paths are several streams over its own pixels"""
+    from hydracore_amd.multi_gpu import tile_owner_mask
+    if "proctex" in name:
+        core, b, _ = _proctex_core(name)
+    else:
+        from hydracore_amd import HipCore
+        _, b = host_scene(name, 96, 54, 5)
+        core = HipCore(96, 54, device=0)
+        core.upload_scene(b)
+    w, h = b["width"], b["height"]
+    core.set_option("samples_in_flight", 4)
+    core.set_tile_partition(0, 1, 16)
+    core.init_path_tracing(99)
+    core.trace_pass(4)
+    full = core.hdr_image(w, h) * core.spp()
+    acc = np.zeros_like(full)
+    for r in range(3):
+        core.set_tile_partition(r, 3, 16)
+        core.init_path_tracing(99)
+        core.trace_pass(4)
+        part = core.hdr_image(w, h) * core.spp()
+        assert (part[~tile_owner_mask(w, h, r, 3, 16)] == 0).all()
+        acc += part
+    assert (acc == full).all() and full[..., :3].mean() > 0.01
+    core.close()
