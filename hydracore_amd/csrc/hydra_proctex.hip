@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include "hk_kernels.h"
 
 static const char* const kAmalgam =
@@ -71,8 +72,9 @@ bool hk_proctex_compile(const char* source, size_t len, std::vector<char>& code,
   }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, program.c_str(), "hydra_proctex.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "proctex_compile: hiprtcCreateProgram failed"; return false; }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value", "-Wno-pragma-once-outside-header"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value", "-Wno-pragma-once-outside-header"};
+  if (getenv("HYDRA_HIP_PROCTEX_RESOURCES") != nullptr) opts.push_back("-Rpass-analysis=kernel-resource-usage");   // registers / spills / occupancy of k_proctex into the build log
+  const hiprtcResult rc = hiprtcCompileProgram(prog, int(opts.size()), opts.data());
   size_t logSize = 0;
   log.clear();
   if (hiprtcGetProgramLogSize(prog, &logSize) == HIPRTC_SUCCESS && logSize > 1) { log.resize(logSize); (void)hiprtcGetProgramLog(prog, &log[0]); }
