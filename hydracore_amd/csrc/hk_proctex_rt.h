@@ -119,6 +119,7 @@ HKU float4 StoreNormal(float3 res, float a_mode) {
 HKU float4 InternalFetch(int a_texId, const float2 texCoord, const int a_flags, const float4* in_texStorage1, const EngineGlobals* in_globals) {
   if (a_texId < 0 || a_texId >= in_globals->hdr[HG_TEX_TABLE_SIZE]) return make_float4(1, 1, 1, 1);
   const int offset = in_globals->texTable[a_texId];
+  if (offset < 0) return make_float4(1, 1, 1, 1);   // an id without a stored texture (another procedural texture, a missing chunk): the reference reads whatever lies before the arena here
   const ::float4 c = ::read_imagef_sw4(reinterpret_cast<const ::int4*>(in_texStorage1) + offset, ::mk2(texCoord.x, texCoord.y), a_flags, (a_flags & HTEX_DATA_HDR) == 0, in_globals->srgbLut);
   return make_float4(c.x, c.y, c.z, c.w);
 }
