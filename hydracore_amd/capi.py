@@ -53,7 +53,7 @@ C_ABI_SYMBOLS = [
     "hydra_hip_stage_pack_unpack", "hydra_hip_stage_light_sample_forward", "hydra_hip_stage_light_pdf_fwd", "hydra_hip_stage_camera_connect",
     "hydra_hip_stage_mutate_kelemen", "hydra_hip_stage_mmlt_f", "hydra_hip_mmlt_begin", "hydra_hip_mmlt_pass", "hydra_hip_mmlt_get_image", "hydra_hip_mmlt_reset_image",
     "hydra_hip_mmlt_get_state", "hydra_hip_mmlt_end", "hydra_hip_sbdpt_pass", "hydra_hip_sbdpt_get_image", "hydra_hip_eval_gbuffer", "hydra_hip_normal_map_from_displacement", "hydra_hip_image_last_error", "hydra_hip_bake_energy_tables", "hydra_hip_bake_last_error", "hydra_hip_bvh_build_mesh", "hydra_hip_bvh_build_mesh_ex", "hydra_hip_bvh_last_error",
-    "hydra_hip_proctex_compile", "hydra_hip_proctex_check", "hydra_hip_stage_proctex", "hydra_hip_stage_set_proctex", "hydra_hip_stage_environment",
+    "hydra_hip_proctex_compile", "hydra_hip_proctex_check", "hydra_hip_stage_proctex", "hydra_hip_stage_set_proctex", "hydra_hip_stage_environment", "hydra_hip_stage_mmlt_accept",
 ]
 
 _hip = None
@@ -115,6 +115,7 @@ def load_hip_library():
         "hydra_hip_stage_shade_point": ([vp, i32, vp, vp, vp, vp, vp, vp], i32),
         "hydra_hip_proctex_compile": ([vp, C.c_char_p, C.c_size_t], i32),
         "hydra_hip_stage_environment": ([vp, i32, vp, vp, vp], i32),
+        "hydra_hip_stage_mmlt_accept": ([vp, i32, vp, vp, vp, C.c_float, vp], i32),
         "hydra_hip_proctex_check": ([C.c_char_p, C.c_size_t], i32),
         "hydra_hip_stage_proctex": ([vp, i32, i32, vp, vp, vp, vp, vp], i32),
         "hydra_hip_stage_set_proctex": ([vp, i32, i32, vp, vp], i32),
@@ -495,6 +496,15 @@ class HipCore:
         self._ck(self.lib.hydra_hip_stage_shade_point(self.h, n, _ptr(surf24), _ptr(dir4), _ptr(flags), _ptr(rnd_light4), _ptr(rands10), _ptr(out)),
                  "stage_shade_point")
         return out
+
+    def stage_mmlt_accept(self, old8, new8, gen2, bk_scale):
+        """one accept / reject step of n chains through k_mmlt_accept (include/hydra_hip.h) -> (out12 float32 [n, 12], generator states after the draw)"""
+        n = len(old8)
+        old8, new8 = np.ascontiguousarray(old8, np.float32), np.ascontiguousarray(new8, np.float32)
+        gen2 = np.ascontiguousarray(gen2, np.uint32).copy()
+        out = np.zeros((n, 12), np.float32)
+        self._ck(self.lib.hydra_hip_stage_mmlt_accept(self.h, n, _ptr(old8), _ptr(new8), _ptr(gen2), float(bk_scale), _ptr(out)), "stage_mmlt_accept")
+        return out, gen2
 
     def stage_environment(self, dir4, in8):
         """the miss shader for n rays (include/hydra_hip.h, hydra_hip_stage_environment): in8 = origin xyz, previous pdf, previous specular, flags, pixel x, y (int bits) -> float32 [n, 4]"""

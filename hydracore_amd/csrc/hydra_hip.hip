@@ -2014,6 +2014,46 @@ struct TmpBufs {
   HCHECK(hipGetLastError());                                                                            \
   HCHECK(hipStreamSynchronize(c->stream));
 
+// One accept / reject step of n Markov chains through the PRODUCTION kernel (k_mmlt_accept -> mmltAcceptReject, hk_bidir.h): chain i holds old8[i] (colour xyz, -, -, -, -, contribFunc)
+// at pixel (2i, 0), the proposal new8[i] lands on pixel (2i + 1, 0) of a 2n x 1 image, so the image IS the pair of contributions; xCur = 0, xNew = 1: accepted chains show 1.
+int hydra_hip_stage_mmlt_accept(hydra_hip_handle c, int n, const float* old8, const float* new8, uint32_t* gen2, float bk_scale, float* out12) {
+  STAGE_PROLOG(false);
+  if (!old8 || !new8 || !gen2 || !out12) return fail(c, HYDRA_HIP_EINVAL, "stage_mmlt_accept: null argument");
+  std::vector<float> ch(size_t(CH_PLANES) * n, 0.0f), o8(new8, new8 + size_t(n) * 8);
+  for (int i = 0; i < n; i++) {
+    ch[size_t(CH_Y) * n + i] = old8[size_t(i) * 8 + 7];
+    for (int k = 0; k < 3; k++) ch[size_t(CH_COLOR + k) * n + i] = old8[size_t(i) * 8 + k];
+    ch[size_t(CH_XS) * n + i] = float(2 * i); ch[size_t(CH_YS) * n + i] = 0.0f;
+    memcpy(&ch[size_t(CH_GEN2) * n + i], &gen2[2 * i], 4); memcpy(&ch[size_t(CH_GEN2 + 1) * n + i], &gen2[2 * i + 1], 4);
+    o8[size_t(i) * 8 + 3] = float(2 * i + 1); o8[size_t(i) * 8 + 4] = 0.0f;
+  }
+  const int stride = mmltStride(2);
+  std::vector<int> depth(size_t(n), 2);
+  std::vector<float> xc(size_t(stride) * n, 0.0f), xn(size_t(stride) * n, 1.0f);
+  float* dch = (float*)tb.up(c, ch.data(), ch.size() * 4, rc);
+  int* ddepth = (int*)tb.up(c, depth.data(), depth.size() * 4, rc);
+  float* dxc = (float*)tb.up(c, xc.data(), xc.size() * 4, rc);
+  float* dxn = (float*)tb.up(c, xn.data(), xn.size() * 4, rc);
+  float* do8 = (float*)tb.up(c, o8.data(), o8.size() * 4, rc);
+  float* dimg = (float*)tb.up(c, nullptr, size_t(2 * n) * 16, rc);
+  if (rc) return rc;
+  HCHECK(hipMemsetAsync(dimg, 0, size_t(2 * n) * 16, c->stream));
+  MmltChains mc; mc.n = n; mc.maxD = 2; mc.ch = dch; mc.depth = ddepth; mc.xCur = dxc; mc.xNew = dxn;
+  hipLaunchKernelGGL(k_mmlt_accept, dim3((n + 255) / 256), dim3(256), 0, c->stream, mc, do8, bk_scale, dimg, 2 * n);
+  STAGE_EPILOG();
+  std::vector<float> img(size_t(2 * n) * 4);
+  HCHECK(hipMemcpy(img.data(), dimg, img.size() * 4, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(ch.data(), dch, ch.size() * 4, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(xc.data(), dxc, size_t(n) * 4, hipMemcpyDeviceToHost));   // plane 0 of xCur
+  for (int i = 0; i < n; i++) {
+    float* r = out12 + size_t(i) * 12;
+    memcpy(r, &img[size_t(2 * i) * 4], 16); memcpy(r + 4, &img[size_t(2 * i + 1) * 4], 16);
+    r[8] = xc[size_t(i)]; r[9] = ch[size_t(CH_ACCEPTED) * n + i]; r[10] = 0.0f; r[11] = 0.0f;
+    memcpy(&gen2[2 * i], &ch[size_t(CH_GEN2) * n + i], 4); memcpy(&gen2[2 * i + 1], &ch[size_t(CH_GEN2 + 1) * n + i], 4);
+  }
+  return HYDRA_HIP_OK;
+}
+
 // the miss shader with a back-plate: environmentColorExtended (hk_shading.h) for n rays that left the scene; in8 = ray origin xyz, previous BSDF pdf, previous bounce
 // specular (0/1), ray flags (int bits), pixel x, y (int bits)
 int hydra_hip_stage_environment(hydra_hip_handle c, int n, const float* ray_dir4, const float* in8, float* out4) {

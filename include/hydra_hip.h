@@ -226,6 +226,13 @@ int hydra_hip_stage_shade_point(hydra_hip_handle h, int n, const float* surf24, 
  * in8 per ray: origin xyz, previous BSDF pdf, previous bounce specular (0/1), ray flags, pixel x, pixel y (the last three as int bits).  out4: colour | 0. */
 int hydra_hip_stage_environment(hydra_hip_handle h, int n, const float* ray_dir4, const float* in8, float* out4);
 
+/* test entry: one accept / reject step of n Markov chains through the production kernel -- the acceptance min(1, f(y) / f(x)), the draw from the chain's second generator and
+ * the two expected-value contributions (IntegratorMMLT::DoPass, hydra_drv/CPUExp_Integrators_MMLT.cpp:400-446; the wavefront layer's MMLTAcceptReject, shaders/mlt.cl:205-262,
+ * whose inputs and outputs tests/golden/ref_mmlt_accept.npz holds).  old8 / new8 per chain: colour xyz, -, -, -, -, contribFunc of the current state / the proposal; gen2: the
+ * generator states (in: before the draw, out: after).  out12: contribution at the old state xyz, its weight 1 - a; at the proposal xyz, its weight a (a pair is zero when the
+ * contribution is below the reference's 1e-12 threshold); [8] = 1 when the chain took the proposal, [9] = the chain's acceptance counter. */
+int hydra_hip_stage_mmlt_accept(hydra_hip_handle h, int n, const float* old8, const float* new8, uint32_t* gen2, float bk_scale, float* out12);
+
 /* One bounce of n paths with every input handed in: the phases of the bounce kernel one after the other -- environment
  * (kernel_HitEnvironment, hydra_drv/CPUExp_Integrators_PT_Loop.cpp:23-33), emission + MIS (kernel_EvalEmission :86-139), light pick and sample with the
  * shadow ray (kernel_LightSelect / kernel_LightSample :141-168), next-event shading (kernel_Shade :181-216), BSDF sampling and the path-state

@@ -3406,6 +3406,27 @@ void orc_mmlt_f(const OrcScene* s, int n, const int32_t* depth, const float* xve
  * (stride floats), in and out; depth[i] = its d.  The clock()-driven stirring (:97-103, :362-368) is left out.  Outputs: image4 (w*h*4,
  * contributions added), chains6 = y, colour, pixel x, y per chain, accepted = count per chain. */
 static float mutateKelemen1(float x, float r0, float r1, float p2, float p1) { float v = x, rr[2] = {r0, r1}, o; orc_mutate_kelemen(1, &v, rr, p2, p1, &o); return o; }
+/* the acceptance probability and the two expected-value contributions of one mutation (CPUExp_Integrators_MMLT.cpp:400-428; MMLTAcceptReject, shaders/mlt.cl:205-262) */
+static void mmltAcceptContrib(float yOld, const float* yOldColor, float yNew, const float* yNewColor, float bkScale, float* a_out, float* cX, float* cY) {
+  const float a = (yOld == 0.0f) ? 1.0f : fminf(1.0f, yNew / yOld);
+  const float kx = (1.0f / fmaxf(yOld, 1e-6f)), ky = (1.0f / fmaxf(yNew, 1e-6f));
+  for (int q = 0; q < 3; q++) { cX[q] = yOldColor[q] * bkScale * kx * (1.0f - a); cY[q] = yNewColor[q] * bkScale * ky * a; }
+  *a_out = a;
+}
+/* that step for n chains handed in (layout: include/hydra_hip.h, hydra_hip_stage_mmlt_accept) */
+void orc_stage_mmlt_accept(int n, const float* old8, const float* new8, uint32_t* gen2, float bkScale, float* out12) {
+  for (int i = 0; i < n; i++) {
+    const float* o = old8 + 8 * (size_t)i; const float* w = new8 + 8 * (size_t)i;
+    float* r = out12 + 12 * (size_t)i;
+    float a, cX[3], cY[3];
+    mmltAcceptContrib(o[7], o, w[7], w, bkScale, &a, cX, cY);
+    const float p = orc_rnd_float1(gen2 + 2 * (size_t)i);
+    memset(r, 0, 12 * sizeof(float));
+    if (cX[0] * cX[0] + cX[1] * cX[1] + cX[2] * cX[2] > 1e-12f) { r[0] = cX[0]; r[1] = cX[1]; r[2] = cX[2]; r[3] = 1.0f - a; }
+    if (cY[0] * cY[0] + cY[1] * cY[1] + cY[2] * cY[2] > 1e-12f) { r[4] = cY[0]; r[5] = cY[1]; r[6] = cY[2]; r[7] = a; }
+    r[8] = (p <= a) ? 1.0f : 0.0f;
+  }
+}
 void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* depth, int mutations, int w, float* image4, float* chains6, float* xrows, int stride, int32_t* accepted) {
 #pragma omp parallel for schedule(dynamic, 16)
   for (int i = 0; i < n; i++) {
@@ -3440,12 +3461,10 @@ void orc_mmlt_run(const OrcScene* s, int n, uint32_t* gens4, const int32_t* dept
       const float yNew = o[7], yOld = y;
       const float yOldColor[3] = {yColor[0], yColor[1], yColor[2]};
       const int xScrOld = xScr, yScrOld = yScr, xScrNew = (int)o[3], yScrNew = (int)o[4];
-      const float a = (yOld == 0.0f) ? 1.0f : fminf(1.0f, yNew / yOld);
+      float a, cX[3], cY[3];
+      mmltAcceptContrib(yOld, yOldColor, yNew, o, 1.0f, &a, cX, cY);
       const float p = orc_rnd_float1(gen2);
       if (p <= a) { memcpy(xCur, xNew, sizeof(float) * (size_t)size); y = yNew; yColor[0] = o[0]; yColor[1] = o[1]; yColor[2] = o[2]; xScr = xScrNew; yScr = yScrNew; acc++; }
-      const float kx = (1.0f / fmaxf(yOld, 1e-6f)), ky = (1.0f / fmaxf(yNew, 1e-6f));
-      const float cX[3] = {yOldColor[0] * 1.0f * kx * (1.0f - a), yOldColor[1] * 1.0f * kx * (1.0f - a), yOldColor[2] * 1.0f * kx * (1.0f - a)};
-      const float cY[3] = {o[0] * 1.0f * ky * a, o[1] * 1.0f * ky * a, o[2] * 1.0f * ky * a};
       if (cX[0] * cX[0] + cX[1] * cX[1] + cX[2] * cX[2] > 1e-12f) {
         float* px = image4 + 4 * (size_t)(yScrOld * w + xScrOld);
         for (int q = 0; q < 3; q++) {

@@ -80,6 +80,8 @@ void orc_stage_environment(const OrcScene* s, int n, const float* dir4, const fl
  * fn(user, surf19 = wp lp n tg bn tc0 ao ao2, material head, ray direction, &count, ids[16], colours[48]); NULL = none (the lists stay empty) */
 void orc_set_proctex_eval(void* fn, void* user);
 void orc_stage_set_proctex(int n, int max_num, const int* ids, const uint16_t* halfs4);
+/* one accept / reject step of n Markov chains handed in (include/hydra_hip.h, hydra_hip_stage_mmlt_accept) */
+void orc_stage_mmlt_accept(int n, const float* old8, const float* new8, uint32_t* gen2, float bkScale, float* out12);
 void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const float* pos4, const float* dir4, const float* surf24, const float* in16,
                       const float* rands10, float* out40);
 

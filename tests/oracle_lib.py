@@ -249,6 +249,17 @@ class Oracle:
         self.lib.orc_gbuffer(C.byref(self.s), self.w, self.h, x0, y0, nx, ny, _p(d1), _p(d2), _p(raw))
         return d1, d2, raw
 
+    def stage_mmlt_accept(self, old8, new8, gen2, bk_scale):
+        """orc_stage_mmlt_accept -> (out12 float32 [n, 12], generator states after the draw)"""
+        n = len(old8)
+        old8, new8 = np.ascontiguousarray(old8, np.float32), np.ascontiguousarray(new8, np.float32)
+        gen2 = np.ascontiguousarray(gen2, np.uint32).copy()
+        out = np.zeros((n, 12), np.float32)
+        self.lib.orc_stage_mmlt_accept.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        self.lib.orc_stage_mmlt_accept.restype = None
+        self.lib.orc_stage_mmlt_accept(n, _p(old8), _p(new8), _p(gen2), float(bk_scale), _p(out))
+        return out, gen2
+
     def stage_environment(self, dir4, in8):
         """orc_stage_environment -> float32 [n, 4]"""
         n = len(in8)

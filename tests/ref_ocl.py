@@ -515,6 +515,28 @@ class RefMmltWavefront:
                     pdf=M.down(m_pdf, f32, (max_d + 2, n, 2)), srpos=srpos, srdir=srdir)
 
 
+def ref_mmlt_accept_reject(x_color4, y_color4, depth, scale_table, gens2, max_bounce=2, device=0):
+    """The reference's own MMLTAcceptReject (shaders/mlt.cl:205-262, compiled unmodified by oracle/build_ref.sh) on n chains: current and proposed colour (w = the packed
+    pixel, passed through), path length d per chain, the per-length scale table, the accept-test generators.  The x / y vectors are 0 / 1 everywhere, so an accepted chain
+    shows ones.  -> dict(x_alpha, y_alpha [n, 4], x_color [n, 4] after, gens [n, 2] after, accepted [n] bool)"""
+    m = RefModule("mlt.hsaco", device)
+    n = len(x_color4)
+    planes = 12 + 6 * max_bounce                                     # MMLT_HEAD_TOTAL_SIZE + MMLT_COMPRESSED_F_PERB per bounce
+    xv, yv = m.up(np.zeros((planes, n), np.float32)), m.up(np.ones((planes, n), np.float32))
+    xc, yc = m.up(np.ascontiguousarray(x_color4, np.float32)), m.up(np.ascontiguousarray(y_color4, np.float32))
+    split = np.zeros((n, 2), np.int32)
+    split[:, 0] = depth
+    g = m.up(np.ascontiguousarray(gens2, np.uint32))
+    xa, ya = m.alloc(n * 16), m.alloc(n * 16)
+    m.launch("MMLTAcceptReject", n, [("p", xv), ("p", yv), ("p", xc), ("p", yc), ("p", m.up(split)), ("p", m.up(np.ascontiguousarray(scale_table, np.float32))),
+                                     ("p", g), ("p", xa), ("p", ya), ("i", max_bounce), ("i", n)], block=256)
+    out = dict(x_alpha=m.down(xa, np.float32, (n, 4)), y_alpha=m.down(ya, np.float32, (n, 4)), x_color=m.down(xc, np.float32, (n, 4)),
+               gens=m.down(g, np.uint32, (n, 2)), accepted=m.down(xv, np.float32, (planes, n)).min(axis=0) == 1.0)
+    assert (m.down(xv, np.float32, (planes, n)).max(axis=0) == out["accepted"]).all()      # a chain takes the whole proposal or nothing
+    m.close()
+    return out
+
+
 class RefGBufferKernels:
     """The reference's OWN G-buffer kernels in the order of GPUOCLLayer::EvalGBuffer (GPUOCLLayerOther.cpp:742-765): MakeEyeRaysSPP (screen.cl:35, GBUFFER_SAMPLES = 64 plane
     Hammersley samples per pixel) -> traversal -> ComputeHit -> GetGBufferSample (material.cl:1347, one work-group of 64 per pixel), compiled unmodified.  Returns the two packed

@@ -680,3 +680,49 @@ def test_oracle_matches_reference_environment_extended(name, built):
         assert np.uint32(vi[35]) == np.uint32(0xFFFFFFFE)
     else:
         assert vi[35] == 1 and vi[41] == (1 if name == "atrium_backsph_small" else 0) and np.allclose(vf[42:45], [0.9, 1.0, 0.8]) and np.isclose(vf[36], 2.2)
+
+
+# ---- the accept / reject step of the Markov chains against the reference's own MMLTAcceptReject kernel (shaders/mlt.cl:205-262)
+def check_mmlt_accept(run):
+    """run(old8, new8, gen2, bk_scale) -> (out12, gens after).  The wavefront kernel and the CPU integrator (CPUExp_Integrators_MMLT.cpp:400-446) agree on the acceptance, the draw
+    and the two contributions except for: the factor two the kernel gives path length 3 (`MMLTCheatThirdBounceContrib`, mlt.cl:230-231; the CPU integrator has none -- divided out
+    here), the place of the scale in the product (last there, first here: last-bit differences), and the 1e-12 threshold under which the CPU integrator drops a contribution (the
+    kernel always writes it: compared where the CPU integrator keeps it, and required to be tiny where it does not)."""
+    fx = load("ref_mmlt_accept.npz")
+    old, new, depth, gens, scale = fx["old"], fx["new"], fx["depth"], fx["gens"], float(fx["scale"])
+    n = len(old)
+
+    def f(c):
+        return np.maximum(np.float32(0.33334) * (c[:, 0] + c[:, 1] + c[:, 2]), np.float32(0)).astype(np.float32)      # contribFunc, cglobals.h:1929-1932
+    old8, new8 = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32)
+    old8[:, :3], old8[:, 7], new8[:, :3], new8[:, 7] = old, f(old), new, f(new)
+    out, gens_after = run(old8, new8, gens, scale)
+    assert (gens_after == fx["out_gens"]).all()                                   # one draw from the accept-test generator, same state after
+    acc_ref = fx["out_accepted"]
+    assert ((out[:, 8] != 0) == acc_ref).all() and 0.3 < acc_ref.mean() < 0.9
+    assert acc_ref[f(old) == 0].all() and not acc_ref[(f(new) == 0) & (f(old) > 0)].any()
+    div = np.where(depth == 3, np.float32(2), np.float32(1))[:, None]
+    for mine, ref in ((out[:, 0:3], fx["out_x_alpha"][:, :3] / div), (out[:, 4:7], fx["out_y_alpha"][:, :3] / div)):
+        kept = (mine ** 2).sum(1) > 0
+        np.testing.assert_allclose(mine[kept], ref[kept], rtol=4e-7, atol=0)
+        assert ((ref[~kept] ** 2).sum(1) <= 1.0000005e-12).all()
+        assert kept.mean() > 0.3
+    a = np.where(f(old) == 0, np.float32(1), np.minimum(np.float32(1), f(new) / np.where(f(old) == 0, np.float32(1), f(old)))).astype(np.float32)
+    kx, ky = (out[:, 0:3] ** 2).sum(1) > 0, (out[:, 4:7] ** 2).sum(1) > 0
+    assert (out[kx, 3] == (np.float32(1) - a)[kx]).all() and (out[ky, 7] == a[ky]).all()
+
+
+def test_oracle_matches_reference_mmlt_accept_reject(built):
+    from oracle_lib import load as load_oracle
+    import ctypes as C
+    lib = load_oracle()
+
+    def run(old8, new8, gen2, bk):
+        n = len(old8)
+        gen2 = np.ascontiguousarray(gen2, np.uint32).copy()
+        out = np.zeros((n, 12), np.float32)
+        lib.orc_stage_mmlt_accept.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        lib.orc_stage_mmlt_accept.restype = None
+        lib.orc_stage_mmlt_accept(n, old8.ctypes.data, new8.ctypes.data, gen2.ctypes.data, bk, out.ctypes.data)
+        return out, gen2
+    check_mmlt_accept(run)

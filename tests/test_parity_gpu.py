@@ -1618,3 +1618,11 @@ def test_tile_partition_is_exact_with_back_plate_and_procedural_textures(name, b
         acc += part
     assert (acc == full).all() and full[..., :3].mean() > 0.01
     core.close()
+
+
+def test_hip_matches_reference_mmlt_accept_reject(gpu224):
+    """the production k_mmlt_accept (hydra_hip_stage_mmlt_accept) against the reference's own MMLTAcceptReject kernel (ref_mmlt_accept.npz); tests/test_golden_ref.py
+    check_mmlt_accept states the comparison and the kernel's factor two at path length 3"""
+    from test_golden_ref import check_mmlt_accept
+    core, _, _ = gpu224
+    check_mmlt_accept(core.stage_mmlt_accept)
