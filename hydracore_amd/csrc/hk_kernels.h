@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK, (ANYHIT && !COUNT) ? HK_TRACE_
     bool done = false;
     if (VOTE) {
       trav_run_vote<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA, UNORD>(t, busy, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive, wq, wt, wi);
-      done = busy && t.top < 0;
+      done = busy && t.top < 0 && t.pend < 0;
     } else if (busy) done = trav_run<ANYHIT, COUNT, true, HkStackT<LDS_DEPTH>, TOPTRIS, ALPHA>(t, bv, haveInst, 0.0f, st, c, queueEmpty ? 0 : minActive);
     if (done) {
       if (ANYHIT) outVis[rayIdx] = (t.hit.primId != -1) ? 0.0f : 1.0f;

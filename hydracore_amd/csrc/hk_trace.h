@@ -243,6 +243,10 @@ struct TravState {
   HydraLiteHit hit;
   int top, left, instDeep, instTop, instId;
   bool searching;
+  // speculative walk (trav_run_vote, HK_SPEC_LEAF): a triangle leaf put aside while the lane goes on with inner nodes, and whether the lane has since popped its way out of
+  // the instance that leaf belongs to (the world ray is restored only after the leaf has been tested)
+  int pend;
+  bool pendExit;
 };
 HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int rootLink = 1) {
   t.pos = pos; t.dir = dir; t.inv = SafeInverse(dir);
@@ -250,6 +254,7 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
   t.hit = hit;
   t.top = 0; t.left = rootLink; t.instDeep = 0; t.instTop = 0; t.instId = -1;
   t.searching = true;
+  t.pend = -1; t.pendExit = false;
 }
 
 // ---- the three kinds of step a ray alternates between.  Each is what BVH4InstTraverse does in one turn of its inner loop
@@ -258,7 +263,7 @@ HK_DEV void trav_init(TravState& t, f3 pos, f3 dir, const HydraLiteHit& hit, int
 
 // one quad: fetch its 4 child boxes, test, order near -> far, push, descend or pop (ctrace.h:866-1006)
 template <bool COUNT, bool TOPCACHE, class STACK, bool SORTED = true>
-HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst, const float t_rayMin, STACK& stack, TravCounters& cnt) {
+HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst, const float t_rayMin, STACK& stack, TravCounters& cnt, const bool deferExit = false) {
   float4 n0a, n0b, n1a, n1b, n2a, n2b, n3a, n3b;
   if (TOPCACHE && (t.left & HK_TOP_FLAG)) {   // one of the hottest quads: 8 LDS reads instead of 8 trips through the texture addresser
     n0a = bv.topPiece(t.left, 0); n0b = bv.topPiece(t.left, 1); n1a = bv.topPiece(t.left, 2); n1b = bv.topPiece(t.left, 3);
@@ -332,7 +337,8 @@ HK_DEV void trav_quad_step(TravState& t, const BvhView& bv, const bool haveInst,
   __builtin_amdgcn_s_setprio(0);
 #endif
   if (haveInst && t.top < t.instTop && t.instDeep == 1) {
-    t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0;   // = SafeInverse(t.odir), same bits (ctrace.h:1000-1006)
+    if (deferExit) t.pendExit = true;   // a leaf of this instance is still waiting for its triangle tests: it needs the object-space ray
+    else { t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0; }   // = SafeInverse(t.odir), same bits (ctrace.h:1000-1006)
   }
 }
 // what follows every leaf of either kind (ctrace.h:1043-1056)
@@ -501,10 +507,49 @@ HK_DEV bool trav_run(TravState& t, const BvhView& bv, const bool haveInst,
 #endif
 // UNORD (any-hit, non-counting kernels only; option shadow_unordered): a quad's children are taken in stored order instead of near to far; closest-hit rays and the
 // counting kernels always walk near to far, as BVH4InstTraverse / BVH4InstTraverseShadow do
+#ifndef HK_SPEC_LEAF
+#define HK_SPEC_LEAF 0
+#endif
 template <bool ANYHIT, bool COUNT, bool TOPCACHE = false, class STACK = HkStack, bool TOPTRIS = false, bool ALPHA = false, bool UNORD = false>
 HK_DEV void trav_run_vote(TravState& t, const bool busy, const BvhView& bv, const bool haveInst,
                           const float t_rayMin, STACK& stack, TravCounters& cnt, const int minActive, const int wq, const int wt, const int wi) {
   static_assert(!UNORD || (ANYHIT && !COUNT), "only an any-hit query is independent of the order");
+  // SPEC (experiment, closest-hit production kernels): a lane that stands at a triangle leaf while the wave does inner nodes puts the leaf aside and walks on; the leaf is
+  // tested at the wave's next triangle turn, before any leaf found later.  The leaves a ray tests, and their order, are a superset of the reference's in the same order
+  // (what is walked in between was not yet pruned by the waiting leaf's hit: nothing in it can be nearer or equal), so hits and their bits do not change.
+  constexpr bool SPEC = (HK_SPEC_LEAF != 0) && !ANYHIT && !COUNT && !TOPTRIS && !ALPHA;
+  if (SPEC) {
+    while (true) {
+      const bool walking = busy && t.top >= 0 && !t.pendExit;
+      const bool alive = busy && (t.top >= 0 || t.pend >= 0);
+      const bool atInst = haveInst && t.instDeep == 0;
+      const bool wantQuad = walking && t.searching, wantInst = walking && !t.searching && atInst && t.pend < 0;
+      const bool atLeaf = walking && !t.searching && !atInst;
+      const bool wantTri = busy && (atLeaf || t.pend >= 0);
+      const int nq = HK_POPC(HK_BALLOT(wantQuad)), nt = HK_POPC(HK_BALLOT(wantTri)), ni = haveInst ? HK_POPC(HK_BALLOT(wantInst)) : 0;
+      const int nAlive = HK_POPC(HK_BALLOT(alive));
+      if (nAlive == 0 || nAlive < minActive) return;
+      const int vq = nq * wq, vt = nt * wt, vi = ni * wi;
+      if (vq >= vt && vq >= vi) {
+        if (wantQuad) trav_quad_step<COUNT, TOPCACHE, STACK, true>(t, bv, haveInst, t_rayMin, stack, cnt, t.pend >= 0);
+        else if (atLeaf && t.pend < 0 && (HK_SPEC_LEAF != 2 || t.hit.primId != -1)) {      // put the leaf aside, take the next node off the stack (what trav_tri_step does after its tests); variant 2: only rays that already have a hit to prune with
+          t.pend = t.left;
+          t.top--;
+          t.left = stack.get(t.top);
+          t.searching = !(t.left & int(HYDRA_BVH_LEAF));
+          t.left = t.left & 0x7fffffff;
+          if (haveInst && t.top < t.instTop && t.instDeep == 1) t.pendExit = true;
+        }
+      } else if (vt >= vi) {
+        if (t.pend >= 0 && busy) {
+          t.hit = haveInst ? IntersectLeaf<false, COUNT, false, false>(t.pos, t.dir, t.pend, t_rayMin, t.hit, bv, t.instId, true, cnt)
+                           : IntersectLeaf<false, COUNT, false, false>(t.pos, t.dir, t.pend, t_rayMin, t.hit, bv, 0, false, cnt);
+          t.pend = -1;
+          if (t.pendExit) { t.pos = t.opos; t.dir = t.odir; t.inv = t.oinv; t.instDeep = 0; t.pendExit = false; }
+        } else if (atLeaf) (void)trav_tri_step<false, COUNT, STACK, false, false>(t, bv, haveInst, t_rayMin, stack, cnt);
+      } else { if (wantInst) trav_inst_step<COUNT>(t, bv, cnt); }
+    }
+  }
   while (true) {
     const bool alive = busy && t.top >= 0;
     const bool atInst = haveInst && t.instDeep == 0;
