@@ -2600,6 +2600,7 @@ __global__ void __launch_bounds__(256) k_gbuffer_resolve(SceneDev s, int w, int 
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = int(__lane_id());
   if (wave >= nPix) return;   // wave-uniform
   const int r = wave * HK_GBUFFER_SAMPLES + lane;
+  s.ptlSlot = (s.ptlIds != nullptr && uint32_t(s.ptlIds[r]) != HYDRA_INVALID_TEXTURE) ? r : -1;   // the ray's procedural texture list (eval_gbuffer runs the scene's program first)
   HydraLiteHit hit = hits[r];
   if (hit.primId != -1) hit.geomId = HK_GEOM_ID(hit.geomId);   // the device's class label is not part of Lite_Hit
   GBufferSample g = gbufferSampleOf(s, xyz(pos4[r]), xyz(dir4[r]), hit);
@@ -2642,7 +2643,7 @@ int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, int w
   HCHECK(hipSetDevice(c->device));
   { const int prc = prepare_geometry(c); if (prc) return prc; }
   { const int vrc = validate_materials(c); if (vrc) return vrc; }
-  if (c->ptlMax > 0) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: materials of the scene bind procedural textures; this layer runs them in the path tracer only (trace_pass)");
+  if (c->ptlMax > 0 && c->procTex == nullptr) return fail(c, HYDRA_HIP_ESTATE, "eval_gbuffer: materials of the scene bind procedural textures, but no program was compiled for them (hydra_hip_proctex_compile)");
   { const int crc = prepare_classes(c); if (crc) return crc; }
   int rc = HYDRA_HIP_OK;
   if ((rc = ensure_fetch_counters(c))) return rc;
@@ -2665,6 +2666,12 @@ int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, int w
   float4* d2 = (float4*)tb.up(c, nullptr, size_t(npix) * 16, rc);
   float* draw = raw14 ? (float*)tb.up(c, nullptr, size_t(npix) * 14 * 4, rc) : nullptr;
   int* dremap = (inst_remap && inst_remap_size > 0) ? (int*)tb.up(c, inst_remap, size_t(inst_remap_size) * 4, rc) : nullptr;
+  // procedural textures: the scene's program on the hits of every block of rays, lists by ray index (GetGBufferSample reads the same per-ray lists, material.cl:1347)
+  int* dptlIds = nullptr; uint2* dptlVals = nullptr;
+  if (c->ptlMax > 0) {
+    dptlIds = (int*)tb.up(c, nullptr, size_t(pixPerBlock) * HK_GBUFFER_SAMPLES * size_t(c->ptlMax) * 4, rc);
+    dptlVals = (uint2*)tb.up(c, nullptr, size_t(pixPerBlock) * HK_GBUFFER_SAMPLES * size_t(c->ptlMax) * 8, rc);
+  }
   if (rc) return rc;
   const SceneDev s = make_scene(c);
   // the rays go through the traversal kernel as a 32-segment queue like the path tracer's: its persistent waves take their rays through one
@@ -2683,7 +2690,12 @@ int hydra_hip_eval_gbuffer(hydra_hip_handle c, float* data1, float* data2, int w
     HCHECK(hipMemsetAsync(fetch, 0, size_t(HK_CROW) * 4, c->stream));
     hipLaunchKernelGGL(k_fill_seg_counts, dim3(1), dim3(64), 0, c->stream, n, capG, nsegG, segCounts);
     launch_closest(c, s, seg_q(segCounts, 0, nsegG, capG), dpos, ddir, dh, nullptr, nullptr, fetch);
-    hipLaunchKernelGGL(k_gbuffer_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, s, c->w, c->h, pix0, nPix, dpos, ddir, dh, dremap, inst_remap_size, d1, d2, draw);
+    SceneDev sr = s;
+    if (c->ptlMax > 0) {
+      HCHECK(hk_proctex_launch_points(c->procTex, c->stream, s, n, dpos, ddir, dh, dptlIds, dptlVals, n, c->ptlMax));
+      sr.ptlIds = dptlIds; sr.ptlVals = dptlVals; sr.ptlStride = n; sr.ptlMax = c->ptlMax;
+    }
+    hipLaunchKernelGGL(k_gbuffer_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, sr, c->w, c->h, pix0, nPix, dpos, ddir, dh, dremap, inst_remap_size, d1, d2, draw);
   }
   HCHECK(hipGetLastError());
   HCHECK(hipEventRecord(ev1, c->stream));

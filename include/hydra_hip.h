@@ -184,7 +184,7 @@ int hydra_hip_stage_pack_unpack(hydra_hip_handle h, float* rgba_frame, int width
  * closest-hit traversal and the bounce kernel of every bounce (where GPUOCLLayer::runKernel_ComputeHit runs ProcTexExec, GPUOCLKernels.cpp:662-690); results reach the
  * shading code as four halfs per texture, as in the reference (WriteProcTextureList, cglobals.h:2327-2359).  HYDRA_HIP_EINVAL with the compiler's log in
  * hydra_hip_last_error when the text does not compile.  source = NULL or length 0 drops the program.  A scene whose materials carry PLAIN_MATERIAL_HAVE_PROC_TEXTURES
- * cannot be traced without one (trace_pass fails), and runs in the path tracer only (mmlt_begin / eval_gbuffer refuse it).  Ambient-occlusion inputs (readAttr_AO) are 1. */
+ * cannot be traced without one (trace_pass / eval_gbuffer fail), and runs in the path tracer and the G-buffer pass (mmlt_begin refuses it).  Ambient-occlusion inputs (readAttr_AO) are 1. */
 int hydra_hip_proctex_compile(hydra_hip_handle h, const char* source, size_t length);
 /* the same compilation without a device or a context (hiprtc builds for gfx950 wherever it runs): HYDRA_HIP_OK, or HYDRA_HIP_EINVAL with the log in hydra_hip_last_error(NULL) */
 int hydra_hip_proctex_check(const char* source, size_t length);

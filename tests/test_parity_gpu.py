@@ -1491,6 +1491,11 @@ def test_flat_procedural_textures_render_the_plain_scene_bit_for_bit(built):
     assert np.isfinite(img_f).all() and img_f[..., :3].mean() > 0.01
     assert (st_f.extensionRays, st_f.shadowRays, st_f.samples) == (st_p.extensionRays, st_p.shadowRays, st_p.samples)
     assert (img_f.view(np.uint32) == img_p.view(np.uint32)).all()
+    # IHWLayer::EvalGBuffer on the two: the procedural colours reach the diffuse-colour layer through the per-ray lists (GetGBufferSample reads them, material.cl:1347)
+    gf, gp = flat.eval_gbuffer(96, 54, raw=True), plain.eval_gbuffer(96, 54, raw=True)
+    for a, b_ in zip(gf, gp):
+        assert (a.view(np.uint32) == b_.view(np.uint32)).all()
+    assert gf[2][..., :].std() > 0
     flat.close(); plain.close()
 
 
@@ -1510,6 +1515,8 @@ def test_procedural_texture_scene_renders_and_refuses_what_it_cannot_run(gpu_atr
         assert (st2.extensionRays, st2.shadowRays) == (st.extensionRays, st.shadowRays)
     with pytest.raises(HydraError, match="procedural"):
         core.mmlt_begin(1024, 1, 3, 5)
+    d1, d2, raw = core.eval_gbuffer(96, 54, raw=True)          # the G-buffer pass runs the scene's program too (below: against a plain scene)
+    assert np.isfinite(raw).all()
     core.proctex_compile("")
     with pytest.raises(HydraError, match="procedural textures"):
         core.trace_pass(1)
