@@ -346,7 +346,8 @@ HK_DEV f3 direct_light_unoccluded(const SceneDev& s, const float* mat, const Sur
 
 // S2 -- BSDF sampling of the next bounce (kernel_NextBounce) with the ten random numbers of RndMatAll handed in; `accum` is the radiance carried on
 template <int F = HK_FEAT_ALL>
-HK_DEV void next_bounce_with(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, const float* rands,
+// returns true when the sampled leaf is a shadow catcher whose throughput awaits this bounce's shadow (hk_shading.h, HK_MATTE_PENDING)
+HK_DEV bool next_bounce_with(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, const float* rands,
                              const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
   MatSample ms;
   MaterialSampleAndEvalBxDF<F>(mat, rands, surf, ray_dir, flags, s, ms);
@@ -360,9 +361,10 @@ HK_DEV void next_bounce_with(const SceneDev& s, const float* mat, const SurfaceH
   oDir = mk4(ms.direction, as_float(int(flags)));
   oThr = mk4(thr, ms.pdf);
   oAcc = mk4(accum, isSpec ? 1.0f : 0.0f);
+  return (ms.flags & HK_MATTE_PENDING) != 0;
 }
 template <int F = HK_FEAT_ALL>
-HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
+HK_DEV bool next_bounce_phase(const SceneDev& s, const float* mat, const SurfaceHit& surf, const f3 ray_dir, uint32_t flags, RandomGen& gen,
                               const float4& thr4, const f3 accum, const float gidBits, float4& oPos, float4& oDir, float4& oThr, float4& oAcc) {
   float rands[10];   // RndMatAll, crandom.h:478-494: 1 draw -> 3 floats, then 7 single draws
   {
@@ -370,7 +372,7 @@ HK_DEV void next_bounce_phase(const SceneDev& s, const float* mat, const Surface
     rands[0] = r4.x; rands[1] = r4.y; rands[2] = r4.z;
     for (int k = 0; k < 7; k++) rands[3 + k] = rndFloat1_Pseudo(gen);
   }
-  next_bounce_with<F>(s, mat, surf, ray_dir, flags, rands, thr4, accum, gidBits, oPos, oDir, oThr, oAcc);
+  return next_bounce_with<F>(s, mat, surf, ray_dir, flags, rands, thr4, accum, gidBits, oPos, oDir, oThr, oAcc);
 }
 
 // Split form, kernel 1 of 2: hit phase, survivors compacted into M
@@ -609,6 +611,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
         const float4 pend = Sin.pend4[i];
         const float vis = sh.vis[i];
         acc4.x = acc4.x + pend.x * vis; acc4.y = acc4.y + pend.y * vis; acc4.z = acc4.z + pend.z * vis;
+        if ((F & HK_FEAT_RARE_LIGHTS) && pend.w != 0.0f) { thr4.x *= vis; thr4.y *= vis; thr4.z *= vis; }   // the previous bounce went through a shadow catcher (hk_shading.h, HK_MATTE_PENDING)
       }
       const uint2 g2 = Sin.rng2[i];
       gen.x = g2.x; gen.y = g2.y;
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(HK_BOUNCE_BLOCK, W) k_bounce(SceneDev sArg, Sc
 #if defined(HK_EXP_BOUNCE_SKIP) && (HK_EXP_BOUNCE_SKIP & 2)
         oPos = mk4(surf.pos, pos4.w); oDir = dir4; oThr = thr4; oAcc = acc4;
 #else
-        next_bounce_phase<F>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc);
+        if (next_bounce_phase<F>(s, mat, surf, ray_dir, uint32_t(as_int(dir4.w)), gen, thr4, xyz(acc4), pos4.w, oPos, oDir, oThr, oAcc)) oPend.w = 1.0f;
 #endif
       }
     }

@@ -437,7 +437,10 @@ enum { HK_FEAT_SKY = 1, HK_FEAT_DELTA_LIGHTS = 2, HK_FEAT_OREN_NAYAR = 4, HK_FEA
        HK_FEAT_CLASSIC = 31 /* everything but normal maps, translucent, Blinn and the anisotropic (Beckmann, TRGGX) nodes */ };   // DELTA_LIGHTS stands for "lights other than area and sky": point, spot, directional, sphere
 
 // ================================================================================================ materials
+// a back-plate named by the header (a sky light's or a shadow catcher's <back>): the miss shader and the shadow catcher then follow the OpenCL layer (environmentColorExtended below)
+HK_DEV bool haveBackPlate(const SceneDev& s) { return uint32_t(g_varsI(s)[HV_I_SHADOW_MATTE_BACK]) != HYDRA_INVALID_TEXTURE; }
 struct MatSample { f3 color; f3 direction; float pdf; int flags; };          // cglobals.h:394-402
+#define HK_MATTE_PENDING (1 << 30)   /* internal bit of MatSample::flags: a shadow catcher sample whose throughput still has to be multiplied by this bounce's shadow (never reaches the ray flags) */
 struct BxDFResult { f3 brdf; float pdfFwd; f3 btdf; float pdfRev; bool diffuse; };   // cmaterial.h:2374-2386
 struct ShadeContext { f3 l, v, n; f2 tc; f3 fn, tg, bn; };                  // cglobals.h:2282-2301 (fn: light-tracing form of materialEval and normal maps; tg, bn: normal maps and the anisotropic lobes)
 
@@ -1261,9 +1264,15 @@ HK_DEV void MaterialSampleAndEvalBxDF(const float* m, const float* rands, const 
     case HMT_GLASS: if (F & HK_FEAT_GLASS) GlassGGXSampleAndEvalBRDF(node, rands, rayDir, hitNorm, sh.texCoord, sh.hfi, s, out, isFwdDir); break;
     case HMT_TRANSLUCENT: if (F & HK_FEAT_TRANSLUCENT) TranslucentSampleAndEvalBRDF(node, rands[0], rands[1], hitNorm, sh.texCoord, s, out); break;
     case HMT_BLINN: if (F & HK_FEAT_BLINN) BlinnSampleAndEvalBRDF(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, s, out); break;
-    case HMT_SHADOW_MATTE:   // ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942, with the shadow value the CPU integrator hands in: (0, 0, 0) (PT_Loop.cpp:240)
-      out.direction = rayDir; out.pdf = 1.0f; out.color = mk3(0, 0, 0) * (1.0f / fmaxf(fabsf(dot(rayDir, hitNorm)), 1e-5f)); out.flags = HRE_S | HRE_T;
+    case HMT_SHADOW_MATTE: {   // ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942.  The CPU integrator hands in the shadow value (0, 0, 0) (PT_Loop.cpp:240): a black
+      // pass-through surface.  With a back-plate in the header (hk_shading.h, haveBackPlate) the surface is the OpenCL layer's shadow catcher instead: NextBounce hands in the
+      // traced shadow of this bounce's light sample (material.cl:812, 897), so the ray goes on to the back-plate darkened by it.  The fused kernel does not know that value
+      // yet: the sample is made with shadow 1 and marked, and the next bounce multiplies the throughput by the shadow ray's result (k_bounce; 0 or 1: the same bits).
+      const bool catcher = (F & HK_FEAT_RARE_LIGHTS) && haveBackPlate(s);
+      const float sv = catcher ? 1.0f : 0.0f;
+      out.direction = rayDir; out.pdf = 1.0f; out.color = mk3(sv, sv, sv) * (1.0f / fmaxf(fabsf(dot(rayDir, hitNorm)), 1e-5f)); out.flags = HRE_S | HRE_T | (catcher ? HK_MATTE_PENDING : 0);
       break;
+    }
     case HMT_BECKMANN: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<false>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
     case HMT_TRGGX: if (F & HK_FEAT_ANISO) AnisoSampleAndEvalBRDF<true>(node, rands[0], rands[1], rayDir, hitNorm, sh.texCoord, sh.tangent, sh.biTangent, s, out); break;
     default: break;
@@ -1949,7 +1958,6 @@ HK_DEV float directLightEvalPDF(const float* L, f3 ray_dir) {   // clight.h:1462
 // returns that sun; any other ray the environment as before, replaced by backColorOfSecondEnv (:543-573) for camera rays and for rays that only passed through
 // transparent surfaces.  The CPU integrator has no such branch (kernel_HitEnvironment calls environmentColor, PT_Loop.cpp:28); this layer takes it when, and only when,
 // the header names a back texture, so every scene without one keeps the CPU path's values.
-HK_DEV bool haveBackPlate(const SceneDev& s) { return uint32_t(g_varsI(s)[HV_I_SHADOW_MATTE_BACK]) != HYDRA_INVALID_TEXTURE; }
 HK_DEV f3 backColorOfSecondEnv(const SceneDev& s, f3 ray_dir, float screenX, float screenY) {
   const float* vf = g_varsF(s);
   const int offset = s.texTable[g_varsI(s)[HV_I_SHADOW_MATTE_BACK]];

@@ -300,7 +300,9 @@ __global__ void k_stage_bounce(SceneDev s, int n, int depth, int maxDepth, const
   surf.tangent = mk3(r[9], r[10], r[11]); surf.biTangent = mk3(r[12], r[13], r[14]); surf.texCoord = mk2(r[15], r[16]);
   surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
   if (surf.matId < 0) {                                   // the ray left the scene: kernel_HitEnvironment, kernel_AddLastBouceContrib
-    const f3 env = environmentColor(s, ray_dir, prevPdf, prevSpec, flags);
+    // in[14] of a ray that left the scene: its pixel, x | y << 16 (the reference's in_packXY), read by the back-plate
+    const f3 env = haveBackPlate(s) ? environmentColorExtended(s, ray_pos, ray_dir, prevPdf, prevSpec, flags, as_int(in[14]) & 0xFFFF, (as_int(in[14]) >> 16) & 0xFFFF)
+                                    : environmentColor(s, ray_dir, prevPdf, prevSpec, flags);
     const f3 fin = acc + (thr * env);
     o[0] = env.x; o[1] = env.y; o[2] = env.z; o[3] = as_float(1);
     o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
@@ -327,7 +329,9 @@ __global__ void k_stage_bounce(SceneDev s, int n, int depth, int maxDepth, const
   o[21] = explicitColor.x; o[22] = explicitColor.y; o[23] = explicitColor.z;
   const f3 accum = acc + (thr * explicitColor);
   float4 oPos, oDir, oThr, oAcc;
-  next_bounce_with(s, mat, surf, ray_dir, flags, rands10 + size_t(i) * 10, make_float4(thr.x, thr.y, thr.z, prevPdf), accum, 0.0f, oPos, oDir, oThr, oAcc);
+  if (next_bounce_with(s, mat, surf, ray_dir, flags, rands10 + size_t(i) * 10, make_float4(thr.x, thr.y, thr.z, prevPdf), accum, 0.0f, oPos, oDir, oThr, oAcc)) {
+    oThr.x *= in[13]; oThr.y *= in[13]; oThr.z *= in[13];   // a shadow catcher: what the next bounce of the production kernel does with the shadow ray's result
+  }
   o[24] = oPos.x; o[25] = oPos.y; o[26] = oPos.z; o[27] = oDir.x; o[28] = oDir.y; o[29] = oDir.z; o[30] = oDir.w;
   o[31] = oThr.x; o[32] = oThr.y; o[33] = oThr.z; o[34] = oAcc.x; o[35] = oAcc.y; o[36] = oAcc.z; o[37] = oThr.w; o[38] = oAcc.w;
 }
@@ -2399,6 +2403,8 @@ int hydra_hip_mmlt_begin(hydra_hip_handle c, int chains, int seed, int first_bou
   STAGE_PROLOG(true);
   if (c->w <= 0 || c->h <= 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: set the image size first");
   if (c->ptlMax > 0) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: materials of the scene bind procedural textures; this layer runs them in the path tracer only (trace_pass)");
+  if (c->hostHeader.size() > size_t(HG_VARS_I + HV_I_SHADOW_MATTE_BACK) && uint32_t(c->hostHeader[HG_VARS_I + HV_I_SHADOW_MATTE_BACK]) != HYDRA_INVALID_TEXTURE)
+    return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the header names a back-plate (HRT_SHADOW_MATTE_BACK); the camera-visible second environment and its shadow catchers exist in the path tracer only");
   if (!mmlt_camera_ready(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header holds no camera yet (IHWLayer::SetCamMatrices + PrepareEngineGlobals: the caller's Draw does both)");
   if (!header_frame_matches(c)) return fail(c, HYDRA_HIP_ESTATE, "mmlt_begin: the globals header's HRT_WIDTH_F x HRT_HEIGHT_F is not the layer's frame (ResizeScreen and the header must agree: splats are tested against one and written into the other)");
   const int maxD = max_depth > 0 ? max_depth : c->hostHeader[HG_VARS_I + HV_I_TRACE_DEPTH];

@@ -726,6 +726,8 @@ static f4 read_imagef_sw4(const int32_t* tex, f2 tc, int flags, int srgb) {
  * half precision (WriteProcTextureList / ReadProcTextureList, :2327-2396).  The oracle restates the CONSUMER: readProcTex (:2402-2441) inside sample2DExt /
  * sample2DAuxExt, over the list of the point being shaded -- handed in by the test (orc_stage_set_proctex: the lists the reference's ProcTexExec wrote) -- kept in a
  * thread-local pointer because the reference threads it through every material function as an argument. */
+static _Thread_local float g_matteShadow = 0.0f;   /* the shadow value a shadow catcher is sampled with (see MT_SHADOW_MATTE) */
+static int orc_have_back_plate(const OrcScene* s);
 typedef struct { int n; int ids[16]; float vals[16][3]; } OrcPtl;
 static _Thread_local const OrcPtl* g_ptl = NULL;
 static inline f4 readProcTex(int texId) {
@@ -1667,9 +1669,12 @@ static void MaterialLeafSampleAndEvalBRDF(const float* m, const SurfaceHit* sh, 
     case MT_THIN_GLASS: ThinglassSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
     case MT_TRANSLUCENT: TranslucentSampleAndEvalBRDF(m, rands[0], rands[1], n, sh->texCoord, s, out); break;
     case MT_BLINN: BlinnSampleAndEvalBRDF(m, rands[0], rands[1], ray_dir, n, sh->texCoord, s, out); break;
-    case MT_SHADOW_MATTE:   /* ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942; a_shadow = (0,0,0) from kernel_NextBounce, PT_Loop.cpp:240 */
-      out->direction = ray_dir; out->pdf = 1.0f; out->color = scale3(v3(0, 0, 0), 1.0f / fmaxf(fabsf(dot3(ray_dir, n)), 1e-5f)); out->flags = RAY_EVENT_S | RAY_EVENT_T;
+    case MT_SHADOW_MATTE: {   /* ShadowmatteSampleAndEvalBRDF, cmaterial.h:1929-1942; a_shadow = (0,0,0) from kernel_NextBounce, PT_Loop.cpp:240 -- or, with a back-plate in the
+      header, the traced shadow of this bounce as the OpenCL layer's NextBounce hands it in (material.cl:812, 897): g_matteShadow, set by stage_next */
+      const float sv = orc_have_back_plate(s) ? g_matteShadow : 0.0f;
+      out->direction = ray_dir; out->pdf = 1.0f; out->color = scale3(v3(sv, sv, sv), 1.0f / fmaxf(fabsf(dot3(ray_dir, n)), 1e-5f)); out->flags = RAY_EVENT_S | RAY_EVENT_T;
       break;
+    }
     case MT_BECKMANN: AnisoSampleAndEvalBRDF(0, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
     case MT_TRGGX: AnisoSampleAndEvalBRDF(1, m, rands[0], rands[1], ray_dir, n, sh->texCoord, sh->tangent, sh->biTangent, s, out); break;
     case MT_GLASS: GlassGGXSampleAndEvalBRDF(m, rands, ray_dir, n, sh->texCoord, sh->hfi, a_isFwdDir, s, out); break;   /* CPUExp_Integrators_PT_Loop.cpp:240 passes false, the light paths of MMLT true */
@@ -2679,6 +2684,7 @@ static float directLightEvalPDF(const float* L, f3 ray_dir) {
 enum { HRT_SHADOW_MATTE_BACK = 35, HRT_SHADOW_MATTE_BACK_MODE = 41, HRT_SHADOW_MATTE_BACK_COLOR_X = 42, HRT_BACK_TEXINPUT_GAMMA = 36, HRT_3WAY_MIS_WEIGHTS = 1024 };   /* cglobals.h:416, 475-484, 537 */
 static _Thread_local int g_screenX = 0, g_screenY = 0;
 static inline int haveBackPlate(const OrcScene* s) { return (uint32_t)g_varsI(s)[HRT_SHADOW_MATTE_BACK] != INVALID_TEXTURE; }
+static int orc_have_back_plate(const OrcScene* s) { return haveBackPlate(s); }
 static f3 backColorOfSecondEnv(const OrcScene* s, f3 ray_dir, float screenX, float screenY) {
   const float* vf = g_varsF(s);
   const int offset = s->globals[s->globals[G_TEX_TABLE] + g_varsI(s)[HRT_SHADOW_MATTE_BACK]];
@@ -2816,9 +2822,11 @@ static f3 stage_shade(const OrcScene* s, const float* mat, const SurfaceHit* sur
 }
 /* kernel_NextBounce :218-256 with RndMatAll's numbers handed in */
 static void stage_next(const OrcScene* s, const float* mat, const SurfaceHit* surf, const float* allRands, f3 explicitColor,
-                       f3* ray_pos, f3* ray_dir, uint32_t* flags, MisData* misPrev, f3* accumColor, f3* thoroughput) {
+                       f3* ray_pos, f3* ray_dir, uint32_t* flags, MisData* misPrev, f3* accumColor, f3* thoroughput, float shadow) {
   MatSample ms;
+  g_matteShadow = shadow;
   MaterialSampleAndEvalBxDF(mat, allRands, surf, *ray_dir, *flags, s, &ms);
+  g_matteShadow = 0.0f;
   const f3 bxdfVal = scale3(ms.color, (1.0f / fmaxf(ms.pdf, 1e-20f)));
   const float cosTheta = fabsf(dot3(ms.direction, surf->normal));
   *ray_dir = ms.direction;
@@ -2891,7 +2899,7 @@ static f3 PathTrace(const OrcScene* s, f3 ray_pos, f3 ray_dir, uint32_t gen[2], 
       allRands[0] = r4[0]; allRands[1] = r4[1]; allRands[2] = r4[2];
       for (int k = 0; k < FLOATS_PER_MLAYER; k++) allRands[FLOATS_PER_SAMPLE + k] = orc_rnd_float1(gen);
     }
-    stage_next(s, mat, &surf, allRands, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput);
+    stage_next(s, mat, &surf, allRands, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput, shadow);
   }
   g_ptl = NULL;
   accumColor = add3(accumColor, mul3(thoroughput, currColor));   /* kernel_AddLastBouceContrib */
@@ -2921,8 +2929,9 @@ void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const f
     surf.texCoord.x = r[15]; surf.texCoord.y = r[16];
     surf.matId = as_int(r[17]); surf.t = r[18]; surf.sRayOff = r[19]; surf.hfi = (r[20] != 0.0f);
     f3 currColor = v3(0, 0, 0);
-    if (surf.matId < 0) {
-      currColor = environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags);
+    if (surf.matId < 0) {   /* in[14] of a ray that left the scene: its pixel, x | y << 16 (the reference's in_packXY), read by the back-plate */
+      currColor = haveBackPlate(s) ? environmentColorExtended(s, ray_pos, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags, as_int(in[14]) & 0xFFFF, (as_int(in[14]) >> 16) & 0xFFFF)
+                                   : environmentColor(s, ray_dir, misPrev.matSamplePdf, misPrev.isSpecular, flags);
       const f3 fin = add3(accumColor, mul3(thoroughput, currColor));
       o[0] = currColor.x; o[1] = currColor.y; o[2] = currColor.z; o[3] = as_float(1); o[34] = fin.x; o[35] = fin.y; o[36] = fin.z;
       continue;
@@ -2944,7 +2953,7 @@ void orc_stage_bounce(const OrcScene* s, int n, int depth, int maxDepth, const f
     o[14] = shadowRayPos.x; o[15] = shadowRayPos.y; o[16] = shadowRayPos.z; o[17] = tfar; o[18] = shadowRayDir.x; o[19] = shadowRayDir.y; o[20] = shadowRayDir.z;
     const f3 explicitColor = stage_shade(s, mat, &surf, ray_dir, shadowRayDir, &sam, lightPickProb, lightOffset, in[13]);
     o[21] = explicitColor.x; o[22] = explicitColor.y; o[23] = explicitColor.z;
-    stage_next(s, mat, &surf, rands10 + 10 * (size_t)i, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput);
+    stage_next(s, mat, &surf, rands10 + 10 * (size_t)i, explicitColor, &ray_pos, &ray_dir, &flags, &misPrev, &accumColor, &thoroughput, in[13]);
     o[24] = ray_pos.x; o[25] = ray_pos.y; o[26] = ray_pos.z; o[27] = ray_dir.x; o[28] = ray_dir.y; o[29] = ray_dir.z; o[30] = as_float((int)flags);
     o[31] = thoroughput.x; o[32] = thoroughput.y; o[33] = thoroughput.z; o[34] = accumColor.x; o[35] = accumColor.y; o[36] = accumColor.z;
     o[37] = misPrev.matSamplePdf; o[38] = misPrev.isSpecular ? 1.0f : 0.0f;

@@ -258,7 +258,8 @@ class RefWavefront:
         if self.texproc:
             self.texproc.close()
 
-    def run(self, pos4, dir4, seed, bounces):
+    def run(self, pos4, dir4, seed, bounces, xy=None):
+        """xy: the pixel of every ray (int [n, 2]) -> in_packXY of HitEnvOrLightKernel (x | y << 16): what a back-plate is projected by"""
         b, n = self.b, len(pos4)
         T, M, L, R = self.mods["trace"], self.mods["material"], self.mods["light"], self.mods["ref_driver"]
         f32, i32, u32 = np.float32, np.int32, np.uint32
@@ -323,7 +324,7 @@ class RefWavefront:
             # ---- HitEnvOrLightKernel
             m_flags, m_color, m_thr, m_mis, m_emis = M.up(flags), M.up(color), M.up(thr), M.up(mis), M.alloc(n * 16)
             m_rpos, m_rdir, m_surf, m_hits = M.up(rpos), M.up(rdir), M.up(surf_planes), M.up(hits)
-            m_xy = M.alloc(n * 4)
+            m_xy = M.up((np.asarray(xy, np.int32)[:, 0] | (np.asarray(xy, np.int32)[:, 1] << 16)).astype(np.int32)) if xy is not None else M.alloc(n * 4)
             M.launch("HitEnvOrLightKernel", n, [("p", m_rpos), ("p", m_rdir), ("p", m_flags), ("p", m_xy), ("p", m_surf), ("p", m_ptl),
                                                 ("p", m_color), ("p", m_thr), ("p", m_mis), ("p", m_emis), ("p", 0), ("p", m_mis), ("p", 0), ("p", 0), ("p", 0),
                                                 ("p", sM["tex"]), ("p", sM["texaux"]), ("p", sM["mat"]), ("p", sM["pdf"]), ("p", sM["glob"]),

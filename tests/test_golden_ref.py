@@ -373,6 +373,8 @@ def check_stage(name, b, run, bounces=3, set_lists=None):
             in16[:, 8:12], in16[:, 12] = rl, rl[:, 3]
             in16[:, 13] = g("shadow")[:, 0].astype(np.float32) / np.float32(65535.0)       # decompressShadow; opaque scenes: 0 or 1
             in16[:, 14], in16[:, 15] = g("hits")["instId"].view(np.float32), flags_hit.astype(np.uint32).view(np.float32)
+            if "xy" in fx:                                  # back-plate scenes: a ray that left the scene carries its pixel there (the reference's in_packXY)
+                in16[left, 14] = (fx["xy"][:, 0] | (fx["xy"][:, 1] << 16)).astype(np.int32).view(np.float32)[left]
             if set_lists is not None:
                 ids, vals = proctex_lists(g("proctex"))
                 ids[:, ~(act & ~left)] = _U32(0xFFFFFFFE).view(np.int32)       # ProcTexExec leaves the rows of inactive rays untouched
@@ -442,6 +444,25 @@ def test_oracle_matches_reference_stage_kernels_with_procedural_textures(built):
     fx = load("ref_stage_atrium_proctex_small.npz")      # the fixture does exercise the lists: all four textures, the two-texture material included
     ids, vals = proctex_lists(fx["b1_proctex"])
     assert {3, 4, 5, 6} <= set(np.unique(ids[:2]).tolist()) and ((ids[1] >= 3) & (ids[1] <= 6)).sum() > 50 and np.isfinite(vals[:2]).all()
+
+
+def test_oracle_matches_reference_stage_kernels_with_back_plate_and_shadow_catcher(built):
+    """the reference's wavefront stage kernels on the hall whose sky light has a <back> texture and whose floor is a shadow catcher (tools/make_atrium.py --back --catcher):
+    HitEnvOrLightKernel's environmentColorExtended with the pixel of every ray (in_packXY), and NextBounce handing the traced shadow of the bounce to the catcher's sampler
+    (material.cl:812, 897; cmaterial.h:1929-1942) -- the throughput after a catcher is the throughput before times the shadow"""
+    _, b = host_scene("atrium_backcatch_small", 96, 54, 5)
+    orc = make_oracle(b)
+    check_stage("atrium_backcatch_small", b, lambda d, pos4, dir4, surf, in16, rands10: orc.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10))
+    fx = load("ref_stage_atrium_backcatch_small.npz")      # the fixture does hold catcher hits in light and in shadow, and camera rays that see the back-plate
+    g, mats = b["globals"], b["materials"].reshape(-1).view(np.int32)
+    table = g[g[219]:g[219] + g[224]]
+    mat_id = fx["b0_surf"][:, 17].view(np.int32)
+    catcher = np.isin(mat_id, [0, 4]) & (fx["b0_flags_hit"] & (128 << 16) == 0)
+    assert all(mats[int(table[m]) * 4] == 6 for m in (0, 4))                       # PLAIN_MAT_CLASS_SHADOW_MATTE
+    lit = fx["b0_shadow"][catcher, 0] > 0
+    assert catcher.sum() > 500 and 0.05 < lit.mean() < 0.95
+    thr = fx["b0_thr_out"][catcher, :3]
+    assert (thr[~lit] == 0).all() and np.allclose(thr[lit], 1.0, rtol=1e-5)
 
 
 def test_the_scene_library_of_procedural_textures_is_packed_and_compiles(built):

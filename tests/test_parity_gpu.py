@@ -1567,7 +1567,7 @@ def test_hip_matches_reference_environment_extended(name, built):
     core.close()
 
 
-@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_backsph_small"])
+@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_backsph_small", "atrium_backcatch_small"])
 def test_back_plate_scene_matches_the_oracle_image(name, built):
     """whole frames through the production kernels (k_bounce<ALL> reads the pixel of every path that leaves the scene) against the oracle; the same hall without the <back>
     node differs exactly where the camera looks out of the open roof"""
@@ -1592,11 +1592,11 @@ def test_back_plate_scene_matches_the_oracle_image(name, built):
     plain.upload_scene(bs)
     img_s, _ = _render(plain, 96, 54, spp=3, seed=777)
     differs = (np.abs(img_s[..., :3] - img[..., :3]) > 1e-3).any(axis=2)
-    assert 0.005 < differs.mean() < 0.6, differs.mean()
+    assert 0.005 < differs.mean() < (0.9 if "catch" in name else 0.6), differs.mean()      # (the catcher scene also changes its whole floor)
     core.close(); plain.close()
 
 
-@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_proctex_small"])
+@pytest.mark.parametrize("name", ["atrium_back_small", "atrium_backcatch_small", "atrium_proctex_small"])
 def test_tile_partition_is_exact_with_back_plate_and_procedural_textures(name, built):
     """row e for the round's late features: the pixel a path belongs to is recovered from its id and this rank's pixel list (back-plate, ScreenOfPath), and the procedural
     texture lists are indexed by queue slot -- both must give the frame of one rank when the frame is dealt to three (disjoint supports, bit-identical sum), with 4 samples
@@ -1633,3 +1633,16 @@ def test_hip_matches_reference_mmlt_accept_reject(gpu224):
     from test_golden_ref import check_mmlt_accept
     core, _, _ = gpu224
     check_mmlt_accept(core.stage_mmlt_accept)
+
+
+def test_hip_against_the_reference_stage_kernels_with_back_plate_and_shadow_catcher(built):
+    """tests/test_golden_ref.py::test_oracle_matches_reference_stage_kernels_with_back_plate_and_shadow_catcher, with the bounce kernel's phases in the oracle's place"""
+    from hydracore_amd import HipCore, HydraError
+    from test_golden_ref import check_stage
+    _, b = host_scene("atrium_backcatch_small", 96, 54, 5)
+    core = HipCore(96, 54, device=0)
+    core.upload_scene(b)
+    check_stage("atrium_backcatch_small", b, lambda d, pos4, dir4, surf, in16, rands10: core.stage_bounce(d, 99, pos4, dir4, surf, in16, rands10))
+    with pytest.raises(HydraError, match="back-plate"):
+        core.mmlt_begin(1024, 1, 3, 5)
+    core.close()

@@ -306,6 +306,8 @@ def main():
     ap.add_argument("--blend", action="store_true", help="closed hall; materials 1, 3 and 5 become hydra_blend materials -- two materials of the library under a mask: "
                     "1 = its former self (now id 12) over a red lambert (13) through the 128^2 checker, 3 = a glossy lobe (14) over a lambert (15) by Fresnel (IOR 1.8, "
                     "luminance extrusion), 5 = blend 1 over material 13 under a constant 0.5 grey texture-less mask: a blend of a blend, and children with higher ids than the blend")
+    ap.add_argument("--catcher", action="store_true", help="materials 0 and 4 (the floor) become shadow catchers (<material type='shadow_catcher'>): with --back the camera sees "
+                    "the back-plate through them, darkened where the roof light and the sky are occluded (the OpenCL layer's shadow matte)")
     ap.add_argument("--ggx", action="store_true", help="every reflectivity layer is a GGX lobe instead of Phong; material 9 (a wall) becomes Fresnel GGX over diffuse")
     args = ap.parse_args()
     args.sky_tex = args.sky_tex or args.sky_hdr or args.portal or (args.back is not None)
@@ -586,6 +588,11 @@ float4 prtex%(n)d_main(const SurfaceInfo* sHit, sampler2D texSide, sampler2D tex
                           '  <material id="13" name="m13" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.7 0.15 0.1" /></diffuse></material>',
                           '  <material id="14" name="m14" type="hydra_material"><reflectivity brdf_type="%s"><color val="0.9 0.9 0.9" /><glossiness val="0.9" /></reflectivity></material>' % refl,
                           '  <material id="15" name="m15" type="hydra_material"><diffuse brdf_type="lambert"><color val="0.2 0.4 0.7" /></diffuse></material>']
+    if args.catcher:
+        for i, line in enumerate(xml):
+            for mid in (0, 4):
+                if line.startswith('  <material id="%d" ' % mid):
+                    xml[i] = '  <material id="%d" name="m%d" type="shadow_catcher"></material>' % (mid, mid)
     if args.height_bump:
         for i, line in enumerate(xml):
             for mid in (0, 4, 9):
