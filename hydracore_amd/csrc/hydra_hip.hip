@@ -1042,6 +1042,17 @@ struct BounceBufs {
   HydraLiteHit* hits;
 };
 
+// the back-plate the header names (HRT_SHADOW_MATTE_BACK) must be a texture of the arena: every kernel that shades a ray leaving the scene fetches it
+static int check_back_plate(hydra_hip_ctx* c, bool& have) {
+  have = false;
+  if (c->hostHeader.size() <= size_t(HG_VARS_I + HV_I_SHADOW_MATTE_BACK_MODE)) return HYDRA_HIP_OK;
+  const int32_t backId = c->hostHeader[HG_VARS_I + HV_I_SHADOW_MATTE_BACK];
+  if (uint32_t(backId) == HYDRA_INVALID_TEXTURE) return HYDRA_HIP_OK;
+  if (backId <= 0 || size_t(backId) >= c->hostTexTable.size() || c->hostTexTable[size_t(backId)] < 0)
+    return fail(c, HYDRA_HIP_EINVAL, "HRT_SHADOW_MATTE_BACK names texture " + std::to_string(backId) + ", which is not in the texture arena");
+  have = true;
+  return HYDRA_HIP_OK;
+}
 // the per-bounce kernel sequence of one sub-pass.  fused: trace -> k_bounce (+compaction) -> shadow;
 // split: trace -> k_hit (+compaction) -> shadow -> k_shade.
 // counters: live / shadowCnt / fetch are arrays of counter rows (HK_CROW words), row = bounce (fetch: 2*bounce + shadow)
@@ -1061,15 +1072,8 @@ static int run_bounces(hydra_hip_ctx* c, const SceneDev& s, int nseg, int segCap
   }
   // the back-plate (hk_shading.h, environmentColorExtended): named by the header's variables, which arrive with every PrepareEngineGlobals -- checked per pass
   bool backPlate = false;
-  if (c->hostHeader.size() > size_t(HG_VARS_I + HV_I_SHADOW_MATTE_BACK_MODE)) {
-    const int32_t backId = c->hostHeader[HG_VARS_I + HV_I_SHADOW_MATTE_BACK];
-    if (uint32_t(backId) != HYDRA_INVALID_TEXTURE) {
-      if (backId <= 0 || size_t(backId) >= c->hostTexTable.size() || c->hostTexTable[size_t(backId)] < 0)
-        return fail(c, HYDRA_HIP_EINVAL, "trace_pass: HRT_SHADOW_MATTE_BACK names texture " + std::to_string(backId) + ", which is not in the texture arena");
-      if (!fused || c->shadeWaves != 3) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the back-plate exists in the fused bounce kernel at its default register budget only (fused_bounce = 1, shade_waves = 3)");
-      backPlate = true;
-    }
-  }
+  { const int brc = check_back_plate(c, backPlate); if (brc) return brc; }
+  if (backPlate && (!fused || c->shadeWaves != 3)) return fail(c, HYDRA_HIP_ESTATE, "trace_pass: the back-plate exists in the fused bounce kernel at its default register budget only (fused_bounce = 1, shade_waves = 3)");
   // procedural textures: k_proctex (the scene's program) runs between the traversal and the bounce kernel and leaves every path its list
   SceneDev sPtl = s;
   if (c->ptlMax > 0) {
@@ -2063,6 +2067,7 @@ int hydra_hip_stage_mmlt_accept(hydra_hip_handle c, int n, const float* old8, co
 int hydra_hip_stage_environment(hydra_hip_handle c, int n, const float* ray_dir4, const float* in8, float* out4) {
   STAGE_PROLOG(true);
   if (!ray_dir4 || !in8 || !out4) return fail(c, HYDRA_HIP_EINVAL, "stage_environment: null argument");
+  { bool have; const int brc = check_back_plate(c, have); if (brc) return brc; }
   float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
   float* din = (float*)tb.up(c, in8, size_t(n) * 32, rc);
   float4* dout = (float4*)tb.up(c, nullptr, size_t(n) * 16, rc);
@@ -2221,6 +2226,7 @@ int hydra_hip_stage_bounce(hydra_hip_handle c, int n, int depth, int max_depth, 
                            const float* rands10, float* out40) {
   STAGE_PROLOG(true);
   if (!ray_pos4 || !ray_dir4 || !surf24 || !in16 || !rands10 || !out40) return fail(c, HYDRA_HIP_EINVAL, "stage_bounce: null argument");
+  { bool have; const int brc = check_back_plate(c, have); if (brc) return brc; }
   float4* dpos = (float4*)tb.up(c, ray_pos4, size_t(n) * 16, rc);
   float4* ddir = (float4*)tb.up(c, ray_dir4, size_t(n) * 16, rc);
   float* dsurf = (float*)tb.up(c, surf24, size_t(n) * 96, rc);

@@ -1646,3 +1646,23 @@ def test_hip_against_the_reference_stage_kernels_with_back_plate_and_shadow_catc
     with pytest.raises(HydraError, match="back-plate"):
         core.mmlt_begin(1024, 1, 3, 5)
     core.close()
+
+
+def test_a_back_plate_that_is_not_in_the_texture_arena_is_refused(built):
+    """HRT_SHADOW_MATTE_BACK is fetched by every kernel that shades a ray leaving the scene: an id outside the texture table, or one without a stored texture, fails
+    loudly in trace_pass and in the stage entries instead of reading past the arena"""
+    from hydracore_amd import HipCore, HydraError
+    _, b = host_scene("atrium_back_small", 96, 54, 5)
+    for bad in (999, 0, 3 + 100):
+        b2 = dict(b)
+        g = b["globals"].copy()
+        g[64 + 35] = bad
+        b2["globals"] = g
+        core = HipCore(96, 54, device=0)
+        core.upload_scene(b2)
+        core.init_path_tracing(1)
+        with pytest.raises(HydraError, match="not in the texture arena"):
+            core.trace_pass(1)
+        with pytest.raises(HydraError, match="not in the texture arena"):
+            core.stage_environment(np.zeros((4, 4), np.float32), np.zeros((4, 8), np.float32))
+        core.close()
