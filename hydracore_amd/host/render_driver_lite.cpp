@@ -431,6 +431,8 @@ bool RenderDriverLite::UpdateMaterial(int32_t a_matId, const XmlNode* a_node) {
       if (back->attr_int("reflection") == 1 || back->attr_int("fix_black_triangles") == 1)
         Unsupported("shadow_catcher <back reflection / fix_black_triangles> (material " + std::to_string(a_matId) + "): camera-mapped reflections of the OpenCL layer's catcher");
     } else { m_shadowMatteBackTexId = int32_t(HYDRA_INVALID_TEXTURE); m_shadowMatteBackColor = float3(1, 1, 1); }
+    if (length(read_value3f(xchild(a_node->child("emission"), "color"))) > 1e-4f)   // PLAIN_MATERIAL_EMISSIVE_SHADOW_CATCHER, PlainMaterialConverter.cpp:1676-1699: read by the OpenCL layer's NextBounce only
+      Unsupported("emissive shadow_catcher (material " + std::to_string(a_matId) + ")");
     PlainMaterialVec mdata = flatten(pMatte);
     m_pMaterialStorage->Update(a_matId, mdata.data(), mdata.size() * sizeof(float));
     return true;
