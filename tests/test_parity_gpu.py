@@ -1666,3 +1666,18 @@ def test_a_back_plate_that_is_not_in_the_texture_arena_is_refused(built):
         with pytest.raises(HydraError, match="not in the texture arena"):
             core.stage_environment(np.zeros((4, 4), np.float32), np.zeros((4, 8), np.float32))
         core.close()
+
+
+def test_procedural_textures_through_the_ihwlayer_adapter(gpu_atrium_proctex):
+    """the drop-in route: the front end hands the program text to IHWLayer::RecompileProcTexShaders of the HIP adapter (hip_layer.cpp), which compiles it; a pass drawn through the
+    adapter gives the image the C-ABI gives when called directly with the same text"""
+    from conftest import scene_path
+    from hydracore_amd import HostScene
+    core, b, sc = gpu_atrium_proctex
+    img, _ = _render(core, 96, 54, spp=4, seed=777)
+    gpu = HostScene(scene_path("atrium_proctex_small"), 96, 54, trace_depth=5, enable_dof=0, use_hip=True, device=0, seed=777)
+    assert gpu.proctex_program() == sc.proctex_program() and gpu.unsupported() == 0
+    gpu.hip().set_option("samples_in_flight", core.samples_in_flight())
+    gpu.draw(passes=1, spp=4)
+    assert (gpu.hdr_image().view(np.uint32) == img.view(np.uint32)).all()
+    gpu.close()
