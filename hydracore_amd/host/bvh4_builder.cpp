@@ -203,6 +203,58 @@ void BVH4Builder::CommitScene() {
       prims.push_back(p);
     }
     if (prims.empty()) RunTimeError("BVH4Builder::CommitScene: mesh without valid triangles");
+    // Experiment (HYDRA_BVH_PRESPLIT = extra references in percent, off by default): early split clipping.  The references with the largest boxes are cut in two along their
+    // longest axis, each half bounded by the part of the triangle inside it, until the budget is spent: a large triangle then sits in several small leaves instead of
+    // inflating one (the leaf lists hold triangles by value, a triangle may appear in more than one; a second hit on it has the same t and is not nearer).
+    if (const char* e = getenv("HYDRA_BVH_PRESPLIT")) {
+      const int budget = int(double(prims.size()) * std::max(0, std::min(400, atoi(e))) / 100.0);
+      auto areaOf = [](const PrimRef& r) { return box_area(r.box.mn, r.box.mx); };
+      auto cmp = [&](int a, int b) { return areaOf(prims[size_t(a)]) < areaOf(prims[size_t(b)]); };
+      std::vector<int> heap(prims.size());
+      for (size_t i = 0; i < prims.size(); i++) heap[i] = int(i);
+      std::make_heap(heap.begin(), heap.end(), cmp);
+      auto clipBox = [&](int tri, int axis, float lo, float hi, const Box& within, Box& out) -> bool {   // the triangle cut to lo <= x[axis] <= hi, inside `within`
+        const int ia = mesh.indices[tri * 3 + 0], ib = mesh.indices[tri * 3 + 1], ic = mesh.indices[tri * 3 + 2];
+        float3 poly[8], tmp[8];
+        int n = 3;
+        poly[0] = float3(v[ia * 4], v[ia * 4 + 1], v[ia * 4 + 2]); poly[1] = float3(v[ib * 4], v[ib * 4 + 1], v[ib * 4 + 2]); poly[2] = float3(v[ic * 4], v[ic * 4 + 1], v[ic * 4 + 2]);
+        for (int side = 0; side < 2 && n > 0; side++) {
+          const float plane = side == 0 ? lo : hi, sgn = side == 0 ? 1.0f : -1.0f;
+          int m = 0;
+          for (int k = 0; k < n; k++) {
+            const float3 P = poly[k], Q = poly[(k + 1) % n];
+            const float dp = sgn * (axis_of(P, axis) - plane), dq = sgn * (axis_of(Q, axis) - plane);
+            if (dp >= 0.0f) tmp[m++] = P;
+            if ((dp >= 0.0f) != (dq >= 0.0f)) { const float t = dp / (dp - dq); tmp[m++] = P + (Q - P) * t; }
+          }
+          n = m;
+          for (int k = 0; k < n; k++) poly[k] = tmp[k];
+        }
+        if (n == 0) return false;
+        box_reset(out.mn, out.mx);
+        for (int k = 0; k < n; k++) { out.mn = vmin(out.mn, poly[k]); out.mx = vmax(out.mx, poly[k]); }
+        out.mn = vmax(out.mn, within.mn); out.mx = vmin(out.mx, within.mx);
+        return out.mn.x <= out.mx.x && out.mn.y <= out.mx.y && out.mn.z <= out.mx.z;
+      };
+      int added = 0;
+      while (added < budget && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const int at = heap.back(); heap.pop_back();
+        const PrimRef r = prims[size_t(at)];
+        const float3 ext = r.box.mx - r.box.mn;
+        const int axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+        if (!(axis_of(ext, axis) > 1e-5f)) continue;
+        const float mid = 0.5f * (axis_of(r.box.mn, axis) + axis_of(r.box.mx, axis));
+        PrimRef a = r, b = r;
+        if (!clipBox(r.id, axis, axis_of(r.box.mn, axis), mid, r.box, a.box) || !clipBox(r.id, axis, mid, axis_of(r.box.mx, axis), r.box, b.box)) continue;
+        a.centroid = (a.box.mn + a.box.mx) * 0.5f; b.centroid = (b.box.mn + b.box.mx) * 0.5f;
+        prims[size_t(at)] = a;
+        prims.push_back(b);
+        heap.push_back(at); std::push_heap(heap.begin(), heap.end(), cmp);
+        heap.push_back(int(prims.size()) - 1); std::push_heap(heap.begin(), heap.end(), cmp);
+        added++;
+      }
+    }
     int leafMax = maxLeafSize;
     if (const char* e = getenv("HYDRA_BVH_MAX_LEAF")) leafMax = std::max(1, std::min(16, atoi(e)));   // tuning sweeps only
     if (gpuBuildDevice >= 0) {   // the tree of this mesh comes from the device in build form; node and primitive indices are rebased into the shared arrays
