@@ -71,7 +71,7 @@ int BVH4Builder::InstanceTriangleMeshes(InstanceInputData d, int a_treeId, int a
 }
 
 // ------------------------------------------------------------------------------------------ build
-int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const {
+int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end, float* a_bestCost, bool a_evalOnly) const {
   static constexpr int NBMAX = 64;
   static const int NB = [] { const char* e = getenv("HYDRA_BVH_BINS"); const int v = e ? atoi(e) : 32; return std::max(4, std::min(NBMAX, v)); }();   // tuning sweeps only
   float3 cmn, cmx;
@@ -107,6 +107,8 @@ int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const
       if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
     }
   }
+  if (a_bestCost) *a_bestCost = bestCost;
+  if (a_evalOnly) return begin;
   if (bestAxis < 0) return (begin + end) / 2;   // all centroids coincide: split in the middle
   const float lo = axis_of(cmn, bestAxis), hi = axis_of(cmx, bestAxis);
   const float scale = float(NB) / (hi - lo);
@@ -149,9 +151,14 @@ int BVH4Builder::BuildRecursive(std::vector<PrimRef>& prims, int begin, int end,
       // which range to split next: the one with the largest box (profiles/r03/ab_open_node_rule.log: closest-hit traversal -2.5 % on atrium250k, shadow traversal -3 % on
       // test_224, +0.9 % on both passes against area x count, the rule of rounds 1-3a); HYDRA_BVH_OPEN = product | count selects the others for A/B
       static const char* const openEnv = getenv("HYDRA_BVH_OPEN");
-      const float w = (openEnv && openEnv[0] == 'p') ? box_area(mn, mx) * float(cnt) + 1e-30f * float(cnt)
-                    : (openEnv && openEnv[0] == 'c') ? float(cnt)
-                    : box_area(mn, mx) + 1e-30f * float(cnt);
+      float w = (openEnv && openEnv[0] == 'p') ? box_area(mn, mx) * float(cnt) + 1e-30f * float(cnt)
+              : (openEnv && openEnv[0] == 'c') ? float(cnt)
+              : box_area(mn, mx) + 1e-30f * float(cnt);
+      if (openEnv && openEnv[0] == 'g') {   // experiment: the range whose best split takes the most off the SAH cost
+        float splitCost = kInf;
+        (void)SplitSAH(prims, r[i].b, r[i].e, &splitCost, true);
+        w = (splitCost < kInf) ? box_area(mn, mx) * float(cnt) - splitCost : 0.0f;
+      }
       if (w > best) { best = w; pick = i; }
     }
     if (pick < 0) break;

@@ -78,7 +78,7 @@ private:
 
   int  BuildTree(std::vector<PrimRef>& prims, int leafMax);
   int  BuildRecursive(std::vector<PrimRef>& prims, int begin, int end, int leafMax);
-  int  SplitSAH(std::vector<PrimRef>& prims, int begin, int end) const;
+  int SplitSAH(std::vector<PrimRef>& prims, int begin, int end, float* a_bestCost = nullptr, bool a_evalOnly = false) const;
 
   size_t Alloc4Nodes();
   size_t EmitTriangleLeaf(const MeshRec& mesh, const TmpNode& leaf);
