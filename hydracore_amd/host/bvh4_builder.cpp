@@ -103,7 +103,9 @@ int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end, float
     for (int b = 0; b < NB - 1; b++) {
       amn = vmin(amn, bmn[b]); amx = vmax(amx, bmx[b]); c += cnt[b];
       if (c == 0 || rightCnt[b + 1] == 0) continue;
-      const float cost = box_area(amn, amx) * float(c) + rightArea[b + 1] * float(rightCnt[b + 1]);
+      static const int leafUnit = [] { const char* e = getenv("HYDRA_BVH_SAH_UNIT"); return e ? std::max(1, atoi(e)) : 1; }();   // experiment: count triangles in units of a leaf
+      const float cl = float((c + leafUnit - 1) / leafUnit), cr = float((rightCnt[b + 1] + leafUnit - 1) / leafUnit);
+      const float cost = box_area(amn, amx) * cl + rightArea[b + 1] * cr;
       if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
     }
   }
