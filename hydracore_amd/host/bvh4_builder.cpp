@@ -84,27 +84,27 @@ int BVH4Builder::SplitSAH(std::vector<PrimRef>& prims, int begin, int end, float
     const float lo = axis_of(cmn, axis), hi = axis_of(cmx, axis);
     if (!(hi > lo)) continue;
     const float scale = float(NB) / (hi - lo);
-    int cnt[NBMAX]; float3 bmn[NBMAX], bmx[NBMAX];
-    for (int b = 0; b < NB; b++) { cnt[b] = 0; box_reset(bmn[b], bmx[b]); }
+    float cnt[NBMAX]; float3 bmn[NBMAX], bmx[NBMAX];
+    for (int b = 0; b < NB; b++) { cnt[b] = 0.0f; box_reset(bmn[b], bmx[b]); }
     for (int i = begin; i < end; i++) {
       int b = int((axis_of(prims[i].centroid, axis) - lo) * scale);
       b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-      cnt[b]++;
+      cnt[b] += prims[i].weight;
       bmn[b] = vmin(bmn[b], prims[i].box.mn); bmx[b] = vmax(bmx[b], prims[i].box.mx);
     }
-    float rightArea[NBMAX]; int rightCnt[NBMAX];
+    float rightArea[NBMAX], rightCnt[NBMAX];
     float3 amn, amx; box_reset(amn, amx);
-    int c = 0;
+    float c = 0.0f;
     for (int b = NB - 1; b > 0; b--) {
       amn = vmin(amn, bmn[b]); amx = vmax(amx, bmx[b]); c += cnt[b];
       rightArea[b] = box_area(amn, amx); rightCnt[b] = c;
     }
-    box_reset(amn, amx); c = 0;
+    box_reset(amn, amx); c = 0.0f;
     for (int b = 0; b < NB - 1; b++) {
       amn = vmin(amn, bmn[b]); amx = vmax(amx, bmx[b]); c += cnt[b];
-      if (c == 0 || rightCnt[b + 1] == 0) continue;
+      if (c == 0.0f || rightCnt[b + 1] == 0.0f) continue;
       static const int leafUnit = [] { const char* e = getenv("HYDRA_BVH_SAH_UNIT"); return e ? std::max(1, atoi(e)) : 1; }();   // experiment: count triangles in units of a leaf
-      const float cl = float((c + leafUnit - 1) / leafUnit), cr = float((rightCnt[b + 1] + leafUnit - 1) / leafUnit);
+      const float cl = (leafUnit > 1) ? ceilf(c / float(leafUnit)) : c, cr = (leafUnit > 1) ? ceilf(rightCnt[b + 1] / float(leafUnit)) : rightCnt[b + 1];
       const float cost = box_area(amn, amx) * cl + rightArea[b + 1] * cr;
       if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
     }
@@ -331,6 +331,9 @@ void BVH4Builder::CommitScene() {
     p.box = in.worldBox;
     p.centroid = (p.box.mn + p.box.mx) * 0.5f;
     p.id = int(i);
+    // experiment (HYDRA_BVH_INST_WEIGHT=1): an instance weighs what walking its mesh tree costs, ~log2 of its triangles, instead of 1
+    static const bool instWeight = getenv("HYDRA_BVH_INST_WEIGHT") != nullptr;
+    if (instWeight) p.weight = log2f(float(m_meshes[in.meshSlot].indices.size() / 3) + 2.0f);
     iprims.push_back(p);
     m_sceneBox.mn = vmin(m_sceneBox.mn, in.worldBox.mn);
     m_sceneBox.mx = vmax(m_sceneBox.mx, in.worldBox.mx);

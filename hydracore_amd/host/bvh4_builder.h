@@ -63,7 +63,7 @@ private:
     int first, count;                // leaf range in the permuted primitive index array (count>0 => leaf)
     TmpNode() : first(0), count(0) { child[0] = child[1] = child[2] = child[3] = -1; }
   };
-  struct PrimRef { Box box; float3 centroid; int id; };
+  struct PrimRef { Box box; float3 centroid; int id; float weight = 1.0f; };   // weight: what entering the reference costs, in units of one triangle (instances: see CommitScene)
 
   std::vector<MeshRec> m_meshes;
   std::vector<InstRec> m_insts;
