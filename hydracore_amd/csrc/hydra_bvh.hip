@@ -286,20 +286,20 @@ __device__ __forceinline__ void listTriangles(int node, int n, const int2* __res
   }
 }
 __global__ void k_bvh_collapse(int n, int leafMax, const WorkItem* __restrict__ in, int inCount, const int2* __restrict__ children, const int* __restrict__ count, const Box3* __restrict__ nodeBoxes,
-                               const uint32_t* __restrict__ sortedTri, HydraBuildNode* __restrict__ out, int* __restrict__ outCount, WorkItem* __restrict__ next, int* __restrict__ nextCount, int* __restrict__ primOut) {
+                               const uint32_t* __restrict__ sortedTri, HydraBuildNode* __restrict__ out, int* __restrict__ outCount, WorkItem* __restrict__ next, int* __restrict__ nextCount, int* __restrict__ primOut, int openByProduct) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= inCount) return;
   const WorkItem item = in[w];
   int c[4];
   int nc = 2;
   { const int2 ch = children[item.binNode]; c[0] = ch.x; c[1] = ch.y; }
-  while (nc < 4) {            // open the child with the largest area x count that still has more than leafMax triangles
+  while (nc < 4) {            // open the child with the largest box that still has more than leafMax triangles (the host builder's rule, bvh4_builder.cpp; openByProduct: area x count, the rule before)
     int pick = -1;
     float best = -1.0f;
     for (int k = 0; k < nc; k++) {
       const int cnt = count[c[k]];
       if (cnt <= leafMax) continue;
-      const float wgt = boxArea(nodeBoxes[c[k]]) * float(cnt);
+      const float wgt = openByProduct ? boxArea(nodeBoxes[c[k]]) * float(cnt) : boxArea(nodeBoxes[c[k]]);
       if (wgt > best) { best = wgt; pick = k; }
     }
     if (pick < 0) break;
@@ -439,6 +439,7 @@ int hydra_hip_bvh_build_mesh_ex(int device, const float* vert4f, int num_vert, c
   }
   BCHECK(hipMemsetAsync(dCounts, 0, 16, nullptr));
   hipLaunchKernelGGL(k_bvh_root, dim3(1), dim3(1), 0, nullptr, n, leaf_max, dChildren, dNodeBox, dVals[cur], dOut, dCounts, dWork[0], dCounts + 1, dPrimOut);
+  static const int openByProduct = [] { const char* e = getenv("HYDRA_GPU_BVH_OPEN"); return (e != nullptr && e[0] == 'p') ? 1 : 0; }();   // A/B switch: area x count, the rule before
   int frontier = 0;
   for (int level = 0; level < 128; level++) {
     int counts[4];
@@ -447,7 +448,7 @@ int hydra_hip_bvh_build_mesh_ex(int device, const float* vert4f, int num_vert, c
     if (inCount == 0) break;
     BCHECK(hipMemsetAsync(dCounts + 1 + (frontier ^ 1), 0, 4, nullptr));
     hipLaunchKernelGGL(k_bvh_collapse, dim3((inCount + 255) / 256), blk, 0, nullptr, n, leaf_max, dWork[frontier], inCount, dChildren, dCount, dNodeBox, dVals[cur], dOut, dCounts,
-                       dWork[frontier ^ 1], dCounts + 1 + (frontier ^ 1), dPrimOut);
+                       dWork[frontier ^ 1], dCounts + 1 + (frontier ^ 1), dPrimOut, openByProduct);
     BCHECK(hipMemsetAsync(dCounts + 1 + frontier, 0, 4, nullptr));
     frontier ^= 1;
   }
